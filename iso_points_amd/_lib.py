@@ -1,0 +1,89 @@
+"""ctypes binding of libisopoints_hip.so (C ABI: include/isopoints.h).
+
+The library is the product; this module only moves pointers.  There is NO CPU
+fallback: if the shared object is missing or an argument lives on the CPU the
+call raises.  torch is used for device memory and the current HIP stream only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libisopoints_hip.so")
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_L = _c.c_int64
+_F = _c.c_float
+
+# name -> (restype, argtypes); must list every symbol include/isopoints.h declares
+SIGNATURES = {
+    "iso_version": (_c.c_char_p, []),
+    "iso_last_error": (_c.c_char_p, []),
+    "iso_project_sphere": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "iso_siren_raw_floats": (_L, [_I, _I]),
+    "iso_siren_packed_floats": (_L, [_I, _I]),
+    "iso_siren_pack_weights": (_I, [_P, _P, _I, _I, _P]),
+    "iso_project_siren_workspace_bytes": (_L, [_L, _I, _I]),
+    "iso_project_siren": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _F, _F, _I, _F, _P, _L, _P]),
+    "iso_siren_sdf_grad": (_I, [_P, _P, _P, _L, _P, _I, _I, _F, _F, _P, _L, _P]),
+    "iso_frnn_make_grid": (_I, [_P, _P, _P, _I, _L, _P, _P]),
+    "iso_frnn_insert_points": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),
+    "iso_prefix_sum_workspace_bytes": (_L, [_L, _I]),
+    "iso_prefix_sum": (_I, [_P, _P, _L, _I, _L, _P, _L, _P]),
+    "iso_frnn_scan_cells": (_I, [_P, _P, _P, _I, _L, _I, _P, _L, _P]),
+    "iso_frnn_counting_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),
+    "iso_frnn_query": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _L, _L, _L, _P]),
+    "iso_frnn_gather": (_I, [_P, _P, _P, _I, _L, _L, _I, _I, _P]),
+    "iso_repulse": (_I, [_P, _P, _P, _L, _P, _L, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "iso_points_amd: %s is missing -- build it with `make` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`.  There is no "
+            "CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("iso_points_amd: tensor must live on the GPU (got %s); "
+                           "there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("iso_points_amd: tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().iso_last_error().decode()
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    check(rc, name)

@@ -1,0 +1,489 @@
+// Fused SIREN SDF + gradient evaluation and Newton step on the f32 matrix cores
+// (v_mfma_f32_16x16x4_f32), gfx950.
+//
+// Reference semantics: Siren.forward (DSS/models/common.py:140-165, SineLayer
+// :86-87) evaluated with autograd.grad inside
+// UniformProjection._compute_sdf_and_grad (levelset_sampling.py:142-170) and
+// iterated by _project_points (:313-342).
+//
+// Work decomposition
+//   * one wave = 16 points.  A hidden layer H->H is the GEMM
+//       Z[H x 16pts] = W[H x H] . Hin[H x 16pts]
+//     tiled as NT = H/16 output tiles of 16 rows; each 16x16x4 MFMA contracts 4
+//     input features.  With the D-layout of that instruction (lane = 16g + j
+//     holds rows 4g..4g+3 of column j) the register i of output tile t in lane
+//     (g,j) is feature 16t+4g+i of point j -- which is exactly what the NEXT
+//     layer's B operand wants for k-step (q=t, i) (B[k=g][j]).  So activations
+//     never change lanes between layers: they are kept per wave in LDS as
+//     hL[q][lane][0..3] (16 B per lane, lane-linear, conflict-free) and the B
+//     operands of four consecutive k-steps are one ds_read_b128.
+//   * the A operand (weights) is pre-arranged by iso_siren_pack_weights into a
+//     lane-linear image FW[q][t][lane][0..3] (and its transpose BW for the
+//     reverse sweep), so one q-chunk of all NT tiles is a contiguous NT KiB
+//     block.  The 4 waves of a workgroup share it through a double-buffered
+//     LDS stage (global -> registers -> LDS, one barrier per chunk).
+//   * reverse-mode gradient: the forward sweep stashes s = w*cos(w*z) of every
+//     sine layer in a per-wave scratch (L2 / Infinity-Cache resident, 1 KiB
+//     coalesced rows); the reverse sweep multiplies the running adjoint by it
+//     and runs the same GEMM loop on the transposed image.
+//   * Newton: one launch = one evaluation (+ move) over the list of still
+//     active points; survivors are appended to the next list with a wave
+//     aggregated atomic, so converged points cost nothing in later launches
+//     (the reference's boolean-mask compaction, without host syncs).
+//
+// Arithmetic: 2*H*H MAC per hidden layer and point (forward + reverse) on the
+// matrix cores; layer 0 (3->H), the head (H->1) and sin/cos on the VALU.
+#include "iso_common.h"
+#include "iso_newton.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- sin/cos ---------------------------------------------------------------
+// 3-term Cody-Waite reduction by pi/2 with FMA, cephes-style minimax kernels on
+// [-pi/4, pi/4].  Max error ~1 ulp for |x| < 1e4 (tests/test_siren.py checks it
+// against float64); larger arguments take the slow libm path.
+__device__ __forceinline__ void iso_sincos(float x, float& s, float& c) {
+  if (!(fabsf(x) < 1.0e4f)) {
+    sincosf(x, &s, &c);
+    return;
+  }
+  const float two_over_pi = 0.636619772367581343f;
+  const float p1 = 1.57079637050628662109375f;        // fl(pi/2)
+  const float p2 = -4.37113882867379288655e-8f;       // fl(pi/2 - p1)
+  const float p3 = -1.71512451000588187280e-15f;      // fl(pi/2 - p1 - p2)
+  float n = rintf(x * two_over_pi);
+  float r = __builtin_fmaf(-n, p1, x);
+  r = __builtin_fmaf(-n, p2, r);
+  r = __builtin_fmaf(-n, p3, r);
+  float r2 = r * r;
+  float ps = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, r2, -1.6666654611e-1f);
+  float sr = __builtin_fmaf(ps * r2, r, r);
+  float pc = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, r2, 4.166664568298827e-2f);
+  float cr = __builtin_fmaf(pc, r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+  int q = (int)n;
+  float ss = (q & 1) ? cr : sr;
+  float cc = (q & 1) ? sr : cr;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// ---- packed weight buffer --------------------------------------------------
+// [W0img 4*H][WLimg H][bL,pad 4][ per hidden layer: bias H | FW H*H | BW H*H ]
+__host__ __device__ inline int64_t off_w0(int H) { (void)H; return 0; }
+__host__ __device__ inline int64_t off_wl(int H) { return 4 * (int64_t)H; }
+__host__ __device__ inline int64_t off_bl(int H) { return 5 * (int64_t)H; }
+__host__ __device__ inline int64_t off_hidden(int H, int l) {
+  return 5 * (int64_t)H + 4 + (int64_t)l * ((int64_t)H + 2 * (int64_t)H * H);
+}
+
+// raw layout: W0[H*3] b0[H] {Wi[H*H] bi[H]}*L WL[H] bL[1]
+__global__ void k_siren_pack(const float* __restrict__ raw, float* __restrict__ packed,
+                             int H, int L) {
+  const int64_t total = off_hidden(H, L);
+  const int64_t HH = (int64_t)H * H;
+  const int NT = H / 16;
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (o < off_wl(H)) {
+      // W0img[g][e][c]: c<3 -> W0[f][c], c==3 -> b0[f];  f = 16*(e>>2)+4g+(e&3)
+      int64_t k = o;
+      int c = (int)(k & 3);
+      int e = (int)((k >> 2) % (H / 4));
+      int g = (int)((k >> 2) / (H / 4));
+      int f = 16 * (e >> 2) + 4 * g + (e & 3);
+      v = (c < 3) ? raw[f * 3 + c] : raw[(int64_t)H * 3 + f];
+    } else if (o < off_bl(H)) {
+      int64_t k = o - off_wl(H);
+      int e = (int)(k % (H / 4));
+      int g = (int)(k / (H / 4));
+      int f = 16 * (e >> 2) + 4 * g + (e & 3);
+      const int64_t raw_wl = (int64_t)H * 4 + (int64_t)L * (HH + H);
+      v = raw[raw_wl + f];
+    } else if (o < off_hidden(H, 0)) {
+      const int64_t raw_wl = (int64_t)H * 4 + (int64_t)L * (HH + H);
+      v = (o == off_bl(H)) ? raw[raw_wl + H] : 0.f;
+    } else {
+      int64_t k = o - off_hidden(H, 0);
+      const int64_t per = H + 2 * HH;
+      int l = (int)(k / per);
+      int64_t w = k % per;
+      const float* Wl = raw + (int64_t)H * 4 + (int64_t)l * (HH + H);
+      const float* bl = Wl + HH;
+      if (w < H) {
+        v = bl[w];
+      } else {
+        w -= H;
+        bool bwd = w >= HH;
+        if (bwd) w -= HH;
+        // image index: [q][t][lane][i]
+        int i = (int)(w & 3);
+        int lane = (int)((w >> 2) & 63);
+        int t = (int)((w >> 8) % NT);
+        int q = (int)((w >> 8) / NT);
+        int a = 16 * t + (lane & 15);            // tile row
+        int b = 16 * q + 4 * (lane >> 4) + i;    // contraction index
+        v = bwd ? Wl[(int64_t)b * H + a]         // BW: out=b (contracted), in=a
+                : Wl[(int64_t)a * H + b];        // FW: out=a, in=b (contracted)
+      }
+    }
+    packed[o] = v;
+  }
+}
+
+// ---- the step kernel -------------------------------------------------------
+struct SirenArgs {
+  float* pts;                // (n,3) in/out
+  float* normals;            // (n,3) out (may be null in eval mode)
+  uint8_t* mask;             // (n) out
+  float* sdf_out;            // eval mode
+  float* grad_out;           // eval mode
+  const int32_t* idx_in;     // active list (null = identity)
+  const int32_t* count_in;   // device count of idx_in (null = n)
+  int32_t* idx_out;          // survivors
+  int32_t* count_out;
+  const float* packed;
+  float* stash;              // per-wave scratch
+  int64_t n;
+  int L;                     // hidden layers
+  float w0, wh, tol;
+  int do_move;               // 0: last evaluation (no move)
+  int eval_only;
+};
+
+template <int NT, bool HAS_BIAS>
+__device__ __forceinline__ void gemm_pass(const float* __restrict__ img,
+                                          const float* __restrict__ bias,
+                                          const float* __restrict__ hL,
+                                          float* __restrict__ wbuf, f32x4 (&acc)[NT],
+                                          int lane, int g) {
+  constexpr int CH = NT * 256;            // floats per q-chunk
+  constexpr int PER = CH / 4 / 256;       // float4 per thread per chunk (NT/4)
+  static_assert(NT % 4 == 0, "NT must be a multiple of 4");
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if constexpr (HAS_BIAS) {
+      acc[t] = *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * g);
+    } else {
+      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  f32x4 st[PER];
+  // prologue: chunk 0 -> wbuf[0]
+#pragma unroll
+  for (int k = 0; k < PER; ++k)
+    st[k] = reinterpret_cast<const f32x4*>(img)[tid + 256 * k];
+#pragma unroll
+  for (int k = 0; k < PER; ++k)
+    reinterpret_cast<f32x4*>(wbuf)[tid + 256 * k] = st[k];
+  __syncthreads();
+  int cur = 0;
+  for (int q = 0; q < NT; ++q) {
+    if (q + 1 < NT) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(img + (int64_t)(q + 1) * CH);
+#pragma unroll
+      for (int k = 0; k < PER; ++k) st[k] = src[tid + 256 * k];
+    }
+    const f32x4 b4 = reinterpret_cast<const f32x4*>(hL)[q * 64 + lane];
+    const f32x4* wa = reinterpret_cast<const f32x4*>(wbuf + cur * CH);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 a4 = wa[t * 64 + lane];
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[t], 0, 0, 0);
+    }
+    if (q + 1 < NT) {
+      f32x4* dst = reinterpret_cast<f32x4*>(wbuf + (cur ^ 1) * CH);
+#pragma unroll
+      for (int k = 0; k < PER; ++k) dst[tid + 256 * k] = st[k];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_siren_step(SirenArgs a) {
+  constexpr int H = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, j = lane & 15;
+  float* hL = smem + wave * (NT * 256);
+  float* wbuf = smem + 4 * NT * 256;
+  const float* W0img = a.packed + off_w0(H);
+  const float* WLimg = a.packed + off_wl(H);
+  const float bL = a.packed[off_bl(H)];
+  float* stash = a.stash + ((int64_t)blockIdx.x * 4 + wave) * (int64_t)(a.L + 1) * NT * 256;
+
+  const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
+  const int64_t n_tiles = (count + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t slot = tile * 64 + wave * 16 + j;
+    const bool valid = slot < count;
+    int64_t idx = -1;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (valid) {
+      idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
+      px = a.pts[idx * 3]; py = a.pts[idx * 3 + 1]; pz = a.pts[idx * 3 + 2];
+    }
+    // ---- layer 0 (3 -> H) on the VALU -------------------------------------
+    for (int e4 = 0; e4 < NT; ++e4) {
+      f32x4 h4, s4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 w = reinterpret_cast<const f32x4*>(W0img)[g * (H / 4) + e4 * 4 + i];
+        float z = ((w.x * px + w.y * py) + w.z * pz) + w.w;
+        float s, c;
+        iso_sincos(a.w0 * z, s, c);
+        h4[i] = s;
+        s4[i] = a.w0 * c;
+      }
+      reinterpret_cast<f32x4*>(hL)[e4 * 64 + lane] = h4;
+      reinterpret_cast<f32x4*>(stash)[e4 * 64 + lane] = s4;
+    }
+    // ---- hidden layers, forward -------------------------------------------
+    f32x4 acc[NT];
+    for (int l = 0; l < a.L; ++l) {
+      const float* base = a.packed + off_hidden(H, l);
+      gemm_pass<NT, true>(base + H, base, hL, wbuf, acc, lane, g);
+      float* st_l = stash + (int64_t)(l + 1) * NT * 256;
+      // pre-activations go back to this wave's LDS slab (static register
+      // indices), then a rolled loop applies sin / stashes w*cos
+#pragma unroll
+      for (int t = 0; t < NT; ++t) reinterpret_cast<f32x4*>(hL)[t * 64 + lane] = acc[t];
+      for (int e4 = 0; e4 < NT; ++e4) {
+        const f32x4 z4 = reinterpret_cast<const f32x4*>(hL)[e4 * 64 + lane];
+        f32x4 h4, s4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float s, c;
+          iso_sincos(a.wh * z4[i], s, c);
+          h4[i] = s;
+          s4[i] = a.wh * c;
+        }
+        reinterpret_cast<f32x4*>(hL)[e4 * 64 + lane] = h4;
+        reinterpret_cast<f32x4*>(st_l)[e4 * 64 + lane] = s4;
+      }
+    }
+    // ---- head (H -> 1) and adjoint seed -----------------------------------
+    float f = 0.f;
+    {
+      const float* st_top = stash + (int64_t)a.L * NT * 256;
+      for (int e4 = 0; e4 < NT; ++e4) {
+        const f32x4 h4 = reinterpret_cast<const f32x4*>(hL)[e4 * 64 + lane];
+        const f32x4 w4 = reinterpret_cast<const f32x4*>(WLimg)[g * NT + e4];
+        const f32x4 s4 = reinterpret_cast<const f32x4*>(st_top)[e4 * 64 + lane];
+        f += (w4.x * h4.x + w4.y * h4.y) + (w4.z * h4.z + w4.w * h4.w);
+        f32x4 gs = {w4.x * s4.x, w4.y * s4.y, w4.z * s4.z, w4.w * s4.w};
+        reinterpret_cast<f32x4*>(hL)[e4 * 64 + lane] = gs;
+      }
+      f += __shfl_xor(f, 16);
+      f += __shfl_xor(f, 32);
+      f += bL;
+    }
+    // ---- hidden layers, reverse -------------------------------------------
+    for (int l = a.L - 1; l >= 0; --l) {
+      const float* base = a.packed + off_hidden(H, l);
+      gemm_pass<NT, false>(base + H + (int64_t)H * H, nullptr, hL, wbuf, acc, lane, g);
+      const float* st_l = stash + (int64_t)l * NT * 256;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 s4 = reinterpret_cast<const f32x4*>(st_l)[t * 64 + lane];
+        f32x4 gs = {acc[t].x * s4.x, acc[t].y * s4.y, acc[t].z * s4.z, acc[t].w * s4.w};
+        reinterpret_cast<f32x4*>(hL)[t * 64 + lane] = gs;
+      }
+    }
+    // ---- layer 0 reverse: grad = W0^T (adjoint . s0) ------------------------
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int e4 = 0; e4 < NT; ++e4) {
+      const f32x4 a4 = reinterpret_cast<const f32x4*>(hL)[e4 * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 w = reinterpret_cast<const f32x4*>(W0img)[g * (H / 4) + e4 * 4 + i];
+        gx += w.x * a4[i];
+        gy += w.y * a4[i];
+        gz += w.z * a4[i];
+      }
+    }
+    gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
+    gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
+    gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
+
+    // ---- epilogue ----------------------------------------------------------
+    bool survive = false;
+    if (valid && g == 0) {
+      if (a.eval_only) {
+        a.sdf_out[idx] = f;
+        a.grad_out[idx * 3] = gx; a.grad_out[idx * 3 + 1] = gy; a.grad_out[idx * 3 + 2] = gz;
+      } else {
+        a.normals[idx * 3] = gx; a.normals[idx * 3 + 1] = gy; a.normals[idx * 3 + 2] = gz;
+        const bool active = fabsf(f) > a.tol;
+        a.mask[idx] = active ? 0 : 1;
+        if (active && a.do_move) {
+          iso_newton_move(f, gx, gy, gz, px, py, pz);
+          a.pts[idx * 3] = px; a.pts[idx * 3 + 1] = py; a.pts[idx * 3 + 2] = pz;
+          survive = true;
+        }
+      }
+    }
+    if (!a.eval_only && a.do_move) {
+      const unsigned long long bal = __ballot(survive);
+      if (bal) {
+        int base = 0;
+        const int leader = __ffsll((long long)bal) - 1;
+        if (lane == leader) base = atomicAdd(a.count_out, __popcll(bal));
+        base = __shfl(base, leader);
+        if (survive) {
+          const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+          a.idx_out[base + rank] = (int32_t)idx;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kSirenBlocks = 256;  // persistent: one workgroup per CU
+
+inline int64_t stash_floats(int H, int L) { return (int64_t)kSirenBlocks * 4 * (L + 1) * H * 16; }
+
+template <int NT>
+int launch_step(const SirenArgs& a, int blocks, hipStream_t s) {
+  const size_t lds = (size_t)(6 * NT * 256) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_siren_step<NT>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_siren_step<NT>, dim3(blocks), dim3(256), lds, s, a);
+  return 0;
+}
+
+int dispatch_step(const SirenArgs& a, int H, int blocks, hipStream_t s) {
+  switch (H / 16) {
+    case 4: return launch_step<4>(a, blocks, s);
+    case 8: return launch_step<8>(a, blocks, s);
+    case 16: return launch_step<16>(a, blocks, s);
+    default: return -1;
+  }
+}
+
+__global__ void k_zero_counts(int32_t* c, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) c[i] = 0;
+}
+
+bool siren_shape_ok(int H, int L) {
+  return (H == 64 || H == 128 || H == 256) && L >= 0 && L <= 8;
+}
+
+}  // namespace
+
+extern "C" int64_t iso_siren_raw_floats(int hidden, int n_hidden) {
+  int64_t H = hidden;
+  return H * 3 + H + (int64_t)n_hidden * (H * H + H) + H + 1;
+}
+
+extern "C" int64_t iso_siren_packed_floats(int hidden, int n_hidden) {
+  return off_hidden(hidden, n_hidden);
+}
+
+extern "C" int iso_siren_pack_weights(const float* raw, float* packed, int hidden,
+                                      int n_hidden, void* stream) {
+  ISO_REQUIRE(siren_shape_ok(hidden, n_hidden), ISO_ERR_UNSUPPORTED,
+              "iso_siren_pack_weights: hidden must be 64/128/256 and 0<=n_hidden<=8 (got %d, %d)",
+              hidden, n_hidden);
+  ISO_REQUIRE(raw && packed, ISO_ERR_INVALID, "iso_siren_pack_weights: null pointer");
+  int64_t total = off_hidden(hidden, n_hidden);
+  hipLaunchKernelGGL(k_siren_pack, dim3(iso_stream_grid(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, raw, packed, hidden, n_hidden);
+  ISO_CHECK_LAUNCH("iso_siren_pack_weights");
+  return ISO_OK;
+}
+
+// workspace: [stash floats][idx A n][idx B n][counts 64]
+extern "C" int64_t iso_project_siren_workspace_bytes(int64_t n, int hidden, int n_hidden) {
+  if (n < 0) n = 0;
+  return stash_floats(hidden, n_hidden) * 4 + 2 * n * 4 + 64 * 4 + 64;
+}
+
+extern "C" int iso_project_siren(const float* pts_in, float* pts_out, float* normals_out,
+                                 uint8_t* mask_out, int64_t n, const float* packed,
+                                 int hidden, int n_hidden, float omega_first,
+                                 float omega_hidden, int max_iters, float tol,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  ISO_REQUIRE(siren_shape_ok(hidden, n_hidden), ISO_ERR_UNSUPPORTED,
+              "iso_project_siren: hidden must be 64/128/256 and 0<=n_hidden<=8 (got %d, %d)",
+              hidden, n_hidden);
+  ISO_REQUIRE(n >= 0 && max_iters >= 0 && max_iters <= 60, ISO_ERR_INVALID,
+              "iso_project_siren: bad n / max_iters (max 60)");
+  if (n == 0) return ISO_OK;
+  ISO_REQUIRE(n < (1ll << 31), ISO_ERR_UNSUPPORTED, "iso_project_siren: n must fit int32");
+  ISO_REQUIRE(pts_in && pts_out && normals_out && mask_out && packed && workspace,
+              ISO_ERR_INVALID, "iso_project_siren: null pointer");
+  ISO_REQUIRE(workspace_bytes >= iso_project_siren_workspace_bytes(n, hidden, n_hidden),
+              ISO_ERR_WORKSPACE, "iso_project_siren: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (pts_out != pts_in)
+    (void)hipMemcpyAsync(pts_out, pts_in, (size_t)n * 12, hipMemcpyDeviceToDevice, s);
+  float* stash = (float*)workspace;
+  int32_t* idxA = (int32_t*)(stash + stash_floats(hidden, n_hidden));
+  int32_t* idxB = idxA + n;
+  int32_t* counts = idxB + n;  // counts[it] = size of the list consumed by launch `it`
+  hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, s, counts, 64);
+  int64_t tiles = (n + 63) / 64;
+  int blocks = (int)(tiles < kSirenBlocks ? tiles : kSirenBlocks);
+  for (int it = 0; it <= max_iters; ++it) {
+    SirenArgs a;
+    a.pts = pts_out; a.normals = normals_out; a.mask = mask_out;
+    a.sdf_out = nullptr; a.grad_out = nullptr;
+    a.idx_in = (it == 0) ? nullptr : ((it & 1) ? idxA : idxB);
+    a.count_in = (it == 0) ? nullptr : counts + it;
+    a.idx_out = (it & 1) ? idxB : idxA;
+    a.count_out = counts + it + 1;
+    a.packed = packed; a.stash = stash; a.n = n; a.L = n_hidden;
+    a.w0 = omega_first; a.wh = omega_hidden; a.tol = tol;
+    a.do_move = (it < max_iters) ? 1 : 0;
+    a.eval_only = 0;
+    ISO_REQUIRE(dispatch_step(a, hidden, blocks, s) == 0, ISO_ERR_UNSUPPORTED,
+                "iso_project_siren: unsupported hidden size %d", hidden);
+  }
+  ISO_CHECK_LAUNCH("iso_project_siren");
+  return ISO_OK;
+}
+
+extern "C" int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_out,
+                                  int64_t n, const float* packed, int hidden,
+                                  int n_hidden, float omega_first, float omega_hidden,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+  ISO_REQUIRE(siren_shape_ok(hidden, n_hidden), ISO_ERR_UNSUPPORTED,
+              "iso_siren_sdf_grad: hidden must be 64/128/256 and 0<=n_hidden<=8 (got %d, %d)",
+              hidden, n_hidden);
+  ISO_REQUIRE(n >= 0, ISO_ERR_INVALID, "iso_siren_sdf_grad: n < 0");
+  if (n == 0) return ISO_OK;
+  ISO_REQUIRE(pts && sdf_out && grad_out && packed && workspace, ISO_ERR_INVALID,
+              "iso_siren_sdf_grad: null pointer");
+  ISO_REQUIRE(workspace_bytes >= stash_floats(hidden, n_hidden) * 4, ISO_ERR_WORKSPACE,
+              "iso_siren_sdf_grad: workspace too small");
+  SirenArgs a;
+  a.pts = const_cast<float*>(pts); a.normals = nullptr; a.mask = nullptr;
+  a.sdf_out = sdf_out; a.grad_out = grad_out;
+  a.idx_in = nullptr; a.count_in = nullptr; a.idx_out = nullptr; a.count_out = nullptr;
+  a.packed = packed; a.stash = (float*)workspace; a.n = n; a.L = n_hidden;
+  a.w0 = omega_first; a.wh = omega_hidden; a.tol = 0.f; a.do_move = 0; a.eval_only = 1;
+  int64_t tiles = (n + 63) / 64;
+  int blocks = (int)(tiles < kSirenBlocks ? tiles : kSirenBlocks);
+  ISO_REQUIRE(dispatch_step(a, hidden, blocks, (hipStream_t)stream) == 0, ISO_ERR_UNSUPPORTED,
+              "iso_siren_sdf_grad: unsupported hidden size %d", hidden);
+  ISO_CHECK_LAUNCH("iso_siren_sdf_grad");
+  return ISO_OK;
+}

@@ -1,0 +1,313 @@
+"""Host-side mirror of the reference's iso-point operators
+(DSS/models/levelset_sampling.py): same class, method names, arguments, return
+types and error behaviour; the arithmetic runs in libisopoints_hip.so.
+
+  UniformProjection._project_points   levelset_sampling.py:290-351
+  UniformProjection.resample          levelset_sampling.py:239-288
+  UniformProjection._create_tree      levelset_sampling.py:110-140
+  UniformProjection.project_points    levelset_sampling.py:353-439
+
+Model dispatch: an analytic sphere and SIREN networks run in the fused
+HIP kernels; any other nn.Module takes the generic route -- the reference's own
+algorithm (model.forward + autograd.grad on compacted active points) on the GPU.
+"""
+from collections import namedtuple
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from . import frnn
+from .sdf_models import PackedSiren, siren_spec
+
+ProjectionResult = namedtuple("ProjectionResult", ("points", "normals", "mask"))
+
+
+# ----------------------------------------------------------------------------- helpers
+def eps_denom(denom, eps=1e-17):
+    """DSS/utils/mathHelper.py:14-18."""
+    denom_sign = denom.sign() + (denom == 0.0).type_as(denom)
+    return denom_sign * torch.clamp(denom.abs(), eps)
+
+
+def with_host_lengths(num_points, host):
+    """Attach the host copy of a lengths tensor so later stages need no .tolist() sync."""
+    num_points._iso_host = [int(x) for x in host]
+    return num_points
+
+
+def host_lengths(num_points):
+    h = getattr(num_points, "_iso_host", None)
+    if h is None:
+        h = [int(x) for x in num_points.tolist()]  # host sync, as the reference (:308)
+        num_points._iso_host = h
+    return h
+
+
+def full_lengths(points):
+    B, P = points.shape[0], points.shape[1]
+    return with_host_lengths(torch.full((B,), P, dtype=torch.long, device=points.device), [P] * B)
+
+
+def convert_pointclouds_to_tensor(pcl):
+    """pytorch3d.ops.utils.convert_pointclouds_to_tensor for the two inputs the reference
+    passes (levelset_sampling.py:374): a padded tensor or a Pointclouds-like object."""
+    if torch.is_tensor(pcl):
+        return pcl, full_lengths(pcl)
+    if hasattr(pcl, "points_padded") and hasattr(pcl, "num_points_per_cloud"):
+        return pcl.points_padded(), pcl.num_points_per_cloud()
+    raise ValueError("The inputs should be either a Pointclouds object or a torch.Tensor")
+
+
+def padded_to_packed(padded, lens):
+    B, P = padded.shape[0], padded.shape[1]
+    if B == 1:
+        return padded[0, : lens[0]]
+    if all(l == P for l in lens):
+        return padded.reshape((B * P,) + tuple(padded.shape[2:]))
+    return torch.cat([padded[b, : lens[b]] for b in range(B)], dim=0)
+
+
+def packed_to_padded(packed, lens, pad_value=0):
+    B = len(lens)
+    mx = max(lens) if B else 0
+    if B == 1:
+        return packed.view((1, mx) + tuple(packed.shape[1:]))
+    if all(l == mx for l in lens):
+        return packed.view((B, mx) + tuple(packed.shape[1:]))
+    out = packed.new_full((B, mx) + tuple(packed.shape[1:]), pad_value)
+    s = 0
+    for b, l in enumerate(lens):
+        out[b, :l] = packed[s : s + l]
+        s += l
+    return out
+
+
+def reduce_mask_padded(values, mask):
+    """DSS/utils/__init__.py:149-169: drop the masked-out rows of each cloud, re-pad with 0."""
+    B = values.shape[0]
+    counts = [int(x) for x in mask.view(B, -1).sum(dim=1).tolist()]
+    packed = values[mask]
+    return packed_to_padded(packed, counts)
+
+
+def _filter_projection_result(result):
+    """levelset_sampling.py:59-65."""
+    points, normals, mask = result
+    return ProjectionResult(reduce_mask_padded(points, mask), reduce_mask_padded(normals, mask),
+                            reduce_mask_padded(mask, mask))
+
+
+# ----------------------------------------------------------------------------- the operator
+class LevelSetProjection(object):
+    def __init__(self, proj_max_iters=10, proj_tolerance=5.0e-5, max_points_per_pass=120000):
+        self.proj_max_iters = proj_max_iters
+        self.proj_tolerance = proj_tolerance
+        self.max_points_per_pass = max_points_per_pass
+
+    def project_points(self, points_init, network, latent, levelset):
+        raise NotImplementedError
+
+
+class UniformProjection(LevelSetProjection):
+    """Same constructor as the reference (levelset_sampling.py:92-108)."""
+
+    def __init__(self, proj_max_iters=10, proj_tolerance=5e-5, max_points_per_pass=120000,
+                 sample_iters=1, knn_k=8, resampling_clip=0.02, **kwargs):
+        super().__init__(proj_max_iters=proj_max_iters, proj_tolerance=proj_tolerance,
+                         max_points_per_pass=max_points_per_pass)
+        self.knn_k = knn_k
+        self.sample_iters = sample_iters
+        self.resampling_clip = resampling_clip  # stored, unused -- as in the reference (:108)
+        self._packed_cache = None
+
+    # -- tree ------------------------------------------------------------------------
+    def _create_tree(self, points_padded, refresh_tree=True, num_points_per_cloud=None):
+        """levelset_sampling.py:110-140: r = sqrt(diag/P)*knn_k, K = knn_k+1 self-inclusive
+        query, column 0 dropped.  Results are cached on self like the reference."""
+        if not refresh_tree and getattr(self, "_knn_idx", None) is not None:
+            return self._knn_idx
+        assert points_padded.ndim == 3
+        if num_points_per_cloud is None:
+            num_points_per_cloud = full_lengths(points_padded)
+        diag = (points_padded.max(dim=1).values - points_padded.min(dim=1).values).norm(dim=-1)
+        search_radius = torch.sqrt(diag / num_points_per_cloud.float()) * self.knn_k
+        dists, idxs, nn, grid = frnn.frnn_grid_points(
+            points_padded, points_padded, num_points_per_cloud, num_points_per_cloud,
+            K=self.knn_k + 1, r=search_radius, grid=None, return_nn=True)
+        self._knn_gather = frnn.frnn_gather
+        self._knn_idx = idxs[..., 1:]
+        self._knn_dists = dists[..., 1:]
+        self._knn_nn = nn[..., 1:, :]
+        self.knn_gather = frnn.frnn_gather
+        return self._knn_idx
+
+    # -- SDF evaluation ----------------------------------------------------------------
+    def _compute_sdf_and_grad(self, points, model, latent=None, **forward_kwargs):
+        """levelset_sampling.py:142-170 (generic route: chunks of max_points_per_pass)."""
+        shp = points.shape
+        points_packed = points.reshape(-1, 3)
+        if siren_spec(model) is not None and points_packed.is_cuda and not forward_kwargs:
+            from .sdf_models import siren_sdf_and_grad
+            sdf, grad = siren_sdf_and_grad(model, points_packed)
+            return sdf.view(shp[:-1]), grad.view(shp)
+        grads, evals = [], []
+        with torch.no_grad():
+            model.eval()
+            for sub in torch.split(points_packed, self.max_points_per_pass, dim=0):
+                with torch.enable_grad():
+                    x = sub.detach().requires_grad_(True)
+                    out = model.forward(x, **forward_kwargs).sdf
+                    (g,) = torch.autograd.grad([out], [x], torch.ones_like(out), retain_graph=False)
+                grads.append(g)
+                evals.append(out.detach())
+            if not grads:
+                return points_packed.new_zeros(shp[:-1]), points_packed.new_zeros(shp)
+            return torch.cat(evals, 0).view(shp[:-1]), torch.cat(grads, 0).view(shp)
+
+    # -- projection --------------------------------------------------------------------
+    def _project_packed(self, model, pts, proj_max_iters, proj_tolerance, **forward_kwargs):
+        """pts (n,3) f32 contiguous on the GPU -> points, normals, mask(bool)."""
+        n = pts.shape[0]
+        dev = pts.device
+        out = torch.empty_like(pts)
+        normals = torch.zeros_like(pts)
+        mask = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        p = _lib.ptr
+        if getattr(model, "iso_analytic", None) == "sphere" and not forward_kwargs:
+            c = [float(x) for x in model.center.tolist()] if not hasattr(model, "_iso_center") else model._iso_center
+            model._iso_center = c
+            _lib.call("iso_project_sphere", p(pts), p(out), p(normals), p(mask), n, c[0], c[1], c[2],
+                      float(model.radius), int(proj_max_iters), float(proj_tolerance), _lib.stream())
+            return out, normals, mask.bool()
+        if siren_spec(model) is not None and not forward_kwargs:
+            ps = PackedSiren(model, dev)
+            ws = ps.workspace(n)
+            _lib.call("iso_project_siren", p(pts), p(out), p(normals), p(mask), n, p(ps.packed),
+                      ps.hidden, ps.n_hidden, ps.omega_first, ps.omega_hidden, int(proj_max_iters),
+                      float(proj_tolerance), p(ws), ws.numel(), _lib.stream())
+            self._packed_cache = ps  # keep the workspace alive until the stream has used it
+            return out, normals, mask.bool()
+        return self._project_packed_generic(model, pts, proj_max_iters, proj_tolerance, **forward_kwargs)
+
+    def _project_packed_generic(self, model, pts, proj_max_iters, proj_tolerance, **forward_kwargs):
+        """The reference's loop (levelset_sampling.py:309-344) for models without a fused kernel."""
+        points_packed = pts.clone()
+        not_converged = torch.ones(points_packed.shape[0], dtype=torch.bool, device=pts.device)
+        normals_packed = torch.zeros_like(points_packed)
+        it = 0
+        while True:
+            curr_points = points_packed[not_converged]
+            curr_sdf, curr_grad = self._compute_sdf_and_grad(curr_points, model, **forward_kwargs)
+            normals_packed[not_converged] = curr_grad
+            curr_not_converged = curr_sdf.reshape(-1).abs() > proj_tolerance
+            nc = not_converged.clone()
+            nc[not_converged] = curr_not_converged
+            not_converged = nc
+            if (~not_converged).all() or it == proj_max_iters:
+                break
+            it += 1
+            active_grad = curr_grad[curr_not_converged]
+            active_sdf = curr_sdf.reshape(-1)[curr_not_converged]
+            active_pts = curr_points[curr_not_converged]
+            ssg = torch.sum(active_grad ** 2, dim=-1, keepdim=True)
+            move = active_sdf.view(-1, 1) * (active_grad / eps_denom(ssg, 1.0e-17))
+            move = F.normalize(move, dim=-1, eps=1e-15) * move.norm(dim=-1, keepdim=True).clamp_max(0.1)
+            points_packed[not_converged] = active_pts - move
+        return points_packed, normals_packed, ~not_converged
+
+    def _project_points(self, model, points, num_points, proj_max_iters=None, proj_tolerance=None,
+                        **forward_kwargs) -> ProjectionResult:
+        """points (B,P,3) padded, num_points (B,) -> ProjectionResult(points, normals, mask)."""
+        proj_max_iters = proj_max_iters or self.proj_max_iters
+        proj_tolerance = proj_tolerance or self.proj_tolerance
+        if not points.is_cuda:
+            raise RuntimeError("iso_points_amd: points must be on the GPU; there is no CPU path")
+        lens = host_lengths(num_points)
+        packed = padded_to_packed(points.detach().float(), lens).contiguous()
+        with torch.no_grad():
+            pts, normals, valid = self._project_packed(model, packed, proj_max_iters, proj_tolerance,
+                                                       **forward_kwargs)
+        return ProjectionResult(packed_to_padded(pts, lens), packed_to_padded(normals, lens),
+                                packed_to_padded(valid, lens, pad_value=False))
+
+    # -- resample ----------------------------------------------------------------------
+    def repulsion_step(self, points, normals_init, idx, inv_sigma):
+        """One tangent-plane repulsion move (levelset_sampling.py:268-284) of a single cloud.
+        points (1,P,3); normals_init un-normalised (normalised on the fly in the kernel);
+        idx (1,P,K) int64 view (row stride may exceed K); inv_sigma: device scalar."""
+        assert points.shape[0] == 1, "resample supports one cloud (as the reference, :256,:274)"
+        P, K = points.shape[1], idx.shape[-1]
+        pts = points[0].contiguous()
+        nrm = normals_init[0].contiguous()
+        assert idx.stride(-1) == 1
+        out = torch.empty_like(pts)
+        _lib.call("iso_repulse", _lib.ptr(pts), _lib.ptr(nrm), _c_ptr(idx), int(idx.stride(-2)),
+                  _lib.ptr(out), P, K, _lib.ptr(inv_sigma), _lib.stream())
+        return out.view(1, P, 3)
+
+    def resample(self, model, points_init, normals_init, num_points, sample_iters=None,
+                 **forward_kwargs) -> ProjectionResult:
+        sample_iters = sample_iters or self.sample_iters
+        batch_size = points_init.shape[0]
+        if num_points is None:
+            num_points = full_lengths(points_init)
+        if sample_iters == 0 or points_init.nelement() < 2 * (self.knn_k + 1):
+            return ProjectionResult(points_init, normals_init,
+                                    points_init.new_full(points_init.shape[:-1], True, dtype=torch.bool))
+        if batch_size != 1:
+            raise NotImplementedError("resample: one cloud per call (the reference's broadcast of "
+                                      "inv_sigma_spatial is only valid for batch size 1, :256,:274)")
+        flat = points_init.reshape(-1, 3)
+        diag = (flat.max(dim=0).values - flat.min(dim=0).values).norm()
+        inv_sigma = (num_points.float() / diag).reshape(1).contiguous()      # device scalar (:256)
+        points = points_init
+        projection_result = None
+        idx = None
+        for sample_iter in range(sample_iters):
+            if sample_iter % 2 == 0:
+                self._create_tree(points, refresh_tree=True, num_points_per_cloud=num_points)
+                idx = self._knn_idx
+            points = self.repulsion_step(points, normals_init, idx, inv_sigma)
+            projection_result = self._project_points(model, points, num_points, proj_max_iters=3,
+                                                     **forward_kwargs)
+        return projection_result
+
+    # -- driver ------------------------------------------------------------------------
+    def project_points(self, point_clouds, model, normals_init: Optional[torch.Tensor] = None,
+                       skip_resampling: bool = False, skip_upsampling: bool = False, ref_pcl=None,
+                       proj_max_iters: Optional[int] = None, sample_iters: Optional[int] = None,
+                       **forward_kwargs):
+        """levelset_sampling.py:353-439.  The upsampling branches (insert / upsample) are the
+        SURVEY 8(f) 'next' rows and are not built yet: pass skip_upsampling=True."""
+        points_init, num_points = convert_pointclouds_to_tensor(point_clouds)
+        proj_max_iters = proj_max_iters or self.proj_max_iters
+        sample_iters = sample_iters or self.sample_iters
+        with torch.no_grad():
+            points_projected, normals_projected, valid_projection = self._project_points(
+                model, points_init, num_points, proj_max_iters=proj_max_iters, **forward_kwargs)
+            if not valid_projection.any():
+                return {"levelset_points": points_projected, "mask": valid_projection}
+            if not skip_resampling:
+                points_projected, normals_projected, valid_projection = _filter_projection_result(
+                    ProjectionResult(points_projected, normals_projected, valid_projection))
+                num_points = valid_projection.sum(dim=-1)
+                points_projected, normals_projected, valid_projection = self.resample(
+                    model, points_projected, normals_projected, num_points, sample_iters=sample_iters,
+                    **forward_kwargs)
+                num_points = valid_projection.sum(dim=-1)
+            if not skip_upsampling:
+                raise NotImplementedError(
+                    "project_points: insert/upsample (levelset_sampling.py:411-434) are not built yet; "
+                    "call with skip_upsampling=True")
+            return {"levelset_points": points_projected, "levelset_normals": normals_projected,
+                    "mask": valid_projection}
+
+
+def _c_ptr(t):
+    """Device pointer of a possibly strided view (caller passes the strides separately)."""
+    import ctypes
+    if not t.is_cuda:
+        raise RuntimeError("iso_points_amd: tensor must live on the GPU")
+    return ctypes.c_void_p(t.data_ptr())

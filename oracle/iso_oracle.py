@@ -1,0 +1,318 @@
+"""CPU oracle for the iso-point hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product path (iso_points_amd) never does and fails loudly if
+the HIP library is missing.
+
+Each function restates one piece of the reference (yifita/iso-points) with the
+same tensor operations in the same order, in float32 on the CPU, and cites the
+file:line it follows.  Pinning status (see DESIGN.md "Oracle"):
+  * projection / repulsion / resample / EWA per-point setup: pinned against the
+    reference's own Python (imported in the build container with shims) through
+    the fixtures in tests/golden/ made by tests/golden/make_golden.py.
+  * splat forward / backward: the C restatement in oracle/oracle_splat.c is
+    pinned against the reference's DSS/csrc/rasterize_points_cpu.cpp compiled
+    as-is into oracle/_ref/ (oracle/Makefile).
+  * FRNN neighbour search: PARITY UNPINNED -- lxxue/FRNN@eab337f is a
+    third-party dependency whose source is not in the reference checkout; the
+    contract below is restated from the call sites and checked against brute
+    force only.
+"""
+from collections import namedtuple
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ProjectionResult = namedtuple("ProjectionResult", ("points", "normals", "mask"))
+SdfOut = namedtuple("SdfOut", ("sdf",))
+
+
+# --------------------------------------------------------------------------- helpers
+def eps_denom(denom, eps=1e-17):
+    """DSS/utils/mathHelper.py:14-18 -- sign-preserving clamp of |x| to >= eps."""
+    denom_sign = denom.sign() + (denom == 0.0).type_as(denom)
+    return denom_sign * torch.clamp(denom.abs(), eps)
+
+
+def eps_sqrt(squared, eps=1e-17):
+    """DSS/utils/mathHelper.py:20-25."""
+    return torch.clamp(squared.abs(), eps)
+
+
+def first_idx_from_num(num_points):
+    """DSS/utils/__init__.py:26-29."""
+    return F.pad(num_points, (1, 0), "constant", 0).cumsum(0)[:-1]
+
+
+def padded_to_packed_list(padded, num_points):
+    return torch.cat([padded[b, : int(n)] for b, n in enumerate(num_points.tolist())], dim=0)
+
+
+def packed_to_padded(packed, num_points, pad_value=0.0):
+    B = len(num_points)
+    mx = int(max(num_points.tolist())) if B else 0
+    out = packed.new_full((B, mx) + tuple(packed.shape[1:]), pad_value)
+    s = 0
+    for b, n in enumerate(num_points.tolist()):
+        out[b, :n] = packed[s : s + n]
+        s += n
+    return out
+
+
+# --------------------------------------------------------------------------- SDF models
+class SphereSDF(torch.nn.Module):
+    """Analytic SDF |x - c| - R with the model contract of DSS/models/common.py:21-23
+    (forward returns an object with `.sdf` of shape (M,1))."""
+
+    def __init__(self, center=(0.0, 0.0, 0.0), radius=1.0):
+        super().__init__()
+        self.register_buffer("center", torch.tensor(center, dtype=torch.float32))
+        self.radius = float(radius)
+
+    def forward(self, x, **kwargs):
+        return SdfOut(sdf=(x - self.center).norm(dim=-1, keepdim=True) - self.radius)
+
+
+class SirenSDF(torch.nn.Module):
+    """SIREN SDF, a restatement of Siren/SineLayer (DSS/models/common.py:56-165) with
+    c_dim=0 and a linear head: h0=sin(w0(W0x+b0)), hi=sin(w(Wih+bi)), out=WLh+bL.
+    Same initialisation (common.py:77-84, :128-131)."""
+
+    def __init__(self, dim=3, hidden_size=256, n_layers=3, first_omega_0=30.0, hidden_omega_0=30.0):
+        super().__init__()
+        self.hidden_size, self.n_layers = hidden_size, n_layers
+        self.first_omega_0, self.hidden_omega_0 = float(first_omega_0), float(hidden_omega_0)
+        lins = [torch.nn.Linear(dim, hidden_size)]
+        with torch.no_grad():
+            lins[0].weight.uniform_(-1 / dim, 1 / dim)
+        for _ in range(n_layers):
+            lin = torch.nn.Linear(hidden_size, hidden_size)
+            with torch.no_grad():
+                b = np.sqrt(6 / hidden_size) / hidden_omega_0
+                lin.weight.uniform_(-b, b)
+            lins.append(lin)
+        head = torch.nn.Linear(hidden_size, 1)
+        with torch.no_grad():
+            b = np.sqrt(6 / hidden_size) / hidden_omega_0
+            head.weight.uniform_(-b, b)
+        lins.append(head)
+        self.lins = torch.nn.ModuleList(lins)
+
+    def forward(self, x, **kwargs):
+        h = torch.sin(self.first_omega_0 * self.lins[0](x))
+        for lin in self.lins[1:-1]:
+            h = torch.sin(self.hidden_omega_0 * lin(h))
+        return SdfOut(sdf=self.lins[-1](h))
+
+    def raw_weights(self):
+        """Packed f32 buffer in the order include/isopoints.h documents."""
+        parts = []
+        for lin in self.lins:
+            parts += [lin.weight.detach().reshape(-1), lin.bias.detach().reshape(-1)]
+        return torch.cat(parts).float().contiguous()
+
+
+def fit_siren_to_sphere(model, radius=1.0, steps=300, seed=0, lr=1e-4, batch=4096):
+    """Short Adam fit of a SirenSDF to |x|-R so Newton projection converges
+    (SURVEY 8(d) cfg 2: 'weights fitted to the sphere for convergence realism')."""
+    g = torch.Generator().manual_seed(seed)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    for _ in range(steps):
+        x = (torch.rand(batch, 3, generator=g) - 0.5) * 3.0
+        y = x.norm(dim=-1, keepdim=True) - radius
+        loss = ((model(x).sdf - y) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    return model
+
+
+def compute_sdf_and_grad(points, model, max_points_per_pass=120000, **kw):
+    """UniformProjection._compute_sdf_and_grad, levelset_sampling.py:142-170
+    (`.detach()` instead of `.detach_()` on the split view: torch>=2 rejects the
+    in-place form)."""
+    shp = points.shape
+    packed = points.reshape(-1, 3)
+    grads, evals = [], []
+    with torch.no_grad():
+        model.eval()
+        for sub in torch.split(packed, max_points_per_pass, dim=0):
+            with torch.enable_grad():
+                x = sub.detach().requires_grad_(True)
+                out = model.forward(x, **kw).sdf
+                (g,) = torch.autograd.grad([out], [x], torch.ones_like(out), retain_graph=False)
+            grads.append(g)
+            evals.append(out.detach())
+        if len(grads) == 0:
+            return packed.new_zeros(shp[:-1]), packed.new_zeros(shp)
+        return torch.cat(evals, 0).view(shp[:-1]), torch.cat(grads, 0).view(shp)
+
+
+# --------------------------------------------------------------------------- A. projection
+def project_points(model, points, num_points, proj_max_iters=10, proj_tolerance=5e-5,
+                   max_points_per_pass=120000, **kw):
+    """UniformProjection._project_points, levelset_sampling.py:290-351.
+    points (B,P,3) padded, num_points (B,) long -> ProjectionResult (padded)."""
+    points_packed = padded_to_packed_list(points, num_points).clone()
+    not_converged = torch.ones(points_packed.shape[0], dtype=torch.bool)
+    normals_packed = torch.zeros_like(points_packed)
+    it = 0
+    while True:
+        curr_points = points_packed[not_converged]
+        curr_sdf, curr_grad = compute_sdf_and_grad(curr_points, model, max_points_per_pass, **kw)
+        normals_packed[not_converged] = curr_grad
+        curr_not_converged = curr_sdf.reshape(-1).abs() > proj_tolerance
+        nc = not_converged.clone()
+        nc[not_converged] = curr_not_converged          # :328 (self-indexed write, torch>=2 safe)
+        not_converged = nc
+        if (~not_converged).all() or it == proj_max_iters:
+            break
+        it += 1
+        active_grad = curr_grad[curr_not_converged]
+        active_sdf = curr_sdf.reshape(-1)[curr_not_converged]
+        active_pts = curr_points[curr_not_converged]
+        ssg = torch.sum(active_grad ** 2, dim=-1, keepdim=True)
+        move = active_sdf.view(-1, 1) * (active_grad / eps_denom(ssg, 1.0e-17))
+        move = F.normalize(move, dim=-1, eps=1e-15) * move.norm(dim=-1, keepdim=True).clamp_max(0.1)
+        points_packed[not_converged] = active_pts - move
+    valid = ~not_converged
+    return ProjectionResult(packed_to_padded(points_packed, num_points),
+                            packed_to_padded(normals_packed, num_points),
+                            packed_to_padded(valid.view(-1, 1).float(), num_points).squeeze(-1).bool())
+
+
+# --------------------------------------------------------------------------- B. FRNN (contract)
+def _d2(q, p):
+    """(dx*dx + dy*dy) + dz*dz in float32, no fused multiply-add."""
+    d = (q[:, None, :] - p[None, :, :]).astype(np.float32)
+    sq = d * d
+    return (sq[..., 0] + sq[..., 1]) + sq[..., 2]
+
+
+def frnn_grid_points(points1, points2, lengths1=None, lengths2=None, K=8, r=0.1,
+                     return_nn=False, use_tree=None):
+    """Contract of frnn.frnn_grid_points as the reference uses it
+    (levelset_sampling.py:132-138): for each query the K nearest points of cloud 2
+    with squared distance < r^2, ascending by (d2, index), -1 padded.  Exact
+    brute force; for big clouds a cKDTree only pre-selects candidates (radius
+    r*(1+1e-4)), distances and order are still computed as above."""
+    p1 = points1.detach().cpu().numpy().astype(np.float32)
+    p2 = points2.detach().cpu().numpy().astype(np.float32)
+    N, P1, _ = p1.shape
+    P2 = p2.shape[1]
+    l1 = [P1] * N if lengths1 is None else [int(x) for x in lengths1.tolist()]
+    l2 = [P2] * N if lengths2 is None else [int(x) for x in lengths2.tolist()]
+    rr = np.broadcast_to(np.asarray(r.detach().cpu().numpy() if torch.is_tensor(r) else r,
+                                    dtype=np.float32).reshape(-1), (N,)) if N else np.zeros(0, np.float32)
+    dists = np.full((N, P1, K), -1.0, np.float32)
+    idxs = np.full((N, P1, K), -1, np.int64)
+    for n in range(N):
+        a, b = p1[n, : l1[n]], p2[n, : l2[n]]
+        r2 = np.float32(rr[n]) * np.float32(rr[n])
+        if len(a) == 0 or len(b) == 0:
+            continue
+        tree = use_tree if use_tree is not None else (len(a) * len(b) > 4e7)
+        if not tree:
+            step = max(1, int(2e7 // max(len(b), 1)))
+            for s in range(0, len(a), step):
+                d2 = _d2(a[s : s + step], b)
+                for i in range(d2.shape[0]):
+                    cand = np.nonzero(d2[i] < r2)[0]
+                    if len(cand) == 0:
+                        continue
+                    order = np.lexsort((cand, d2[i, cand]))[:K]
+                    sel = cand[order]
+                    dists[n, s + i, : len(sel)] = d2[i, sel]
+                    idxs[n, s + i, : len(sel)] = sel
+        else:
+            from scipy.spatial import cKDTree
+            kd = cKDTree(b.astype(np.float64))
+            lists = kd.query_ball_point(a.astype(np.float64), float(rr[n]) * (1 + 1e-4) + 1e-7)
+            for i, cand in enumerate(lists):
+                if len(cand) == 0:
+                    continue
+                cand = np.asarray(cand, dtype=np.int64)
+                d = (a[i][None, :] - b[cand]).astype(np.float32)
+                sq = d * d
+                d2 = (sq[:, 0] + sq[:, 1]) + sq[:, 2]
+                keep = d2 < r2
+                cand, d2 = cand[keep], d2[keep]
+                order = np.lexsort((cand, d2))[:K]
+                dists[n, i, : len(order)] = d2[order]
+                idxs[n, i, : len(order)] = cand[order]
+    dists_t, idxs_t = torch.from_numpy(dists), torch.from_numpy(idxs)
+    nn = frnn_gather(points2.detach().cpu().float(), idxs_t) if return_nn else None
+    return dists_t, idxs_t, nn, None
+
+
+def frnn_gather(x, idxs, lengths=None):
+    """frnn.frnn_gather: x (N,P2,U), idxs (N,P1,K) -> (N,P1,K,U); zeros where idx<0."""
+    N, P1, K = idxs.shape
+    U = x.shape[-1]
+    safe = idxs.clamp(min=0)
+    out = torch.gather(x, 1, safe.reshape(N, P1 * K, 1).expand(-1, -1, U)).view(N, P1, K, U)
+    return out * (idxs >= 0)[..., None].to(x.dtype)
+
+
+def search_radius(points_padded, num_points, knn_k):
+    """levelset_sampling.py:129-131.  Like the reference, min/max run over the
+    whole padded tensor."""
+    diag = (points_padded.max(dim=1).values - points_padded.min(dim=1).values).norm(dim=-1)
+    return torch.sqrt(diag / num_points.float()) * knn_k
+
+
+# --------------------------------------------------------------------------- C. repulsion / resample
+def repulsion_step(points, normals_unit, idx, inv_sigma_spatial):
+    """Body of UniformProjection.resample, levelset_sampling.py:268-284.
+    points (1,P,3), normals_unit = F.normalize(normals_init), idx (1,P,K) long."""
+    nn_normals = frnn_gather(normals_unit, idx)
+    knn_nn = frnn_gather(points, idx)
+    knn_diff = points[:, :, None, :] - knn_nn
+    knn_dists = torch.sum(knn_diff ** 2, dim=-1)
+    spatial_w = torch.exp(-knn_dists * inv_sigma_spatial)
+    spatial_w[idx < 0] = 0
+    density_w = torch.sum(spatial_w, dim=-1, keepdim=True) + 1.0
+    pts_diff_proj = knn_diff - (knn_diff * nn_normals).sum(dim=-1, keepdim=True) * nn_normals
+    move = density_w * torch.sum(spatial_w[..., None] * pts_diff_proj, dim=-2) / \
+        eps_denom(torch.sum(spatial_w, dim=-1, keepdim=True))
+    return points + move
+
+
+def resample(model, points_init, normals_init, num_points, sample_iters=1, knn_k=8,
+             proj_tolerance=5e-5, max_points_per_pass=120000, frnn_fn=None, **kw):
+    """UniformProjection.resample, levelset_sampling.py:239-288 (single cloud)."""
+    frnn_fn = frnn_fn or frnn_grid_points
+    B = points_init.shape[0]
+    if num_points is None:
+        num_points = torch.full((B,), points_init.shape[1], dtype=torch.long)
+    full = points_init.new_full(points_init.shape[:-1], True, dtype=torch.bool)
+    if sample_iters == 0 or points_init.nelement() < 2 * (knn_k + 1):
+        return ProjectionResult(points_init, normals_init, full)
+    flat = points_init.view(-1, 3)
+    diag = (flat.max(dim=0).values - flat.min(0).values).norm().item()
+    inv_sigma_spatial = num_points / diag
+    points = points_init
+    normals = F.normalize(normals_init, dim=-1)
+    result, idx = None, None
+    for it in range(sample_iters):
+        if it % 2 == 0:
+            r = search_radius(points, num_points, knn_k)
+            _, idxs, _, _ = frnn_fn(points, points, num_points, num_points, K=knn_k + 1, r=r)
+            idx = idxs[..., 1:]
+        points = repulsion_step(points, normals, idx, inv_sigma_spatial)
+        result = project_points(model, points, num_points, proj_max_iters=3,
+                                proj_tolerance=proj_tolerance,
+                                max_points_per_pass=max_points_per_pass, **kw)
+    return result
+
+
+def reduce_mask_padded(padded, mask):
+    """DSS/utils/__init__.py:149-169: keep masked rows per cloud, re-pad with 0."""
+    lst = [padded[b][mask[b]] for b in range(padded.shape[0])]
+    mx = max([x.shape[0] for x in lst]) if lst else 0
+    out = padded.new_zeros((len(lst), mx) + tuple(padded.shape[2:]))
+    for b, x in enumerate(lst):
+        out[b, : x.shape[0]] = x
+    return out

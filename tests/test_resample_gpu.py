@@ -1,0 +1,82 @@
+"""Tangent-plane repulsion and the full resample (levelset_sampling.py:239-288) vs the oracle."""
+import pytest
+import torch
+
+from util import sphere_cloud, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _oracle():
+    from oracle import iso_oracle
+    return iso_oracle
+
+
+def test_repulsion_step(dev):
+    O = _oracle()
+    from iso_points_amd.levelset_sampling import UniformProjection
+    P, K = 5000, 8
+    p = sphere_cloud(P, seed=31)
+    g = torch.Generator().manual_seed(32)
+    normals = p + 0.1 * torch.randn(1, P, 3, generator=g)          # un-normalised, like grad SDF
+    r = O.search_radius(p, torch.tensor([P]), K)
+    _, idxs, _, _ = O.frnn_grid_points(p, p, K=K + 1, r=r)
+    idxs[0, ::7, -2:] = -1                                          # some padded neighbours
+    idx = idxs[..., 1:]
+    diag = (p.view(-1, 3).max(0).values - p.view(-1, 3).min(0).values).norm().item()
+    inv_sigma = torch.tensor([P]) / diag
+    ref = O.repulsion_step(p, torch.nn.functional.normalize(normals, dim=-1), idx, inv_sigma)
+    proj = UniformProjection(knn_k=K)
+    out = proj.repulsion_step(p.to(dev), normals.to(dev), idxs.to(dev)[..., 1:],
+                              inv_sigma.float().to(dev))
+    move_ref = (ref - p)
+    assert ((out.cpu() - ref).abs().max() / move_ref.abs().max()).item() < TOL
+
+
+@pytest.mark.parametrize("model_kind,sample_iters", [("sphere", 1), ("sphere", 3), ("siren", 1)])
+def test_resample_full(dev, model_kind, sample_iters):
+    """project(T=10) -> resample: FRNN + repulsion + project(T=3), one cloud."""
+    O = _oracle()
+    from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
+    from iso_points_amd.sdf_models import SphereSDF
+    P = 3000
+    pts = sphere_cloud(P, seed=41)
+    if model_kind == "sphere":
+        m_cpu, m_gpu = O.SphereSDF(), SphereSDF().to(dev)
+    else:
+        torch.manual_seed(0)
+        m_cpu = O.fit_siren_to_sphere(O.SirenSDF(hidden_size=256, n_layers=3), steps=200)
+        m_gpu = m_cpu
+    num = torch.tensor([P])
+    r0 = O.project_points(m_cpu, pts, num, proj_max_iters=10)
+    ref = O.resample(m_cpu, r0.points, r0.normals, num, sample_iters=sample_iters, knn_k=8)
+    proj = UniformProjection(knn_k=8)
+    g = pts.to(dev)
+    g0 = proj._project_points(m_gpu, g, full_lengths(g), proj_max_iters=10)
+    res = proj.resample(m_gpu, g0.points, g0.normals, full_lengths(g), sample_iters=sample_iters)
+    assert rel_err(res.points, ref.points) < TOL
+    assert rel_err(res.normals, ref.normals) < 5 * TOL
+    assert (res.mask.cpu() == ref.mask).float().mean() > 0.999
+
+
+def test_project_points_driver(dev):
+    """UniformProjection.project_points(skip_upsampling=True): project -> filter -> resample."""
+    O = _oracle()
+    from iso_points_amd.levelset_sampling import UniformProjection
+    from iso_points_amd.sdf_models import SphereSDF
+    P = 2000
+    g = torch.Generator().manual_seed(51)
+    pts = (torch.rand(1, P, 3, generator=g) - 0.5) * 2.6     # some start > 1 away: never converge in 3 its
+    proj = UniformProjection(proj_max_iters=3, knn_k=8)
+    out = proj.project_points(pts.to(dev), SphereSDF().to(dev), skip_upsampling=True)
+    r0 = O.project_points(O.SphereSDF(), pts, torch.tensor([P]), proj_max_iters=3)
+    assert not r0.mask.all()
+    keep = r0.mask
+    p1 = O.reduce_mask_padded(r0.points, keep)
+    n1 = O.reduce_mask_padded(r0.normals, keep)
+    num = keep.sum(-1)
+    ref = O.resample(O.SphereSDF(), p1, n1, num, sample_iters=1, knn_k=8)
+    assert out["levelset_points"].shape == ref.points.shape
+    assert rel_err(out["levelset_points"], ref.points) < TOL
+    assert set(out.keys()) == {"levelset_points", "levelset_normals", "mask"}
