@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from util import sphere_cloud, rel_err
+from util import sphere_cloud, rel_err, assert_projection_close
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -34,9 +34,13 @@ def test_repulsion_step(dev):
     assert ((out.cpu() - ref).abs().max() / move_ref.abs().max()).item() < TOL
 
 
-@pytest.mark.parametrize("model_kind,sample_iters", [("sphere", 1), ("sphere", 3), ("siren", 1)])
-def test_resample_full(dev, model_kind, sample_iters):
-    """project(T=10) -> resample: FRNN + repulsion + project(T=3), one cloud."""
+@pytest.mark.parametrize("model_kind,sample_iters,stop_tol",
+                         [("sphere", 1, 5e-5), ("sphere", 3, 5e-5), ("siren", 1, 5e-5),
+                          ("sphere", 1, 1e-30), ("siren", 1, 1e-30)])
+def test_resample_full(dev, model_kind, sample_iters, stop_tol):
+    """project(T=10) -> resample: FRNN + repulsion + project(T=3), one cloud.
+    stop_tol=1e-30 pins the iteration count (nothing ever "converges"): strict 1e-5 on
+    every point; the default tolerance additionally allows rare stop flips."""
     O = _oracle()
     from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
     from iso_points_amd.sdf_models import SphereSDF
@@ -49,15 +53,23 @@ def test_resample_full(dev, model_kind, sample_iters):
         m_cpu = O.fit_siren_to_sphere(O.SirenSDF(hidden_size=256, n_layers=3), steps=200)
         m_gpu = m_cpu
     num = torch.tensor([P])
-    r0 = O.project_points(m_cpu, pts, num, proj_max_iters=10)
-    ref = O.resample(m_cpu, r0.points, r0.normals, num, sample_iters=sample_iters, knn_k=8)
-    proj = UniformProjection(knn_k=8)
+    r0 = O.project_points(m_cpu, pts, num, proj_max_iters=10, proj_tolerance=stop_tol)
+    ref = O.resample(m_cpu, r0.points, r0.normals, num, sample_iters=sample_iters, knn_k=8,
+                     proj_tolerance=stop_tol)
+    proj = UniformProjection(knn_k=8, proj_tolerance=stop_tol)
     g = pts.to(dev)
     g0 = proj._project_points(m_gpu, g, full_lengths(g), proj_max_iters=10)
-    res = proj.resample(m_gpu, g0.points, g0.normals, full_lengths(g), sample_iters=sample_iters)
-    assert rel_err(res.points, ref.points) < TOL
-    assert rel_err(res.normals, ref.normals) < 5 * TOL
-    assert (res.mask.cpu() == ref.mask).float().mean() > 0.999
+    # feed the oracle's projection forward so the second stage is compared on equal inputs
+    res = proj.resample(m_gpu, r0.points.to(dev), r0.normals.to(dev), full_lengths(g),
+                        sample_iters=sample_iters)
+    if stop_tol < 1e-20:
+        assert rel_err(g0.points, r0.points) < TOL
+        assert rel_err(res.points, ref.points) < TOL
+        assert rel_err(res.normals, ref.normals) < 5 * TOL
+    else:
+        assert_projection_close(g0.points, r0.points, stop_tol)
+        assert_projection_close(res.points, ref.points, stop_tol)
+        assert (res.mask.cpu() == ref.mask).float().mean() > 0.995
 
 
 def test_project_points_driver(dev):
@@ -78,5 +90,5 @@ def test_project_points_driver(dev):
     num = keep.sum(-1)
     ref = O.resample(O.SphereSDF(), p1, n1, num, sample_iters=1, knn_k=8)
     assert out["levelset_points"].shape == ref.points.shape
-    assert rel_err(out["levelset_points"], ref.points) < TOL
+    assert_projection_close(out["levelset_points"], ref.points)
     assert set(out.keys()) == {"levelset_points", "levelset_normals", "mask"}
