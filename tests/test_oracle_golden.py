@@ -1,0 +1,96 @@
+"""Pin the oracle: its restatement of projection / resample must reproduce the golden vectors
+that tests/golden/make_golden.py obtained by running the reference's own Python
+(levelset_sampling.py with import shims) in the build container.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import assert_projection_close, rel_err
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TIGHT = 2e-6   # same float32 torch ops in the same order; slack for a different host CPU
+
+
+def load(name):
+    d = np.load(os.path.join(GOLD, name))
+    return {k: (torch.from_numpy(d[k]) if d[k].ndim else d[k].item()) for k in d.files}
+
+
+def siren_from(g):
+    from oracle import iso_oracle as O
+    m = O.SirenSDF(hidden_size=int(g["siren_hidden"]), n_layers=int(g["siren_layers"]))
+    raw = g["siren_raw"]
+    o = 0
+    with torch.no_grad():
+        for lin in m.lins:
+            n = lin.weight.numel()
+            lin.weight.copy_(raw[o:o + n].view_as(lin.weight)); o += n
+            n = lin.bias.numel()
+            lin.bias.copy_(raw[o:o + n]); o += n
+    assert o == raw.numel()
+    return m
+
+
+def test_projection_sphere_cfg1():
+    from oracle import iso_oracle as O
+    g = load("proj_sphere_cfg1.npz")
+    num = torch.tensor([g["points"].shape[1]])
+    for T in (1, 10):
+        r = O.project_points(O.SphereSDF(), g["points"], num, proj_max_iters=T)
+        assert_projection_close(r.points, g["T%d_points" % T], tol=TIGHT)
+        assert rel_err(r.normals, g["T%d_normals" % T]) < 1e-5
+        assert (r.mask == g["T%d_mask" % T]).float().mean() > 0.999
+
+
+def test_projection_sphere_ragged():
+    from oracle import iso_oracle as O
+    g = load("proj_sphere_ragged.npz")
+    m = O.SphereSDF(tuple(g["center"].tolist()), float(g["radius"]))
+    r = O.project_points(m, g["points"], g["num_points"], proj_max_iters=int(g["T"]))
+    assert r.points.shape == g["out_points"].shape
+    assert_projection_close(r.points, g["out_points"], tol=TIGHT)
+    assert torch.equal(r.mask, g["out_mask"])
+
+
+def test_siren_eval_and_projection():
+    from oracle import iso_oracle as O
+    g = load("proj_siren_small.npz")
+    m = siren_from(g)
+    sdf, grad = O.compute_sdf_and_grad(g["points"], m)
+    assert rel_err(sdf, g["sdf"]) < TIGHT and rel_err(grad, g["grad"]) < TIGHT
+    n = torch.tensor([g["points"].shape[1]])
+    r = O.project_points(m, g["points"], n, proj_max_iters=int(g["T"]))
+    assert rel_err(r.points, g["out_points"]) < 1e-4     # random SIREN: chaotic, 4 clamped moves
+    g = load("proj_siren_fitted.npz")
+    m = siren_from(g)
+    n = torch.tensor([g["points"].shape[1]])
+    r = O.project_points(m, g["points"], n, proj_max_iters=10)
+    assert_projection_close(r.points, g["out_points"], tol=1e-5)
+    r0 = O.project_points(m, g["points"], n, proj_max_iters=10, proj_tolerance=1e-30)
+    assert rel_err(r0.points, g["fixed_points"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["sphere", "sphere3", "siren"])
+def test_resample(tag):
+    from oracle import iso_oracle as O
+    g = load("resample_%s.npz" % tag)
+    m = siren_from(g) if tag == "siren" else O.SphereSDF()
+    n = torch.tensor([g["points"].shape[1]])
+    r = O.resample(m, g["proj_points"], g["proj_normals"], n, sample_iters=int(g["sample_iters"]),
+                   knn_k=int(g["knn_k"]))
+    assert_projection_close(r.points, g["out_points"], tol=1e-5)
+    assert (r.mask == g["out_mask"]).float().mean() > 0.995
+
+
+def test_project_points_driver_filtering():
+    from oracle import iso_oracle as O
+    g = load("project_points_driver.npz")
+    P = g["points"].shape[1]
+    r0 = O.project_points(O.SphereSDF(), g["points"], torch.tensor([P]), proj_max_iters=int(g["T"]))
+    p1 = O.reduce_mask_padded(r0.points, r0.mask)
+    n1 = O.reduce_mask_padded(r0.normals, r0.mask)
+    r = O.resample(O.SphereSDF(), p1, n1, r0.mask.sum(-1), sample_iters=1, knn_k=int(g["knn_k"]))
+    assert r.points.shape == g["levelset_points"].shape
+    assert_projection_close(r.points, g["levelset_points"], tol=1e-5)
