@@ -226,13 +226,12 @@ def gen_resample(L, m_fit):
 def main():
     install_shims()
     L = load_reference_levelset()
-    m_fit = gen_projection(L)
-    gen_resample(L, m_fit)
-    try:
-        from make_golden_splat import gen_splat  # second half, added with the splat path
+    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "levelset"):
+        m_fit = gen_projection(L)
+        gen_resample(L, m_fit)
+    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "splat"):
+        from make_golden_splat import gen_splat
         gen_splat()
-    except ImportError:
-        pass
 
 
 if __name__ == "__main__":

@@ -94,3 +94,36 @@ def test_project_points_driver_filtering():
     r = O.resample(O.SphereSDF(), p1, n1, r0.mask.sum(-1), sample_iters=1, knn_k=int(g["knn_k"]))
     assert r.points.shape == g["levelset_points"].shape
     assert_projection_close(r.points, g["levelset_points"], tol=1e-5)
+
+
+def test_splat_per_point_setup():
+    """oracle per_point_info / vrk_h vs SurfaceSplatting._get_per_point_info run from the
+    reference (rasterizer.py:344-563).  The reference draws a random tangent frame; any frame
+    gives the same result mathematically, so the comparison is to rounding (2e-4), not bitwise."""
+    from oracle import splat_oracle as SO
+    g = load("splat_setup.npz")
+    num = g["num"]
+    pts_l = torch.split(g["points"], num.tolist())
+    mx = int(num.max())
+    padded = torch.zeros(len(num), mx, 3)
+    for i, p in enumerate(pts_l):
+        padded[i, : len(p)] = p
+    h = SO.vrk_h(padded, num, float(g["frnn_radius"]))
+    assert torch.equal(h, g["Vrk_h"])          # same frnn contract + same torch ops
+    s = 0
+    for i, n in enumerate(num.tolist()):
+        M44 = g["views"][i] @ g["proj"]
+        info = SO.per_point_info(g["points"][s:s + n], g["normals"][s:s + n], h[s:s + n], M44,
+                                 int(g["image_size"]), float(g["cutoff"]), float(g["sigma"]))
+        for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler"):
+            ref = g[k][s:s + n].reshape(n, -1)
+            # per-point scale: b of (a,b,c) can be ~0, so normalise by the row's largest entry
+            err = ((info[k].reshape(n, -1) - ref).abs() / ref.abs().amax(-1, keepdim=True)).max().item()
+            assert err < 1e-4, (k, err)
+        s += n
+
+
+def test_gather_with_neg_idx():
+    from oracle import splat_oracle as SO
+    g = load("gather_neg_idx.npz")
+    assert torch.equal(SO.gather_scaler(g["scaler"], g["idx"]), g["out"])
