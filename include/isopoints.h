@@ -181,6 +181,102 @@ int iso_repulse(const float* points, const float* normals, const int64_t* idx,
                 int64_t idx_row_stride, float* points_out, int64_t n, int K,
                 const float* inv_sigma, void* stream);
 
+/* ------------------------------------------------------------------------
+ * D. EWA surface splatting
+ *    replaces SurfaceSplatting (DSS/core/rasterizer.py:103-661), the pybind module
+ *    DSS._C (DSS/csrc/ext.cpp:5-18: splat_points, _splat_points_naive,
+ *    _splat_points_occ_backward, _splat_points_occ_fast_cuda_backward,
+ *    _backward_zbuf) and SurfaceSplattingRenderer.forward (DSS/core/renderer.py:36-82).
+ *    Matrices are 4x4 row-major in pytorch3d's row-vector convention
+ *    (p' = [p,1] @ M).  Packed clouds: cloud n owns rows
+ *    [first_idx[n], first_idx[n]+num_pts[n]).
+ * ---------------------------------------------------------------------- */
+
+/* filter_renderable (rasterizer.py:184-254): flags (n_views, P) i32 = 1 when
+ * znear <= z_view <= zfar and (backface_culling ? normal_view.z < 0 : 1).        */
+int iso_splat_view_flags(const float* points, const float* normals, const float* views,
+                         int32_t* flags, int64_t P, int n_views, float znear, float zfar,
+                         int backface_culling, void* stream);
+/* stable stream compaction of U-float rows: out[offsets[e]] = in[e % P] where
+ * flags[e] != 0, e in [0,total) (offsets = exclusive scan of flags).           */
+int iso_compact_rows(const float* in, const int32_t* flags, const int32_t* offsets,
+                     float* out, int64_t P, int64_t total, int U, void* stream);
+/* _compute_isotropic_Vrk (rasterizer.py:367-386): dists (N,p_stride,7) from the
+ * K=7 self query -> h (packed) = clamp(0.5*max_{6 nn} d2, 5e-5, 0.01); clouds
+ * with fewer than 7 points use d2 = 1e-3.                                        */
+int iso_splat_vrk_h(const float* dists, const int64_t* first_idx, const int64_t* num_pts,
+                    float* h, int n_clouds, int64_t p_stride, void* stream);
+/* _get_per_point_info + PointsRasterizer.transform (rasterizer.py:441-563,:618):
+ * per packed point: NDC position (xy projected, z = view depth), ellipse (a,b,c),
+ * cutoff, bbox radii, EWA normaliser.  views = world->view, projs = full
+ * world->NDC, both (n_views,4,4).                                               */
+int iso_splat_setup(const float* points, const float* normals, const float* h,
+                    const int64_t* first_idx, const int64_t* num_pts, const float* views,
+                    const float* projs, int n_views, int64_t max_pts, int image_size,
+                    float sigma, float cutoff, float* ndc_out, float* ellipse_out,
+                    float* cutoff_out, float* radii_out, float* scaler_out, void* stream);
+
+/* Forward rasterisation = _C.splat_points (rasterize_points.h:461-525).
+ * Two calls around one caller-side read of the pair count:
+ *   iso_splat_bin_count : tile_cnt (n_clouds*T*T, zero on entry) += splats per
+ *                         16x16 tile (T = iso_splat_tiles_per_side(S));
+ *   caller: tile_off = exclusive scan (iso_prefix_sum), total = off[last]+cnt[last],
+ *           allocate `pairs` (i32, >= total), zero tile_cursor and overflow_flag;
+ *   iso_splat_forward   : fill + raster.  Per pixel the points_per_pixel (<= 32)
+ *                         smallest (z, idx) hits, entries with z - z0 >
+ *                         depth_merging_thres reset to -1, occupancy = any hit.
+ * Outputs as the reference: idx i32, zbuf/qvalue f32 (N,S,S,K), occ f32 (N,S,S),
+ * image flipped in both axes (+X left, +Y up).  *overflow_flag != 0 afterwards
+ * means pair_capacity was too small (result incomplete).                        */
+int iso_splat_tiles_per_side(int image_size);
+int iso_splat_bin_count(const float* points, const float* radii, const int64_t* first_idx,
+                        const int64_t* num_pts, int n_clouds, int64_t max_pts, int image_size,
+                        int32_t* tile_cnt, void* stream);
+int iso_splat_forward(const float* points, const float* ellipse, const float* cutoff,
+                      const float* radii, const int64_t* first_idx, const int64_t* num_pts,
+                      int n_clouds, int64_t max_pts, float depth_merging_thres, int image_size,
+                      int points_per_pixel, int32_t* tile_cursor, const int32_t* tile_off,
+                      int32_t* pairs, int64_t pair_capacity, int32_t* overflow_flag,
+                      int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out,
+                      void* stream);
+
+/* renderer.py:53-78: w = exp(-0.5 q) * scaler[idx] (0 where idx < 0);
+ * image[..., c] = sum_k w f / max(sum_k w, eps) (norm_weighted) or sum_k w f;
+ * image[..., channels] = occupancy.  frag_scaler_out (n_pixels,K) may be NULL.  */
+int iso_splat_composite(const int32_t* idx, const float* qvalue, const float* occ,
+                        const float* scaler, const float* features, int64_t n_pixels,
+                        int points_per_pixel, int channels, int norm_weighted, float eps,
+                        float* frag_scaler_out, float* image_out, void* stream);
+
+/* Backward = EllipticalRasterizer.backward, default fast path
+ * (rasterizer.py:841-968 + rasterize_points_backward.cu:85-178 +
+ * rasterize_points.cu:823-846), point-major and atomic-free:
+ *   iso_splat_mark_visible: visible[p] = 1 for points listed in pixels whose first
+ *                           slot is filled (visible zeroed by the caller);
+ *   iso_splat_backward    : grad_points (P,3): xy = sum over pixels within
+ *                           search_radius[n] of grad_occ * d/sdeno(|d|^2,1e-10)
+ *                           (visible points; grad>0 pixels outside the splat rect
+ *                           skipped), z = sum of grad_zbuf over the slots that list
+ *                           the point.  Sums run in image order -> bit-stable.
+ * grad_zbuf/idx may be NULL (no z gradient); visible may be NULL (= all).
+ * rect_mode = 1 switches the xy support to the slow reference kernel's rectangle
+ * |d| <= radii * radii_s (_C._splat_points_occ_backward, rasterize_points.cu:673-760);
+ * search_radius is then unused.                                                  */
+int iso_splat_mark_visible(const int32_t* idx, int64_t n_pixels, int points_per_pixel,
+                           uint8_t* visible, void* stream);
+int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size);
+int iso_splat_backward(const float* points, const float* radii, const uint8_t* visible,
+                       const float* search_radius, const int64_t* first_idx,
+                       const int64_t* num_pts, int n_clouds, int64_t max_pts,
+                       const float* grad_occ, const int32_t* idx, const float* grad_zbuf,
+                       int image_size, int points_per_pixel, int rect_mode, float radii_s,
+                       void* workspace, int64_t workspace_bytes, float* grad_points,
+                       void* stream);
+/* _C._backward_zbuf alone (rasterize_points.cu:823-846): z_grad[idx] += grad_zbuf
+ * by atomic scatter, accumulating into the caller's (P) buffer.                 */
+int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbuf, int64_t n_pixels,
+                            int points_per_pixel, float* z_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

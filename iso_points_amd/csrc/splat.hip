@@ -1,0 +1,681 @@
+// EWA surface splatting for gfx950: per-point set-up, tile binning, per-tile
+// rasterisation, compositing and the (deterministic) backward pass.
+//
+// Reference semantics
+//   set-up   : SurfaceSplatting._get_per_point_info and helpers,
+//              DSS/core/rasterizer.py:344-563; filter_renderable :184-254
+//   forward  : _C.splat_points -> RasterizePoints{Naive,Coarse,Fine}
+//              DSS/csrc/rasterize_points.cu:65-211,293-430,506-596 (CPU twin
+//              rasterize_points_cpu.cpp:27-144)
+//   composite: SurfaceSplattingRenderer.forward, DSS/core/renderer.py:53-78
+//   backward : EllipticalRasterizer.backward (rasterizer.py:841-968) +
+//              RasterizePointsBackwardCudaFastKernel
+//              (rasterize_points_backward.cu:85-178) + ZbufBackwardKernel
+//              (rasterize_points.cu:823-846)
+//
+// Design (MI355X): the reference bins 512-point chunks into <=21x21 bins with 64
+// workgroups and then lets every pixel scan all M = max(1e4,P) slots of its
+// bin (an N*B*B*M int table: 4 GB at 1M points).  Here points are binned into
+// 16x16-pixel tiles by a count -> scan -> fill counting sort (one int per
+// point-tile pair), and one 256-lane workgroup per tile streams its candidate
+// list through LDS in 256-entry chunks (every lane reads the same LDS word:
+// broadcast, conflict free) while each lane keeps the K front-most (z, idx)
+// hits of its own pixel in registers.  4096 tiles at 512^2 x 4 views fill the
+// 256 CUs 16 times over.  The K-best rule is the reference CPU's
+// lexicographic (z, idx) order, so per-pixel index lists are deterministic and
+// bit-identical to the compiled reference no matter in which order the atomics
+// of the fill pass land.
+//
+// Backward is point-major: every visible point walks the pixels of its
+// support in image order and accumulates in registers -- no float atomics, so
+// gradients are bit-stable (the reference's gpuAtomicAdd order is not).
+#include <float.h>
+#include "iso_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int TILE = 16;  // pixels per tile side; one workgroup = 16x16 lanes
+
+__device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1 + (2 * i + 1.0f) / S; }
+
+__device__ __forceinline__ float esqrt_arg(float x) {  // eps_sqrt, mathHelper.py:20-25
+  float a = fabsf(x);
+  return a < 1e-17f ? 1e-17f : a;
+}
+
+// ---------------------------------------------------------------- visibility
+// flags[n*P+i] = 1 when point i is renderable in view n (rasterizer.py:184-254)
+__global__ void k_view_flags(const float* __restrict__ pts, const float* __restrict__ nrm,
+                             const float* __restrict__ views, int32_t* __restrict__ flags,
+                             int64_t P, float znear, float zfar, int backface) {
+  const int n = blockIdx.y;
+  const float* V = views + n * 16;  // row-vector convention: p_view = [p,1] @ V
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    float zv = ((x * V[2] + y * V[6]) + z * V[10]) + V[14];
+    bool ok = (zv >= znear) && (zv <= zfar);
+    if (backface) {
+      float nx = nrm[i * 3], ny = nrm[i * 3 + 1], nz = nrm[i * 3 + 2];
+      float nzv = (nx * V[2] + ny * V[6]) + nz * V[10];
+      ok = ok && (nzv < 0.f);
+    }
+    flags[(int64_t)n * P + i] = ok ? 1 : 0;
+  }
+}
+
+// out[off[e]] = in[e % P] for flagged e (stable: packed order = view-major, point ascending)
+__global__ void k_compact_rows(const float* __restrict__ in, const int32_t* __restrict__ flags,
+                               const int32_t* __restrict__ off, float* __restrict__ out,
+                               int64_t P, int64_t total, int U) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    if (flags[e]) {
+      const float* s = in + (e % P) * U;
+      float* d = out + (int64_t)off[e] * U;
+      for (int u = 0; u < U; ++u) d[u] = s[u];
+    }
+  }
+}
+
+// h = clamp(0.5 * max_{6 nn} d2, 5e-5, 0.01)   (rasterizer.py:375-386)
+__global__ void k_vrk_h(const float* __restrict__ dists /*(N,Pmax,7)*/,
+                        const int64_t* __restrict__ first, const int64_t* __restrict__ num,
+                        float* __restrict__ h, int64_t pmax) {
+  const int n = blockIdx.y;
+  const int64_t len = num[n];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float* d = dists + ((int64_t)n * pmax + i) * 7;
+    float m = -FLT_MAX;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) {
+      float v = (len < 7) ? 1e-3f : d[k];
+      m = fmaxf(m, v);
+    }
+    float hv = 0.5f * m;
+    hv = fminf(fmaxf(hv, 5e-5f), 0.01f);
+    h[first[n] + i] = hv;
+  }
+}
+
+// ---------------------------------------------------------------- per-point EWA set-up
+struct SetupOut {
+  float* ndc;      // (P,3)
+  float* ellipse;  // (P,3)
+  float* cutoff;   // (P)
+  float* radii;    // (P,2)
+  float* scaler;   // (P)
+};
+
+__global__ void k_splat_setup(const float* __restrict__ pts, const float* __restrict__ nrm,
+                              const float* __restrict__ h, const int64_t* __restrict__ first,
+                              const int64_t* __restrict__ num, const float* __restrict__ views,
+                              const float* __restrict__ projs, int S, float sigma, float cutoffC,
+                              SetupOut o) {
+  const int n = blockIdx.y;
+  const float* V = views + n * 16;
+  const float* M = projs + n * 16;  // full world->NDC, row-vector convention
+  const int64_t len = num[n], base = first[n];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = base + i;
+    const float x = pts[p * 3], y = pts[p * 3 + 1], z = pts[p * 3 + 2];
+    // [p,1] @ M columns 0,1,3 and view depth
+    const float xv = ((x * M[0] + y * M[4]) + z * M[8]) + M[12];
+    const float yv = ((x * M[1] + y * M[5]) + z * M[9]) + M[13];
+    const float t = ((x * M[3] + y * M[7]) + z * M[11]) + M[15];
+    const float zv = ((x * V[2] + y * V[6]) + z * V[10]) + V[14];
+    const float t2 = iso_eps_denom(t * t, 1e-17f);
+    const float td = iso_eps_denom(t, 1e-17f);
+    const float j00 = 1.0f / td;
+    const float j30 = -1.0f / t2 * xv, j31 = -1.0f / t2 * yv;
+    // WJk = M[:3,:] @ Jk  (3x2)
+    float w0[3], w1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      w0[r] = M[r * 4 + 0] * j00 + M[r * 4 + 3] * j30;
+      w1[r] = M[r * 4 + 1] * j00 + M[r * 4 + 3] * j31;
+    }
+    // tangent frame: u0 = normalize(n x (n + e)), u1 = normalize(n x u0), e = axis least
+    // aligned with n (a deterministic instance of rasterizer.py:395-397)
+    const float nx = nrm[p * 3], ny = nrm[p * 3 + 1], nz = nrm[p * 3 + 2];
+    float ex = 0.f, ey = 0.f, ez = 0.f;
+    const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+    if (ax <= ay && ax <= az) ex = 1.f; else if (ay <= az) ey = 1.f; else ez = 1.f;
+    const float mx = nx + ex, my = ny + ey, mz = nz + ez;
+    float ux = ny * mz - nz * my, uy = nz * mx - nx * mz, uz = nx * my - ny * mx;
+    float un = sqrtf((ux * ux + uy * uy) + uz * uz);
+    un = un > 1e-12f ? un : 1e-12f;
+    ux /= un; uy /= un; uz /= un;
+    float vx = ny * uz - nz * uy, vy = nz * ux - nx * uz, vz = nx * uy - ny * ux;
+    float vn = sqrtf((vx * vx + vy * vy) + vz * vz);
+    vn = vn > 1e-12f ? vn : 1e-12f;
+    vx /= vn; vy /= vn; vz /= vn;
+    // Mk = Sk @ WJk (2x2);  Vk = h * Mk^T Mk
+    const float m00 = (ux * w0[0] + uy * w0[1]) + uz * w0[2];
+    const float m01 = (ux * w1[0] + uy * w1[1]) + uz * w1[2];
+    const float m10 = (vx * w0[0] + vy * w0[1]) + vz * w0[2];
+    const float m11 = (vx * w1[0] + vy * w1[1]) + vz * w1[2];
+    const float hk = h[p];
+    const float ps = 2.0f / (float)S;
+    const float lp = sigma * (ps * ps);
+    const float g00 = hk * (m00 * m00 + m10 * m10) + lp;
+    const float g01 = hk * (m00 * m01 + m10 * m11);
+    const float g11 = hk * (m01 * m01 + m11 * m11) + lp;
+    const float detM = m00 * m11 - m01 * m10;
+    // det(h M^T M + lp I) = h^2 det(M)^2 + lp h |M|_F^2 + lp^2: all terms positive, so no
+    // cancellation (the textbook g00*g11 - g01^2 loses ~cond(G) digits on grazing splats)
+    const float fro = (m00 * m00 + m10 * m10) + (m01 * m01 + m11 * m11);
+    const float detG = (hk * hk) * (detM * detM) + (lp * hk * fro + lp * lp);
+    const float a = g11 / detG, c = g00 / detG, b = (-g01 / detG) + (-g01 / detG);
+    const float den = iso_eps_denom(4.0f * a * c - b * b, 1e-17f);
+    const float ry = sqrtf(esqrt_arg(4.0f * a * cutoffC / den));
+    const float rx = sqrtf(esqrt_arg(4.0f * c * cutoffC / den));
+    const float sc = fabsf(detM) / iso_eps_denom(sqrtf(esqrt_arg(detG * 4.0f * 3.14159265358979323846f * 3.14159265358979323846f)), 1e-17f);
+    o.ndc[p * 3] = xv / t; o.ndc[p * 3 + 1] = yv / t; o.ndc[p * 3 + 2] = zv;
+    o.ellipse[p * 3] = a; o.ellipse[p * 3 + 1] = b; o.ellipse[p * 3 + 2] = c;
+    o.cutoff[p] = cutoffC;
+    o.radii[p * 2] = rx; o.radii[p * 2 + 1] = ry;
+    o.scaler[p] = sc;
+  }
+}
+
+// ---------------------------------------------------------------- tile binning
+// NDC-index range of pixels whose centre can lie within [c-r, c+r] (one pixel of slack on
+// each side; the exact reference test runs in the raster kernel)
+__device__ __forceinline__ bool pixel_range(float c, float r, int S, int& lo, int& hi) {
+  if (!(r >= 0.f) || !(c == c)) return false;
+  float flo = ((c - r) + 1.0f) * 0.5f * (float)S - 0.5f;
+  float fhi = ((c + r) + 1.0f) * 0.5f * (float)S - 0.5f;
+  if (!(flo < 1e9f)) return false;
+  if (!(fhi > -1e9f)) return false;
+  flo = fmaxf(flo, -4.0f);
+  fhi = fminf(fhi, (float)S + 4.0f);
+  lo = (int)ceilf(flo) - 1;
+  hi = (int)floorf(fhi) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > S - 1) hi = S - 1;
+  return lo <= hi;
+}
+
+template <bool FILL>
+__global__ void k_bin(const float* __restrict__ pts, const float* __restrict__ radii,
+                      const int64_t* __restrict__ first, const int64_t* __restrict__ num, int S,
+                      int T /*tiles per side*/, int32_t* __restrict__ tile_cnt,
+                      const int32_t* __restrict__ tile_off, int32_t* __restrict__ pairs,
+                      int64_t capacity, int32_t* __restrict__ overflow) {
+  const int n = blockIdx.y;
+  const int64_t len = num[n], base = first[n];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = base + i;
+    const float z = pts[p * 3 + 2];
+    if (!(z >= 0.f)) continue;  // behind the camera (rasterize_points.cu:87-88) or NaN
+    int x0, x1, y0, y1;
+    if (!pixel_range(pts[p * 3], radii[p * 2], S, x0, x1)) continue;
+    if (!pixel_range(pts[p * 3 + 1], radii[p * 2 + 1], S, y0, y1)) continue;
+    for (int ty = y0 / TILE; ty <= y1 / TILE; ++ty)
+      for (int tx = x0 / TILE; tx <= x1 / TILE; ++tx) {
+        const int tile = (n * T + ty) * T + tx;
+        const int slot = atomicAdd(&tile_cnt[tile], 1);
+        if (FILL) {
+          const int64_t dst = (int64_t)tile_off[tile] + slot;
+          if (dst < capacity) pairs[dst] = (int32_t)p;
+          else *overflow = 1;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------- raster
+template <int KMAX>
+struct PixK {
+  float z[KMAX];
+  float q[KMAX];
+  int id[KMAX];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) { z[j] = FLT_MAX; q[j] = -1.f; id[j] = 0x7fffffff; }
+  }
+  __device__ __forceinline__ void push(float cz, int ci, float cq, int K) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < K && (cz < z[j] || (cz == z[j] && ci < id[j]))) {
+        float tz = z[j], tq = q[j]; int ti = id[j];
+        z[j] = cz; q[j] = cq; id[j] = ci;
+        cz = tz; cq = tq; ci = ti;
+      }
+    }
+  }
+};
+
+struct Cand {  // one LDS record per candidate (SoA in LDS)
+  float px, py, pz, a, b, c, rx, ry, cut;
+  int id;
+};
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_raster(
+    const float* __restrict__ pts, const float* __restrict__ ellipse,
+    const float* __restrict__ cutoff, const float* __restrict__ radii,
+    const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ tile_off,
+    const int32_t* __restrict__ pairs, int64_t capacity, int S, int T, int K, float depth_thres,
+    int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out,
+    float* __restrict__ occ_out) {
+  __shared__ float s_px[256], s_py[256], s_pz[256], s_a[256], s_b[256], s_c[256], s_rx[256],
+      s_ry[256], s_cut[256];
+  __shared__ int s_id[256];
+  const int tile = blockIdx.x;          // (n*T + ty)*T + tx
+  const int tx = tile % T, ty = (tile / T) % T, n = tile / (T * T);
+  const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
+  const int xi = tx * TILE + lx, yi = ty * TILE + ly;  // NDC pixel index
+  const bool inside = xi < S && yi < S;
+  const float xf = pix_to_ndc(xi, S), yf = pix_to_ndc(yi, S);
+  PixK<KMAX> best;
+  best.init();
+  float wz = FLT_MAX;
+  int wi = 0x7fffffff;
+  const int64_t off = tile_off[tile];
+  int cnt = tile_cnt[tile];
+  if (off + cnt > capacity) cnt = off < capacity ? (int)(capacity - off) : 0;  // overflow guard
+  for (int c0 = 0; c0 < cnt; c0 += 256) {
+    const int m = min(256, cnt - c0);
+    __syncthreads();
+    if ((int)threadIdx.x < m) {
+      const int p = pairs[off + c0 + threadIdx.x];
+      s_px[threadIdx.x] = pts[(int64_t)p * 3];
+      s_py[threadIdx.x] = pts[(int64_t)p * 3 + 1];
+      s_pz[threadIdx.x] = pts[(int64_t)p * 3 + 2];
+      s_a[threadIdx.x] = ellipse[(int64_t)p * 3];
+      s_b[threadIdx.x] = ellipse[(int64_t)p * 3 + 1];
+      s_c[threadIdx.x] = ellipse[(int64_t)p * 3 + 2];
+      s_rx[threadIdx.x] = radii[(int64_t)p * 2];
+      s_ry[threadIdx.x] = radii[(int64_t)p * 2 + 1];
+      s_cut[threadIdx.x] = cutoff[p];
+      s_id[threadIdx.x] = p;
+    }
+    __syncthreads();
+    if (inside) {
+      for (int k = 0; k < m; ++k) {
+        const float dx = xf - s_px[k], dy = yf - s_py[k];
+        if (fabsf(dx) > s_rx[k] || fabsf(dy) > s_ry[k]) continue;  // rasterize_points.cu:92
+        const float q = s_a[k] * dx * dx + s_b[k] * dx * dy + s_c[k] * dy * dy;  // :94
+        if (q > s_cut[k]) continue;                                              // :96
+        const float pz = s_pz[k];
+        const int id = s_id[k];
+        if (pz < wz || (pz == wz && id < wi)) {
+          best.push(pz, id, q, K);
+#pragma unroll
+          for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wz = best.z[j]; wi = best.id[j]; }
+        }
+      }
+    }
+  }
+  if (!inside) return;
+  // output pixel is flipped in both axes (+X left, +Y up; rasterize_points.cu:577-580)
+  const int yo = S - 1 - yi, xo = S - 1 - xi;
+  const int64_t pix = ((int64_t)n * S + yo) * S + xo;
+  const float z0 = best.z[0];
+  const bool hit = z0 < FLT_MAX;
+  occ_out[pix] = hit ? 1.0f : 0.0f;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    if (j < K) {
+      const bool ok = best.z[j] < FLT_MAX && !((best.z[j] - z0) > depth_thres);
+      idx_out[pix * K + j] = ok ? best.id[j] : -1;
+      zbuf_out[pix * K + j] = ok ? best.z[j] : -1.0f;
+      q_out[pix * K + j] = ok ? best.q[j] : -1.0f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- compositing
+// w = exp(-0.5 q) * scaler[idx]; out[...,c] = sum w f / max(sum w, eps) ; out[...,C] = occupancy
+__global__ void k_composite(const int32_t* __restrict__ idx, const float* __restrict__ qv,
+                            const float* __restrict__ occ, const float* __restrict__ scaler,
+                            const float* __restrict__ feat, int K, int C, int norm, float eps,
+                            int64_t npix, float* __restrict__ frag_scaler /* may be null */,
+                            float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float sw = 0.f;
+    float acc[8];
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int p = idx[i * K + k];
+      float s = 0.f, w = 0.f;
+      if (p >= 0) {
+        s = scaler[p];
+        w = expf(-0.5f * qv[i * K + k]) * s;
+        for (int c = 0; c < C; ++c) acc[c] += w * feat[(int64_t)p * C + c];
+        sw += w;
+      }
+      if (frag_scaler) frag_scaler[i * K + k] = s;
+    }
+    float d = 1.0f;
+    if (norm) d = sw > eps ? sw : eps;
+    for (int c = 0; c < C; ++c) out[i * (C + 1) + c] = norm ? acc[c] / d : acc[c];
+    out[i * (C + 1) + C] = occ[i];
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// visible[p] = 1 for every point listed in a pixel whose first slot is filled
+// (rasterizer.py:850-856)
+__global__ void k_mark_visible(const int32_t* __restrict__ idx, int K, int64_t npix,
+                               uint8_t* __restrict__ visible) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (idx[i * K] < 0) continue;
+    for (int k = 0; k < K; ++k) {
+      const int p = idx[i * K + k];
+      if (p >= 0) visible[p] = 1;
+    }
+  }
+}
+
+// ZbufBackwardKernel (rasterize_points.cu:823-846): z_grad[idx] += grad_zbuf, zeros skipped,
+// stop at the first idx < 0.  Atomic scatter (order-dependent like the reference's).
+__global__ void k_zbuf_scatter(const int32_t* __restrict__ idx, const float* __restrict__ gz,
+                               int K, int64_t npix, float* __restrict__ z_grad) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    for (int k = 0; k < K; ++k) {
+      const float g = gz[i * K + k];
+      if (g == 0.0f) continue;
+      const int p = idx[i * K + k];
+      if (p < 0) break;
+      atomicAdd(&z_grad[p], g);
+    }
+  }
+}
+
+// coarse map of 8x8 pixel blocks that hold a non-zero occupancy gradient
+constexpr int GB = 8;
+__global__ void k_grad_blocks(const float* __restrict__ grad_occ, int S, int NB, int N,
+                              uint8_t* __restrict__ blk) {
+  const int64_t total = (int64_t)N * NB * NB;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    const int bx = b % NB, by = (b / NB) % NB, n = b / ((int64_t)NB * NB);
+    uint8_t any = 0;
+    for (int y = by * GB; y < min(S, (by + 1) * GB) && !any; ++y)
+      for (int x = bx * GB; x < min(S, (bx + 1) * GB); ++x)
+        if (grad_occ[((int64_t)n * S + y) * S + x] != 0.0f) { any = 1; break; }
+    blk[b] = any;
+  }
+}
+
+// output-pixel range [lo,hi] (after the axis flip) whose centres may lie within c +- r
+__device__ __forceinline__ bool out_range(float c, float r, int S, int& lo, int& hi) {
+  int a, b;
+  if (!pixel_range(c, r, S, a, b)) return false;
+  lo = S - 1 - b;
+  hi = S - 1 - a;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_splat_backward(
+    const float* __restrict__ pts, const float* __restrict__ radii,
+    const uint8_t* __restrict__ visible, const float* __restrict__ rs,
+    const int64_t* __restrict__ first, const int64_t* __restrict__ num,
+    const float* __restrict__ grad_occ, const uint8_t* __restrict__ blk,
+    const int32_t* __restrict__ idx, const float* __restrict__ grad_zbuf, int S, int K, int NB,
+    int rect_mode, float radii_s, float* __restrict__ grad /* (P,3) */) {
+  const int n = blockIdx.y;
+  const int64_t len = num[n], base = first[n];
+  const float r = rect_mode ? 0.f : rs[n], r2 = r * r;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = base + i;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
+    const float rx = radii[p * 2], ry = radii[p * 2 + 1];
+    // ---- z: sum grad_zbuf over the fragment slots that list this point (pixel order)
+    if (grad_zbuf) {
+      int x0, x1, y0, y1;
+      if (pz >= 0.f && out_range(px, rx, S, x0, x1) && out_range(py, ry, S, y0, y1)) {
+        for (int yo = y0; yo <= y1; ++yo)
+          for (int xo = x0; xo <= x1; ++xo) {
+            const int64_t pix = ((int64_t)n * S + yo) * S + xo;
+            for (int k = 0; k < K; ++k) {
+              const float g = grad_zbuf[pix * K + k];
+              if (g == 0.0f) continue;
+              const int q = idx[pix * K + k];
+              if (q < 0) break;
+              if (q == (int)p) gz += g;
+            }
+          }
+      }
+    }
+    // ---- xy: occupancy gradient over the disc of radius r (visible points only)
+    const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
+    if ((!visible || visible[p]) && !(pz < 0.f || fabsf(py) > 1.0f || fabsf(px) > 1.0f) &&
+        sx > 0.f && sy > 0.f) {
+      int x0, x1, y0, y1;
+      if (out_range(px, sx, S, x0, x1) && out_range(py, sy, S, y0, y1)) {
+        for (int yo = y0; yo <= y1; ++yo) {
+          const float yf = pix_to_ndc(S - 1 - yo, S);
+          const float dy = yf - py;
+          for (int xo = x0; xo <= x1; ++xo) {
+            if ((xo & (GB - 1)) == 0 || xo == x0) {
+              // skip 8-pixel runs without any gradient
+              if (!blk[((int64_t)n * NB + yo / GB) * NB + xo / GB]) {
+                xo = (xo / GB) * GB + GB - 1;
+                continue;
+              }
+            }
+            const float g = grad_occ[((int64_t)n * S + yo) * S + xo];
+            if (g == 0.0f) continue;
+            const float xf = pix_to_ndc(S - 1 - xo, S);
+            const float dx = xf - px;
+            const float dist2 = dx * dx + dy * dy;
+            bool outside;
+            if (rect_mode) {  // rasterize_points.cu:726-746 (slow CUDA kernel)
+              if (fabsf(dx) > sx || fabsf(dy) > sy) continue;
+              outside = (fabsf(dx) > sx / radii_s) || (fabsf(dy) > sy / radii_s);
+            } else {          // rasterize_points_backward.cu:156-161 (fast kernel)
+              if (dist2 > r2) continue;
+              outside = (fabsf(dx) > rx) || (fabsf(dy) > ry);
+            }
+            if (g > 0.0f && outside) continue;
+            const float denom = iso_eps_denom(dist2, 1e-10f);
+            gx += dx / denom * g;
+            gy += dy / denom * g;
+          }
+        }
+      }
+    }
+    grad[p * 3] = gx; grad[p * 3 + 1] = gy; grad[p * 3 + 2] = gz;
+  }
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" int iso_splat_view_flags(const float* points, const float* normals,
+                                    const float* views, int32_t* flags, int64_t P, int n_views,
+                                    float znear, float zfar, int backface_culling, void* stream) {
+  ISO_REQUIRE(P >= 0 && n_views >= 0, ISO_ERR_INVALID, "iso_splat_view_flags: bad sizes");
+  if (P == 0 || n_views == 0) return ISO_OK;
+  ISO_REQUIRE(points && views && flags && (normals || !backface_culling), ISO_ERR_INVALID,
+              "iso_splat_view_flags: null pointer");
+  int gx = iso_div_up(P, 256); if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(k_view_flags, dim3(gx, n_views), dim3(256), 0, (hipStream_t)stream, points,
+                     normals, views, flags, P, znear, zfar, backface_culling);
+  ISO_CHECK_LAUNCH("iso_splat_view_flags");
+  return ISO_OK;
+}
+
+extern "C" int iso_compact_rows(const float* in, const int32_t* flags, const int32_t* offsets,
+                                float* out, int64_t P, int64_t total, int U, void* stream) {
+  ISO_REQUIRE(P >= 0 && total >= 0 && U >= 0, ISO_ERR_INVALID, "iso_compact_rows: bad sizes");
+  if (total == 0 || U == 0) return ISO_OK;
+  ISO_REQUIRE(in && flags && offsets && out && P > 0, ISO_ERR_INVALID, "iso_compact_rows: null pointer");
+  hipLaunchKernelGGL(k_compact_rows, dim3(iso_stream_grid(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, flags, offsets, out, P, total, U);
+  ISO_CHECK_LAUNCH("iso_compact_rows");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_vrk_h(const float* dists, const int64_t* first_idx, const int64_t* num_pts,
+                               float* h, int n_clouds, int64_t p_stride, void* stream) {
+  ISO_REQUIRE(n_clouds >= 0 && p_stride >= 0, ISO_ERR_INVALID, "iso_splat_vrk_h: bad sizes");
+  if (n_clouds == 0 || p_stride == 0) return ISO_OK;
+  ISO_REQUIRE(dists && first_idx && num_pts && h, ISO_ERR_INVALID, "iso_splat_vrk_h: null pointer");
+  int gx = iso_div_up(p_stride, 256); if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(k_vrk_h, dim3(gx, n_clouds), dim3(256), 0, (hipStream_t)stream, dists,
+                     first_idx, num_pts, h, p_stride);
+  ISO_CHECK_LAUNCH("iso_splat_vrk_h");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_setup(const float* points, const float* normals, const float* h,
+                               const int64_t* first_idx, const int64_t* num_pts,
+                               const float* views, const float* projs, int n_views,
+                               int64_t max_pts, int image_size, float sigma, float cutoff,
+                               float* ndc_out, float* ellipse_out, float* cutoff_out,
+                               float* radii_out, float* scaler_out, void* stream) {
+  ISO_REQUIRE(n_views >= 0 && max_pts >= 0 && image_size > 0, ISO_ERR_INVALID, "iso_splat_setup: bad sizes");
+  if (n_views == 0 || max_pts == 0) return ISO_OK;
+  ISO_REQUIRE(points && normals && h && first_idx && num_pts && views && projs && ndc_out &&
+                  ellipse_out && cutoff_out && radii_out && scaler_out,
+              ISO_ERR_INVALID, "iso_splat_setup: null pointer");
+  SetupOut o{ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out};
+  int gx = iso_div_up(max_pts, 256); if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(k_splat_setup, dim3(gx, n_views), dim3(256), 0, (hipStream_t)stream, points,
+                     normals, h, first_idx, num_pts, views, projs, image_size, sigma, cutoff, o);
+  ISO_CHECK_LAUNCH("iso_splat_setup");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_tiles_per_side(int image_size) { return (image_size + TILE - 1) / TILE; }
+
+extern "C" int iso_splat_bin_count(const float* points, const float* radii,
+                                   const int64_t* first_idx, const int64_t* num_pts, int n_clouds,
+                                   int64_t max_pts, int image_size, int32_t* tile_cnt,
+                                   void* stream) {
+  ISO_REQUIRE(n_clouds >= 0 && max_pts >= 0 && image_size > 0, ISO_ERR_INVALID, "iso_splat_bin_count: bad sizes");
+  if (n_clouds == 0 || max_pts == 0) return ISO_OK;
+  ISO_REQUIRE(points && radii && first_idx && num_pts && tile_cnt, ISO_ERR_INVALID,
+              "iso_splat_bin_count: null pointer");
+  const int T = iso_splat_tiles_per_side(image_size);
+  int gx = iso_div_up(max_pts, 256); if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(k_bin<false>, dim3(gx, n_clouds), dim3(256), 0, (hipStream_t)stream, points,
+                     radii, first_idx, num_pts, image_size, T, tile_cnt, nullptr, nullptr, 0, nullptr);
+  ISO_CHECK_LAUNCH("iso_splat_bin_count");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_forward(const float* points, const float* ellipse, const float* cutoff,
+                                 const float* radii, const int64_t* first_idx,
+                                 const int64_t* num_pts, int n_clouds, int64_t max_pts,
+                                 float depth_merging_thres, int image_size, int points_per_pixel,
+                                 int32_t* tile_cursor, const int32_t* tile_off, int32_t* pairs,
+                                 int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
+                                 float* zbuf_out, float* qvalue_out, float* occ_out, void* stream) {
+  ISO_REQUIRE(points_per_pixel >= 1 && points_per_pixel <= 32, ISO_ERR_UNSUPPORTED,
+              "iso_splat_forward: points_per_pixel must be in [1,32], got %d", points_per_pixel);
+  ISO_REQUIRE(n_clouds >= 0 && max_pts >= 0 && image_size > 0, ISO_ERR_INVALID, "iso_splat_forward: bad sizes");
+  if (n_clouds == 0) return ISO_OK;
+  ISO_REQUIRE(first_idx && num_pts && tile_cursor && tile_off && overflow_flag && idx_out &&
+                  zbuf_out && qvalue_out && occ_out && (pairs || pair_capacity == 0),
+              ISO_ERR_INVALID, "iso_splat_forward: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int T = iso_splat_tiles_per_side(image_size);
+  if (max_pts > 0) {
+    ISO_REQUIRE(points && ellipse && cutoff && radii, ISO_ERR_INVALID, "iso_splat_forward: null pointer");
+    int gx = iso_div_up(max_pts, 256); if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_bin<true>, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, first_idx,
+                       num_pts, image_size, T, tile_cursor, tile_off, pairs, pair_capacity,
+                       overflow_flag);
+  }
+  const int tiles = n_clouds * T * T;
+  const int K = points_per_pixel;
+#define ISO_LAUNCH_R(KM)                                                                        \
+  hipLaunchKernelGGL(k_raster<KM>, dim3(tiles), dim3(256), 0, s, points, ellipse, cutoff, radii, \
+                     tile_cursor, tile_off, pairs, pair_capacity, image_size, T, K,              \
+                     depth_merging_thres,                                                        \
+                     idx_out, zbuf_out, qvalue_out, occ_out)
+  if (K <= 4) ISO_LAUNCH_R(4);
+  else if (K <= 8) ISO_LAUNCH_R(8);
+  else if (K <= 16) ISO_LAUNCH_R(16);
+  else ISO_LAUNCH_R(32);
+#undef ISO_LAUNCH_R
+  ISO_CHECK_LAUNCH("iso_splat_forward");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_composite(const int32_t* idx, const float* qvalue, const float* occ,
+                                   const float* scaler, const float* features, int64_t n_pixels,
+                                   int points_per_pixel, int channels, int norm_weighted, float eps,
+                                   float* frag_scaler_out, float* image_out, void* stream) {
+  ISO_REQUIRE(channels >= 0 && channels <= 8, ISO_ERR_UNSUPPORTED, "iso_splat_composite: channels must be <= 8");
+  ISO_REQUIRE(n_pixels >= 0 && points_per_pixel >= 1, ISO_ERR_INVALID, "iso_splat_composite: bad sizes");
+  if (n_pixels == 0) return ISO_OK;
+  ISO_REQUIRE(idx && qvalue && occ && scaler && image_out && (features || channels == 0),
+              ISO_ERR_INVALID, "iso_splat_composite: null pointer");
+  hipLaunchKernelGGL(k_composite, dim3(iso_stream_grid(n_pixels, 256)), dim3(256), 0,
+                     (hipStream_t)stream, idx, qvalue, occ, scaler, features, points_per_pixel,
+                     channels, norm_weighted, eps, n_pixels, frag_scaler_out, image_out);
+  ISO_CHECK_LAUNCH("iso_splat_composite");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_mark_visible(const int32_t* idx, int64_t n_pixels, int points_per_pixel,
+                                      uint8_t* visible, void* stream) {
+  ISO_REQUIRE(n_pixels >= 0 && points_per_pixel >= 1, ISO_ERR_INVALID, "iso_splat_mark_visible: bad sizes");
+  if (n_pixels == 0) return ISO_OK;
+  ISO_REQUIRE(idx && visible, ISO_ERR_INVALID, "iso_splat_mark_visible: null pointer");
+  hipLaunchKernelGGL(k_mark_visible, dim3(iso_stream_grid(n_pixels, 256)), dim3(256), 0,
+                     (hipStream_t)stream, idx, points_per_pixel, n_pixels, visible);
+  ISO_CHECK_LAUNCH("iso_splat_mark_visible");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbuf,
+                                       int64_t n_pixels, int points_per_pixel, float* z_grad,
+                                       void* stream) {
+  ISO_REQUIRE(n_pixels >= 0 && points_per_pixel >= 1, ISO_ERR_INVALID, "iso_splat_zbuf_backward: bad sizes");
+  if (n_pixels == 0) return ISO_OK;
+  ISO_REQUIRE(idx && grad_zbuf && z_grad, ISO_ERR_INVALID, "iso_splat_zbuf_backward: null pointer");
+  hipLaunchKernelGGL(k_zbuf_scatter, dim3(iso_stream_grid(n_pixels, 256)), dim3(256), 0,
+                     (hipStream_t)stream, idx, grad_zbuf, points_per_pixel, n_pixels, z_grad);
+  ISO_CHECK_LAUNCH("iso_splat_zbuf_backward");
+  return ISO_OK;
+}
+
+extern "C" int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size) {
+  int64_t nb = (image_size + GB - 1) / GB;
+  return (int64_t)n_clouds * nb * nb;
+}
+
+extern "C" int iso_splat_backward(const float* points, const float* radii, const uint8_t* visible,
+                                  const float* search_radius, const int64_t* first_idx,
+                                  const int64_t* num_pts, int n_clouds, int64_t max_pts,
+                                  const float* grad_occ, const int32_t* idx,
+                                  const float* grad_zbuf, int image_size, int points_per_pixel,
+                                  int rect_mode, float radii_s, void* workspace,
+                                  int64_t workspace_bytes, float* grad_points, void* stream) {
+  ISO_REQUIRE(n_clouds >= 0 && max_pts >= 0 && image_size > 0, ISO_ERR_INVALID, "iso_splat_backward: bad sizes");
+  if (n_clouds == 0 || max_pts == 0) return ISO_OK;
+  ISO_REQUIRE(points && radii && (search_radius || rect_mode) && first_idx && num_pts && grad_occ &&
+                  grad_points && workspace && (!grad_zbuf || idx),
+              ISO_ERR_INVALID, "iso_splat_backward: null pointer");
+  ISO_REQUIRE(workspace_bytes >= iso_splat_backward_workspace_bytes(n_clouds, image_size),
+              ISO_ERR_WORKSPACE, "iso_splat_backward: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int NB = (image_size + GB - 1) / GB;
+  uint8_t* blk = (uint8_t*)workspace;
+  hipLaunchKernelGGL(k_grad_blocks, dim3(iso_stream_grid((int64_t)n_clouds * NB * NB, 256)), dim3(256),
+                     0, s, grad_occ, image_size, NB, n_clouds, blk);
+  int gx = iso_div_up(max_pts, 256); if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(k_splat_backward, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, visible,
+                     search_radius, first_idx, num_pts, grad_occ, blk, idx, grad_zbuf, image_size,
+                     points_per_pixel, NB, rect_mode, radii_s, grad_points);
+  ISO_CHECK_LAUNCH("iso_splat_backward");
+  return ISO_OK;
+}

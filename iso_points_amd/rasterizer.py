@@ -1,0 +1,433 @@
+"""Host-side mirror of the reference's splat rasteriser (DSS/core/rasterizer.py,
+DSS/core/renderer.py and the pybind module DSS._C, DSS/csrc/ext.cpp:5-18).
+
+  _C.splat_points / _splat_points_naive / _splat_points_occ_backward /
+  _splat_points_occ_fast_cuda_backward / _backward_zbuf        ext.cpp:8-17
+  rasterize_elliptical_points                                  rasterizer.py:678-740
+  EllipticalRasterizer (autograd.Function)                     rasterizer.py:743-973
+  PointsRasterizationSettings                                  rasterizer.py:39-100
+  SurfaceSplatting.forward (filter -> per-point info -> NDC -> raster)  rasterizer.py:584-661
+  SurfaceSplattingRenderer.forward (weights + compositing)     renderer.py:36-82
+
+pytorch3d containers (Pointclouds, cameras) are out of scope: clouds are handed over as
+`PackedClouds` (packed points + first_idx + num_points) and cameras as two (N,4,4) matrices
+in pytorch3d's row-vector convention (world->view and full world->NDC).
+All arithmetic runs in libisopoints_hip.so (include/isopoints.h section D).
+"""
+from typing import NamedTuple, Optional
+
+import torch
+import torch.autograd as autograd
+
+from . import _lib
+from . import frnn
+from .levelset_sampling import host_lengths, with_host_lengths
+
+kMaxPointsPerPixel = 32      # registers-resident K-best list (the reference allows 150)
+
+
+class PointFragments(NamedTuple):
+    idx: torch.Tensor
+    zbuf: torch.Tensor
+    qvalue: torch.Tensor
+    scaler: torch.Tensor
+    occupancy: torch.Tensor
+
+
+class PointsRasterizationSettings:
+    """rasterizer.py:39-100 (same slots and defaults)."""
+    __slots__ = ["cutoff_threshold", "backface_culling", "depth_merging_threshold", "Vrk_invariant",
+                 "Vrk_isotropic", "radii_backward_scaler", "image_size", "points_per_pixel", "bin_size",
+                 "max_points_per_bin", "clip_pts_grad", "antialiasing_sigma"]
+
+    def __init__(self, backface_culling=True, cutoff_threshold=1, depth_merging_threshold=0.05,
+                 Vrk_invariant=False, Vrk_isotropic=True, radii_backward_scaler=10, image_size=256,
+                 points_per_pixel=8, bin_size=0, max_points_per_bin=None, clip_pts_grad=-1,
+                 antialiasing_sigma=1.0):
+        self.cutoff_threshold = cutoff_threshold
+        self.backface_culling = backface_culling
+        self.depth_merging_threshold = depth_merging_threshold
+        self.Vrk_invariant = Vrk_invariant
+        self.Vrk_isotropic = Vrk_isotropic
+        self.radii_backward_scaler = radii_backward_scaler
+        self.image_size = image_size
+        self.points_per_pixel = points_per_pixel
+        self.bin_size = bin_size
+        self.max_points_per_bin = max_points_per_bin
+        self.clip_pts_grad = clip_pts_grad
+        self.antialiasing_sigma = antialiasing_sigma
+
+
+class PackedClouds(object):
+    """The three accessors rasterize_elliptical_points uses on its Pointclouds argument
+    (rasterizer.py:700-702)."""
+
+    def __init__(self, points_packed, first_idx, num_points):
+        self._p, self._f, self._n = points_packed, first_idx, num_points
+
+    def points_packed(self):
+        return self._p
+
+    def cloud_to_packed_first_idx(self):
+        return self._f
+
+    def num_points_per_cloud(self):
+        return self._n
+
+
+# ----------------------------------------------------------------------------- _C
+def _f32c(t):
+    return t.detach().float().contiguous()
+
+
+def _i64c(t):
+    return t.detach().to(torch.int64).contiguous()
+
+
+def _max_pts(num_points):
+    h = host_lengths(num_points)
+    return max(h) if h else 0
+
+
+class _CNamespace(object):
+    """Drop-in for `from DSS import _C` (ext.cpp:5-18)."""
+
+    @staticmethod
+    def splat_points(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
+                     num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel,
+                     bin_size=0, max_points_per_bin=0):
+        """-> (idx i32 (N,S,S,K), zbuf, qvalue f32 (N,S,S,K), occupancy f32 (N,S,S)).
+        bin_size / max_points_per_bin are accepted and ignored: binning is internal (16x16 tiles,
+        exact-size pair list), so the reference's num_bins<22 / max_points_per_bin limits do not
+        exist here."""
+        if not points.is_cuda:
+            raise RuntimeError("iso_points_amd._C.splat_points: tensors must be on the GPU; there is no CPU path")
+        K, S = int(points_per_pixel), int(image_size)
+        if K > kMaxPointsPerPixel or K < 1:
+            raise RuntimeError("Must have 1 <= points_per_pixel <= %d" % kMaxPointsPerPixel)
+        if points.ndim != 2 or points.shape[1] != 3:
+            raise RuntimeError("points must have shape (P, 3)")
+        P = points.shape[0]
+        if ellipse_params.shape != (P, 3) or radii.shape != (P, 2) or cutoff_thres.shape != (P,):
+            raise RuntimeError("ellipse_params (P,3), radii (P,2), cutoff_thres (P,) expected")
+        dev = points.device
+        N = num_points_per_cloud.shape[0]
+        pts, el, cu, ra = _f32c(points), _f32c(ellipse_params), _f32c(cutoff_thres), _f32c(radii)
+        first, num = _i64c(cloud_to_packed_first_idx), _i64c(num_points_per_cloud)
+        if hasattr(num_points_per_cloud, "_iso_host"):
+            num._iso_host = num_points_per_cloud._iso_host
+        idx = torch.empty((N, S, S, K), dtype=torch.int32, device=dev)
+        zbuf = torch.empty((N, S, S, K), dtype=torch.float32, device=dev)
+        qv = torch.empty((N, S, S, K), dtype=torch.float32, device=dev)
+        occ = torch.empty((N, S, S), dtype=torch.float32, device=dev)
+        if N == 0 or S == 0:
+            return idx, zbuf, qv, occ
+        lib = _lib.load()
+        T = lib.iso_splat_tiles_per_side(S)
+        ntiles = N * T * T
+        maxp = _max_pts(num)
+        p, s = _lib.ptr, _lib.stream()
+        tile_cnt = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)
+        _lib.call("iso_splat_bin_count", p(pts), p(ra), p(first), p(num), N, maxp, S, p(tile_cnt), s)
+        tile_off = torch.empty_like(tile_cnt)
+        ws_b = lib.iso_prefix_sum_workspace_bytes(ntiles + 1, 1)
+        ws = torch.empty((ws_b,), dtype=torch.uint8, device=dev)
+        _lib.call("iso_prefix_sum", p(tile_cnt), p(tile_off), ntiles + 1, 1, ntiles + 1, p(ws), ws_b, s)
+        total = int(tile_off[ntiles].item())          # the one host read of the forward pass
+        pairs = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
+        cursor = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)   # [ntiles] = overflow flag
+        _lib.call("iso_splat_forward", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
+                  float(depth_merging_thres), S, K, p(cursor), p(tile_off), p(pairs), total,
+                  _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), s)
+        return idx, zbuf, qv, occ
+
+    @staticmethod
+    def _splat_points_naive(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
+                            num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel):
+        return _CNamespace.splat_points(points, ellipse_params, cutoff_thres, radii,
+                                        cloud_to_packed_first_idx, num_points_per_cloud,
+                                        depth_merging_thres, image_size, points_per_pixel, 0, 0)
+
+    @staticmethod
+    def _backward(points, radii, grad_occ, first, num, visible=None, rs=None, rect_mode=0, radii_s=10.0,
+                  idx=None, grad_zbuf=None):
+        dev = points.device
+        P = points.shape[0]
+        N, S = grad_occ.shape[0], grad_occ.shape[1]
+        if grad_occ.shape[1] != grad_occ.shape[2]:
+            raise RuntimeError("splat backward only supports square images")
+        grad = torch.zeros((P, 3), dtype=torch.float32, device=dev)
+        if P == 0 or N == 0:
+            return grad
+        pts, ra, go = _f32c(points), _f32c(radii), _f32c(grad_occ)
+        first, num_c = _i64c(first), _i64c(num)
+        if hasattr(num, "_iso_host"):
+            num_c._iso_host = num._iso_host
+        lib = _lib.load()
+        ws_b = lib.iso_splat_backward_workspace_bytes(N, S)
+        ws = torch.empty((max(ws_b, 1),), dtype=torch.uint8, device=dev)
+        K = idx.shape[-1] if idx is not None else 1
+        p = _lib.ptr
+        _lib.call("iso_splat_backward", p(pts), p(ra), p(visible) if visible is not None else None,
+                  p(_f32c(rs)) if rs is not None else None, p(first), p(num_c), N, _max_pts(num_c), p(go),
+                  p(idx.contiguous()) if idx is not None else None,
+                  p(_f32c(grad_zbuf)) if grad_zbuf is not None else None, S, K, int(rect_mode),
+                  float(radii_s), p(ws), ws.numel(), p(grad), _lib.stream())
+        return grad
+
+    @staticmethod
+    def _splat_points_occ_backward(points, radii, grad_occ, cloud_to_packed_first_idx,
+                                   num_points_per_cloud, radii_s, depth_merging_thres):
+        """Slow rect-support occupancy backward (rasterize_points.cu:673-760) -> (P,2)."""
+        g = _CNamespace._backward(points, radii, grad_occ, cloud_to_packed_first_idx, num_points_per_cloud,
+                                  rect_mode=1, radii_s=radii_s)
+        return g[:, :2].contiguous()
+
+    @staticmethod
+    def _splat_points_occ_fast_cuda_backward(points_sorted, radii_sorted, rs, grad_occ,
+                                             num_points_per_cloud, cloud_to_packed_first_idx,
+                                             points_grid_off=None, grid_params=None):
+        """Disc-support occupancy backward (rasterize_points_backward.cu:30-212) -> (P,2).
+        The 2-D grid arguments are accepted for signature compatibility and ignored: the kernel is
+        point-major (each point walks its own pixel window), so no point grid is needed; the
+        gradient of row i belongs to row i whatever order the caller sorted the points in."""
+        g = _CNamespace._backward(points_sorted, radii_sorted, grad_occ, cloud_to_packed_first_idx,
+                                  num_points_per_cloud, rs=rs)
+        return g[:, :2].contiguous()
+
+    @staticmethod
+    def _backward_zbuf(idx, grad_zbuf, point_z_grad):
+        """In-place: point_z_grad (P,1) += scatter of grad_zbuf (rasterize_points.cu:823-846)."""
+        if idx.shape != grad_zbuf.shape or point_z_grad.ndim != 2 or point_z_grad.shape[1] != 1:
+            raise RuntimeError("_backward_zbuf: idx/grad_zbuf (N,H,W,K) and point_z_grad (P,1) expected")
+        if not point_z_grad.is_contiguous():
+            raise RuntimeError("_backward_zbuf: point_z_grad must be contiguous")
+        npix = idx.numel() // max(idx.shape[-1], 1)
+        _lib.call("iso_splat_zbuf_backward", _lib.ptr(idx.contiguous()), _lib.ptr(_f32c(grad_zbuf)), npix,
+                  idx.shape[-1], _lib.ptr(point_z_grad), _lib.stream())
+
+    @staticmethod
+    def _rasterize_coarse(*a, **k):
+        raise NotImplementedError("the reference's two-stage bin table (N,B,B,M) is replaced by the "
+                                  "internal tile binning of splat_points")
+
+    _rasterize_fine = _rasterize_coarse
+
+
+_C = _CNamespace()
+
+
+# ----------------------------------------------------------------------------- autograd op
+def _visible_and_radius(idx, radii, first_idx, num_points, radii_s):
+    """rasterizer.py:850-856,884: visible set + per-cloud r = median(visible radii) * radii_s,
+    computed on the device (sort + device-side index, no host sync)."""
+    P = radii.shape[0]
+    dev = radii.device
+    vis = torch.zeros((P,), dtype=torch.uint8, device=dev)
+    npix = idx.numel() // idx.shape[-1]
+    _lib.call("iso_splat_mark_visible", _lib.ptr(idx.contiguous()), npix, idx.shape[-1], _lib.ptr(vis),
+              _lib.stream())
+    firsts = host_lengths(first_idx)
+    nums = host_lengths(num_points)
+    rs = []
+    big = torch.finfo(torch.float32).max
+    for f, n in zip(firsts, nums):
+        if n == 0:
+            rs.append(torch.zeros((), device=dev))
+            continue
+        v = vis[f:f + n].bool()
+        vals = torch.where(v[:, None], radii[f:f + n], radii.new_full((), big)).reshape(-1)
+        srt = torch.sort(vals)[0]
+        cnt = v.sum() * 2
+        k = torch.clamp((cnt - 1) // 2, min=0)                   # lower median (torch.median)
+        med = srt[k]
+        rs.append(torch.where(cnt > 0, med * radii_s, torch.zeros_like(med)))
+    return vis, torch.stack(rs).float().contiguous()
+
+
+class EllipticalRasterizer(autograd.Function):
+    """rasterizer.py:743-973.  backward returns d/d(pts_screen) only, from occ_grad (xy) and
+    zbuf_grad (z); idx/qvalue gradients are ignored exactly as in the reference (:784)."""
+
+    @staticmethod
+    def forward(ctx, pts_screen, ellipse_param, cutoff_threshold, radii, cloud_to_packed_first_idx,
+                num_points_per_cloud, depth_merging_threshold, image_size, points_per_pixel,
+                bin_size=0, max_points_per_bin=0, radii_backward_scaler=10.0):
+        idx, zbuf, qvalue_map, occ_map = _C.splat_points(
+            pts_screen, ellipse_param, cutoff_threshold, radii, cloud_to_packed_first_idx,
+            num_points_per_cloud, depth_merging_threshold, image_size, points_per_pixel, bin_size,
+            max_points_per_bin)
+        ctx.radii_backward_scaler = radii_backward_scaler
+        ctx.depth_merging_threshold = depth_merging_threshold
+        ctx.host = (host_lengths(cloud_to_packed_first_idx), host_lengths(num_points_per_cloud))
+        if radii_backward_scaler == 0:
+            raise NotImplementedError("radii_backward_scaler == 0 ('WeightBackward') does not exist in the "
+                                      "reference either: its backward unpacks 8 saved tensors where 4 were "
+                                      "saved (rasterizer.py:774-776 vs :807-809)")
+        ctx.save_for_backward(pts_screen, radii, idx, cloud_to_packed_first_idx, num_points_per_cloud)
+        ctx.mark_non_differentiable(idx)
+        return idx, zbuf, qvalue_map, occ_map
+
+    @staticmethod
+    def backward(ctx, idx_grad, zbuf_grad, qvalue_grad, occ_grad):
+        pts_screen, radii, idx, first_idx, num_points = ctx.saved_tensors
+        with_host_lengths(first_idx, ctx.host[0])
+        with_host_lengths(num_points, ctx.host[1])
+        if occ_grad is None:
+            occ_grad = torch.zeros(idx.shape[:3], dtype=torch.float32, device=idx.device)
+        vis, rs = _visible_and_radius(idx, radii, first_idx, num_points, ctx.radii_backward_scaler)
+        grads = _C._backward(pts_screen, radii, occ_grad, first_idx, num_points, visible=vis, rs=rs,
+                             idx=idx, grad_zbuf=zbuf_grad)
+        return (grads, None, None, None, None, None, None, None, None, None, None, None)
+
+
+def rasterize_elliptical_points(pcls_screen, ellipse_params, cutoff_threshold, radii,
+                                depth_merging_threshold: float = 0.05, image_size: int = 512,
+                                points_per_pixel: int = 5, bin_size: Optional[int] = None,
+                                max_points_per_bin: Optional[int] = None,
+                                radii_backward_scaler: float = 10.0, clip_pts_grad: float = -1.0):
+    """rasterizer.py:678-740."""
+    points_packed = pcls_screen.points_packed()
+    first = pcls_screen.cloud_to_packed_first_idx()
+    num = pcls_screen.num_points_per_cloud()
+    cutoff_threshold = cutoff_threshold.expand(points_packed.shape[0])
+    if points_packed.requires_grad and clip_pts_grad > 0:
+        def _clip(grad, value=clip_pts_grad):
+            scaler = grad.norm(dim=-1, keepdim=True).clamp(0, value)
+            return torch.nn.functional.normalize(grad, dim=-1) * scaler
+        points_packed.register_hook(_clip)
+    return EllipticalRasterizer.apply(points_packed, ellipse_params, cutoff_threshold, radii, first, num,
+                                      depth_merging_threshold, image_size, points_per_pixel, bin_size or 0,
+                                      max_points_per_bin or 0, radii_backward_scaler)
+
+
+# ----------------------------------------------------------------------------- SurfaceSplatting
+class SurfaceSplatting(object):
+    """SurfaceSplatting.forward (rasterizer.py:584-661) on plain tensors.
+
+    cameras = (views, projs): world->view and FULL world->NDC matrices, (N,4,4) each, row-vector
+    convention; znear/zfar as on the reference's cameras (defaults 1, 100, :191-192)."""
+
+    def __init__(self, cameras=None, raster_settings=None, frnn_radius=0.2, znear=1.0, zfar=100.0):
+        self.cameras = cameras
+        self.raster_settings = raster_settings or PointsRasterizationSettings()
+        self.frnn_radius = frnn_radius
+        self.znear, self.zfar = znear, zfar
+        self._Vrk_h = None
+
+    def filter_renderable(self, points, normals, views):
+        """-> flags (N,P) int32, offsets (N*P) int32 exclusive scan, lens (host list)."""
+        P, N = points.shape[0], views.shape[0]
+        dev = points.device
+        rs = self.raster_settings
+        flags = torch.empty((N * P + 1,), dtype=torch.int32, device=dev)
+        flags[N * P] = 0
+        p = _lib.ptr
+        _lib.call("iso_splat_view_flags", p(points), p(normals), p(views), p(flags), P, N,
+                  float(self.znear), float(self.zfar), int(bool(rs.backface_culling)), _lib.stream())
+        off = torch.empty_like(flags)
+        lib = _lib.load()
+        ws_b = lib.iso_prefix_sum_workspace_bytes(N * P + 1, 1)
+        ws = torch.empty((ws_b,), dtype=torch.uint8, device=dev)
+        _lib.call("iso_prefix_sum", p(flags), p(off), N * P + 1, 1, N * P + 1, p(ws), ws_b, _lib.stream())
+        bounds = off[torch.arange(0, N + 1, device=dev) * P].tolist()      # host read (N+1 ints)
+        lens = [bounds[i + 1] - bounds[i] for i in range(N)]
+        return flags, off, lens
+
+    def compact(self, x, flags, off, P, total_out):
+        U = x.shape[1]
+        out = torch.empty((total_out, U), dtype=torch.float32, device=x.device)
+        _lib.call("iso_compact_rows", _lib.ptr(_f32c(x)), _lib.ptr(flags), _lib.ptr(off), _lib.ptr(out), P,
+                  flags.numel() - 1, U, _lib.stream())
+        return out
+
+    def per_point_info(self, points_f, normals_f, first, num, views, projs):
+        """_get_per_point_info + transform for already filtered packed clouds."""
+        rs = self.raster_settings
+        if rs.Vrk_invariant or not rs.Vrk_isotropic:
+            raise NotImplementedError("only the default isotropic Vrk is built (SURVEY 2.1 #3)")
+        dev = points_f.device
+        lens = host_lengths(num)
+        N, mx, tot = len(lens), (max(lens) if lens else 0), points_f.shape[0]
+        p = _lib.ptr
+        s = _lib.stream()
+        # h: K=7 self query per filtered view cloud (rasterizer.py:367-386)
+        padded = torch.zeros((N, max(mx, 1), 3), dtype=torch.float32, device=dev)
+        firsts = host_lengths(first)
+        for i in range(N):
+            padded[i, :lens[i]] = points_f[firsts[i]:firsts[i] + lens[i]]
+        dists, _, _, _ = frnn.frnn_grid_points(padded, padded, num, num, K=7, r=self.frnn_radius)
+        h = torch.empty((tot,), dtype=torch.float32, device=dev)
+        _lib.call("iso_splat_vrk_h", p(dists), p(first), p(num), p(h), N, dists.shape[1], s)
+        self._Vrk_h = h
+        ndc = torch.empty((tot, 3), dtype=torch.float32, device=dev)
+        ellipse = torch.empty((tot, 3), dtype=torch.float32, device=dev)
+        cutoff = torch.empty((tot,), dtype=torch.float32, device=dev)
+        radii = torch.empty((tot, 2), dtype=torch.float32, device=dev)
+        scaler = torch.empty((tot,), dtype=torch.float32, device=dev)
+        _lib.call("iso_splat_setup", p(points_f), p(normals_f), p(h), p(first), p(num), p(_f32c(views)),
+                  p(_f32c(projs)), N, mx, int(rs.image_size), float(rs.antialiasing_sigma),
+                  float(rs.cutoff_threshold), p(ndc), p(ellipse), p(cutoff), p(radii), p(scaler), s)
+        return ndc, {"radii": radii, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "scaler": scaler}
+
+    def forward(self, points, normals, cameras=None, features=None):
+        """points/normals (P,3) one cloud seen by N cameras (the reference extends the cloud to the
+        number of cameras, :597-598).  Returns (PointFragments, filtered dict)."""
+        views, projs = cameras or self.cameras
+        rs = self.raster_settings
+        pts, nrm = _f32c(points), _f32c(normals)
+        P, N = pts.shape[0], views.shape[0]
+        dev = pts.device
+        views_c = _f32c(views)
+        flags, off, lens = self.filter_renderable(pts, nrm, views_c)
+        tot = sum(lens)
+        num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
+        fl = [sum(lens[:i]) for i in range(N)]
+        first = with_host_lengths(torch.tensor(fl, dtype=torch.int64, device=dev), fl)
+        S, K = int(rs.image_size), int(rs.points_per_pixel)
+        if tot == 0:
+            idx = torch.full((N, S, S, K), -1, dtype=torch.int32, device=dev)
+            neg = torch.full((N, S, S, K), -1.0, dtype=torch.float32, device=dev)
+            occ = torch.zeros((N, S, S), dtype=torch.float32, device=dev)
+            return PointFragments(idx, neg, neg.clone(), neg.clone(), occ), {"num_points": num, "first_idx": first}
+        pts_f = self.compact(pts, flags, off, P, tot)
+        nrm_f = self.compact(nrm, flags, off, P, tot)
+        feat_f = self.compact(features, flags, off, P, tot) if features is not None else None
+        with torch.no_grad():
+            ndc, info = self.per_point_info(pts_f, nrm_f, first, num, views_c, projs)
+        if points.requires_grad:
+            raise NotImplementedError("gradient w.r.t. world points goes through the camera transform, "
+                                      "which is the caller's (pytorch3d's) job: rasterise NDC points that "
+                                      "require grad with rasterize_elliptical_points")
+        idx, zbuf, qv, occ = rasterize_elliptical_points(
+            PackedClouds(ndc, first, num), info["ellipse_params"], info["cutoff_threshold"], info["radii"],
+            depth_merging_threshold=rs.depth_merging_threshold, image_size=S, points_per_pixel=K,
+            bin_size=rs.bin_size, max_points_per_bin=rs.max_points_per_bin,
+            radii_backward_scaler=rs.radii_backward_scaler, clip_pts_grad=rs.clip_pts_grad)
+        frag_scaler = gather_with_neg_idx(info["scaler"], idx)
+        frags = PointFragments(idx, zbuf, qv, frag_scaler, occ)
+        vis = torch.zeros((tot,), dtype=torch.uint8, device=dev)
+        _lib.call("iso_splat_mark_visible", _lib.ptr(idx), N * S * S, K, _lib.ptr(vis), _lib.stream())
+        filtered = {"points": pts_f, "normals": nrm_f, "features": feat_f, "ndc": ndc, "num_points": num,
+                    "first_idx": first, "flags": flags[:-1].view(N, P), "visibility": vis.bool(), **info}
+        return frags, filtered
+
+
+def gather_with_neg_idx(values, idx):
+    """utils/__init__.py:172-185: values[idx], 0 where idx < 0."""
+    g = values[idx.long().clamp(min=0)]
+    return torch.where(idx >= 0, g, torch.zeros_like(g))
+
+
+def composite(fragments, scaler, features, norm_weighted=True, eps=1e-4):
+    """SurfaceSplattingRenderer.forward (renderer.py:53-78): per-pixel weights exp(-q/2)*scaler,
+    (norm-)weighted sum of per-point features, occupancy appended as alpha -> (N,S,S,C+1).
+    `scaler` is the per-point EWA normaliser (P,), features (P,C) packed."""
+    idx, qv, occ = fragments.idx, fragments.qvalue, fragments.occupancy
+    N, S, _, K = idx.shape
+    C = features.shape[1]
+    out = torch.empty((N, S, S, C + 1), dtype=torch.float32, device=idx.device)
+    _lib.call("iso_splat_composite", _lib.ptr(idx.contiguous()), _lib.ptr(_f32c(qv)), _lib.ptr(_f32c(occ)),
+              _lib.ptr(_f32c(scaler)), _lib.ptr(_f32c(features)), N * S * S, K, C, int(bool(norm_weighted)),
+              float(eps), None, _lib.ptr(out), _lib.stream())
+    return out

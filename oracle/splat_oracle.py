@@ -191,9 +191,12 @@ def tangent_frame(normals):
     return torch.stack([u0, u1], dim=1)
 
 
-def per_point_info(points, normals, h, M44, image_size, cutoff=1.0, sigma=1.0, Sk=None):
+def per_point_info(points, normals, h, M44, image_size, cutoff=1.0, sigma=1.0, Sk=None, dtype=None):
     """SurfaceSplatting._get_per_point_info for ONE view (rasterizer.py:441-563).
-    points/normals (P,3) already filtered, h (P,), M44 full world->NDC projection (4,4)."""
+    points/normals (P,3) already filtered, h (P,), M44 full world->NDC projection (4,4).
+    dtype=torch.float64 evaluates the same formulas in double (ground truth for tests)."""
+    if dtype is not None:
+        points, normals, h, M44 = points.to(dtype), normals.to(dtype), h.to(dtype), M44.to(dtype)
     P = points.shape[0]
     ph = torch.cat([points, torch.ones_like(points[:, :1])], dim=-1)          # to_homogen
     W = M44[:3, :].expand(P, 3, 4)
@@ -213,7 +216,7 @@ def per_point_info(points, normals, h, M44, image_size, cutoff=1.0, sigma=1.0, S
     Mk = Sk @ WJk
     Vk = WJk.transpose(1, 2) @ Vrk @ WJk
     pixel_size = 2.0 / image_size
-    GV = Vk + sigma * torch.eye(2).expand(P, 2, 2) * (pixel_size ** 2)
+    GV = Vk + sigma * torch.eye(2, dtype=points.dtype).expand(P, 2, 2) * (pixel_size ** 2)
     detMk = torch.det(Mk)
     GVdet = torch.det(GV)
     GVinv = torch.inverse(GV)

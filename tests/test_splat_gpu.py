@@ -1,0 +1,275 @@
+"""HIP EWA splatting vs the oracle (oracle_splat.c pinned to the compiled reference;
+splat_oracle.py pinned to the reference's Python through tests/golden).
+Bar: per-pixel index lists, depths and q-values bit-exact given identical inputs;
+per-point set-up and gradients within 1e-5 relative."""
+import pytest
+import torch
+
+from splat_util import random_splats, sphere_scene
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _SO():
+    from oracle import splat_oracle as SO
+    return SO
+
+
+def _fwd_gpu(dev, sc, S, K, thres=0.05):
+    from iso_points_amd.rasterizer import _C
+    return _C.splat_points(sc["ndc"].to(dev), sc["ellipse"].to(dev), sc["cutoff"].to(dev), sc["radii"].to(dev),
+                           sc["first"].to(dev), sc["num"].to(dev), thres, S, K, 0, 0)
+
+
+def _assert_fwd_equal(got, ref):
+    names = ("idx", "zbuf", "qvalue", "occupancy")
+    for g, r, nm in zip(got, ref, names):
+        assert g.shape == r.shape and g.dtype == r.dtype, nm
+        assert torch.equal(g.cpu(), r), "%s differs (%d entries)" % (nm, (g.cpu() != r).sum().item())
+
+
+@pytest.mark.parametrize("S,K", [(64, 8), (48, 5), (50, 1), (33, 16), (16, 3)])
+def test_forward_scene_bit_exact(dev, S, K):
+    SO = _SO()
+    sc = sphere_scene(4000, n_views=2, S=S, seed=S + K)
+    ref = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"], sc["num"],
+                           0.05, S, K, bbox_or=True)
+    _assert_fwd_equal(_fwd_gpu(dev, sc, S, K), ref)
+    assert ref[3].sum() > 50
+
+
+@pytest.mark.parametrize("K,pad", [(8, 1.0), (4, 0.7), (32, 1.3)])
+def test_forward_random_splats_bit_exact(dev, K, pad):
+    """Unstructured input: points behind the camera, off screen, z ties, radii smaller/larger than
+    the true ellipse bbox (the `||` reject rule matters when pad < 1)."""
+    SO = _SO()
+    sc = random_splats(1500, N=3, seed=K, pad=pad)
+    ref = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"], sc["num"],
+                           0.08, 40, K, bbox_or=True)
+    _assert_fwd_equal(_fwd_gpu(dev, sc, 40, K, 0.08), ref)
+
+
+def test_forward_against_compiled_reference(dev):
+    """Directly against the reference's own CPU rasteriser (oracle/_ref) where it is available:
+    true-bbox radii so the CPU `&&` and CUDA `||` reject rules coincide."""
+    SO = _SO()
+    if not SO.ref_available():
+        pytest.skip("oracle/_ref not built")
+    sc = sphere_scene(3000, n_views=2, S=48, seed=1)
+    ref = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"], sc["num"],
+                           0.05, 48, 8, use_ref=True)
+    _assert_fwd_equal(_fwd_gpu(dev, sc, 48, 8), ref)
+
+
+def test_forward_edge_cases(dev):
+    from iso_points_amd.rasterizer import _C
+    z = lambda *s: torch.zeros(*s, device=dev)
+    # empty clouds
+    idx, zb, qv, occ = _C.splat_points(z(0, 3), z(0, 3), z(0), z(0, 2), torch.zeros(2, dtype=torch.long, device=dev),
+                                       torch.zeros(2, dtype=torch.long, device=dev), 0.05, 32, 4, 0, 0)
+    assert idx.shape == (2, 32, 32, 4) and (idx == -1).all() and (occ == 0).all() and (zb == -1).all()
+    # one huge splat covering every tile
+    pts = torch.tensor([[0.0, 0.0, 2.0]], device=dev)
+    ell = torch.tensor([[1e-3, 0.0, 1e-3]], device=dev)
+    idx, zb, qv, occ = _C.splat_points(pts, ell, torch.ones(1, device=dev), torch.full((1, 2), 5.0, device=dev),
+                                       torch.zeros(1, dtype=torch.long, device=dev),
+                                       torch.ones(1, dtype=torch.long, device=dev), 0.05, 70, 2, 0, 0)
+    assert (occ == 1).all() and (idx[..., 0] == 0).all() and (idx[..., 1] == -1).all()
+    with pytest.raises(RuntimeError):
+        _C.splat_points(pts, ell, torch.ones(1, device=dev), torch.ones(1, 2, device=dev),
+                        torch.zeros(1, dtype=torch.long, device=dev), torch.ones(1, dtype=torch.long, device=dev),
+                        0.05, 32, 200, 0, 0)
+
+
+def test_setup_matches_oracle(dev):
+    SO = _SO()
+    from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    from iso_points_amd.levelset_sampling import with_host_lengths
+    S = 64
+    sc = sphere_scene(5000, n_views=3, S=S, seed=33)
+    ss = SurfaceSplatting(raster_settings=PointsRasterizationSettings(image_size=S))
+    num = with_host_lengths(sc["num"].to(dev), sc["num"].tolist())
+    first = with_host_lengths(sc["first"].to(dev), sc["first"].tolist())
+    projs = torch.stack([v @ sc["proj"] for v in sc["views"]])
+    ndc, info = ss.per_point_info(sc["points"].to(dev), sc["normals"].to(dev), first, num,
+                                  sc["views"].to(dev), projs.to(dev))
+    assert torch.equal(ss._Vrk_h.cpu(), sc["h"])          # FRNN distances are bit-exact
+    assert rel_err(ndc, sc["ndc"]) < 1e-6
+    # float64 evaluation of the reference formulas = ground truth.  The float32 reference
+    # arithmetic (det(G) = g00*g11 - g01^2) loses ~cond(G) digits on grazing splats; the kernel
+    # uses the cancellation-free expansion, so it must sit at least as close to the truth as the
+    # float32 oracle does, and agree with the oracle wherever the oracle itself is accurate.
+    s0 = 0
+    truth = {"radii": [], "ellipse_params": [], "scaler": []}
+    for i, n in enumerate(sc["num"].tolist()):
+        t = SO.per_point_info(sc["points"][s0:s0 + n], sc["normals"][s0:s0 + n], sc["h"][s0:s0 + n],
+                              sc["views"][i] @ sc["proj"], S, dtype=torch.float64)
+        for k in truth:
+            truth[k].append(t[k])
+        s0 += n
+    for k, ref in (("radii", sc["radii"]), ("ellipse_params", sc["ellipse"]), ("scaler", sc["scaler"])):
+        tr = torch.cat(truth[k]).reshape(ref.shape[0], -1)
+        got = info[k].cpu().double().reshape(ref.shape[0], -1)
+        r = ref.double().reshape(ref.shape[0], -1)
+        sc_ = tr.abs().amax(-1, keepdim=True)
+        e_got = ((got - tr).abs() / sc_).amax(-1)
+        e_ref = ((r - tr).abs() / sc_).amax(-1)
+        e_mut = ((got - r).abs() / sc_).amax(-1)
+        print(k, "max err vs f64 truth: hip %.3g  f32 oracle %.3g ; hip vs oracle: max %.3g, frac>1e-5 %.4f"
+              % (e_got.max(), e_ref.max(), e_mut.max(), (e_mut > 1e-5).double().mean()))
+        # grazing splats make det(Sk WJk) a small difference of O(1) products: float32 noise there is
+        # inherent (the reference's own float32 result shows it too), so the bar is "no worse than
+        # ~3x the float32 reference arithmetic" at the worst point and 1e-5 agreement in bulk
+        assert e_got.max() <= 3 * e_ref.max().item() + 2e-6, (k, e_got.max().item(), e_ref.max().item())
+        assert (e_got > 1e-5).double().mean() < 0.01 and e_got.median() < 1e-6
+        assert (e_mut > 1e-5).double().mean() < 0.01 and e_mut.median() < 1e-6, (k, e_mut.max().item())
+    assert torch.equal(info["cutoff_threshold"].cpu(), sc["cutoff"])
+
+
+def test_surface_splatting_end_to_end(dev):
+    """filter -> h -> set-up -> raster through SurfaceSplatting.forward vs the oracle chain."""
+    SO = _SO()
+    from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    S, K = 64, 8
+    sc = sphere_scene(6000, n_views=2, S=S, seed=44)
+    projs = torch.stack([v @ sc["proj"] for v in sc["views"]])
+    ss = SurfaceSplatting(raster_settings=PointsRasterizationSettings(image_size=S, points_per_pixel=K))
+    frags, filt = ss.forward(sc["world_points"].to(dev), sc["world_normals"].to(dev),
+                             cameras=(sc["views"].to(dev), projs.to(dev)))
+    assert torch.equal(filt["flags"].bool().cpu(), sc["keep"])             # same renderable set
+    assert filt["num_points"].tolist() == sc["num"].tolist()
+    assert torch.equal(filt["points"].cpu(), sc["points"])                 # packed order = reference order
+    ref = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"], sc["num"],
+                           0.05, S, K)
+    same = (frags.idx.cpu() == ref[0]).float().mean().item()
+    assert same > 0.999                                                    # set-up differs by rounding only
+    assert (frags.occupancy.cpu() == ref[3]).float().mean() > 0.999
+    sc_ref = SO.gather_scaler(sc["scaler"], ref[0])
+    m = frags.idx.cpu() == ref[0]
+    assert rel_err(frags.scaler.cpu()[m], sc_ref[m]) < 1e-5
+    vis_ref = torch.zeros(sc["ndc"].shape[0], dtype=torch.bool)
+    sel = ref[0][ref[0][..., 0] >= 0].reshape(-1).long()
+    vis_ref[sel[sel >= 0]] = True
+    assert (filt["visibility"].cpu() == vis_ref).float().mean() > 0.999
+
+
+def test_composite(dev):
+    SO = _SO()
+    from iso_points_amd.rasterizer import PointFragments, composite
+    S, K = 48, 6
+    sc = sphere_scene(3000, n_views=2, S=S, seed=55)
+    idx, zb, qv, occ = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"],
+                                        sc["num"], 0.05, S, K)
+    feat = 0.5 * (sc["normals"] + 1)
+    fr = SO.PointFragments(idx, zb, qv, SO.gather_scaler(sc["scaler"], idx), occ)
+    for norm in (True, False):
+        ref = SO.composite(fr, feat, norm_weighted=norm)
+        got = composite(PointFragments(idx.to(dev), zb.to(dev), qv.to(dev), None, occ.to(dev)),
+                        sc["scaler"].to(dev), feat.to(dev), norm_weighted=norm)
+        assert got.shape == (2, S, S, 4)
+        assert rel_err(got, ref) < 1e-5
+
+
+def _grads(S, seed, sparse=True):
+    g = torch.Generator().manual_seed(seed)
+    go = torch.randn(2, S, S, generator=g)
+    if sparse:
+        go[go.abs() < 1.0] = 0.0
+    return go
+
+
+def test_backward_matches_oracle(dev):
+    """Default fast path: visible set, median radius, disc support, zbuf scatter."""
+    SO = _SO()
+    from iso_points_amd.rasterizer import EllipticalRasterizer
+    from iso_points_amd.levelset_sampling import with_host_lengths
+    S, K = 48, 5
+    sc = sphere_scene(3000, n_views=2, S=S, seed=66)
+    idx, zb, qv, occ = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"],
+                                        sc["num"], 0.05, S, K)
+    go = _grads(S, 1)
+    g = torch.Generator().manual_seed(2)
+    gz = torch.randn(zb.shape, generator=g)
+    gz[gz.abs() < 0.5] = 0
+    ref, vis_ref, rs_ref = SO.splat_backward(sc["ndc"], sc["radii"], idx, sc["first"], sc["num"], go, gz, 10.0)
+    pts = sc["ndc"].to(dev).requires_grad_(True)
+    first = with_host_lengths(sc["first"].to(dev), sc["first"].tolist())
+    num = with_host_lengths(sc["num"].to(dev), sc["num"].tolist())
+    oi, oz, oq, oo = EllipticalRasterizer.apply(pts, sc["ellipse"].to(dev), sc["cutoff"].to(dev),
+                                                sc["radii"].to(dev), first, num, 0.05, S, K, 0, 0, 10.0)
+    assert torch.equal(oi.cpu(), idx)
+    loss = (oo * go.to(dev)).sum() + (oz * gz.to(dev)).sum()
+    loss.backward()
+    got = pts.grad.cpu()
+    assert ref.abs().sum() > 0
+    scale = ref.abs().max(dim=0).values
+    err = ((got - ref).abs().max(dim=0).values / scale)
+    assert (err < 1e-5).all(), err
+    # with identical arithmetic and summation order the match is in fact exact
+    assert torch.equal(got[:, 2], ref[:, 2])
+
+
+def test_backward_low_level_api(dev):
+    """_C._splat_points_occ_fast_cuda_backward / _splat_points_occ_backward / _backward_zbuf
+    called the way EllipticalRasterizer.backward does (rasterizer.py:831-838,947,967)."""
+    SO = _SO()
+    from iso_points_amd.rasterizer import _C
+    S, K = 40, 4
+    sc = sphere_scene(2000, n_views=2, S=S, seed=77)
+    idx, zb, qv, occ = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"],
+                                        sc["num"], 0.05, S, K)
+    go = _grads(S, 3)
+    rs = torch.tensor([0.3, 0.25])
+    ref_fast = SO.occ_backward(sc["ndc"], sc["radii"], go, sc["first"], sc["num"], 10.0, rs=rs, mode=2)
+    got_fast = _C._splat_points_occ_fast_cuda_backward(sc["ndc"].to(dev), sc["radii"].to(dev), rs.to(dev),
+                                                       go.to(dev), sc["num"].to(dev), sc["first"].to(dev))
+    assert got_fast.shape == ref_fast.shape
+    assert rel_err(got_fast, ref_fast) < 1e-6
+    ref_slow = SO.occ_backward(sc["ndc"], sc["radii"], go, sc["first"], sc["num"], 6.0, mode=1)
+    got_slow = _C._splat_points_occ_backward(sc["ndc"].to(dev), sc["radii"].to(dev), go.to(dev),
+                                             sc["first"].to(dev), sc["num"].to(dev), 6.0, 0.05)
+    assert rel_err(got_slow, ref_slow) < 1e-6
+    gz = torch.randn(zb.shape, generator=torch.Generator().manual_seed(4))
+    out = torch.zeros(sc["ndc"].shape[0], 1, device=dev)
+    _C._backward_zbuf(idx.to(dev), gz.to(dev), out)
+    ref_z = SO.zbuf_backward(idx, gz, sc["ndc"].shape[0])
+    assert rel_err(out[:, 0], ref_z) < 1e-5        # atomic order differs from the sequential sum
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json configs[2] shape: ~1M points, 512x512, 4 views, K=8 -- too big for the CPU
+    oracle, so check size-independent properties of the result."""
+    from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    P, S, K, N = 1000000, 512, 8, 4
+    SO = _SO()
+    g = torch.Generator().manual_seed(0)
+    pts = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    nrm = pts.clone()
+    views = torch.stack([SO.look_at_view(5.0, 20.0, 90.0 * i) for i in range(N)]).to(dev)
+    projs = views @ SO.perspective(30.0).to(dev)
+    ss = SurfaceSplatting(raster_settings=PointsRasterizationSettings(image_size=S, points_per_pixel=K))
+    frags, filt = ss.forward(pts, nrm, cameras=(views, projs))
+    idx, zb, qv, occ = frags.idx, frags.zbuf, frags.qvalue, frags.occupancy
+    valid = idx >= 0
+    assert torch.equal(occ.bool(), valid[..., 0])                       # occupancy <=> first slot filled
+    assert (valid[..., 1:] <= valid[..., :-1]).all()                     # -1 padding is a suffix
+    z = torch.where(valid, zb, torch.full_like(zb, float("inf")))
+    assert (z[..., 1:] >= z[..., :-1]).all()                             # ascending depth
+    assert ((zb - zb[..., :1])[valid] <= 0.05).all()                     # depth-merging cut
+    assert (qv[valid] <= 1.0).all() and (qv[valid] >= 0).all()           # inside the cutoff ellipse
+    assert (zb[~valid] == -1).all() and (qv[~valid] == -1).all()
+    # every listed point belongs to the pixel's own view
+    first, num = filt["first_idx"], filt["num_points"]
+    view_of = torch.arange(N, device=dev).view(N, 1, 1, 1).expand_as(idx)[valid]
+    li = idx[valid].long()
+    assert ((li >= first[view_of]) & (li < first[view_of] + num[view_of])).all()
+    # the sphere covers a disc of the image; silhouette area within 2 % of the analytic value
+    frac = occ.mean().item()
+    import math
+    half = math.tan(math.radians(15.0))
+    r_img = (1.0 / math.sqrt(25.0 - 1.0)) / half                         # tangent cone of a unit sphere at d=5
+    assert abs(frac - math.pi * r_img ** 2 / 4) < 0.02
+    # determinism: a second run gives identical lists although the fill pass uses atomics
+    frags2, _ = ss.forward(pts, nrm, cameras=(views, projs))
+    assert torch.equal(frags2.idx, idx) and torch.equal(frags2.zbuf, zb)
