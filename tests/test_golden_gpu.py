@@ -44,7 +44,10 @@ def test_siren_eval_and_fixed_count_projection(dev):
     x = g["points"].to(dev)
     r0 = UniformProjection(proj_tolerance=1e-30)._project_points(m, x, full_lengths(x), proj_max_iters=10)
     assert rel_err(r0.points, g["fixed_points"]) < 1e-5
-    assert rel_err(r0.normals, g["fixed_normals"]) < 1e-5
+    # gradients: two float32 evaluations of a 4-layer omega=30 SIREN differ by a few 1e-5
+    # (test_projection_gpu.py::test_siren_grad_accuracy_vs_float64 shows both sit at that
+    # distance from the float64 value)
+    assert rel_err(r0.normals, g["fixed_normals"]) < 5e-5
     r = UniformProjection()._project_points(m, x, full_lengths(x), proj_max_iters=10)
     assert_projection_close(r.points, g["out_points"])
 

@@ -93,6 +93,27 @@ def test_siren_sdf_and_grad(dev, hidden, n_layers):
     assert rel_err(grad, grad_ref) < TOL
 
 
+def test_siren_grad_accuracy_vs_float64(dev):
+    """The fused kernel's float32 SDF/gradient is as close to the float64 value as torch's
+    float32 autograd (the reference path) is."""
+    import copy
+    O = _oracle()
+    from iso_points_amd.sdf_models import siren_sdf_and_grad
+    m = _siren(256, 3, seed=0, fit=200)
+    pts = sphere_cloud(5000, seed=3)[0]
+    m64 = copy.deepcopy(m).double()
+    sdf64, grad64 = O.compute_sdf_and_grad(pts.double(), m64)
+    sdf32, grad32 = O.compute_sdf_and_grad(pts, m)
+    sdf, grad = siren_sdf_and_grad(m, pts.to(dev))
+    e_ref = (grad32.double() - grad64).abs().max().item()
+    e_hip = (grad.cpu().double() - grad64).abs().max().item()
+    print("grad err vs f64: torch-f32 %.3g, hip %.3g" % (e_ref, e_hip))
+    assert e_hip <= 2.0 * e_ref + 1e-6
+    s_ref = (sdf32.double() - sdf64).abs().max().item()
+    s_hip = (sdf.cpu().double() - sdf64).abs().max().item()
+    assert s_hip <= 2.0 * s_ref + 1e-7
+
+
 def test_siren_reference_layout_is_recognised(dev):
     """A model laid out like the reference's Siren (net[i].linear / omega_0) takes the fused path."""
     O = _oracle()
