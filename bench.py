@@ -1,0 +1,310 @@
+"""bench.py -- iso-point cycle throughput on MI355X.
+
+Metric (BASELINE.json): Mpoints/s of the full iso-point cycle (project + resample + splat),
+1M points; workload = configs[2] "1M points project+resample + DSS EWA splat fwd/bwd at
+512x512x4 views", SDF = the 4-layer x 256 SIREN of configs[1] (SURVEY 8(d) cfg 3b).
+
+One step = one pass of the hot path over the same synthetic batch:
+  _project_points(T=10) -> resample(sample_iters=1) [= FRNN K+1=9, one tangent-plane repulsion,
+  _project_points(T=3)] -> filter / K=7 FRNN / per-point EWA set-up for 4 views -> splat forward
+  512^2 x 4 (K=8) -> compositing -> backward (occupancy + zbuf gradients).
+Inputs are resident in HBM before the timed region; every step restarts from the same
+initial cloud so the work per step is constant.
+
+python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run,
+one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+P_TOTAL = 1000000
+IMAGE = 512
+VIEWS = 4
+KPIX = 8
+HIDDEN, LAYERS = 256, 3
+FLOP_PER_EVAL = 2.0 * (2 * LAYERS * HIDDEN * HIDDEN + 2 * 3 * HIDDEN + 2 * HIDDEN)   # 0.79 MFLOP
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA
+PEAK_HBM_TBS = 8.0
+
+
+def sphere_cloud(P, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.nn.functional.normalize(torch.randn(1, P, 3, generator=g), dim=-1)
+    return (p + 0.05 * (torch.rand(1, P, 3, generator=g) - 0.5)).to(device)
+
+
+def fitted_siren(device, steps=300, seed=0):
+    """Siren(3->256x4->1) fitted to the unit-sphere SDF (SURVEY 8(d) cfg 2: 'weights fitted to the
+    sphere for convergence realism'); untimed set-up, deterministic."""
+    from iso_points_amd.sdf_models import Siren
+    torch.manual_seed(seed)
+    m = Siren(dim=3, hidden_size=HIDDEN, n_layers=LAYERS, c_dim=0).to(device)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for _ in range(steps):
+        x = ((torch.rand(4096, 3, generator=g) - 0.5) * 3.0).to(device)
+        y = x.norm(dim=-1, keepdim=True) - 1.0
+        loss = ((m(x).sdf - y) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m.eval()
+
+
+def cameras(device):
+    from iso_points_amd.cameras import look_at_view, perspective
+    views = torch.stack([look_at_view(3.0, 20.0, 90.0 * i) for i in range(VIEWS)]).to(device)
+    projs = views @ perspective(30.0).to(device)
+    return views, projs
+
+
+class Cycle(object):
+    """The hot path, called through the reference-shaped operators of iso_points_amd."""
+
+    def __init__(self, device, model, n_points, rank=0, world=1):
+        from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
+        from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+        self.dev, self.model = device, model
+        self.rank, self.world = rank, world
+        self.full_lengths = full_lengths
+        self.proj = UniformProjection(proj_max_iters=10, proj_tolerance=5e-5, knn_k=8, sample_iters=1)
+        self.rs = PointsRasterizationSettings(image_size=IMAGE, points_per_pixel=KPIX, cutoff_threshold=1.0,
+                                              depth_merging_threshold=0.05, radii_backward_scaler=10,
+                                              backface_culling=True, Vrk_isotropic=True, bin_size=None)
+        self.splat = SurfaceSplatting(raster_settings=self.rs)
+        self.views, self.projs = cameras(device)
+        self.pts0 = sphere_cloud(n_points, seed=rank, device=device)
+        self.num = full_lengths(self.pts0)
+        # analytic silhouette of the unit sphere for the loss (SURVEY 8(d) cfg 3)
+        S = IMAGE
+        ax = -1 + (2 * torch.arange(S, device=device) + 1.0) / S
+        rr = (1.0 / math.sqrt(9.0 - 1.0)) / math.tan(math.radians(15.0))
+        yy, xx = torch.meshgrid(ax, ax, indexing="ij")
+        self.target = ((xx ** 2 + yy ** 2) <= rr ** 2).float()[None].expand(VIEWS, S, S).contiguous()
+        self.ev = []          # (start, end) events around the SIREN projections
+        self.timed = False
+
+    def _project(self, pts, T):
+        if self.timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        r = self.proj._project_points(self.model, pts, self.num, proj_max_iters=T)
+        if self.timed:
+            b.record()
+            self.ev.append((a, b, T, self.proj._packed_cache))
+        return r
+
+    def step(self):
+        from iso_points_amd.rasterizer import _C, _visible_and_radius, composite
+        # 1. Newton projection, T=10
+        r0 = self._project(self.pts0, 10)
+        # 2. resample: FRNN (K+1=9) + tangent-plane repulsion + projection T=3
+        proj = self.proj
+        flat = r0.points.reshape(-1, 3)
+        diag = (flat.max(dim=0).values - flat.min(dim=0).values).norm()
+        inv_sigma = (self.num.float() / diag).reshape(1).contiguous()
+        proj._create_tree(r0.points, refresh_tree=True, num_points_per_cloud=self.num)
+        moved = proj.repulsion_step(r0.points, r0.normals, proj._knn_idx, inv_sigma)
+        r1 = self._project(moved, 3)
+        # 3. splat forward: filter, K=7 FRNN, per-point set-up, tile binning + raster, compositing
+        pts, nrm = r1.points[0], r1.normals[0]
+        frags, filt = self.splat.forward(pts, nrm, cameras=(self.views, self.projs),
+                                         features=0.5 * (torch.nn.functional.normalize(nrm, dim=-1) + 1))
+        img = composite(frags, filt["scaler"], filt["features"], norm_weighted=True)
+        # 4. loss gradients (SURVEY 8(d) cfg 3) and splat backward
+        alpha = img[..., 3]
+        occ_grad = 2.0 * (alpha - self.target) / alpha.numel()
+        zbuf_grad = torch.zeros_like(frags.zbuf)
+        zbuf_grad[..., 0] = 1e-3 / alpha.numel()
+        vis, rs = _visible_and_radius(frags.idx, filt["radii"], filt["first_idx"], filt["num_points"],
+                                      float(self.rs.radii_backward_scaler))
+        grad = _C._backward(filt["ndc"], filt["radii"], occ_grad, filt["first_idx"], filt["num_points"],
+                            visible=vis, rs=rs, idx=frags.idx, grad_zbuf=zbuf_grad)
+        return r1, img, grad
+
+    def siren_stats(self):
+        """(total flops, total ms, launches) of the timed SIREN projections, from HIP events on the
+        launch stream and the kernel's own device-side active-point counters."""
+        from iso_points_amd import _lib
+        lib = _lib.load()
+        n = self.pts0.shape[1]
+        flops, ms, launches = 0.0, 0.0, 0
+        for a, b, T, ps in self.ev:
+            ms += a.elapsed_time(b)
+            launches += T + 1
+        return ms, launches
+
+
+def active_counts(cycle):
+    """Re-run the two projections once, reading the kernel's active-list counters after each."""
+    from iso_points_amd import _lib
+    lib = _lib.load()
+    n = cycle.pts0.shape[1]
+    tot = 0
+    out = {}
+    proj = cycle.proj
+    r0 = proj._project_points(cycle.model, cycle.pts0, cycle.num, proj_max_iters=10)
+    torch.cuda.synchronize()
+    off = lib.iso_project_siren_workspace_bytes(n, HIDDEN, LAYERS) - 64 * 4 - 64
+    ws = proj._packed_cache._ws
+    c = ws[off:off + 64 * 4].view(torch.int32).tolist()
+    out["T10"] = [n] + c[1:11]
+    flat = r0.points.reshape(-1, 3)
+    diag = (flat.max(dim=0).values - flat.min(dim=0).values).norm()
+    inv_sigma = (cycle.num.float() / diag).reshape(1).contiguous()
+    proj._create_tree(r0.points, refresh_tree=True, num_points_per_cloud=cycle.num)
+    moved = proj.repulsion_step(r0.points, r0.normals, proj._knn_idx, inv_sigma)
+    proj._project_points(cycle.model, moved, cycle.num, proj_max_iters=3)
+    torch.cuda.synchronize()
+    ws = proj._packed_cache._ws
+    c = ws[off:off + 64 * 4].view(torch.int32).tolist()
+    out["T3"] = [n] + c[1:4]
+    return out
+
+
+def cpu_baseline(gpu_model):
+    """The oracle (CPU restatement of the reference's pure-PyTorch path + C rasteriser) timed on
+    the host cores on a bounded sample of the same workload (same fitted SIREN weights)."""
+    from oracle import iso_oracle as O
+    from oracle import splat_oracle as SO
+    ncores = torch.get_num_threads()
+    P, S, V = 50000, 256, 1
+    m = O.SirenSDF(hidden_size=HIDDEN, n_layers=LAYERS)
+    with torch.no_grad():
+        src = [l.linear for l in list(gpu_model.net)[:-1]] + [gpu_model.net[-1]]
+        for dst, s_ in zip(m.lins, src):
+            dst.weight.copy_(s_.weight.detach().cpu())
+            dst.bias.copy_(s_.bias.detach().cpu())
+    g = torch.Generator().manual_seed(0)
+    pts = torch.nn.functional.normalize(torch.randn(1, P, 3, generator=g), dim=-1)
+    pts = pts + 0.05 * (torch.rand(1, P, 3, generator=g) - 0.5)
+    num = torch.tensor([P])
+    t0 = time.perf_counter()
+    r0 = O.project_points(m, pts, num, proj_max_iters=10)
+    r1 = O.resample(m, r0.points, r0.normals, num, sample_iters=1, knn_k=8)
+    t_pr = time.perf_counter() - t0
+    p, n = r1.points[0], r1.normals[0]
+    view = SO.look_at_view(3.0, 20.0, 0.0)
+    M44 = view @ SO.perspective(30.0)
+    keep = SO.filter_renderable(p, n, view)
+    pf, nf = p[keep], n[keep]
+    h = SO.vrk_h(pf[None], torch.tensor([pf.shape[0]]), 0.2)
+    info = SO.per_point_info(pf, nf, h, M44, S)
+    ndc = SO.transform_to_ndc(pf, view, M44)
+    first, numv = torch.tensor([0]), torch.tensor([pf.shape[0]])
+    idx, zb, qv, occ = SO.splat_forward(ndc, info["ellipse_params"], info["cutoff_threshold"], info["radii"],
+                                        first, numv, 0.05, S, KPIX)
+    fr = SO.PointFragments(idx, zb, qv, SO.gather_scaler(info["scaler"], idx), occ)
+    img = SO.composite(fr, 0.5 * (torch.nn.functional.normalize(nf, dim=-1) + 1))
+    go = 2.0 * (img[..., 3] - 0.5) / img[..., 3].numel()
+    gz = torch.zeros_like(zb)
+    SO.splat_backward(ndc, info["radii"], idx, first, numv, go, gz, 10.0)
+    t_all = time.perf_counter() - t0
+    return {"value": round(P / t_all / 1e6, 6), "unit": "Mpoints/s", "cores": ncores, "kind": "port",
+            "sample": "oracle (torch-CPU restatement of the reference's PyTorch path, %d threads; C rasteriser "
+                      "single-threaded) on %d points, SIREN 4x256 fitted, project T=10 + resample + splat "
+                      "fwd/bwd at %dx%dx%d view: %.1f s total, %.1f s project+resample"
+                      % (ncores, P, S, S, V, t_all, t_pr)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus %d needs torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    model = fitted_siren(dev)
+    n_local = P_TOTAL // world
+    cyc = Cycle(dev, model, n_local, rank=rank, world=world)
+
+    for _ in range(args.warmup):
+        cyc.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    cyc.timed = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cyc.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    cyc.timed = False
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+
+    siren_ms, siren_launches = cyc.siren_stats()
+    counts = active_counts(cyc)
+    evals_per_step = sum(counts["T10"]) + sum(counts["T3"])
+    flop_per_step = evals_per_step * FLOP_PER_EVAL
+    launches_per_step = siren_launches / max(args.steps, 1)
+    ach = flop_per_step / (siren_ms / args.steps * 1e-3) / 1e12 if siren_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "Mpoints/s full iso-point cycle (project+resample+splat), 1M pts",
+            "value": round(n_local * world / (ms_per_step * 1e-3) / 1e6, 4),
+            "unit": "Mpoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: 1M points project(T=10)+resample(FRNN K=9, repulsion, T=3) + EWA "
+                                   "splat fwd/bwd 512x512x4 views, K=8",
+                       "sdf": "SIREN 3->256x4->1 (omega 30), fitted to the unit sphere (300 Adam steps, seed 0)",
+                       "points": n_local * world, "parallelism": "1 rank" if world == 1 else "points sharded x%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "k_siren_step<16> (fused SIREN SDF+grad Newton step)",
+                         "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": launches_per_step,
+                         "avg_launch_ms": round(siren_ms / max(siren_launches, 1), 4),
+                         "point_evals_per_step": evals_per_step,
+                         "share_of_step": round(siren_ms / args.steps / ms_per_step, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
