@@ -161,9 +161,15 @@ __device__ __forceinline__ void gemm_pass(const float* __restrict__ img,
                                           const float* __restrict__ hL,
                                           float* __restrict__ wbuf, f32x4 (&acc)[NT],
                                           int lane, int g) {
-  constexpr int CH = NT * 256;            // floats per q-chunk
-  constexpr int PER = CH / 4 / 256;       // float4 per thread per chunk (NT/4)
-  static_assert(NT % 4 == 0, "NT must be a multiple of 4");
+  // One pass = NT q-chunks; each q-chunk is staged in two halves of TC = NT/2 tiles so
+  // that the LDS stage is 2 x (NT/2) KiB and two workgroups fit on a CU.  All A
+  // fragments of a half are requested up front (TC ds_read_b128 in flight) and the MFMAs
+  // consume them as they land.
+  constexpr int TC = NT / 2;              // tiles per staged half
+  constexpr int CH = TC * 256;            // floats per half-chunk
+  constexpr int NV = CH / 4;              // float4 per half-chunk
+  constexpr int PER = (NV + 255) / 256;   // float4 per thread per half-chunk
+  static_assert(NT % 2 == 0, "NT must be even");
   const int tid = threadIdx.x;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -174,50 +180,57 @@ __device__ __forceinline__ void gemm_pass(const float* __restrict__ img,
     }
   }
   f32x4 st[PER];
-  // prologue: chunk 0 -> wbuf[0]
 #pragma unroll
   for (int k = 0; k < PER; ++k)
-    st[k] = reinterpret_cast<const f32x4*>(img)[tid + 256 * k];
+    if (tid + 256 * k < NV) st[k] = reinterpret_cast<const f32x4*>(img)[tid + 256 * k];
 #pragma unroll
   for (int k = 0; k < PER; ++k)
-    reinterpret_cast<f32x4*>(wbuf)[tid + 256 * k] = st[k];
+    if (tid + 256 * k < NV) reinterpret_cast<f32x4*>(wbuf)[tid + 256 * k] = st[k];
   __syncthreads();
-  int cur = 0;
   for (int q = 0; q < NT; ++q) {
-    if (q + 1 < NT) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(img + (int64_t)(q + 1) * CH);
-#pragma unroll
-      for (int k = 0; k < PER; ++k) st[k] = src[tid + 256 * k];
-    }
     const f32x4 b4 = reinterpret_cast<const f32x4*>(hL)[q * 64 + lane];
-    const f32x4* wa = reinterpret_cast<const f32x4*>(wbuf + cur * CH);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const f32x4 a4 = wa[t * 64 + lane];
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[t], 0, 0, 0);
-    }
-    if (q + 1 < NT) {
-      f32x4* dst = reinterpret_cast<f32x4*>(wbuf + (cur ^ 1) * CH);
+    for (int half = 0; half < 2; ++half) {
+      const int c = 2 * q + half;          // half-chunk index; buffer = half (c & 1)
+      const bool more = (c + 1) < 2 * NT;
+      if (more) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(img + (int64_t)(c + 1) * CH);
 #pragma unroll
-      for (int k = 0; k < PER; ++k) dst[tid + 256 * k] = st[k];
+        for (int k = 0; k < PER; ++k)
+          if (tid + 256 * k < NV) st[k] = src[tid + 256 * k];
+      }
+      const f32x4* wa = reinterpret_cast<const f32x4*>(wbuf + half * CH);
+      f32x4 a4[TC];
+#pragma unroll
+      for (int t = 0; t < TC; ++t) a4[t] = wa[t * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < TC; ++t) {
+        f32x4& d = acc[half * TC + t];
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].x, b4.x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].y, b4.y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].z, b4.z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].w, b4.w, d, 0, 0, 0);
+      }
+      if (more) {
+        f32x4* dst = reinterpret_cast<f32x4*>(wbuf + (half ^ 1) * CH);
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+          if (tid + 256 * k < NV) dst[tid + 256 * k] = st[k];
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    cur ^= 1;
   }
 }
 
 template <int NT>
-__global__ __launch_bounds__(256, 1) void k_siren_step(SirenArgs a) {
+__global__ __launch_bounds__(256, 2) void k_siren_step(SirenArgs a) {
   constexpr int H = NT * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, j = lane & 15;
   float* hL = smem + wave * (NT * 256);
-  float* wbuf = smem + 4 * NT * 256;
+  float* wbuf = smem + 4 * NT * 256;   // 2 x (NT/2) KiB stage
   const float* W0img = a.packed + off_w0(H);
   const float* WLimg = a.packed + off_wl(H);
   const float bL = a.packed[off_bl(H)];
@@ -351,13 +364,13 @@ __global__ __launch_bounds__(256, 1) void k_siren_step(SirenArgs a) {
   }
 }
 
-constexpr int kSirenBlocks = 256;  // persistent: one workgroup per CU
+constexpr int kSirenBlocks = 512;  // persistent: two workgroups per CU (80 KiB LDS each)
 
 inline int64_t stash_floats(int H, int L) { return (int64_t)kSirenBlocks * 4 * (L + 1) * H * 16; }
 
 template <int NT>
 int launch_step(const SirenArgs& a, int blocks, hipStream_t s) {
-  const size_t lds = (size_t)(6 * NT * 256) * sizeof(float);
+  const size_t lds = (size_t)(5 * NT * 256) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_siren_step<NT>),
