@@ -108,12 +108,12 @@ class Cycle(object):
 
     def step(self):
         from iso_points_amd.rasterizer import _C, _visible_and_radius, composite
+        from iso_points_amd.levelset_sampling import cloud_diag
         # 1. Newton projection, T=10
         r0 = self._project(self.pts0, 10)
         # 2. resample: FRNN (K+1=9) + tangent-plane repulsion + projection T=3
         proj = self.proj
-        flat = r0.points.reshape(-1, 3)
-        diag = (flat.max(dim=0).values - flat.min(dim=0).values).norm()
+        diag = cloud_diag(r0.points.reshape(1, -1, 3))[0]
         inv_sigma = (self.num.float() / diag).reshape(1).contiguous()
         proj._create_tree(r0.points, refresh_tree=True, num_points_per_cloud=self.num)
         moved = proj.repulsion_step(r0.points, r0.normals, proj._knn_idx, inv_sigma)
@@ -161,8 +161,8 @@ def active_counts(cycle):
     ws = proj._packed_cache._ws
     c = ws[off:off + 64 * 4].view(torch.int32).tolist()
     out["T10"] = [n] + c[1:11]
-    flat = r0.points.reshape(-1, 3)
-    diag = (flat.max(dim=0).values - flat.min(dim=0).values).norm()
+    from iso_points_amd.levelset_sampling import cloud_diag
+    diag = cloud_diag(r0.points.reshape(1, -1, 3))[0]
     inv_sigma = (cycle.num.float() / diag).reshape(1).contiguous()
     proj._create_tree(r0.points, refresh_tree=True, num_points_per_cloud=cycle.num)
     moved = proj.repulsion_step(r0.points, r0.normals, proj._knn_idx, inv_sigma)

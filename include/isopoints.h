@@ -102,6 +102,13 @@ int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_out,
 /* upper bound of `total` for a grid built by iso_frnn_make_grid */
 #define ISO_GRID3_MAX_CELLS ((ISO_GRID_MAX_RES + 1) * (ISO_GRID_MAX_RES + 1) * (ISO_GRID_MAX_RES + 1))
 
+/* Axis-aligned bounding box of each cloud: minmax (N,8) f32 =
+ * [min_x,min_y,min_z,0, max_x,max_y,max_z,0] (zeros for an empty cloud).  Feeds the
+ * search radius / kernel width of levelset_sampling.py:129-131 and :254-256 without
+ * torch's dim-reductions or a host sync.                                         */
+int iso_points_bbox(const float* points, const int64_t* lengths, int n_clouds,
+                    int64_t p_stride, float* minmax, void* stream);
+
 /* Device-side grid sizing for clouds `points` (N, P, 3) padded, lengths (N)
  * i64 (NULL = all P), radius (N) f32.  Writes params (N, 8).  Cell size is
  * chosen from point density (about 8 points per occupied cell on a surface)

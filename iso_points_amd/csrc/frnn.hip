@@ -42,23 +42,29 @@ __global__ void k_bbox_init(unsigned* __restrict__ keys, int n_clouds) {
   }
 }
 
-// keys[n][0..2] = min xyz, keys[n][4..6] = max xyz (uint keys)
+// keys[n][0..2] = min xyz, keys[n][4..6] = max xyz (uint keys).  Each workgroup reduces its
+// grid-stride slice in registers -> wave shuffles -> LDS, and issues ONE set of six atomics
+// (a few hundred atomics per cloud in total: same-address atomics serialise in L2).
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_bbox(const float* __restrict__ pts,
                                                 const int64_t* __restrict__ lengths,
                                                 int64_t p_stride,
                                                 unsigned* __restrict__ keys) {
+  __shared__ float s_mn[BLOCK / 64][3], s_mx[BLOCK / 64][3];
   const int n = blockIdx.y;
   const int64_t len = lengths ? lengths[n] : p_stride;
+  if (len <= 0) return;
   const float* p = pts + (int64_t)n * p_stride * 3;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < len;
+  // flat float index so consecutive lanes read consecutive dwords
+  const int64_t nfl = len * 3;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < nfl;
        i += (int64_t)gridDim.x * BLOCK) {
+    const float v = p[i];
+    const int a = (int)(i % 3);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      float v = p[i * 3 + a];
-      mn[a] = fminf(mn[a], v);
-      mx[a] = fmaxf(mx[a], v);
+    for (int c = 0; c < 3; ++c) {
+      if (a == c) { mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v); }
     }
   }
 #pragma unroll
@@ -69,13 +75,35 @@ __global__ __launch_bounds__(BLOCK) void k_bbox(const float* __restrict__ pts,
       mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
     }
   }
-  if ((threadIdx.x & 63) == 0 && len > 0) {
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      atomicMin(&keys[n * 8 + a], f2key(mn[a]));
-      atomicMax(&keys[n * 8 + 4 + a], f2key(mx[a]));
-    }
+    for (int a = 0; a < 3; ++a) { s_mn[w][a] = mn[a]; s_mx[w][a] = mx[a]; }
   }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    float lo = s_mn[0][a], hi = s_mx[0][a];
+#pragma unroll
+    for (int k = 1; k < BLOCK / 64; ++k) { lo = fminf(lo, s_mn[k][a]); hi = fmaxf(hi, s_mx[k][a]); }
+    atomicMin(&keys[n * 8 + a], f2key(lo));
+    atomicMax(&keys[n * 8 + 4 + a], f2key(hi));
+  }
+}
+
+// decode the keys in place: out[n] = [min xyz, 0, max xyz, 0] as floats
+__global__ void k_bbox_decode(unsigned* __restrict__ keys, const int64_t* __restrict__ lengths,
+                              int64_t p_stride, int n_clouds) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_clouds) return;
+  const int64_t len = lengths ? lengths[n] : p_stride;
+  float* f = reinterpret_cast<float*>(keys + n * 8);
+  for (int a = 0; a < 3; ++a) {
+    float lo = key2f(keys[n * 8 + a]), hi = key2f(keys[n * 8 + 4 + a]);
+    if (len <= 0) { lo = 0.f; hi = 0.f; }
+    f[a] = lo; f[4 + a] = hi;
+  }
+  f[3] = 0.f; f[7] = 0.f;
 }
 
 __global__ void k_grid_finalize(float* __restrict__ params,
@@ -487,13 +515,32 @@ extern "C" int iso_frnn_make_grid(const float* points, const int64_t* lengths,
   unsigned* keys = reinterpret_cast<unsigned*>(grid_params);
   hipLaunchKernelGGL(k_bbox_init, dim3(iso_div_up(n_clouds * 8, 256)), dim3(256), 0, s, keys, n_clouds);
   if (p_stride > 0) {
-    int gx = iso_div_up(p_stride, 256 * 4);
-    if (gx > 1024) gx = 1024;
+    int gx = iso_div_up(p_stride * 3, 256 * 16);
+    if (gx > 256) gx = 256;
     hipLaunchKernelGGL(k_bbox<256>, dim3(gx, n_clouds), dim3(256), 0, s, points, lengths, p_stride, keys);
   }
   hipLaunchKernelGGL(k_grid_finalize, dim3(iso_div_up(n_clouds, 64)), dim3(64), 0, s,
                      grid_params, lengths, p_stride, radius, n_clouds);
   ISO_CHECK_LAUNCH("iso_frnn_make_grid");
+  return ISO_OK;
+}
+
+extern "C" int iso_points_bbox(const float* points, const int64_t* lengths, int n_clouds,
+                               int64_t p_stride, float* minmax, void* stream) {
+  ISO_REQUIRE(n_clouds >= 0 && p_stride >= 0, ISO_ERR_INVALID, "iso_points_bbox: bad sizes");
+  if (n_clouds == 0) return ISO_OK;
+  ISO_REQUIRE(minmax && (points || p_stride == 0), ISO_ERR_INVALID, "iso_points_bbox: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned* keys = reinterpret_cast<unsigned*>(minmax);
+  hipLaunchKernelGGL(k_bbox_init, dim3(iso_div_up(n_clouds * 8, 256)), dim3(256), 0, s, keys, n_clouds);
+  if (p_stride > 0) {
+    int gx = iso_div_up(p_stride * 3, 256 * 16);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(k_bbox<256>, dim3(gx, n_clouds), dim3(256), 0, s, points, lengths, p_stride, keys);
+  }
+  hipLaunchKernelGGL(k_bbox_decode, dim3(iso_div_up(n_clouds, 64)), dim3(64), 0, s, keys, lengths,
+                     p_stride, n_clouds);
+  ISO_CHECK_LAUNCH("iso_points_bbox");
   return ISO_OK;
 }
 

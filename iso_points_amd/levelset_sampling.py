@@ -50,6 +50,17 @@ def full_lengths(points):
     return with_host_lengths(torch.full((B,), P, dtype=torch.long, device=points.device), [P] * B)
 
 
+def cloud_diag(points_padded, lengths=None):
+    """|bbox diagonal| of each cloud, (N,) device tensor (iso_points_bbox; no host sync).
+    lengths=None spans the whole padded tensor, like the reference's max/min over dim 1."""
+    N, P = points_padded.shape[0], points_padded.shape[1]
+    pts = points_padded.detach().float().contiguous()
+    mm = torch.empty((N, 8), dtype=torch.float32, device=pts.device)
+    _lib.call("iso_points_bbox", _lib.ptr(pts), _lib.ptr(lengths) if lengths is not None else None, N, P,
+              _lib.ptr(mm), _lib.stream())
+    return (mm[:, 4:7] - mm[:, 0:3]).norm(dim=-1)
+
+
 def convert_pointclouds_to_tensor(pcl):
     """pytorch3d.ops.utils.convert_pointclouds_to_tensor for the two inputs the reference
     passes (levelset_sampling.py:374): a padded tensor or a Pointclouds-like object."""
@@ -131,7 +142,7 @@ class UniformProjection(LevelSetProjection):
         assert points_padded.ndim == 3
         if num_points_per_cloud is None:
             num_points_per_cloud = full_lengths(points_padded)
-        diag = (points_padded.max(dim=1).values - points_padded.min(dim=1).values).norm(dim=-1)
+        diag = cloud_diag(points_padded)            # (max - min).norm over the padded tensor (:129-130)
         search_radius = torch.sqrt(diag / num_points_per_cloud.float()) * self.knn_k
         dists, idxs, nn, grid = frnn.frnn_grid_points(
             points_padded, points_padded, num_points_per_cloud, num_points_per_cloud,
@@ -259,8 +270,7 @@ class UniformProjection(LevelSetProjection):
         if batch_size != 1:
             raise NotImplementedError("resample: one cloud per call (the reference's broadcast of "
                                       "inv_sigma_spatial is only valid for batch size 1, :256,:274)")
-        flat = points_init.reshape(-1, 3)
-        diag = (flat.max(dim=0).values - flat.min(dim=0).values).norm()
+        diag = cloud_diag(points_init.reshape(1, -1, 3))[0]                   # :254-255
         inv_sigma = (num_points.float() / diag).reshape(1).contiguous()      # device scalar (:256)
         points = points_init
         projection_result = None
