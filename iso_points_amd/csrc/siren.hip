@@ -179,46 +179,59 @@ __device__ __forceinline__ void gemm_pass(const float* __restrict__ img,
       acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
-  f32x4 st[PER];
+  constexpr bool FULL = (NV % 256) == 0;  // every thread moves PER float4 (no tail guard)
+  // Two register sets: the global loads of half-chunk c+2 are issued while chunk c is
+  // multiplied and chunk c+1 (loaded one stage earlier) is written to the other LDS buffer,
+  // so a load has two MFMA stages (~2k cycles) to land before it is needed.
+  f32x4 sx[PER], sy[PER];
+  auto gload = [&](f32x4 (&r)[PER], int c) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(img + (int64_t)c * CH);
 #pragma unroll
-  for (int k = 0; k < PER; ++k)
-    if (tid + 256 * k < NV) st[k] = reinterpret_cast<const f32x4*>(img)[tid + 256 * k];
+    for (int k = 0; k < PER; ++k)
+      if (FULL || tid + 256 * k < NV) r[k] = src[tid + 256 * k];
+  };
+  auto lwrite = [&](const f32x4 (&r)[PER], int buf) {
+    f32x4* dst = reinterpret_cast<f32x4*>(wbuf + buf * CH);
 #pragma unroll
-  for (int k = 0; k < PER; ++k)
-    if (tid + 256 * k < NV) reinterpret_cast<f32x4*>(wbuf)[tid + 256 * k] = st[k];
+    for (int k = 0; k < PER; ++k)
+      if (FULL || tid + 256 * k < NV) dst[tid + 256 * k] = r[k];
+  };
+  auto stage = [&](int half, const f32x4& b4) {
+    const f32x4* wa = reinterpret_cast<const f32x4*>(wbuf + half * CH);
+    f32x4 a4[TC];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) a4[t] = wa[t * 64 + lane];
+    // keep the TC reads ahead of the MFMA block: the scheduler otherwise sinks each read
+    // next to its consumer (2 in flight, full LDS latency exposed every 8 MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+      f32x4& d = acc[half * TC + t];
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].x, b4.x, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].y, b4.y, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].z, b4.z, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].w, b4.w, d, 0, 0, 0);
+    }
+    // ... and the LDS write + barrier of the next chunk BEHIND it (hoisted, they make the wave
+    // drain all of its reads with only a few MFMAs in flight)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  gload(sx, 0);
+  lwrite(sx, 0);
+  gload(sx, 1);
   __syncthreads();
   for (int q = 0; q < NT; ++q) {
     const f32x4 b4 = reinterpret_cast<const f32x4*>(hL)[q * 64 + lane];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int c = 2 * q + half;          // half-chunk index; buffer = half (c & 1)
-      const bool more = (c + 1) < 2 * NT;
-      if (more) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(img + (int64_t)(c + 1) * CH);
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-          if (tid + 256 * k < NV) st[k] = src[tid + 256 * k];
-      }
-      const f32x4* wa = reinterpret_cast<const f32x4*>(wbuf + half * CH);
-      f32x4 a4[TC];
-#pragma unroll
-      for (int t = 0; t < TC; ++t) a4[t] = wa[t * 64 + lane];
-#pragma unroll
-      for (int t = 0; t < TC; ++t) {
-        f32x4& d = acc[half * TC + t];
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].x, b4.x, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].y, b4.y, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].z, b4.z, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].w, b4.w, d, 0, 0, 0);
-      }
-      if (more) {
-        f32x4* dst = reinterpret_cast<f32x4*>(wbuf + (half ^ 1) * CH);
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-          if (tid + 256 * k < NV) dst[tid + 256 * k] = st[k];
-      }
-      __syncthreads();
-    }
+    // ---- half 0: chunk 2q in buffer 0; sx holds chunk 2q+1
+    if (2 * q + 2 < 2 * NT) gload(sy, 2 * q + 2);
+    stage(0, b4);
+    lwrite(sx, 1);
+    __syncthreads();
+    // ---- half 1: chunk 2q+1 in buffer 1; sy holds chunk 2q+2
+    if (2 * q + 3 < 2 * NT) gload(sx, 2 * q + 3);
+    stage(1, b4);
+    if (2 * q + 2 < 2 * NT) lwrite(sy, 0);
+    __syncthreads();
   }
 }
 
