@@ -71,107 +71,63 @@ def cameras(device):
 
 
 class Cycle(object):
-    """The hot path, called through the reference-shaped operators of iso_points_amd."""
+    """The hot path = iso_points_amd.dist.IsoCycle (the same class for 1 and N GPUs), plus HIP
+    events around the SIREN projections for the roofline figure."""
 
-    def __init__(self, device, model, n_points, rank=0, world=1):
-        from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
-        from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
-        self.dev, self.model = device, model
-        self.rank, self.world = rank, world
-        self.full_lengths = full_lengths
-        self.proj = UniformProjection(proj_max_iters=10, proj_tolerance=5e-5, knn_k=8, sample_iters=1)
-        self.rs = PointsRasterizationSettings(image_size=IMAGE, points_per_pixel=KPIX, cutoff_threshold=1.0,
-                                              depth_merging_threshold=0.05, radii_backward_scaler=10,
-                                              backface_culling=True, Vrk_isotropic=True, bin_size=None)
-        self.splat = SurfaceSplatting(raster_settings=self.rs)
-        self.views, self.projs = cameras(device)
-        self.pts0 = sphere_cloud(n_points, seed=rank, device=device)
-        self.num = full_lengths(self.pts0)
-        # analytic silhouette of the unit sphere for the loss (SURVEY 8(d) cfg 3)
-        S = IMAGE
-        ax = -1 + (2 * torch.arange(S, device=device) + 1.0) / S
-        rr = (1.0 / math.sqrt(9.0 - 1.0)) / math.tan(math.radians(15.0))
-        yy, xx = torch.meshgrid(ax, ax, indexing="ij")
-        self.target = ((xx ** 2 + yy ** 2) <= rr ** 2).float()[None].expand(VIEWS, S, S).contiguous()
-        self.ev = []          # (start, end) events around the SIREN projections
+    def __init__(self, device, model, comm):
+        from iso_points_amd.dist import IsoCycle, sphere_silhouette
+        from iso_points_amd.rasterizer import PointsRasterizationSettings
+        self.dev, self.model, self.comm = device, model, comm
+        rs = PointsRasterizationSettings(image_size=IMAGE, points_per_pixel=KPIX, cutoff_threshold=1.0,
+                                         depth_merging_threshold=0.05, radii_backward_scaler=10,
+                                         backface_culling=True, Vrk_isotropic=True, bin_size=None)
+        views, projs = cameras(device)
+        pts0 = sphere_cloud(P_TOTAL, seed=0, device=device)          # identical on every rank
+        self.cyc = IsoCycle(model, pts0, views, projs, raster_settings=rs, knn_k=8, comm=comm,
+                            target=sphere_silhouette(IMAGE, VIEWS, 3.0, 30.0, device))
+        self.cyc.project_hook = self._timed_project
+        self.ev = []
         self.timed = False
 
-    def _project(self, pts, T):
-        if self.timed:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-        r = self.proj._project_points(self.model, pts, self.num, proj_max_iters=T)
-        if self.timed:
-            b.record()
-            self.ev.append((a, b, T, self.proj._packed_cache))
+    def _timed_project(self, fn, T):
+        if not self.timed:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.ev.append((a, b, T))
         return r
 
     def step(self):
-        from iso_points_amd.rasterizer import _C, _visible_and_radius, composite
-        from iso_points_amd.levelset_sampling import cloud_diag
-        # 1. Newton projection, T=10
-        r0 = self._project(self.pts0, 10)
-        # 2. resample: FRNN (K+1=9) + tangent-plane repulsion + projection T=3
-        proj = self.proj
-        diag = cloud_diag(r0.points.reshape(1, -1, 3))[0]
-        inv_sigma = (self.num.float() / diag).reshape(1).contiguous()
-        proj._create_tree(r0.points, refresh_tree=True, num_points_per_cloud=self.num)
-        moved = proj.repulsion_step(r0.points, r0.normals, proj._knn_idx, inv_sigma)
-        r1 = self._project(moved, 3)
-        # 3. splat forward: filter, K=7 FRNN, per-point set-up, tile binning + raster, compositing
-        pts, nrm = r1.points[0], r1.normals[0]
-        frags, filt = self.splat.forward(pts, nrm, cameras=(self.views, self.projs),
-                                         features=0.5 * (torch.nn.functional.normalize(nrm, dim=-1) + 1))
-        img = composite(frags, filt["scaler"], filt["features"], norm_weighted=True)
-        # 4. loss gradients (SURVEY 8(d) cfg 3) and splat backward
-        alpha = img[..., 3]
-        occ_grad = 2.0 * (alpha - self.target) / alpha.numel()
-        zbuf_grad = torch.zeros_like(frags.zbuf)
-        zbuf_grad[..., 0] = 1e-3 / alpha.numel()
-        vis, rs = _visible_and_radius(frags.idx, filt["radii"], filt["first_idx"], filt["num_points"],
-                                      float(self.rs.radii_backward_scaler))
-        grad = _C._backward(filt["ndc"], filt["radii"], occ_grad, filt["first_idx"], filt["num_points"],
-                            visible=vis, rs=rs, idx=frags.idx, grad_zbuf=zbuf_grad)
-        return r1, img, grad
+        return self.cyc.step()
 
     def siren_stats(self):
-        """(total flops, total ms, launches) of the timed SIREN projections, from HIP events on the
-        launch stream and the kernel's own device-side active-point counters."""
-        from iso_points_amd import _lib
-        lib = _lib.load()
-        n = self.pts0.shape[1]
-        flops, ms, launches = 0.0, 0.0, 0
-        for a, b, T, ps in self.ev:
-            ms += a.elapsed_time(b)
-            launches += T + 1
+        """(ms, launches) of the timed SIREN projections: HIP events on the launch stream."""
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.ev)
+        launches = sum(T + 1 for _, _, T in self.ev)
         return ms, launches
 
+    def active_counts(self):
+        """Point-evaluations of one cycle on this rank, from the kernel's own device-side
+        active-list counters (one extra untimed pass of the two projections)."""
+        from iso_points_amd import _lib
+        lib = _lib.load()
+        cyc = self.cyc
+        n = cyc.pts0_local.shape[1]
+        off = lib.iso_project_siren_workspace_bytes(n, HIDDEN, LAYERS) - 64 * 4 - 64
+        counts = []
 
-def active_counts(cycle):
-    """Re-run the two projections once, reading the kernel's active-list counters after each."""
-    from iso_points_amd import _lib
-    lib = _lib.load()
-    n = cycle.pts0.shape[1]
-    tot = 0
-    out = {}
-    proj = cycle.proj
-    r0 = proj._project_points(cycle.model, cycle.pts0, cycle.num, proj_max_iters=10)
-    torch.cuda.synchronize()
-    off = lib.iso_project_siren_workspace_bytes(n, HIDDEN, LAYERS) - 64 * 4 - 64
-    ws = proj._packed_cache._ws
-    c = ws[off:off + 64 * 4].view(torch.int32).tolist()
-    out["T10"] = [n] + c[1:11]
-    from iso_points_amd.levelset_sampling import cloud_diag
-    diag = cloud_diag(r0.points.reshape(1, -1, 3))[0]
-    inv_sigma = (cycle.num.float() / diag).reshape(1).contiguous()
-    proj._create_tree(r0.points, refresh_tree=True, num_points_per_cloud=cycle.num)
-    moved = proj.repulsion_step(r0.points, r0.normals, proj._knn_idx, inv_sigma)
-    proj._project_points(cycle.model, moved, cycle.num, proj_max_iters=3)
-    torch.cuda.synchronize()
-    ws = proj._packed_cache._ws
-    c = ws[off:off + 64 * 4].view(torch.int32).tolist()
-    out["T3"] = [n] + c[1:4]
-    return out
+        def hook(fn, T):
+            r = fn()
+            torch.cuda.synchronize()
+            c = cyc.proj._packed_cache._ws[off:off + 64 * 4].view(torch.int32).tolist()
+            counts.append([n] + c[1:T + 1])
+            return r
+        cyc.project_hook = hook
+        cyc.project_resample()
+        cyc.project_hook = self._timed_project
+        return counts
 
 
 def cpu_baseline(gpu_model):
@@ -241,10 +197,10 @@ def main():
         dist = dist_mod
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from iso_points_amd.dist import Comm
+    comm = Comm(enabled=(world > 1))
     model = fitted_siren(dev)
-    n_local = P_TOTAL // world
-    cyc = Cycle(dev, model, n_local, rank=rank, world=world)
+    cyc = Cycle(dev, model, comm)
 
     for _ in range(args.warmup):
         cyc.step()
@@ -269,8 +225,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     siren_ms, siren_launches = cyc.siren_stats()
-    counts = active_counts(cyc)
-    evals_per_step = sum(counts["T10"]) + sum(counts["T3"])
+    counts = cyc.active_counts()
+    evals_per_step = sum(sum(c) for c in counts)          # this rank's share
     flop_per_step = evals_per_step * FLOP_PER_EVAL
     launches_per_step = siren_launches / max(args.steps, 1)
     ach = flop_per_step / (siren_ms / args.steps * 1e-3) / 1e12 if siren_ms > 0 else 0.0
@@ -278,7 +234,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "Mpoints/s full iso-point cycle (project+resample+splat), 1M pts",
-            "value": round(n_local * world / (ms_per_step * 1e-3) / 1e6, 4),
+            "value": round(P_TOTAL / (ms_per_step * 1e-3) / 1e6, 4),
             "unit": "Mpoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
@@ -290,13 +246,16 @@ def main():
             "config": {"workload": "configs[2]: 1M points project(T=10)+resample(FRNN K=9, repulsion, T=3) + EWA "
                                    "splat fwd/bwd 512x512x4 views, K=8",
                        "sdf": "SIREN 3->256x4->1 (omega 30), fitted to the unit sphere (300 Adam steps, seed 0)",
-                       "points": n_local * world, "parallelism": "1 rank" if world == 1 else "points sharded x%d" % world},
+                       "points": P_TOTAL,
+                       "parallelism": "1 rank" if world == 1 else
+                       "points (per-point stages) and tile-row bands (per-pixel stages) sharded x%d, RCCL "
+                       "all-gather/all-reduce" % world},
             "roofline": {"bound": "mfma", "kernel": "k_siren_step<16> (fused SIREN SDF+grad Newton step)",
                          "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                          "launches_per_step": launches_per_step,
                          "avg_launch_ms": round(siren_ms / max(siren_launches, 1), 4),
-                         "point_evals_per_step": evals_per_step,
+                         "point_evals_per_step_rank0": evals_per_step,
                          "share_of_step": round(siren_ms / args.steps / ms_per_step, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

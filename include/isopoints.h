@@ -180,13 +180,16 @@ int iso_frnn_gather(const float* x, const int64_t* idx, float* out,
  *      n_j = normalize(normals[j]) ; D = p_i - p_j ; w = exp(-|D|^2 * inv_sigma)
  *      Dt = D - (D.n_j) n_j ; move = (sum w + 1) * sum(w Dt) / sdeno(sum w)
  *      out_i = p_i + move_i
+ *    Moves the n points [first_point, first_point+n) of `points` (rows 0..n-1 of idx and
+ *    points_out belong to them; neighbour indices address the whole array) -- a rank of
+ *    a sharded run passes its own slice, a single-GPU caller first_point = 0, n = P.
  *    idx: row i starts at idx + i*idx_row_stride (i64, K entries, -1 padding:
  *    weight 0 there) -- lets the caller pass the [:,1:] view of a (P,K+1)
  *    query result without copying.  inv_sigma (= P/diag, :256) is a DEVICE
  *    scalar so the bounding-box reduction needs no host sync.                 */
 int iso_repulse(const float* points, const float* normals, const int64_t* idx,
-                int64_t idx_row_stride, float* points_out, int64_t n, int K,
-                const float* inv_sigma, void* stream);
+                int64_t idx_row_stride, float* points_out, int64_t n,
+                int64_t first_point, int K, const float* inv_sigma, void* stream);
 
 /* ------------------------------------------------------------------------
  * D. EWA surface splatting
@@ -210,9 +213,12 @@ int iso_compact_rows(const float* in, const int32_t* flags, const int32_t* offse
                      float* out, int64_t P, int64_t total, int U, void* stream);
 /* _compute_isotropic_Vrk (rasterizer.py:367-386): dists (N,p_stride,7) from the
  * K=7 self query -> h (packed) = clamp(0.5*max_{6 nn} d2, 5e-5, 0.01); clouds
- * with fewer than 7 points use d2 = 1e-3.                                        */
+ * with fewer than 7 points use d2 = 1e-3.  Row i of cloud n (i < num_pts[n]) is written to
+ * h[first_idx[n] + i]; a rank that queried only a sub-range of each cloud passes the
+ * sub-range in first_idx/num_pts and the true cloud sizes in cloud_num_pts (NULL = num_pts). */
 int iso_splat_vrk_h(const float* dists, const int64_t* first_idx, const int64_t* num_pts,
-                    float* h, int n_clouds, int64_t p_stride, void* stream);
+                    const int64_t* cloud_num_pts, float* h, int n_clouds, int64_t p_stride,
+                    void* stream);
 /* _get_per_point_info + PointsRasterizer.transform (rasterizer.py:441-563,:618):
  * per packed point: NDC position (xy projected, z = view depth), ellipse (a,b,c),
  * cutoff, bbox radii, EWA normaliser.  views = world->view, projs = full
@@ -234,15 +240,19 @@ int iso_splat_setup(const float* points, const float* normals, const float* h,
  *                         depth_merging_thres reset to -1, occupancy = any hit.
  * Outputs as the reference: idx i32, zbuf/qvalue f32 (N,S,S,K), occ f32 (N,S,S),
  * image flipped in both axes (+X left, +Y up).  *overflow_flag != 0 afterwards
- * means pair_capacity was too small (result incomplete).                        */
+ * means pair_capacity was too small (result incomplete).
+ * [tile_row_begin, tile_row_end) restricts both calls to a band of tile rows (in NDC pixel
+ * order, i.e. before the flip): a rank of a sharded run rasterises only its band and leaves
+ * the other pixels of the output tensors untouched; pass 0, T for the whole image.          */
 int iso_splat_tiles_per_side(int image_size);
 int iso_splat_bin_count(const float* points, const float* radii, const int64_t* first_idx,
                         const int64_t* num_pts, int n_clouds, int64_t max_pts, int image_size,
-                        int32_t* tile_cnt, void* stream);
+                        int tile_row_begin, int tile_row_end, int32_t* tile_cnt, void* stream);
 int iso_splat_forward(const float* points, const float* ellipse, const float* cutoff,
                       const float* radii, const int64_t* first_idx, const int64_t* num_pts,
                       int n_clouds, int64_t max_pts, float depth_merging_thres, int image_size,
-                      int points_per_pixel, int32_t* tile_cursor, const int32_t* tile_off,
+                      int points_per_pixel, int tile_row_begin, int tile_row_end,
+                      int32_t* tile_cursor, const int32_t* tile_off,
                       int32_t* pairs, int64_t pair_capacity, int32_t* overflow_flag,
                       int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out,
                       void* stream);

@@ -38,14 +38,14 @@ SIGNATURES = {
     "iso_frnn_counting_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),
     "iso_frnn_query": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _L, _L, _L, _P]),
     "iso_frnn_gather": (_I, [_P, _P, _P, _I, _L, _L, _I, _I, _P]),
-    "iso_repulse": (_I, [_P, _P, _P, _L, _P, _L, _I, _P, _P]),
+    "iso_repulse": (_I, [_P, _P, _P, _L, _P, _L, _L, _I, _P, _P]),
     "iso_splat_view_flags": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _I, _P]),
     "iso_compact_rows": (_I, [_P, _P, _P, _P, _L, _L, _I, _P]),
-    "iso_splat_vrk_h": (_I, [_P, _P, _P, _P, _I, _L, _P]),
+    "iso_splat_vrk_h": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "iso_splat_setup": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "iso_splat_tiles_per_side": (_I, [_I]),
-    "iso_splat_bin_count": (_I, [_P, _P, _P, _P, _I, _L, _I, _P, _P]),
-    "iso_splat_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P]),
+    "iso_splat_bin_count": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P]),
+    "iso_splat_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P]),
     "iso_splat_composite": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _P, _P]),
     "iso_splat_mark_visible": (_I, [_P, _L, _I, _P, _P]),
     "iso_splat_backward_workspace_bytes": (_L, [_I, _I]),

@@ -19,7 +19,7 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_repulse(
     const float* __restrict__ pts, const float* __restrict__ nrm,
     const int64_t* __restrict__ idx, int64_t idx_stride, float* __restrict__ out,
-    int64_t n, int K, const float* __restrict__ inv_sigma_ptr) {
+    int64_t n, int64_t first, int K, const float* __restrict__ inv_sigma_ptr) {
   const float inv_sigma = *inv_sigma_ptr;
   __shared__ __attribute__((aligned(16))) float tile[BLOCK * 3];
   const int t = threadIdx.x;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(BLOCK) void k_repulse(
   for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
     const int64_t base = tl * BLOCK;
     const int cnt = (int)((n - base) < BLOCK ? (n - base) : BLOCK);
-    iso_tile_load3<BLOCK>(pts, base, cnt, tile);
+    iso_tile_load3<BLOCK>(pts, first + base, cnt, tile);
     __syncthreads();
     float px = 0.f, py = 0.f, pz = 0.f;
     if (t < cnt) {
@@ -70,9 +70,9 @@ __global__ __launch_bounds__(BLOCK) void k_repulse(
 
 extern "C" int iso_repulse(const float* points, const float* normals,
                            const int64_t* idx, int64_t idx_row_stride,
-                           float* points_out, int64_t n, int K,
+                           float* points_out, int64_t n, int64_t first_point, int K,
                            const float* inv_sigma, void* stream) {
-  ISO_REQUIRE(n >= 0 && K >= 0, ISO_ERR_INVALID, "iso_repulse: bad sizes");
+  ISO_REQUIRE(n >= 0 && K >= 0 && first_point >= 0, ISO_ERR_INVALID, "iso_repulse: bad sizes");
   if (n == 0) return ISO_OK;
   ISO_REQUIRE(points && normals && points_out && inv_sigma && (idx || K == 0),
               ISO_ERR_INVALID, "iso_repulse: null pointer");
@@ -82,7 +82,7 @@ extern "C" int iso_repulse(const float* points, const float* normals,
   constexpr int BLOCK = 256;
   hipLaunchKernelGGL(k_repulse<BLOCK>, dim3(iso_stream_grid(n, BLOCK)), dim3(BLOCK),
                      0, (hipStream_t)stream, points, normals, idx, idx_row_stride,
-                     points_out, n, K, inv_sigma);
+                     points_out, n, first_point, K, inv_sigma);
   ISO_CHECK_LAUNCH("iso_repulse");
   return ISO_OK;
 }

@@ -83,16 +83,17 @@ __global__ void k_compact_rows(const float* __restrict__ in, const int32_t* __re
 // h = clamp(0.5 * max_{6 nn} d2, 5e-5, 0.01)   (rasterizer.py:375-386)
 __global__ void k_vrk_h(const float* __restrict__ dists /*(N,Pmax,7)*/,
                         const int64_t* __restrict__ first, const int64_t* __restrict__ num,
-                        float* __restrict__ h, int64_t pmax) {
+                        const int64_t* __restrict__ cloud_num, float* __restrict__ h, int64_t pmax) {
   const int n = blockIdx.y;
   const int64_t len = num[n];
+  const int64_t clen = cloud_num ? cloud_num[n] : len;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
        i += (int64_t)gridDim.x * blockDim.x) {
     const float* d = dists + ((int64_t)n * pmax + i) * 7;
     float m = -FLT_MAX;
 #pragma unroll
     for (int k = 1; k < 7; ++k) {
-      float v = (len < 7) ? 1e-3f : d[k];
+      float v = (clen < 7) ? 1e-3f : d[k];
       m = fmaxf(m, v);
     }
     float hv = 0.5f * m;
@@ -204,7 +205,8 @@ __device__ __forceinline__ bool pixel_range(float c, float r, int S, int& lo, in
 template <bool FILL>
 __global__ void k_bin(const float* __restrict__ pts, const float* __restrict__ radii,
                       const int64_t* __restrict__ first, const int64_t* __restrict__ num, int S,
-                      int T /*tiles per side*/, int32_t* __restrict__ tile_cnt,
+                      int T /*tiles per side*/, int ty_begin, int ty_end,
+                      int32_t* __restrict__ tile_cnt,
                       const int32_t* __restrict__ tile_off, int32_t* __restrict__ pairs,
                       int64_t capacity, int32_t* __restrict__ overflow) {
   const int n = blockIdx.y;
@@ -217,7 +219,7 @@ __global__ void k_bin(const float* __restrict__ pts, const float* __restrict__ r
     int x0, x1, y0, y1;
     if (!pixel_range(pts[p * 3], radii[p * 2], S, x0, x1)) continue;
     if (!pixel_range(pts[p * 3 + 1], radii[p * 2 + 1], S, y0, y1)) continue;
-    for (int ty = y0 / TILE; ty <= y1 / TILE; ++ty)
+    for (int ty = max(y0 / TILE, ty_begin); ty <= min(y1 / TILE, ty_end - 1); ++ty)
       for (int tx = x0 / TILE; tx <= x1 / TILE; ++tx) {
         const int tile = (n * T + ty) * T + tx;
         const int slot = atomicAdd(&tile_cnt[tile], 1);
@@ -262,14 +264,16 @@ __global__ __launch_bounds__(256) void k_raster(
     const float* __restrict__ pts, const float* __restrict__ ellipse,
     const float* __restrict__ cutoff, const float* __restrict__ radii,
     const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ tile_off,
-    const int32_t* __restrict__ pairs, int64_t capacity, int S, int T, int K, float depth_thres,
-    int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out,
+    const int32_t* __restrict__ pairs, int64_t capacity, int S, int T, int ty_begin, int ty_rows,
+    int K, float depth_thres, int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out,
     float* __restrict__ occ_out) {
   __shared__ float s_px[256], s_py[256], s_pz[256], s_a[256], s_b[256], s_c[256], s_rx[256],
       s_ry[256], s_cut[256];
   __shared__ int s_id[256];
-  const int tile = blockIdx.x;          // (n*T + ty)*T + tx
-  const int tx = tile % T, ty = (tile / T) % T, n = tile / (T * T);
+  // blockIdx.x enumerates the tiles of the band [ty_begin, ty_begin+ty_rows) of every cloud
+  const int tx = blockIdx.x % T, ty = ty_begin + (blockIdx.x / T) % ty_rows,
+            n = blockIdx.x / (T * ty_rows);
+  const int tile = (n * T + ty) * T + tx;
   const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
   const int xi = tx * TILE + lx, yi = ty * TILE + ly;  // NDC pixel index
   const bool inside = xi < S && yi < S;
@@ -522,13 +526,14 @@ extern "C" int iso_compact_rows(const float* in, const int32_t* flags, const int
 }
 
 extern "C" int iso_splat_vrk_h(const float* dists, const int64_t* first_idx, const int64_t* num_pts,
-                               float* h, int n_clouds, int64_t p_stride, void* stream) {
+                               const int64_t* cloud_num_pts, float* h, int n_clouds,
+                               int64_t p_stride, void* stream) {
   ISO_REQUIRE(n_clouds >= 0 && p_stride >= 0, ISO_ERR_INVALID, "iso_splat_vrk_h: bad sizes");
   if (n_clouds == 0 || p_stride == 0) return ISO_OK;
   ISO_REQUIRE(dists && first_idx && num_pts && h, ISO_ERR_INVALID, "iso_splat_vrk_h: null pointer");
   int gx = iso_div_up(p_stride, 256); if (gx > 4096) gx = 4096;
   hipLaunchKernelGGL(k_vrk_h, dim3(gx, n_clouds), dim3(256), 0, (hipStream_t)stream, dists,
-                     first_idx, num_pts, h, p_stride);
+                     first_idx, num_pts, cloud_num_pts, h, p_stride);
   ISO_CHECK_LAUNCH("iso_splat_vrk_h");
   return ISO_OK;
 }
@@ -556,16 +561,19 @@ extern "C" int iso_splat_tiles_per_side(int image_size) { return (image_size + T
 
 extern "C" int iso_splat_bin_count(const float* points, const float* radii,
                                    const int64_t* first_idx, const int64_t* num_pts, int n_clouds,
-                                   int64_t max_pts, int image_size, int32_t* tile_cnt,
-                                   void* stream) {
+                                   int64_t max_pts, int image_size, int tile_row_begin,
+                                   int tile_row_end, int32_t* tile_cnt, void* stream) {
   ISO_REQUIRE(n_clouds >= 0 && max_pts >= 0 && image_size > 0, ISO_ERR_INVALID, "iso_splat_bin_count: bad sizes");
   if (n_clouds == 0 || max_pts == 0) return ISO_OK;
   ISO_REQUIRE(points && radii && first_idx && num_pts && tile_cnt, ISO_ERR_INVALID,
               "iso_splat_bin_count: null pointer");
   const int T = iso_splat_tiles_per_side(image_size);
+  ISO_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= T,
+              ISO_ERR_INVALID, "iso_splat_bin_count: bad tile row band");
   int gx = iso_div_up(max_pts, 256); if (gx > 4096) gx = 4096;
   hipLaunchKernelGGL(k_bin<false>, dim3(gx, n_clouds), dim3(256), 0, (hipStream_t)stream, points,
-                     radii, first_idx, num_pts, image_size, T, tile_cnt, nullptr, nullptr, 0, nullptr);
+                     radii, first_idx, num_pts, image_size, T, tile_row_begin, tile_row_end, tile_cnt,
+                     nullptr, nullptr, 0, nullptr);
   ISO_CHECK_LAUNCH("iso_splat_bin_count");
   return ISO_OK;
 }
@@ -574,7 +582,8 @@ extern "C" int iso_splat_forward(const float* points, const float* ellipse, cons
                                  const float* radii, const int64_t* first_idx,
                                  const int64_t* num_pts, int n_clouds, int64_t max_pts,
                                  float depth_merging_thres, int image_size, int points_per_pixel,
-                                 int32_t* tile_cursor, const int32_t* tile_off, int32_t* pairs,
+                                 int tile_row_begin, int tile_row_end, int32_t* tile_cursor,
+                                 const int32_t* tile_off, int32_t* pairs,
                                  int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
                                  float* zbuf_out, float* qvalue_out, float* occ_out, void* stream) {
   ISO_REQUIRE(points_per_pixel >= 1 && points_per_pixel <= 32, ISO_ERR_UNSUPPORTED,
@@ -586,19 +595,23 @@ extern "C" int iso_splat_forward(const float* points, const float* ellipse, cons
               ISO_ERR_INVALID, "iso_splat_forward: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int T = iso_splat_tiles_per_side(image_size);
+  ISO_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= T,
+              ISO_ERR_INVALID, "iso_splat_forward: bad tile row band");
+  if (tile_row_begin == tile_row_end) return ISO_OK;
   if (max_pts > 0) {
     ISO_REQUIRE(points && ellipse && cutoff && radii, ISO_ERR_INVALID, "iso_splat_forward: null pointer");
     int gx = iso_div_up(max_pts, 256); if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(k_bin<true>, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, first_idx,
-                       num_pts, image_size, T, tile_cursor, tile_off, pairs, pair_capacity,
-                       overflow_flag);
+                       num_pts, image_size, T, tile_row_begin, tile_row_end, tile_cursor, tile_off,
+                       pairs, pair_capacity, overflow_flag);
   }
-  const int tiles = n_clouds * T * T;
+  const int ty_rows = tile_row_end - tile_row_begin;
+  const int tiles = n_clouds * T * ty_rows;
   const int K = points_per_pixel;
 #define ISO_LAUNCH_R(KM)                                                                        \
   hipLaunchKernelGGL(k_raster<KM>, dim3(tiles), dim3(256), 0, s, points, ellipse, cutoff, radii, \
-                     tile_cursor, tile_off, pairs, pair_capacity, image_size, T, K,              \
-                     depth_merging_thres,                                                        \
+                     tile_cursor, tile_off, pairs, pair_capacity, image_size, T, tile_row_begin, \
+                     ty_rows, K, depth_merging_thres,                                            \
                      idx_out, zbuf_out, qvalue_out, occ_out)
   if (K <= 4) ISO_LAUNCH_R(4);
   else if (K <= 8) ISO_LAUNCH_R(8);

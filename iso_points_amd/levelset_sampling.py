@@ -244,19 +244,21 @@ class UniformProjection(LevelSetProjection):
                                 packed_to_padded(valid, lens, pad_value=False))
 
     # -- resample ----------------------------------------------------------------------
-    def repulsion_step(self, points, normals_init, idx, inv_sigma):
+    def repulsion_step(self, points, normals_init, idx, inv_sigma, first_point=0):
         """One tangent-plane repulsion move (levelset_sampling.py:268-284) of a single cloud.
         points (1,P,3); normals_init un-normalised (normalised on the fly in the kernel);
-        idx (1,P,K) int64 view (row stride may exceed K); inv_sigma: device scalar."""
+        idx (1,n,K) int64 view (row stride may exceed K) for the n points starting at
+        `first_point` (n = P, first_point = 0 unless the cloud is sharded over ranks);
+        inv_sigma: device scalar.  Returns the moved (1,n,3) points."""
         assert points.shape[0] == 1, "resample supports one cloud (as the reference, :256,:274)"
-        P, K = points.shape[1], idx.shape[-1]
+        n, K = idx.shape[1], idx.shape[-1]
         pts = points[0].contiguous()
         nrm = normals_init[0].contiguous()
-        assert idx.stride(-1) == 1
-        out = torch.empty_like(pts)
+        assert idx.stride(-1) == 1 and first_point + n <= pts.shape[0]
+        out = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
         _lib.call("iso_repulse", _lib.ptr(pts), _lib.ptr(nrm), _c_ptr(idx), int(idx.stride(-2)),
-                  _lib.ptr(out), P, K, _lib.ptr(inv_sigma), _lib.stream())
-        return out.view(1, P, 3)
+                  _lib.ptr(out), n, int(first_point), K, _lib.ptr(inv_sigma), _lib.stream())
+        return out.view(1, n, 3)
 
     def resample(self, model, points_init, normals_init, num_points, sample_iters=None,
                  **forward_kwargs) -> ProjectionResult:

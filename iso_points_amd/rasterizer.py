@@ -95,11 +95,12 @@ class _CNamespace(object):
     @staticmethod
     def splat_points(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
                      num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel,
-                     bin_size=0, max_points_per_bin=0):
+                     bin_size=0, max_points_per_bin=0, tile_rows=None, out=None):
         """-> (idx i32 (N,S,S,K), zbuf, qvalue f32 (N,S,S,K), occupancy f32 (N,S,S)).
         bin_size / max_points_per_bin are accepted and ignored: binning is internal (16x16 tiles,
         exact-size pair list), so the reference's num_bins<22 / max_points_per_bin limits do not
-        exist here."""
+        exist here.  tile_rows=(begin, end) (extension, used by the sharded path) rasterises
+        only that band of 16-pixel tile rows (NDC pixel order) into `out` (or fresh -1/0 tensors)."""
         if not points.is_cuda:
             raise RuntimeError("iso_points_amd._C.splat_points: tensors must be on the GPU; there is no CPU path")
         K, S = int(points_per_pixel), int(image_size)
@@ -116,19 +117,29 @@ class _CNamespace(object):
         first, num = _i64c(cloud_to_packed_first_idx), _i64c(num_points_per_cloud)
         if hasattr(num_points_per_cloud, "_iso_host"):
             num._iso_host = num_points_per_cloud._iso_host
-        idx = torch.empty((N, S, S, K), dtype=torch.int32, device=dev)
-        zbuf = torch.empty((N, S, S, K), dtype=torch.float32, device=dev)
-        qv = torch.empty((N, S, S, K), dtype=torch.float32, device=dev)
-        occ = torch.empty((N, S, S), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        T = lib.iso_splat_tiles_per_side(S) if S > 0 else 0
+        band = (0, T) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
+        if out is not None:
+            idx, zbuf, qv, occ = out
+        elif band == (0, T):
+            idx = torch.empty((N, S, S, K), dtype=torch.int32, device=dev)
+            zbuf = torch.empty((N, S, S, K), dtype=torch.float32, device=dev)
+            qv = torch.empty((N, S, S, K), dtype=torch.float32, device=dev)
+            occ = torch.empty((N, S, S), dtype=torch.float32, device=dev)
+        else:
+            idx = torch.full((N, S, S, K), -1, dtype=torch.int32, device=dev)
+            zbuf = torch.full((N, S, S, K), -1.0, dtype=torch.float32, device=dev)
+            qv = torch.full((N, S, S, K), -1.0, dtype=torch.float32, device=dev)
+            occ = torch.zeros((N, S, S), dtype=torch.float32, device=dev)
         if N == 0 or S == 0:
             return idx, zbuf, qv, occ
-        lib = _lib.load()
-        T = lib.iso_splat_tiles_per_side(S)
         ntiles = N * T * T
         maxp = _max_pts(num)
         p, s = _lib.ptr, _lib.stream()
         tile_cnt = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)
-        _lib.call("iso_splat_bin_count", p(pts), p(ra), p(first), p(num), N, maxp, S, p(tile_cnt), s)
+        _lib.call("iso_splat_bin_count", p(pts), p(ra), p(first), p(num), N, maxp, S, band[0], band[1],
+                  p(tile_cnt), s)
         tile_off = torch.empty_like(tile_cnt)
         ws_b = lib.iso_prefix_sum_workspace_bytes(ntiles + 1, 1)
         ws = torch.empty((ws_b,), dtype=torch.uint8, device=dev)
@@ -137,7 +148,7 @@ class _CNamespace(object):
         pairs = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
         cursor = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)   # [ntiles] = overflow flag
         _lib.call("iso_splat_forward", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
-                  float(depth_merging_thres), S, K, p(cursor), p(tile_off), p(pairs), total,
+                  float(depth_merging_thres), S, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
                   _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), s)
         return idx, zbuf, qv, occ
 
@@ -358,7 +369,7 @@ class SurfaceSplatting(object):
             padded[i, :lens[i]] = points_f[firsts[i]:firsts[i] + lens[i]]
         dists, _, _, _ = frnn.frnn_grid_points(padded, padded, num, num, K=7, r=self.frnn_radius)
         h = torch.empty((tot,), dtype=torch.float32, device=dev)
-        _lib.call("iso_splat_vrk_h", p(dists), p(first), p(num), p(h), N, dists.shape[1], s)
+        _lib.call("iso_splat_vrk_h", p(dists), p(first), p(num), None, p(h), N, dists.shape[1], s)
         self._Vrk_h = h
         ndc = torch.empty((tot, 3), dtype=torch.float32, device=dev)
         ellipse = torch.empty((tot, 3), dtype=torch.float32, device=dev)
