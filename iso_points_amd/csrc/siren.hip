@@ -261,6 +261,10 @@ __global__ __launch_bounds__(256, 2) void k_siren_step(SirenArgs a) {
       px = a.pts[idx * 3]; py = a.pts[idx * 3 + 1]; pz = a.pts[idx * 3 + 2];
     }
     // ---- layer 0 (3 -> H) on the VALU -------------------------------------
+    // The TOP sine layer needs no stash: its adjoint seed is the head weight, so
+    // gs = WL * w cos(w z) is formed on the spot (and the head dot product with it).
+    float f = 0.f;
+    const bool top0 = (a.L == 0);
     for (int e4 = 0; e4 < NT; ++e4) {
       f32x4 h4, s4;
 #pragma unroll
@@ -272,8 +276,13 @@ __global__ __launch_bounds__(256, 2) void k_siren_step(SirenArgs a) {
         h4[i] = s;
         s4[i] = a.w0 * c;
       }
+      if (top0) {
+        const f32x4 w4 = reinterpret_cast<const f32x4*>(WLimg)[g * NT + e4];
+        f += (w4.x * h4.x + w4.y * h4.y) + (w4.z * h4.z + w4.w * h4.w);
+        h4 = (f32x4){w4.x * s4.x, w4.y * s4.y, w4.z * s4.z, w4.w * s4.w};
+      }
       reinterpret_cast<f32x4*>(hL)[e4 * 64 + lane] = h4;
-      reinterpret_cast<f32x4*>(stash)[e4 * 64 + lane] = s4;
+      if (!top0) reinterpret_cast<f32x4*>(stash)[e4 * 64 + lane] = s4;
     }
     // ---- hidden layers, forward -------------------------------------------
     f32x4 acc[NT];
@@ -281,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void k_siren_step(SirenArgs a) {
       const float* base = a.packed + off_hidden(H, l);
       gemm_pass<NT, true>(base + H, base, hL, wbuf, acc, lane, g);
       float* st_l = stash + (int64_t)(l + 1) * NT * 256;
+      const bool top = (l == a.L - 1);
       // pre-activations go back to this wave's LDS slab (static register
       // indices), then a rolled loop applies sin / stashes w*cos
 #pragma unroll
@@ -295,26 +305,21 @@ __global__ __launch_bounds__(256, 2) void k_siren_step(SirenArgs a) {
           h4[i] = s;
           s4[i] = a.wh * c;
         }
-        reinterpret_cast<f32x4*>(hL)[e4 * 64 + lane] = h4;
-        reinterpret_cast<f32x4*>(st_l)[e4 * 64 + lane] = s4;
+        if (top) {
+          const f32x4 w4 = reinterpret_cast<const f32x4*>(WLimg)[g * NT + e4];
+          f += (w4.x * h4.x + w4.y * h4.y) + (w4.z * h4.z + w4.w * h4.w);
+          h4 = (f32x4){w4.x * s4.x, w4.y * s4.y, w4.z * s4.z, w4.w * s4.w};
+          reinterpret_cast<f32x4*>(hL)[e4 * 64 + lane] = h4;
+        } else {
+          reinterpret_cast<f32x4*>(hL)[e4 * 64 + lane] = h4;
+          reinterpret_cast<f32x4*>(st_l)[e4 * 64 + lane] = s4;
+        }
       }
     }
-    // ---- head (H -> 1) and adjoint seed -----------------------------------
-    float f = 0.f;
-    {
-      const float* st_top = stash + (int64_t)a.L * NT * 256;
-      for (int e4 = 0; e4 < NT; ++e4) {
-        const f32x4 h4 = reinterpret_cast<const f32x4*>(hL)[e4 * 64 + lane];
-        const f32x4 w4 = reinterpret_cast<const f32x4*>(WLimg)[g * NT + e4];
-        const f32x4 s4 = reinterpret_cast<const f32x4*>(st_top)[e4 * 64 + lane];
-        f += (w4.x * h4.x + w4.y * h4.y) + (w4.z * h4.z + w4.w * h4.w);
-        f32x4 gs = {w4.x * s4.x, w4.y * s4.y, w4.z * s4.z, w4.w * s4.w};
-        reinterpret_cast<f32x4*>(hL)[e4 * 64 + lane] = gs;
-      }
-      f += __shfl_xor(f, 16);
-      f += __shfl_xor(f, 32);
-      f += bL;
-    }
+    // ---- head: finish the dot product across the 4 lane groups ---------------
+    f += __shfl_xor(f, 16);
+    f += __shfl_xor(f, 32);
+    f += bL;
     // ---- hidden layers, reverse -------------------------------------------
     for (int l = a.L - 1; l >= 0; --l) {
       const float* base = a.packed + off_hidden(H, l);
