@@ -157,7 +157,10 @@ int iso_frnn_counting_sort(const float* points, const int64_t* lengths,
  * points1 == NULL means "cloud 2 queried against itself": queries are then
  * processed in cell order (neighbouring lanes walk the same cells) and rows
  * are written at their original index.
- * sorted2 / sorted_idx2 / off come from the build calls above.               */
+ * sorted2 / sorted_idx2 / off come from the build calls above.
+ * workspace (iso_frnn_query_workspace_bytes): list of the queries a single lane could not
+ * finish within two rings of cells; a second kernel serves each of them with a whole wave. */
+int64_t iso_frnn_query_workspace_bytes(int n_clouds, int64_t p1_stride);
 int iso_frnn_query(const float* points1, const int64_t* lengths1,
                    const float* points2, const float* sorted2,
                    const int32_t* sorted_idx2,
@@ -165,7 +168,8 @@ int iso_frnn_query(const float* points1, const int64_t* lengths1,
                    const float* grid_params, const float* radius, int K,
                    float* dists_out, int64_t* idxs_out, float* nn_out,
                    int n_clouds, int64_t p1_stride, int64_t p2_stride,
-                   int64_t g_stride, void* stream);
+                   int64_t g_stride, void* workspace, int64_t workspace_bytes,
+                   void* stream);
 
 /* frnn.frnn_gather: out[n,i,k,:] = x[n, idx[n,i,k], :], zeros where idx < 0.
  * x (N,P2,U) f32, idx (N,P1,K) i64, out (N,P1,K,U).                           */

@@ -36,7 +36,8 @@ SIGNATURES = {
     "iso_prefix_sum": (_I, [_P, _P, _L, _I, _L, _P, _L, _P]),
     "iso_frnn_scan_cells": (_I, [_P, _P, _P, _I, _L, _I, _P, _L, _P]),
     "iso_frnn_counting_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),
-    "iso_frnn_query": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _L, _L, _L, _P]),
+    "iso_frnn_query_workspace_bytes": (_L, [_I, _L]),
+    "iso_frnn_query": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _L, _L, _L, _P, _L, _P]),
     "iso_frnn_gather": (_I, [_P, _P, _P, _I, _L, _L, _I, _I, _P]),
     "iso_repulse": (_I, [_P, _P, _P, _L, _P, _L, _L, _I, _P, _P]),
     "iso_splat_view_flags": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _I, _P]),

@@ -319,6 +319,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_final(
 }
 
 // ---- query ----------------------------------------------------------------
+constexpr int kRingCap = 2;
+
 __device__ __forceinline__ bool pair_lt(float d1, int i1, float d2, int i2) {
   return d1 < d2 || (d1 == d2 && i1 < i2);
 }
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void k_query(
     const float* __restrict__ params, const float* __restrict__ radius, int K,
     float* __restrict__ dists_out, int64_t* __restrict__ idxs_out,
     float* __restrict__ nn_out, int64_t p1_stride, int64_t p2_stride,
-    int64_t g_stride) {
+    int64_t g_stride, int32_t* __restrict__ tail_list, int32_t* __restrict__ tail_count) {
   const int n = blockIdx.y;
   const bool self = (points1 == nullptr);
   const int64_t len2 = lengths2 ? lengths2[n] : p2_stride;
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(256) void k_query(
     best.init();
     float wd = FLT_MAX;      // current K-th best (d2, idx)
     int wi = 0x7fffffff;
+    bool unfinished = false;
     if (len2 > 0 && r > 0.f && qx == qx && qy == qy && qz == qz) {
       // unclamped integer cell of the query (may lie outside the grid)
       float fx = floorf((qx - mnx) * delta), fy = floorf((qy - mny) * delta),
@@ -415,7 +418,13 @@ __global__ __launch_bounds__(256) void k_query(
       int rho0 = max(gapx, max(gapy, gapz));
       int span = max(rx, max(ry, rz)) + rho0;  // beyond this no cell exists
       int rho_max = (rho_f < (float)span) ? (int)rho_f : span;
-      for (int rho = rho0; rho <= rho_max; ++rho) {
+      // A lane walks at most kRingCap rings itself; the rare query that is still open after
+      // that (an isolated point, a huge radius) is handed to k_query_tail, where a whole
+      // wave sweeps the remaining cell columns -- one slow lane would otherwise hold up its
+      // wave for thousands of dependent loads.
+      const int rho_stop = min(rho_max, rho0 + kRingCap);
+      unfinished = rho_stop < rho_max;
+      for (int rho = rho0; rho <= rho_stop; ++rho) {
         const int x0 = max(cx - rho, 0), x1 = min(cx + rho, rx - 1);
         const int y0 = max(cy - rho, 0), y1 = min(cy + rho, ry - 1);
         for (int x = x0; x <= x1; ++x) {
@@ -454,10 +463,16 @@ __global__ __launch_bounds__(256) void k_query(
         }
         if (rho >= 1) {
           float g = (float)rho * cell * 0.999f;
-          if (g >= r) break;
-          if (wd < FLT_MAX && wd <= g * g) break;
+          if (g >= r) { unfinished = false; break; }
+          if (wd < FLT_MAX && wd <= g * g) { unfinished = false; break; }
         }
       }
+    }
+    if (unfinished) {
+      // row left for the tail kernel (it recomputes the query from scratch)
+      const int slot = atomicAdd(tail_count + n, 1);
+      tail_list[(int64_t)n * p1_stride + slot] = (int32_t)t;
+      continue;
     }
     // write the row
     float* drow = dists_out + ((int64_t)n * p1_stride + row) * K;
@@ -480,6 +495,168 @@ __global__ __launch_bounds__(256) void k_query(
       }
     }
   }
+}
+
+
+// One WAVE per unfinished query.  The wave walks the same Chebyshev shells as k_query, but the
+// lanes split each shell's cell columns (an edge column is one contiguous z-run, an interior
+// column its two cap cells) and keep private top-K lists.  After every shell the global K-th
+// distance is obtained by K rounds of a wave-wide arg-min over the lanes' list heads, and the
+// same stopping rule as k_query is applied; the final K results come out of the same merge --
+// identical (d2, idx) order, so the output does not depend on which kernel served a query.
+template <int KMAX>
+__device__ __forceinline__ void wave_merge(const TopK<KMAX>& best, int K, float& kth, float* drow,
+                                           int64_t* irow, float* nnrow, const float* pts2, int lane) {
+  // kth = K-th merged distance (FLT_MAX if fewer than K); when drow != null lane 0 also writes
+  // the merged row (dists, idxs, optional nn)
+  int head = 0;
+  kth = FLT_MAX;
+  for (int k = 0; k < K; ++k) {
+    float hd = FLT_MAX;
+    int hi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) if (j == head) { hd = best.d[j]; hi = best.id[j]; }
+    float md = hd;
+    int mi = hi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float od = __shfl_xor(md, o);
+      int oi = __shfl_xor(mi, o);
+      if (pair_lt(od, oi, md, mi)) { md = od; mi = oi; }
+    }
+    if (hd == md && hi == mi && md < FLT_MAX) ++head;   // the winner pops its head
+    if (k == K - 1) kth = md;
+    if (drow && lane == 0) {
+      const bool ok = md < FLT_MAX;
+      drow[k] = ok ? md : -1.0f;
+      irow[k] = ok ? (int64_t)mi : (int64_t)-1;
+      if (nnrow) {
+        if (ok) {
+          const float* sp = pts2 + (int64_t)mi * 3;
+          nnrow[k * 3] = sp[0]; nnrow[k * 3 + 1] = sp[1]; nnrow[k * 3 + 2] = sp[2];
+        } else {
+          nnrow[k * 3] = 0.f; nnrow[k * 3 + 1] = 0.f; nnrow[k * 3 + 2] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(64) void k_query_tail(
+    const float* __restrict__ points1, const int64_t* __restrict__ lengths1,
+    const float* __restrict__ points2, const float* __restrict__ sorted2,
+    const int32_t* __restrict__ sorted_idx2, const int64_t* __restrict__ lengths2,
+    const int32_t* __restrict__ off, const float* __restrict__ params,
+    const float* __restrict__ radius, int K, float* __restrict__ dists_out,
+    int64_t* __restrict__ idxs_out, float* __restrict__ nn_out, int64_t p1_stride,
+    int64_t p2_stride, int64_t g_stride, const int32_t* __restrict__ tail_list,
+    const int32_t* __restrict__ tail_count) {
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x;
+  const bool self = (points1 == nullptr);
+  const int64_t len2 = lengths2 ? lengths2[n] : p2_stride;
+  const float* gp = params + n * ISO_GRID3_PARAMS;
+  const float mnx = gp[0], mny = gp[1], mnz = gp[2], delta = gp[3];
+  const int rx = (int)gp[4], ry = (int)gp[5], rz = (int)gp[6];
+  const int total = (int)gp[7];
+  const float r = radius[n];
+  const float r2 = r * r;
+  const float cell = 1.0f / delta;
+  const float* s2 = sorted2 + (int64_t)n * p2_stride * 3;
+  const int32_t* sidx = sorted_idx2 + (int64_t)n * p2_stride;
+  const int32_t* offn = off + (int64_t)n * g_stride;
+  const int count = tail_count[n];
+  for (int w = blockIdx.x; w < count; w += gridDim.x) {
+    const int64_t t = tail_list[(int64_t)n * p1_stride + w];
+    float qx, qy, qz;
+    int64_t row;
+    if (self) {
+      qx = s2[t * 3]; qy = s2[t * 3 + 1]; qz = s2[t * 3 + 2];
+      row = sidx[t];
+    } else {
+      const float* q = points1 + ((int64_t)n * p1_stride + t) * 3;
+      qx = q[0]; qy = q[1]; qz = q[2];
+      row = t;
+    }
+    const float lim = 1.0e6f;
+    const int cx = (int)fminf(fmaxf(floorf((qx - mnx) * delta), -lim), lim);
+    const int cy = (int)fminf(fmaxf(floorf((qy - mny) * delta), -lim), lim);
+    const int cz = (int)fminf(fmaxf(floorf((qz - mnz) * delta), -lim), lim);
+    const float rho_f = ceilf(r * delta * 1.0011f);
+    const int gapx = cx < 0 ? -cx : (cx >= rx ? cx - rx + 1 : 0);
+    const int gapy = cy < 0 ? -cy : (cy >= ry ? cy - ry + 1 : 0);
+    const int gapz = cz < 0 ? -cz : (cz >= rz ? cz - rz + 1 : 0);
+    const int rho0 = max(gapx, max(gapy, gapz));
+    const int span = max(rx, max(ry, rz)) + rho0;
+    const int rho_max = (rho_f < (float)span) ? (int)rho_f : span;
+    TopK<KMAX> best;
+    best.init();
+    float wd = FLT_MAX;
+    int wi = 0x7fffffff;
+    int found = 0;   // candidates within r seen by this lane (capped: only >= K matters)
+    for (int rho = rho0; rho <= rho_max; ++rho) {
+      const int x0 = max(cx - rho, 0), x1 = min(cx + rho, rx - 1);
+      const int y0 = max(cy - rho, 0), y1 = min(cy + rho, ry - 1);
+      if (x0 <= x1 && y0 <= y1) {
+        const int ny = y1 - y0 + 1;
+        const int ncols = (x1 - x0 + 1) * ny;
+        for (int col = lane; col < ncols; col += 64) {
+          const int x = x0 + col / ny, y = y0 + col % ny;
+          const bool edge = (x == cx - rho) || (x == cx + rho) || (y == cy - rho) || (y == cy + rho);
+          const int nseg = edge ? 1 : (rho == 0 ? 1 : 2);
+          for (int sgm = 0; sgm < nseg; ++sgm) {
+            int za, zb;
+            if (edge) { za = cz - rho; zb = cz + rho; }
+            else if (sgm == 0) { za = cz - rho; zb = cz - rho; }
+            else { za = cz + rho; zb = cz + rho; }
+            za = max(za, 0); zb = min(zb, rz - 1);
+            if (za > zb) continue;
+            const int c0 = (x * ry + y) * rz + za, c1 = (x * ry + y) * rz + zb;
+            const int64_t i0 = offn[c0];
+            const int64_t i1 = (c1 + 1 < total) ? (int64_t)offn[c1 + 1] : len2;
+            for (int64_t i = i0; i < i1; ++i) {
+              float dx = qx - s2[i * 3], dy = qy - s2[i * 3 + 1], dz = qz - s2[i * 3 + 2];
+              float d2 = (dx * dx + dy * dy) + dz * dz;
+              if (d2 < r2) {
+                if (found < KMAX) ++found;
+                if (d2 <= wd) {
+                  int oi = sidx[i];
+                  if (pair_lt(d2, oi, wd, wi)) {
+                    best.push(d2, oi, K);
+                    wd = best.worst(K);
+                    wi = best.worst_id(K);
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      if (rho >= 1) {
+        const float g = (float)rho * cell * 0.999f;
+        if (g >= r) break;
+        int tot = found;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        if (tot >= K) {                       // wave-uniform
+          float kth;
+          wave_merge<KMAX>(best, K, kth, nullptr, nullptr, nullptr, nullptr, lane);
+          if (kth < FLT_MAX && kth <= g * g) break;
+        }
+      }
+    }
+    float kth;
+    wave_merge<KMAX>(best, K, kth, dists_out + ((int64_t)n * p1_stride + row) * K,
+                     idxs_out + ((int64_t)n * p1_stride + row) * K,
+                     nn_out ? nn_out + ((int64_t)n * p1_stride + row) * K * 3 : nullptr,
+                     points2 ? points2 + (int64_t)n * p2_stride * 3 : nullptr, lane);
+  }
+}
+
+__global__ void k_zero_i32(int32_t* p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
 }
 
 // nn gather for the query result: nn[n,i,k,:] = points2[n, idx[n,i,k], :]
@@ -648,6 +825,12 @@ extern "C" int iso_frnn_gather(const float* x, const int64_t* idx, float* out,
   return ISO_OK;
 }
 
+extern "C" int64_t iso_frnn_query_workspace_bytes(int n_clouds, int64_t p1_stride) {
+  if (n_clouds < 0) n_clouds = 0;
+  if (p1_stride < 0) p1_stride = 0;
+  return 4 * (64 * (int64_t)((n_clouds + 63) / 64) + (int64_t)n_clouds * p1_stride);
+}
+
 extern "C" int iso_frnn_query(const float* points1, const int64_t* lengths1,
                               const float* points2, const float* sorted2,
                               const int32_t* sorted_idx2,
@@ -655,7 +838,8 @@ extern "C" int iso_frnn_query(const float* points1, const int64_t* lengths1,
                               const float* grid_params, const float* radius, int K,
                               float* dists_out, int64_t* idxs_out, float* nn_out,
                               int n_clouds, int64_t p1_stride, int64_t p2_stride,
-                              int64_t g_stride, void* stream) {
+                              int64_t g_stride, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
   ISO_REQUIRE(K >= 1 && K <= 32, ISO_ERR_UNSUPPORTED, "iso_frnn_query: K must be in [1,32], got %d", K);
   ISO_REQUIRE(n_clouds >= 0 && p1_stride >= 0 && p2_stride >= 0, ISO_ERR_INVALID, "iso_frnn_query: bad sizes");
   if (n_clouds == 0 || p1_stride == 0) return ISO_OK;
@@ -664,17 +848,28 @@ extern "C" int iso_frnn_query(const float* points1, const int64_t* lengths1,
   ISO_REQUIRE(points1 || p1_stride == p2_stride, ISO_ERR_INVALID,
               "iso_frnn_query: self query needs p1_stride == p2_stride");
   ISO_REQUIRE(!nn_out || points2, ISO_ERR_INVALID, "iso_frnn_query: nn_out needs points2");
+  ISO_REQUIRE(workspace && workspace_bytes >= iso_frnn_query_workspace_bytes(n_clouds, p1_stride),
+              ISO_ERR_WORKSPACE, "iso_frnn_query: workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  int32_t* tail_count = (int32_t*)workspace;                 // [n_clouds] (padded to 64 ints)
+  int32_t* tail_list = tail_count + 64 * ((n_clouds + 63) / 64);
+  hipLaunchKernelGGL(k_zero_i32, dim3(iso_div_up(n_clouds, 64)), dim3(64), 0, s, tail_count, n_clouds);
   int gx = iso_div_up(p1_stride, 256);
   if (gx > 65535) gx = 65535;
 #define ISO_LAUNCH_Q(KM)                                                          \
   hipLaunchKernelGGL(k_query<KM>, dim3(gx, n_clouds), dim3(256), 0, s, points1,   \
                      lengths1, points2, sorted2, sorted_idx2, lengths2, off, grid_params,  \
                      radius, K, dists_out, idxs_out, nn_out, p1_stride, p2_stride, \
-                     g_stride)
-  if (K <= 8) ISO_LAUNCH_Q(8);
-  else if (K <= 16) ISO_LAUNCH_Q(16);
-  else ISO_LAUNCH_Q(32);
+                     g_stride, tail_list, tail_count);                            \
+  hipLaunchKernelGGL(k_query_tail<KM>, dim3(tail_blocks, n_clouds), dim3(64), 0, s, points1,      \
+                     lengths1, points2, sorted2, sorted_idx2, lengths2, off, grid_params,         \
+                     radius, K, dists_out, idxs_out, nn_out, p1_stride, p2_stride, g_stride,      \
+                     tail_list, tail_count)
+  int tail_blocks = (int)(p1_stride < 2048 ? p1_stride : 2048);
+  if (tail_blocks < 1) tail_blocks = 1;
+  if (K <= 8) { ISO_LAUNCH_Q(8); }
+  else if (K <= 16) { ISO_LAUNCH_Q(16); }
+  else { ISO_LAUNCH_Q(32); }
 #undef ISO_LAUNCH_Q
   ISO_CHECK_LAUNCH("iso_frnn_query");
   return ISO_OK;

@@ -438,8 +438,10 @@ __global__ __launch_bounds__(256) void k_splat_backward(
     float gx = 0.f, gy = 0.f, gz = 0.f;
     const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
     const float rx = radii[p * 2], ry = radii[p * 2 + 1];
-    // ---- z: sum grad_zbuf over the fragment slots that list this point (pixel order)
-    if (grad_zbuf) {
+    // ---- z: sum grad_zbuf over the fragment slots that list this point (pixel order).
+    // A point that is listed anywhere is "visible" (lists are packed, so its pixel's first
+    // slot is filled): everything else has no z gradient and is skipped.
+    if (grad_zbuf && (!visible || visible[p])) {
       int x0, x1, y0, y1;
       if (pz >= 0.f && out_range(px, rx, S, x0, x1) && out_range(py, ry, S, y0, y1)) {
         for (int yo = y0; yo <= y1; ++yo)

@@ -110,10 +110,13 @@ def frnn_grid_points(points1, points2, lengths1=None, lengths2=None, K=-1, r=-1,
             if nn is not None:
                 nn.zero_()
         p = _lib.ptr
+        ws_bytes = _lib.load().iso_frnn_query_workspace_bytes(N, P1)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         _lib.call("iso_frnn_query", None if self_query else p(p1), None if self_query else p(l1),
                   p(p2), p(grid.sorted_points), p(grid.sorted_idx), p(l2), p(grid.off),
                   p(grid.params), p(radius), K, p(dists), p(idxs), p(nn) if nn is not None else None,
-                  N, P1, P2, _G3_MAX, _lib.stream())
+                  N, P1, P2, _G3_MAX, p(ws), ws_bytes, _lib.stream())
+        grid.tail_counts = ws[: 4 * N].view(torch.int32)   # diagnostics: queries served by the tail kernel
     return dists, idxs, nn, grid
 
 

@@ -177,3 +177,21 @@ def test_prefix_sum_sizes(dev, n):
     prefix_sum_cuda(cnt, n, off)
     ref = torch.cumsum(cnt.long(), 0) - cnt.long()
     assert torch.equal(off.long(), ref)
+
+
+@pytest.mark.parametrize("K", [7, 20])
+def test_tail_kernel_isolated_queries(dev, K):
+    """Queries a single lane cannot finish within two rings of cells (isolated outliers next to a
+    dense surface, large radius) are served by the wave-per-query tail kernel: same exact result."""
+    g = torch.Generator().manual_seed(77)
+    dense = sphere_cloud(60000, seed=5)
+    outl = torch.nn.functional.normalize(torch.randn(1, 40, 3, generator=g), dim=-1) * \
+        (1.0 + 0.05 + 0.1 * torch.rand(1, 40, 1, generator=g))
+    far = torch.tensor([[[3.0, 3.0, 3.0], [-2.5, 0.0, 0.0]]])
+    p = torch.cat([dense, outl, far], dim=1)
+    d, i, nn, grid = _cmp(dev, p, p, None, None, K, 0.2, same=True)
+    assert int(grid.tail_counts.sum()) > 0
+    # separate query set with points far outside the grid box
+    q = torch.cat([outl * 1.5, far + 0.1, dense[:, :100]], dim=1)
+    d, i, nn, grid = _cmp(dev, q, p, None, None, K, 0.45)
+    assert int(grid.tail_counts.sum()) > 0
