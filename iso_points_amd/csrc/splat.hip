@@ -413,6 +413,21 @@ __global__ void k_grad_blocks(const float* __restrict__ grad_occ, int S, int NB,
   }
 }
 
+// second level: 64x64-pixel super blocks (8x8 of the 8x8 blocks)
+__global__ void k_grad_superblocks(const uint8_t* __restrict__ blk, int NB, int NB2, int N,
+                                   uint8_t* __restrict__ blk2) {
+  const int64_t total = (int64_t)N * NB2 * NB2;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    const int bx = b % NB2, by = (b / NB2) % NB2, n = b / ((int64_t)NB2 * NB2);
+    uint8_t any = 0;
+    for (int y = by * 8; y < min(NB, (by + 1) * 8) && !any; ++y)
+      for (int x = bx * 8; x < min(NB, (bx + 1) * 8); ++x)
+        if (blk[((int64_t)n * NB + y) * NB + x]) { any = 1; break; }
+    blk2[b] = any;
+  }
+}
+
 // output-pixel range [lo,hi] (after the axis flip) whose centres may lie within c +- r
 __device__ __forceinline__ bool out_range(float c, float r, int S, int& lo, int& hi) {
   int a, b;
@@ -427,6 +442,7 @@ __global__ __launch_bounds__(256) void k_splat_backward(
     const uint8_t* __restrict__ visible, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num,
     const float* __restrict__ grad_occ, const uint8_t* __restrict__ blk,
+    const uint8_t* __restrict__ blk2, int NB2,
     const int32_t* __restrict__ idx, const float* __restrict__ grad_zbuf, int S, int K, int NB,
     int rect_mode, float radii_s, float* __restrict__ grad /* (P,3) */) {
   const int n = blockIdx.y;
@@ -463,34 +479,59 @@ __global__ __launch_bounds__(256) void k_splat_backward(
         sx > 0.f && sy > 0.f) {
       int x0, x1, y0, y1;
       if (out_range(px, sx, S, x0, x1) && out_range(py, sy, S, y0, y1)) {
-        for (int yo = y0; yo <= y1; ++yo) {
-          const float yf = pix_to_ndc(S - 1 - yo, S);
-          const float dy = yf - py;
-          for (int xo = x0; xo <= x1; ++xo) {
-            if ((xo & (GB - 1)) == 0 || xo == x0) {
-              // skip 8-pixel runs without any gradient
-              if (!blk[((int64_t)n * NB + yo / GB) * NB + xo / GB]) {
-                xo = (xo / GB) * GB + GB - 1;
-                continue;
+        // level 2: does any 64x64 super block under the window hold a gradient at all?
+        bool any2 = false;
+        for (int sy2 = y0 / 64; sy2 <= y1 / 64 && !any2; ++sy2)
+          for (int sx2 = x0 / 64; sx2 <= x1 / 64; ++sx2)
+            if (blk2[((int64_t)n * NB2 + sy2) * NB2 + sx2]) { any2 = true; break; }
+        if (any2) {
+          // walk 8-row bands; per band fetch the 8x8-block flags once (bit i = block bx0+i),
+          // then visit the pixels of flagged blocks row by row -> image order is preserved
+          const int bx0 = x0 / GB, bx1 = x1 / GB;     // <= 256 blocks (image side <= 2048)
+          for (int by = y0 / GB; by <= y1 / GB; ++by) {
+            unsigned long long bits[4] = {0ull, 0ull, 0ull, 0ull};
+            bool anyb = false;
+            for (int bx = bx0; bx <= bx1; ++bx)
+              if (blk[((int64_t)n * NB + by) * NB + bx]) {
+                const int o = bx - bx0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if ((o >> 6) == c) bits[c] |= 1ull << (o & 63);
+                anyb = true;
+              }
+            if (!anyb) continue;
+            const int ya = max(y0, by * GB), yb = min(y1, by * GB + GB - 1);
+            for (int yo = ya; yo <= yb; ++yo) {
+              const float yf = pix_to_ndc(S - 1 - yo, S);
+              const float dy = yf - py;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                unsigned long long rem = bits[c];
+                while (rem) {
+                  const int bi = 64 * c + __ffsll((long long)rem) - 1;
+                  rem &= rem - 1;
+                  const int xa = max(x0, (bx0 + bi) * GB), xb = min(x1, (bx0 + bi) * GB + GB - 1);
+                  for (int xo = xa; xo <= xb; ++xo) {
+                    const float g = grad_occ[((int64_t)n * S + yo) * S + xo];
+                    if (g == 0.0f) continue;
+                    const float xf = pix_to_ndc(S - 1 - xo, S);
+                    const float dx = xf - px;
+                    const float dist2 = dx * dx + dy * dy;
+                    bool outside;
+                    if (rect_mode) {  // rasterize_points.cu:726-746 (slow CUDA kernel)
+                      if (fabsf(dx) > sx || fabsf(dy) > sy) continue;
+                      outside = (fabsf(dx) > sx / radii_s) || (fabsf(dy) > sy / radii_s);
+                    } else {          // rasterize_points_backward.cu:156-161 (fast kernel)
+                      if (dist2 > r2) continue;
+                      outside = (fabsf(dx) > rx) || (fabsf(dy) > ry);
+                    }
+                    if (g > 0.0f && outside) continue;
+                    const float denom = iso_eps_denom(dist2, 1e-10f);
+                    gx += dx / denom * g;
+                    gy += dy / denom * g;
+                  }
+                }
               }
             }
-            const float g = grad_occ[((int64_t)n * S + yo) * S + xo];
-            if (g == 0.0f) continue;
-            const float xf = pix_to_ndc(S - 1 - xo, S);
-            const float dx = xf - px;
-            const float dist2 = dx * dx + dy * dy;
-            bool outside;
-            if (rect_mode) {  // rasterize_points.cu:726-746 (slow CUDA kernel)
-              if (fabsf(dx) > sx || fabsf(dy) > sy) continue;
-              outside = (fabsf(dx) > sx / radii_s) || (fabsf(dy) > sy / radii_s);
-            } else {          // rasterize_points_backward.cu:156-161 (fast kernel)
-              if (dist2 > r2) continue;
-              outside = (fabsf(dx) > rx) || (fabsf(dy) > ry);
-            }
-            if (g > 0.0f && outside) continue;
-            const float denom = iso_eps_denom(dist2, 1e-10f);
-            gx += dx / denom * g;
-            gy += dy / denom * g;
           }
         }
       }
@@ -665,7 +706,8 @@ extern "C" int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbu
 
 extern "C" int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size) {
   int64_t nb = (image_size + GB - 1) / GB;
-  return (int64_t)n_clouds * nb * nb;
+  int64_t nb2 = (nb + 7) / 8;
+  return (int64_t)n_clouds * (nb * nb + nb2 * nb2);
 }
 
 extern "C" int iso_splat_backward(const float* points, const float* radii, const uint8_t* visible,
@@ -682,15 +724,20 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
               ISO_ERR_INVALID, "iso_splat_backward: null pointer");
   ISO_REQUIRE(workspace_bytes >= iso_splat_backward_workspace_bytes(n_clouds, image_size),
               ISO_ERR_WORKSPACE, "iso_splat_backward: workspace too small");
+  ISO_REQUIRE(image_size <= 2048, ISO_ERR_UNSUPPORTED, "iso_splat_backward: image_size must be <= 2048");
   hipStream_t s = (hipStream_t)stream;
   const int NB = (image_size + GB - 1) / GB;
   uint8_t* blk = (uint8_t*)workspace;
+  const int NB2 = (NB + 7) / 8;
+  uint8_t* blk2 = blk + (int64_t)n_clouds * NB * NB;
   hipLaunchKernelGGL(k_grad_blocks, dim3(iso_stream_grid((int64_t)n_clouds * NB * NB, 256)), dim3(256),
                      0, s, grad_occ, image_size, NB, n_clouds, blk);
+  hipLaunchKernelGGL(k_grad_superblocks, dim3(iso_stream_grid((int64_t)n_clouds * NB2 * NB2, 256)),
+                     dim3(256), 0, s, blk, NB, NB2, n_clouds, blk2);
   int gx = iso_div_up(max_pts, 256); if (gx > 8192) gx = 8192;
   hipLaunchKernelGGL(k_splat_backward, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, visible,
-                     search_radius, first_idx, num_pts, grad_occ, blk, idx, grad_zbuf, image_size,
-                     points_per_pixel, NB, rect_mode, radii_s, grad_points);
+                     search_radius, first_idx, num_pts, grad_occ, blk, blk2, NB2, idx, grad_zbuf,
+                     image_size, points_per_pixel, NB, rect_mode, radii_s, grad_points);
   ISO_CHECK_LAUNCH("iso_splat_backward");
   return ISO_OK;
 }
