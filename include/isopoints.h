@@ -195,6 +195,23 @@ int iso_repulse(const float* points, const float* normals, const int64_t* idx,
                 int64_t idx_row_stride, float* points_out, int64_t n,
                 int64_t first_point, int K, const float* inv_sigma, void* stream);
 
+/* Sparsest-edge candidates of point_processing.upsample
+ * (DSS/utils/point_processing.py:326-339): per point p with neighbours nn_k (knn (n,K,3)):
+ * mid_k = (nn_k + 2p)/3, spars_k = min_j |mid_k - nn_j|, sparsity = max_k spars_k,
+ * candidate = mid_argmax (first maximum).  K <= 64.                               */
+int iso_upsample_candidates(const float* points, const float* knn, int64_t n, int K,
+                            float* sparsity_out, float* candidates_out, void* stream);
+
+/* Farthest-point sampling = torch_cluster.fps as wlop uses it
+ * (DSS/utils/point_processing.py:473-499): per cloud n, out_idx[n, 0..n_samples[n]) =
+ * start[n], then repeatedly the point farthest from the chosen set (squared f32 distances,
+ * ties -> lowest index).  work: (N, p_stride) f32 scratch.  out_idx rows are left
+ * untouched beyond n_samples[n].                                                  */
+int iso_farthest_point_sampling(const float* points, const int64_t* lengths,
+                                const int64_t* n_samples, const int64_t* start, int n_clouds,
+                                int64_t p_stride, int64_t out_stride, float* work,
+                                int64_t* out_idx, void* stream);
+
 /* ------------------------------------------------------------------------
  * D. EWA surface splatting
  *    replaces SurfaceSplatting (DSS/core/rasterizer.py:103-661), the pybind module

@@ -86,3 +86,60 @@ extern "C" int iso_repulse(const float* points, const float* normals,
   ISO_CHECK_LAUNCH("iso_repulse");
   return ISO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Sparsest-edge candidates for point_processing.upsample (DSS/utils/point_processing.py:326-339):
+// for every point p with neighbours nn_0..nn_{K-1}:
+//   mid_k      = (nn_k + 2 p) / 3
+//   spars_k    = min_j | mid_k - nn_j |            (norm, not squared: :336-337)
+//   sparsity   = max_k spars_k ,  father_nb = argmax_k (first maximum)
+//   candidate  = mid_{father_nb}
+// The reference materialises the (N,P,K,K,3) difference tensor (11.5 kB/point at K=31); here one
+// lane keeps its K neighbours in LDS (K*12 B per lane) and never writes the K^2 distances.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_upsample_candidates(
+    const float* __restrict__ pts, const float* __restrict__ knn /*(n,K,3)*/, int64_t n, int K,
+    float* __restrict__ sparsity, float* __restrict__ cand /*(n,3)*/) {
+  extern __shared__ float s_nn[];   // [K*3][BLOCK]  (component-major: conflict-free per lane)
+  const int t = threadIdx.x;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + t; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+    for (int k = 0; k < K * 3; ++k) s_nn[k * BLOCK + t] = knn[i * K * 3 + k];
+    float best = -1.0f;
+    float bx = px, by = py, bz = pz;
+    for (int k = 0; k < K; ++k) {
+      const float mx = (s_nn[(k * 3) * BLOCK + t] + 2.0f * px) / 3.0f;
+      const float my = (s_nn[(k * 3 + 1) * BLOCK + t] + 2.0f * py) / 3.0f;
+      const float mz = (s_nn[(k * 3 + 2) * BLOCK + t] + 2.0f * pz) / 3.0f;
+      float mn = 3.0e38f;
+      for (int j = 0; j < K; ++j) {
+        const float dx = mx - s_nn[(j * 3) * BLOCK + t], dy = my - s_nn[(j * 3 + 1) * BLOCK + t],
+                    dz = mz - s_nn[(j * 3 + 2) * BLOCK + t];
+        const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+        mn = d < mn ? d : mn;
+      }
+      if (mn > best) { best = mn; bx = mx; by = my; bz = mz; }
+    }
+    sparsity[i] = best;
+    cand[i * 3] = bx; cand[i * 3 + 1] = by; cand[i * 3 + 2] = bz;
+  }
+}
+
+}  // namespace
+
+extern "C" int iso_upsample_candidates(const float* points, const float* knn, int64_t n, int K,
+                                       float* sparsity_out, float* candidates_out, void* stream) {
+  ISO_REQUIRE(n >= 0 && K >= 1 && K <= 64, ISO_ERR_INVALID, "iso_upsample_candidates: bad sizes (1 <= K <= 64)");
+  if (n == 0) return ISO_OK;
+  ISO_REQUIRE(points && knn && sparsity_out && candidates_out, ISO_ERR_INVALID,
+              "iso_upsample_candidates: null pointer");
+  constexpr int BLOCK = 64;
+  const size_t lds = (size_t)K * 3 * BLOCK * sizeof(float);
+  hipLaunchKernelGGL(k_upsample_candidates<BLOCK>, dim3(iso_stream_grid(n, BLOCK)), dim3(BLOCK), lds,
+                     (hipStream_t)stream, points, knn, n, K, sparsity_out, candidates_out);
+  ISO_CHECK_LAUNCH("iso_upsample_candidates");
+  return ISO_OK;
+}

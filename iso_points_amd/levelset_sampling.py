@@ -243,6 +243,65 @@ class UniformProjection(LevelSetProjection):
         return ProjectionResult(packed_to_padded(pts, lens), packed_to_padded(normals, lens),
                                 packed_to_padded(valid, lens, pad_value=False))
 
+    # -- insert / upsample ---------------------------------------------------------------
+    def insert(self, ref_pcl, points, num_points, current_knn_result=None):
+        """Insert points around high-metric reference points (levelset_sampling.py:172-233).
+        ref_pcl: an object with points_packed(), features_packed() (P_ref,1 metric),
+        num_points_per_cloud() -- one cloud.  Returns (points, num_points, child_pts, child_per_batch)."""
+        import math
+        from . import frnn as _frnn
+        batch_size = points.shape[0]
+        flat = points.reshape(-1, 3)
+        diag = (flat.max(dim=0).values - flat.min(0).values).norm().item()
+        num_ref_cloud = int(ref_pcl.num_points_per_cloud().item())
+        avg_spacing = math.sqrt(diag / num_ref_cloud)
+        patch_size = 8
+        knn_k = patch_size
+        search_radius = min(avg_spacing * knn_k, 0.2)
+        if current_knn_result is None:
+            dists, idxs, nn, _ = _frnn.frnn_grid_points(points, points, num_points, num_points, K=knn_k + 1,
+                                                        r=search_radius, grid=None, return_nn=True)
+            cur_idx = idxs[..., 1:]
+        else:
+            cur_idx = current_knn_result.idx
+        try:
+            metrics = ref_pcl.features_packed()
+            num_ref = metrics.shape[0]
+            threshold = min(metrics.median() * 2, metrics.max() * 0.5)
+            ref_all = ref_pcl.points_packed()
+            ref_pts = ref_all[(metrics > threshold).squeeze(-1)].view(1, -1, 3)
+            if ref_pts.shape[1] == 0 or ref_pts.shape[1] > min(50, int(num_ref / 20)):
+                top = metrics.sort(dim=0).indices[-max(min(50, int(num_ref / 20)), 1):, 0]
+                ref_pts = ref_all[top].view(1, -1, 3).expand(batch_size, -1, -1)
+            ref_b = ref_pts.expand(batch_size, -1, -1).contiguous()
+            dists_to_ref, _, _, _ = _frnn.frnn_grid_points(points, ref_b, lengths1=num_points, lengths2=None,
+                                                           K=1, return_nn=True, grid=None, r=search_radius * 4)
+            dists_to_ref = dists_to_ref.view(batch_size, -1)
+            dist_threshold = avg_spacing ** 2
+            father_pts_mask = (dists_to_ref < 4 * dist_threshold) & (dists_to_ref > 0)
+            father_pts = points[father_pts_mask]
+            mother_pts = _frnn.frnn_gather(points, cur_idx[..., -patch_size:].contiguous())
+            mother_pts = mother_pts[father_pts_mask]
+            child_pts = 2 * father_pts.unsqueeze(-2) / 3 + mother_pts / 3
+            child_per_batch = father_pts_mask.sum(-1) * mother_pts.shape[-2]
+            child_pts = child_pts.view(-1, 3)
+            lens = [int(x) for x in child_per_batch.tolist()]
+            child_pts = packed_to_padded(child_pts, lens) if sum(lens) > 0 else points.new_zeros((batch_size, 0, 3))
+            child_per_batch = with_host_lengths(child_per_batch, lens)
+        except Exception as e:  # same catch-all as the reference (:226-229)
+            import logging
+            logging.getLogger(__name__).error("Error occurred during insertion {}".format(e))
+            child_pts = points.new_zeros((batch_size, 0, 3))
+            child_per_batch = with_host_lengths(num_points.new_zeros((batch_size,)), [0] * batch_size)
+        points = torch.cat((points, child_pts), dim=1)
+        num_points = num_points + child_per_batch
+        return points, num_points, child_pts, child_per_batch
+
+    def upsample(self, points, n_points, model, num_points=None, **forward_kwargs):
+        """levelset_sampling.py:235-237."""
+        from .point_processing import upsample as _upsample
+        return _upsample(points, n_points, num_points=num_points, neighborhood_size=31)
+
     # -- resample ----------------------------------------------------------------------
     def repulsion_step(self, points, normals_init, idx, inv_sigma, first_point=0):
         """One tangent-plane repulsion move (levelset_sampling.py:268-284) of a single cloud.
@@ -291,9 +350,9 @@ class UniformProjection(LevelSetProjection):
                        skip_resampling: bool = False, skip_upsampling: bool = False, ref_pcl=None,
                        proj_max_iters: Optional[int] = None, sample_iters: Optional[int] = None,
                        **forward_kwargs):
-        """levelset_sampling.py:353-439.  The upsampling branches (insert / upsample) are the
-        SURVEY 8(f) 'next' rows and are not built yet: pass skip_upsampling=True."""
+        """levelset_sampling.py:353-439."""
         points_init, num_points = convert_pointclouds_to_tensor(point_clouds)
+        num_points_init = num_points
         proj_max_iters = proj_max_iters or self.proj_max_iters
         sample_iters = sample_iters or self.sample_iters
         with torch.no_grad():
@@ -309,12 +368,69 @@ class UniformProjection(LevelSetProjection):
                     model, points_projected, normals_projected, num_points, sample_iters=sample_iters,
                     **forward_kwargs)
                 num_points = valid_projection.sum(dim=-1)
-            if not skip_upsampling:
-                raise NotImplementedError(
-                    "project_points: insert/upsample (levelset_sampling.py:411-434) are not built yet; "
-                    "call with skip_upsampling=True")
+            if not skip_upsampling and ref_pcl is not None:                       # :411-424
+                points_projected, normals_projected, valid_projection = _filter_projection_result(
+                    ProjectionResult(points_projected, normals_projected, valid_projection))
+                num_points = valid_projection.sum(dim=-1)
+                _, _, new_points, num_new_points = self.insert(ref_pcl, points_projected, num_points)
+                if new_points.shape[1] > 0:
+                    npj, nnj, nvj = self._project_points(model, new_points, num_new_points, proj_max_iters=10,
+                                                         **forward_kwargs)
+                    points_projected = torch.cat([points_projected, npj], dim=1)
+                    normals_projected = torch.cat([normals_projected, nnj], dim=1)
+                    valid_projection = torch.cat([valid_projection, nvj], dim=1)
+            elif not skip_upsampling:                                             # :426-434
+                points_projected, normals_projected, valid_projection = _filter_projection_result(
+                    ProjectionResult(points_projected, normals_projected, valid_projection))
+                num_points = valid_projection.sum(dim=-1)
+                points_projected, num_points = self.upsample(points_projected, num_points_init, model,
+                                                             num_points, **forward_kwargs)
+                points_projected, normals_projected, valid_projection = self._project_points(
+                    model, points_projected, num_points, proj_max_iters=10, **forward_kwargs)
             return {"levelset_points": points_projected, "levelset_normals": normals_projected,
                     "mask": valid_projection}
+
+
+def mask_padded_to_list(values, mask):
+    """DSS/utils/__init__.py:119-146 for padded inputs: per cloud, the rows where mask is True."""
+    return [values[b][mask[b]] for b in range(values.shape[0])]
+
+
+def sample_uniform_iso_points(model, n_points, init_points=None, bounding_sphere_radius=1.0, generator=None,
+                              device=None):
+    """levelset_sampling.py:1405-1445: project 4n random points -> drop |p| >= R -> wlop ->
+    project + upsample(K=31) -> upsample(n) -> project.  Returns the iso-points (1, n', 3)
+    (the reference wraps them in a pytorch3d Pointclouds)."""
+    from .point_processing import upsample, wlop
+    projector = UniformProjection(max_points_per_pass=16000, proj_max_iters=10, proj_tolerance=5e-5, knn_k=8)
+    if init_points is None:
+        if device is None:
+            device = next(model.parameters()).device if any(True for _ in model.parameters()) else torch.device("cuda")
+        init_points = ((torch.rand((1, n_points * 4, 3), generator=generator) - 0.5) * 2 * bounding_sphere_radius)
+        init_points = init_points.to(device)
+    res = projector.project_points(init_points, model, skip_resampling=True, skip_upsampling=True)
+    boundary_mask = res["levelset_points"].norm(dim=-1) < bounding_sphere_radius
+    pts = mask_padded_to_list(res["levelset_points"], res["mask"] & boundary_mask.view_as(res["mask"]))[0]
+    pcl = pts.view(1, -1, 3).contiguous()
+    X, num_X = wlop(pcl, None, min(0.5, n_points / max(pcl.shape[1], 1)), generator=generator)
+    res = projector.project_points(_ClipLengths(X, num_X), model, skip_resampling=True, skip_upsampling=False)
+    pts = mask_padded_to_list(res["levelset_points"], res["mask"])[0].view(1, -1, 3).contiguous()
+    up, num_up = upsample(pts, n_points)
+    res = projector.project_points(_ClipLengths(up, num_up), model, skip_resampling=True, skip_upsampling=False)
+    return mask_padded_to_list(res["levelset_points"], res["mask"])[0].view(1, -1, 3)
+
+
+class _ClipLengths(object):
+    """Minimal Pointclouds stand-in: padded points + per-cloud lengths."""
+
+    def __init__(self, points_padded, num_points):
+        self._p, self._n = points_padded, num_points
+
+    def points_padded(self):
+        return self._p
+
+    def num_points_per_cloud(self):
+        return self._n
 
 
 def _c_ptr(t):

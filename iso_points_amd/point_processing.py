@@ -1,0 +1,203 @@
+"""Host-side mirror of the iso-point parts of DSS/utils/point_processing.py
+(SURVEY 8(a) rows a8/a9 and 8(f)):
+
+  upsample            point_processing.py:281-362   sparsest-edge midpoint insertion
+  wlop                point_processing.py:35-122    FPS subsample + 3 LOP iterations
+  farthest_sampling   point_processing.py:473-499   (torch_cluster.fps)
+  knn_points          pytorch3d.ops.knn_points as upsample uses it (:315,:358)
+
+Inputs are padded tensors (N,P,3) + lengths (pytorch3d's Pointclouds container is out of scope;
+objects exposing points_padded()/num_points_per_cloud() are accepted).  Neighbour search, the
+K^2 sparsity scan and FPS run in libisopoints_hip.so; the remaining glue is a handful of torch
+ops on the GPU, exactly where the reference has them.
+"""
+import math
+from collections import namedtuple
+
+import torch
+
+from . import _lib
+from . import frnn
+from .levelset_sampling import (cloud_diag, convert_pointclouds_to_tensor, eps_denom, full_lengths, host_lengths,
+                                with_host_lengths)
+
+_KNN = namedtuple("KNN", "dists idx knn")
+
+
+def knn_points(p1, p2, lengths1=None, lengths2=None, K=1, return_nn=False, return_sorted=True):
+    """Exact K nearest neighbours (squared distances, ascending; ties -> lower index).
+    Implemented as the FRNN ring search with an infinite radius.  Like pytorch3d, slots that
+    cannot be filled (cloud 2 has fewer than K points) hold idx 0 / dist 0."""
+    N = p1.shape[0]
+    r = torch.full((N,), float("inf"), dtype=torch.float32, device=p2.device)
+    dists, idxs, nn, _ = frnn.frnn_grid_points(p1, p2, lengths1, lengths2, K=K, r=r, return_nn=return_nn)
+    pad = idxs < 0
+    dists = torch.where(pad, torch.zeros_like(dists), dists)
+    idxs = torch.where(pad, torch.zeros_like(idxs), idxs)
+    if nn is not None:
+        nn = nn  # frnn already zero-fills the padded rows
+    return _KNN(dists=dists, idx=idxs, knn=nn)
+
+
+def _upsample_candidates(points, knn):
+    """(N,P,3), (N,P,K,3) -> sparsity (N,P), candidate (N,P,3)  [point_processing.py:326-339]."""
+    N, P, K = knn.shape[0], knn.shape[1], knn.shape[2]
+    pts = points.detach().float().contiguous()
+    kn = knn.detach().float().contiguous()
+    spars = torch.empty((N, P), dtype=torch.float32, device=pts.device)
+    cand = torch.empty((N, P, 3), dtype=torch.float32, device=pts.device)
+    _lib.call("iso_upsample_candidates", _lib.ptr(pts), _lib.ptr(kn), N * P, K, _lib.ptr(spars), _lib.ptr(cand),
+              _lib.stream())
+    return spars, cand
+
+
+def upsample(pcl, n_points, num_points=None, neighborhood_size=16, knn_result=None):
+    """Iteratively add midpoints in the sparsest regions until every cloud has n_points
+    (point_processing.py:281-362).  Returns (points_padded, num_points)."""
+    points, np_conv = convert_pointclouds_to_tensor(pcl)
+    if num_points is None:
+        num_points = np_conv
+    knn_k = neighborhood_size
+    dev = points.device
+    if not torch.is_tensor(n_points):
+        n_points = torch.full_like(num_points, int(n_points))
+    n_points = n_points.to(dev)
+    if int(num_points.sum()) == 0:
+        return points, num_points
+    n_remaining = (n_points - num_points).to(dtype=torch.long)
+    if bool((n_remaining <= 0).all()):
+        return points, num_points
+
+    def _knn(pts, lens):
+        r = knn_points(pts, pts, lens, lens, K=knn_k + 1, return_nn=True, return_sorted=True)
+        return _KNN(dists=r.dists[..., 1:], idx=r.idx[..., 1:], knn=r.knn[..., 1:, :])
+
+    if knn_result is None:
+        knn_result = _knn(points, num_points)
+    while True:
+        if bool((n_remaining == 0).all()):
+            break
+        batch_size, P, _ = points.shape
+        max_P = P // 8
+        father_sparsity, cand = _upsample_candidates(points, knn_result.knn)            # :331-339
+        sparsity_sorted = father_sparsity.sort(dim=1).indices
+        n_new_points = n_remaining.clone()
+        n_new_points[n_new_points > max_P] = max_P
+        sparsity_sorted = sparsity_sorted[:, -max_P:] if max_P > 0 else sparsity_sorted[:, :0]
+        new_pts = torch.gather(cand, 1, sparsity_sorted.unsqueeze(-1).expand(-1, -1, 3))
+        lens = [int(x) for x in num_points.tolist()]
+        nnew = [int(x) for x in n_new_points.tolist()]
+        total = []
+        for b in range(batch_size):
+            nb = new_pts[b][new_pts.shape[1] - nnew[b]:] if nnew[b] > 0 else new_pts[b][:0]
+            total.append(torch.cat([nb, points[b, :lens[b]]], dim=0))                    # :350-353
+        mx = max(t.shape[0] for t in total)
+        points = points.new_zeros((batch_size, mx, 3))
+        for b, t in enumerate(total):
+            points[b, : t.shape[0]] = t
+        n_remaining = n_remaining - n_new_points
+        num_points = n_new_points + num_points
+        if max_P == 0:
+            break
+        knn_result = _knn(points, num_points)
+    return points, num_points
+
+
+# ----------------------------------------------------------------------------- FPS / WLOP
+def farthest_sampling(points, num_points, ratio, random_start=False, generator=None):
+    """Farthest-point sampling of ceil(ratio * n) points per cloud (torch_cluster.fps semantics;
+    point_processing.py:473-499).  points (N,P,3) padded.  Returns (sampled_padded, num_sampled,
+    idx_padded).  random_start=False starts from point 0 of each cloud (deterministic); True draws
+    the start like torch_cluster does."""
+    N, P, _ = points.shape
+    dev = points.device
+    lens = host_lengths(num_points)
+    ns = [int(math.ceil(ratio * l)) for l in lens]
+    mx = max(ns) if ns else 0
+    pts = points.detach().float().contiguous()
+    start = torch.zeros((N,), dtype=torch.int64, device=dev)
+    if random_start:
+        u = torch.rand((N,), generator=generator, device="cpu")
+        start = (u * torch.tensor(lens, dtype=torch.float32)).long().clamp(max=max(max(lens) - 1, 0)).to(dev)
+    out_idx = torch.full((N, max(mx, 1)), -1, dtype=torch.int64, device=dev)
+    nsamp = with_host_lengths(torch.tensor(ns, dtype=torch.int64, device=dev), ns)
+    work = torch.empty((N, max(P, 1)), dtype=torch.float32, device=dev)
+    if mx > 0:
+        _lib.call("iso_farthest_point_sampling", _lib.ptr(pts), _lib.ptr(num_points.to(torch.int64).contiguous()),
+                  _lib.ptr(nsamp), _lib.ptr(start), N, P, out_idx.shape[1], _lib.ptr(work), _lib.ptr(out_idx),
+                  _lib.stream())
+    safe = out_idx.clamp(min=0)
+    sampled = torch.gather(pts, 1, safe.unsqueeze(-1).expand(-1, -1, 3))
+    sampled = sampled * (out_idx >= 0).unsqueeze(-1).float()
+    return sampled[:, :mx], nsamp, out_idx[:, :mx]
+
+
+def wlop(points, num_points=None, ratio=0.5, neighborhood_size=16, iters=3, repulsion_mu=0.5,
+         generator=None, perturb=True, random_start=False):
+    """Weighted locally optimal projection (point_processing.py:35-122) on padded tensors.
+    Returns (X (N,I,3), num_points_X).  `perturb` adds the reference's randn*h*0.1 offset (:59)."""
+    P, num_P = convert_pointclouds_to_tensor(points)
+    if num_points is not None:
+        num_P = num_points
+    dev = P.device
+    lensP = host_lengths(num_P)
+    N = P.shape[0]
+    # bbox diagonal per cloud over the valid points (Pointclouds.get_bounding_boxes, :43-45)
+    diag = cloud_diag(P, num_P.to(torch.int64).contiguous())
+    h = 4 * torch.sqrt(diag / num_P.float())
+    search_radius = torch.clamp(h * neighborhood_size, max=0.2)          # min(h*ns, 0.2) per cloud (:47)
+    theta_sigma_inv = 16 / h / h
+    if ratio < 1.0:
+        X, num_X, _ = farthest_sampling(P, num_P, ratio, random_start=random_start, generator=generator)
+    elif ratio == 1.0:
+        X, num_X = P.clone(), num_P
+    else:
+        raise ValueError("ratio must be less or equal to 1.0")
+    if perturb:
+        noise = torch.randn(X.shape, generator=generator, device="cpu").to(dev) if generator is not None \
+            else torch.randn_like(X)
+        X = X + noise * (h * 0.1).view(-1, 1, 1)
+    tsi = theta_sigma_inv.view(-1, 1, 1)
+
+    def theta(r2):
+        return torch.exp(-r2 * tsi)
+
+    K = neighborhood_size
+    dists, idxs, _, grid = frnn.frnn_grid_points(P, P, num_P, num_P, K=K + 1, r=search_radius)
+    idx_pp = idxs[..., 1:]
+    deltapp = torch.norm(P.unsqueeze(-2) - frnn.frnn_gather(P, idx_pp.contiguous()), dim=-1)
+    theta_pp = theta(deltapp ** 2)
+    theta_pp[idx_pp < 0] = 0
+    density_P = torch.sum(theta_pp, dim=-1) + 1
+    for _ in range(iters):
+        _, idx_xp, _, grid = frnn.frnn_grid_points(X, P, num_X, num_P, K=K, r=search_radius, grid=grid)
+        _, idx_xx, _, _ = frnn.frnn_grid_points(X, X, num_X, num_X, K=K + 1, r=search_radius)
+        idx_xx = idx_xx[..., 1:].contiguous()
+        nn_XtoP = frnn.frnn_gather(P, idx_xp)
+        epsilon = X.unsqueeze(-2) - nn_XtoP
+        delta = X.unsqueeze(-2) - frnn.frnn_gather(X, idx_xx)
+        deltaxx2 = (delta ** 2).sum(dim=-1)
+        deltaxp2 = (epsilon ** 2).sum(dim=-1)
+        alpha = theta(deltaxp2) / eps_denom(epsilon.norm(dim=-1))
+        beta = theta(deltaxx2) * torch.ones_like(deltaxx2) / eps_denom(delta.norm(dim=-1))
+        density_X = torch.sum(theta(deltaxx2), dim=-1) + 1
+        new_alpha = alpha / frnn.frnn_gather(density_P.unsqueeze(-1), idx_xp).squeeze(-1)
+        new_alpha[idx_xp < 0] = 0
+        new_beta = density_X.unsqueeze(-1) * beta
+        new_beta[idx_xx < 0] = 0
+        term_data = torch.sum(new_alpha[..., None] * nn_XtoP, dim=-2) / \
+            eps_denom(torch.sum(new_alpha, dim=-1, keepdim=True))
+        term_repul = repulsion_mu * torch.sum(new_beta[..., None] * delta, dim=-2) / \
+            eps_denom(torch.sum(new_beta, dim=-1, keepdim=True))
+        X = term_data + term_repul
+    return X, num_X
+
+
+def resample_uniformly(points, num_points=None, neighborhood_size=8, shrink_ratio=0.5, repulsion_mu=1.0,
+                       generator=None):
+    """wlop + upsample back to the original count (point_processing.py:126-166, tensor inputs)."""
+    pts, num = convert_pointclouds_to_tensor(points)
+    if num_points is not None:
+        num = num_points
+    X, num_X = wlop(pts, num, ratio=shrink_ratio, repulsion_mu=repulsion_mu, generator=generator)
+    return upsample(X, num, num_points=num_X)

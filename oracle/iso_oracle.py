@@ -316,3 +316,157 @@ def reduce_mask_padded(padded, mask):
     for b, x in enumerate(lst):
         out[b, : x.shape[0]] = x
     return out
+
+
+# --------------------------------------------------------------------------- upsample / insert / wlop / FPS
+KNN = namedtuple("KNN", "dists idx knn")
+
+
+def knn_points(p1, p2, lengths1=None, lengths2=None, K=1, return_nn=True):
+    """pytorch3d.ops.knn_points as upsample uses it (point_processing.py:315,358): exact K nearest,
+    squared distances ascending; unfilled slots idx 0 / dist 0.  PARITY UNPINNED (pytorch3d is
+    absent); brute force with the same (d2, index) order as the FRNN contract."""
+    d, i, nn, _ = frnn_grid_points(p1, p2, lengths1, lengths2, K=K, r=float("inf"), return_nn=return_nn,
+                                   use_tree=False)
+    pad = i < 0
+    d = torch.where(pad, torch.zeros_like(d), d)
+    i = torch.where(pad, torch.zeros_like(i), i)
+    return KNN(dists=d, idx=i, knn=nn)
+
+
+def upsample(points, n_points, num_points=None, neighborhood_size=16):
+    """point_processing.upsample, point_processing.py:281-362 (tensor inputs)."""
+    if num_points is None:
+        num_points = torch.full((points.shape[0],), points.shape[1], dtype=torch.long)
+    knn_k = neighborhood_size
+    if not torch.is_tensor(n_points):
+        n_points = torch.full_like(num_points, int(n_points))
+    if num_points.sum() == 0:
+        return points, num_points
+    n_remaining = (n_points - num_points).to(dtype=torch.long)
+    if (n_remaining <= 0).all():
+        return points, num_points
+
+    def _knn(pts, lens):
+        r = knn_points(pts, pts, lens, lens, K=knn_k + 1, return_nn=True)
+        return KNN(dists=r.dists[..., 1:], idx=r.idx[..., 1:], knn=r.knn[..., 1:, :])
+
+    knn_result = _knn(points, num_points)
+    while True:
+        if (n_remaining == 0).all():
+            break
+        sparse_pts, sparse_knn = points, knn_result.knn
+        batch_size, P, _ = sparse_pts.shape
+        max_P = P // 8
+        mid_points = (sparse_knn + 2 * sparse_pts[..., None, :]) / 3
+        mid_nn_diff = mid_points.unsqueeze(-2) - sparse_knn.unsqueeze(-3)
+        min_dist2 = torch.norm(mid_nn_diff, dim=-1).min(dim=-1)[0]
+        father_sparsity, father_nb = min_dist2.max(dim=-1)
+        sparsity_sorted = father_sparsity.sort(dim=1).indices
+        n_new_points = n_remaining.clone()
+        n_new_points[n_new_points > max_P] = max_P
+        sparsity_sorted = sparsity_sorted[:, -max_P:]
+        sel = mid_points[torch.arange(mid_points.shape[0]).view(-1, 1, 1),
+                         torch.arange(mid_points.shape[1]).view(1, -1, 1), father_nb.unsqueeze(-1)].squeeze(-2)
+        new_pts = torch.gather(sel, 1, sparsity_sorted.unsqueeze(-1).expand(-1, -1, 3))
+        total = []
+        for b in range(batch_size):
+            pts_b = points[b, : int(num_points[b])]
+            total.append(torch.cat([new_pts[b][-int(n_new_points[b]):], pts_b], dim=0))
+        mx = max(t.shape[0] for t in total)
+        points = points.new_zeros((batch_size, mx, 3))
+        for b, t in enumerate(total):
+            points[b, : t.shape[0]] = t
+        n_remaining = n_remaining - n_new_points
+        num_points = n_new_points + num_points
+        knn_result = _knn(points, num_points)
+    return points, num_points
+
+
+def insert(ref_points, ref_metrics, points, num_points):
+    """UniformProjection.insert, levelset_sampling.py:172-233 (one reference cloud).
+    Returns (child_pts padded, child_per_batch)."""
+    batch_size = points.shape[0]
+    diag = (points.view(-1, 3).max(dim=0).values - points.view(-1, 3).min(0).values).norm().item()
+    avg_spacing = math.sqrt(diag / ref_points.shape[0])
+    patch_size = 8
+    knn_k = patch_size
+    search_radius = min(avg_spacing * knn_k, 0.2)
+    _, idxs, _, _ = frnn_grid_points(points, points, num_points, num_points, K=knn_k + 1, r=search_radius)
+    cur_idx = idxs[..., 1:]
+    metrics = ref_metrics
+    num_ref = metrics.shape[0]
+    threshold = min(metrics.median() * 2, metrics.max() * 0.5)
+    ref_pts = ref_points[(metrics > threshold).squeeze(-1)].view(1, -1, 3)
+    if ref_pts.shape[1] == 0 or ref_pts.shape[1] > min(50, int(num_ref / 20)):
+        ref_pts = ref_points[metrics.sort(dim=0).indices[-max(min(50, int(num_ref / 20)), 1):, 0]].view(1, -1, 3)
+    ref_b = ref_pts.expand(batch_size, -1, -1)
+    dists_to_ref, _, _, _ = frnn_grid_points(points, ref_b, num_points, None, K=1, r=search_radius * 4)
+    dists_to_ref = dists_to_ref.view(batch_size, -1)
+    father_mask = (dists_to_ref < 4 * avg_spacing ** 2) & (dists_to_ref > 0)
+    father_pts = points[father_mask]
+    mother_pts = frnn_gather(points, cur_idx[..., -patch_size:])[father_mask]
+    child_pts = (2 * father_pts.unsqueeze(-2) / 3 + mother_pts / 3).view(-1, 3)
+    child_per_batch = father_mask.sum(-1) * mother_pts.shape[-2]
+    return packed_to_padded(child_pts, child_per_batch), child_per_batch
+
+
+def farthest_point_sampling(points, n_samples, start=0):
+    """Exact FPS (torch_cluster.fps contract): squared f32 distances, ties -> lowest index."""
+    p = points.detach().cpu().numpy().astype(np.float32)
+    n = p.shape[0]
+    mind = np.full((n,), np.finfo(np.float32).max, np.float32)
+    out = np.zeros((n_samples,), np.int64)
+    cur = int(start)
+    for s in range(n_samples):
+        out[s] = cur
+        d = (p - p[cur]).astype(np.float32)
+        sq = d * d
+        d2 = (sq[:, 0] + sq[:, 1]) + sq[:, 2]
+        mind = np.minimum(mind, d2)
+        cur = int(np.argmax(mind))
+    return torch.from_numpy(out)
+
+
+def wlop_iterations(P, num_P, X, num_X, neighborhood_size=16, iters=3, repulsion_mu=0.5):
+    """The LOP iterations of point_processing.wlop (point_processing.py:43-48,68-118) for a given
+    start set X (= FPS subsample + perturbation in the reference)."""
+    lo = torch.stack([P[b, : int(num_P[b])].min(dim=0).values for b in range(P.shape[0])])
+    hi = torch.stack([P[b, : int(num_P[b])].max(dim=0).values for b in range(P.shape[0])])
+    diag = torch.norm(lo - hi, dim=-1)
+    h = 4 * torch.sqrt(diag / num_P.float())
+    search_radius = torch.clamp(h * neighborhood_size, max=0.2)
+    tsi = (16 / h / h).view(-1, 1, 1)
+
+    def theta(r2):
+        return torch.exp(-r2 * tsi)
+
+    K = neighborhood_size
+    _, idxs, _, _ = frnn_grid_points(P, P, num_P, num_P, K=K + 1, r=search_radius)
+    idx_pp = idxs[..., 1:]
+    deltapp = torch.norm(P.unsqueeze(-2) - frnn_gather(P, idx_pp), dim=-1)
+    theta_pp = theta(deltapp ** 2)
+    theta_pp[idx_pp < 0] = 0
+    density_P = torch.sum(theta_pp, dim=-1) + 1
+    for _ in range(iters):
+        _, idx_xp, _, _ = frnn_grid_points(X, P, num_X, num_P, K=K, r=search_radius)
+        _, idx_xx, _, _ = frnn_grid_points(X, X, num_X, num_X, K=K + 1, r=search_radius)
+        idx_xx = idx_xx[..., 1:]
+        nn_XtoP = frnn_gather(P, idx_xp)
+        epsilon = X.unsqueeze(-2) - nn_XtoP
+        delta = X.unsqueeze(-2) - frnn_gather(X, idx_xx)
+        deltaxx2 = (delta ** 2).sum(dim=-1)
+        deltaxp2 = (epsilon ** 2).sum(dim=-1)
+        alpha = theta(deltaxp2) / eps_denom(epsilon.norm(dim=-1))
+        beta = theta(deltaxx2) * torch.ones_like(deltaxx2) / eps_denom(delta.norm(dim=-1))
+        density_X = torch.sum(theta(deltaxx2), dim=-1) + 1
+        new_alpha = alpha / frnn_gather(density_P.unsqueeze(-1), idx_xp).squeeze(-1)
+        new_alpha[idx_xp < 0] = 0
+        new_beta = density_X.unsqueeze(-1) * beta
+        new_beta[idx_xx < 0] = 0
+        term_data = torch.sum(new_alpha[..., None] * nn_XtoP, dim=-2) / \
+            eps_denom(torch.sum(new_alpha, dim=-1, keepdim=True))
+        term_repul = repulsion_mu * torch.sum(new_beta[..., None] * delta, dim=-2) / \
+            eps_denom(torch.sum(new_beta, dim=-1, keepdim=True))
+        X = term_data + term_repul
+    return X

@@ -229,6 +229,9 @@ def main():
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "levelset"):
         m_fit = gen_projection(L)
         gen_resample(L, m_fit)
+    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "pp"):
+        from make_golden_pp import gen_pp
+        gen_pp(L)
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "splat"):
         from make_golden_splat import gen_splat
         gen_splat()

@@ -133,3 +133,38 @@ def test_gather_with_neg_idx():
     from oracle import splat_oracle as SO
     g = load("gather_neg_idx.npz")
     assert torch.equal(SO.gather_scaler(g["scaler"], g["idx"]), g["out"])
+
+
+@pytest.mark.parametrize("name", ["upsample_K16.npz", "upsample_K31.npz", "upsample_batch.npz"])
+def test_upsample(name):
+    """oracle upsample vs the reference's point_processing.upsample (knn_points shimmed)."""
+    from oracle import iso_oracle as O
+    g = load(name)
+    num = g["num_points"] if "num_points" in g else None
+    n_points = g["n_points"] if torch.is_tensor(g["n_points"]) else int(g["n_points"])
+    up, n = O.upsample(g["points"], n_points, num_points=num, neighborhood_size=int(g["K"]))
+    assert torch.equal(n, g["out_num"])
+    assert up.shape == g["out_points"].shape
+    assert rel_err(up, g["out_points"]) < TIGHT
+
+
+def test_wlop_iterations():
+    from oracle import iso_oracle as O
+    g = load("wlop_ratio1.npz")
+    P = g["points"]
+    num = torch.tensor([P.shape[1]])
+    lo, hi = P[0].min(0).values, P[0].max(0).values
+    h = 4 * torch.sqrt(torch.norm(lo - hi) / P.shape[1])
+    torch.manual_seed(int(g["seed"]))
+    X0 = P + torch.randn_like(P[0]) * h * 0.1               # point_processing.py:59-60
+    X = O.wlop_iterations(P, num, X0, num, neighborhood_size=int(g["K"]), iters=int(g["iters"]),
+                          repulsion_mu=float(g["mu"]))
+    assert rel_err(X, g["out_points"]) < 1e-5
+
+
+def test_insert():
+    from oracle import iso_oracle as O
+    g = load("insert.npz")
+    child, cpb = O.insert(g["ref_points"], g["ref_metrics"], g["points"], torch.tensor([g["points"].shape[1]]))
+    assert torch.equal(cpb, g["child_per_batch"]) and int(cpb[0]) > 0
+    assert rel_err(child, g["child_pts"]) < TIGHT
