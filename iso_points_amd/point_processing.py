@@ -89,7 +89,10 @@ def upsample(pcl, n_points, num_points=None, neighborhood_size=16, knn_result=No
         nnew = [int(x) for x in n_new_points.tolist()]
         total = []
         for b in range(batch_size):
-            nb = new_pts[b][new_pts.shape[1] - nnew[b]:] if nnew[b] > 0 else new_pts[b][:0]
+            # reference quirk kept on purpose: `new_pts[b][-n:]` with n == 0 is the WHOLE array
+            # (point_processing.py:352), so a cloud that is already full in a heterogeneous batch
+            # still gets max_P rows prepended (the reference warns about such batches, :305-307)
+            nb = new_pts[b][new_pts.shape[1] - nnew[b]:] if nnew[b] > 0 else new_pts[b]
             total.append(torch.cat([nb, points[b, :lens[b]]], dim=0))                    # :350-353
         mx = max(t.shape[0] for t in total)
         points = points.new_zeros((batch_size, mx, 3))
