@@ -79,6 +79,24 @@ int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_out,
                        int n_hidden, float omega_first, float omega_hidden,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
+/* IDR-style SDF (DSS/models/common.py:220-310): positional encoding with n_freq
+ * frequencies (D0 = 3 + 6*n_freq <= 63), n_layers softplus(beta) layers of width `hidden`
+ * (128/256/512), optional skip connection [h, e(x)]/sqrt(2) into layer skip_layer (< 0: none;
+ * layer skip_layer-1 is then hidden-D0 wide), linear head, tanh.  Weight-norm must already be
+ * folded into the weights.  raw = for l = 0..n_layers: W_l (row-major [out][in]) then b_l.     */
+int64_t iso_idr_raw_floats(int hidden, int n_layers, int skip_layer, int n_freq);
+int64_t iso_idr_packed_floats(int hidden, int n_layers);
+int iso_idr_pack_weights(const float* raw, float* packed, int hidden, int n_layers,
+                         int skip_layer, int n_freq, void* stream);
+int64_t iso_project_idr_workspace_bytes(int64_t n, int hidden, int n_layers);
+int iso_project_idr(const float* pts_in, float* pts_out, float* normals_out, uint8_t* mask_out,
+                    int64_t n, const float* packed, int hidden, int n_layers, int skip_layer,
+                    int n_freq, float beta, int max_iters, float tol, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+int iso_idr_sdf_grad(const float* pts, float* sdf_out, float* grad_out, int64_t n,
+                     const float* packed, int hidden, int n_layers, int skip_layer, int n_freq,
+                     float beta, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * B. Fixed-radius nearest neighbours on a uniform grid
  *    replaces the third-party `frnn` / `prefix_sum` extensions the reference

@@ -1,0 +1,461 @@
+// Fused IDR-style SDF + gradient evaluation and Newton step (f32 MFMA), gfx950.
+//
+// Reference network: SDF.forward, DSS/models/common.py:220-310 (based on IDR / SAL):
+//   e(x)   = [x, sin(2^k x), cos(2^k x)]_{k<F}                       (get_embedder :205-217)
+//   h_0    = softplus_b(W_0 e + b_0)
+//   h_l    = softplus_b(W_l in_l + b_l),  in_l = [h_{l-1}, e]/sqrt(2) when l == skip  (:297-298)
+//   sdf    = tanh(W_n h_{n-1} + b_n)                                  (:305)
+// with weight-normalised linears (:277-278; the effective weights g*v/|v| are formed by the
+// caller), beta = 100, torch's softplus threshold 20.  Layer skip-1 outputs H - D0 features so
+// that the concatenation is H wide (:251-252).
+//
+// Same machinery as siren.hip (one wave = 16 points, activations per wave in LDS in the MFMA
+// B-operand layout, weight images shared by the 4 waves through a double-buffered LDS stage,
+// reverse-mode gradient with a stash of the activation derivatives, one launch per Newton
+// iteration over a device-side active list).  Differences:
+//   * layer 0 is an MFMA pass with nq = D0pad/16 chunks: its B operand is the positional
+//     encoding, which every lane evaluates for the slots it owns;
+//   * the narrow layer is zero-padded to H rows; after its activation the owned encoding slots
+//     overwrite the padding and everything is divided by sqrt(2);
+//   * backward of layer 0 (H -> D0) and the encoding Jacobian run on the VALU;
+//   * tanh' is a per-point scalar: the adjoint seed is W_n * s_{n-1} and the final gradient is
+//     multiplied by 1 - tanh^2.
+#include "iso_common.h"
+#include "iso_newton.h"
+#include "mlp_common.h"
+
+namespace {
+
+constexpr int kD0Pad = 64;          // padded encoding width (D0 = 3 + 6F <= 63)
+constexpr int kW0Row = 64;          // floats per feature row of the VALU backward image
+
+struct IdrShape {
+  int H, n_layers, skip, F, D0;     // skip < 0: no skip connection
+};
+
+// packed buffer (floats):
+//   [b0 H][FW0 (kD0Pad/16)*NT*256][W0v 4*(H/4)*kW0Row]
+//   per l = 1..n_layers-1: [b_l H][FW_l H*H][BW_l H*H]
+//   [WLimg H][b_last, pad 4]
+__host__ __device__ inline int64_t idr_off_b0() { return 0; }
+__host__ __device__ inline int64_t idr_off_fw0(int H) { return H; }
+__host__ __device__ inline int64_t idr_off_w0v(int H) { return H + (int64_t)(kD0Pad / 16) * (H / 16) * 256; }
+__host__ __device__ inline int64_t idr_off_layer(int H, int l) {   // l >= 1
+  return idr_off_w0v(H) + (int64_t)H * kW0Row + (int64_t)(l - 1) * ((int64_t)H + 2 * (int64_t)H * H);
+}
+__host__ __device__ inline int64_t idr_off_wl(int H, int n_layers) { return idr_off_layer(H, n_layers); }
+__host__ __device__ inline int64_t idr_total(int H, int n_layers) { return idr_off_wl(H, n_layers) + H + 4; }
+
+// raw layout (effective weights, torch row-major [out][in]):
+//   for l = 0..n_layers: W_l[out_l*in_l] b_l[out_l];
+//   in_0 = D0, out_l = H (H - D0 for l == skip-1), last layer in = H, out = 1
+__host__ __device__ inline int idr_out_dim(const IdrShape& s, int l) {
+  if (l == s.n_layers) return 1;
+  return (s.skip >= 1 && l == s.skip - 1) ? s.H - s.D0 : s.H;
+}
+__host__ __device__ inline int idr_in_dim(const IdrShape& s, int l) { return l == 0 ? s.D0 : s.H; }
+__host__ __device__ inline int64_t idr_raw_off(const IdrShape& s, int l) {
+  int64_t o = 0;
+  for (int k = 0; k < l; ++k) o += (int64_t)idr_out_dim(s, k) * idr_in_dim(s, k) + idr_out_dim(s, k);
+  return o;
+}
+
+__global__ void k_idr_pack(const float* __restrict__ raw, float* __restrict__ packed, IdrShape s) {
+  const int H = s.H, NT = H / 16;
+  const int64_t total = idr_total(H, s.n_layers);
+  const int64_t HH = (int64_t)H * H;
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (o < idr_off_fw0(H)) {                                    // b0
+      v = raw[idr_raw_off(s, 0) + (int64_t)H * s.D0 + o];
+    } else if (o < idr_off_w0v(H)) {                             // FW0 [q][t][lane][i], in = padded encoding
+      int64_t w = o - idr_off_fw0(H);
+      int i = (int)(w & 3), lane = (int)((w >> 2) & 63);
+      int t = (int)((w >> 8) % NT), q = (int)((w >> 8) / NT);
+      int a = 16 * t + (lane & 15), b = 16 * q + 4 * (lane >> 4) + i;
+      v = (b < s.D0) ? raw[idr_raw_off(s, 0) + (int64_t)a * s.D0 + b] : 0.f;
+    } else if (o < idr_off_layer(H, 1)) {                        // W0v [g][k][e]: input columns for the VALU reverse
+      int64_t w = o - idr_off_w0v(H);
+      int e = (int)(w % (H / 4));
+      int k = (int)((w / (H / 4)) % kW0Row), g = (int)((w / (H / 4)) / kW0Row);
+      int f = 16 * (e >> 2) + 4 * g + (e & 3);
+      v = (k < s.D0) ? raw[idr_raw_off(s, 0) + (int64_t)f * s.D0 + k] : 0.f;
+    } else if (o < idr_off_wl(H, s.n_layers)) {
+      int64_t k = o - idr_off_layer(H, 1);
+      const int64_t per = H + 2 * HH;
+      int l = 1 + (int)(k / per);
+      int64_t w = k % per;
+      const int od = idr_out_dim(s, l);
+      const float* Wl = raw + idr_raw_off(s, l);
+      const float* bl = Wl + (int64_t)od * H;
+      if (w < H) {
+        v = (w < od) ? bl[w] : 0.f;
+      } else {
+        w -= H;
+        bool bwd = w >= HH;
+        if (bwd) w -= HH;
+        int i = (int)(w & 3), lane = (int)((w >> 2) & 63);
+        int t = (int)((w >> 8) % NT), q = (int)((w >> 8) / NT);
+        int a = 16 * t + (lane & 15), b = 16 * q + 4 * (lane >> 4) + i;
+        if (bwd) v = (b < od) ? Wl[(int64_t)b * H + a] : 0.f;   // contracted index = out row
+        else v = (a < od) ? Wl[(int64_t)a * H + b] : 0.f;       // tile row = out row
+      }
+    } else {
+      int64_t k = o - idr_off_wl(H, s.n_layers);
+      const float* Wn = raw + idr_raw_off(s, s.n_layers);
+      if (k < H) {
+        int e = (int)(k % (H / 4)), g = (int)(k / (H / 4));
+        v = Wn[16 * (e >> 2) + 4 * g + (e & 3)];
+      } else {
+        v = (k == H) ? Wn[H] : 0.f;
+      }
+    }
+    packed[o] = v;
+  }
+}
+
+// positional-encoding feature `f` (< D0) of a point, its coordinate and derivative
+__device__ __forceinline__ void posenc(int f, float x0, float x1, float x2, float& val, int& coord,
+                                       float& dval) {
+  if (f < 3) {
+    coord = f;
+    val = f == 0 ? x0 : (f == 1 ? x1 : x2);
+    dval = 1.0f;
+    return;
+  }
+  const int m = f - 3, k = m / 6, r = m % 6;
+  coord = r % 3;
+  const float xc = coord == 0 ? x0 : (coord == 1 ? x1 : x2);
+  const float fr = (float)(1 << k);               // 2^k exactly (get_embedder: 2**linspace(0, F-1, F))
+  float sn, cs;
+  iso_sincos(xc * fr, sn, cs);
+  if (r < 3) { val = sn; dval = fr * cs; }
+  else { val = cs; dval = -fr * sn; }
+}
+
+__device__ __forceinline__ void softplus_b(float z, float beta, float& y, float& dy) {
+  // torch.nn.Softplus(beta, threshold=20) and its derivative (sigmoid)
+  const float t = z * beta;
+  if (t > 20.0f) { y = z; dy = 1.0f; return; }
+  const float e = expf(t);
+  y = log1pf(e) / beta;
+  dy = e / (e + 1.0f);
+}
+
+struct IdrArgs {
+  float* pts; float* normals; uint8_t* mask; float* sdf_out; float* grad_out;
+  const int32_t* idx_in; const int32_t* count_in; int32_t* idx_out; int32_t* count_out;
+  const float* packed; float* stash;
+  int64_t n;
+  IdrShape s;
+  float beta, tol;
+  int do_move, eval_only;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_idr_step(IdrArgs a) {
+  constexpr int H = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+  float* hL = smem + wave * (NT * 256);
+  float* wbuf = smem + 4 * NT * 256;
+  const IdrShape s = a.s;
+  const int nL = s.n_layers;
+  const float inv_sqrt2_den = 1.41421356237309515f;     // x / np.sqrt(2) as float32
+  const float* WLimg = a.packed + idr_off_wl(H, nL);
+  const float b_last = a.packed[idr_off_wl(H, nL) + H];
+  float* stash = a.stash + ((int64_t)blockIdx.x * 4 + wave) * (int64_t)nL * NT * 256;
+  const int first_enc_slot = H - s.D0;                  // concat: slots [H-D0, H) hold e(x)
+
+  const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
+  const int64_t n_tiles = (count + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t slot = tile * 64 + wave * 16 + j;
+    const bool valid = slot < count;
+    int64_t idx = -1;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (valid) {
+      idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
+      px = a.pts[idx * 3]; py = a.pts[idx * 3 + 1]; pz = a.pts[idx * 3 + 2];
+    }
+    // ---- encoding -> B operand of layer 0 (slots 16q+4g+i, q < kD0Pad/16)
+    for (int q = 0; q < kD0Pad / 16; ++q) {
+      f32x4 e4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 16 * q + 4 * g + i;
+        float v = 0.f, dv; int c;
+        if (f < s.D0) posenc(f, px, py, pz, v, c, dv);
+        e4[i] = v;
+      }
+      reinterpret_cast<f32x4*>(hL)[q * 64 + lane] = e4;
+    }
+    f32x4 acc[NT];
+    float fsum = 0.f;
+    // ---- forward
+    for (int l = 0; l < nL; ++l) {
+      if (l == 0) {
+        gemm_pass<NT, true>(a.packed + idr_off_fw0(H), a.packed + idr_off_b0(), hL, wbuf, acc, lane, g,
+                            kD0Pad / 16);
+      } else {
+        const float* base = a.packed + idr_off_layer(H, l);
+        gemm_pass<NT, true>(base + H, base, hL, wbuf, acc, lane, g);
+      }
+      float* st_l = stash + (int64_t)l * NT * 256;
+      const bool top = (l == nL - 1);
+      const bool narrow = (s.skip >= 1 && l == s.skip - 1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) reinterpret_cast<f32x4*>(hL)[t * 64 + lane] = acc[t];
+      for (int e4i = 0; e4i < NT; ++e4i) {
+        const f32x4 z4 = reinterpret_cast<const f32x4*>(hL)[e4i * 64 + lane];
+        f32x4 h4, s4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float y, dy;
+          softplus_b(z4[i], a.beta, y, dy);
+          h4[i] = y; s4[i] = dy;
+        }
+        if (top) {
+          const f32x4 w4 = reinterpret_cast<const f32x4*>(WLimg)[g * NT + e4i];
+          fsum += (w4.x * h4.x + w4.y * h4.y) + (w4.z * h4.z + w4.w * h4.w);
+          h4 = (f32x4){w4.x * s4.x, w4.y * s4.y, w4.z * s4.z, w4.w * s4.w};
+        } else {
+          if (narrow) {
+            // concat [h, e(x)] / sqrt(2): owned encoding slots replace the zero-padded rows
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int f = 16 * e4i + 4 * g + i;
+              if (f >= first_enc_slot) {
+                float v, dv; int c;
+                posenc(f - first_enc_slot, px, py, pz, v, c, dv);
+                h4[i] = v;
+                s4[i] = 0.f;            // no adjoint flows into the padded rows of the narrow layer
+              }
+              h4[i] = h4[i] / inv_sqrt2_den;
+            }
+          }
+          reinterpret_cast<f32x4*>(st_l)[e4i * 64 + lane] = s4;
+        }
+        reinterpret_cast<f32x4*>(hL)[e4i * 64 + lane] = h4;
+      }
+    }
+    fsum += __shfl_xor(fsum, 16);
+    fsum += __shfl_xor(fsum, 32);
+    const float fval = tanhf(fsum + b_last);
+    const float dtanh = 1.0f - fval * fval;
+    // ---- reverse (seed W_n * s_top is already in hL); encoding adjoint -> gradient on the fly
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int l = nL - 1; l >= 1; --l) {
+      const float* base = a.packed + idr_off_layer(H, l);
+      gemm_pass<NT, false>(base + H + (int64_t)H * H, nullptr, hL, wbuf, acc, lane, g);
+      const float* st_p = stash + (int64_t)(l - 1) * NT * 256;
+      const bool cat = (l == s.skip);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) reinterpret_cast<f32x4*>(hL)[t * 64 + lane] = acc[t];
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 s4 = reinterpret_cast<const f32x4*>(st_p)[t * 64 + lane];
+        f32x4 av = reinterpret_cast<const f32x4*>(hL)[t * 64 + lane];
+        if (cat) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            av[i] = av[i] / inv_sqrt2_den;
+            const int f = 16 * t + 4 * g + i;
+            if (f >= first_enc_slot) {       // adjoint of an encoding slot -> d/dx
+              float v, dv; int c;
+              posenc(f - first_enc_slot, px, py, pz, v, c, dv);
+              const float contrib = av[i] * dv;
+              gx += c == 0 ? contrib : 0.f;
+              gy += c == 1 ? contrib : 0.f;
+              gz += c == 2 ? contrib : 0.f;
+            }
+          }
+        }
+        f32x4 gs = {av.x * s4.x, av.y * s4.y, av.z * s4.z, av.w * s4.w};
+        reinterpret_cast<f32x4*>(hL)[t * 64 + lane] = gs;
+      }
+    }
+    // ---- layer 0 reverse on the VALU: p_k = sum_f W0[f][k] gs0[f] over this lane's features,
+    //      folded with the encoding Jacobian (rolled over the D0 inputs)
+    {
+      const float* W0v = a.packed + idr_off_w0v(H) + (int64_t)g * kW0Row * (H / 4);
+      for (int k = 0; k < s.D0; ++k) {
+        const f32x4* col = reinterpret_cast<const f32x4*>(W0v + (int64_t)k * (H / 4));
+        float pk = 0.f;
+        for (int e4i = 0; e4i < NT; ++e4i) {
+          const f32x4 a4 = reinterpret_cast<const f32x4*>(hL)[e4i * 64 + lane];
+          const f32x4 w = col[e4i];
+          pk += (w.x * a4.x + w.y * a4.y) + (w.z * a4.z + w.w * a4.w);
+        }
+        float v, dv; int c;
+        posenc(k, px, py, pz, v, c, dv);
+        const float contrib = pk * dv;
+        gx += c == 0 ? contrib : 0.f;
+        gy += c == 1 ? contrib : 0.f;
+        gz += c == 2 ? contrib : 0.f;
+      }
+    }
+    gx += __shfl_xor(gx, 16); gx += __shfl_xor(gx, 32);
+    gy += __shfl_xor(gy, 16); gy += __shfl_xor(gy, 32);
+    gz += __shfl_xor(gz, 16); gz += __shfl_xor(gz, 32);
+    gx *= dtanh; gy *= dtanh; gz *= dtanh;
+    const float f = fval;
+
+    bool survive = false;
+    if (valid && g == 0) {
+      if (a.eval_only) {
+        a.sdf_out[idx] = f;
+        a.grad_out[idx * 3] = gx; a.grad_out[idx * 3 + 1] = gy; a.grad_out[idx * 3 + 2] = gz;
+      } else {
+        a.normals[idx * 3] = gx; a.normals[idx * 3 + 1] = gy; a.normals[idx * 3 + 2] = gz;
+        const bool active = fabsf(f) > a.tol;
+        a.mask[idx] = active ? 0 : 1;
+        if (active && a.do_move) {
+          iso_newton_move(f, gx, gy, gz, px, py, pz);
+          a.pts[idx * 3] = px; a.pts[idx * 3 + 1] = py; a.pts[idx * 3 + 2] = pz;
+          survive = true;
+        }
+      }
+    }
+    if (!a.eval_only && a.do_move) {
+      const unsigned long long bal = __ballot(survive);
+      if (bal) {
+        int base = 0;
+        const int leader = __ffsll((long long)bal) - 1;
+        if (lane == leader) base = atomicAdd(a.count_out, __popcll(bal));
+        base = __shfl(base, leader);
+        if (survive) a.idx_out[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)idx;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kIdrBlocks = 256;   // one 160 KiB workgroup per CU at H = 512
+
+inline int64_t idr_stash_floats(int H, int n_layers) { return (int64_t)kIdrBlocks * 4 * n_layers * H * 16; }
+
+template <int NT>
+void idr_launch(const IdrArgs& a, int blocks, hipStream_t st) {
+  const size_t lds = (size_t)(5 * NT * 256) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idr_step<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_idr_step<NT>, dim3(blocks), dim3(256), lds, st, a);
+}
+
+int idr_dispatch(const IdrArgs& a, int blocks, hipStream_t st) {
+  switch (a.s.H / 16) {
+    case 8: idr_launch<8>(a, blocks, st); return 0;
+    case 16: idr_launch<16>(a, blocks, st); return 0;
+    case 32: idr_launch<32>(a, blocks, st); return 0;
+    default: return -1;
+  }
+}
+
+bool idr_shape_ok(int H, int n_layers, int skip, int F) {
+  const int D0 = 3 + 6 * F;
+  return (H == 128 || H == 256 || H == 512) && n_layers >= 2 && n_layers <= 12 && F >= 0 && F <= 10 &&
+         D0 <= 63 && (skip < 0 || (skip >= 1 && skip < n_layers)) && H > D0;
+}
+
+IdrShape mk_shape(int H, int n_layers, int skip, int F) { return IdrShape{H, n_layers, skip, F, 3 + 6 * F}; }
+
+__global__ void k_idr_zero(int32_t* c, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) c[i] = 0;
+}
+
+}  // namespace
+
+extern "C" int64_t iso_idr_raw_floats(int hidden, int n_layers, int skip_layer, int n_freq) {
+  IdrShape s = mk_shape(hidden, n_layers, skip_layer, n_freq);
+  return idr_raw_off(s, n_layers + 1);
+}
+extern "C" int64_t iso_idr_packed_floats(int hidden, int n_layers) { return idr_total(hidden, n_layers); }
+
+extern "C" int iso_idr_pack_weights(const float* raw, float* packed, int hidden, int n_layers,
+                                    int skip_layer, int n_freq, void* stream) {
+  ISO_REQUIRE(idr_shape_ok(hidden, n_layers, skip_layer, n_freq), ISO_ERR_UNSUPPORTED,
+              "iso_idr_pack_weights: unsupported shape (hidden 128/256/512, 2..12 layers, <=10 frequencies)");
+  ISO_REQUIRE(raw && packed, ISO_ERR_INVALID, "iso_idr_pack_weights: null pointer");
+  IdrShape s = mk_shape(hidden, n_layers, skip_layer, n_freq);
+  hipLaunchKernelGGL(k_idr_pack, dim3(iso_stream_grid(idr_total(hidden, n_layers), 256)), dim3(256), 0,
+                     (hipStream_t)stream, raw, packed, s);
+  ISO_CHECK_LAUNCH("iso_idr_pack_weights");
+  return ISO_OK;
+}
+
+extern "C" int64_t iso_project_idr_workspace_bytes(int64_t n, int hidden, int n_layers) {
+  if (n < 0) n = 0;
+  return idr_stash_floats(hidden, n_layers) * 4 + 2 * n * 4 + 64 * 4 + 64;
+}
+
+static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint8_t* mask_out,
+                   float* sdf_out, float* grad_out, int64_t n, const float* packed, int hidden,
+                   int n_layers, int skip_layer, int n_freq, float beta, int max_iters, float tol,
+                   void* workspace, int64_t workspace_bytes, void* stream, bool eval_only, const char* who) {
+  ISO_REQUIRE(idr_shape_ok(hidden, n_layers, skip_layer, n_freq), ISO_ERR_UNSUPPORTED,
+              "%s: unsupported shape (hidden 128/256/512, 2..12 layers, <=10 frequencies)", who);
+  ISO_REQUIRE(n >= 0 && max_iters >= 0 && max_iters <= 60, ISO_ERR_INVALID, "%s: bad n / max_iters", who);
+  if (n == 0) return ISO_OK;
+  ISO_REQUIRE(n < (1ll << 31), ISO_ERR_UNSUPPORTED, "%s: n must fit int32", who);
+  ISO_REQUIRE(packed && workspace, ISO_ERR_INVALID, "%s: null pointer", who);
+  ISO_REQUIRE(workspace_bytes >= iso_project_idr_workspace_bytes(n, hidden, n_layers), ISO_ERR_WORKSPACE,
+              "%s: workspace too small", who);
+  hipStream_t st = (hipStream_t)stream;
+  float* stash = (float*)workspace;
+  int32_t* idxA = (int32_t*)(stash + idr_stash_floats(hidden, n_layers));
+  int32_t* idxB = idxA + n;
+  int32_t* counts = idxB + n;
+  int64_t tiles = (n + 63) / 64;
+  int blocks = (int)(tiles < kIdrBlocks ? tiles : kIdrBlocks);
+  IdrArgs a;
+  a.packed = packed; a.stash = stash; a.n = n; a.s = mk_shape(hidden, n_layers, skip_layer, n_freq);
+  a.beta = beta; a.tol = tol;
+  if (eval_only) {
+    a.pts = const_cast<float*>(pts_in); a.normals = nullptr; a.mask = nullptr;
+    a.sdf_out = sdf_out; a.grad_out = grad_out;
+    a.idx_in = nullptr; a.count_in = nullptr; a.idx_out = nullptr; a.count_out = nullptr;
+    a.do_move = 0; a.eval_only = 1;
+    ISO_REQUIRE(idr_dispatch(a, blocks, st) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size", who);
+  } else {
+    if (pts_out != pts_in) (void)hipMemcpyAsync(pts_out, pts_in, (size_t)n * 12, hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(k_idr_zero, dim3(1), dim3(64), 0, st, counts, 64);
+    for (int it = 0; it <= max_iters; ++it) {
+      a.pts = pts_out; a.normals = normals_out; a.mask = mask_out; a.sdf_out = nullptr; a.grad_out = nullptr;
+      a.idx_in = (it == 0) ? nullptr : ((it & 1) ? idxA : idxB);
+      a.count_in = (it == 0) ? nullptr : counts + it;
+      a.idx_out = (it & 1) ? idxB : idxA;
+      a.count_out = counts + it + 1;
+      a.do_move = (it < max_iters) ? 1 : 0;
+      a.eval_only = 0;
+      ISO_REQUIRE(idr_dispatch(a, blocks, st) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size", who);
+    }
+  }
+  ISO_CHECK_LAUNCH(who);
+  return ISO_OK;
+}
+
+extern "C" int iso_project_idr(const float* pts_in, float* pts_out, float* normals_out,
+                               uint8_t* mask_out, int64_t n, const float* packed, int hidden,
+                               int n_layers, int skip_layer, int n_freq, float beta, int max_iters,
+                               float tol, void* workspace, int64_t workspace_bytes, void* stream) {
+  ISO_REQUIRE(n == 0 || (pts_in && pts_out && normals_out && mask_out), ISO_ERR_INVALID,
+              "iso_project_idr: null pointer");
+  return idr_run(pts_in, pts_out, normals_out, mask_out, nullptr, nullptr, n, packed, hidden, n_layers,
+                 skip_layer, n_freq, beta, max_iters, tol, workspace, workspace_bytes, stream, false,
+                 "iso_project_idr");
+}
+
+extern "C" int iso_idr_sdf_grad(const float* pts, float* sdf_out, float* grad_out, int64_t n,
+                                const float* packed, int hidden, int n_layers, int skip_layer,
+                                int n_freq, float beta, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
+  ISO_REQUIRE(n == 0 || (pts && sdf_out && grad_out), ISO_ERR_INVALID, "iso_idr_sdf_grad: null pointer");
+  return idr_run(pts, nullptr, nullptr, nullptr, sdf_out, grad_out, n, packed, hidden, n_layers, skip_layer,
+                 n_freq, beta, 0, 0.f, workspace, workspace_bytes, stream, true, "iso_idr_sdf_grad");
+}

@@ -1,0 +1,118 @@
+// Shared pieces of the fused-MLP kernels (siren.hip, idr.hip): accurate sin/cos and the
+// LDS-staged f32 MFMA layer pass.  See siren.hip for the data-layout story.
+#pragma once
+#include "iso_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- sin/cos ---------------------------------------------------------------
+// 3-term Cody-Waite reduction by pi/2 with FMA, cephes-style minimax kernels on
+// [-pi/4, pi/4].  Max error ~1 ulp for |x| < 1e4 (tests/test_siren.py checks it
+// against float64); larger arguments take the slow libm path.
+__device__ __forceinline__ void iso_sincos(float x, float& s, float& c) {
+  if (!(fabsf(x) < 1.0e4f)) {
+    sincosf(x, &s, &c);
+    return;
+  }
+  const float two_over_pi = 0.636619772367581343f;
+  const float p1 = 1.57079637050628662109375f;        // fl(pi/2)
+  const float p2 = -4.37113882867379288655e-8f;       // fl(pi/2 - p1)
+  const float p3 = -1.71512451000588187280e-15f;      // fl(pi/2 - p1 - p2)
+  float n = rintf(x * two_over_pi);
+  float r = __builtin_fmaf(-n, p1, x);
+  r = __builtin_fmaf(-n, p2, r);
+  r = __builtin_fmaf(-n, p3, r);
+  float r2 = r * r;
+  float ps = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, r2, -1.6666654611e-1f);
+  float sr = __builtin_fmaf(ps * r2, r, r);
+  float pc = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, r2, 4.166664568298827e-2f);
+  float cr = __builtin_fmaf(pc, r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+  int q = (int)n;
+  float ss = (q & 1) ? cr : sr;
+  float cc = (q & 1) ? sr : cr;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
+template <int NT, bool HAS_BIAS>
+__device__ __forceinline__ void gemm_pass(const float* __restrict__ img,
+                                          const float* __restrict__ bias,
+                                          const float* __restrict__ hL,
+                                          float* __restrict__ wbuf, f32x4 (&acc)[NT],
+                                          int lane, int g, int nq = NT) {
+  // One pass = nq q-chunks (nq = NT for a square layer); each q-chunk is staged in two halves of TC = NT/2 tiles so
+  // that the LDS stage is 2 x (NT/2) KiB and two workgroups fit on a CU.  All A
+  // fragments of a half are requested up front (TC ds_read_b128 in flight) and the MFMAs
+  // consume them as they land.
+  constexpr int TC = NT / 2;              // tiles per staged half
+  constexpr int CH = TC * 256;            // floats per half-chunk
+  constexpr int NV = CH / 4;              // float4 per half-chunk
+  constexpr int PER = (NV + 255) / 256;   // float4 per thread per half-chunk
+  static_assert(NT % 2 == 0, "NT must be even");
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if constexpr (HAS_BIAS) {
+      acc[t] = *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * g);
+    } else {
+      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  constexpr bool FULL = (NV % 256) == 0;  // every thread moves PER float4 (no tail guard)
+  // Two register sets: the global loads of half-chunk c+2 are issued while chunk c is
+  // multiplied and chunk c+1 (loaded one stage earlier) is written to the other LDS buffer,
+  // so a load has two MFMA stages (~2k cycles) to land before it is needed.
+  f32x4 sx[PER], sy[PER];
+  auto gload = [&](f32x4 (&r)[PER], int c) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(img + (int64_t)c * CH);
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (FULL || tid + 256 * k < NV) r[k] = src[tid + 256 * k];
+  };
+  auto lwrite = [&](const f32x4 (&r)[PER], int buf) {
+    f32x4* dst = reinterpret_cast<f32x4*>(wbuf + buf * CH);
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (FULL || tid + 256 * k < NV) dst[tid + 256 * k] = r[k];
+  };
+  auto stage = [&](int half, const f32x4& b4) {
+    const f32x4* wa = reinterpret_cast<const f32x4*>(wbuf + half * CH);
+    f32x4 a4[TC];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) a4[t] = wa[t * 64 + lane];
+    // keep the TC reads ahead of the MFMA block: the scheduler otherwise sinks each read
+    // next to its consumer (2 in flight, full LDS latency exposed every 8 MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+      f32x4& d = acc[half * TC + t];
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].x, b4.x, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].y, b4.y, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].z, b4.z, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].w, b4.w, d, 0, 0, 0);
+    }
+    // ... and the LDS write + barrier of the next chunk BEHIND it (hoisted, they make the wave
+    // drain all of its reads with only a few MFMAs in flight)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  gload(sx, 0);
+  lwrite(sx, 0);
+  gload(sx, 1);
+  __syncthreads();
+  for (int q = 0; q < nq; ++q) {
+    const f32x4 b4 = reinterpret_cast<const f32x4*>(hL)[q * 64 + lane];
+    // ---- half 0: chunk 2q in buffer 0; sx holds chunk 2q+1
+    if (2 * q + 2 < 2 * nq) gload(sy, 2 * q + 2);
+    stage(0, b4);
+    lwrite(sx, 1);
+    __syncthreads();
+    // ---- half 1: chunk 2q+1 in buffer 1; sy holds chunk 2q+2
+    if (2 * q + 3 < 2 * nq) gload(sx, 2 * q + 3);
+    stage(1, b4);
+    if (2 * q + 2 < 2 * nq) lwrite(sy, 0);
+    __syncthreads();
+  }
+}
+

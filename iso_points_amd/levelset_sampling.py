@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from . import frnn
-from .sdf_models import PackedSiren, siren_spec
+from .sdf_models import PackedIdr, PackedSiren, idr_spec, siren_spec
 
 ProjectionResult = namedtuple("ProjectionResult", ("points", "normals", "mask"))
 
@@ -163,6 +163,10 @@ class UniformProjection(LevelSetProjection):
             from .sdf_models import siren_sdf_and_grad
             sdf, grad = siren_sdf_and_grad(model, points_packed)
             return sdf.view(shp[:-1]), grad.view(shp)
+        if idr_spec(model) is not None and points_packed.is_cuda and not forward_kwargs:
+            from .sdf_models import idr_sdf_and_grad
+            sdf, grad = idr_sdf_and_grad(model, points_packed)
+            return sdf.view(shp[:-1]), grad.view(shp)
         grads, evals = [], []
         with torch.no_grad():
             model.eval()
@@ -199,6 +203,14 @@ class UniformProjection(LevelSetProjection):
                       ps.hidden, ps.n_hidden, ps.omega_first, ps.omega_hidden, int(proj_max_iters),
                       float(proj_tolerance), p(ws), ws.numel(), _lib.stream())
             self._packed_cache = ps  # keep the workspace alive until the stream has used it
+            return out, normals, mask.bool()
+        if idr_spec(model) is not None and not forward_kwargs:
+            pk = PackedIdr(model, dev)
+            ws = pk.workspace(n)
+            _lib.call("iso_project_idr", p(pts), p(out), p(normals), p(mask), n, p(pk.packed), pk.hidden,
+                      pk.n_layers, pk.skip, pk.n_freq, 100.0, int(proj_max_iters), float(proj_tolerance),
+                      p(ws), ws.numel(), _lib.stream())
+            self._packed_cache = pk
             return out, normals, mask.bool()
         return self._project_packed_generic(model, pts, proj_max_iters, proj_tolerance, **forward_kwargs)
 

@@ -158,3 +158,99 @@ def siren_sdf_and_grad(model, points):
               _lib.ptr(ps.packed), ps.hidden, ps.n_hidden, ps.omega_first, ps.omega_hidden,
               _lib.ptr(ws), ws.numel(), _lib.stream())
     return sdf.view(shp[:-1]), grad.view(shp)
+
+
+# ----------------------------------------------------------------------------- IDR-style SDF
+def _effective_weight(lin):
+    """Weight of a (possibly weight-normalised) nn.Linear: g * v / |v| (common.py:277-278)."""
+    if hasattr(lin, "weight_g") and hasattr(lin, "weight_v"):
+        v = lin.weight_v
+        return v * (lin.weight_g / v.norm(dim=1, keepdim=True))
+    par = getattr(lin, "parametrizations", None)
+    if par is not None and hasattr(par, "weight"):
+        return lin.weight                       # new-style parametrization recomputes on access
+    return lin.weight
+
+
+def idr_spec(model):
+    """(weights, biases, hidden, n_layers, skip, n_freq) if `model` is an IDR-style SDF
+    (DSS/models/common.py:220-310; also the oracle's IdrSDF) the fused kernel supports, else None."""
+    try:
+        if hasattr(model, "v") and hasattr(model, "g") and hasattr(model, "dims"):      # oracle IdrSDF
+            n_lin = model.num_layers - 1
+            Ws = [model.weight(l) for l in range(n_lin)]
+            bs = [model.b[l] for l in range(n_lin)]
+            F_ = model.F
+            skip_in = tuple(model.skip_in)
+        elif hasattr(model, "lin0") and hasattr(model, "skip_in") and hasattr(model, "num_layers"):
+            n_lin = model.num_layers - 1
+            lins = [getattr(model, "lin%d" % l) for l in range(n_lin)]
+            Ws = [_effective_weight(l) for l in lins]
+            bs = [l.bias for l in lins]
+            d0 = Ws[0].shape[1]
+            if model.embed_fn is None or (d0 - 3) % 6 != 0:
+                return None
+            F_ = (d0 - 3) // 6
+            skip_in = tuple(model.skip_in)
+            sp = getattr(model, "softplus", None)
+            if sp is None or abs(float(sp.beta) - 100.0) > 0 or float(getattr(sp, "threshold", 20)) != 20:
+                return None
+        else:
+            return None
+        n_layers = n_lin - 1
+        H = Ws[-1].shape[1]
+        if len(skip_in) > 1 or H not in (128, 256, 512) or not (2 <= n_layers <= 12) or F_ > 10:
+            return None
+        skip = skip_in[0] if len(skip_in) == 1 else -1
+        d0 = 3 + 6 * F_
+        if Ws[0].shape[1] != d0 or Ws[-1].shape[0] != 1:
+            return None
+        for l in range(n_layers):
+            want = H - d0 if (skip >= 1 and l == skip - 1) else H
+            if Ws[l].shape[0] != want or (l > 0 and Ws[l].shape[1] != H):
+                return None
+        if skip == 0 or skip >= n_layers:
+            return None
+        return Ws, bs, H, n_layers, skip, F_
+    except Exception:
+        return None
+
+
+class PackedIdr(object):
+    """Device-side MFMA weight image of an IDR-style SDF (iso_idr_pack_weights)."""
+
+    def __init__(self, model, device):
+        spec = idr_spec(model)
+        if spec is None:
+            raise ValueError("model is not an IDR-style SDF the fused kernel supports")
+        Ws, bs, self.hidden, self.n_layers, self.skip, self.n_freq = spec
+        parts = []
+        for W, b in zip(Ws, bs):
+            parts += [W.detach().reshape(-1), b.detach().reshape(-1)]
+        raw = torch.cat(parts).to(device=device, dtype=torch.float32).contiguous()
+        lib = _lib.load()
+        assert raw.numel() == lib.iso_idr_raw_floats(self.hidden, self.n_layers, self.skip, self.n_freq)
+        self.packed = torch.empty((lib.iso_idr_packed_floats(self.hidden, self.n_layers),), dtype=torch.float32,
+                                  device=device)
+        _lib.call("iso_idr_pack_weights", _lib.ptr(raw), _lib.ptr(self.packed), self.hidden, self.n_layers,
+                  self.skip, self.n_freq, _lib.stream())
+        self._ws = None
+
+    def workspace(self, n):
+        need = _lib.load().iso_project_idr_workspace_bytes(int(n), self.hidden, self.n_layers)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=self.packed.device)
+        return self._ws
+
+
+def idr_sdf_and_grad(model, points):
+    shp = points.shape
+    pts = points.detach().reshape(-1, 3).float().contiguous()
+    pk = PackedIdr(model, pts.device)
+    n = pts.shape[0]
+    sdf = torch.empty((n,), dtype=torch.float32, device=pts.device)
+    grad = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    ws = pk.workspace(n)
+    _lib.call("iso_idr_sdf_grad", _lib.ptr(pts), _lib.ptr(sdf), _lib.ptr(grad), n, _lib.ptr(pk.packed), pk.hidden,
+              pk.n_layers, pk.skip, pk.n_freq, 100.0, _lib.ptr(ws), ws.numel(), _lib.stream())
+    return sdf.view(shp[:-1]), grad.view(shp)

@@ -470,3 +470,69 @@ def wlop_iterations(P, num_P, X, num_X, neighborhood_size=16, iters=3, repulsion
             eps_denom(torch.sum(new_beta, dim=-1, keepdim=True))
         X = term_data + term_repul
     return X
+
+
+# --------------------------------------------------------------------------- IDR-style SDF
+class IdrSDF(torch.nn.Module):
+    """Restatement of SDF (DSS/models/common.py:220-310): positional encoding (get_embedder
+    :205-217, include_input, log-sampled 2^k, [sin, cos] per frequency), n_layers softplus(beta=100)
+    layers with a skip concatenation /sqrt(2) into layer `skip_in`, geometric initialisation
+    (:258-275), weight-norm as explicit (g, v) parameters (:277-278), final tanh (:305)."""
+
+    def __init__(self, hidden_size=512, n_layers=8, bias=0.6, skip_in=(4,), num_frequencies=6):
+        super().__init__()
+        self.F = num_frequencies
+        d0 = 3 + 6 * num_frequencies
+        dims = [d0] + [hidden_size] * n_layers + [1]
+        self.dims, self.skip_in, self.num_layers = dims, tuple(skip_in), len(dims)
+        self.hidden_size, self.n_layers = hidden_size, n_layers
+        self.v, self.g, self.b = torch.nn.ParameterList(), torch.nn.ParameterList(), torch.nn.ParameterList()
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            lin = torch.nn.Linear(dims[l], out_dim)
+            if l == self.num_layers - 2:
+                torch.nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                torch.nn.init.constant_(lin.bias, -bias)
+            elif num_frequencies > 0 and l == 0:
+                torch.nn.init.constant_(lin.bias, 0.0)
+                torch.nn.init.constant_(lin.weight[:, 3:], 0.0)
+                torch.nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            elif num_frequencies > 0 and l in self.skip_in:
+                torch.nn.init.constant_(lin.bias, 0.0)
+                torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                torch.nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
+            else:
+                torch.nn.init.constant_(lin.bias, 0.0)
+                torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            w = lin.weight.detach()
+            self.v.append(torch.nn.Parameter(w.clone()))
+            self.g.append(torch.nn.Parameter(w.norm(dim=1, keepdim=True).clone()))   # weight_norm init: g = |v|
+            self.b.append(torch.nn.Parameter(lin.bias.detach().clone()))
+
+    def embed(self, x):
+        outs = [x]
+        for k in range(self.F):
+            f = 2.0 ** k
+            outs += [torch.sin(x * f), torch.cos(x * f)]
+        return torch.cat(outs, -1)
+
+    def weight(self, l):
+        v = self.v[l]
+        return v * (self.g[l] / v.norm(dim=1, keepdim=True))
+
+    def forward(self, inp, **kwargs):
+        inp = self.embed(inp) if self.F > 0 else inp
+        x = inp
+        for l in range(self.num_layers - 1):
+            if l in self.skip_in:
+                x = torch.cat([x, inp], -1) / np.sqrt(2)
+            x = F.linear(x, self.weight(l), self.b[l])
+            if l < self.num_layers - 2:
+                x = F.softplus(x, beta=100)
+        return SdfOut(sdf=torch.tanh(x))
+
+    def raw_weights(self):
+        parts = []
+        for l in range(self.num_layers - 1):
+            parts += [self.weight(l).detach().reshape(-1), self.b[l].detach().reshape(-1)]
+        return torch.cat(parts).float().contiguous()

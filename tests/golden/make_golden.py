@@ -232,6 +232,9 @@ def main():
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "pp"):
         from make_golden_pp import gen_pp
         gen_pp(L)
+    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "idr"):
+        from make_golden_pp import gen_idr
+        gen_idr(L)
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "splat"):
         from make_golden_splat import gen_splat
         gen_splat()

@@ -128,3 +128,33 @@ def gen_pp(L):
     up = L.UniformProjection(knn_k=8)
     _, num_after, child, cpb = up.insert(Clouds([ref], [met]), pts.clone(), torch.tensor([3000]))
     npz("insert.npz", points=pts, ref_points=ref, ref_metrics=met, child_pts=child, child_per_batch=cpb)
+
+
+def gen_idr(L):
+    """The reference's own IDR-style SDF class (DSS/models/common.py:220-310, weight_norm on)
+    evaluated through the reference's _compute_sdf_and_grad / _project_points."""
+    import importlib
+    import warnings
+    from make_golden import npz
+    warnings.filterwarnings("ignore")
+    C = importlib.import_module("DSS.models.common")
+    torch.manual_seed(3)
+    H, NL, SK, NF = 128, 4, (2,), 6
+    m = C.SDF(dim=3, hidden_size=H, n_layers=NL, skip_in=SK, num_frequencies=NF, weight_norm=True, bias=0.6)
+    # perturb away from the geometric init so every weight matters (incl. the zeroed columns)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(1, 1200, 3, generator=g) - 0.5) * 2
+    up = L.UniformProjection()
+    sdf, grad = up._compute_sdf_and_grad(x.clone(), m)
+    res = up._project_points(m, x.clone(), torch.tensor([1200]), proj_max_iters=5, proj_tolerance=1e-30)
+    parts = []
+    for l in range(m.num_layers - 1):
+        lin = getattr(m, "lin%d" % l)
+        v = lin.weight_v.detach()
+        W = v * (lin.weight_g.detach() / v.norm(dim=1, keepdim=True))
+        parts += [W.reshape(-1), lin.bias.detach().reshape(-1)]
+    npz("idr_small.npz", points=x, sdf=sdf, grad=grad, hidden=H, n_layers=NL, skip=SK[0], n_freq=NF,
+        raw=torch.cat(parts), T=5, fixed_points=res.points, fixed_normals=res.normals)

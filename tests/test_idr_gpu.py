@@ -1,0 +1,114 @@
+"""Fused IDR-style SDF kernel (iso_points_amd/csrc/idr.hip) vs the oracle's restatement of the
+reference SDF class (pinned through tests/golden/idr_small.npz) and vs float64."""
+import copy
+
+import pytest
+import torch
+
+from test_oracle_golden import idr_from, load
+from util import cube_cloud, rel_err, sphere_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _O():
+    from oracle import iso_oracle as O
+    return O
+
+
+def test_idr_golden(dev):
+    from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
+    from iso_points_amd.sdf_models import idr_sdf_and_grad, idr_spec
+    g = load("idr_small.npz")
+    m = idr_from(g)
+    assert idr_spec(m) is not None
+    sdf, grad = idr_sdf_and_grad(m, g["points"].to(dev))
+    assert rel_err(sdf, g["sdf"]) < 1e-5
+    assert rel_err(grad, g["grad"]) < 1e-5
+    x = g["points"].to(dev)
+    r = UniformProjection(proj_tolerance=1e-30)._project_points(m, x, full_lengths(x), proj_max_iters=int(g["T"]))
+    assert rel_err(r.points, g["fixed_points"]) < 1e-4
+    assert rel_err(r.normals, g["fixed_normals"]) < 1e-4
+
+
+@pytest.mark.parametrize("H,NL,skip,NF", [(512, 8, (4,), 6), (256, 5, (), 4), (128, 3, (1,), 0), (256, 4, (3,), 10)])
+def test_idr_shapes_vs_oracle_and_float64(dev, H, NL, skip, NF):
+    """cfg 4 network (8 x 512, skip 4, 6 frequencies) and other shapes: the fused float32 result is as
+    close to the float64 value as torch's float32 autograd (the reference path) is."""
+    O = _O()
+    from iso_points_amd.sdf_models import idr_sdf_and_grad
+    torch.manual_seed(H + NL)
+    m = O.IdrSDF(hidden_size=H, n_layers=NL, skip_in=skip, num_frequencies=NF)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    pts = cube_cloud(1500, seed=NL)[0]
+    sdf32, grad32 = O.compute_sdf_and_grad(pts, m)
+    sdf64, grad64 = O.compute_sdf_and_grad(pts.double(), copy.deepcopy(m).double())
+    sdf, grad = idr_sdf_and_grad(m, pts.to(dev))
+    e_ref = (grad32.double() - grad64).abs().max().item()
+    e_hip = (grad.cpu().double() - grad64).abs().max().item()
+    s_ref = (sdf32.double() - sdf64).abs().max().item()
+    s_hip = (sdf.cpu().double() - sdf64).abs().max().item()
+    print("H=%d L=%d: grad err vs f64: torch-f32 %.3g hip %.3g; sdf %.3g / %.3g" % (H, NL, e_ref, e_hip, s_ref, s_hip))
+    assert e_hip <= 3 * e_ref + 2e-6 and s_hip <= 3 * s_ref + 2e-7
+    assert rel_err(sdf, sdf32) < 1e-5 and rel_err(grad, grad32) < 2e-5
+
+
+def test_idr_projection_converges_like_oracle(dev):
+    """Geometric init ~ sphere of radius 0.6: the full Newton projection (default tolerance)."""
+    O = _O()
+    from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
+    from util import assert_projection_close
+    torch.manual_seed(1)
+    m = O.IdrSDF(hidden_size=256, n_layers=4, skip_in=(2,), num_frequencies=6)
+    pts = sphere_cloud(3000, seed=2) * 0.6
+    ref = O.project_points(m, pts, torch.tensor([3000]), proj_max_iters=10)
+    x = pts.to(dev)
+    res = UniformProjection()._project_points(m, x, full_lengths(x), proj_max_iters=10)
+    assert_projection_close(res.points, ref.points)
+    assert (res.mask.cpu() == ref.mask).float().mean() > 0.995
+    assert ref.mask.float().mean() > 0.9
+
+
+def test_reference_style_module_is_recognised(dev):
+    """A module laid out like the reference's SDF (lin{l} with weight_norm, embed_fn, skip_in,
+    softplus beta=100) takes the fused path."""
+    import numpy as np
+    import torch.nn as nn
+    O = _O()
+    from iso_points_amd.sdf_models import idr_sdf_and_grad, idr_spec
+
+    class RefLike(nn.Module):
+        def __init__(self, H=128, n_layers=3, skip_in=(2,), F=6):
+            super().__init__()
+            d0 = 3 + 6 * F
+            dims = [d0] + [H] * n_layers + [1]
+            self.num_layers, self.skip_in, self.F = len(dims), skip_in, F
+            self.embed_fn = lambda x: torch.cat([x] + [f(x * 2.0 ** k) for k in range(F) for f in (torch.sin, torch.cos)], -1)
+            for l in range(self.num_layers - 1):
+                out = dims[l + 1] - d0 if (l + 1) in skip_in else dims[l + 1]
+                lin = nn.Linear(dims[l], out)
+                setattr(self, "lin%d" % l, nn.utils.weight_norm(lin))
+            self.softplus = nn.Softplus(beta=100)
+
+        def forward(self, inp, **kw):
+            inp = self.embed_fn(inp)
+            x = inp
+            for l in range(self.num_layers - 1):
+                if l in self.skip_in:
+                    x = torch.cat([x, inp], -1) / np.sqrt(2)
+                x = getattr(self, "lin%d" % l)(x)
+                if l < self.num_layers - 2:
+                    x = self.softplus(x)
+            return O.SdfOut(sdf=torch.tanh(x))
+
+    import warnings
+    warnings.filterwarnings("ignore")
+    torch.manual_seed(5)
+    m = RefLike()
+    assert idr_spec(m) is not None
+    pts = cube_cloud(700, seed=3)[0]
+    sdf_ref, grad_ref = O.compute_sdf_and_grad(pts, m)
+    sdf, grad = idr_sdf_and_grad(m.to(dev), pts.to(dev))
+    assert rel_err(sdf, sdf_ref) < 1e-5 and rel_err(grad, grad_ref) < 2e-5

@@ -168,3 +168,33 @@ def test_insert():
     child, cpb = O.insert(g["ref_points"], g["ref_metrics"], g["points"], torch.tensor([g["points"].shape[1]]))
     assert torch.equal(cpb, g["child_per_batch"]) and int(cpb[0]) > 0
     assert rel_err(child, g["child_pts"]) < TIGHT
+
+
+def idr_from(g):
+    from oracle import iso_oracle as O
+    m = O.IdrSDF(hidden_size=int(g["hidden"]), n_layers=int(g["n_layers"]), skip_in=(int(g["skip"]),),
+                 num_frequencies=int(g["n_freq"]))
+    raw, o = g["raw"], 0
+    with torch.no_grad():
+        for l in range(m.num_layers - 1):
+            n = m.v[l].numel()
+            W = raw[o:o + n].view_as(m.v[l]); o += n
+            m.v[l].copy_(W)
+            m.g[l].copy_(W.norm(dim=1, keepdim=True))       # g = |v|  =>  effective weight == W
+            n = m.b[l].numel()
+            m.b[l].copy_(raw[o:o + n]); o += n
+    assert o == raw.numel()
+    return m
+
+
+def test_idr_sdf_restatement():
+    """oracle IdrSDF vs the reference's own SDF class (common.py:220-310) evaluated through the
+    reference's _compute_sdf_and_grad / _project_points."""
+    from oracle import iso_oracle as O
+    g = load("idr_small.npz")
+    m = idr_from(g)
+    sdf, grad = O.compute_sdf_and_grad(g["points"], m)
+    assert rel_err(sdf, g["sdf"]) < 1e-5 and rel_err(grad, g["grad"]) < 1e-5
+    r = O.project_points(m, g["points"], torch.tensor([g["points"].shape[1]]), proj_max_iters=int(g["T"]),
+                         proj_tolerance=1e-30)
+    assert rel_err(r.points, g["fixed_points"]) < 1e-4
