@@ -67,20 +67,21 @@ __global__ void k_idr_pack(const float* __restrict__ raw, float* __restrict__ pa
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total;
        o += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
+    const int od0 = idr_out_dim(s, 0);                           // H, or H - D0 when layer 0 is the narrow one
     if (o < idr_off_fw0(H)) {                                    // b0
-      v = raw[idr_raw_off(s, 0) + (int64_t)H * s.D0 + o];
+      v = (o < od0) ? raw[idr_raw_off(s, 0) + (int64_t)od0 * s.D0 + o] : 0.f;
     } else if (o < idr_off_w0v(H)) {                             // FW0 [q][t][lane][i], in = padded encoding
       int64_t w = o - idr_off_fw0(H);
       int i = (int)(w & 3), lane = (int)((w >> 2) & 63);
       int t = (int)((w >> 8) % NT), q = (int)((w >> 8) / NT);
       int a = 16 * t + (lane & 15), b = 16 * q + 4 * (lane >> 4) + i;
-      v = (b < s.D0) ? raw[idr_raw_off(s, 0) + (int64_t)a * s.D0 + b] : 0.f;
+      v = (b < s.D0 && a < od0) ? raw[idr_raw_off(s, 0) + (int64_t)a * s.D0 + b] : 0.f;
     } else if (o < idr_off_layer(H, 1)) {                        // W0v [g][k][e]: input columns for the VALU reverse
       int64_t w = o - idr_off_w0v(H);
       int e = (int)(w % (H / 4));
       int k = (int)((w / (H / 4)) % kW0Row), g = (int)((w / (H / 4)) / kW0Row);
       int f = 16 * (e >> 2) + 4 * g + (e & 3);
-      v = (k < s.D0) ? raw[idr_raw_off(s, 0) + (int64_t)f * s.D0 + k] : 0.f;
+      v = (k < s.D0 && f < od0) ? raw[idr_raw_off(s, 0) + (int64_t)f * s.D0 + k] : 0.f;
     } else if (o < idr_off_wl(H, s.n_layers)) {
       int64_t k = o - idr_off_layer(H, 1);
       const int64_t per = H + 2 * HH;
