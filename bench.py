@@ -256,6 +256,7 @@ def main():
                          "launches_per_step": launches_per_step,
                          "avg_launch_ms": round(siren_ms / max(siren_launches, 1), 4),
                          "point_evals_per_step_rank0": evals_per_step,
+                         "active_points_per_launch_rank0": counts,
                          "share_of_step": round(siren_ms / args.steps / ms_per_step, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

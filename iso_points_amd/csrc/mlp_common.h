@@ -101,6 +101,9 @@ __device__ __forceinline__ void gemm_pass(const float* __restrict__ img,
   lwrite(sx, 0);
   gload(sx, 1);
   __syncthreads();
+  // the wave in its MFMA phase outranks a co-resident wave that is in a VALU (sin/cos) phase:
+  // +2 % measured (98.2 -> 100.2 TFLOP/s); the two workgroups of a CU stay better interleaved
+  __builtin_amdgcn_s_setprio(1);
   for (int q = 0; q < nq; ++q) {
     const f32x4 b4 = reinterpret_cast<const f32x4*>(hL)[q * 64 + lane];
     // ---- half 0: chunk 2q in buffer 0; sx holds chunk 2q+1
@@ -114,5 +117,62 @@ __device__ __forceinline__ void gemm_pass(const float* __restrict__ img,
     if (2 * q + 2 < 2 * nq) lwrite(sy, 0);
     __syncthreads();
   }
+  __builtin_amdgcn_s_setprio(0);
 }
 
+
+
+// EXPERIMENT (not the default; build siren.hip with -DISO_SIREN_DIRECT): measured 84 TFLOP/s vs
+// 98 TFLOP/s for the LDS-staged pass on the bench workload -- the 8 waves of a CU re-reading the
+// image through L1/L2 cost more than the barriers they save.
+// Variant without the shared LDS stage: every wave streams its own A fragments straight from
+// the (L2-resident, lane-linear) weight image with 16-B loads, double-buffered in registers
+// (set X = even half-chunks, set Y = odd ones; a set is re-loaded right after the MFMAs that
+// read it have been issued, so a load has a whole half-chunk of MFMAs to land).  No workgroup
+// barrier at all: the waves of a CU drift freely and fill each other's stalls.
+template <int NT, bool HAS_BIAS>
+__device__ __forceinline__ void gemm_pass_direct(const float* __restrict__ img,
+                                                 const float* __restrict__ bias,
+                                                 const float* __restrict__ hL, f32x4 (&acc)[NT],
+                                                 int lane, int g, int nq = NT) {
+  constexpr int TC = NT / 2;
+  constexpr int CH = TC * 256;
+  static_assert(NT % 2 == 0, "NT must be even");
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if constexpr (HAS_BIAS) {
+      acc[t] = *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * g);
+    } else {
+      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  f32x4 ax[TC], ay[TC];
+  auto gload = [&](f32x4 (&r)[TC], int c) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(img + (int64_t)c * CH) + lane;
+#pragma unroll
+    for (int t = 0; t < TC; ++t) r[t] = src[t * 64];
+  };
+  auto mm = [&](const f32x4 (&a4)[TC], int half, const f32x4& b4) {
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+      f32x4& d = acc[half * TC + t];
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].x, b4.x, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].y, b4.y, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].z, b4.z, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].w, b4.w, d, 0, 0, 0);
+    }
+  };
+  gload(ax, 0);
+  gload(ay, 1);
+  for (int q = 0; q < nq; ++q) {
+    const f32x4 b4 = reinterpret_cast<const f32x4*>(hL)[q * 64 + lane];
+    mm(ax, 0, b4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (2 * q + 2 < 2 * nq) gload(ax, 2 * q + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(ay, 1, b4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (2 * q + 3 < 2 * nq) gload(ay, 2 * q + 3);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}

@@ -123,6 +123,14 @@ struct SirenArgs {
   int eval_only;
 };
 
+#ifdef ISO_SIREN_DIRECT
+#define ISO_GEMM_FWD(img, bias) gemm_pass_direct<NT, true>(img, bias, hL, acc, lane, g)
+#define ISO_GEMM_BWD(img) gemm_pass_direct<NT, false>(img, nullptr, hL, acc, lane, g)
+#else
+#define ISO_GEMM_FWD(img, bias) gemm_pass<NT, true>(img, bias, hL, wbuf, acc, lane, g)
+#define ISO_GEMM_BWD(img) gemm_pass<NT, false>(img, nullptr, hL, wbuf, acc, lane, g)
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(256, 2) void k_siren_step(SirenArgs a) {
   constexpr int H = NT * 16;
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void k_siren_step(SirenArgs a) {
     f32x4 acc[NT];
     for (int l = 0; l < a.L; ++l) {
       const float* base = a.packed + off_hidden(H, l);
-      gemm_pass<NT, true>(base + H, base, hL, wbuf, acc, lane, g);
+      ISO_GEMM_FWD(base + H, base);
       float* st_l = stash + (int64_t)(l + 1) * NT * 256;
       const bool top = (l == a.L - 1);
       // pre-activations go back to this wave's LDS slab (static register
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_siren_step(SirenArgs a) {
     // ---- hidden layers, reverse -------------------------------------------
     for (int l = a.L - 1; l >= 0; --l) {
       const float* base = a.packed + off_hidden(H, l);
-      gemm_pass<NT, false>(base + H + (int64_t)H * H, nullptr, hL, wbuf, acc, lane, g);
+      ISO_GEMM_BWD(base + H + (int64_t)H * H);
       const float* st_l = stash + (int64_t)l * NT * 256;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
