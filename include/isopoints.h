@@ -313,21 +313,23 @@ int iso_splat_composite(const int32_t* idx, const float* qvalue, const float* oc
  *                           search_radius[n] of grad_occ * d/sdeno(|d|^2,1e-10)
  *                           (visible points; grad>0 pixels outside the splat rect
  *                           skipped), z = sum of grad_zbuf over the slots that list
- *                           the point.  Sums run in image order -> bit-stable.
+ *                           the point.  No float atomics: z sums run in image order, xy sums are
+ *                           lane-private partials combined by a fixed butterfly -> bit-stable.
+ *                           total_points = rows of `points` (sizes the heavy-point list).
  * grad_zbuf/idx may be NULL (no z gradient); visible may be NULL (= all).
  * rect_mode = 1 switches the xy support to the slow reference kernel's rectangle
  * |d| <= radii * radii_s (_C._splat_points_occ_backward, rasterize_points.cu:673-760);
  * search_radius is then unused.                                                  */
 int iso_splat_mark_visible(const int32_t* idx, int64_t n_pixels, int points_per_pixel,
                            uint8_t* visible, void* stream);
-int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size);
+int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size, int64_t total_points);
 int iso_splat_backward(const float* points, const float* radii, const uint8_t* visible,
                        const float* search_radius, const int64_t* first_idx,
                        const int64_t* num_pts, int n_clouds, int64_t max_pts,
                        const float* grad_occ, const int32_t* idx, const float* grad_zbuf,
                        int image_size, int points_per_pixel, int rect_mode, float radii_s,
-                       void* workspace, int64_t workspace_bytes, float* grad_points,
-                       void* stream);
+                       int64_t total_points, void* workspace, int64_t workspace_bytes,
+                       float* grad_points, void* stream);
 /* _C._backward_zbuf alone (rasterize_points.cu:823-846): z_grad[idx] += grad_zbuf
  * by atomic scatter, accumulating into the caller's (P) buffer.                 */
 int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbuf, int64_t n_pixels,

@@ -437,106 +437,152 @@ __device__ __forceinline__ bool out_range(float c, float r, int S, int& lo, int&
   return true;
 }
 
+// xy contribution of one pixel to one point (shared by both backward kernels)
+__device__ __forceinline__ void occ_term(float g, float dx, float dy, float rx, float ry, float sx,
+                                         float sy, float r2, int rect_mode, float radii_s, float& gx,
+                                         float& gy) {
+  if (g == 0.0f) return;
+  const float dist2 = dx * dx + dy * dy;
+  bool outside;
+  if (rect_mode) {  // rasterize_points.cu:726-746 (slow CUDA kernel)
+    if (fabsf(dx) > sx || fabsf(dy) > sy) return;
+    outside = (fabsf(dx) > sx / radii_s) || (fabsf(dy) > sy / radii_s);
+  } else {          // rasterize_points_backward.cu:156-161 (fast kernel)
+    if (dist2 > r2) return;
+    outside = (fabsf(dx) > rx) || (fabsf(dy) > ry);
+  }
+  if (g > 0.0f && outside) return;
+  const float denom = iso_eps_denom(dist2, 1e-10f);
+  gx += dx / denom * g;
+  gy += dy / denom * g;
+}
+
+// Pass 1, one lane per point: z gradient (sum over the fragment slots that list the point, in
+// pixel order) and the cheap part of the xy gradient: a point whose support touches no 64x64
+// super block with a gradient is done (xy = 0); the others are appended to the heavy list.
 __global__ __launch_bounds__(256) void k_splat_backward(
     const float* __restrict__ pts, const float* __restrict__ radii,
     const uint8_t* __restrict__ visible, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num,
-    const float* __restrict__ grad_occ, const uint8_t* __restrict__ blk,
-    const uint8_t* __restrict__ blk2, int NB2,
-    const int32_t* __restrict__ idx, const float* __restrict__ grad_zbuf, int S, int K, int NB,
-    int rect_mode, float radii_s, float* __restrict__ grad /* (P,3) */) {
+    const uint8_t* __restrict__ blk2, int NB2, const int32_t* __restrict__ idx,
+    const float* __restrict__ grad_zbuf, int S, int K, int rect_mode, float radii_s,
+    int32_t* __restrict__ heavy, int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
   const int n = blockIdx.y;
   const int64_t len = num[n], base = first[n];
-  const float r = rect_mode ? 0.f : rs[n], r2 = r * r;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = base + i;
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-    const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
-    const float rx = radii[p * 2], ry = radii[p * 2 + 1];
-    // ---- z: sum grad_zbuf over the fragment slots that list this point (pixel order).
-    // A point that is listed anywhere is "visible" (lists are packed, so its pixel's first
-    // slot is filled): everything else has no z gradient and is skipped.
-    if (grad_zbuf && (!visible || visible[p])) {
-      int x0, x1, y0, y1;
-      if (pz >= 0.f && out_range(px, rx, S, x0, x1) && out_range(py, ry, S, y0, y1)) {
-        for (int yo = y0; yo <= y1; ++yo)
-          for (int xo = x0; xo <= x1; ++xo) {
-            const int64_t pix = ((int64_t)n * S + yo) * S + xo;
-            for (int k = 0; k < K; ++k) {
-              const float g = grad_zbuf[pix * K + k];
-              if (g == 0.0f) continue;
-              const int q = idx[pix * K + k];
-              if (q < 0) break;
-              if (q == (int)p) gz += g;
-            }
-          }
-      }
-    }
-    // ---- xy: occupancy gradient over the disc of radius r (visible points only)
-    const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
-    if ((!visible || visible[p]) && !(pz < 0.f || fabsf(py) > 1.0f || fabsf(px) > 1.0f) &&
-        sx > 0.f && sy > 0.f) {
-      int x0, x1, y0, y1;
-      if (out_range(px, sx, S, x0, x1) && out_range(py, sy, S, y0, y1)) {
-        // level 2: does any 64x64 super block under the window hold a gradient at all?
-        bool any2 = false;
-        for (int sy2 = y0 / 64; sy2 <= y1 / 64 && !any2; ++sy2)
-          for (int sx2 = x0 / 64; sx2 <= x1 / 64; ++sx2)
-            if (blk2[((int64_t)n * NB2 + sy2) * NB2 + sx2]) { any2 = true; break; }
-        if (any2) {
-          // walk 8-row bands; per band fetch the 8x8-block flags once (bit i = block bx0+i),
-          // then visit the pixels of flagged blocks row by row -> image order is preserved
-          const int bx0 = x0 / GB, bx1 = x1 / GB;     // <= 256 blocks (image side <= 2048)
-          for (int by = y0 / GB; by <= y1 / GB; ++by) {
-            unsigned long long bits[4] = {0ull, 0ull, 0ull, 0ull};
-            bool anyb = false;
-            for (int bx = bx0; bx <= bx1; ++bx)
-              if (blk[((int64_t)n * NB + by) * NB + bx]) {
-                const int o = bx - bx0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) if ((o >> 6) == c) bits[c] |= 1ull << (o & 63);
-                anyb = true;
-              }
-            if (!anyb) continue;
-            const int ya = max(y0, by * GB), yb = min(y1, by * GB + GB - 1);
-            for (int yo = ya; yo <= yb; ++yo) {
-              const float yf = pix_to_ndc(S - 1 - yo, S);
-              const float dy = yf - py;
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                unsigned long long rem = bits[c];
-                while (rem) {
-                  const int bi = 64 * c + __ffsll((long long)rem) - 1;
-                  rem &= rem - 1;
-                  const int xa = max(x0, (bx0 + bi) * GB), xb = min(x1, (bx0 + bi) * GB + GB - 1);
-                  for (int xo = xa; xo <= xb; ++xo) {
-                    const float g = grad_occ[((int64_t)n * S + yo) * S + xo];
-                    if (g == 0.0f) continue;
-                    const float xf = pix_to_ndc(S - 1 - xo, S);
-                    const float dx = xf - px;
-                    const float dist2 = dx * dx + dy * dy;
-                    bool outside;
-                    if (rect_mode) {  // rasterize_points.cu:726-746 (slow CUDA kernel)
-                      if (fabsf(dx) > sx || fabsf(dy) > sy) continue;
-                      outside = (fabsf(dx) > sx / radii_s) || (fabsf(dy) > sy / radii_s);
-                    } else {          // rasterize_points_backward.cu:156-161 (fast kernel)
-                      if (dist2 > r2) continue;
-                      outside = (fabsf(dx) > rx) || (fabsf(dy) > ry);
-                    }
-                    if (g > 0.0f && outside) continue;
-                    const float denom = iso_eps_denom(dist2, 1e-10f);
-                    gx += dx / denom * g;
-                    gy += dy / denom * g;
-                  }
+  const float r = rect_mode ? 0.f : rs[n];
+  const int lane = threadIdx.x & 63;
+  const int64_t span = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < len; i0 += span) {
+    const int64_t i = i0 + threadIdx.x;
+    bool is_heavy = false;
+    int64_t p = -1;
+    if (i < len) {
+      p = base + i;
+      float gz = 0.f;
+      const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
+      const float rx = radii[p * 2], ry = radii[p * 2 + 1];
+      const bool vis = (!visible || visible[p]);
+      // a point that is listed anywhere is "visible" (lists are packed, so its pixel's first
+      // slot is filled): everything else has no z gradient
+      if (grad_zbuf && vis) {
+        int x0, x1, y0, y1;
+        if (pz >= 0.f && out_range(px, rx, S, x0, x1) && out_range(py, ry, S, y0, y1)) {
+          // ZbufBackwardKernel semantics (zeros skipped, stop at the first idx < 0) == sum of
+          // grad_zbuf over the slots whose idx is this point (a point is listed at most once per
+          // pixel): look at the index list first (16-B loads), fetch a gradient only on a match
+          const bool vec = (K % 4) == 0;
+          for (int yo = y0; yo <= y1; ++yo)
+            for (int xo = x0; xo <= x1; ++xo) {
+              const int64_t pix = ((int64_t)n * S + yo) * S + xo;
+              int hit = -1;
+              if (vec) {
+                const int4* row = reinterpret_cast<const int4*>(idx + pix * K);
+                for (int k4 = 0; k4 < K / 4 && hit < 0; ++k4) {
+                  const int4 q = row[k4];
+                  if (q.x == (int)p) hit = k4 * 4;
+                  else if (q.y == (int)p) hit = k4 * 4 + 1;
+                  else if (q.z == (int)p) hit = k4 * 4 + 2;
+                  else if (q.w == (int)p) hit = k4 * 4 + 3;
+                  if (q.w < 0) break;
+                }
+              } else {
+                for (int k = 0; k < K; ++k) {
+                  const int q = idx[pix * K + k];
+                  if (q < 0) break;
+                  if (q == (int)p) { hit = k; break; }
                 }
               }
+              if (hit >= 0) gz += grad_zbuf[pix * K + hit];
             }
-          }
+        }
+      }
+      grad[p * 3] = 0.f; grad[p * 3 + 1] = 0.f; grad[p * 3 + 2] = gz;
+      const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
+      if (vis && !(pz < 0.f || fabsf(py) > 1.0f || fabsf(px) > 1.0f) && sx > 0.f && sy > 0.f) {
+        int x0, x1, y0, y1;
+        if (out_range(px, sx, S, x0, x1) && out_range(py, sy, S, y0, y1)) {
+          for (int sy2 = y0 / 64; sy2 <= y1 / 64 && !is_heavy; ++sy2)
+            for (int sx2 = x0 / 64; sx2 <= x1 / 64; ++sx2)
+              if (blk2[((int64_t)n * NB2 + sy2) * NB2 + sx2]) { is_heavy = true; break; }
         }
       }
     }
-    grad[p * 3] = gx; grad[p * 3 + 1] = gy; grad[p * 3 + 2] = gz;
+    const unsigned long long bal = __ballot(is_heavy);
+    if (bal) {
+      int b0 = 0;
+      const int leader = __ffsll((long long)bal) - 1;
+      if (lane == leader) b0 = atomicAdd(heavy_count, __popcll(bal));
+      b0 = __shfl(b0, leader);
+      if (is_heavy) heavy[b0 + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)p;
+    }
+  }
+}
+
+// Pass 2, one WAVE per heavy point: the 8x8 blocks of the support that hold a gradient are
+// visited band by band, one pixel per lane; lane-private partial sums are combined by a
+// fixed butterfly -> bit-stable (no atomics), independent of how many waves run.
+__global__ __launch_bounds__(256) void k_splat_backward_heavy(
+    const float* __restrict__ pts, const float* __restrict__ radii, const float* __restrict__ rs,
+    const int64_t* __restrict__ first, const int64_t* __restrict__ num, int n_clouds,
+    const float* __restrict__ grad_occ, const uint8_t* __restrict__ blk, int NB, int S,
+    int rect_mode, float radii_s, const int32_t* __restrict__ heavy,
+    const int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int count = *heavy_count;
+  for (int w = wave; w < count; w += nwaves) {
+    const int64_t p = heavy[w];
+    int n = 0;
+    for (int c = 1; c < n_clouds; ++c) if (p >= first[c]) n = c;     // clouds are packed in order
+    const float r = rect_mode ? 0.f : rs[n], r2 = r * r;
+    const float px = pts[p * 3], py = pts[p * 3 + 1];
+    const float rx = radii[p * 2], ry = radii[p * 2 + 1];
+    const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
+    int x0, x1, y0, y1;
+    float gx = 0.f, gy = 0.f;
+    if (out_range(px, sx, S, x0, x1) && out_range(py, sy, S, y0, y1)) {
+      const int bx0 = x0 / GB, bx1 = x1 / GB;
+      const int ly = lane >> 3, lx = lane & 7;
+      for (int by = y0 / GB; by <= y1 / GB; ++by) {
+        const int yo = by * GB + ly;
+        const float dy = pix_to_ndc(S - 1 - yo, S) - py;
+        for (int bx = bx0; bx <= bx1; ++bx) {
+          if (!blk[((int64_t)n * NB + by) * NB + bx]) continue;     // wave-uniform
+          const int xo = bx * GB + lx;
+          if (yo < y0 || yo > y1 || xo < x0 || xo > x1) continue;
+          const float g = grad_occ[((int64_t)n * S + yo) * S + xo];
+          const float dx = pix_to_ndc(S - 1 - xo, S) - px;
+          occ_term(g, dx, dy, rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      gx += __shfl_xor(gx, o);
+      gy += __shfl_xor(gy, o);
+    }
+    if (lane == 0) { grad[p * 3] = gx; grad[p * 3 + 1] = gy; }
   }
 }
 
@@ -704,10 +750,16 @@ extern "C" int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbu
   return ISO_OK;
 }
 
-extern "C" int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size) {
+static int64_t bwd_maps_bytes(int n_clouds, int image_size) {
   int64_t nb = (image_size + GB - 1) / GB;
   int64_t nb2 = (nb + 7) / 8;
-  return (int64_t)n_clouds * (nb * nb + nb2 * nb2);
+  return (((int64_t)n_clouds * (nb * nb + nb2 * nb2)) + 63) / 64 * 64;
+}
+
+extern "C" int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size,
+                                                      int64_t total_points) {
+  if (total_points < 0) total_points = 0;
+  return bwd_maps_bytes(n_clouds, image_size) + 64 + 4 * total_points;
 }
 
 extern "C" int iso_splat_backward(const float* points, const float* radii, const uint8_t* visible,
@@ -715,14 +767,15 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
                                   const int64_t* num_pts, int n_clouds, int64_t max_pts,
                                   const float* grad_occ, const int32_t* idx,
                                   const float* grad_zbuf, int image_size, int points_per_pixel,
-                                  int rect_mode, float radii_s, void* workspace,
-                                  int64_t workspace_bytes, float* grad_points, void* stream) {
+                                  int rect_mode, float radii_s, int64_t total_points,
+                                  void* workspace, int64_t workspace_bytes, float* grad_points,
+                                  void* stream) {
   ISO_REQUIRE(n_clouds >= 0 && max_pts >= 0 && image_size > 0, ISO_ERR_INVALID, "iso_splat_backward: bad sizes");
   if (n_clouds == 0 || max_pts == 0) return ISO_OK;
   ISO_REQUIRE(points && radii && (search_radius || rect_mode) && first_idx && num_pts && grad_occ &&
                   grad_points && workspace && (!grad_zbuf || idx),
               ISO_ERR_INVALID, "iso_splat_backward: null pointer");
-  ISO_REQUIRE(workspace_bytes >= iso_splat_backward_workspace_bytes(n_clouds, image_size),
+  ISO_REQUIRE(workspace_bytes >= iso_splat_backward_workspace_bytes(n_clouds, image_size, total_points),
               ISO_ERR_WORKSPACE, "iso_splat_backward: workspace too small");
   ISO_REQUIRE(image_size <= 2048, ISO_ERR_UNSUPPORTED, "iso_splat_backward: image_size must be <= 2048");
   hipStream_t s = (hipStream_t)stream;
@@ -734,10 +787,16 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
                      0, s, grad_occ, image_size, NB, n_clouds, blk);
   hipLaunchKernelGGL(k_grad_superblocks, dim3(iso_stream_grid((int64_t)n_clouds * NB2 * NB2, 256)),
                      dim3(256), 0, s, blk, NB, NB2, n_clouds, blk2);
+  int32_t* heavy_count = (int32_t*)((uint8_t*)workspace + bwd_maps_bytes(n_clouds, image_size));
+  int32_t* heavy = heavy_count + 16;
+  (void)hipMemsetAsync(heavy_count, 0, 64, s);
   int gx = iso_div_up(max_pts, 256); if (gx > 8192) gx = 8192;
   hipLaunchKernelGGL(k_splat_backward, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, visible,
-                     search_radius, first_idx, num_pts, grad_occ, blk, blk2, NB2, idx, grad_zbuf,
-                     image_size, points_per_pixel, NB, rect_mode, radii_s, grad_points);
+                     search_radius, first_idx, num_pts, blk2, NB2, idx, grad_zbuf, image_size,
+                     points_per_pixel, rect_mode, radii_s, heavy, heavy_count, grad_points);
+  hipLaunchKernelGGL(k_splat_backward_heavy, dim3(2048), dim3(256), 0, s, points, radii, search_radius,
+                     first_idx, num_pts, n_clouds, grad_occ, blk, NB, image_size, rect_mode, radii_s,
+                     heavy, heavy_count, grad_points);
   ISO_CHECK_LAUNCH("iso_splat_backward");
   return ISO_OK;
 }

@@ -175,7 +175,7 @@ class _CNamespace(object):
         if hasattr(num, "_iso_host"):
             num_c._iso_host = num._iso_host
         lib = _lib.load()
-        ws_b = lib.iso_splat_backward_workspace_bytes(N, S)
+        ws_b = lib.iso_splat_backward_workspace_bytes(N, S, P)
         ws = torch.empty((max(ws_b, 1),), dtype=torch.uint8, device=dev)
         K = idx.shape[-1] if idx is not None else 1
         p = _lib.ptr
@@ -183,7 +183,7 @@ class _CNamespace(object):
                   p(_f32c(rs)) if rs is not None else None, p(first), p(num_c), N, _max_pts(num_c), p(go),
                   p(idx.contiguous()) if idx is not None else None,
                   p(_f32c(grad_zbuf)) if grad_zbuf is not None else None, S, K, int(rect_mode),
-                  float(radii_s), p(ws), ws.numel(), p(grad), _lib.stream())
+                  float(radii_s), P, p(ws), ws.numel(), p(grad), _lib.stream())
         return grad
 
     @staticmethod
