@@ -322,6 +322,14 @@ int iso_splat_composite(const int32_t* idx, const float* qvalue, const float* oc
  * search_radius is then unused.                                                  */
 int iso_splat_mark_visible(const int32_t* idx, int64_t n_pixels, int points_per_pixel,
                            uint8_t* visible, void* stream);
+/* search_radius_out[n] = lower-median(radii of the visible points of cloud n, both columns
+ * flattened) * radii_s  (rasterizer.py:884, torch.median semantics), 0 for a cloud without
+ * visible points.  Exact: 4-pass 8-bit radix select on the f32 bit patterns.                */
+int64_t iso_splat_median_radius_workspace_bytes(int n_clouds);
+int iso_splat_median_radius(const float* radii, const uint8_t* visible, const int64_t* first_idx,
+                            const int64_t* num_pts, int n_clouds, int64_t max_pts, float radii_s,
+                            void* workspace, int64_t workspace_bytes, float* search_radius_out,
+                            void* stream);
 int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size, int64_t total_points);
 int iso_splat_backward(const float* points, const float* radii, const uint8_t* visible,
                        const float* search_radius, const int64_t* first_idx,

@@ -586,6 +586,80 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
   }
 }
 
+// ---------------------------------------------------------------- median radius (radix select)
+// r_n = lower-median(radii of the visible points of cloud n, both columns) * radii_s
+// (rasterizer.py:884; torch.median of the flattened (n,2) tensor).  Radii are >= 0, so their
+// f32 bit patterns order like unsigned integers: four 8-bit histogram passes pin the k-th key.
+struct RselState {      // one per cloud
+  unsigned prefix;      // bits decided so far
+  int shift;            // next digit = (key >> shift) & 255 ; starts at 24
+  long long k;          // rank still to find inside the current prefix bucket
+  long long cnt;        // number of values (2 * visible points)
+};
+
+__global__ void k_rsel_init(RselState* st, unsigned* hist, int n_clouds) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_clouds) { st[i].prefix = 0u; st[i].shift = 24; st[i].k = -1; st[i].cnt = 0; }
+  if (i < n_clouds * 256) hist[i] = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_rsel_hist(const float* __restrict__ radii,
+                                                   const uint8_t* __restrict__ visible,
+                                                   const int64_t* __restrict__ first,
+                                                   const int64_t* __restrict__ num,
+                                                   const RselState* __restrict__ st,
+                                                   unsigned* __restrict__ hist) {
+  __shared__ unsigned lh[256];
+  const int n = blockIdx.y;
+  lh[threadIdx.x] = 0u;
+  __syncthreads();
+  const unsigned prefix = st[n].prefix;
+  const int shift = st[n].shift;
+  const unsigned hi_mask = shift >= 24 ? 0u : (0xffffffffu << (shift + 8));
+  const int64_t len = num[n], base = first[n];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = base + i;
+    if (!visible[p]) continue;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const unsigned key = __float_as_uint(radii[p * 2 + c]);
+      if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&lh[(key >> shift) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  if (lh[threadIdx.x]) atomicAdd(&hist[n * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ void k_rsel_pick(RselState* st, unsigned* hist, int n_clouds, float radii_s,
+                            float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_clouds) return;
+  RselState s = st[n];
+  unsigned* h = hist + n * 256;
+  if (s.k < 0) {                       // first pass: total count and target rank
+    long long tot = 0;
+    for (int b = 0; b < 256; ++b) tot += h[b];
+    s.cnt = tot;
+    s.k = tot > 0 ? (tot - 1) / 2 : 0;
+  }
+  if (s.cnt > 0) {
+    long long cum = 0;
+    int b = 0;
+    for (; b < 256; ++b) {
+      if (cum + (long long)h[b] > s.k) break;
+      cum += h[b];
+    }
+    if (b > 255) b = 255;
+    s.k -= cum;
+    s.prefix |= ((unsigned)b) << s.shift;
+  }
+  s.shift -= 8;
+  for (int b = 0; b < 256; ++b) h[b] = 0u;
+  st[n] = s;
+  if (s.shift < 0) out[n] = s.cnt > 0 ? __uint_as_float(s.prefix) * radii_s : 0.0f;
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -735,6 +809,38 @@ extern "C" int iso_splat_mark_visible(const int32_t* idx, int64_t n_pixels, int 
   hipLaunchKernelGGL(k_mark_visible, dim3(iso_stream_grid(n_pixels, 256)), dim3(256), 0,
                      (hipStream_t)stream, idx, points_per_pixel, n_pixels, visible);
   ISO_CHECK_LAUNCH("iso_splat_mark_visible");
+  return ISO_OK;
+}
+
+extern "C" int64_t iso_splat_median_radius_workspace_bytes(int n_clouds) {
+  if (n_clouds < 0) n_clouds = 0;
+  return (int64_t)n_clouds * (256 * 4 + (int64_t)sizeof(RselState)) + 64;
+}
+
+extern "C" int iso_splat_median_radius(const float* radii, const uint8_t* visible,
+                                       const int64_t* first_idx, const int64_t* num_pts,
+                                       int n_clouds, int64_t max_pts, float radii_s,
+                                       void* workspace, int64_t workspace_bytes,
+                                       float* search_radius_out, void* stream) {
+  ISO_REQUIRE(n_clouds >= 0 && max_pts >= 0, ISO_ERR_INVALID, "iso_splat_median_radius: bad sizes");
+  if (n_clouds == 0) return ISO_OK;
+  ISO_REQUIRE(first_idx && num_pts && workspace && search_radius_out && (max_pts == 0 || (radii && visible)),
+              ISO_ERR_INVALID, "iso_splat_median_radius: null pointer");
+  ISO_REQUIRE(workspace_bytes >= iso_splat_median_radius_workspace_bytes(n_clouds), ISO_ERR_WORKSPACE,
+              "iso_splat_median_radius: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned* hist = (unsigned*)workspace;
+  RselState* st = (RselState*)(hist + (int64_t)n_clouds * 256);
+  hipLaunchKernelGGL(k_rsel_init, dim3(iso_div_up((int64_t)n_clouds * 256, 256)), dim3(256), 0, s, st, hist, n_clouds);
+  int gx = iso_div_up(max_pts > 0 ? max_pts : 1, 256 * 8);
+  if (gx > 512) gx = 512;
+  for (int pass = 0; pass < 4; ++pass) {
+    if (max_pts > 0)
+      hipLaunchKernelGGL(k_rsel_hist, dim3(gx, n_clouds), dim3(256), 0, s, radii, visible, first_idx, num_pts, st, hist);
+    hipLaunchKernelGGL(k_rsel_pick, dim3(iso_div_up(n_clouds, 64)), dim3(64), 0, s, st, hist, n_clouds, radii_s,
+                       search_radius_out);
+  }
+  ISO_CHECK_LAUNCH("iso_splat_median_radius");
   return ISO_OK;
 }
 

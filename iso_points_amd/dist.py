@@ -30,7 +30,7 @@ from . import _lib
 from . import frnn
 from .levelset_sampling import UniformProjection, cloud_diag, full_lengths, with_host_lengths
 from .rasterizer import (PointFragments, PointsRasterizationSettings, SurfaceSplatting, _C, _f32c,
-                         _visible_and_radius, gather_with_neg_idx)
+                         _visible_and_radius, gather_with_neg_idx, median_radius)
 
 
 # ----------------------------------------------------------------------------- pure helpers
@@ -245,7 +245,7 @@ class IsoCycle(object):
         vis_i = vis.to(torch.int32)
         c.all_reduce_(vis_i, "max")
         vis = vis_i.to(torch.uint8)
-        rs_ = _radius_from_visible(vis, filt["radii"], fl, lens, float(self.rs.radii_backward_scaler))
+        rs_ = median_radius(vis, filt["radii"], first, num, float(self.rs.radii_backward_scaler))
         # xy: point-major over this rank's slice of every view
         sub = [shard_bounds(l, c.world, c.rank) for l in lens]
         sfirst = [f + lo for f, (lo, hi) in zip(fl, sub)]
@@ -282,25 +282,6 @@ class IsoCycle(object):
         zbuf_grad[:, y0:y1, :, 0] = 1e-3 / alpha.numel()
         grad, vis = self.backward(frags, filt, occ_grad, zbuf_grad)
         return r1, img, grad, frags, filt
-
-
-def _radius_from_visible(vis, radii, firsts, nums, radii_s):
-    """rasterizer.py:884: r_n = median(radii of the visible points of cloud n, both columns) * s."""
-    dev = radii.device
-    big = torch.finfo(torch.float32).max
-    out = []
-    for f, n in zip(firsts, nums):
-        if n == 0:
-            out.append(torch.zeros((), device=dev))
-            continue
-        v = vis[f:f + n].bool()
-        vals = torch.where(v[:, None], radii[f:f + n], radii.new_full((), big)).reshape(-1)
-        srt = torch.sort(vals)[0]
-        cnt = v.sum() * 2
-        k = torch.clamp((cnt - 1) // 2, min=0)
-        med = srt[k]
-        out.append(torch.where(cnt > 0, med * radii_s, torch.zeros_like(med)))
-    return torch.stack(out).float().contiguous()
 
 
 def sphere_silhouette(S, n_views, dist, fov_deg, device):

@@ -238,22 +238,21 @@ def _visible_and_radius(idx, radii, first_idx, num_points, radii_s):
     npix = idx.numel() // idx.shape[-1]
     _lib.call("iso_splat_mark_visible", _lib.ptr(idx.contiguous()), npix, idx.shape[-1], _lib.ptr(vis),
               _lib.stream())
-    firsts = host_lengths(first_idx)
-    nums = host_lengths(num_points)
-    rs = []
-    big = torch.finfo(torch.float32).max
-    for f, n in zip(firsts, nums):
-        if n == 0:
-            rs.append(torch.zeros((), device=dev))
-            continue
-        v = vis[f:f + n].bool()
-        vals = torch.where(v[:, None], radii[f:f + n], radii.new_full((), big)).reshape(-1)
-        srt = torch.sort(vals)[0]
-        cnt = v.sum() * 2
-        k = torch.clamp((cnt - 1) // 2, min=0)                   # lower median (torch.median)
-        med = srt[k]
-        rs.append(torch.where(cnt > 0, med * radii_s, torch.zeros_like(med)))
-    return vis, torch.stack(rs).float().contiguous()
+    return vis, median_radius(vis, radii, first_idx, num_points, radii_s)
+
+
+def median_radius(vis, radii, first_idx, num_points, radii_s):
+    """(N,) device tensor r_n = median(visible radii of cloud n) * radii_s (iso_splat_median_radius)."""
+    dev = radii.device
+    N = num_points.shape[0]
+    lib = _lib.load()
+    ws_b = lib.iso_splat_median_radius_workspace_bytes(N)
+    ws = torch.empty((ws_b,), dtype=torch.uint8, device=dev)
+    out = torch.empty((N,), dtype=torch.float32, device=dev)
+    p = _lib.ptr
+    _lib.call("iso_splat_median_radius", p(_f32c(radii)), p(vis), p(_i64c(first_idx)), p(_i64c(num_points)), N,
+              _max_pts(num_points), float(radii_s), p(ws), ws_b, p(out), _lib.stream())
+    return out
 
 
 class EllipticalRasterizer(autograd.Function):

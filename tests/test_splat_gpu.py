@@ -273,3 +273,29 @@ def test_full_size_properties(dev):
     # determinism: a second run gives identical lists although the fill pass uses atomics
     frags2, _ = ss.forward(pts, nrm, cameras=(views, projs))
     assert torch.equal(frags2.idx, idx) and torch.equal(frags2.zbuf, zb)
+
+
+@pytest.mark.gpu
+def test_median_radius_matches_torch_median():
+    """rasterizer.py:884: r_n = torch.median(radii[visible of cloud n]) * scaler -- the radix select
+    must return the same element bit for bit (lower median, duplicates, empty visible set)."""
+    from iso_points_amd.rasterizer import median_radius
+    from iso_points_amd.levelset_sampling import with_host_lengths
+    g = torch.Generator().manual_seed(5)
+    lens = [1, 7, 0, 5000, 123457, 64]
+    tot = sum(lens)
+    radii = torch.rand((tot, 2), generator=g) * 0.05
+    radii[2000:4000] = radii[2000:2001]            # many duplicates
+    radii[10:20, 0] = 0.0
+    vis = (torch.rand((tot,), generator=g) < 0.6).to(torch.uint8)
+    firsts = [sum(lens[:i]) for i in range(len(lens))]
+    vis[firsts[5]:firsts[5] + lens[5]] = 0           # cloud 5: nothing visible
+    vis[0] = 1
+    dev = "cuda"
+    first = with_host_lengths(torch.tensor(firsts, dtype=torch.int64, device=dev), firsts)
+    num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
+    got = median_radius(vis.to(dev), radii.to(dev), first, num, 1.5).cpu()
+    for n, (f, l) in enumerate(zip(firsts, lens)):
+        sel = radii[f:f + l][vis[f:f + l].bool()]
+        want = float(torch.median(sel.reshape(-1)) * 1.5) if sel.numel() else 0.0
+        assert float(got[n]) == pytest.approx(want, rel=0, abs=0), (n, float(got[n]), want)
