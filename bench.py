@@ -34,6 +34,8 @@ KPIX = 8
 HIDDEN, LAYERS = 256, 3
 FLOP_PER_EVAL = 2.0 * (2 * LAYERS * HIDDEN * HIDDEN + 2 * 3 * HIDDEN + 2 * HIDDEN)   # 0.79 MFLOP
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md: dense bf16 MFMA (2.5 PF); 16x the f32 rate
+X3_PASSES = 6                      # bf16 MFMA passes per f32 product in the 3xbf16 mode (siren_x3.hip)
 PEAK_HBM_TBS = 8.0
 
 
@@ -231,6 +233,12 @@ def main():
     launches_per_step = siren_launches / max(args.steps, 1)
     ach = flop_per_step / (siren_ms / args.steps * 1e-3) / 1e12 if siren_ms > 0 else 0.0
 
+    from iso_points_amd import _lib
+    x3 = _lib.load().iso_siren_get_gemm_mode() == 1
+    # roofline peak for ALGORITHMIC (f32-equivalent) flops: the f32 MFMA peak for the f32 kernel;
+    # for the split-bf16 kernel every algorithmic flop costs 6 bf16-MFMA flops, so the ceiling is
+    # bf16 dense peak / 6 = 419 TFLOP/s (executed bf16 flops = 6 x achieved, reported alongside).
+    peak = PEAK_BF16_MFMA_TFLOPS / X3_PASSES if x3 else PEAK_F32_MFMA_TFLOPS
     if rank == 0:
         out = {
             "metric": "Mpoints/s full iso-point cycle (project+resample+splat), 1M pts",
@@ -241,7 +249,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (hidden-layer products: exact 3-way bf16 split of both operands, 6 bf16 MFMA passes, "
+                     "f32 accumulate)" if x3 else "f32",
             "data": "synthetic",
             "config": {"workload": "configs[2]: 1M points project(T=10)+resample(FRNN K=9, repulsion, T=3) + EWA "
                                    "splat fwd/bwd 512x512x4 views, K=8",
@@ -250,9 +259,13 @@ def main():
                        "parallelism": "1 rank" if world == 1 else
                        "points (per-point stages) and tile-row bands (per-pixel stages) sharded x%d, RCCL "
                        "all-gather/all-reduce" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_siren_step<16> (fused SIREN SDF+grad Newton step)",
-                         "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("k_siren_step_x3<256,4,3> (fused SIREN SDF+grad Newton step, 3xbf16 MFMA)" if x3
+                                    else "k_siren_step<16> (fused SIREN SDF+grad Newton step, f32 MFMA)"),
+                         "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": None,
+                         "peak_note": ("bf16 dense MFMA peak 2516.6 / 6 passes per f32 product; executed bf16 "
+                                       "rate = %.1f TFLOP/s" % (ach * X3_PASSES)) if x3 else "f32 dense MFMA peak",
                          "launches_per_step": launches_per_step,
                          "avg_launch_ms": round(siren_ms / max(siren_launches, 1), 4),
                          "point_evals_per_step_rank0": evals_per_step,

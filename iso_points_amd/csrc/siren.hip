@@ -33,20 +33,12 @@
 //
 // Arithmetic: 2*H*H MAC per hidden layer and point (forward + reverse) on the
 // matrix cores; layer 0 (3->H), the head (H->1) and sin/cos on the VALU.
-#include "iso_common.h"
+#include <stdlib.h>
+#include "siren_common.h"
 #include "iso_newton.h"
 #include "mlp_common.h"
 
 namespace {
-
-// ---- packed weight buffer --------------------------------------------------
-// [W0img 4*H][WLimg H][bL,pad 4][ per hidden layer: bias H | FW H*H | BW H*H ]
-__host__ __device__ inline int64_t off_w0(int H) { (void)H; return 0; }
-__host__ __device__ inline int64_t off_wl(int H) { return 4 * (int64_t)H; }
-__host__ __device__ inline int64_t off_bl(int H) { return 5 * (int64_t)H; }
-__host__ __device__ inline int64_t off_hidden(int H, int l) {
-  return 5 * (int64_t)H + 4 + (int64_t)l * ((int64_t)H + 2 * (int64_t)H * H);
-}
 
 // raw layout: W0[H*3] b0[H] {Wi[H*H] bi[H]}*L WL[H] bL[1]
 __global__ void k_siren_pack(const float* __restrict__ raw, float* __restrict__ packed,
@@ -104,25 +96,6 @@ __global__ void k_siren_pack(const float* __restrict__ raw, float* __restrict__ 
 }
 
 // ---- the step kernel -------------------------------------------------------
-struct SirenArgs {
-  float* pts;                // (n,3) in/out
-  float* normals;            // (n,3) out (may be null in eval mode)
-  uint8_t* mask;             // (n) out
-  float* sdf_out;            // eval mode
-  float* grad_out;           // eval mode
-  const int32_t* idx_in;     // active list (null = identity)
-  const int32_t* count_in;   // device count of idx_in (null = n)
-  int32_t* idx_out;          // survivors
-  int32_t* count_out;
-  const float* packed;
-  float* stash;              // per-wave scratch
-  int64_t n;
-  int L;                     // hidden layers
-  float w0, wh, tol;
-  int do_move;               // 0: last evaluation (no move)
-  int eval_only;
-};
-
 #ifdef ISO_SIREN_DIRECT
 #define ISO_GEMM_FWD(img, bias) gemm_pass_direct<NT, true>(img, bias, hL, acc, lane, g)
 #define ISO_GEMM_BWD(img) gemm_pass_direct<NT, false>(img, nullptr, hL, acc, lane, g)
@@ -313,6 +286,31 @@ bool siren_shape_ok(int H, int L) {
   return (H == 64 || H == 128 || H == 256) && L >= 0 && L <= 8;
 }
 
+// 0 = f32 MFMA kernel (this file), 1 = split-bf16 MFMA kernel (siren_x3.hip) where it applies.
+// Default 1; the environment variable ISO_SIREN_GEMM=f32 selects 0 at load time.
+int g_gemm_mode = -1;
+int gemm_mode() {
+  if (g_gemm_mode < 0) {
+    const char* e = getenv("ISO_SIREN_GEMM");
+    g_gemm_mode = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;
+  }
+  return g_gemm_mode;
+}
+bool use_x3(int H, int L) { return gemm_mode() == 1 && siren_x3_supported(H, L); }
+
+int64_t stash_floats_any(int H, int L) {
+  int64_t a = stash_floats(H, L);
+  int64_t b = siren_x3_supported(H, L) ? siren_x3_stash_floats(H, L) : 0;
+  return a > b ? a : b;
+}
+
+int run_step(const SirenArgs& a, int H, int64_t n, hipStream_t s) {
+  if (use_x3(H, a.L)) return siren_x3_launch(a, H, n, s);
+  int64_t tiles = (n + 63) / 64;
+  int blocks = (int)(tiles < kSirenBlocks ? tiles : kSirenBlocks);
+  return dispatch_step(a, H, blocks, s);
+}
+
 }  // namespace
 
 extern "C" int64_t iso_siren_raw_floats(int hidden, int n_hidden) {
@@ -321,8 +319,16 @@ extern "C" int64_t iso_siren_raw_floats(int hidden, int n_hidden) {
 }
 
 extern "C" int64_t iso_siren_packed_floats(int hidden, int n_hidden) {
-  return off_hidden(hidden, n_hidden);
+  return siren_packed_total(hidden, n_hidden);
 }
+
+extern "C" int iso_siren_set_gemm_mode(int mode) {
+  ISO_REQUIRE(mode == 0 || mode == 1, ISO_ERR_INVALID, "iso_siren_set_gemm_mode: mode must be 0 (f32) or 1 (3xbf16)");
+  g_gemm_mode = mode;
+  return ISO_OK;
+}
+
+extern "C" int iso_siren_get_gemm_mode(void) { return gemm_mode(); }
 
 extern "C" int iso_siren_pack_weights(const float* raw, float* packed, int hidden,
                                       int n_hidden, void* stream) {
@@ -333,6 +339,7 @@ extern "C" int iso_siren_pack_weights(const float* raw, float* packed, int hidde
   int64_t total = off_hidden(hidden, n_hidden);
   hipLaunchKernelGGL(k_siren_pack, dim3(iso_stream_grid(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, raw, packed, hidden, n_hidden);
+  if (hidden % 32 == 0) siren_x3_pack(raw, packed, hidden, n_hidden, (hipStream_t)stream);
   ISO_CHECK_LAUNCH("iso_siren_pack_weights");
   return ISO_OK;
 }
@@ -340,7 +347,7 @@ extern "C" int iso_siren_pack_weights(const float* raw, float* packed, int hidde
 // workspace: [stash floats][idx A n][idx B n][counts 64]
 extern "C" int64_t iso_project_siren_workspace_bytes(int64_t n, int hidden, int n_hidden) {
   if (n < 0) n = 0;
-  return stash_floats(hidden, n_hidden) * 4 + 2 * n * 4 + 64 * 4 + 64;
+  return stash_floats_any(hidden, n_hidden) * 4 + 2 * n * 4 + 64 * 4 + 64;
 }
 
 extern "C" int iso_project_siren(const float* pts_in, float* pts_out, float* normals_out,
@@ -363,12 +370,10 @@ extern "C" int iso_project_siren(const float* pts_in, float* pts_out, float* nor
   if (pts_out != pts_in)
     (void)hipMemcpyAsync(pts_out, pts_in, (size_t)n * 12, hipMemcpyDeviceToDevice, s);
   float* stash = (float*)workspace;
-  int32_t* idxA = (int32_t*)(stash + stash_floats(hidden, n_hidden));
+  int32_t* idxA = (int32_t*)(stash + stash_floats_any(hidden, n_hidden));
   int32_t* idxB = idxA + n;
   int32_t* counts = idxB + n;  // counts[it] = size of the list consumed by launch `it`
   hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, s, counts, 64);
-  int64_t tiles = (n + 63) / 64;
-  int blocks = (int)(tiles < kSirenBlocks ? tiles : kSirenBlocks);
   for (int it = 0; it <= max_iters; ++it) {
     SirenArgs a;
     a.pts = pts_out; a.normals = normals_out; a.mask = mask_out;
@@ -381,7 +386,7 @@ extern "C" int iso_project_siren(const float* pts_in, float* pts_out, float* nor
     a.w0 = omega_first; a.wh = omega_hidden; a.tol = tol;
     a.do_move = (it < max_iters) ? 1 : 0;
     a.eval_only = 0;
-    ISO_REQUIRE(dispatch_step(a, hidden, blocks, s) == 0, ISO_ERR_UNSUPPORTED,
+    ISO_REQUIRE(run_step(a, hidden, n, s) == 0, ISO_ERR_UNSUPPORTED,
                 "iso_project_siren: unsupported hidden size %d", hidden);
   }
   ISO_CHECK_LAUNCH("iso_project_siren");
@@ -399,7 +404,7 @@ extern "C" int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_
   if (n == 0) return ISO_OK;
   ISO_REQUIRE(pts && sdf_out && grad_out && packed && workspace, ISO_ERR_INVALID,
               "iso_siren_sdf_grad: null pointer");
-  ISO_REQUIRE(workspace_bytes >= stash_floats(hidden, n_hidden) * 4, ISO_ERR_WORKSPACE,
+  ISO_REQUIRE(workspace_bytes >= stash_floats_any(hidden, n_hidden) * 4, ISO_ERR_WORKSPACE,
               "iso_siren_sdf_grad: workspace too small");
   SirenArgs a;
   a.pts = const_cast<float*>(pts); a.normals = nullptr; a.mask = nullptr;
@@ -407,9 +412,7 @@ extern "C" int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_
   a.idx_in = nullptr; a.count_in = nullptr; a.idx_out = nullptr; a.count_out = nullptr;
   a.packed = packed; a.stash = (float*)workspace; a.n = n; a.L = n_hidden;
   a.w0 = omega_first; a.wh = omega_hidden; a.tol = 0.f; a.do_move = 0; a.eval_only = 1;
-  int64_t tiles = (n + 63) / 64;
-  int blocks = (int)(tiles < kSirenBlocks ? tiles : kSirenBlocks);
-  ISO_REQUIRE(dispatch_step(a, hidden, blocks, (hipStream_t)stream) == 0, ISO_ERR_UNSUPPORTED,
+  ISO_REQUIRE(run_step(a, hidden, n, (hipStream_t)stream) == 0, ISO_ERR_UNSUPPORTED,
               "iso_siren_sdf_grad: unsupported hidden size %d", hidden);
   ISO_CHECK_LAUNCH("iso_siren_sdf_grad");
   return ISO_OK;

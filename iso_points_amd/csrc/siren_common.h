@@ -1,0 +1,59 @@
+// Shared between siren.hip (f32-MFMA step kernel, packing, C ABI) and siren_x3.hip (the
+// split-bf16 MFMA step kernel): argument block and the layout of the packed weight buffer.
+#pragma once
+#include "iso_common.h"
+
+struct SirenArgs {
+  float* pts;                // (n,3) in/out
+  float* normals;            // (n,3) out (may be null in eval mode)
+  uint8_t* mask;             // (n) out
+  float* sdf_out;            // eval mode
+  float* grad_out;           // eval mode
+  const int32_t* idx_in;     // active list (null = identity)
+  const int32_t* count_in;   // device count of idx_in (null = n)
+  int32_t* idx_out;          // survivors
+  int32_t* count_out;
+  const float* packed;
+  float* stash;              // per-wave scratch
+  int64_t n;
+  int L;                     // hidden layers
+  float w0, wh, tol;
+  int do_move;               // 0: last evaluation (no move)
+  int eval_only;
+};
+
+// ---- packed weight buffer, f32 section (siren.hip) ---------------------------------------
+// [W0img 4*H][WLimg H][bL,pad 4][ per hidden layer: bias H | FW H*H | BW H*H ]
+__host__ __device__ inline int64_t off_w0(int H) { (void)H; return 0; }
+__host__ __device__ inline int64_t off_wl(int H) { return 4 * (int64_t)H; }
+__host__ __device__ inline int64_t off_bl(int H) { return 5 * (int64_t)H; }
+__host__ __device__ inline int64_t off_hidden(int H, int l) {
+  return 5 * (int64_t)H + 4 + (int64_t)l * ((int64_t)H + 2 * (int64_t)H * H);
+}
+
+// ---- packed weight buffer, split-bf16 section (siren_x3.hip), appended to the f32 section ----
+// All per-feature vectors are in "K-order": position ko = (s*2 + h)*8 + e  <->  feature
+//   f = x3_feat(s, 8h+e),  s = K-step of 16 features, h = lane half, e = element of the lane's
+// 16-B B-operand entry.  With the D layout of v_mfma_f32_32x32x16_bf16 (lane (h,j), register
+// r of output tile T is row 8(r/4)+4h+(r%4)) registers 8p..8p+7 of tile T are exactly the
+// lane's entry for K-step s = 2T+p, so activations never change lanes between layers.
+//   [W0k 4*H][WLk H][ per hidden layer: bias_k H | FWx3 3*H*H/2 | BWx3 3*H*H/2 ]   (float units)
+// FWx3/BWx3: uint4 index ((s*NTO + To)*3 + part)*64 + lane, 8 bf16 each (part 0/1/2 = high /
+// middle / low third of the f32 mantissa), lane = 32h'+row:  W[32To+row][x3_feat(s,8h'+e)]
+// (BWx3: the transpose).
+__host__ __device__ inline int x3_feat(int s, int kappa) {
+  return 32 * (s >> 1) + 16 * (s & 1) + 8 * ((kappa & 7) >> 2) + 4 * (kappa >> 3) + (kappa & 3);
+}
+__host__ __device__ inline int64_t x3_base(int H, int L) { return off_hidden(H, L); }
+__host__ __device__ inline int64_t x3_off_w0(int H, int L) { return x3_base(H, L); }
+__host__ __device__ inline int64_t x3_off_wl(int H, int L) { return x3_base(H, L) + 4 * (int64_t)H; }
+__host__ __device__ inline int64_t x3_off_layer(int H, int L, int l) {
+  return x3_base(H, L) + 5 * (int64_t)H + (int64_t)l * ((int64_t)H + 3 * (int64_t)H * H);
+}
+__host__ __device__ inline int64_t siren_packed_total(int H, int L) { return x3_off_layer(H, L, L); }
+
+// ---- siren_x3.hip entry points -----------------------------------------------------------
+bool siren_x3_supported(int H, int L);
+int64_t siren_x3_stash_floats(int H, int L);
+void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s);
+int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s);

@@ -1,0 +1,463 @@
+// Fused SIREN SDF + gradient evaluation and Newton step with the hidden-layer GEMMs on the
+// bf16 matrix cores at f32 accuracy (v_mfma_f32_32x32x16_bf16, gfx950).
+//
+// Reference semantics are those of siren.hip (Siren.forward DSS/models/common.py:140-165 under
+// autograd.grad in UniformProjection._compute_sdf_and_grad, levelset_sampling.py:142-170, iterated
+// by _project_points :313-342); this file only changes how the H x H products are formed.
+//
+// f32 product from bf16 MFMAs.  Every f32 operand is cut exactly into three bf16 numbers
+// (x = xh + xm + xl: 8+8+8 mantissa bits, round-to-nearest at each cut, the remainders are
+// exact), and W.x is accumulated in f32 from the six products whose weight is >= 2^-16:
+//     Wl.xh + Wh.xl + Wm.xm + Wm.xh + Wh.xm + Wh.xh
+// bf16 x bf16 products are exact in f32, so the only approximation is the three dropped terms
+// (<= 2^-23 relative, below the f32 accumulation error of a 256-term dot product; measured
+// against float64 in tests/test_projection_gpu.py next to the f32-MFMA kernel).  The bf16 pipe
+// runs 16x the f32 MFMA rate, so six passes are 2.7x faster than one f32 pass.
+//
+// Work decomposition (differs from siren.hip: weights are NOT staged through LDS)
+//   * one workgroup = P = 32*NB points (NB = 3), NW = 4 waves, one wave per SIMD.
+//   * the OUTPUT features of a layer are split across the waves (wave w owns tiles
+//     TW*w .. TW*w+TW-1 of 32 features): each weight element is needed by exactly one wave,
+//     which streams it from L2 straight into registers (lane-linear pre-split image, one 16-B
+//     load per lane per (K-step, tile, part)), double-buffered one K-step (1152 cycles) ahead.
+//   * the activations of all P points live in LDS, already split (3 x 8 bf16 per lane entry,
+//     [K-step][point tile][part][lane]: every B operand is one conflict-free ds_read_b128).
+//     Each wave reads all of them, and after the GEMM writes the K-steps made of its own output
+//     features.  Two workgroup barriers per layer (readers done / writers done) replace the
+//     per-chunk staging barriers of the f32 kernel.
+//   * sin/cos: the accumulators are parked (f32) in the tail of the wave's own, now dead, LDS
+//     region so that a rolled loop can walk them; results overwrite the region front to back.
+//   * reverse sweep: same GEMM on the transposed image; w*cos(w z) comes back from the
+//     per-lane global stash (written in the forward sweep by the same lane).
+#include "siren_common.h"
+#include "iso_newton.h"
+#include "mlp_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// exact three-way cut of two floats; element 0 in the low half of each word
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid,
+                                           unsigned& lo) {
+  const bf16x2 h = __builtin_convertvector((f32x2){x0, x1}, bf16x2);
+  const f32x2 hf = __builtin_convertvector(h, f32x2);
+  const float r0 = x0 - hf.x, r1 = x1 - hf.y;
+  const bf16x2 m = __builtin_convertvector((f32x2){r0, r1}, bf16x2);
+  const f32x2 mf = __builtin_convertvector(m, f32x2);
+  const bf16x2 l = __builtin_convertvector((f32x2){r0 - mf.x, r1 - mf.y}, bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  mid = __builtin_bit_cast(unsigned, m);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    unsigned a, b, c;
+    split_pair(v[2 * d], v[2 * d + 1], a, b, c);
+    hi[d] = a; mid[d] = b; lo[d] = c;
+  }
+}
+
+__device__ __forceinline__ f32x4 as_f32x4(const u32x4& v) { return __builtin_bit_cast(f32x4, v); }
+__device__ __forceinline__ u32x4 as_u32x4(const f32x4& v) { return __builtin_bit_cast(u32x4, v); }
+
+// ---- packing -------------------------------------------------------------------------------
+// raw layout: W0[H*3] b0[H] {Wi[H*H] bi[H]}*L WL[H] bL[1]
+__global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict__ packed, int H, int L) {
+  const int64_t base = x3_base(H, L), total = siren_packed_total(H, L);
+  const int64_t HH = (int64_t)H * H;
+  const int NTO = H / 32;
+  const float* b0 = raw + (int64_t)H * 3;
+  const float* WL = raw + (int64_t)H * 4 + (int64_t)L * (HH + H);
+  for (int64_t o = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t rel = o - base;
+    auto feat_of = [](int64_t ko) { return x3_feat((int)(ko >> 4), 8 * (int)((ko >> 3) & 1) + (int)(ko & 7)); };
+    if (rel < 4 * (int64_t)H) {
+      const int f = feat_of(rel >> 2), c = (int)(rel & 3);
+      packed[o] = (c < 3) ? raw[f * 3 + c] : b0[f];
+    } else if (rel < 5 * (int64_t)H) {
+      packed[o] = WL[feat_of(rel - 4 * (int64_t)H)];
+    } else {
+      const int64_t per = H + 3 * HH;
+      const int64_t r2 = rel - 5 * (int64_t)H;
+      const int l = (int)(r2 / per);
+      int64_t q = r2 % per;
+      const float* Wl = raw + (int64_t)H * 4 + (int64_t)l * (HH + H);
+      if (q < H) {
+        packed[o] = Wl[HH + feat_of(q)];
+      } else {
+        q -= H;
+        const bool bwd = q >= 3 * HH / 2;
+        if (bwd) q -= 3 * HH / 2;
+        const int d = (int)(q & 3), lane = (int)((q >> 2) & 63);
+        const int64_t blk = q >> 8;                 // (s*NTO + To)*3 + part
+        const int part = (int)(blk % 3);
+        const int To = (int)((blk / 3) % NTO), s = (int)(blk / (3 * NTO));
+        const int fo = 32 * To + (lane & 31);
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int fi = x3_feat(s, 8 * (lane >> 5) + 2 * d + u);
+          v[u] = bwd ? Wl[(int64_t)fi * H + fo] : Wl[(int64_t)fo * H + fi];
+        }
+        unsigned a, b, c;
+        split_pair(v[0], v[1], a, b, c);
+        reinterpret_cast<unsigned*>(packed)[o] = part == 0 ? a : (part == 1 ? b : c);
+      }
+    }
+  }
+}
+
+// ---- the layer GEMM --------------------------------------------------------------------------
+// acc[t][n] (32 features x 32 points each) += W[tiles of this wave] . act, K-steps 0..NS-1.
+// imgw = image + (TW*w*3)*64 + lane ;  actl = act + lane ;  bias_h = bias_k + h*8 (K-order)
+template <int TW, int NB, int NTO, int NS, bool BIAS>
+__device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const float* __restrict__ bias_h,
+                                        const u32x4* actl, f32x16 (&acc)[TW][NB], int w) {
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    f32x16 init;
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const float* bp = bias_h + (2 * (TW * w + t) + p) * 16;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(bp);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { init[8 * p + e] = lo[e]; init[8 * p + 4 + e] = hi[e]; }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) init[r] = 0.f;
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[t][n] = init;
+  }
+  u32x4 A0[TW][3], A1[TW][3], B0[NB][3], B1[NB][3];
+  auto ldA = [&](u32x4 (&A)[TW][3], int s) {
+    const u32x4* p = imgw + (int64_t)s * (NTO * 3 * 64);
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) A[t][c] = p[(t * 3 + c) * 64];
+  };
+  auto ldB = [&](u32x4 (&B)[NB][3], int s) {
+    const u32x4* p = actl + s * (NB * 3 * 64);
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) B[n][c] = p[(n * 3 + c) * 64];
+  };
+  auto mma = [&](const u32x4 (&A)[TW][3], const u32x4 (&B)[NB][3]) {
+    // smallest terms first; consecutive MFMAs go to different accumulators
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+          acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[t][PA[q]]),
+                                                              __builtin_bit_cast(bf16x8, B[n][PB[q]]),
+                                                              acc[t][n], 0, 0, 0);
+  };
+  ldA(A0, 0);
+  ldB(B0, 0);
+  for (int s = 0; s < NS; s += 2) {
+    ldA(A1, s + 1);
+    ldB(B1, s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(A0, B0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < NS) {
+      ldA(A0, s + 2);
+      ldB(B0, s + 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(A1, B1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- the step kernel -------------------------------------------------------------------------
+template <int H, int NW, int NB>
+struct X3Shape {
+  static constexpr int NS = H / 16;        // K-steps of a hidden layer
+  static constexpr int NTO = H / 32;       // output tiles
+  static constexpr int TW = NTO / NW;      // output tiles per wave
+  static constexpr int SL = 2 * TW;        // K-steps of the next layer produced by one wave
+  static constexpr int NG = SL * NB;       // 8-value groups per lane
+  static constexpr int P = 32 * NB;        // points per workgroup
+  static constexpr size_t kActBytes = (size_t)NS * NB * 3 * 1024;
+  static constexpr size_t kLds = kActBytes + (size_t)NW * P * 16;
+  static constexpr int64_t kStashPerWg(int L) { return (int64_t)NW * (L + 1) * NG * 512; }  // floats
+  static_assert(NTO % NW == 0 && TW >= 1, "features must split evenly over the waves");
+};
+
+template <int H, int NW, int NB, int MINB>
+__global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
+  using S = X3Shape<H, NW, NB>;
+  constexpr int NS = S::NS, NTO = S::NTO, TW = S::TW, SL = S::SL, NG = S::NG, P = S::P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* act = reinterpret_cast<u32x4*>(smem_raw);
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw + S::kActBytes);   // [NW][P] {f,gx,gy,gz}
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, h = lane >> 5, j = lane & 31;
+  u32x4* own = act + (size_t)(SL * w) * NB * 3 * 64 + lane;      // this wave's K-steps (+lane)
+  u32x4* park = own + (size_t)NG * 64;                           // last NG*2 KiB of the region
+  const int L = a.L;
+  const float* X = a.packed + x3_base(H, L);
+  const f32x4* W0k = reinterpret_cast<const f32x4*>(X) + (SL * w * 2 + h) * 8;
+  const float* WLk = X + 4 * H + (SL * w * 2 + h) * 8;
+  const float bL = a.packed[off_bl(H)];
+  f32x4* stash = reinterpret_cast<f32x4*>(a.stash) +
+                 ((int64_t)blockIdx.x * NW + w) * (int64_t)(L + 1) * NG * 128 + lane;
+
+  const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
+  const int64_t n_tiles = (count + P - 1) / P;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    float px[NB], py[NB], pz[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int64_t slot = tile * P + 32 * n + j;
+      px[n] = py[n] = pz[n] = 0.f;
+      if (slot < count) {
+        const int64_t idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
+        px[n] = a.pts[idx * 3]; py[n] = a.pts[idx * 3 + 1]; pz[n] = a.pts[idx * 3 + 2];
+      }
+    }
+    // ---- layer 0 (3 -> H) on the VALU: this wave's H/NW features of all P points ------------
+    for (int sl = 0; sl < SL; ++sl) {
+      f32x4 wv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[e] = W0k[sl * 16 + e];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        float hv[8], sv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float z = ((wv[e].x * px[n] + wv[e].y * py[n]) + wv[e].z * pz[n]) + wv[e].w;
+          float s_, c_;
+          iso_sincos(a.w0 * z, s_, c_);
+          hv[e] = s_;
+          sv[e] = a.w0 * c_;
+        }
+        const int k = sl * NB + n;
+        u32x4 p0, p1, p2;
+        split8(hv, p0, p1, p2);
+        own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+        stash[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+        stash[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+      }
+    }
+    __syncthreads();
+
+    f32x16 acc[TW][NB];
+    float fpart[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) fpart[n] = 0.f;
+    // ---- hidden layers, forward --------------------------------------------------------------
+    for (int l = 0; l < L; ++l) {
+      const float* lay = a.packed + x3_off_layer(H, L, l);
+      const u32x4* img = reinterpret_cast<const u32x4*>(lay + H) + (TW * w * 3) * 64 + lane;
+      gemm_x3<TW, NB, NTO, NS, true>(img, lay + h * 8, act + lane, acc, w);
+      __syncthreads();                      // every wave has finished reading the activations
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int k = (2 * t + p) * NB + n;
+            const f32x16& v = acc[t][n];
+            park[(k * 2 + 0) * 64] = as_u32x4((f32x4){v[8 * p], v[8 * p + 1], v[8 * p + 2], v[8 * p + 3]});
+            park[(k * 2 + 1) * 64] = as_u32x4((f32x4){v[8 * p + 4], v[8 * p + 5], v[8 * p + 6], v[8 * p + 7]});
+          }
+      const bool top = (l == L - 1);
+      f32x4* st_l = stash + (int64_t)(l + 1) * NG * 128;
+      for (int sl = 0; sl < SL; ++sl) {
+        f32x4 z[NB][2];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          z[n][0] = as_f32x4(park[((sl * NB + n) * 2 + 0) * 64]);
+          z[n][1] = as_f32x4(park[((sl * NB + n) * 2 + 1) * 64]);
+        }
+        f32x4 wl0 = {0.f, 0.f, 0.f, 0.f}, wl1 = wl0;
+        if (top) {
+          wl0 = *reinterpret_cast<const f32x4*>(WLk + sl * 16);
+          wl1 = *reinterpret_cast<const f32x4*>(WLk + sl * 16 + 4);
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          float hv[8], sv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float s_, c_;
+            iso_sincos(a.wh * z[n][e >> 2][e & 3], s_, c_);
+            hv[e] = s_;
+            sv[e] = a.wh * c_;
+          }
+          const int k = sl * NB + n;
+          if (top) {
+            // adjoint seed of the top sine layer = head weight * w cos(w z); head dot product here
+            float f0 = (wl0.x * hv[0] + wl0.y * hv[1]) + (wl0.z * hv[2] + wl0.w * hv[3]);
+            float f1 = (wl1.x * hv[4] + wl1.y * hv[5]) + (wl1.z * hv[6] + wl1.w * hv[7]);
+            fpart[n] += f0 + f1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hv[e] = wl0[e] * sv[e]; hv[4 + e] = wl1[e] * sv[4 + e]; }
+          } else {
+            st_l[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+            st_l[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+          }
+          u32x4 p0, p1, p2;
+          split8(hv, p0, p1, p2);
+          own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+        }
+      }
+      __syncthreads();                      // the next layer's inputs are complete
+    }
+    // ---- hidden layers, reverse --------------------------------------------------------------
+    float gx[NB], gy[NB], gz[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) gx[n] = gy[n] = gz[n] = 0.f;
+    for (int l = L - 1; l >= 0; --l) {
+      const float* lay = a.packed + x3_off_layer(H, L, l);
+      const u32x4* img = reinterpret_cast<const u32x4*>(lay + H + 3 * (H * H / 2)) + (TW * w * 3) * 64 + lane;
+      gemm_x3<TW, NB, NTO, NS, false>(img, nullptr, act + lane, acc, w);
+      const f32x4* st_l = stash + (int64_t)l * NG * 128;
+      f32x4 sv[NG][2];
+#pragma unroll
+      for (int k = 0; k < NG; ++k) { sv[k][0] = st_l[(k * 2) * 64]; sv[k][1] = st_l[(k * 2 + 1) * 64]; }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          f32x4 wv[8];
+          if (l == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wv[e] = W0k[(2 * t + p) * 16 + e];
+          }
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            const int k = (2 * t + p) * NB + n;
+            float av[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = acc[t][n][8 * p + e] * sv[k][e >> 2][e & 3];
+            if (l > 0) {
+              u32x4 p0, p1, p2;
+              split8(av, p0, p1, p2);
+              own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                gx[n] += wv[e].x * av[e];
+                gy[n] += wv[e].y * av[e];
+                gz[n] += wv[e].z * av[e];
+              }
+            }
+          }
+        }
+      if (l > 0) __syncthreads();
+    }
+    // ---- reduce head + gradient over the lane halves and the waves -----------------------------
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      float f = fpart[n] + __shfl_xor(fpart[n], 32);
+      float x = gx[n] + __shfl_xor(gx[n], 32);
+      float y = gy[n] + __shfl_xor(gy[n], 32);
+      float z = gz[n] + __shfl_xor(gz[n], 32);
+      if (h == 0) red[w * P + 32 * n + j] = (f32x4){f, x, y, z};
+    }
+    __syncthreads();
+    // ---- epilogue: thread tid handles point `tid` of the tile ----------------------------------
+    bool survive = false;
+    int64_t idx = -1;
+    {
+      const int64_t slot = tile * P + tid;
+      if (tid < P && slot < count) {
+        f32x4 r = red[tid];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) {
+          const f32x4 q = red[ww * P + tid];
+          r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+        }
+        const float f = r.x + bL;
+        idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
+        if (a.eval_only) {
+          a.sdf_out[idx] = f;
+          a.grad_out[idx * 3] = r.y; a.grad_out[idx * 3 + 1] = r.z; a.grad_out[idx * 3 + 2] = r.w;
+        } else {
+          a.normals[idx * 3] = r.y; a.normals[idx * 3 + 1] = r.z; a.normals[idx * 3 + 2] = r.w;
+          const bool active = fabsf(f) > a.tol;
+          a.mask[idx] = active ? 0 : 1;
+          if (active && a.do_move) {
+            float qx = a.pts[idx * 3], qy = a.pts[idx * 3 + 1], qz = a.pts[idx * 3 + 2];
+            iso_newton_move(f, r.y, r.z, r.w, qx, qy, qz);
+            a.pts[idx * 3] = qx; a.pts[idx * 3 + 1] = qy; a.pts[idx * 3 + 2] = qz;
+            survive = true;
+          }
+        }
+      }
+    }
+    if (!a.eval_only && a.do_move) {
+      const unsigned long long bal = __ballot(survive);
+      if (bal) {
+        int base = 0;
+        const int leader = __ffsll((long long)bal) - 1;
+        if (lane == leader) base = atomicAdd(a.count_out, __popcll(bal));
+        base = __shfl(base, leader);
+        if (survive) {
+          const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+          a.idx_out[base + rank] = (int32_t)idx;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int H, int NW, int NB, int MINB>
+int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
+  using S = X3Shape<H, NW, NB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_siren_step_x3<H, NW, NB, MINB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
+    attr_done = true;
+  }
+  const int64_t tiles = (n_upper + S::P - 1) / S::P;
+  const int64_t cap = 256 * MINB;
+  const int blocks = (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
+  hipLaunchKernelGGL((k_siren_step_x3<H, NW, NB, MINB>), dim3(blocks), dim3(64 * NW), S::kLds, s, a);
+  return 0;
+}
+
+}  // namespace
+
+bool siren_x3_supported(int H, int L) { return (H == 256 || H == 128) && L >= 1 && L <= 8; }
+
+int64_t siren_x3_stash_floats(int H, int L) {
+  if (H == 256) return 256 * X3Shape<256, 4, 3>::kStashPerWg(L);
+  if (H == 128) return 512 * X3Shape<128, 4, 3>::kStashPerWg(L);
+  return 0;
+}
+
+void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s) {
+  const int64_t words = siren_packed_total(H, L) - x3_base(H, L);
+  hipLaunchKernelGGL(k_siren_pack_x3, dim3(iso_stream_grid(words, 256)), dim3(256), 0, s, raw, packed, H, L);
+}
+
+int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
+  if (H == 256) return launch_x3<256, 4, 3, 1>(a, n_upper, s);
+  if (H == 128) return launch_x3<128, 4, 3, 2>(a, n_upper, s);
+  return -1;
+}
