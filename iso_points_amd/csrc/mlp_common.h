@@ -9,11 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 3-term Cody-Waite reduction by pi/2 with FMA, cephes-style minimax kernels on
 // [-pi/4, pi/4].  Max error ~1 ulp for |x| < 1e4 (tests/test_siren.py checks it
 // against float64); larger arguments take the slow libm path.
-__device__ __forceinline__ void iso_sincos(float x, float& s, float& c) {
-  if (!(fabsf(x) < 1.0e4f)) {
-    sincosf(x, &s, &c);
-    return;
-  }
+__device__ __forceinline__ void iso_sincos_core(float x, float& s, float& c) {
   const float two_over_pi = 0.636619772367581343f;
   const float p1 = 1.57079637050628662109375f;        // fl(pi/2)
   const float p2 = -4.37113882867379288655e-8f;       // fl(pi/2 - p1)
@@ -34,6 +30,86 @@ __device__ __forceinline__ void iso_sincos(float x, float& s, float& c) {
   float cc = (q & 1) ? sr : cr;
   s = (q & 2) ? -ss : ss;
   c = ((q + 1) & 2) ? -cc : cc;
+}
+
+__device__ __forceinline__ void iso_sincos(float x, float& s, float& c) {
+  if (!(fabsf(x) < 1.0e4f)) {
+    sincosf(x, &s, &c);
+    return;
+  }
+  iso_sincos_core(x, s, c);
+}
+
+// Two arguments per instruction: on gfx950 a plain wave64 VALU op issues in 4 cycles and the
+// packed f32 forms (v_pk_fma_f32 / v_pk_mul_f32) do two values in the same slot, so the
+// polynomial part of sin/cos is written on float2.  Same constants, same operation order per
+// element as iso_sincos_core (bitwise identical results).
+typedef float iso_f32x2 __attribute__((ext_vector_type(2)));
+typedef int iso_i32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void iso_sincos_core2(iso_f32x2 x, iso_f32x2& s, iso_f32x2& c) {
+  const iso_f32x2 two_over_pi = {0.636619772367581343f, 0.636619772367581343f};
+  const iso_f32x2 p1 = {1.57079637050628662109375f, 1.57079637050628662109375f};
+  const iso_f32x2 p2 = {-4.37113882867379288655e-8f, -4.37113882867379288655e-8f};
+  const iso_f32x2 p3 = {-1.71512451000588187280e-15f, -1.71512451000588187280e-15f};
+  auto splat = [](float v) { return (iso_f32x2){v, v}; };
+  iso_f32x2 t = x * two_over_pi;
+  iso_f32x2 n = {rintf(t.x), rintf(t.y)};
+  iso_f32x2 r = __builtin_elementwise_fma(-n, p1, x);
+  r = __builtin_elementwise_fma(-n, p2, r);
+  r = __builtin_elementwise_fma(-n, p3, r);
+  iso_f32x2 r2 = r * r;
+  iso_f32x2 ps = __builtin_elementwise_fma(r2, splat(-1.9515295891e-4f), splat(8.3321608736e-3f));
+  ps = __builtin_elementwise_fma(ps, r2, splat(-1.6666654611e-1f));
+  iso_f32x2 sr = __builtin_elementwise_fma(ps * r2, r, r);
+  iso_f32x2 pc = __builtin_elementwise_fma(r2, splat(2.443315711809948e-5f), splat(-1.388731625493765e-3f));
+  pc = __builtin_elementwise_fma(pc, r2, splat(4.166664568298827e-2f));
+  iso_f32x2 cr = __builtin_elementwise_fma(pc, r2 * r2, __builtin_elementwise_fma(splat(-0.5f), r2, splat(1.0f)));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = (int)n[i];
+    const float ss = (q & 1) ? cr[i] : sr[i];
+    const float cc = (q & 1) ? sr[i] : cr[i];
+    // quadrant signs as sign-bit flips: sin negative for q&2, cos negative for (q+1)&2
+    s[i] = __uint_as_float(__float_as_uint(ss) ^ (((unsigned)q & 2u) << 30));
+    c[i] = __uint_as_float(__float_as_uint(cc) ^ (((unsigned)(q + 1) & 2u) << 30));
+  }
+}
+
+// Eight arguments at once: the polynomial path for all, then ONE wave-uniform branch for the
+// (practically never taken) large-argument fix-up.  s = sin(w*z), c = w*cos(w*z).
+__device__ __forceinline__ void iso_sin_wcos8(float w, const float (&z)[8], float (&s)[8], float (&c)[8]) {
+  bool big = false;
+  const iso_f32x2 w2 = {w, w};
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const iso_f32x2 x = (iso_f32x2){z[e], z[e + 1]} * w2;
+    iso_f32x2 s2, c2;
+    iso_sincos_core2(x, s2, c2);
+    c2 = c2 * w2;
+    s[e] = s2.x; s[e + 1] = s2.y;
+    c[e] = c2.x; c[e + 1] = c2.y;
+    big |= !(fmaxf(fabsf(x.x), fabsf(x.y)) < 1.0e4f);
+  }
+  if (__builtin_expect(__any(big), 0)) {
+    // |x| >= 1e4 (never seen with trained SIRENs): libm's Payne-Hanek path, one rolled copy
+    float xs[8], ss[8], cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xs[e] = w * z[e]; ss[e] = s[e]; cs[e] = c[e]; }
+#pragma unroll 1
+    for (int e = 0; e < 8; ++e) {
+      float x = xs[0], s0, c0;
+      sincosf(x, &s0, &c0);
+      const bool fix = !(fabsf(x) < 1.0e4f);
+      const float sn = fix ? s0 : ss[0], cn = fix ? w * c0 : cs[0];
+      // rotate so that the loop body only ever touches element 0 (static register indices)
+#pragma unroll
+      for (int i = 0; i < 7; ++i) { xs[i] = xs[i + 1]; ss[i] = ss[i + 1]; cs[i] = cs[i + 1]; }
+      xs[7] = x; ss[7] = sn; cs[7] = cn;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = ss[e]; c[e] = cs[e]; }
+  }
 }
 
 template <int NT, bool HAS_BIAS>

@@ -64,6 +64,17 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mi
   }
 }
 
+// Timing experiments only (tools/build_variant.sh): -DX3_DBG_NOSINCOS / NOMMA / NOSTASH knock out
+// one ingredient each; results are then wrong by construction.
+__device__ __forceinline__ void x3_sin_wcos8(float w, const float (&z)[8], float (&s)[8], float (&c)[8]) {
+#ifdef X3_DBG_NOSINCOS
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = w * z[e]; c[e] = w; }
+#else
+  iso_sin_wcos8(w, z, s, c);
+#endif
+}
+
 __device__ __forceinline__ f32x4 as_f32x4(const u32x4& v) { return __builtin_bit_cast(f32x4, v); }
 __device__ __forceinline__ u32x4 as_u32x4(const f32x4& v) { return __builtin_bit_cast(u32x4, v); }
 
@@ -140,22 +151,38 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
 #pragma unroll
     for (int n = 0; n < NB; ++n) acc[t][n] = init;
   }
-  u32x4 A0[TW][3], A1[TW][3], B0[NB][3], B1[NB][3];
-  auto ldA = [&](u32x4 (&A)[TW][3], int s) {
+  // Operand pipeline (K loop fully unrolled, register sets indexed statically): weight fragments
+  // are requested kADist K-steps ahead (L2 latency under load exceeds one K-step of MFMAs),
+  // activation fragments one K-step ahead (LDS).
+#ifndef X3_ADIST
+#define X3_ADIST 2
+#endif
+  constexpr int kADist = X3_ADIST, kASets = kADist + 1;
+  u32x4 A[kASets][TW][3], B[2][NB][3];
+  auto ldA = [&](u32x4 (&Ar)[TW][3], int s) {
     const u32x4* p = imgw + (int64_t)s * (NTO * 3 * 64);
 #pragma unroll
     for (int t = 0; t < TW; ++t)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) A[t][c] = p[(t * 3 + c) * 64];
+      for (int c = 0; c < 3; ++c) Ar[t][c] = p[(t * 3 + c) * 64];
   };
-  auto ldB = [&](u32x4 (&B)[NB][3], int s) {
+  auto ldB = [&](u32x4 (&Br)[NB][3], int s) {
     const u32x4* p = actl + s * (NB * 3 * 64);
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) B[n][c] = p[(n * 3 + c) * 64];
+      for (int c = 0; c < 3; ++c) Br[n][c] = p[(n * 3 + c) * 64];
   };
-  auto mma = [&](const u32x4 (&A)[TW][3], const u32x4 (&B)[NB][3]) {
+  auto mma = [&](const u32x4 (&Ar)[TW][3], const u32x4 (&Br)[NB][3]) {
+#ifdef X3_DBG_NOMMA
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[t][n][c] += __builtin_bit_cast(f32x4, Ar[t][c]).x * __builtin_bit_cast(f32x4, Br[n][c]).y;
+    return;
+#endif
     // smallest terms first; consecutive MFMAs go to different accumulators
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
     constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
@@ -165,26 +192,46 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
       for (int t = 0; t < TW; ++t)
 #pragma unroll
         for (int n = 0; n < NB; ++n)
-          acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[t][PA[q]]),
-                                                              __builtin_bit_cast(bf16x8, B[n][PB[q]]),
+          acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ar[t][PA[q]]),
+                                                              __builtin_bit_cast(bf16x8, Br[n][PB[q]]),
                                                               acc[t][n], 0, 0, 0);
   };
-  ldA(A0, 0);
-  ldB(B0, 0);
-  for (int s = 0; s < NS; s += 2) {
-    ldA(A1, s + 1);
-    ldB(B1, s + 1);
+#ifndef X3_KLOOP_UNROLLED
+#define X3_KLOOP_UNROLLED 0
+#endif
+#if X3_KLOOP_UNROLLED
+#pragma unroll
+  for (int d = 0; d < kADist; ++d)
+    if (d < NS) ldA(A[d % kASets], d);
+  ldB(B[0], 0);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (s + kADist < NS) ldA(A[(s + kADist) % kASets], s + kADist);
+    if (s + 1 < NS) ldB(B[(s + 1) & 1], s + 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma(A0, B0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < NS) {
-      ldA(A0, s + 2);
-      ldB(B0, s + 2);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mma(A1, B1);
+    mma(A[s % kASets], B[s & 1]);
     __builtin_amdgcn_sched_barrier(0);
   }
+#else
+  // rolled by two K-steps (compact code: the instruction cache is shared by two CUs), operands one
+  // K-step ahead
+  ldA(A[0], 0);
+  ldB(B[0], 0);
+  for (int s = 0; s < NS; s += 2) {
+    ldA(A[1], s + 1);
+    ldB(B[1], s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(A[0], B[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < NS) {
+      ldA(A[0], s + 2);
+      ldB(B[0], s + 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(A[1], B[1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
 }
 
 // ---- the step kernel -------------------------------------------------------------------------
@@ -241,21 +288,18 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       for (int e = 0; e < 8; ++e) wv[e] = W0k[sl * 16 + e];
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
-        float hv[8], sv[8];
+        float zz[8], hv[8], sv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float z = ((wv[e].x * px[n] + wv[e].y * py[n]) + wv[e].z * pz[n]) + wv[e].w;
-          float s_, c_;
-          iso_sincos(a.w0 * z, s_, c_);
-          hv[e] = s_;
-          sv[e] = a.w0 * c_;
-        }
+        for (int e = 0; e < 8; ++e) zz[e] = ((wv[e].x * px[n] + wv[e].y * py[n]) + wv[e].z * pz[n]) + wv[e].w;
+        x3_sin_wcos8(a.w0, zz, hv, sv);
         const int k = sl * NB + n;
         u32x4 p0, p1, p2;
         split8(hv, p0, p1, p2);
         own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+#ifndef X3_DBG_NOSTASH
         stash[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
         stash[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+#endif
       }
     }
     __syncthreads();
@@ -270,56 +314,79 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       const u32x4* img = reinterpret_cast<const u32x4*>(lay + H) + (TW * w * 3) * 64 + lane;
       gemm_x3<TW, NB, NTO, NS, true>(img, lay + h * 8, act + lane, acc, w);
       __syncthreads();                      // every wave has finished reading the activations
-#pragma unroll
-      for (int t = 0; t < TW; ++t)
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            const int k = (2 * t + p) * NB + n;
-            const f32x16& v = acc[t][n];
-            park[(k * 2 + 0) * 64] = as_u32x4((f32x4){v[8 * p], v[8 * p + 1], v[8 * p + 2], v[8 * p + 3]});
-            park[(k * 2 + 1) * 64] = as_u32x4((f32x4){v[8 * p + 4], v[8 * p + 5], v[8 * p + 6], v[8 * p + 7]});
-          }
       const bool top = (l == L - 1);
       f32x4* st_l = stash + (int64_t)(l + 1) * NG * 128;
-      for (int sl = 0; sl < SL; ++sl) {
-        f32x4 z[NB][2];
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          z[n][0] = as_f32x4(park[((sl * NB + n) * 2 + 0) * 64]);
-          z[n][1] = as_f32x4(park[((sl * NB + n) * 2 + 1) * 64]);
-        }
-        f32x4 wl0 = {0.f, 0.f, 0.f, 0.f}, wl1 = wl0;
+      // one 8-value group: sin / w cos, head or stash, split, store as the next layer's B entry
+      auto act_group = [&](int k, int sl, const float (&zz)[8], float& fp) {
+        float hv[8], sv[8];
+        x3_sin_wcos8(a.wh, zz, hv, sv);
         if (top) {
-          wl0 = *reinterpret_cast<const f32x4*>(WLk + sl * 16);
-          wl1 = *reinterpret_cast<const f32x4*>(WLk + sl * 16 + 4);
+          // adjoint seed of the top sine layer = head weight * w cos(w z); head dot product here
+          const f32x4 wl0 = *reinterpret_cast<const f32x4*>(WLk + sl * 16);
+          const f32x4 wl1 = *reinterpret_cast<const f32x4*>(WLk + sl * 16 + 4);
+          const float f0 = (wl0.x * hv[0] + wl0.y * hv[1]) + (wl0.z * hv[2] + wl0.w * hv[3]);
+          const float f1 = (wl1.x * hv[4] + wl1.y * hv[5]) + (wl1.z * hv[6] + wl1.w * hv[7]);
+          fp += f0 + f1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { hv[e] = wl0[e] * sv[e]; hv[4 + e] = wl1[e] * sv[4 + e]; }
+        } else {
+#ifndef X3_DBG_NOSTASH
+          st_l[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+          st_l[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+#endif
         }
+        u32x4 p0, p1, p2;
+        split8(hv, p0, p1, p2);
+        own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+      };
+#ifndef X3_DIRECT_ACT
+#define X3_DIRECT_ACT 1
+#endif
+#ifndef X3_EARLY_STASH
+#define X3_EARLY_STASH 0
+#endif
+      if constexpr (NG <= 6 && X3_DIRECT_ACT) {
+        // few enough values per lane to walk the accumulators with static indices
 #pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          float hv[8], sv[8];
+        for (int t = 0; t < TW; ++t)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float s_, c_;
-            iso_sincos(a.wh * z[n][e >> 2][e & 3], s_, c_);
-            hv[e] = s_;
-            sv[e] = a.wh * c_;
+          for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+              float zz[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) zz[e] = acc[t][n][8 * p + e];
+              act_group((2 * t + p) * NB + n, 2 * t + p, zz, fpart[n]);
+              __builtin_amdgcn_sched_barrier(0);     // one group at a time: bounds register pressure
+            }
+      } else {
+        // park the accumulators (f32) in the tail of this wave's own, now dead, LDS region and
+        // walk them with a rolled loop; results overwrite the region front to back
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const int k = (2 * t + p) * NB + n;
+              const f32x16& v = acc[t][n];
+              park[(k * 2 + 0) * 64] = as_u32x4((f32x4){v[8 * p], v[8 * p + 1], v[8 * p + 2], v[8 * p + 3]});
+              park[(k * 2 + 1) * 64] = as_u32x4((f32x4){v[8 * p + 4], v[8 * p + 5], v[8 * p + 6], v[8 * p + 7]});
+            }
+        for (int sl = 0; sl < SL; ++sl) {
+          f32x4 z[NB][2];
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            z[n][0] = as_f32x4(park[((sl * NB + n) * 2 + 0) * 64]);
+            z[n][1] = as_f32x4(park[((sl * NB + n) * 2 + 1) * 64]);
           }
-          const int k = sl * NB + n;
-          if (top) {
-            // adjoint seed of the top sine layer = head weight * w cos(w z); head dot product here
-            float f0 = (wl0.x * hv[0] + wl0.y * hv[1]) + (wl0.z * hv[2] + wl0.w * hv[3]);
-            float f1 = (wl1.x * hv[4] + wl1.y * hv[5]) + (wl1.z * hv[6] + wl1.w * hv[7]);
-            fpart[n] += f0 + f1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { hv[e] = wl0[e] * sv[e]; hv[4 + e] = wl1[e] * sv[4 + e]; }
-          } else {
-            st_l[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
-            st_l[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+          for (int n = 0; n < NB; ++n) {
+            float zz[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zz[e] = z[n][e >> 2][e & 3];
+            act_group(sl * NB + n, sl, zz, fpart[n]);
           }
-          u32x4 p0, p1, p2;
-          split8(hv, p0, p1, p2);
-          own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
         }
       }
       __syncthreads();                      // the next layer's inputs are complete
@@ -331,11 +398,22 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     for (int l = L - 1; l >= 0; --l) {
       const float* lay = a.packed + x3_off_layer(H, L, l);
       const u32x4* img = reinterpret_cast<const u32x4*>(lay + H + 3 * (H * H / 2)) + (TW * w * 3) * 64 + lane;
-      gemm_x3<TW, NB, NTO, NS, false>(img, nullptr, act + lane, acc, w);
       const f32x4* st_l = stash + (int64_t)l * NG * 128;
       f32x4 sv[NG][2];
+      auto ld_stash = [&]() {
 #pragma unroll
-      for (int k = 0; k < NG; ++k) { sv[k][0] = st_l[(k * 2) * 64]; sv[k][1] = st_l[(k * 2 + 1) * 64]; }
+        for (int k = 0; k < NG; ++k) {
+#ifdef X3_DBG_NOSTASH
+          sv[k][0] = sv[k][1] = (f32x4){1.f, 1.f, 1.f, (float)l};
+#else
+          sv[k][0] = st_l[(k * 2) * 64]; sv[k][1] = st_l[(k * 2 + 1) * 64];
+#endif
+        }
+      };
+      // w cos(w z) of the layer below: requested before the GEMM when the registers allow it
+      if constexpr (NG <= 6 && X3_EARLY_STASH) ld_stash();
+      gemm_x3<TW, NB, NTO, NS, false>(img, nullptr, act + lane, acc, w);
+      if constexpr (NG > 6 || !X3_EARLY_STASH) ld_stash();
       __syncthreads();
 #pragma unroll
       for (int t = 0; t < TW; ++t)
@@ -443,10 +521,13 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 
 }  // namespace
 
+#ifndef X3_NW
+#define X3_NW 8
+#endif
 bool siren_x3_supported(int H, int L) { return (H == 256 || H == 128) && L >= 1 && L <= 8; }
 
 int64_t siren_x3_stash_floats(int H, int L) {
-  if (H == 256) return 256 * X3Shape<256, 4, 3>::kStashPerWg(L);
+  if (H == 256) return 256 * X3Shape<256, X3_NW, 3>::kStashPerWg(L);
   if (H == 128) return 512 * X3Shape<128, 4, 3>::kStashPerWg(L);
   return 0;
 }
@@ -457,7 +538,7 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
 }
 
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
-  if (H == 256) return launch_x3<256, 4, 3, 1>(a, n_upper, s);
+  if (H == 256) return launch_x3<256, X3_NW, 3, 1>(a, n_upper, s);
   if (H == 128) return launch_x3<128, 4, 3, 2>(a, n_upper, s);
   return -1;
 }
