@@ -129,43 +129,58 @@ __global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict
 // ---- the layer GEMM --------------------------------------------------------------------------
 // acc[t][n] (32 features x 32 points each) += W[tiles of this wave] . act, K-steps 0..NS-1.
 // imgw = image + (TW*w*3)*64 + lane ;  actl = act + lane ;  bias_h = bias_k + h*8 (K-order)
-template <int TW, int NB, int NTO, int NS, bool BIAS>
+
+// Weight-fragment pipeline: 4 register sets, requested kAD = 3 K-steps ahead (an L2 hit under
+// load takes longer than one K-step of MFMAs).  The fragments of the first kAD K-steps are
+// expected in A[0..kAD-1] on entry (requested by the previous stage, so no L2 latency is exposed
+// after a barrier); on exit A[0..kAD-1] hold the first fragments of the next GEMM stage (image
+// next_imgw, K-steps next_s..).  Activation fragments (LDS) run one K-step ahead.
+constexpr int kAD = 3;
+
+template <int TW, int NTO>
+__device__ __forceinline__ void x3_load_a(u32x4 (&Ar)[TW][3], const u32x4* __restrict__ imgw, int s) {
+  const u32x4* p = imgw + (int64_t)s * (NTO * 3 * 64);
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Ar[t][c] = p[(t * 3 + c) * 64];
+}
+
+template <int TW, int NTO>
+__device__ __forceinline__ void x3_prefetch_a(u32x4 (&A)[4][TW][3], const u32x4* __restrict__ imgw, int s) {
+#pragma unroll
+  for (int d = 0; d < kAD; ++d) x3_load_a<TW, NTO>(A[d], imgw, s + d);
+}
+
+enum { kAccumulate = 0, kZero = 1, kBias = 2 };
+
+template <int TW, int NB, int NTO, int KS, int INIT>
 __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const float* __restrict__ bias_h,
-                                        const u32x4* actl, f32x16 (&acc)[TW][NB], int w) {
+                                        const u32x4* actl, f32x16 (&acc)[TW][NB], int w, int s0,
+                                        u32x4 (&A)[4][TW][3], const u32x4* __restrict__ next_imgw, int next_s) {
+  static_assert(KS % 4 == 0, "K-steps are processed in groups of four");
+  if constexpr (INIT != kAccumulate) {
 #pragma unroll
-  for (int t = 0; t < TW; ++t) {
-    f32x16 init;
-    if constexpr (BIAS) {
+    for (int t = 0; t < TW; ++t) {
+      f32x16 init;
+      if constexpr (INIT == kBias) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const float* bp = bias_h + (2 * (TW * w + t) + p) * 16;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(bp);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(bp + 4);
+        for (int p = 0; p < 2; ++p) {
+          const float* bp = bias_h + (2 * (TW * w + t) + p) * 16;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(bp);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(bp + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { init[8 * p + e] = lo[e]; init[8 * p + 4 + e] = hi[e]; }
+          for (int e = 0; e < 4; ++e) { init[8 * p + e] = lo[e]; init[8 * p + 4 + e] = hi[e]; }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) init[r] = 0.f;
       }
-    } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) init[r] = 0.f;
+      for (int n = 0; n < NB; ++n) acc[t][n] = init;
     }
-#pragma unroll
-    for (int n = 0; n < NB; ++n) acc[t][n] = init;
   }
-  // Operand pipeline (K loop fully unrolled, register sets indexed statically): weight fragments
-  // are requested kADist K-steps ahead (L2 latency under load exceeds one K-step of MFMAs),
-  // activation fragments one K-step ahead (LDS).
-#ifndef X3_ADIST
-#define X3_ADIST 2
-#endif
-  constexpr int kADist = X3_ADIST, kASets = kADist + 1;
-  u32x4 A[kASets][TW][3], B[2][NB][3];
-  auto ldA = [&](u32x4 (&Ar)[TW][3], int s) {
-    const u32x4* p = imgw + (int64_t)s * (NTO * 3 * 64);
-#pragma unroll
-    for (int t = 0; t < TW; ++t)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Ar[t][c] = p[(t * 3 + c) * 64];
-  };
+  u32x4 B[2][NB][3];
   auto ldB = [&](u32x4 (&Br)[NB][3], int s) {
     const u32x4* p = actl + s * (NB * 3 * 64);
 #pragma unroll
@@ -196,42 +211,29 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
                                                               __builtin_bit_cast(bf16x8, Br[n][PB[q]]),
                                                               acc[t][n], 0, 0, 0);
   };
-#ifndef X3_KLOOP_UNROLLED
-#define X3_KLOOP_UNROLLED 0
+  ldB(B[0], s0);
+#ifndef X3_GEMM_PRIO
+#define X3_GEMM_PRIO 0
 #endif
-#if X3_KLOOP_UNROLLED
+  __builtin_amdgcn_s_setprio(X3_GEMM_PRIO);
+#ifdef X3_KROLLED
+#pragma unroll 1
+#endif
+  for (int i = 0; i < KS; i += 4) {
 #pragma unroll
-  for (int d = 0; d < kADist; ++d)
-    if (d < NS) ldA(A[d % kASets], d);
-  ldB(B[0], 0);
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    if (s + kADist < NS) ldA(A[(s + kADist) % kASets], s + kADist);
-    if (s + 1 < NS) ldB(B[(s + 1) & 1], s + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(A[s % kASets], B[s & 1]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#else
-  // rolled by two K-steps (compact code: the instruction cache is shared by two CUs), operands one
-  // K-step ahead
-  ldA(A[0], 0);
-  ldB(B[0], 0);
-  for (int s = 0; s < NS; s += 2) {
-    ldA(A[1], s + 1);
-    ldB(B[1], s + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(A[0], B[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < NS) {
-      ldA(A[0], s + 2);
-      ldB(B[0], s + 2);
+    for (int jj = 0; jj < 4; ++jj) {
+      const int k = i + jj;                       // K-step of this stage being multiplied
+      // set (jj+3)%4 was consumed one K-step ago: refill it with K-step k+3 (or the next stage's)
+      if (k + kAD < KS) x3_load_a<TW, NTO>(A[(jj + kAD) & 3], imgw, s0 + k + kAD);
+      else x3_load_a<TW, NTO>(A[(jj + kAD) & 3], next_imgw, next_s + (k + kAD - KS));
+      if (k + 1 < KS) ldB(B[(jj + 1) & 1], s0 + k + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(A[jj], B[jj & 1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    mma(A[1], B[1]);
-    __builtin_amdgcn_sched_barrier(0);
   }
-#endif
+  // the next stage starts again at set 0: with KS % 4 == 0 the rotation is already aligned
+  __builtin_amdgcn_s_setprio(0);
 }
 
 // ---- the step kernel -------------------------------------------------------------------------
@@ -249,6 +251,18 @@ struct X3Shape {
   static_assert(NTO % NW == 0 && TW >= 1, "features must split evenly over the waves");
 };
 
+// -DX3_DBG_TIMES (timing experiment): waves of workgroup 0 stamp the shader clock at every stage
+// boundary of their second tile into the tail of the stash workspace (tools/siren_stage_times.py).
+#ifdef X3_DBG_TIMES
+#define X3_STAMP()                                                                         \
+  do {                                                                                     \
+    if (dbg_on && lane == 0) dbg[w * 128 + (dbg_i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    ++dbg_i;                                                                               \
+  } while (0)
+#else
+#define X3_STAMP() do {} while (0)
+#endif
+
 template <int H, int NW, int NB, int MINB>
 __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   using S = X3Shape<H, NW, NB>;
@@ -260,6 +274,21 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   const int w = tid >> 6, lane = tid & 63, h = lane >> 5, j = lane & 31;
   u32x4* own = act + (size_t)(SL * w) * NB * 3 * 64 + lane;      // this wave's K-steps (+lane)
   u32x4* park = own + (size_t)NG * 64;                           // last NG*2 KiB of the region
+  // Two teams (NW == 8): waves 0..NW/2-1 own the lower half of the features (K-steps 0..NS/2-1 of
+  // the next layer), the others the upper half, one wave of each team per SIMD.  Team 1 runs the
+  // same sequence of stages ONE STAGE BEHIND team 0 (it takes one extra barrier first, team 0
+  // one extra at the end), and a layer is cut into three stages
+  //     [GEMM over K-half a]  [GEMM over K-half b]  [sin/cos + split + store]
+  // so that while one wave of a SIMD is in its VALU stage its partner is in a GEMM stage: the
+  // matrix pipe and the VALU run concurrently.  Hazards: a team overwrites its K-half of the
+  // activation buffer in stage i+2 after the halves were read in stages i (own team) and i+1
+  // (other team); its new values are first read in stage i+3 / i+4.  One barrier per stage.
+#ifndef X3_SKEW
+#define X3_SKEW 0
+#endif
+  constexpr bool SKEW = (NW == 8) && X3_SKEW;
+  constexpr int KH = NS / 2;
+  const int team = SKEW ? (w >= NW / 2) : 0;
   const int L = a.L;
   const float* X = a.packed + x3_base(H, L);
   const f32x4* W0k = reinterpret_cast<const f32x4*>(X) + (SL * w * 2 + h) * 8;
@@ -268,9 +297,27 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   f32x4* stash = reinterpret_cast<f32x4*>(a.stash) +
                  ((int64_t)blockIdx.x * NW + w) * (int64_t)(L + 1) * NG * 128 + lane;
 
+  // weight images of this wave: forward / transposed image of hidden layer l
+  auto fw_img = [&](int l) {
+    return reinterpret_cast<const u32x4*>(a.packed + x3_off_layer(H, L, l) + H) + (TW * w * 3) * 64 + lane;
+  };
+  auto bw_img = [&](int l) {
+    return reinterpret_cast<const u32x4*>(a.packed + x3_off_layer(H, L, l) + H + 3 * (H * H / 2)) + (TW * w * 3) * 64 + lane;
+  };
+  u32x4 A[4][TW][3];                     // weight-fragment pipeline, carried across stages
+  x3_prefetch_a<TW, NTO>(A, fw_img(0), 0);
+
   const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
   const int64_t n_tiles = (count + P - 1) / P;
+#ifdef X3_DBG_TIMES
+  long long* dbg = reinterpret_cast<long long*>(a.stash + (int64_t)gridDim.x * S::kStashPerWg(L)) - NW * 128;
+#endif
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#ifdef X3_DBG_TIMES
+    const bool dbg_on = blockIdx.x == 0 && tile == (int64_t)gridDim.x;
+    int dbg_i = 0;
+#endif
+    X3_STAMP();
     float px[NB], py[NB], pz[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
@@ -281,6 +328,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         px[n] = a.pts[idx * 3]; py[n] = a.pts[idx * 3 + 1]; pz[n] = a.pts[idx * 3 + 2];
       }
     }
+    X3_STAMP();
+    if (SKEW && team == 1) __syncthreads();
+    X3_STAMP();
     // ---- layer 0 (3 -> H) on the VALU: this wave's H/NW features of all P points ------------
     for (int sl = 0; sl < SL; ++sl) {
       f32x4 wv[8];
@@ -302,7 +352,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 #endif
       }
     }
+    X3_STAMP();
     __syncthreads();
+    X3_STAMP();
 
     f32x16 acc[TW][NB];
     float fpart[NB];
@@ -311,9 +363,20 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     // ---- hidden layers, forward --------------------------------------------------------------
     for (int l = 0; l < L; ++l) {
       const float* lay = a.packed + x3_off_layer(H, L, l);
-      const u32x4* img = reinterpret_cast<const u32x4*>(lay + H) + (TW * w * 3) * 64 + lane;
-      gemm_x3<TW, NB, NTO, NS, true>(img, lay + h * 8, act + lane, acc, w);
-      __syncthreads();                      // every wave has finished reading the activations
+      const u32x4* img = fw_img(l);
+      const u32x4* nxt = l + 1 < L ? fw_img(l + 1) : bw_img(L - 1);
+      if constexpr (SKEW) {
+        gemm_x3<TW, NB, NTO, KH, kBias>(img, lay + h * 8, act + lane, acc, w, 0, A, img, KH);
+        X3_STAMP();
+        __syncthreads();
+        X3_STAMP();
+        gemm_x3<TW, NB, NTO, KH, kAccumulate>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0);
+      } else {
+        gemm_x3<TW, NB, NTO, NS, kBias>(img, lay + h * 8, act + lane, acc, w, 0, A, nxt, 0);
+      }
+      X3_STAMP();
+      __syncthreads();                      // both teams have read this team's K-half
+      X3_STAMP();
       const bool top = (l == L - 1);
       f32x4* st_l = stash + (int64_t)(l + 1) * NG * 128;
       // one 8-value group: sin / w cos, head or stash, split, store as the next layer's B entry
@@ -389,15 +452,16 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
           }
         }
       }
+      X3_STAMP();
       __syncthreads();                      // the next layer's inputs are complete
+      X3_STAMP();
     }
     // ---- hidden layers, reverse --------------------------------------------------------------
     float gx[NB], gy[NB], gz[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) gx[n] = gy[n] = gz[n] = 0.f;
     for (int l = L - 1; l >= 0; --l) {
-      const float* lay = a.packed + x3_off_layer(H, L, l);
-      const u32x4* img = reinterpret_cast<const u32x4*>(lay + H + 3 * (H * H / 2)) + (TW * w * 3) * 64 + lane;
+      const u32x4* img = bw_img(l);
       const f32x4* st_l = stash + (int64_t)l * NG * 128;
       f32x4 sv[NG][2];
       auto ld_stash = [&]() {
@@ -412,9 +476,20 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       };
       // w cos(w z) of the layer below: requested before the GEMM when the registers allow it
       if constexpr (NG <= 6 && X3_EARLY_STASH) ld_stash();
-      gemm_x3<TW, NB, NTO, NS, false>(img, nullptr, act + lane, acc, w);
+      const u32x4* nxt = l > 0 ? bw_img(l - 1) : fw_img(0);
+      if constexpr (SKEW) {
+        gemm_x3<TW, NB, NTO, KH, kZero>(img, nullptr, act + lane, acc, w, 0, A, img, KH);
+        X3_STAMP();
+        __syncthreads();
+        X3_STAMP();
+        gemm_x3<TW, NB, NTO, KH, kAccumulate>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0);
+      } else {
+        gemm_x3<TW, NB, NTO, NS, kZero>(img, nullptr, act + lane, acc, w, 0, A, nxt, 0);
+      }
       if constexpr (NG > 6 || !X3_EARLY_STASH) ld_stash();
+      X3_STAMP();
       __syncthreads();
+      X3_STAMP();
 #pragma unroll
       for (int t = 0; t < TW; ++t)
 #pragma unroll
@@ -444,8 +519,12 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
             }
           }
         }
-      if (l > 0) __syncthreads();
+      X3_STAMP();
+      __syncthreads();
+      X3_STAMP();
     }
+    if (SKEW && team == 0) __syncthreads();
+    X3_STAMP();
     // ---- reduce head + gradient over the lane halves and the waves -----------------------------
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
@@ -455,7 +534,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       float z = gz[n] + __shfl_xor(gz[n], 32);
       if (h == 0) red[w * P + 32 * n + j] = (f32x4){f, x, y, z};
     }
+    X3_STAMP();
     __syncthreads();
+    X3_STAMP();
     // ---- epilogue: thread tid handles point `tid` of the tile ----------------------------------
     bool survive = false;
     int64_t idx = -1;
@@ -499,7 +580,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         }
       }
     }
+    X3_STAMP();
     __syncthreads();
+    X3_STAMP();
   }
 }
 
