@@ -29,6 +29,7 @@
 //     region so that a rolled loop can walk them; results overwrite the region front to back.
 //   * reverse sweep: same GEMM on the transposed image; w*cos(w z) comes back from the
 //     per-lane global stash (written in the forward sweep by the same lane).
+#include <type_traits>
 #include "siren_common.h"
 #include "iso_newton.h"
 #include "mlp_common.h"
@@ -137,19 +138,26 @@ __global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict
 // next_imgw, K-steps next_s..).  Activation fragments (LDS) run one K-step ahead.
 constexpr int kAD = 3;
 
+// imgw is WAVE-UNIFORM (no lane term): the loads take the scalar-base + 32-bit lane-offset form,
+// so no 64-bit per-lane address registers are needed.
 template <int TW, int NTO>
-__device__ __forceinline__ void x3_load_a(u32x4 (&Ar)[TW][3], const u32x4* __restrict__ imgw, int s) {
-  const u32x4* p = imgw + (int64_t)s * (NTO * 3 * 64);
+__device__ __forceinline__ void x3_load_a(u32x4 (&Ar)[TW][3], const u32x4* __restrict__ imgw, int s,
+                                          unsigned lane) {
+  const char* p = reinterpret_cast<const char*>(imgw + (int64_t)s * (NTO * 3 * 64));
+  const unsigned lane_off = lane * 16u;      // 32-bit byte offset: keeps the scalar-base form
 #pragma unroll
-  for (int t = 0; t < TW; ++t)
+  for (int t = 0; t < TW; ++t) {
+    const char* pt = p + t * 3072;          // scalar; the three parts are immediate offsets
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Ar[t][c] = p[(t * 3 + c) * 64];
+    for (int c = 0; c < 3; ++c) Ar[t][c] = *reinterpret_cast<const u32x4*>(pt + lane_off + c * 1024);
+  }
 }
 
 template <int TW, int NTO>
-__device__ __forceinline__ void x3_prefetch_a(u32x4 (&A)[4][TW][3], const u32x4* __restrict__ imgw, int s) {
+__device__ __forceinline__ void x3_prefetch_a(u32x4 (&A)[4][TW][3], const u32x4* __restrict__ imgw, int s,
+                                              unsigned lane) {
 #pragma unroll
-  for (int d = 0; d < kAD; ++d) x3_load_a<TW, NTO>(A[d], imgw, s + d);
+  for (int d = 0; d < kAD; ++d) x3_load_a<TW, NTO>(A[d], imgw, s + d, lane);
 }
 
 enum { kAccumulate = 0, kZero = 1, kBias = 2 };
@@ -157,7 +165,8 @@ enum { kAccumulate = 0, kZero = 1, kBias = 2 };
 template <int TW, int NB, int NTO, int KS, int INIT>
 __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const float* __restrict__ bias_h,
                                         const u32x4* actl, f32x16 (&acc)[TW][NB], int w, int s0,
-                                        u32x4 (&A)[4][TW][3], const u32x4* __restrict__ next_imgw, int next_s) {
+                                        u32x4 (&A)[4][TW][3], const u32x4* __restrict__ next_imgw, int next_s,
+                                        unsigned lane) {
   static_assert(KS % 4 == 0, "K-steps are processed in groups of four");
   if constexpr (INIT != kAccumulate) {
 #pragma unroll
@@ -224,8 +233,8 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
     for (int jj = 0; jj < 4; ++jj) {
       const int k = i + jj;                       // K-step of this stage being multiplied
       // set (jj+3)%4 was consumed one K-step ago: refill it with K-step k+3 (or the next stage's)
-      if (k + kAD < KS) x3_load_a<TW, NTO>(A[(jj + kAD) & 3], imgw, s0 + k + kAD);
-      else x3_load_a<TW, NTO>(A[(jj + kAD) & 3], next_imgw, next_s + (k + kAD - KS));
+      if (k + kAD < KS) x3_load_a<TW, NTO>(A[(jj + kAD) & 3], imgw, s0 + k + kAD, lane);
+      else x3_load_a<TW, NTO>(A[(jj + kAD) & 3], next_imgw, next_s + (k + kAD - KS), lane);
       if (k + 1 < KS) ldB(B[(jj + 1) & 1], s0 + k + 1);
       __builtin_amdgcn_sched_barrier(0);
       mma(A[jj], B[jj & 1]);
@@ -271,7 +280,10 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   u32x4* act = reinterpret_cast<u32x4*>(smem_raw);
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw + S::kActBytes);   // [NW][P] {f,gx,gy,gz}
   const int tid = threadIdx.x;
-  const int w = tid >> 6, lane = tid & 63, h = lane >> 5, j = lane & 31;
+  // the wave index is wave-uniform: say so, and everything derived from it (weight-image and
+  // stash bases) lives in SGPRs; loads then use the scalar-base + lane-offset form
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, h = lane >> 5, j = lane & 31;
   u32x4* own = act + (size_t)(SL * w) * NB * 3 * 64 + lane;      // this wave's K-steps (+lane)
   u32x4* park = own + (size_t)NG * 64;                           // last NG*2 KiB of the region
   // Two teams (NW == 8): waves 0..NW/2-1 own the lower half of the features (K-steps 0..NS/2-1 of
@@ -299,13 +311,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 
   // weight images of this wave: forward / transposed image of hidden layer l
   auto fw_img = [&](int l) {
-    return reinterpret_cast<const u32x4*>(a.packed + x3_off_layer(H, L, l) + H) + (TW * w * 3) * 64 + lane;
+    return reinterpret_cast<const u32x4*>(a.packed + x3_off_layer(H, L, l) + H) + (TW * w * 3) * 64;
   };
   auto bw_img = [&](int l) {
-    return reinterpret_cast<const u32x4*>(a.packed + x3_off_layer(H, L, l) + H + 3 * (H * H / 2)) + (TW * w * 3) * 64 + lane;
+    return reinterpret_cast<const u32x4*>(a.packed + x3_off_layer(H, L, l) + H + 3 * (H * H / 2)) + (TW * w * 3) * 64;
   };
   u32x4 A[4][TW][3];                     // weight-fragment pipeline, carried across stages
-  x3_prefetch_a<TW, NTO>(A, fw_img(0), 0);
+  x3_prefetch_a<TW, NTO>(A, fw_img(0), 0, lane);
 
   const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
   const int64_t n_tiles = (count + P - 1) / P;
@@ -366,13 +378,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       const u32x4* img = fw_img(l);
       const u32x4* nxt = l + 1 < L ? fw_img(l + 1) : bw_img(L - 1);
       if constexpr (SKEW) {
-        gemm_x3<TW, NB, NTO, KH, kBias>(img, lay + h * 8, act + lane, acc, w, 0, A, img, KH);
+        gemm_x3<TW, NB, NTO, KH, kBias>(img, lay + h * 8, act + lane, acc, w, 0, A, img, KH, lane);
         X3_STAMP();
         __syncthreads();
         X3_STAMP();
-        gemm_x3<TW, NB, NTO, KH, kAccumulate>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0);
+        gemm_x3<TW, NB, NTO, KH, kAccumulate>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0, lane);
       } else {
-        gemm_x3<TW, NB, NTO, NS, kBias>(img, lay + h * 8, act + lane, acc, w, 0, A, nxt, 0);
+        gemm_x3<TW, NB, NTO, NS, kBias>(img, lay + h * 8, act + lane, acc, w, 0, A, nxt, 0, lane);
       }
       X3_STAMP();
       __syncthreads();                      // both teams have read this team's K-half
@@ -478,13 +490,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       if constexpr (NG <= 6 && X3_EARLY_STASH) ld_stash();
       const u32x4* nxt = l > 0 ? bw_img(l - 1) : fw_img(0);
       if constexpr (SKEW) {
-        gemm_x3<TW, NB, NTO, KH, kZero>(img, nullptr, act + lane, acc, w, 0, A, img, KH);
+        gemm_x3<TW, NB, NTO, KH, kZero>(img, nullptr, act + lane, acc, w, 0, A, img, KH, lane);
         X3_STAMP();
         __syncthreads();
         X3_STAMP();
-        gemm_x3<TW, NB, NTO, KH, kAccumulate>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0);
+        gemm_x3<TW, NB, NTO, KH, kAccumulate>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0, lane);
       } else {
-        gemm_x3<TW, NB, NTO, NS, kZero>(img, nullptr, act + lane, acc, w, 0, A, nxt, 0);
+        gemm_x3<TW, NB, NTO, NS, kZero>(img, nullptr, act + lane, acc, w, 0, A, nxt, 0, lane);
       }
       if constexpr (NG > 6 || !X3_EARLY_STASH) ld_stash();
       X3_STAMP();
@@ -586,6 +598,24 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   }
 }
 
+#include "siren_x3_pipe.h"
+
+template <int H, int NW, int NB, int MINB>
+int launch_x3p(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
+  using S = X3Shape<H, NW, NB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_siren_step_x3p<H, NW, NB, MINB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
+    attr_done = true;
+  }
+  const int64_t tiles = (n_upper + S::P - 1) / S::P;
+  const int64_t cap = 256 * MINB;
+  const int blocks = (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
+  hipLaunchKernelGGL((k_siren_step_x3p<H, NW, NB, MINB>), dim3(blocks), dim3(64 * NW), S::kLds, s, a);
+  return 0;
+}
+
 template <int H, int NW, int NB, int MINB>
 int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
   using S = X3Shape<H, NW, NB>;
@@ -605,7 +635,10 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 }  // namespace
 
 #ifndef X3_NW
-#define X3_NW 8
+#define X3_NW 4
+#endif
+#ifndef X3_PIPE
+#define X3_PIPE 0      // 1: software-pipelined kernel (siren_x3_pipe.h, NW == 4; measured: no gain); 0: plain stages
 #endif
 bool siren_x3_supported(int H, int L) { return (H == 256 || H == 128) && L >= 1 && L <= 8; }
 
@@ -621,7 +654,11 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
 }
 
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
+#if X3_PIPE
+  if (H == 256) return launch_x3p<256, 4, 3, 1>(a, n_upper, s);
+#else
   if (H == 256) return launch_x3<256, X3_NW, 3, 1>(a, n_upper, s);
+#endif
   if (H == 128) return launch_x3<128, 4, 3, 2>(a, n_upper, s);
   return -1;
 }
