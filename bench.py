@@ -263,7 +263,14 @@ def main():
                          "kernel": ("k_siren_step_x3<256,4,3> (fused SIREN SDF+grad Newton step, 3xbf16 MFMA)" if x3
                                     else "k_siren_step<16> (fused SIREN SDF+grad Newton step, f32 MFMA)"),
                          "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": None,
+                         "frac": round(ach / peak, 4),
+                         # HBM-side bytes per launch from the PMC passes of this same command
+                         # (profiles/r01_v5_pmc_3.txt, _4.txt: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction);
+                         # bench.py cannot run rocprofv3 on itself, so this is the committed measurement
+                         "traffic": 1.944e9 if x3 else 2.47e9,
+                         "traffic_note": "bytes/launch, PMC (2*FETCH_SIZE+WRITE_SIZE) from profiles/; algorithmic point "
+                                         "I/O is %.1f MB/launch -- the rest is the w*cos stash round trip"
+                                         % (evals_per_step / max(launches_per_step, 1) * 37 / 1e6),
                          "peak_note": ("bf16 dense MFMA peak 2516.6 / 6 passes per f32 product; executed bf16 "
                                        "rate = %.1f TFLOP/s" % (ach * X3_PASSES)) if x3 else "f32 dense MFMA peak",
                          "launches_per_step": launches_per_step,
