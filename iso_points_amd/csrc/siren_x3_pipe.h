@@ -1,28 +1,36 @@
 // Included by siren_x3.hip (inside its anonymous namespace): the software-pipelined variant of
-// the split-bf16 SIREN step kernel.
+// the split-bf16 SIREN step kernel.  EXPERIMENT, not the default (build siren_x3.hip with
+// -DX3_PIPE=1 -fno-slp-vectorize): it passes the same tests and runs as fast as the plain kernel
+// (4.46-4.59 vs 4.55 ms per 1 M evaluations), so the simpler kernel stays the default.
 //
 // One wave per SIMD (NW = 4).  Measured on the plain kernel (tools/siren_stage_times.py): per
 // 96-point tile the matrix pipe is busy 51 % of the time and the sin/cos + split stages (VALU,
-// 4 cycles per wave instruction) take 36 % -- strictly one after the other, and two co-resident
-// MFMA streams on one SIMD only reach 47 cycles per 32x32x16 MFMA instead of 32.  So the overlap
-// has to come from ONE wave issuing both: the activation of layer l is fused with the GEMM of
-// layer l+1 and both advance in SL = 2*TW rounds,
+// 4 cycles per wave instruction) take 36 % -- strictly one after the other.  Here the activation
+// of layer l is fused with the GEMM of layer l+1 and both advance in SL = 2*TW rounds,
 //
 //   round r of the GEMM consumes K-steps { SL*w' + r : w' = 0..NW-1 }  = group r of every wave,
-//   while the wave's VALU produces its group r+1 (sin/cos, split, LDS store) in the shadow of
-//   those MFMAs (an MFMA occupies 3 of the 8 issue slots of its 32 cycles).
+//   while the wave's VALU produces its group r+1 (sin/cos, split, LDS store) between those MFMAs,
+//   pair by pair, spread evenly over the K-steps of the round (sched_group_barrier: 1 MFMA, 7 VALU).
 //
 // A stage = [park accumulators in the dead tail of the own LDS region] [produce group 0]
 // barrier { [MFMA round r || produce group r+1] barrier } x SL.  The barrier that ends a round
 // publishes group r+1 and retires the readers of group r; the last one also tells every wave
-// that the whole input vector is dead (the next stage may park / overwrite).  The weight-fragment
-// pipeline (4 register sets, 3 K-steps ahead) runs through all stages of a tile and into the
-// next tile.
+// that the whole input vector is dead (the next stage may park / overwrite).
+//
+// What the hardware does with it (tools/probes/mfma_filler.hip, one wave per SIMD, cycles per
+// v_mfma_f32_32x32x16_bf16 with N independent fillers behind it): plain v_fma_f32 N=2/4/6/8 ->
+// 34.0/36.7/38.4/47.7 (32.0 bare), i.e. ~6 plain VALU ops per MFMA are nearly free; a dependent
+// chain 6 -> 55; v_pk_fma_f32 2/4/8 -> 46/59/85 (!): packed f32 ops must not sit beside MFMAs, so
+// the in-round producers use plain f32 ops (and SLP vectorisation has to be off, it re-packs them).
+// With 7 fillers per MFMA a fused round takes 7.5 k cycles against 5.9 k for an MFMA-only round:
+// the 960 VALU ops of a round cost 1.6 k instead of 4.0 k.  That gain (about 3.5 k per forward
+// stage) is eaten by the five barriers per stage instead of two, the exposed first group and the
+// B-operand prologue after every barrier; the reverse stages, which have little VALU work, get
+// slower.  A version of this that pays would need the rounds to be barrier-free.
 //
 // sin/cos here is the branch-free Cody-Waite + minimax path only (|w z| < 1e5: max abs error
-// 1.1e-7 up to 1e6, tests/test_projection_gpu.py); a larger argument -- impossible for a SIREN
-// with finite weights of sane size -- turns that point's SDF into NaN instead of silently using
-// an inaccurate value.
+// 1.1e-7 up to 1e6); a larger argument -- impossible for a SIREN with finite weights of sane
+// size -- turns that point's SDF into NaN instead of silently using an inaccurate value.
 
 // PACKED: two values per v_pk_* instruction (fewest issue slots: right when no MFMA is in flight);
 // !PACKED: plain f32 ops -- beside MFMAs of the same wave a packed f32 op costs ~12 cycles more
@@ -58,6 +66,20 @@ __device__ __forceinline__ void x3p_sin_wcos8(float w, const float (&z)[8], floa
       amax = __builtin_fmaxf(amax, __builtin_fabsf(x));
     }
   }
+#endif
+}
+
+// two values with plain f32 ops (see above: packed ops are poison beside the wave's own MFMAs)
+__device__ __forceinline__ void x3p_sin_wcos2(float w, float z0, float z1, float& s0, float& s1, float& c0,
+                                              float& c1, float& amax) {
+#ifdef X3_DBG_NOSINCOS
+  s0 = w * z0; s1 = w * z1; c0 = w; c1 = w;
+#else
+  const float x0 = w * z0, x1 = w * z1;
+  iso_sincos_core(x0, s0, c0);
+  iso_sincos_core(x1, s1, c1);
+  c0 *= w; c1 *= w;
+  amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));
 #endif
 }
 
@@ -126,6 +148,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3p(SirenArgs a) {
     }
     f32x16 acc[TW][NB];
     u32x4 B[2][NB][3];
+    float gq[8], gh[8], gs[8];           // the group being produced pair by pair inside a GEMM round (gz also: adjoint)
 
     auto ldB = [&](u32x4 (&Br)[NB][3], int s) {
       const u32x4* p = actl + s * (NB * 3 * 64);
@@ -183,7 +206,12 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3p(SirenArgs a) {
           }
     };
     // One fused stage: `prod(r, n)` produces group (r, n) of this wave's part of the GEMM input.
-    auto stage = [&](const u32x4* img, const u32x4* nxt, const float* bias_h, auto&& prod) {
+    // `pair(r, pi)` produces values 2*(pi%4), +1 of group (r, pi/4) with plain f32 ops and finishes the
+    // group with its 4th pair; the 4*NB pairs of round r+1 are spread evenly over the NW K-steps of
+    // GEMM round r.
+    constexpr int PPK = 4 * NB / NW;          // pairs per K-step
+    static_assert(PPK * NW == 4 * NB, "pairs must divide evenly over the K-steps of a round");
+    auto stage = [&](const u32x4* img, const u32x4* nxt, const float* bias_h, auto&& prod, auto&& pair) {
 #pragma unroll
       for (int n = 0; n < NB; ++n) prod(0, n, std::true_type{});
       X3_STAMP();
@@ -218,9 +246,25 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3p(SirenArgs a) {
           if (jj + 1 < NW) ldB(B[(jj + 1) & 1], s_of(q + 1));
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (decltype(with_prod)::value) {
-            if (jj < NB) prod(r + 1, jj, std::false_type{});       // VALU work issued in the shadow of the MFMAs below
+            // VALU work issued in the shadow of the MFMAs below
+#pragma unroll
+            for (int pi = PPK * jj; pi < PPK * (jj + 1); ++pi) pair(r + 1, pi);
           }
           mma(A[jj % kSets], B[jj & 1]);
+          if constexpr (decltype(with_prod)::value) {
+            {
+              // ask for  MFMA, kFill VALU, MFMA, kFill VALU, ...  (plain f32 VALU ops hide behind
+              // an MFMA of the same wave up to ~6 per MFMA: tools/probes/mfma_filler.hip)
+#ifndef X3P_FILL
+#define X3P_FILL 7
+#endif
+#pragma unroll
+              for (int g = 0; g < TW * NB * 6; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, X3P_FILL, 0);
+              }
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         X3_STAMP();
@@ -249,8 +293,22 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3p(SirenArgs a) {
         stash[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
 #endif
       };
+      auto pair0 = [&](int r, int pi) {
+        const int n = pi >> 2, e0 = 2 * (pi & 3), k = r * NB + n;
+        const f32x4 w0 = W0k[r * 16 + e0], w1 = W0k[r * 16 + e0 + 1];
+        const float z0 = ((w0.x * px[n] + w0.y * py[n]) + w0.z * pz[n]) + w0.w;
+        const float z1 = ((w1.x * px[n] + w1.y * py[n]) + w1.z * pz[n]) + w1.w;
+        x3p_sin_wcos2(a.w0, z0, z1, gh[e0], gh[e0 + 1], gs[e0], gs[e0 + 1], amax[n]);
+        if ((pi & 3) == 3) {
+          store_group(k, gh);
+#ifndef X3_DBG_NOSTASH
+          stash[(k * 2 + 0) * 64] = (f32x4){gs[0], gs[1], gs[2], gs[3]};
+          stash[(k * 2 + 1) * 64] = (f32x4){gs[4], gs[5], gs[6], gs[7]};
+#endif
+        }
+      };
       const float* lay = a.packed + x3_off_layer(H, L, 0);
-      stage(fw_img(0), L > 1 ? fw_img(1) : bw_img(L - 1), lay + h * 8, prod0);
+      stage(fw_img(0), L > 1 ? fw_img(1) : bw_img(L - 1), lay + h * 8, prod0, pair0);
     }
     // ---- S_l, l = 1..L-1: sin/cos of hidden layer l-1 fused with the GEMM of hidden layer l --------
     for (int l = 1; l < L; ++l) {
@@ -267,8 +325,20 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3p(SirenArgs a) {
         st_l[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
 #endif
       };
+      auto pair = [&](int r, int pi) {
+        const int n = pi >> 2, e0 = 2 * (pi & 3), k = r * NB + n;
+        if ((pi & 3) == 0) load_park(k, gq);
+        x3p_sin_wcos2(a.wh, gq[e0], gq[e0 + 1], gh[e0], gh[e0 + 1], gs[e0], gs[e0 + 1], amax[n]);
+        if ((pi & 3) == 3) {
+          store_group(k, gh);
+#ifndef X3_DBG_NOSTASH
+          st_l[(k * 2 + 0) * 64] = (f32x4){gs[0], gs[1], gs[2], gs[3]};
+          st_l[(k * 2 + 1) * 64] = (f32x4){gs[4], gs[5], gs[6], gs[7]};
+#endif
+        }
+      };
       const float* lay = a.packed + x3_off_layer(H, L, l);
-      stage(fw_img(l), l + 1 < L ? fw_img(l + 1) : bw_img(L - 1), lay + h * 8, prod);
+      stage(fw_img(l), l + 1 < L ? fw_img(l + 1) : bw_img(L - 1), lay + h * 8, prod, pair);
     }
     // ---- S_L: top sine layer (head dot product, adjoint seed) fused with the first reverse GEMM ----
     {
@@ -287,7 +357,22 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3p(SirenArgs a) {
         for (int e = 0; e < 4; ++e) { hv[e] = wl0[e] * sv[e]; hv[4 + e] = wl1[e] * sv[4 + e]; }
         store_group(k, hv);
       };
-      stage(bw_img(L - 1), L > 1 ? bw_img(L - 2) : fw_img(0), nullptr, prod);
+      auto pair = [&](int r, int pi) {
+        const int n = pi >> 2, e0 = 2 * (pi & 3), k = r * NB + n;
+        if ((pi & 3) == 0) load_park(k, gq);
+        x3p_sin_wcos2(a.wh, gq[e0], gq[e0 + 1], gh[e0], gh[e0 + 1], gs[e0], gs[e0 + 1], amax[n]);
+        if ((pi & 3) == 3) {
+          const f32x4 wl0 = *reinterpret_cast<const f32x4*>(WLk + r * 16);
+          const f32x4 wl1 = *reinterpret_cast<const f32x4*>(WLk + r * 16 + 4);
+          const float f0 = (wl0.x * gh[0] + wl0.y * gh[1]) + (wl0.z * gh[2] + wl0.w * gh[3]);
+          const float f1 = (wl1.x * gh[4] + wl1.y * gh[5]) + (wl1.z * gh[6] + wl1.w * gh[7]);
+          fpart[n] += f0 + f1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gh[e] = wl0[e] * gs[e]; gh[4 + e] = wl1[e] * gs[4 + e]; }
+          store_group(k, gh);
+        }
+      };
+      stage(bw_img(L - 1), L > 1 ? bw_img(L - 2) : fw_img(0), nullptr, prod, pair);
     }
     // ---- reverse sweep: adjoint * w cos(w z) of the layer below, fused with the next reverse GEMM --
     for (int jl = L - 2; jl >= 0; --jl) {
@@ -298,7 +383,12 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3p(SirenArgs a) {
         load_park(k, av);
         store_group(k, av);
       };
-      stage(bw_img(jl), jl > 0 ? bw_img(jl - 1) : fw_img(0), nullptr, prod);
+      auto pair = [&](int r, int pi) {
+        const int k = r * NB + (pi >> 2);
+        if ((pi & 3) == 0) load_park(k, gq);
+        if ((pi & 3) == 3) store_group(k, gq);
+      };
+      stage(bw_img(jl), jl > 0 ? bw_img(jl - 1) : fw_img(0), nullptr, prod, pair);
     }
     // ---- layer 0 reverse: grad = W0^T (adjoint . w0 cos) -------------------------------------------
     float gx[NB], gy[NB], gz[NB];
