@@ -72,12 +72,8 @@ def test_project_empty(dev):
 
 
 def _siren(hidden, n_layers, seed=0, fit=0):
-    O = _oracle()
-    torch.manual_seed(seed)
-    m = O.SirenSDF(hidden_size=hidden, n_layers=n_layers)
-    if fit:
-        O.fit_siren_to_sphere(m, steps=fit)
-    return m
+    from util import fitted_siren
+    return fitted_siren(_oracle(), hidden, n_layers, seed=seed, fit=fit)
 
 
 @pytest.mark.parametrize("hidden,n_layers", [(256, 3), (64, 1), (128, 2), (256, 0), (256, 1), (128, 4)])

@@ -49,8 +49,8 @@ def test_resample_full(dev, model_kind, sample_iters, stop_tol):
     if model_kind == "sphere":
         m_cpu, m_gpu = O.SphereSDF(), SphereSDF().to(dev)
     else:
-        torch.manual_seed(0)
-        m_cpu = O.fit_siren_to_sphere(O.SirenSDF(hidden_size=256, n_layers=3), steps=200)
+        from util import fitted_siren
+        m_cpu = fitted_siren(O, 256, 3, seed=0, fit=200)
         m_gpu = m_cpu
     num = torch.tensor([P])
     r0 = O.project_points(m_cpu, pts, num, proj_max_iters=10, proj_tolerance=stop_tol)

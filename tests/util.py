@@ -43,3 +43,21 @@ def assert_projection_close(res_pts, ref_pts, stop_tol=5e-5, tol=1e-5, max_flip_
     if bad.any():
         assert err[bad].max().item() < 3 * stop_tol / scale.item() + tol, \
             "point differs by %g (> one residual Newton move)" % err[bad].max().item()
+
+
+_FIT_CACHE = {}
+
+
+def fitted_siren(O, hidden, n_layers, seed=0, fit=0):
+    """oracle SirenSDF(hidden, n_layers) seeded and Adam-fitted to the unit sphere for `fit` steps.
+    The (deterministic, CPU) fit takes ~20 s for 4x256: it is done once per test session and a
+    deep copy is handed out."""
+    import copy
+    key = (hidden, n_layers, seed, fit)
+    if key not in _FIT_CACHE:
+        torch.manual_seed(seed)
+        m = O.SirenSDF(hidden_size=hidden, n_layers=n_layers)
+        if fit:
+            O.fit_siren_to_sphere(m, steps=fit)
+        _FIT_CACHE[key] = m
+    return copy.deepcopy(_FIT_CACHE[key])
