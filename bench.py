@@ -132,6 +132,27 @@ class Cycle(object):
         return counts
 
 
+def analytic_cycle(dev, comm, args):
+    """SURVEY 8(d) cfg 3a: the same cycle with the analytic sphere SDF -- the HBM-bound variant.
+    Reported beside the headline (cfg 3b), not instead of it."""
+    from iso_points_amd.sdf_models import SphereSDF
+    cyc = Cycle(dev, SphereSDF().to(dev), comm)
+    for _ in range(max(args.warmup, 1)):
+        cyc.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cyc.step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    gb = 1.19                                            # SURVEY 8(d): algorithmic bytes of one cfg-3a cycle
+    return {"ms_per_step": round(ms, 4), "value": round(P_TOTAL / (ms * 1e-3) / 1e6, 3), "unit": "Mpoints/s",
+            "roofline": {"bound": "hbm", "achieved": round(gb / (ms * 1e-3) / 1e3, 4), "peak": PEAK_HBM_TBS,
+                         "unit": "TB/s", "frac": round(gb / (ms * 1e-3) / 1e3 / PEAK_HBM_TBS, 4),
+                         "note": "1.19 GB algorithmic bytes per cycle (SURVEY 8(d)); the neighbour-search and "
+                                 "raster stages are latency/L2-bound, not HBM-bound"}}
+
+
 def cpu_baseline(gpu_model):
     """The oracle (CPU restatement of the reference's pure-PyTorch path + C rasteriser) timed on
     the host cores on a bounded sample of the same workload (same fitted SIREN weights)."""
@@ -279,6 +300,8 @@ def main():
                          "active_points_per_launch_rank0": counts,
                          "share_of_step": round(siren_ms / args.steps / ms_per_step, 4)},
         }
+        if world == 1:
+            out["cfg3a_analytic_sdf"] = analytic_cycle(dev, comm, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))

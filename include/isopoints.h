@@ -125,8 +125,8 @@ int iso_idr_sdf_grad(const float* pts, float* sdf_out, float* grad_out, int64_t 
  * ---------------------------------------------------------------------- */
 #define ISO_GRID3_PARAMS 8
 #define ISO_GRID2_PARAMS 6
-#define ISO_GRID_MAX_RES 128
-/* upper bound of `total` for a grid built by iso_frnn_make_grid */
+#define ISO_GRID_MAX_RES 256
+/* upper bound of `total` for a grid built by iso_frnn_make_grid with max_res = ISO_GRID_MAX_RES */
 #define ISO_GRID3_MAX_CELLS ((ISO_GRID_MAX_RES + 1) * (ISO_GRID_MAX_RES + 1) * (ISO_GRID_MAX_RES + 1))
 
 /* Axis-aligned bounding box of each cloud: minmax (N,8) f32 =
@@ -139,12 +139,14 @@ int iso_points_bbox(const float* points, const int64_t* lengths, int n_clouds,
 /* Device-side grid sizing for clouds `points` (N, P, 3) padded, lengths (N)
  * i64 (NULL = all P), radius (N) f32.  Writes params (N, 8).  Cell size is
  * chosen from point density (about 8 points per occupied cell on a surface)
- * but never finer than r/2 or (max extent)/128; the query walks Chebyshev
+ * but never finer than r/2 or (max extent)/max_res; the query walks Chebyshev
  * rings of cells so the result does not depend on the cell size.  No host
- * sync: allocate grid arrays for ISO_GRID3_MAX_CELLS.                         */
+ * sync: the caller picks max_res (1..ISO_GRID_MAX_RES; 128 is plenty below ~250 k
+ * points, 1 M points on a surface want 256) and allocates the grid arrays for
+ * (max_res+1)^3 cells.                                                          */
 int iso_frnn_make_grid(const float* points, const int64_t* lengths,
                        const float* radius, int n_clouds, int64_t p_stride,
-                       float* grid_params, void* stream);
+                       int max_res, float* grid_params, void* stream);
 
 /* frnn._C.insert_points_cuda: cell id and arrival slot of each point;
  * cnt (N,G) must be zero on entry.  dim = 2 or 3 (points have `dim` floats).  */
@@ -185,9 +187,10 @@ int iso_frnn_counting_sort(const float* points, const int64_t* lengths,
  * processed in cell order (neighbouring lanes walk the same cells) and rows
  * are written at their original index.
  * sorted2 / sorted_idx2 / off come from the build calls above.
- * workspace (iso_frnn_query_workspace_bytes): list of the queries a single lane could not
- * finish within two rings of cells; a second kernel serves each of them with a whole wave. */
-int64_t iso_frnn_query_workspace_bytes(int n_clouds, int64_t p1_stride);
+ * workspace (iso_frnn_query_workspace_bytes, 16-B aligned): list of the queries a single lane
+ * could not finish within two rings of cells (a second kernel serves each of them with a whole
+ * wave), and the per-call candidate records (x,y,z,index: one 16-B load per candidate).        */
+int64_t iso_frnn_query_workspace_bytes(int n_clouds, int64_t p1_stride, int64_t p2_stride);
 int iso_frnn_query(const float* points1, const int64_t* lengths1,
                    const float* points2, const float* sorted2,
                    const int32_t* sorted_idx2,

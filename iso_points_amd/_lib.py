@@ -38,13 +38,13 @@ SIGNATURES = {
     "iso_project_idr": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _I, _F, _P, _L, _P]),
     "iso_idr_sdf_grad": (_I, [_P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P, _L, _P]),
     "iso_points_bbox": (_I, [_P, _P, _I, _L, _P, _P]),
-    "iso_frnn_make_grid": (_I, [_P, _P, _P, _I, _L, _P, _P]),
+    "iso_frnn_make_grid": (_I, [_P, _P, _P, _I, _L, _I, _P, _P]),
     "iso_frnn_insert_points": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),
     "iso_prefix_sum_workspace_bytes": (_L, [_L, _I]),
     "iso_prefix_sum": (_I, [_P, _P, _L, _I, _L, _P, _L, _P]),
     "iso_frnn_scan_cells": (_I, [_P, _P, _P, _I, _L, _I, _P, _L, _P]),
     "iso_frnn_counting_sort": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),
-    "iso_frnn_query_workspace_bytes": (_L, [_I, _L]),
+    "iso_frnn_query_workspace_bytes": (_L, [_I, _L, _L]),
     "iso_frnn_query": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _L, _L, _L, _P, _L, _P]),
     "iso_frnn_gather": (_I, [_P, _P, _P, _I, _L, _L, _I, _I, _P]),
     "iso_repulse": (_I, [_P, _P, _P, _L, _P, _L, _L, _I, _P, _P]),

@@ -109,7 +109,7 @@ __global__ void k_bbox_decode(unsigned* __restrict__ keys, const int64_t* __rest
 __global__ void k_grid_finalize(float* __restrict__ params,
                                 const int64_t* __restrict__ lengths,
                                 int64_t p_stride,
-                                const float* __restrict__ radius, int n_clouds) {
+                                const float* __restrict__ radius, int n_clouds, int max_res) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= n_clouds) return;
   unsigned* keys = reinterpret_cast<unsigned*>(params + n * 8);
@@ -127,16 +127,16 @@ __global__ void k_grid_finalize(float* __restrict__ params,
   float r = radius[n];
   // density-driven resolution: ~8 points per occupied cell on a 2-manifold
   float nres = ceilf(sqrtf((float)len * 0.125f));
-  nres = fminf(fmaxf(nres, 1.f), (float)ISO_GRID_MAX_RES);
+  nres = fminf(fmaxf(nres, 1.f), (float)max_res);
   float cell = emax / nres;
   float half_r = 0.5f * r;
-  if (half_r < cell) cell = fmaxf(half_r, emax / (float)ISO_GRID_MAX_RES);
+  if (half_r < cell) cell = fmaxf(half_r, emax / (float)max_res);
   if (!(cell > 1e-12f)) cell = 1.0f;  // degenerate cloud: one cell
   float res[3];
   float total = 1.f;
   for (int a = 0; a < 3; ++a) {
     res[a] = floorf(ext[a] / cell) + 1.f;
-    res[a] = fminf(res[a], (float)(ISO_GRID_MAX_RES + 1));
+    res[a] = fminf(res[a], (float)(max_res + 1));
     total *= res[a];
   }
   params[n * 8 + 0] = mn[0];
@@ -367,9 +367,11 @@ __global__ __launch_bounds__(256) void k_query(
     const float* __restrict__ params, const float* __restrict__ radius, int K,
     float* __restrict__ dists_out, int64_t* __restrict__ idxs_out,
     float* __restrict__ nn_out, int64_t p1_stride, int64_t p2_stride,
-    int64_t g_stride, int32_t* __restrict__ tail_list, int32_t* __restrict__ tail_count) {
+    int64_t g_stride, int32_t* __restrict__ tail_list, int32_t* __restrict__ tail_count,
+    const float4* __restrict__ xyzi) {
   const int n = blockIdx.y;
   const bool self = (points1 == nullptr);
+  const float4* s4 = xyzi + (int64_t)blockIdx.y * p2_stride;
   const int64_t len2 = lengths2 ? lengths2[n] : p2_stride;
   const int64_t len1 = self ? len2 : (lengths1 ? lengths1[n] : p1_stride);
   const float* gp = params + n * ISO_GRID3_PARAMS;
@@ -445,16 +447,33 @@ __global__ __launch_bounds__(256) void k_query(
               const int c1 = (x * ry + y) * rz + zb;
               const int64_t i0 = offn[c0];
               const int64_t i1 = (c1 + 1 < total) ? (int64_t)offn[c1 + 1] : len2;
-              for (int64_t i = i0; i < i1; ++i) {
-                float dx = qx - s2[i * 3], dy = qy - s2[i * 3 + 1],
-                      dz = qz - s2[i * 3 + 2];
-                float d2 = (dx * dx + dy * dy) + dz * dz;
-                if (d2 < r2 && d2 <= wd) {
-                  int oi = sidx[i];
-                  if (pair_lt(d2, oi, wd, wi)) {
-                    best.push(d2, oi, K);
-                    wd = best.worst(K);
-                    wi = best.worst_id(K);
+              // two candidates per trip: two independent 16-B loads in flight per lane
+              for (int64_t i = i0; i < i1; i += 2) {
+                const bool two = i + 1 < i1;
+                const float4 ca = s4[i];
+                const float4 cb = s4[two ? i + 1 : i];
+                {
+                  float dx = qx - ca.x, dy = qy - ca.y, dz = qz - ca.z;
+                  float d2 = (dx * dx + dy * dy) + dz * dz;
+                  if (d2 < r2 && d2 <= wd) {
+                    int oi = __float_as_int(ca.w);
+                    if (pair_lt(d2, oi, wd, wi)) {
+                      best.push(d2, oi, K);
+                      wd = best.worst(K);
+                      wi = best.worst_id(K);
+                    }
+                  }
+                }
+                if (two) {
+                  float dx = qx - cb.x, dy = qy - cb.y, dz = qz - cb.z;
+                  float d2 = (dx * dx + dy * dy) + dz * dz;
+                  if (d2 < r2 && d2 <= wd) {
+                    int oi = __float_as_int(cb.w);
+                    if (pair_lt(d2, oi, wd, wi)) {
+                      best.push(d2, oi, K);
+                      wd = best.worst(K);
+                      wi = best.worst_id(K);
+                    }
                   }
                 }
               }
@@ -551,9 +570,10 @@ __global__ __launch_bounds__(64) void k_query_tail(
     const float* __restrict__ radius, int K, float* __restrict__ dists_out,
     int64_t* __restrict__ idxs_out, float* __restrict__ nn_out, int64_t p1_stride,
     int64_t p2_stride, int64_t g_stride, const int32_t* __restrict__ tail_list,
-    const int32_t* __restrict__ tail_count) {
+    const int32_t* __restrict__ tail_count, const float4* __restrict__ xyzi) {
   const int n = blockIdx.y;
   const int lane = threadIdx.x;
+  const float4* s4 = xyzi + (int64_t)blockIdx.y * p2_stride;
   const bool self = (points1 == nullptr);
   const int64_t len2 = lengths2 ? lengths2[n] : p2_stride;
   const float* gp = params + n * ISO_GRID3_PARAMS;
@@ -616,12 +636,13 @@ __global__ __launch_bounds__(64) void k_query_tail(
             const int64_t i0 = offn[c0];
             const int64_t i1 = (c1 + 1 < total) ? (int64_t)offn[c1 + 1] : len2;
             for (int64_t i = i0; i < i1; ++i) {
-              float dx = qx - s2[i * 3], dy = qy - s2[i * 3 + 1], dz = qz - s2[i * 3 + 2];
+              const float4 ca = s4[i];
+              float dx = qx - ca.x, dy = qy - ca.y, dz = qz - ca.z;
               float d2 = (dx * dx + dy * dy) + dz * dz;
               if (d2 < r2) {
                 if (found < KMAX) ++found;
                 if (d2 <= wd) {
-                  int oi = sidx[i];
+                  int oi = __float_as_int(ca.w);
                   if (pair_lt(d2, oi, wd, wi)) {
                     best.push(d2, oi, K);
                     wd = best.worst(K);
@@ -654,6 +675,19 @@ __global__ __launch_bounds__(64) void k_query_tail(
   }
 }
 
+// candidate records for the query kernels: (x, y, z, original index as bits) -- one 16-B load per
+// candidate instead of three strided dword loads plus the index load
+__global__ void k_pack_xyzi(const float* __restrict__ sorted, const int32_t* __restrict__ sorted_idx,
+                            const int64_t* __restrict__ lengths, int64_t p_stride, float4* __restrict__ out) {
+  const int n = blockIdx.y;
+  const int64_t len = lengths ? lengths[n] : p_stride;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float* q = sorted + ((int64_t)n * p_stride + i) * 3;
+    out[(int64_t)n * p_stride + i] = make_float4(q[0], q[1], q[2], __int_as_float(sorted_idx[(int64_t)n * p_stride + i]));
+  }
+}
+
 __global__ void k_zero_i32(int32_t* p, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0;
@@ -682,9 +716,11 @@ __global__ void k_gather(const float* __restrict__ x,
 // ---------------------------------------------------------------------------
 extern "C" int iso_frnn_make_grid(const float* points, const int64_t* lengths,
                                   const float* radius, int n_clouds,
-                                  int64_t p_stride, float* grid_params,
+                                  int64_t p_stride, int max_res, float* grid_params,
                                   void* stream) {
   ISO_REQUIRE(n_clouds >= 0 && p_stride >= 0, ISO_ERR_INVALID, "iso_frnn_make_grid: bad sizes");
+  ISO_REQUIRE(max_res >= 1 && max_res <= ISO_GRID_MAX_RES, ISO_ERR_INVALID,
+              "iso_frnn_make_grid: max_res must be in [1,%d], got %d", ISO_GRID_MAX_RES, max_res);
   if (n_clouds == 0) return ISO_OK;
   ISO_REQUIRE(radius && grid_params && (points || p_stride == 0), ISO_ERR_INVALID,
               "iso_frnn_make_grid: null pointer");
@@ -697,7 +733,7 @@ extern "C" int iso_frnn_make_grid(const float* points, const int64_t* lengths,
     hipLaunchKernelGGL(k_bbox<256>, dim3(gx, n_clouds), dim3(256), 0, s, points, lengths, p_stride, keys);
   }
   hipLaunchKernelGGL(k_grid_finalize, dim3(iso_div_up(n_clouds, 64)), dim3(64), 0, s,
-                     grid_params, lengths, p_stride, radius, n_clouds);
+                     grid_params, lengths, p_stride, radius, n_clouds, max_res);
   ISO_CHECK_LAUNCH("iso_frnn_make_grid");
   return ISO_OK;
 }
@@ -825,10 +861,18 @@ extern "C" int iso_frnn_gather(const float* x, const int64_t* idx, float* out,
   return ISO_OK;
 }
 
-extern "C" int64_t iso_frnn_query_workspace_bytes(int n_clouds, int64_t p1_stride) {
+// workspace: [tail_count: n_clouds ints, padded to 64][tail_list: n_clouds*p1_stride ints]
+//            [pad to 16 B][candidate records: n_clouds*p2_stride float4]
+static int64_t query_ws_tail_bytes(int n_clouds, int64_t p1_stride) {
+  int64_t b = 4 * (64 * (int64_t)((n_clouds + 63) / 64) + (int64_t)n_clouds * p1_stride);
+  return (b + 15) / 16 * 16;
+}
+
+extern "C" int64_t iso_frnn_query_workspace_bytes(int n_clouds, int64_t p1_stride, int64_t p2_stride) {
   if (n_clouds < 0) n_clouds = 0;
   if (p1_stride < 0) p1_stride = 0;
-  return 4 * (64 * (int64_t)((n_clouds + 63) / 64) + (int64_t)n_clouds * p1_stride);
+  if (p2_stride < 0) p2_stride = 0;
+  return query_ws_tail_bytes(n_clouds, p1_stride) + 16 * (int64_t)n_clouds * p2_stride;
 }
 
 extern "C" int iso_frnn_query(const float* points1, const int64_t* lengths1,
@@ -848,23 +892,30 @@ extern "C" int iso_frnn_query(const float* points1, const int64_t* lengths1,
   ISO_REQUIRE(points1 || p1_stride == p2_stride, ISO_ERR_INVALID,
               "iso_frnn_query: self query needs p1_stride == p2_stride");
   ISO_REQUIRE(!nn_out || points2, ISO_ERR_INVALID, "iso_frnn_query: nn_out needs points2");
-  ISO_REQUIRE(workspace && workspace_bytes >= iso_frnn_query_workspace_bytes(n_clouds, p1_stride),
+  ISO_REQUIRE(workspace && workspace_bytes >= iso_frnn_query_workspace_bytes(n_clouds, p1_stride, p2_stride),
               ISO_ERR_WORKSPACE, "iso_frnn_query: workspace too small");
+  ISO_REQUIRE(((uintptr_t)workspace & 15) == 0, ISO_ERR_INVALID, "iso_frnn_query: workspace must be 16-B aligned");
   hipStream_t s = (hipStream_t)stream;
   int32_t* tail_count = (int32_t*)workspace;                 // [n_clouds] (padded to 64 ints)
   int32_t* tail_list = tail_count + 64 * ((n_clouds + 63) / 64);
+  float4* xyzi = reinterpret_cast<float4*>((char*)workspace + query_ws_tail_bytes(n_clouds, p1_stride));
   hipLaunchKernelGGL(k_zero_i32, dim3(iso_div_up(n_clouds, 64)), dim3(64), 0, s, tail_count, n_clouds);
+  if (p2_stride > 0) {
+    int gp = iso_div_up(p2_stride, 256);
+    if (gp > 4096) gp = 4096;
+    hipLaunchKernelGGL(k_pack_xyzi, dim3(gp, n_clouds), dim3(256), 0, s, sorted2, sorted_idx2, lengths2, p2_stride, xyzi);
+  }
   int gx = iso_div_up(p1_stride, 256);
   if (gx > 65535) gx = 65535;
 #define ISO_LAUNCH_Q(KM)                                                          \
   hipLaunchKernelGGL(k_query<KM>, dim3(gx, n_clouds), dim3(256), 0, s, points1,   \
                      lengths1, points2, sorted2, sorted_idx2, lengths2, off, grid_params,  \
                      radius, K, dists_out, idxs_out, nn_out, p1_stride, p2_stride, \
-                     g_stride, tail_list, tail_count);                            \
+                     g_stride, tail_list, tail_count, xyzi);                      \
   hipLaunchKernelGGL(k_query_tail<KM>, dim3(tail_blocks, n_clouds), dim3(64), 0, s, points1,      \
                      lengths1, points2, sorted2, sorted_idx2, lengths2, off, grid_params,         \
                      radius, K, dists_out, idxs_out, nn_out, p1_stride, p2_stride, g_stride,      \
-                     tail_list, tail_count)
+                     tail_list, tail_count, xyzi)
   int tail_blocks = (int)(p1_stride < 2048 ? p1_stride : 2048);
   if (tail_blocks < 1) tail_blocks = 1;
   if (K <= 8) { ISO_LAUNCH_Q(8); }

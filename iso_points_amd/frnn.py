@@ -16,14 +16,22 @@ from . import _lib
 
 GRID_3D_PARAMS_SIZE = 8
 GRID_2D_PARAMS_SIZE = 6
-MAX_RES = 128
-_G3_MAX = (MAX_RES + 1) ** 3
+MAX_RES = 256                      # ISO_GRID_MAX_RES
+
+
+def grid_max_res(p2):
+    """Cells per axis the dense grid may use: 128 is plenty below ~250 k points, a 1 M-point
+    surface wants 256 (4x fewer candidates per query); the arrays are (max_res+1)^3 ints."""
+    if p2 <= 262144:
+        return 128
+    return 192 if p2 <= 655360 else MAX_RES
 
 
 class FrnnGrid(object):
     """Opaque grid handle returned by frnn_grid_points (reusable for the same points2)."""
 
-    def __init__(self, params, off, sorted_points, sorted_idx, lengths2, points2_shape):
+    def __init__(self, params, off, sorted_points, sorted_idx, lengths2, points2_shape, g_stride=None):
+        self.g_stride = int(g_stride if g_stride is not None else off.shape[1])
         self.params = params
         self.off = off
         self.sorted_points = sorted_points
@@ -53,24 +61,26 @@ def build_grid(points2, lengths2, radius):
     assert D == 3, "frnn_grid_points: only 3-D clouds are built here (2-D: use _C.*)"
     dev = points2.device
     params = torch.empty((N, GRID_3D_PARAMS_SIZE), dtype=torch.float32, device=dev)
-    cnt = torch.zeros((N, _G3_MAX), dtype=torch.int32, device=dev)
-    off = torch.empty((N, _G3_MAX), dtype=torch.int32, device=dev)
+    max_res = grid_max_res(P2)
+    G = (max_res + 1) ** 3
+    cnt = torch.zeros((N, G), dtype=torch.int32, device=dev)
+    off = torch.empty((N, G), dtype=torch.int32, device=dev)
     cell = torch.empty((N, max(P2, 1)), dtype=torch.int32, device=dev)
     slot = torch.empty((N, max(P2, 1)), dtype=torch.int32, device=dev)
     sorted_pts = torch.empty((N, max(P2, 1), 3), dtype=torch.float32, device=dev)
     sorted_idx = torch.empty((N, max(P2, 1)), dtype=torch.int32, device=dev)
     lib = _lib.load()
-    ws_bytes = lib.iso_prefix_sum_workspace_bytes(_G3_MAX, N)
+    ws_bytes = lib.iso_prefix_sum_workspace_bytes(G, N)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     s = _lib.stream()
     p = _lib.ptr
-    _lib.call("iso_frnn_make_grid", p(points2), p(lengths2), p(radius), N, P2, p(params), s)
+    _lib.call("iso_frnn_make_grid", p(points2), p(lengths2), p(radius), N, P2, max_res, p(params), s)
     _lib.call("iso_frnn_insert_points", p(points2), p(lengths2), p(params), p(cnt), p(cell), p(slot),
-              N, P2, _G3_MAX, 3, s)
-    _lib.call("iso_frnn_scan_cells", p(cnt), p(off), p(params), N, _G3_MAX, 3, p(ws), ws_bytes, s)
+              N, P2, G, 3, s)
+    _lib.call("iso_frnn_scan_cells", p(cnt), p(off), p(params), N, G, 3, p(ws), ws_bytes, s)
     _lib.call("iso_frnn_counting_sort", p(points2), p(lengths2), p(cell), p(slot), p(off),
-              p(sorted_pts), p(sorted_idx), N, P2, _G3_MAX, 3, s)
-    return FrnnGrid(params, off, sorted_pts, sorted_idx, lengths2, points2.shape)
+              p(sorted_pts), p(sorted_idx), N, P2, G, 3, s)
+    return FrnnGrid(params, off, sorted_pts, sorted_idx, lengths2, points2.shape, g_stride=G)
 
 
 def frnn_grid_points(points1, points2, lengths1=None, lengths2=None, K=-1, r=-1, grid=None,
@@ -110,12 +120,12 @@ def frnn_grid_points(points1, points2, lengths1=None, lengths2=None, K=-1, r=-1,
             if nn is not None:
                 nn.zero_()
         p = _lib.ptr
-        ws_bytes = _lib.load().iso_frnn_query_workspace_bytes(N, P1)
+        ws_bytes = _lib.load().iso_frnn_query_workspace_bytes(N, P1, P2)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         _lib.call("iso_frnn_query", None if self_query else p(p1), None if self_query else p(l1),
                   p(p2), p(grid.sorted_points), p(grid.sorted_idx), p(l2), p(grid.off),
                   p(grid.params), p(radius), K, p(dists), p(idxs), p(nn) if nn is not None else None,
-                  N, P1, P2, _G3_MAX, p(ws), ws_bytes, _lib.stream())
+                  N, P1, P2, grid.g_stride, p(ws), ws_bytes, _lib.stream())
         grid.tail_counts = ws[: 4 * N].view(torch.int32)   # diagnostics: queries served by the tail kernel
     return dists, idxs, nn, grid
 
