@@ -232,6 +232,72 @@ __global__ void k_bin(const float* __restrict__ pts, const float* __restrict__ r
   }
 }
 
+// Same binning with the per-tile counters privatised in LDS (one view's T*T tiles fit for S <= 1024):
+// a workgroup walks kBinChunk consecutive points, counts them per tile in LDS, reserves one range per
+// touched tile with a single global atomic and (FILL) hands out the slots from LDS.  The hot tiles on
+// a silhouette otherwise take thousands of same-address global atomics.
+constexpr int kBinChunk = 8192;
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin_lds(const float* __restrict__ pts, const float* __restrict__ radii,
+                                                 const int64_t* __restrict__ first, const int64_t* __restrict__ num,
+                                                 int S, int T, int ty_begin, int ty_end,
+                                                 int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ tile_off,
+                                                 int32_t* __restrict__ pairs, int64_t capacity,
+                                                 int32_t* __restrict__ overflow) {
+  extern __shared__ int lh[];          // T*T
+  const int n = blockIdx.y;
+  const int64_t len = num[n], base = first[n];
+  const int64_t i0 = (int64_t)blockIdx.x * kBinChunk;
+  if (i0 >= len) return;
+  const int64_t i1 = min(len, i0 + kBinChunk);
+  for (int t = threadIdx.x; t < T * T; t += blockDim.x) lh[t] = 0;
+  __syncthreads();
+  auto walk = [&](auto&& visit) {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+      const int64_t p = base + i;
+      const float z = pts[p * 3 + 2];
+      if (!(z >= 0.f)) continue;  // behind the camera (rasterize_points.cu:87-88) or NaN
+      int x0, x1, y0, y1;
+      if (!pixel_range(pts[p * 3], radii[p * 2], S, x0, x1)) continue;
+      if (!pixel_range(pts[p * 3 + 1], radii[p * 2 + 1], S, y0, y1)) continue;
+      for (int ty = max(y0 / TILE, ty_begin); ty <= min(y1 / TILE, ty_end - 1); ++ty)
+        for (int tx = x0 / TILE; tx <= x1 / TILE; ++tx) visit(ty * T + tx, p);
+    }
+  };
+  walk([&](int t, int64_t) { atomicAdd(&lh[t], 1); });
+  __syncthreads();
+  for (int t = threadIdx.x; t < T * T; t += blockDim.x) {
+    const int c = lh[t];
+    if (c) {
+      const int b = atomicAdd(&tile_cnt[n * T * T + t], c);
+      if (FILL) lh[t] = b;
+    }
+  }
+  if (!FILL) return;
+  __syncthreads();
+  walk([&](int t, int64_t p) {
+    const int slot = atomicAdd(&lh[t], 1);
+    const int64_t dst = (int64_t)tile_off[n * T * T + t] + slot;
+    if (dst < capacity) pairs[dst] = (int32_t)p;
+    else *overflow = 1;
+  });
+}
+
+template <bool FILL>
+void launch_bin(const float* points, const float* radii, const int64_t* first_idx, const int64_t* num_pts,
+                int n_clouds, int64_t max_pts, int S, int T, int ty0, int ty1, int32_t* tile_cnt,
+                const int32_t* tile_off, int32_t* pairs, int64_t capacity, int32_t* overflow, hipStream_t s) {
+  if (T * T <= 4096) {
+    hipLaunchKernelGGL(k_bin_lds<FILL>, dim3(iso_div_up(max_pts, kBinChunk), n_clouds), dim3(256),
+                       (size_t)T * T * sizeof(int), s, points, radii, first_idx, num_pts, S, T, ty0, ty1, tile_cnt,
+                       tile_off, pairs, capacity, overflow);
+  } else {
+    int gx = iso_div_up(max_pts, 256); if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_bin<FILL>, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, first_idx, num_pts, S, T,
+                       ty0, ty1, tile_cnt, tile_off, pairs, capacity, overflow);
+  }
+}
+
 // ---------------------------------------------------------------- raster
 template <int KMAX>
 struct PixK {
@@ -263,47 +329,84 @@ template <int KMAX>
 __global__ __launch_bounds__(256) void k_raster(
     const float* __restrict__ pts, const float* __restrict__ ellipse,
     const float* __restrict__ cutoff, const float* __restrict__ radii,
-    const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ tile_off,
-    const int32_t* __restrict__ pairs, int64_t capacity, int S, int T, int ty_begin, int ty_rows,
+    const int32_t* __restrict__ tile_order, const int32_t* __restrict__ tile_off,
+    const int32_t* __restrict__ pairs, int64_t capacity, int S, int T,
     int K, float depth_thres, int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out,
     float* __restrict__ occ_out) {
   __shared__ float s_px[256], s_py[256], s_pz[256], s_a[256], s_b[256], s_c[256], s_rx[256],
       s_ry[256], s_cut[256];
   __shared__ int s_id[256];
-  // blockIdx.x enumerates the tiles of the band [ty_begin, ty_begin+ty_rows) of every cloud
-  const int tx = blockIdx.x % T, ty = ty_begin + (blockIdx.x / T) % ty_rows,
-            n = blockIdx.x / (T * ty_rows);
-  const int tile = (n * T + ty) * T + tx;
+  // per-wave candidate lists: wave w owns pixel rows 4w..4w+3 of the tile and only walks the
+  // candidates whose y-extent reaches those rows (splats are a few pixels wide: ~40 % of them)
+  __shared__ short s_list[4][256];
+  __shared__ int s_cntw[4][4];       // [source wave][target wave]
+  // workgroups take the tiles of the band heaviest first (k_tile_order): a tile on the sphere's
+  // silhouette holds 8x the mean number of candidates and would otherwise finish long after the rest
+  const int tile = tile_order[blockIdx.x];
+  const int tx = tile % T, ty = (tile / T) % T, n = tile / (T * T);
   const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
   const int xi = tx * TILE + lx, yi = ty * TILE + ly;  // NDC pixel index
   const bool inside = xi < S && yi < S;
   const float xf = pix_to_ndc(xi, S), yf = pix_to_ndc(yi, S);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // NDC y-range of the four row bands (pix_to_ndc is increasing), widened a little so that the
+  // band test is a strict superset of the exact per-pixel test below
+  float band_lo[4], band_hi[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    band_lo[w] = pix_to_ndc(ty * TILE + 4 * w, S) - 1.0e-6f;
+    band_hi[w] = pix_to_ndc(ty * TILE + 4 * w + 3, S) + 1.0e-6f;
+  }
   PixK<KMAX> best;
   best.init();
   float wz = FLT_MAX;
   int wi = 0x7fffffff;
   const int64_t off = tile_off[tile];
-  int cnt = tile_cnt[tile];
+  int cnt = tile_off[tile + 1] - tile_off[tile];
   if (off + cnt > capacity) cnt = off < capacity ? (int)(capacity - off) : 0;  // overflow guard
   for (int c0 = 0; c0 < cnt; c0 += 256) {
     const int m = min(256, cnt - c0);
     __syncthreads();
+    bool hit_band[4] = {false, false, false, false};
     if ((int)threadIdx.x < m) {
       const int p = pairs[off + c0 + threadIdx.x];
+      const float py = pts[(int64_t)p * 3 + 1], ry = radii[(int64_t)p * 2 + 1];
       s_px[threadIdx.x] = pts[(int64_t)p * 3];
-      s_py[threadIdx.x] = pts[(int64_t)p * 3 + 1];
+      s_py[threadIdx.x] = py;
       s_pz[threadIdx.x] = pts[(int64_t)p * 3 + 2];
       s_a[threadIdx.x] = ellipse[(int64_t)p * 3];
       s_b[threadIdx.x] = ellipse[(int64_t)p * 3 + 1];
       s_c[threadIdx.x] = ellipse[(int64_t)p * 3 + 2];
       s_rx[threadIdx.x] = radii[(int64_t)p * 2];
-      s_ry[threadIdx.x] = radii[(int64_t)p * 2 + 1];
+      s_ry[threadIdx.x] = ry;
       s_cut[threadIdx.x] = cutoff[p];
       s_id[threadIdx.x] = p;
+      const float ylo = py - ry * 1.000001f - 1.0e-6f, yhi = py + ry * 1.000001f + 1.0e-6f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) hit_band[w] = !(yhi < band_lo[w]) && !(ylo > band_hi[w]);   // NaN -> kept
+    }
+    int rank[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned long long bal = __ballot(hit_band[w]);
+      rank[w] = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) s_cntw[wave][w] = __popcll(bal);
     }
     __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (hit_band[w]) {
+        int base = 0;
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) base += (sw < wave) ? s_cntw[sw][w] : 0;
+        s_list[w][base + rank[w]] = (short)threadIdx.x;
+      }
+    }
+    const int mine = s_cntw[0][wave] + s_cntw[1][wave] + s_cntw[2][wave] + s_cntw[3][wave];
+    __syncthreads();
     if (inside) {
-      for (int k = 0; k < m; ++k) {
+      for (int i = 0; i < mine; ++i) {
+        const int k = s_list[wave][i];
         const float dx = xf - s_px[k], dy = yf - s_py[k];
         if (fabsf(dx) > s_rx[k] || fabsf(dy) > s_ry[k]) continue;  // rasterize_points.cu:92
         const float q = s_a[k] * dx * dx + s_b[k] * dx * dy + s_c[k] * dy * dy;  // :94
@@ -333,6 +436,32 @@ __global__ __launch_bounds__(256) void k_raster(
       zbuf_out[pix * K + j] = ok ? best.z[j] : -1.0f;
       q_out[pix * K + j] = ok ? best.q[j] : -1.0f;
     }
+  }
+}
+
+// Tiles of the band [ty_begin, ty_begin+ty_rows) of every cloud, heaviest first (64 buckets of the
+// candidate count; the order inside a bucket is arbitrary -- it only affects scheduling).
+__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_off, int T, int ty_begin,
+                                                     int ty_rows, int n_clouds, int32_t* __restrict__ order) {
+  __shared__ int hist[64], base[64];
+  const int tiles = n_clouds * T * ty_rows;
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+  __syncthreads();
+  auto tile_of = [&](int i) { return ((i / (T * ty_rows)) * T + ty_begin + (i / T) % ty_rows) * T + i % T; };
+  auto bucket_of = [&](int tile) {
+    const int c = tile_off[tile + 1] - tile_off[tile];
+    return min(c >> 6, 63);
+  };
+  for (int i = threadIdx.x; i < tiles; i += blockDim.x) atomicAdd(&hist[bucket_of(tile_of(i))], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 63; b >= 0; --b) { base[b] = run; run += hist[b]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
+    const int tile = tile_of(i);
+    order[atomicAdd(&base[bucket_of(tile)], 1)] = tile;
   }
 }
 
@@ -733,10 +862,8 @@ extern "C" int iso_splat_bin_count(const float* points, const float* radii,
   const int T = iso_splat_tiles_per_side(image_size);
   ISO_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= T,
               ISO_ERR_INVALID, "iso_splat_bin_count: bad tile row band");
-  int gx = iso_div_up(max_pts, 256); if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(k_bin<false>, dim3(gx, n_clouds), dim3(256), 0, (hipStream_t)stream, points,
-                     radii, first_idx, num_pts, image_size, T, tile_row_begin, tile_row_end, tile_cnt,
-                     nullptr, nullptr, 0, nullptr);
+  launch_bin<false>(points, radii, first_idx, num_pts, n_clouds, max_pts, image_size, T, tile_row_begin,
+                    tile_row_end, tile_cnt, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
   ISO_CHECK_LAUNCH("iso_splat_bin_count");
   return ISO_OK;
 }
@@ -763,18 +890,19 @@ extern "C" int iso_splat_forward(const float* points, const float* ellipse, cons
   if (tile_row_begin == tile_row_end) return ISO_OK;
   if (max_pts > 0) {
     ISO_REQUIRE(points && ellipse && cutoff && radii, ISO_ERR_INVALID, "iso_splat_forward: null pointer");
-    int gx = iso_div_up(max_pts, 256); if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(k_bin<true>, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, first_idx,
-                       num_pts, image_size, T, tile_row_begin, tile_row_end, tile_cursor, tile_off,
-                       pairs, pair_capacity, overflow_flag);
+    launch_bin<true>(points, radii, first_idx, num_pts, n_clouds, max_pts, image_size, T, tile_row_begin,
+                     tile_row_end, tile_cursor, tile_off, pairs, pair_capacity, overflow_flag, s);
   }
   const int ty_rows = tile_row_end - tile_row_begin;
   const int tiles = n_clouds * T * ty_rows;
   const int K = points_per_pixel;
+  // the fill cursors are dead now: their array takes the heaviest-first tile order
+  hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tile_off, T, tile_row_begin, ty_rows, n_clouds,
+                     tile_cursor);
 #define ISO_LAUNCH_R(KM)                                                                        \
   hipLaunchKernelGGL(k_raster<KM>, dim3(tiles), dim3(256), 0, s, points, ellipse, cutoff, radii, \
-                     tile_cursor, tile_off, pairs, pair_capacity, image_size, T, tile_row_begin, \
-                     ty_rows, K, depth_merging_thres,                                            \
+                     tile_cursor, tile_off, pairs, pair_capacity, image_size, T,                 \
+                     K, depth_merging_thres,                                                     \
                      idx_out, zbuf_out, qvalue_out, occ_out)
   if (K <= 4) ISO_LAUNCH_R(4);
   else if (K <= 8) ISO_LAUNCH_R(8);
