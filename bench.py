@@ -285,6 +285,7 @@ def main():
                                     else "k_siren_step<16> (fused SIREN SDF+grad Newton step, f32 MFMA)"),
                          "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),
+                         "frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                          # HBM-side bytes per launch from the PMC passes of this same command
                          # (profiles/r01_v5_pmc_3.txt, _4.txt: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction);
                          # bench.py cannot run rocprofv3 on itself, so this is the committed measurement

@@ -79,7 +79,7 @@ __device__ __forceinline__ void iso_sincos_core2(iso_f32x2 x, iso_f32x2& s, iso_
 // Eight arguments at once: the polynomial path for all, then ONE wave-uniform branch for the
 // (practically never taken) large-argument fix-up.  s = sin(w*z), c = w*cos(w*z).
 __device__ __forceinline__ void iso_sin_wcos8(float w, const float (&z)[8], float (&s)[8], float (&c)[8]) {
-  bool big = false;
+  float amax = 0.f;
   const iso_f32x2 w2 = {w, w};
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
@@ -89,8 +89,9 @@ __device__ __forceinline__ void iso_sin_wcos8(float w, const float (&z)[8], floa
     c2 = c2 * w2;
     s[e] = s2.x; s[e + 1] = s2.y;
     c[e] = c2.x; c[e + 1] = c2.y;
-    big |= !(fmaxf(fabsf(x.x), fabsf(x.y)) < 1.0e4f);
+    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)));   // one v_max3
   }
+  const bool big = !(amax < 1.0e4f);                 // also true for NaN arguments
   if (__builtin_expect(__any(big), 0)) {
     // |x| >= 1e4 (never seen with trained SIRENs): libm's Payne-Hanek path, one rolled copy
     float xs[8], ss[8], cs[8];

@@ -420,7 +420,10 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 #ifndef X3_EARLY_STASH
 #define X3_EARLY_STASH 0
 #endif
-      if constexpr (NG <= 6 && X3_DIRECT_ACT) {
+#ifndef X3_DIRECT_NG
+#define X3_DIRECT_NG 6
+#endif
+      if constexpr (NG <= X3_DIRECT_NG && X3_DIRECT_ACT) {
         // few enough values per lane to walk the accumulators with static indices
 #pragma unroll
         for (int t = 0; t < TW; ++t)
