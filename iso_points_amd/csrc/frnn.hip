@@ -426,7 +426,54 @@ __global__ __launch_bounds__(256) void k_query(
       // wave for thousands of dependent loads.
       const int rho_stop = min(rho_max, rho0 + kRingCap);
       unfinished = rho_stop < rho_max;
-      for (int rho = rho0; rho <= rho_stop; ++rho) {
+      auto scan = [&](int64_t i0, int64_t i1) {
+        // two candidates per trip: two independent 16-B loads in flight per lane
+        for (int64_t i = i0; i < i1; i += 2) {
+          const bool two = i + 1 < i1;
+          const float4 ca = s4[i];
+          const float4 cb = s4[two ? i + 1 : i];
+          {
+            float dx = qx - ca.x, dy = qy - ca.y, dz = qz - ca.z;
+            float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < r2 && d2 <= wd) {
+              int oi = __float_as_int(ca.w);
+              if (pair_lt(d2, oi, wd, wi)) {
+                best.push(d2, oi, K);
+                wd = best.worst(K);
+                wi = best.worst_id(K);
+              }
+            }
+          }
+          if (two) {
+            float dx = qx - cb.x, dy = qy - cb.y, dz = qz - cb.z;
+            float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < r2 && d2 <= wd) {
+              int oi = __float_as_int(cb.w);
+              if (pair_lt(d2, oi, wd, wi)) {
+                best.push(d2, oi, K);
+                wd = best.worst(K);
+                wi = best.worst_id(K);
+              }
+            }
+          }
+        }
+      };
+      int rho_first = rho0;
+      bool done = false;
+      if (rho0 == 0 && rho_stop >= 1) {
+        // rings 0 and 1 together: the 3x3x3 block is nine z-runs, each one contiguous range of the
+        // sorted array (the common case ends here)
+        const int za = max(cz - 1, 0), zb = min(cz + 1, rz - 1);
+        for (int x = max(cx - 1, 0); x <= min(cx + 1, rx - 1); ++x)
+          for (int y = max(cy - 1, 0); y <= min(cy + 1, ry - 1); ++y) {
+            const int c0 = (x * ry + y) * rz + za, c1 = (x * ry + y) * rz + zb;
+            scan(offn[c0], (c1 + 1 < total) ? (int64_t)offn[c1 + 1] : len2);
+          }
+        const float g = cell * 0.999f;
+        if (g >= r || (wd < FLT_MAX && wd <= g * g)) { done = true; unfinished = false; }
+        rho_first = 2;
+      }
+      for (int rho = rho_first; rho <= rho_stop && !done; ++rho) {
         const int x0 = max(cx - rho, 0), x1 = min(cx + rho, rx - 1);
         const int y0 = max(cy - rho, 0), y1 = min(cy + rho, ry - 1);
         for (int x = x0; x <= x1; ++x) {
@@ -447,36 +494,7 @@ __global__ __launch_bounds__(256) void k_query(
               const int c1 = (x * ry + y) * rz + zb;
               const int64_t i0 = offn[c0];
               const int64_t i1 = (c1 + 1 < total) ? (int64_t)offn[c1 + 1] : len2;
-              // two candidates per trip: two independent 16-B loads in flight per lane
-              for (int64_t i = i0; i < i1; i += 2) {
-                const bool two = i + 1 < i1;
-                const float4 ca = s4[i];
-                const float4 cb = s4[two ? i + 1 : i];
-                {
-                  float dx = qx - ca.x, dy = qy - ca.y, dz = qz - ca.z;
-                  float d2 = (dx * dx + dy * dy) + dz * dz;
-                  if (d2 < r2 && d2 <= wd) {
-                    int oi = __float_as_int(ca.w);
-                    if (pair_lt(d2, oi, wd, wi)) {
-                      best.push(d2, oi, K);
-                      wd = best.worst(K);
-                      wi = best.worst_id(K);
-                    }
-                  }
-                }
-                if (two) {
-                  float dx = qx - cb.x, dy = qy - cb.y, dz = qz - cb.z;
-                  float d2 = (dx * dx + dy * dy) + dz * dz;
-                  if (d2 < r2 && d2 <= wd) {
-                    int oi = __float_as_int(cb.w);
-                    if (pair_lt(d2, oi, wd, wi)) {
-                      best.push(d2, oi, K);
-                      wd = best.worst(K);
-                      wi = best.worst_id(K);
-                    }
-                  }
-                }
-              }
+              scan(i0, i1);
             }
           }
         }
