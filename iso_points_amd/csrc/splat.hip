@@ -557,6 +557,26 @@ __global__ void k_grad_superblocks(const uint8_t* __restrict__ blk, int NB, int 
   }
 }
 
+// 8x8 pixel blocks that hold a non-zero depth gradient in any fragment slot: the point-major z sum
+// skips a point whose footprint touches none (ZbufBackwardKernel skips zeros, rasterize_points.cu:835;
+// losses on colour / occupancy alone leave grad_zbuf all zero)
+__global__ void k_gradz_blocks(const float* __restrict__ grad_zbuf, int S, int NB, int N, int K,
+                               uint8_t* __restrict__ blkz) {
+  const int64_t total = (int64_t)N * NB * NB;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    const int bx = b % NB, by = (b / NB) % NB, n = b / ((int64_t)NB * NB);
+    uint8_t any = 0;
+    for (int y = by * GB; y < min(S, (by + 1) * GB) && !any; ++y) {
+      const float* row = grad_zbuf + (((int64_t)n * S + y) * S + bx * GB) * K;
+      const int m = (min(S, (bx + 1) * GB) - bx * GB) * K;
+      for (int e = 0; e < m; ++e)
+        if (row[e] != 0.0f) { any = 1; break; }
+    }
+    blkz[b] = any;
+  }
+}
+
 // output-pixel range [lo,hi] (after the axis flip) whose centres may lie within c +- r
 __device__ __forceinline__ bool out_range(float c, float r, int S, int& lo, int& hi) {
   int a, b;
@@ -593,7 +613,8 @@ __global__ __launch_bounds__(256) void k_splat_backward(
     const float* __restrict__ pts, const float* __restrict__ radii,
     const uint8_t* __restrict__ visible, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num,
-    const uint8_t* __restrict__ blk2, int NB2, const int32_t* __restrict__ idx,
+    const uint8_t* __restrict__ blk2, int NB2, const uint8_t* __restrict__ blkz, int NB,
+    const int32_t* __restrict__ idx,
     const float* __restrict__ grad_zbuf, int S, int K, int rect_mode, float radii_s,
     int32_t* __restrict__ heavy, int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
   const int n = blockIdx.y;
@@ -615,7 +636,12 @@ __global__ __launch_bounds__(256) void k_splat_backward(
       // slot is filled): everything else has no z gradient
       if (grad_zbuf && vis) {
         int x0, x1, y0, y1;
+        bool anyz = false;
         if (pz >= 0.f && out_range(px, rx, S, x0, x1) && out_range(py, ry, S, y0, y1)) {
+          for (int by = y0 / GB; by <= y1 / GB; ++by)
+            for (int bx = x0 / GB; bx <= x1 / GB; ++bx) anyz |= blkz[((int64_t)n * NB + by) * NB + bx] != 0;
+        }
+        if (anyz) {
           // ZbufBackwardKernel semantics (zeros skipped, stop at the first idx < 0) == sum of
           // grad_zbuf over the slots whose idx is this point (a point is listed at most once per
           // pixel): look at the index list first (16-B loads), fetch a gradient only on a match
@@ -987,7 +1013,7 @@ extern "C" int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbu
 static int64_t bwd_maps_bytes(int n_clouds, int image_size) {
   int64_t nb = (image_size + GB - 1) / GB;
   int64_t nb2 = (nb + 7) / 8;
-  return (((int64_t)n_clouds * (nb * nb + nb2 * nb2)) + 63) / 64 * 64;
+  return (((int64_t)n_clouds * (2 * nb * nb + nb2 * nb2)) + 63) / 64 * 64;   // blk, blk2, blkz
 }
 
 extern "C" int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size,
@@ -1017,6 +1043,10 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
   uint8_t* blk = (uint8_t*)workspace;
   const int NB2 = (NB + 7) / 8;
   uint8_t* blk2 = blk + (int64_t)n_clouds * NB * NB;
+  uint8_t* blkz = blk2 + (int64_t)n_clouds * NB2 * NB2;
+  if (grad_zbuf)
+    hipLaunchKernelGGL(k_gradz_blocks, dim3(iso_stream_grid((int64_t)n_clouds * NB * NB, 64)), dim3(64), 0, s,
+                       grad_zbuf, image_size, NB, n_clouds, points_per_pixel, blkz);
   hipLaunchKernelGGL(k_grad_blocks, dim3(iso_stream_grid((int64_t)n_clouds * NB * NB, 256)), dim3(256),
                      0, s, grad_occ, image_size, NB, n_clouds, blk);
   hipLaunchKernelGGL(k_grad_superblocks, dim3(iso_stream_grid((int64_t)n_clouds * NB2 * NB2, 256)),
@@ -1026,7 +1056,7 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
   (void)hipMemsetAsync(heavy_count, 0, 64, s);
   int gx = iso_div_up(max_pts, 256); if (gx > 8192) gx = 8192;
   hipLaunchKernelGGL(k_splat_backward, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, visible,
-                     search_radius, first_idx, num_pts, blk2, NB2, idx, grad_zbuf, image_size,
+                     search_radius, first_idx, num_pts, blk2, NB2, blkz, NB, idx, grad_zbuf, image_size,
                      points_per_pixel, rect_mode, radii_s, heavy, heavy_count, grad_points);
   hipLaunchKernelGGL(k_splat_backward_heavy, dim3(2048), dim3(256), 0, s, points, radii, search_radius,
                      first_idx, num_pts, n_clouds, grad_occ, blk, NB, image_size, rect_mode, radii_s,
