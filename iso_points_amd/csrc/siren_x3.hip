@@ -15,7 +15,7 @@
 // runs 16x the f32 MFMA rate, so six passes are 2.7x faster than one f32 pass.
 //
 // Work decomposition (differs from siren.hip: weights are NOT staged through LDS)
-//   * one workgroup = P = 32*NB points (NB = 3), NW = 4 waves, one wave per SIMD.
+//   * one workgroup = P = 32*NB points (NB = 3), NW = 8 waves (two per SIMD; NW = 4 also builds).
 //   * the OUTPUT features of a layer are split across the waves (wave w owns tiles
 //     TW*w .. TW*w+TW-1 of 32 features): each weight element is needed by exactly one wave,
 //     which streams it from L2 straight into registers (lane-linear pre-split image, one 16-B
@@ -236,9 +236,30 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
       if (k + kAD < KS) x3_load_a<TW, NTO>(A[(jj + kAD) & 3], imgw, s0 + k + kAD, lane);
       else x3_load_a<TW, NTO>(A[(jj + kAD) & 3], next_imgw, next_s + (k + kAD - KS), lane);
       if (k + 1 < KS) ldB(B[(jj + 1) & 1], s0 + k + 1);
+#ifndef X3_INTERLEAVE_LOADS
+#define X3_INTERLEAVE_LOADS 1
+#endif
+#if X3_INTERLEAVE_LOADS
+      // the operand requests for the coming K-steps ride in the shadow of this K-step's MFMAs (one
+      // memory instruction behind each of the first MFMAs) instead of draining the matrix pipe
+      // between K-steps
+      mma(A[jj], B[jj & 1]);
+#pragma unroll
+      for (int g = 0; g < NB * 3; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < TW * 3; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#else
       __builtin_amdgcn_sched_barrier(0);
       mma(A[jj], B[jj & 1]);
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   }
   // the next stage starts again at set 0: with KS % 4 == 0 the rotation is already aligned
@@ -638,7 +659,7 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 }  // namespace
 
 #ifndef X3_NW
-#define X3_NW 4
+#define X3_NW 8
 #endif
 #ifndef X3_PIPE
 #define X3_PIPE 0      // 1: software-pipelined kernel (siren_x3_pipe.h, NW == 4; measured: no gain); 0: plain stages
