@@ -198,3 +198,28 @@ def test_generic_model_route(dev):
     g = pts.to(dev)
     res = UniformProjection()._project_points(Torus(), g, full_lengths(g), proj_max_iters=10)
     _check_projection(res, ref, Torus())
+
+
+@pytest.mark.parametrize("hidden,n_layers,P", [(256, 3, 150001), (128, 2, 150001), (64, 1, 40003)])
+def test_project_siren_is_repeatable_and_order_independent(dev, hidden, n_layers, P, gemm_mode):
+    """Random SIREN weights make the Newton iteration chaotic: a single flipped bit anywhere shows
+    up as a different end point.  The projection must be bit-identical from run to run, for a
+    shuffled copy of the cloud and for a prefix of it (a point's result may not depend on which
+    workgroup / lane it lands in) -- this is what makes the sharded cycle equal the single-GPU one."""
+    from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
+    from iso_points_amd.sdf_models import Siren
+    torch.manual_seed(0)
+    m = Siren(hidden_size=hidden, n_layers=n_layers).to(dev)
+    pts = sphere_cloud(P, seed=3).to(dev)
+    proj = UniformProjection(proj_max_iters=10, proj_tolerance=5e-5, knn_k=8)
+    ref = proj._project_points(m, pts, full_lengths(pts), proj_max_iters=10)
+    g = torch.Generator().manual_seed(7)
+    for rep in range(3):
+        out = proj._project_points(m, pts, full_lengths(pts), proj_max_iters=10)
+        assert torch.equal(out.points, ref.points) and torch.equal(out.normals, ref.normals), rep
+        perm = torch.randperm(P, generator=g).to(dev)
+        out = proj._project_points(m, pts[:, perm].contiguous(), full_lengths(pts), proj_max_iters=10)
+        assert torch.equal(out.points, ref.points[:, perm]) and torch.equal(out.normals, ref.normals[:, perm]), rep
+    half = pts[:, : P // 2].contiguous()
+    out = proj._project_points(m, half, full_lengths(half), proj_max_iters=10)
+    assert torch.equal(out.points, ref.points[:, : P // 2])
