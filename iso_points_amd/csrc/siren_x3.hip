@@ -352,7 +352,11 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   // be scheduled between the MFMAs (tools/siren_stress.py: every repeat differs; the same source
   // with one workgroup per CU, and the 8-wave H = 256 build over 60 chaotic-weight repeats, are
   // bit-stable).  Cause not found yet, so that shape keeps the loads in front of the MFMA block.
+#ifdef X3_FORCE_IL
+  constexpr bool IL = true;
+#else
   constexpr bool IL = (NW == 8);
+#endif
   constexpr int KH = NS / 2;
   const int team = SKEW ? (w >= NW / 2) : 0;
   const int L = a.L;
@@ -683,7 +687,11 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
     attr_done = true;
   }
   const int64_t tiles = (n_upper + S::P - 1) / S::P;
+#ifdef X3_CAP_BLOCKS
+  const int64_t cap = X3_CAP_BLOCKS;
+#else
   const int64_t cap = 256 * MINB;
+#endif
   const int blocks = (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
   hipLaunchKernelGGL((k_siren_step_x3<H, NW, NB, MINB>), dim3(blocks), dim3(64 * NW), S::kLds, s, a);
   return 0;

@@ -13,7 +13,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int D>
+template <int D, bool HOG>
 __global__ __launch_bounds__(512, 1) void k(float* out, int trips) {
   __shared__ u32x4 lds[2][64];
   const int lane = threadIdx.x & 63;
@@ -29,6 +29,16 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int trips) {
   u32x4 bv = lds[0][lane];
   u32x4 other = lds[0][lane];
   const unsigned ax = (unsigned)(size_t)&lds[0][lane], ay = (unsigned)(size_t)&lds[1][lane];
+  if (HOG && (threadIdx.x >> 6) >= 4) {
+    // the co-resident wave of every SIMD only streams MFMAs (an independent GEMM phase)
+    for (int t = 0; t < trips * 12; ++t) {
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n" : "+v"(f1) : "v"(a), "v"(other));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n" : "+v"(f2) : "v"(a), "v"(other));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n" : "+v"(f3) : "v"(a), "v"(other));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = trips * 16.0f + 1e-30f * (f1[0] + f2[0] + f3[0]);
+    return;
+  }
   for (int t = 0; t < trips; ++t) {
     asm volatile("s_waitcnt lgkmcnt(0)\n v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n" : "+v"(acc0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(a), "v"(bv));
 #pragma unroll
@@ -44,23 +54,24 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int trips) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int D>
+template <int D, bool HOG>
 void run(int threads) {
   const int trips = 2000, blocks = 256;
   float* d; hipMalloc((void**)&d, blocks * threads * 4);
-  hipLaunchKernelGGL(k<D>, dim3(blocks), dim3(threads), 0, 0, d, trips);
+  hipLaunchKernelGGL((k<D, HOG>), dim3(blocks), dim3(threads), 0, 0, d, trips);
   hipDeviceSynchronize();
   std::vector<float> h(blocks * threads);
   hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost);
   const float want = trips * 16.0f;      // 16 k-values of 1*1 per trip
   long bad = 0; float worst = want;
   for (float v : h) if (v != want) { ++bad; if (fabsf(v - want) > fabsf(worst - want)) worst = v; }
-  printf("waves/SIMD=%d  reader->load distance %d MFMAs: %ld of %zu lanes wrong (expected %.0f, worst %.0f)\n",
-         threads / 256, D, bad, h.size(), want, worst);
+  printf("%s waves/SIMD=%d  reader->load distance %d MFMAs: %ld of %zu lanes wrong (expected %.0f, worst %.0f)\n",
+         HOG ? "partner streams MFMAs:" : "partner runs the same code:", threads / 256, D, bad, h.size(), want, worst);
   hipFree(d);
 }
 
 int main() {
-  run<0>(256); run<0>(512); run<1>(256); run<1>(512); run<2>(512); run<4>(512); run<8>(512);
+  run<1, false>(256); run<0, false>(256); run<0, false>(512); run<1, false>(512);
+  run<0, true>(512); run<1, true>(512); run<2, true>(512); run<4, true>(512); run<8, true>(512);
   return 0;
 }
