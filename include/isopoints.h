@@ -325,8 +325,9 @@ int iso_splat_composite(const int32_t* idx, const float* qvalue, const float* oc
  *                           search_radius[n] of grad_occ * d/sdeno(|d|^2,1e-10)
  *                           (visible points; grad>0 pixels outside the splat rect
  *                           skipped), z = sum of grad_zbuf over the slots that list
- *                           the point.  No float atomics: z sums run in image order, xy sums are
- *                           lane-private partials combined by a fixed butterfly -> bit-stable.
+ *                           the point.  No float atomics: xy sums are lane-private partials
+ *                           combined by a fixed butterfly, the z sum is a pixel-major scatter in
+ *                           64-bit fixed point (integer atomics, exactly rounded) -> bit-stable.
  *                           total_points = rows of `points` (sizes the heavy-point list).
  * grad_zbuf/idx may be NULL (no z gradient); visible may be NULL (= all).
  * rect_mode = 1 switches the xy support to the slow reference kernel's rectangle

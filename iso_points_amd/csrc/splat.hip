@@ -557,25 +557,6 @@ __global__ void k_grad_superblocks(const uint8_t* __restrict__ blk, int NB, int 
   }
 }
 
-// 8x8 pixel blocks that hold a non-zero depth gradient in any fragment slot: the point-major z sum
-// skips a point whose footprint touches none (ZbufBackwardKernel skips zeros, rasterize_points.cu:835;
-// losses on colour / occupancy alone leave grad_zbuf all zero)
-__global__ void k_gradz_blocks(const float* __restrict__ grad_zbuf, int S, int NB, int N, int K,
-                               uint8_t* __restrict__ blkz) {
-  const int64_t total = (int64_t)N * NB * NB;
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total;
-       b += (int64_t)gridDim.x * blockDim.x) {
-    const int bx = b % NB, by = (b / NB) % NB, n = b / ((int64_t)NB * NB);
-    uint8_t any = 0;
-    for (int y = by * GB; y < min(S, (by + 1) * GB) && !any; ++y) {
-      const float* row = grad_zbuf + (((int64_t)n * S + y) * S + bx * GB) * K;
-      const int m = (min(S, (bx + 1) * GB) - bx * GB) * K;
-      for (int e = 0; e < m; ++e)
-        if (row[e] != 0.0f) { any = 1; break; }
-    }
-    blkz[b] = any;
-  }
-}
 
 // output-pixel range [lo,hi] (after the axis flip) whose centres may lie within c +- r
 __device__ __forceinline__ bool out_range(float c, float r, int S, int& lo, int& hi) {
@@ -606,16 +587,13 @@ __device__ __forceinline__ void occ_term(float g, float dx, float dy, float rx, 
   gy += dy / denom * g;
 }
 
-// Pass 1, one lane per point: z gradient (sum over the fragment slots that list the point, in
-// pixel order) and the cheap part of the xy gradient: a point whose support touches no 64x64
+// Pass 1, one lane per point, the cheap part of the xy gradient: a point whose support touches no 64x64
 // super block with a gradient is done (xy = 0); the others are appended to the heavy list.
 __global__ __launch_bounds__(256) void k_splat_backward(
     const float* __restrict__ pts, const float* __restrict__ radii,
     const uint8_t* __restrict__ visible, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num,
-    const uint8_t* __restrict__ blk2, int NB2, const uint8_t* __restrict__ blkz, int NB,
-    const int32_t* __restrict__ idx,
-    const float* __restrict__ grad_zbuf, int S, int K, int rect_mode, float radii_s,
+    const uint8_t* __restrict__ blk2, int NB2, int S, int rect_mode, float radii_s,
     int32_t* __restrict__ heavy, int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
   const int n = blockIdx.y;
   const int64_t len = num[n], base = first[n];
@@ -628,50 +606,10 @@ __global__ __launch_bounds__(256) void k_splat_backward(
     int64_t p = -1;
     if (i < len) {
       p = base + i;
-      float gz = 0.f;
       const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
       const float rx = radii[p * 2], ry = radii[p * 2 + 1];
       const bool vis = (!visible || visible[p]);
-      // a point that is listed anywhere is "visible" (lists are packed, so its pixel's first
-      // slot is filled): everything else has no z gradient
-      if (grad_zbuf && vis) {
-        int x0, x1, y0, y1;
-        bool anyz = false;
-        if (pz >= 0.f && out_range(px, rx, S, x0, x1) && out_range(py, ry, S, y0, y1)) {
-          for (int by = y0 / GB; by <= y1 / GB; ++by)
-            for (int bx = x0 / GB; bx <= x1 / GB; ++bx) anyz |= blkz[((int64_t)n * NB + by) * NB + bx] != 0;
-        }
-        if (anyz) {
-          // ZbufBackwardKernel semantics (zeros skipped, stop at the first idx < 0) == sum of
-          // grad_zbuf over the slots whose idx is this point (a point is listed at most once per
-          // pixel): look at the index list first (16-B loads), fetch a gradient only on a match
-          const bool vec = (K % 4) == 0;
-          for (int yo = y0; yo <= y1; ++yo)
-            for (int xo = x0; xo <= x1; ++xo) {
-              const int64_t pix = ((int64_t)n * S + yo) * S + xo;
-              int hit = -1;
-              if (vec) {
-                const int4* row = reinterpret_cast<const int4*>(idx + pix * K);
-                for (int k4 = 0; k4 < K / 4 && hit < 0; ++k4) {
-                  const int4 q = row[k4];
-                  if (q.x == (int)p) hit = k4 * 4;
-                  else if (q.y == (int)p) hit = k4 * 4 + 1;
-                  else if (q.z == (int)p) hit = k4 * 4 + 2;
-                  else if (q.w == (int)p) hit = k4 * 4 + 3;
-                  if (q.w < 0) break;
-                }
-              } else {
-                for (int k = 0; k < K; ++k) {
-                  const int q = idx[pix * K + k];
-                  if (q < 0) break;
-                  if (q == (int)p) { hit = k; break; }
-                }
-              }
-              if (hit >= 0) gz += grad_zbuf[pix * K + hit];
-            }
-        }
-      }
-      grad[p * 3] = 0.f; grad[p * 3 + 1] = 0.f; grad[p * 3 + 2] = gz;
+      grad[p * 3] = 0.f; grad[p * 3 + 1] = 0.f; grad[p * 3 + 2] = 0.f;   // z: k_z_scatter / k_z_finish
       const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
       if (vis && !(pz < 0.f || fabsf(py) > 1.0f || fabsf(px) > 1.0f) && sx > 0.f && sy > 0.f) {
         int x0, x1, y0, y1;
@@ -1010,16 +948,87 @@ extern "C" int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbu
   return ISO_OK;
 }
 
+// ---- z gradient by pixel-major scatter in 64-bit fixed point -------------------------------------
+// z_grad[p] = sum of grad_zbuf over the slots that list p (ZbufBackwardKernel, rasterize_points.cu:
+// 823-846: zeros skipped, a row ends at the first idx < 0).  The reference scatters with float
+// atomics (order-dependent).  Here every contribution is converted exactly to a 64-bit integer
+// multiple of q = 2^-e (e chosen from max|grad| so that 2^44 * q >= max|grad|), added with integer
+// atomics -- associative, so the result does not depend on the order -- and converted back once:
+// the exactly rounded sum (error <= 2^-44 max|grad| per term), bit-stable from run to run.
+struct ZScale { unsigned max_bits; int exp2; };
+
+__global__ __launch_bounds__(256) void k_z_absmax(const float* __restrict__ gz, int64_t n, ZScale* __restrict__ zs) {
+  __shared__ unsigned sm[4];
+  unsigned m = 0u;
+  const int64_t n4 = n / 4;
+  const uint4* g4 = reinterpret_cast<const uint4*>(gz);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = g4[i];                                          // |x| as ordered bits (NaN/Inf on top)
+    const unsigned a = max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), b = max(v.z & 0x7fffffffu, v.w & 0x7fffffffu);
+    m = max(m, max(a, b));
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(gz[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+    if (m) atomicMax(&zs->max_bits, m);
+  }
+}
+
+__global__ void k_z_scale(ZScale* zs) {
+  const unsigned b = zs->max_bits;
+  int e = 0;
+  if (b != 0u && b < 0x7f800000u) {
+    int ex;
+    (void)frexpf(__uint_as_float(b), &ex);      // max = f * 2^ex, f in [0.5,1)
+    e = 44 - ex;
+  }
+  zs->exp2 = e;
+}
+
+__global__ void k_z_scatter(const int32_t* __restrict__ idx, const float* __restrict__ gz, int K, int64_t npix,
+                            const ZScale* __restrict__ zs, long long* __restrict__ acc) {
+  const int e = zs->exp2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int k = 0; k < K; ++k) {
+      const int p = idx[i * K + k];
+      if (p < 0) break;
+      const float g = gz[i * K + k];
+      if (g == 0.0f) continue;
+      long long q;
+      if (g != g || fabsf(g) > 3.0e38f) q = 1ll << 61;               // poison: the point ends up NaN
+      else q = __double2ll_rn(ldexp((double)g, e));
+      atomicAdd(reinterpret_cast<unsigned long long*>(&acc[p]), (unsigned long long)q);
+    }
+  }
+}
+
+__global__ void k_z_finish(const long long* __restrict__ acc, const ZScale* __restrict__ zs, int64_t n,
+                           float* __restrict__ grad) {
+  const int e = zs->exp2;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    const long long a = acc[p];
+    float z = (float)ldexp((double)a, -e);
+    if (a >= (1ll << 60) || a <= -(1ll << 60)) z = __builtin_nanf("");
+    grad[p * 3 + 2] = z;
+  }
+}
+
 static int64_t bwd_maps_bytes(int n_clouds, int image_size) {
   int64_t nb = (image_size + GB - 1) / GB;
   int64_t nb2 = (nb + 7) / 8;
-  return (((int64_t)n_clouds * (2 * nb * nb + nb2 * nb2)) + 63) / 64 * 64;   // blk, blk2, blkz
+  return (((int64_t)n_clouds * (nb * nb + nb2 * nb2)) + 63) / 64 * 64;   // blk, blk2
 }
 
 extern "C" int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size,
                                                       int64_t total_points) {
   if (total_points < 0) total_points = 0;
-  return bwd_maps_bytes(n_clouds, image_size) + 64 + 4 * total_points;
+  // [block maps][heavy count (64 B) + heavy list (4 B/pt)][pad 16][ZScale 16 B][z accumulators 8 B/pt]
+  return bwd_maps_bytes(n_clouds, image_size) + 64 + (4 * total_points + 15) / 16 * 16 + 16 + 8 * total_points;
 }
 
 extern "C" int iso_splat_backward(const float* points, const float* radii, const uint8_t* visible,
@@ -1043,10 +1052,6 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
   uint8_t* blk = (uint8_t*)workspace;
   const int NB2 = (NB + 7) / 8;
   uint8_t* blk2 = blk + (int64_t)n_clouds * NB * NB;
-  uint8_t* blkz = blk2 + (int64_t)n_clouds * NB2 * NB2;
-  if (grad_zbuf)
-    hipLaunchKernelGGL(k_gradz_blocks, dim3(iso_stream_grid((int64_t)n_clouds * NB * NB, 64)), dim3(64), 0, s,
-                       grad_zbuf, image_size, NB, n_clouds, points_per_pixel, blkz);
   hipLaunchKernelGGL(k_grad_blocks, dim3(iso_stream_grid((int64_t)n_clouds * NB * NB, 256)), dim3(256),
                      0, s, grad_occ, image_size, NB, n_clouds, blk);
   hipLaunchKernelGGL(k_grad_superblocks, dim3(iso_stream_grid((int64_t)n_clouds * NB2 * NB2, 256)),
@@ -1055,9 +1060,23 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
   int32_t* heavy = heavy_count + 16;
   (void)hipMemsetAsync(heavy_count, 0, 64, s);
   int gx = iso_div_up(max_pts, 256); if (gx > 8192) gx = 8192;
+  // xy part point-major (z written as 0), then the z part pixel-major in fixed point
   hipLaunchKernelGGL(k_splat_backward, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, visible,
-                     search_radius, first_idx, num_pts, blk2, NB2, blkz, NB, idx, grad_zbuf, image_size,
-                     points_per_pixel, rect_mode, radii_s, heavy, heavy_count, grad_points);
+                     search_radius, first_idx, num_pts, blk2, NB2, image_size, rect_mode, radii_s, heavy,
+                     heavy_count, grad_points);
+  if (grad_zbuf && total_points > 0) {
+    ZScale* zs = reinterpret_cast<ZScale*>((char*)(heavy_count) + 64 + (4 * total_points + 15) / 16 * 16);
+    long long* zacc = reinterpret_cast<long long*>((char*)zs + 16);
+    const int64_t npix = (int64_t)n_clouds * image_size * image_size;
+    (void)hipMemsetAsync(zs, 0, 16 + 8 * (size_t)total_points, s);
+    int gm = iso_div_up(npix * points_per_pixel, 256 * 16); if (gm > 1024) gm = 1024; if (gm < 1) gm = 1;
+    hipLaunchKernelGGL(k_z_absmax, dim3(gm), dim3(256), 0, s, grad_zbuf, npix * points_per_pixel, zs);
+    hipLaunchKernelGGL(k_z_scale, dim3(1), dim3(1), 0, s, zs);
+    hipLaunchKernelGGL(k_z_scatter, dim3(iso_stream_grid(npix, 256)), dim3(256), 0, s, idx, grad_zbuf,
+                       points_per_pixel, npix, zs, zacc);
+    hipLaunchKernelGGL(k_z_finish, dim3(iso_stream_grid(total_points, 256)), dim3(256), 0, s, zacc, zs,
+                       total_points, grad_points);
+  }
   hipLaunchKernelGGL(k_splat_backward_heavy, dim3(2048), dim3(256), 0, s, points, radii, search_radius,
                      first_idx, num_pts, n_clouds, grad_occ, blk, NB, image_size, rect_mode, radii_s,
                      heavy, heavy_count, grad_points);
