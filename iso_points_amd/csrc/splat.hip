@@ -620,14 +620,23 @@ __global__ __launch_bounds__(256) void k_splat_backward(
         }
       }
     }
+    // one global atomic per workgroup: wave counts -> LDS -> base
+    __shared__ int s_wcnt[4], s_base;
     const unsigned long long bal = __ballot(is_heavy);
-    if (bal) {
-      int b0 = 0;
-      const int leader = __ffsll((long long)bal) - 1;
-      if (lane == leader) b0 = atomicAdd(heavy_count, __popcll(bal));
-      b0 = __shfl(b0, leader);
-      if (is_heavy) heavy[b0 + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)p;
+    const int wv = threadIdx.x >> 6;
+    if (lane == 0) s_wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+      s_base = tot ? atomicAdd(heavy_count, tot) : 0;
     }
+    __syncthreads();
+    if (is_heavy) {
+      int b0 = s_base;
+      for (int q = 0; q < wv; ++q) b0 += s_wcnt[q];
+      heavy[b0 + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)p;
+    }
+    __syncthreads();
   }
 }
 
