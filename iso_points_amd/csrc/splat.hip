@@ -646,7 +646,8 @@ __global__ __launch_bounds__(256) void k_splat_backward(
 __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     const float* __restrict__ pts, const float* __restrict__ radii, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num, int n_clouds,
-    const float* __restrict__ grad_occ, const uint8_t* __restrict__ blk, int NB, int S,
+    const float* __restrict__ grad_occ, const uint8_t* __restrict__ blk, int NB,
+    const uint8_t* __restrict__ blk2, int NB2, int S,
     int rect_mode, float radii_s, const int32_t* __restrict__ heavy,
     const int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
   const int lane = threadIdx.x & 63;
@@ -664,20 +665,25 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     int x0, x1, y0, y1;
     float gx = 0.f, gy = 0.f;
     if (out_range(px, sx, S, x0, x1) && out_range(py, sy, S, y0, y1)) {
-      const int bx0 = x0 / GB, bx1 = x1 / GB;
+      const int bx0 = x0 / GB, bx1 = x1 / GB, by0 = y0 / GB, by1 = y1 / GB;
       const int ly = lane >> 3, lx = lane & 7;
-      for (int by = y0 / GB; by <= y1 / GB; ++by) {
-        const int yo = by * GB + ly;
-        const float dy = pix_to_ndc(S - 1 - yo, S) - py;
-        for (int bx = bx0; bx <= bx1; ++bx) {
-          if (!blk[((int64_t)n * NB + by) * NB + bx]) continue;     // wave-uniform
-          const int xo = bx * GB + lx;
-          if (yo < y0 || yo > y1 || xo < x0 || xo > x1) continue;
-          const float g = grad_occ[((int64_t)n * S + yo) * S + xo];
-          const float dx = pix_to_ndc(S - 1 - xo, S) - px;
-          occ_term(g, dx, dy, rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
+      // 64x64 super blocks first (one flag per 64 8x8 blocks), then the flagged 8x8 blocks inside
+      for (int sby = by0 / 8; sby <= by1 / 8; ++sby)
+        for (int sbx = bx0 / 8; sbx <= bx1 / 8; ++sbx) {
+          if (!blk2[((int64_t)n * NB2 + sby) * NB2 + sbx]) continue;               // wave-uniform
+          for (int by = max(by0, sby * 8); by <= min(by1, sby * 8 + 7); ++by) {
+            const int yo = by * GB + ly;
+            const float dy = pix_to_ndc(S - 1 - yo, S) - py;
+            for (int bx = max(bx0, sbx * 8); bx <= min(bx1, sbx * 8 + 7); ++bx) {
+              if (!blk[((int64_t)n * NB + by) * NB + bx]) continue;                 // wave-uniform
+              const int xo = bx * GB + lx;
+              if (yo < y0 || yo > y1 || xo < x0 || xo > x1) continue;
+              const float g = grad_occ[((int64_t)n * S + yo) * S + xo];
+              const float dx = pix_to_ndc(S - 1 - xo, S) - px;
+              occ_term(g, dx, dy, rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
+            }
+          }
         }
-      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1087,7 +1093,7 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
                        total_points, grad_points);
   }
   hipLaunchKernelGGL(k_splat_backward_heavy, dim3(2048), dim3(256), 0, s, points, radii, search_radius,
-                     first_idx, num_pts, n_clouds, grad_occ, blk, NB, image_size, rect_mode, radii_s,
+                     first_idx, num_pts, n_clouds, grad_occ, blk, NB, blk2, NB2, image_size, rect_mode, radii_s,
                      heavy, heavy_count, grad_points);
   ISO_CHECK_LAUNCH("iso_splat_backward");
   return ISO_OK;
