@@ -65,15 +65,28 @@ __device__ __forceinline__ void iso_sincos_core2(iso_f32x2 x, iso_f32x2& s, iso_
   iso_f32x2 pc = __builtin_elementwise_fma(r2, splat(2.443315711809948e-5f), splat(-1.388731625493765e-3f));
   pc = __builtin_elementwise_fma(pc, r2, splat(4.166664568298827e-2f));
   iso_f32x2 cr = __builtin_elementwise_fma(pc, r2 * r2, __builtin_elementwise_fma(splat(-0.5f), r2, splat(1.0f)));
+#ifdef ISO_SINCOS_INT_QUADRANT     // previous form (integer selects), kept for A/B timing
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int q = (int)n[i];
     const float ss = (q & 1) ? cr[i] : sr[i];
     const float cc = (q & 1) ? sr[i] : cr[i];
-    // quadrant signs as sign-bit flips: sin negative for q&2, cos negative for (q+1)&2
     s[i] = __uint_as_float(__float_as_uint(ss) ^ (((unsigned)q & 2u) << 30));
     c[i] = __uint_as_float(__float_as_uint(cc) ^ (((unsigned)(q + 1) & 2u) << 30));
   }
+  return;
+#endif
+  // quadrant: rotate (sr, cr) by q*90 degrees with exact 0/+-1 factors, all on packed f32 ops
+  //   m = n - 4*rint(n/4) in {-2..2};  a = cos(m pi/2) = 1 - |m|;  b = sin(m pi/2) = m*(1 + a)
+  //   sin x = a*sr + b*cr ;  cos x = a*cr - b*sr      (one term of each sum is an exact zero)
+  const iso_f32x2 q4 = n * splat(0.25f);
+  const iso_f32x2 u = {rintf(q4.x), rintf(q4.y)};
+  const iso_f32x2 m = __builtin_elementwise_fma(splat(-4.0f), u, n);
+  const iso_f32x2 am = {__builtin_fabsf(m.x), __builtin_fabsf(m.y)};
+  const iso_f32x2 a = splat(1.0f) - am;
+  const iso_f32x2 b = __builtin_elementwise_fma(m, a, m);
+  s = __builtin_elementwise_fma(a, sr, b * cr);
+  c = __builtin_elementwise_fma(a, cr, -(b * sr));
 }
 
 // Eight arguments at once: the polynomial path for all, then ONE wave-uniform branch for the
