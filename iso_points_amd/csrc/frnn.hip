@@ -936,7 +936,11 @@ extern "C" int iso_frnn_query(const float* points1, const int64_t* lengths1,
                      tail_list, tail_count, xyzi)
   int tail_blocks = (int)(p1_stride < 2048 ? p1_stride : 2048);
   if (tail_blocks < 1) tail_blocks = 1;
-  if (K <= 8) { ISO_LAUNCH_Q(8); }
+  // the K-best list is register-resident and an insertion walks all KMAX slots: keep KMAX tight
+  // for the K values the path uses (K+1 = 9 neighbour trees, K = 7 splat bandwidth)
+  if (K <= 4) { ISO_LAUNCH_Q(4); }
+  else if (K <= 8) { ISO_LAUNCH_Q(8); }
+  else if (K <= 10) { ISO_LAUNCH_Q(10); }
   else if (K <= 16) { ISO_LAUNCH_Q(16); }
   else { ISO_LAUNCH_Q(32); }
 #undef ISO_LAUNCH_Q
