@@ -39,6 +39,18 @@ def test_forward_scene_bit_exact(dev, S, K):
     assert ref[3].sum() > 50
 
 
+def test_forward_large_image_bit_exact(dev):
+    """S = 1040 -> 65 x 65 tiles per view: more than the LDS-privatised binning holds (4096), so the
+    global-atomic binning path and the tile order for T = 65 are the ones exercised."""
+    SO = _SO()
+    S, K = 1040, 4
+    sc = sphere_scene(600, n_views=1, S=S, seed=9)
+    ref = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"], sc["num"],
+                           0.05, S, K, bbox_or=True)
+    _assert_fwd_equal(_fwd_gpu(dev, sc, S, K), ref)
+    assert ref[3].sum() > 50
+
+
 @pytest.mark.parametrize("K,pad", [(8, 1.0), (4, 0.7), (32, 1.3)])
 def test_forward_random_splats_bit_exact(dev, K, pad):
     """Unstructured input: points behind the camera, off screen, z ties, radii smaller/larger than
