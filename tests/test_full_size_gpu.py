@@ -52,10 +52,12 @@ def test_full_size_siren_projection_reaches_the_level_set(dev):
     assert torch.equal(r2.points[0][mask], r.points[0][mask])
 
 
-def test_full_size_neighbour_search(dev):
+@pytest.mark.parametrize("P_N", [P_FULL, 400000])       # dense-grid caps 256 and 192 (frnn.grid_max_res)
+def test_full_size_neighbour_search(dev, P_N):
     from iso_points_amd import frnn
     from iso_points_amd.levelset_sampling import cloud_diag, full_lengths
     K = 9
+    P_FULL = P_N
     pts = torch.nn.functional.normalize(sphere_cloud(P_FULL, seed=13), dim=-1).to(dev).contiguous()
     num = full_lengths(pts)
     radius = (torch.sqrt(cloud_diag(pts) / num.float()) * 8).contiguous()      # levelset_sampling.py:129-131
