@@ -136,7 +136,10 @@ __global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict
 // expected in A[0..kAD-1] on entry (requested by the previous stage, so no L2 latency is exposed
 // after a barrier); on exit A[0..kAD-1] hold the first fragments of the next GEMM stage (image
 // next_imgw, K-steps next_s..).  Activation fragments (LDS) run one K-step ahead.
-constexpr int kAD = 3;
+#ifndef X3_KAD
+#define X3_KAD 3
+#endif
+constexpr int kAD = X3_KAD;
 
 // imgw is WAVE-UNIFORM (no lane term): the loads take the scalar-base + 32-bit lane-offset form,
 // so no 64-bit per-lane address registers are needed.
