@@ -19,14 +19,18 @@
 //   * the OUTPUT features of a layer are split across the waves (wave w owns tiles
 //     TW*w .. TW*w+TW-1 of 32 features): each weight element is needed by exactly one wave,
 //     which streams it from L2 straight into registers (lane-linear pre-split image, one 16-B
-//     load per lane per (K-step, tile, part)), double-buffered one K-step (1152 cycles) ahead.
+//     load per lane per (K-step, tile, part)), three K-steps ahead through four rotating register
+//     sets that run on across layers and tiles; with 8 waves the operand requests are pinned one
+//     behind each of the first MFMAs of a K-step (gemm_x3).
 //   * the activations of all P points live in LDS, already split (3 x 8 bf16 per lane entry,
 //     [K-step][point tile][part][lane]: every B operand is one conflict-free ds_read_b128).
 //     Each wave reads all of them, and after the GEMM writes the K-steps made of its own output
 //     features.  Two workgroup barriers per layer (readers done / writers done) replace the
 //     per-chunk staging barriers of the f32 kernel.
-//   * sin/cos: the accumulators are parked (f32) in the tail of the wave's own, now dead, LDS
-//     region so that a rolled loop can walk them; results overwrite the region front to back.
+//   * sin/cos (packed f32 ops): with 8 waves a lane holds 48 values and walks its accumulators with
+//     static indices; with 4 waves (96 values) they are first parked (f32) in the tail of the wave's
+//     own, now dead, LDS region so that a rolled loop can walk them, results overwriting the region
+//     front to back.
 //   * reverse sweep: same GEMM on the transposed image; w*cos(w z) comes back from the
 //     per-lane global stash (written in the forward sweep by the same lane).
 #include <type_traits>
