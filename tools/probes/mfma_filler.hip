@@ -33,6 +33,8 @@ __global__ __launch_bounds__(512, 1) void k(long long* out, float* sink, int ite
         if (KIND == 4) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[r]) : "v"(f[r]), "v"(f[(r + 1) & 7]));
         if (KIND == 5) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[r]) : "v"(u[(r + 3) & 7]));
         if (KIND == 6) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[0]) : "v"(c1), "v"(c2));
+        if (KIND == 7) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[(m * NFILL + q) % 6]) : "v"(c1), "v"(c2));
+        if (KIND == 8) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[(m * NFILL + q) % 3]) : "v"(c1), "v"(c2));
       }
     }
   }
@@ -73,5 +75,10 @@ int main() {
   ROW(3, "v_cndmask_b32")
   ROW(4, "v_cvt_pk_bf16_f32")
   ROW(5, "v_xor_b32")
+  ROW(7, "v_fma_f32, 6 chains")
+  ROW(8, "v_fma_f32, 3 chains")
+  run<7, 7, true>("v_fma_f32, 6 chains", 256, d_out, d_sink);
+  run<1, 7, true>("v_fma_f32 independent", 256, d_out, d_sink);
+  run<1, 5, true>("v_fma_f32 independent", 256, d_out, d_sink);
   return 0;
 }
