@@ -24,6 +24,12 @@
 #include "iso_newton.h"
 #include "mlp_common.h"
 
+#ifdef ISO_IDR_PLAIN_GEMM          // the shared, non-pipelined pass (A/B timing)
+#define IDR_GEMM gemm_pass
+#else
+#define IDR_GEMM gemm_pass_pipe
+#endif
+
 namespace {
 
 constexpr int kD0Pad = 64;          // padded encoding width (D0 = 3 + 6F <= 63)
@@ -197,11 +203,11 @@ __global__ __launch_bounds__(256, 1) void k_idr_step(IdrArgs a) {
     // ---- forward
     for (int l = 0; l < nL; ++l) {
       if (l == 0) {
-        gemm_pass<NT, true>(a.packed + idr_off_fw0(H), a.packed + idr_off_b0(), hL, wbuf, acc, lane, g,
+        IDR_GEMM<NT, true>(a.packed + idr_off_fw0(H), a.packed + idr_off_b0(), hL, wbuf, acc, lane, g,
                             kD0Pad / 16);
       } else {
         const float* base = a.packed + idr_off_layer(H, l);
-        gemm_pass<NT, true>(base + H, base, hL, wbuf, acc, lane, g);
+        IDR_GEMM<NT, true>(base + H, base, hL, wbuf, acc, lane, g);
       }
       float* st_l = stash + (int64_t)l * NT * 256;
       const bool top = (l == nL - 1);
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void k_idr_step(IdrArgs a) {
     float gx = 0.f, gy = 0.f, gz = 0.f;
     for (int l = nL - 1; l >= 1; --l) {
       const float* base = a.packed + idr_off_layer(H, l);
-      gemm_pass<NT, false>(base + H + (int64_t)H * H, nullptr, hL, wbuf, acc, lane, g);
+      IDR_GEMM<NT, false>(base + H + (int64_t)H * H, nullptr, hL, wbuf, acc, lane, g);
       const float* st_p = stash + (int64_t)(l - 1) * NT * 256;
       const bool cat = (l == s.skip);
 #pragma unroll

@@ -175,14 +175,15 @@ __device__ __forceinline__ void gemm_pass(const float* __restrict__ img,
     // keep the TC reads ahead of the MFMA block: the scheduler otherwise sinks each read
     // next to its consumer (2 in flight, full LDS latency exposed every 8 MFMAs)
     __builtin_amdgcn_sched_barrier(0);
+    // k-major: consecutive MFMAs hit different accumulators (32 cycles issue, 40 dependent latency)
 #pragma unroll
-    for (int t = 0; t < TC; ++t) {
-      f32x4& d = acc[half * TC + t];
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].x, b4.x, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].y, b4.y, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].z, b4.z, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].w, b4.w, d, 0, 0, 0);
-    }
+    for (int t = 0; t < TC; ++t) acc[half * TC + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].x, b4.x, acc[half * TC + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TC; ++t) acc[half * TC + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].y, b4.y, acc[half * TC + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TC; ++t) acc[half * TC + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].z, b4.z, acc[half * TC + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TC; ++t) acc[half * TC + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t].w, b4.w, acc[half * TC + t], 0, 0, 0);
     // ... and the LDS write + barrier of the next chunk BEHIND it (hoisted, they make the wave
     // drain all of its reads with only a few MFMAs in flight)
     __builtin_amdgcn_sched_barrier(0);
@@ -211,6 +212,115 @@ __device__ __forceinline__ void gemm_pass(const float* __restrict__ img,
 }
 
 
+
+// Register-pipelined form of gemm_pass (used by idr.hip: one workgroup per CU, so nothing else hides
+// an LDS round trip).  Same staging protocol -- half q-chunks through two LDS buffers, one barrier
+// per half -- but the A fragments of half-chunk c+1 are read from LDS into a second register set
+// WHILE half-chunk c is multiplied (they were published by the previous barrier), the global loads
+// of chunk c+3 and the LDS store of chunk c+2 ride behind the same MFMAs (sched_group_barrier), and
+// the four k-steps of a tile are issued k-major so that consecutive MFMAs never hit the same
+// accumulator (v_mfma_f32_16x16x4_f32: 32 cycles issue but 40 cycles dependent latency).
+template <int NT, bool HAS_BIAS>
+__device__ __forceinline__ void gemm_pass_pipe(const float* __restrict__ img,
+                                               const float* __restrict__ bias,
+                                               const float* __restrict__ hL,
+                                               float* __restrict__ wbuf, f32x4 (&acc)[NT],
+                                               int lane, int g, int nq = NT) {
+  constexpr int TC = NT / 2;              // tiles per staged half
+  constexpr int CH = TC * 256;            // floats per half-chunk
+  constexpr int NV = CH / 4;              // float4 per half-chunk
+  constexpr int PER = (NV + 255) / 256;   // float4 per thread per half-chunk
+  constexpr bool FULL = (NV % 256) == 0;
+  static_assert(NT % 2 == 0, "NT must be even");
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if constexpr (HAS_BIAS) {
+      acc[t] = *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * g);
+    } else {
+      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  f32x4 F[2][TC], G[2][PER];
+  auto gload = [&](f32x4 (&r)[PER], int c) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(img + (int64_t)c * CH);
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (FULL || tid + 256 * k < NV) r[k] = src[tid + 256 * k];
+  };
+  auto lwrite = [&](const f32x4 (&r)[PER], int buf) {
+    f32x4* dst = reinterpret_cast<f32x4*>(wbuf + buf * CH);
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (FULL || tid + 256 * k < NV) dst[tid + 256 * k] = r[k];
+  };
+  auto fread = [&](f32x4 (&f)[TC], int buf) {
+    const f32x4* wa = reinterpret_cast<const f32x4*>(wbuf + buf * CH);
+#pragma unroll
+    for (int t = 0; t < TC; ++t) f[t] = wa[t * 64 + lane];
+  };
+  auto mma = [&](const f32x4 (&f)[TC], int half, const f32x4& b4) {
+#pragma unroll
+    for (int t = 0; t < TC; ++t) acc[half * TC + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[t].x, b4.x, acc[half * TC + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TC; ++t) acc[half * TC + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[t].y, b4.y, acc[half * TC + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TC; ++t) acc[half * TC + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[t].z, b4.z, acc[half * TC + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TC; ++t) acc[half * TC + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[t].w, b4.w, acc[half * TC + t], 0, 0, 0);
+  };
+  auto pattern = [&]() {
+    // [2 MFMA, 1 LDS read] x TC, [MFMA, global load] x PER, [MFMA, LDS store] x PER, rest MFMAs
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+  };
+  const int nc = 2 * nq;
+  // prologue: chunk 0 -> buffer 0 -> F[0]; chunk 1 -> buffer 1; chunk 2 in flight in G[0]
+  gload(G[0], 0);
+  lwrite(G[0], 0);
+  if (nc > 1) gload(G[1], 1);
+  __syncthreads();
+  fread(F[0], 0);
+  if (nc > 1) lwrite(G[1], 1);
+  if (nc > 2) gload(G[0], 2);
+  f32x4 b4 = reinterpret_cast<const f32x4*>(hL)[lane];
+  __syncthreads();
+  for (int q = 0; q < nq; ++q) {
+    const int c = 2 * q;
+    // ---- half 0: multiply chunk c (F[0]); fetch chunk c+1 fragments, request chunk c+3, store chunk c+2
+    if (c + 1 < nc) fread(F[1], 1);
+    if (c + 3 < nc) gload(G[1], c + 3);
+    mma(F[0], 0, b4);
+    if (c + 2 < nc) lwrite(G[0], 0);
+    pattern();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // ---- half 1: multiply chunk c+1 (F[1]); fetch chunk c+2 fragments, request chunk c+4, store chunk c+3
+    f32x4 b4n = b4;
+    if (q + 1 < nq) b4n = reinterpret_cast<const f32x4*>(hL)[(q + 1) * 64 + lane];
+    if (c + 2 < nc) fread(F[0], 0);
+    if (c + 4 < nc) gload(G[0], c + 4);
+    mma(F[1], 1, b4);
+    if (c + 3 < nc) lwrite(G[1], 1);
+    pattern();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    b4 = b4n;
+  }
+}
 
 // EXPERIMENT (not the default; build siren.hip with -DISO_SIREN_DIRECT): measured 84 TFLOP/s vs
 // 98 TFLOP/s for the LDS-staged pass on the bench workload -- the 8 waves of a CU re-reading the
