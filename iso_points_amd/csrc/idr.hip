@@ -143,6 +143,9 @@ __device__ __forceinline__ void posenc(int f, float x0, float x1, float x2, floa
 
 __device__ __forceinline__ void softplus_b(float z, float beta, float& y, float& dy) {
   // torch.nn.Softplus(beta, threshold=20) and its derivative (sigmoid)
+#ifdef IDR_DBG_NOACT      // timing experiment: results wrong by construction
+  y = z; dy = beta; return;
+#endif
   const float t = z * beta;
   if (t > 20.0f) { y = z; dy = 1.0f; return; }
   const float e = expf(t);
@@ -286,7 +289,11 @@ __global__ __launch_bounds__(256, 1) void k_idr_step(IdrArgs a) {
     //      folded with the encoding Jacobian (rolled over the D0 inputs)
     {
       const float* W0v = a.packed + idr_off_w0v(H) + (int64_t)g * kW0Row * (H / 4);
+#ifdef IDR_DBG_NOL0REV
+      for (int k = 0; k < 1; ++k) {
+#else
       for (int k = 0; k < s.D0; ++k) {
+#endif
         const f32x4* col = reinterpret_cast<const f32x4*>(W0v + (int64_t)k * (H / 4));
         float pk = 0.f;
         for (int e4i = 0; e4i < NT; ++e4i) {
