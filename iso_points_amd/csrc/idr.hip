@@ -345,12 +345,337 @@ __global__ __launch_bounds__(256, 1) void k_idr_step(IdrArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Feature-split form (the default; -DISO_IDR_STAGED selects the staged kernel above).
+//
+// Same idea as siren_x3.hip, with the f32 matrix cores: a workgroup holds the activations of
+// P = 64 points (NB = 4 point tiles of 16) in LDS in the B-operand layout, act[q][n][lane][4]
+// (= 128 KiB at H = 512), every wave OWNS the output tiles TW*w .. TW*w+TW-1 of a layer and streams
+// exactly those rows of the (unchanged) weight image FW[q][t][lane][4] from L2 / Infinity Cache
+// straight into registers -- no LDS staging, two workgroup barriers per layer instead of one per 64
+// MFMAs.  A q-chunk is TW*NB*4 = 128 MFMAs (4096 cycles) per wave for 8 weight loads and 4 LDS reads
+// per lane, which ride behind the MFMAs.  The positional encoding and its derivative are
+// evaluated once per tile into a small LDS table.
+template <int NT>
+struct IdrFs {
+  static constexpr int NB = 4, P = 16 * NB, NW = 4, TW = NT / NW;
+  static constexpr size_t kActBytes = (size_t)NT * NB * 1024;
+  static constexpr int kEncRows = 48;                    // D0 <= 48 (F <= 7) here; wider encodings use the staged kernel
+  static constexpr size_t kEncBytes = (size_t)2 * kEncRows * P * sizeof(float);     // value + derivative
+  static constexpr size_t kRedBytes = (size_t)NW * P * 16;
+  static constexpr size_t kLds = kActBytes + kEncBytes + kRedBytes;
+  static_assert(NT % NW == 0, "tiles must split evenly over the waves");
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_idr_step_fs(IdrArgs a) {
+  using S = IdrFs<NT>;
+  constexpr int H = NT * 16, NB = S::NB, P = S::P, NW = S::NW, TW = S::TW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* act = reinterpret_cast<f32x4*>(smem_raw);                               // [q][n][lane]
+  float* encv = reinterpret_cast<float*>(smem_raw + S::kActBytes);               // [k][P]
+  float* encd = encv + S::kEncRows * P;
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw + S::kActBytes + S::kEncBytes); // [w][P]
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, g = lane >> 4, j = lane & 15;
+  const IdrShape s = a.s;
+  const int nL = s.n_layers;
+  const float inv_sqrt2_den = 1.41421356237309515f;
+  const float* WLimg = a.packed + idr_off_wl(H, nL);
+  const float b_last = a.packed[idr_off_wl(H, nL) + H];
+  f32x4* stash = reinterpret_cast<f32x4*>(a.stash) +
+                 ((int64_t)blockIdx.x * NW + w) * (int64_t)nL * TW * NB * 64 + lane;   // [l][t][n][lane]
+  const int first_enc_slot = H - s.D0;
+  const unsigned lane_off = (unsigned)lane * 16u;
+
+  // one layer GEMM over q-chunks [0, nq): acc[t][n] (+)= W[own tiles] . act
+  f32x4 acc[TW][NB];
+  auto gemm = [&](const float* img, const float* bias, int nq) {
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      f32x4 init = {0.f, 0.f, 0.f, 0.f};
+      if (bias) init = *reinterpret_cast<const f32x4*>(bias + 16 * (TW * w + t) + 4 * g);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[t][n] = init;
+    }
+    f32x4 A[2][TW], B[2][NB];
+    auto ldA = [&](f32x4 (&Ar)[TW], int q) {
+      const char* pq = reinterpret_cast<const char*>(img) + ((int64_t)q * NT + TW * w) * 1024;
+#pragma unroll
+      for (int t = 0; t < TW; ++t) Ar[t] = *reinterpret_cast<const f32x4*>(pq + lane_off + t * 1024);
+    };
+    auto ldB = [&](f32x4 (&Br)[NB], int q) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) Br[n] = act[(q * NB + n) * 64 + lane];
+    };
+    auto mma = [&](const f32x4 (&Ar)[TW], const f32x4 (&Br)[NB]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[t][i], Br[n][i], acc[t][n], 0, 0, 0);
+    };
+    auto pattern = [&]() {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    };
+    ldA(A[0], 0);
+    ldB(B[0], 0);
+    for (int q = 0; q < nq; q += 2) {
+      if (q + 1 < nq) { ldA(A[1], q + 1); ldB(B[1], q + 1); }
+      mma(A[0], B[0]);
+      pattern();
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 1 < nq) {
+        if (q + 2 < nq) { ldA(A[0], q + 2); ldB(B[0], q + 2); }
+        mma(A[1], B[1]);
+        pattern();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
+  const int64_t n_tiles = (count + P - 1) / P;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // ---- encoding table: thread (k-row, point) pairs, [k][P] value and d/dx_c
+    {
+      const int pt = tid & (P - 1);
+      const int64_t slot = tile * P + pt;
+      float qx = 0.f, qy = 0.f, qz = 0.f;
+      if (slot < count) {
+        const int64_t id = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
+        qx = a.pts[id * 3]; qy = a.pts[id * 3 + 1]; qz = a.pts[id * 3 + 2];
+      }
+      for (int k = tid / P; k < S::kEncRows; k += 256 / P) {
+        float v = 0.f, dv = 0.f; int c;
+        if (k < s.D0) posenc(k, qx, qy, qz, v, c, dv);
+        encv[k * P + pt] = v;
+        encd[k * P + pt] = dv;
+      }
+    }
+    __syncthreads();
+    // B operand of layer 0: chunk q = w (kD0Pad / 16 = 4 chunks, one per wave)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      f32x4 e4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 16 * w + 4 * g + i;
+        e4[i] = f < S::kEncRows ? encv[f * P + 16 * n + j] : 0.f;
+      }
+      act[(w * NB + n) * 64 + lane] = e4;
+    }
+    __syncthreads();
+    float fsum[NB], gx[NB], gy[NB], gz[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) fsum[n] = gx[n] = gy[n] = gz[n] = 0.f;
+    // ---- forward
+    for (int l = 0; l < nL; ++l) {
+      if (l == 0) {
+        gemm(a.packed + idr_off_fw0(H), a.packed + idr_off_b0(), kD0Pad / 16);
+      } else {
+        const float* base = a.packed + idr_off_layer(H, l);
+        gemm(base + H, base, NT);
+      }
+      __syncthreads();                               // every wave has read the activations
+      const bool top = (l == nL - 1);
+      const bool narrow = (s.skip >= 1 && l == s.skip - 1);
+      f32x4* st_l = stash + (int64_t)l * TW * NB * 64;
+      for (int t = 0; t < TW; ++t) {
+        const int tg = TW * w + t;                  // global tile = q-chunk of the next layer
+        f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
+        if (top) w4 = reinterpret_cast<const f32x4*>(WLimg)[g * NT + tg];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          // acc[t][n] with a rolled t: select through a static switch (TW <= 8)
+          f32x4 z4 = acc[0][n];
+#pragma unroll
+          for (int tt = 1; tt < TW; ++tt) if (t == tt) z4 = acc[tt][n];
+          f32x4 h4, s4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float y, dy;
+            softplus_b(z4[i], a.beta, y, dy);
+            h4[i] = y; s4[i] = dy;
+          }
+          if (top) {
+            fsum[n] += (w4.x * h4.x + w4.y * h4.y) + (w4.z * h4.z + w4.w * h4.w);
+            h4 = (f32x4){w4.x * s4.x, w4.y * s4.y, w4.z * s4.z, w4.w * s4.w};
+          } else {
+            if (narrow) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int f = 16 * tg + 4 * g + i;
+                if (f >= first_enc_slot) {
+                  h4[i] = encv[(f - first_enc_slot) * P + 16 * n + j];
+                  s4[i] = 0.f;
+                }
+                h4[i] = h4[i] / inv_sqrt2_den;
+              }
+            }
+            st_l[(t * NB + n) * 64] = s4;
+          }
+          act[(tg * NB + n) * 64 + lane] = h4;
+        }
+      }
+      __syncthreads();                               // the next layer's inputs are complete
+    }
+    // ---- reverse (the seed W_n * s_top is in act)
+    for (int l = nL - 1; l >= 1; --l) {
+      const float* base = a.packed + idr_off_layer(H, l);
+      gemm(base + H + (int64_t)H * H, nullptr, NT);
+      __syncthreads();
+      const f32x4* st_p = stash + (int64_t)(l - 1) * TW * NB * 64;
+      const bool cat = (l == s.skip);
+      for (int t = 0; t < TW; ++t) {
+        const int tg = TW * w + t;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          f32x4 av = acc[0][n];
+#pragma unroll
+          for (int tt = 1; tt < TW; ++tt) if (t == tt) av = acc[tt][n];
+          const f32x4 s4 = st_p[(t * NB + n) * 64];
+          if (cat) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              av[i] = av[i] / inv_sqrt2_den;
+              const int f = 16 * tg + 4 * g + i;
+              if (f >= first_enc_slot) {             // adjoint of an encoding slot -> d/dx
+                const int k = f - first_enc_slot;
+                const float contrib = av[i] * encd[k * P + 16 * n + j];
+                const int c = k < 3 ? k : (k - 3) % 3;
+                gx[n] += c == 0 ? contrib : 0.f;
+                gy[n] += c == 1 ? contrib : 0.f;
+                gz[n] += c == 2 ? contrib : 0.f;
+              }
+            }
+          }
+          const f32x4 gs = {av.x * s4.x, av.y * s4.y, av.z * s4.z, av.w * s4.w};
+          act[(tg * NB + n) * 64 + lane] = gs;
+        }
+      }
+      __syncthreads();
+    }
+    // ---- layer 0 reverse on the VALU over this wave's features: p_k = sum_f W0[f][k] gs0[f]
+    {
+      const float* W0v = a.packed + idr_off_w0v(H) + (int64_t)g * kW0Row * (H / 4);
+      for (int k = 0; k < s.D0; ++k) {
+        const f32x4* col = reinterpret_cast<const f32x4*>(W0v + (int64_t)k * (H / 4));
+        float pk[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) pk[n] = 0.f;
+        for (int t = 0; t < TW; ++t) {
+          const int tg = TW * w + t;
+          const f32x4 wv = col[tg];
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            const f32x4 a4 = act[(tg * NB + n) * 64 + lane];
+            pk[n] += (wv.x * a4.x + wv.y * a4.y) + (wv.z * a4.z + wv.w * a4.w);
+          }
+        }
+        const int c = k < 3 ? k : (k - 3) % 3;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const float contrib = pk[n] * encd[k * P + 16 * n + j];
+          gx[n] += c == 0 ? contrib : 0.f;
+          gy[n] += c == 1 ? contrib : 0.f;
+          gz[n] += c == 2 ? contrib : 0.f;
+        }
+      }
+    }
+    // ---- reduce over the lane groups and the waves
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      float f = fsum[n], x = gx[n], y = gy[n], z = gz[n];
+      f += __shfl_xor(f, 16); f += __shfl_xor(f, 32);
+      x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+      y += __shfl_xor(y, 16); y += __shfl_xor(y, 32);
+      z += __shfl_xor(z, 16); z += __shfl_xor(z, 32);
+      if (g == 0) red[w * P + 16 * n + j] = (f32x4){f, x, y, z};
+    }
+    __syncthreads();
+    bool survive = false;
+    int64_t idx = -1;
+    {
+      const int64_t slot = tile * P + tid;
+      if (tid < P && slot < count) {
+        f32x4 r = red[tid];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) {
+          const f32x4 q = red[ww * P + tid];
+          r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+        }
+        const float f = tanhf(r.x + b_last);
+        const float dtanh = 1.0f - f * f;
+        const float nx = r.y * dtanh, ny = r.z * dtanh, nz = r.w * dtanh;
+        idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
+        if (a.eval_only) {
+          a.sdf_out[idx] = f;
+          a.grad_out[idx * 3] = nx; a.grad_out[idx * 3 + 1] = ny; a.grad_out[idx * 3 + 2] = nz;
+        } else {
+          a.normals[idx * 3] = nx; a.normals[idx * 3 + 1] = ny; a.normals[idx * 3 + 2] = nz;
+          const bool active = fabsf(f) > a.tol;
+          a.mask[idx] = active ? 0 : 1;
+          if (active && a.do_move) {
+            float qx = a.pts[idx * 3], qy = a.pts[idx * 3 + 1], qz = a.pts[idx * 3 + 2];
+            iso_newton_move(f, nx, ny, nz, qx, qy, qz);
+            a.pts[idx * 3] = qx; a.pts[idx * 3 + 1] = qy; a.pts[idx * 3 + 2] = qz;
+            survive = true;
+          }
+        }
+      }
+    }
+    if (!a.eval_only && a.do_move) {
+      const unsigned long long bal = __ballot(survive);
+      if (bal) {
+        int base = 0;
+        const int leader = __ffsll((long long)bal) - 1;
+        if (lane == leader) base = atomicAdd(a.count_out, __popcll(bal));
+        base = __shfl(base, leader);
+        if (survive) a.idx_out[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)idx;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 constexpr int kIdrBlocks = 256;   // one 160 KiB workgroup per CU at H = 512
 
 inline int64_t idr_stash_floats(int H, int n_layers) { return (int64_t)kIdrBlocks * 4 * n_layers * H * 16; }
 
 template <int NT>
+void idr_launch_fs(const IdrArgs& a, int blocks, hipStream_t st) {
+  const size_t lds = IdrFs<NT>::kLds;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idr_step_fs<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_idr_step_fs<NT>, dim3(blocks), dim3(256), lds, st, a);
+}
+
+template <int NT>
 void idr_launch(const IdrArgs& a, int blocks, hipStream_t st) {
+#ifndef ISO_IDR_STAGED
+  // H = 128 leaves only 32 MFMAs per q-chunk and wave: the staged kernel is 7 % faster there
+  if (NT >= 16 && a.s.D0 <= IdrFs<NT>::kEncRows) {
+    idr_launch_fs<NT>(a, blocks, st);
+    return;
+  }
+#endif
   const size_t lds = (size_t)(5 * NT * 256) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
