@@ -82,7 +82,10 @@ int iso_project_siren(const float* pts_in, float* pts_out, float* normals_out,
                       float omega_hidden, int max_iters, float tol,
                       void* workspace, int64_t workspace_bytes, void* stream);
 /* one SDF + gradient evaluation, no Newton move (used by tests and by callers
- * that only need _compute_sdf_and_grad, levelset_sampling.py:142-170)        */
+ * that only need _compute_sdf_and_grad, levelset_sampling.py:142-170).
+ * grad_out may be NULL: value only, the reverse sweep is skipped (the `sdf` callable of
+ * RayTracing, levelset_sampling.py:831-1167, and the candidate evaluations of
+ * combined_modeling.py:376-380).                                              */
 int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_out,
                        int64_t n, const float* packed, int hidden,
                        int n_hidden, float omega_first, float omega_hidden,
@@ -102,9 +105,34 @@ int iso_project_idr(const float* pts_in, float* pts_out, float* normals_out, uin
                     int64_t n, const float* packed, int hidden, int n_layers, int skip_layer,
                     int n_freq, float beta, int max_iters, float tol, void* workspace,
                     int64_t workspace_bytes, void* stream);
+/* grad_out may be NULL (value only, forward sweep only). */
 int iso_idr_sdf_grad(const float* pts, float* sdf_out, float* grad_out, int64_t n,
                      const float* packed, int hidden, int n_layers, int skip_layer, int n_freq,
                      float beta, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Sphere tracing along given rays: SphereTracing.project_points,
+ * DSS/models/levelset_sampling.py:679-808 (callers implicit_modeling.py:305,313).
+ *   p_0 = ray0; per iteration (max_iters advances, max_iters + 1 evaluations):
+ *     f = sdf(p)                                       value only -- the gradient the reference
+ *                                                      computes at :745-757 is never used (:806)
+ *     still active: |f| > 0.1 * tol  and  inside       (:764)
+ *     m = (alpha f) d;  m = m / max(|m|,1e-15) * min(|m|,0.1);  q = p + m        (:771-775)
+ *     inside = |q| < bound (= radius + padding);  p = q only while inside        (:776-779)
+ *   outputs: pts_out (n,3) the last position inside the bounding sphere, sdf_out (n) the value at
+ *   it (`network_eval_on_levelset_points`), mask_out (n) = |sdf| <= tol (:790).
+ *   dirs (n,3) are the (normalised) ray directions.  One launch per iteration over a device-side
+ *   active list, as iso_project_*; workspaces are those of iso_project_siren / iso_project_idr. */
+int iso_trace_sphere(const float* ray0, const float* dirs, float* pts_out, float* sdf_out,
+                     uint8_t* mask_out, int64_t n, float cx, float cy, float cz, float radius,
+                     float alpha, float bound, int max_iters, float tol, void* stream);
+int iso_trace_siren(const float* ray0, const float* dirs, float* pts_out, float* sdf_out,
+                    uint8_t* mask_out, int64_t n, const float* packed, int hidden, int n_hidden,
+                    float omega_first, float omega_hidden, float alpha, float bound, int max_iters,
+                    float tol, void* workspace, int64_t workspace_bytes, void* stream);
+int iso_trace_idr(const float* ray0, const float* dirs, float* pts_out, float* sdf_out,
+                  uint8_t* mask_out, int64_t n, const float* packed, int hidden, int n_layers,
+                  int skip_layer, int n_freq, float beta, float alpha, float bound, int max_iters,
+                  float tol, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * B. Fixed-radius nearest neighbours on a uniform grid

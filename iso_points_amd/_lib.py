@@ -37,6 +37,9 @@ SIGNATURES = {
     "iso_project_idr_workspace_bytes": (_L, [_L, _I, _I]),
     "iso_project_idr": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _I, _F, _P, _L, _P]),
     "iso_idr_sdf_grad": (_I, [_P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P, _L, _P]),
+    "iso_trace_sphere": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "iso_trace_siren": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _F, _F, _F, _F, _I, _F, _P, _L, _P]),
+    "iso_trace_idr": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _F, _F, _I, _F, _P, _L, _P]),
     "iso_points_bbox": (_I, [_P, _P, _I, _L, _P, _P]),
     "iso_frnn_make_grid": (_I, [_P, _P, _P, _I, _L, _I, _P, _P]),
     "iso_frnn_insert_points": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),

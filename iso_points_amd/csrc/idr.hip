@@ -161,6 +161,10 @@ struct IdrArgs {
   IdrShape s;
   float beta, tol;
   int do_move, eval_only;
+  // sphere tracing (iso_trace_idr): unit ray directions (n,3); null = Newton / evaluation
+  const float* dirs = nullptr;
+  float alpha = 1.f, bound = 0.f, tol_valid = 0.f;
+  int fwd_only = 0;          // 1: the gradient is not needed
 };
 
 template <int NT>
@@ -316,21 +320,7 @@ __global__ __launch_bounds__(256, 1) void k_idr_step(IdrArgs a) {
     const float f = fval;
 
     bool survive = false;
-    if (valid && g == 0) {
-      if (a.eval_only) {
-        a.sdf_out[idx] = f;
-        a.grad_out[idx * 3] = gx; a.grad_out[idx * 3 + 1] = gy; a.grad_out[idx * 3 + 2] = gz;
-      } else {
-        a.normals[idx * 3] = gx; a.normals[idx * 3 + 1] = gy; a.normals[idx * 3 + 2] = gz;
-        const bool active = fabsf(f) > a.tol;
-        a.mask[idx] = active ? 0 : 1;
-        if (active && a.do_move) {
-          iso_newton_move(f, gx, gy, gz, px, py, pz);
-          a.pts[idx * 3] = px; a.pts[idx * 3 + 1] = py; a.pts[idx * 3 + 2] = pz;
-          survive = true;
-        }
-      }
-    }
+    if (valid && g == 0) survive = iso_step_finish(a, idx, f, gx, gy, gz);
     if (!a.eval_only && a.do_move) {
       const unsigned long long bal = __ballot(survive);
       if (bal) {
@@ -367,7 +357,8 @@ struct IdrFs {
   static_assert(NT % NW == 0, "tiles must split evenly over the waves");
 };
 
-template <int NT>
+// FWD: value only (no stash, no reverse sweep).
+template <int NT, bool FWD>
 __global__ __launch_bounds__(256, 1) void k_idr_step_fs(IdrArgs a) {
   using S = IdrFs<NT>;
   constexpr int H = NT * 16, NB = S::NB, P = S::P, NW = S::NW, TW = S::TW;
@@ -512,6 +503,7 @@ __global__ __launch_bounds__(256, 1) void k_idr_step_fs(IdrArgs a) {
           }
           if (top) {
             fsum[n] += (w4.x * h4.x + w4.y * h4.y) + (w4.z * h4.z + w4.w * h4.w);
+            if constexpr (FWD) continue;
             h4 = (f32x4){w4.x * s4.x, w4.y * s4.y, w4.z * s4.z, w4.w * s4.w};
           } else {
             if (narrow) {
@@ -525,7 +517,7 @@ __global__ __launch_bounds__(256, 1) void k_idr_step_fs(IdrArgs a) {
                 h4[i] = h4[i] / inv_sqrt2_den;
               }
             }
-            st_l[(t * NB + n) * 64] = s4;
+            if constexpr (!FWD) st_l[(t * NB + n) * 64] = s4;
           }
           act[(tg * NB + n) * 64 + lane] = h4;
         }
@@ -533,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void k_idr_step_fs(IdrArgs a) {
       __syncthreads();                               // the next layer's inputs are complete
     }
     // ---- reverse (the seed W_n * s_top is in act)
-    for (int l = nL - 1; l >= 1; --l) {
+    for (int l = FWD ? 0 : nL - 1; l >= 1; --l) {
       const float* base = a.packed + idr_off_layer(H, l);
       gemm(base + H + (int64_t)H * H, nullptr, NT);
       __syncthreads();
@@ -569,7 +561,7 @@ __global__ __launch_bounds__(256, 1) void k_idr_step_fs(IdrArgs a) {
       __syncthreads();
     }
     // ---- layer 0 reverse on the VALU over this wave's features: p_k = sum_f W0[f][k] gs0[f]
-    {
+    if constexpr (!FWD) {
       const float* W0v = a.packed + idr_off_w0v(H) + (int64_t)g * kW0Row * (H / 4);
       for (int k = 0; k < s.D0; ++k) {
         const f32x4* col = reinterpret_cast<const f32x4*>(W0v + (int64_t)k * (H / 4));
@@ -621,20 +613,7 @@ __global__ __launch_bounds__(256, 1) void k_idr_step_fs(IdrArgs a) {
         const float dtanh = 1.0f - f * f;
         const float nx = r.y * dtanh, ny = r.z * dtanh, nz = r.w * dtanh;
         idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
-        if (a.eval_only) {
-          a.sdf_out[idx] = f;
-          a.grad_out[idx * 3] = nx; a.grad_out[idx * 3 + 1] = ny; a.grad_out[idx * 3 + 2] = nz;
-        } else {
-          a.normals[idx * 3] = nx; a.normals[idx * 3 + 1] = ny; a.normals[idx * 3 + 2] = nz;
-          const bool active = fabsf(f) > a.tol;
-          a.mask[idx] = active ? 0 : 1;
-          if (active && a.do_move) {
-            float qx = a.pts[idx * 3], qy = a.pts[idx * 3 + 1], qz = a.pts[idx * 3 + 2];
-            iso_newton_move(f, nx, ny, nz, qx, qy, qz);
-            a.pts[idx * 3] = qx; a.pts[idx * 3 + 1] = qy; a.pts[idx * 3 + 2] = qz;
-            survive = true;
-          }
-        }
+        survive = iso_step_finish(a, idx, f, nx, ny, nz);
       }
     }
     if (!a.eval_only && a.do_move) {
@@ -655,24 +634,26 @@ constexpr int kIdrBlocks = 256;   // one 160 KiB workgroup per CU at H = 512
 
 inline int64_t idr_stash_floats(int H, int n_layers) { return (int64_t)kIdrBlocks * 4 * n_layers * H * 16; }
 
-template <int NT>
+template <int NT, bool FWD>
 void idr_launch_fs(const IdrArgs& a, int blocks, hipStream_t st) {
   const size_t lds = IdrFs<NT>::kLds;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idr_step_fs<NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idr_step_fs<NT, FWD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_idr_step_fs<NT>, dim3(blocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_idr_step_fs<NT, FWD>), dim3(blocks), dim3(256), lds, st, a);
 }
 
 template <int NT>
 void idr_launch(const IdrArgs& a, int blocks, hipStream_t st) {
 #ifndef ISO_IDR_STAGED
   // H = 128 leaves only 32 MFMAs per q-chunk and wave: the staged kernel is 7 % faster there
-  if (NT >= 16 && a.s.D0 <= IdrFs<NT>::kEncRows) {
-    idr_launch_fs<NT>(a, blocks, st);
+  // (value-only evaluations always take it where it exists: the staged kernel has no forward-only form)
+  if ((NT >= 16 || a.fwd_only) && a.s.D0 <= IdrFs<NT>::kEncRows) {
+    if (a.fwd_only) idr_launch_fs<NT, true>(a, blocks, st);
+    else idr_launch_fs<NT, false>(a, blocks, st);
     return;
   }
 #endif
@@ -733,10 +714,13 @@ extern "C" int64_t iso_project_idr_workspace_bytes(int64_t n, int hidden, int n_
   return idr_stash_floats(hidden, n_layers) * 4 + 2 * n * 4 + 64 * 4 + 64;
 }
 
+struct IdrTrace { const float* dirs; float alpha, bound; };
+
 static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint8_t* mask_out,
                    float* sdf_out, float* grad_out, int64_t n, const float* packed, int hidden,
                    int n_layers, int skip_layer, int n_freq, float beta, int max_iters, float tol,
-                   void* workspace, int64_t workspace_bytes, void* stream, bool eval_only, const char* who) {
+                   void* workspace, int64_t workspace_bytes, void* stream, bool eval_only, const char* who,
+                   const IdrTrace* trace = nullptr) {
   ISO_REQUIRE(idr_shape_ok(hidden, n_layers, skip_layer, n_freq), ISO_ERR_UNSUPPORTED,
               "%s: unsupported shape (hidden 128/256/512, 2..12 layers, <=10 frequencies)", who);
   ISO_REQUIRE(n >= 0 && max_iters >= 0 && max_iters <= 60, ISO_ERR_INVALID, "%s: bad n / max_iters", who);
@@ -760,12 +744,17 @@ static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint
     a.sdf_out = sdf_out; a.grad_out = grad_out;
     a.idx_in = nullptr; a.count_in = nullptr; a.idx_out = nullptr; a.count_out = nullptr;
     a.do_move = 0; a.eval_only = 1;
+    a.fwd_only = grad_out ? 0 : 1;
     ISO_REQUIRE(idr_dispatch(a, blocks, st) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size", who);
   } else {
     if (pts_out != pts_in) (void)hipMemcpyAsync(pts_out, pts_in, (size_t)n * 12, hipMemcpyDeviceToDevice, st);
     hipLaunchKernelGGL(k_idr_zero, dim3(1), dim3(64), 0, st, counts, 64);
+    if (trace) {                         // levelset_sampling.py:764,790: active above 0.1 tol, valid up to tol
+      a.dirs = trace->dirs; a.alpha = trace->alpha; a.bound = trace->bound;
+      a.tol = 0.1f * tol; a.tol_valid = tol; a.fwd_only = 1;
+    }
     for (int it = 0; it <= max_iters; ++it) {
-      a.pts = pts_out; a.normals = normals_out; a.mask = mask_out; a.sdf_out = nullptr; a.grad_out = nullptr;
+      a.pts = pts_out; a.normals = normals_out; a.mask = mask_out; a.sdf_out = trace ? sdf_out : nullptr; a.grad_out = nullptr;
       a.idx_in = (it == 0) ? nullptr : ((it & 1) ? idxA : idxB);
       a.count_in = (it == 0) ? nullptr : counts + it;
       a.idx_out = (it & 1) ? idxB : idxA;
@@ -794,7 +783,19 @@ extern "C" int iso_idr_sdf_grad(const float* pts, float* sdf_out, float* grad_ou
                                 const float* packed, int hidden, int n_layers, int skip_layer,
                                 int n_freq, float beta, void* workspace, int64_t workspace_bytes,
                                 void* stream) {
-  ISO_REQUIRE(n == 0 || (pts && sdf_out && grad_out), ISO_ERR_INVALID, "iso_idr_sdf_grad: null pointer");
+  ISO_REQUIRE(n == 0 || (pts && sdf_out), ISO_ERR_INVALID, "iso_idr_sdf_grad: null pointer");
   return idr_run(pts, nullptr, nullptr, nullptr, sdf_out, grad_out, n, packed, hidden, n_layers, skip_layer,
                  n_freq, beta, 0, 0.f, workspace, workspace_bytes, stream, true, "iso_idr_sdf_grad");
+}
+
+extern "C" int iso_trace_idr(const float* ray0, const float* dirs, float* pts_out, float* sdf_out,
+                             uint8_t* mask_out, int64_t n, const float* packed, int hidden,
+                             int n_layers, int skip_layer, int n_freq, float beta, float alpha,
+                             float bound, int max_iters, float tol, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  ISO_REQUIRE(n == 0 || (ray0 && dirs && pts_out && sdf_out && mask_out), ISO_ERR_INVALID,
+              "iso_trace_idr: null pointer");
+  const IdrTrace tr = {dirs, alpha, bound};
+  return idr_run(ray0, pts_out, nullptr, mask_out, sdf_out, nullptr, n, packed, hidden, n_layers, skip_layer,
+                 n_freq, beta, max_iters, tol, workspace, workspace_bytes, stream, false, "iso_trace_idr", &tr);
 }

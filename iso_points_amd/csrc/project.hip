@@ -67,6 +67,51 @@ __global__ __launch_bounds__(BLOCK) void k_project_sphere(
   }
 }
 
+// Sphere tracing against the analytic sphere (SphereTracing.project_points,
+// DSS/models/levelset_sampling.py:735-779): the whole loop in registers, 12+12 B in, 12+4+1 B out.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_trace_sphere(
+    const float* __restrict__ ray0, const float* __restrict__ dirs, float* __restrict__ pts_out,
+    float* __restrict__ sdf_out, uint8_t* __restrict__ mask_out, int64_t n, SphereSdf sdf,
+    float alpha, float bound, int max_iters, float tol) {
+  __shared__ __attribute__((aligned(16))) float tile[BLOCK * 3];
+  const int t = threadIdx.x;
+  const int64_t n_tiles = (n + BLOCK - 1) / BLOCK;
+  const float tol_active = 0.1f * tol;
+  for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const int64_t base = tl * BLOCK;
+    const int cnt = (int)((n - base) < BLOCK ? (n - base) : BLOCK);
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    iso_tile_load3<BLOCK>(dirs, base, cnt, tile);
+    __syncthreads();
+    if (t < cnt) { dx = tile[3 * t]; dy = tile[3 * t + 1]; dz = tile[3 * t + 2]; }
+    __syncthreads();
+    iso_tile_load3<BLOCK>(ray0, base, cnt, tile);
+    __syncthreads();
+    float px = 0.f, py = 0.f, pz = 0.f, f = 0.f;
+    if (t < cnt) {
+      px = tile[3 * t + 0];
+      py = tile[3 * t + 1];
+      pz = tile[3 * t + 2];
+      for (int it = 0;; ++it) {
+        float gx, gy, gz;
+        sdf.eval(px, py, pz, f, gx, gy, gz);
+        if (!(fabsf(f) > tol_active) || it == max_iters) break;
+        if (!iso_trace_move(f, dx, dy, dz, alpha, bound, px, py, pz)) break;   // left the sphere: frozen
+      }
+    }
+    __syncthreads();
+    if (t < cnt) { tile[3 * t] = px; tile[3 * t + 1] = py; tile[3 * t + 2] = pz; }
+    __syncthreads();
+    iso_tile_store3<BLOCK>(pts_out, base, cnt, tile);
+    if (t < cnt) {
+      sdf_out[base + t] = f;
+      mask_out[base + t] = fabsf(f) <= tol ? 1 : 0;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int iso_project_sphere(const float* pts_in, float* pts_out,
@@ -85,5 +130,23 @@ extern "C" int iso_project_sphere(const float* pts_in, float* pts_out,
                      dim3(BLOCK), 0, (hipStream_t)stream, pts_in, pts_out,
                      normals_out, mask_out, n, sdf, max_iters, tol);
   ISO_CHECK_LAUNCH("iso_project_sphere");
+  return ISO_OK;
+}
+
+extern "C" int iso_trace_sphere(const float* ray0, const float* dirs, float* pts_out, float* sdf_out,
+                                uint8_t* mask_out, int64_t n, float cx, float cy, float cz,
+                                float radius, float alpha, float bound, int max_iters, float tol,
+                                void* stream) {
+  ISO_REQUIRE(n >= 0, ISO_ERR_INVALID, "iso_trace_sphere: n < 0");
+  ISO_REQUIRE(max_iters >= 0, ISO_ERR_INVALID, "iso_trace_sphere: max_iters < 0");
+  if (n == 0) return ISO_OK;
+  ISO_REQUIRE(ray0 && dirs && pts_out && sdf_out && mask_out, ISO_ERR_INVALID,
+              "iso_trace_sphere: null pointer");
+  constexpr int BLOCK = 256;
+  SphereSdf sdf{cx, cy, cz, radius};
+  hipLaunchKernelGGL(k_trace_sphere<BLOCK>, dim3(iso_stream_grid(n, BLOCK)), dim3(BLOCK), 0,
+                     (hipStream_t)stream, ray0, dirs, pts_out, sdf_out, mask_out, n, sdf, alpha, bound,
+                     max_iters, tol);
+  ISO_CHECK_LAUNCH("iso_trace_sphere");
   return ISO_OK;
 }

@@ -219,21 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_siren_step(SirenArgs a) {
 
     // ---- epilogue ----------------------------------------------------------
     bool survive = false;
-    if (valid && g == 0) {
-      if (a.eval_only) {
-        a.sdf_out[idx] = f;
-        a.grad_out[idx * 3] = gx; a.grad_out[idx * 3 + 1] = gy; a.grad_out[idx * 3 + 2] = gz;
-      } else {
-        a.normals[idx * 3] = gx; a.normals[idx * 3 + 1] = gy; a.normals[idx * 3 + 2] = gz;
-        const bool active = fabsf(f) > a.tol;
-        a.mask[idx] = active ? 0 : 1;
-        if (active && a.do_move) {
-          iso_newton_move(f, gx, gy, gz, px, py, pz);
-          a.pts[idx * 3] = px; a.pts[idx * 3 + 1] = py; a.pts[idx * 3 + 2] = pz;
-          survive = true;
-        }
-      }
-    }
+    if (valid && g == 0) survive = iso_step_finish(a, idx, f, gx, gy, gz);
     if (!a.eval_only && a.do_move) {
       const unsigned long long bal = __ballot(survive);
       if (bal) {
@@ -350,6 +336,27 @@ extern "C" int64_t iso_project_siren_workspace_bytes(int64_t n, int hidden, int 
   return stash_floats_any(hidden, n_hidden) * 4 + 2 * n * 4 + 64 * 4 + 64;
 }
 
+// The iteration driver shared by the Newton projection and sphere tracing: launch `it` evaluates
+// the list launch it-1 left (device-side counts, no host read), the last one does not move.
+static int run_iterations(SirenArgs a, int hidden, int64_t n, int max_iters, void* workspace,
+                          hipStream_t s, const char* who) {
+  float* stash = (float*)workspace;
+  int32_t* idxA = (int32_t*)(stash + stash_floats_any(hidden, a.L));
+  int32_t* idxB = idxA + n;
+  int32_t* counts = idxB + n;  // counts[it] = size of the list consumed by launch `it`
+  hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, s, counts, 64);
+  a.stash = stash; a.n = n; a.eval_only = 0; a.sdf_out = a.dirs ? a.sdf_out : nullptr; a.grad_out = nullptr;
+  for (int it = 0; it <= max_iters; ++it) {
+    a.idx_in = (it == 0) ? nullptr : ((it & 1) ? idxA : idxB);
+    a.count_in = (it == 0) ? nullptr : counts + it;
+    a.idx_out = (it & 1) ? idxB : idxA;
+    a.count_out = counts + it + 1;
+    a.do_move = (it < max_iters) ? 1 : 0;
+    ISO_REQUIRE(run_step(a, hidden, n, s) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size %d", who, hidden);
+  }
+  return ISO_OK;
+}
+
 extern "C" int iso_project_siren(const float* pts_in, float* pts_out, float* normals_out,
                                  uint8_t* mask_out, int64_t n, const float* packed,
                                  int hidden, int n_hidden, float omega_first,
@@ -369,27 +376,46 @@ extern "C" int iso_project_siren(const float* pts_in, float* pts_out, float* nor
   hipStream_t s = (hipStream_t)stream;
   if (pts_out != pts_in)
     (void)hipMemcpyAsync(pts_out, pts_in, (size_t)n * 12, hipMemcpyDeviceToDevice, s);
-  float* stash = (float*)workspace;
-  int32_t* idxA = (int32_t*)(stash + stash_floats_any(hidden, n_hidden));
-  int32_t* idxB = idxA + n;
-  int32_t* counts = idxB + n;  // counts[it] = size of the list consumed by launch `it`
-  hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, s, counts, 64);
-  for (int it = 0; it <= max_iters; ++it) {
-    SirenArgs a;
-    a.pts = pts_out; a.normals = normals_out; a.mask = mask_out;
-    a.sdf_out = nullptr; a.grad_out = nullptr;
-    a.idx_in = (it == 0) ? nullptr : ((it & 1) ? idxA : idxB);
-    a.count_in = (it == 0) ? nullptr : counts + it;
-    a.idx_out = (it & 1) ? idxB : idxA;
-    a.count_out = counts + it + 1;
-    a.packed = packed; a.stash = stash; a.n = n; a.L = n_hidden;
-    a.w0 = omega_first; a.wh = omega_hidden; a.tol = tol;
-    a.do_move = (it < max_iters) ? 1 : 0;
-    a.eval_only = 0;
-    ISO_REQUIRE(run_step(a, hidden, n, s) == 0, ISO_ERR_UNSUPPORTED,
-                "iso_project_siren: unsupported hidden size %d", hidden);
-  }
+  SirenArgs a;
+  a.pts = pts_out; a.normals = normals_out; a.mask = mask_out;
+  a.packed = packed; a.L = n_hidden;
+  a.w0 = omega_first; a.wh = omega_hidden; a.tol = tol;
+  int rc = run_iterations(a, hidden, n, max_iters, workspace, s, "iso_project_siren");
+  if (rc != ISO_OK) return rc;
   ISO_CHECK_LAUNCH("iso_project_siren");
+  return ISO_OK;
+}
+
+extern "C" int iso_trace_siren(const float* ray0, const float* dirs, float* pts_out, float* sdf_out,
+                               uint8_t* mask_out, int64_t n, const float* packed, int hidden,
+                               int n_hidden, float omega_first, float omega_hidden, float alpha,
+                               float bound, int max_iters, float tol, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+  ISO_REQUIRE(siren_shape_ok(hidden, n_hidden), ISO_ERR_UNSUPPORTED,
+              "iso_trace_siren: hidden must be 64/128/256 and 0<=n_hidden<=8 (got %d, %d)",
+              hidden, n_hidden);
+  ISO_REQUIRE(n >= 0 && max_iters >= 0 && max_iters <= 60, ISO_ERR_INVALID,
+              "iso_trace_siren: bad n / max_iters (max 60)");
+  if (n == 0) return ISO_OK;
+  ISO_REQUIRE(n < (1ll << 31), ISO_ERR_UNSUPPORTED, "iso_trace_siren: n must fit int32");
+  ISO_REQUIRE(ray0 && dirs && pts_out && sdf_out && mask_out && packed && workspace,
+              ISO_ERR_INVALID, "iso_trace_siren: null pointer");
+  ISO_REQUIRE(workspace_bytes >= iso_project_siren_workspace_bytes(n, hidden, n_hidden),
+              ISO_ERR_WORKSPACE, "iso_trace_siren: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (pts_out != ray0)
+    (void)hipMemcpyAsync(pts_out, ray0, (size_t)n * 12, hipMemcpyDeviceToDevice, s);
+  SirenArgs a;
+  a.pts = pts_out; a.normals = nullptr; a.mask = mask_out; a.sdf_out = sdf_out;
+  a.packed = packed; a.L = n_hidden;
+  a.w0 = omega_first; a.wh = omega_hidden;
+  a.dirs = dirs; a.alpha = alpha; a.bound = bound;
+  a.tol = 0.1f * tol;                  // levelset_sampling.py:764: still active above 1e-1 * tolerance
+  a.tol_valid = tol;                   // :790: valid projection = |sdf| <= tolerance
+  a.fwd_only = 1;
+  int rc = run_iterations(a, hidden, n, max_iters, workspace, s, "iso_trace_siren");
+  if (rc != ISO_OK) return rc;
+  ISO_CHECK_LAUNCH("iso_trace_siren");
   return ISO_OK;
 }
 
@@ -402,7 +428,7 @@ extern "C" int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_
               hidden, n_hidden);
   ISO_REQUIRE(n >= 0, ISO_ERR_INVALID, "iso_siren_sdf_grad: n < 0");
   if (n == 0) return ISO_OK;
-  ISO_REQUIRE(pts && sdf_out && grad_out && packed && workspace, ISO_ERR_INVALID,
+  ISO_REQUIRE(pts && sdf_out && packed && workspace, ISO_ERR_INVALID,
               "iso_siren_sdf_grad: null pointer");
   ISO_REQUIRE(workspace_bytes >= stash_floats_any(hidden, n_hidden) * 4, ISO_ERR_WORKSPACE,
               "iso_siren_sdf_grad: workspace too small");
@@ -412,6 +438,7 @@ extern "C" int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_
   a.idx_in = nullptr; a.count_in = nullptr; a.idx_out = nullptr; a.count_out = nullptr;
   a.packed = packed; a.stash = (float*)workspace; a.n = n; a.L = n_hidden;
   a.w0 = omega_first; a.wh = omega_hidden; a.tol = 0.f; a.do_move = 0; a.eval_only = 1;
+  a.fwd_only = grad_out ? 0 : 1;       // value only: forward sweep only where the kernel has one
   ISO_REQUIRE(run_step(a, hidden, n, (hipStream_t)stream) == 0, ISO_ERR_UNSUPPORTED,
               "iso_siren_sdf_grad: unsupported hidden size %d", hidden);
   ISO_CHECK_LAUNCH("iso_siren_sdf_grad");

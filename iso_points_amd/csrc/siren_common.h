@@ -20,6 +20,10 @@ struct SirenArgs {
   float w0, wh, tol;
   int do_move;               // 0: last evaluation (no move)
   int eval_only;
+  // sphere tracing (iso_trace_siren): unit ray directions (n,3); null = Newton / evaluation
+  const float* dirs = nullptr;
+  float alpha = 1.f, bound = 0.f, tol_valid = 0.f;
+  int fwd_only = 0;          // 1: the gradient is not needed (evaluation of the value / tracing)
 };
 
 // ---- packed weight buffer, f32 section (siren.hip) ---------------------------------------

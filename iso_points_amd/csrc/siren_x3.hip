@@ -327,7 +327,8 @@ struct X3Shape {
 #define X3_STAMP() do {} while (0)
 #endif
 
-template <int H, int NW, int NB, int MINB>
+// FWD: value only (iso_siren_sdf, sphere tracing) -- no stash, no reverse sweep, no w cos(w z)
+template <int H, int NW, int NB, int MINB, bool FWD>
 __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   using S = X3Shape<H, NW, NB>;
   constexpr int NS = S::NS, NTO = S::NTO, TW = S::TW, SL = S::SL, NG = S::NG, P = S::P;
@@ -424,8 +425,10 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         split8(hv, p0, p1, p2);
         own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
 #ifndef X3_DBG_NOSTASH
-        stash[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
-        stash[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+        if constexpr (!FWD) {
+          stash[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+          stash[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+        }
 #endif
       }
     }
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     for (int l = 0; l < L; ++l) {
       const float* lay = a.packed + x3_off_layer(H, L, l);
       const u32x4* img = fw_img(l);
-      const u32x4* nxt = l + 1 < L ? fw_img(l + 1) : bw_img(L - 1);
+      const u32x4* nxt = l + 1 < L ? fw_img(l + 1) : (FWD ? fw_img(0) : bw_img(L - 1));
       if constexpr (SKEW) {
         gemm_x3<TW, NB, NTO, KH, kBias, IL>(img, lay + h * 8, act + lane, acc, w, 0, A, img, KH, lane);
         X3_STAMP();
@@ -467,12 +470,15 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
           const float f0 = (wl0.x * hv[0] + wl0.y * hv[1]) + (wl0.z * hv[2] + wl0.w * hv[3]);
           const float f1 = (wl1.x * hv[4] + wl1.y * hv[5]) + (wl1.z * hv[6] + wl1.w * hv[7]);
           fp += f0 + f1;
+          if constexpr (FWD) return;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { hv[e] = wl0[e] * sv[e]; hv[4 + e] = wl1[e] * sv[4 + e]; }
         } else {
 #ifndef X3_DBG_NOSTASH
-          st_l[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
-          st_l[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+          if constexpr (!FWD) {
+            st_l[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+            st_l[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+          }
 #endif
         }
         u32x4 p0, p1, p2;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     float gx[NB], gy[NB], gz[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) gx[n] = gy[n] = gz[n] = 0.f;
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = FWD ? -1 : L - 1; l >= 0; --l) {
       const u32x4* img = bw_img(l);
       const f32x4* st_l = stash + (int64_t)l * NG * 128;
       f32x4 sv[NG][2];
@@ -631,20 +637,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         }
         const float f = r.x + bL;
         idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
-        if (a.eval_only) {
-          a.sdf_out[idx] = f;
-          a.grad_out[idx * 3] = r.y; a.grad_out[idx * 3 + 1] = r.z; a.grad_out[idx * 3 + 2] = r.w;
-        } else {
-          a.normals[idx * 3] = r.y; a.normals[idx * 3 + 1] = r.z; a.normals[idx * 3 + 2] = r.w;
-          const bool active = fabsf(f) > a.tol;
-          a.mask[idx] = active ? 0 : 1;
-          if (active && a.do_move) {
-            float qx = a.pts[idx * 3], qy = a.pts[idx * 3 + 1], qz = a.pts[idx * 3 + 2];
-            iso_newton_move(f, r.y, r.z, r.w, qx, qy, qz);
-            a.pts[idx * 3] = qx; a.pts[idx * 3 + 1] = qy; a.pts[idx * 3 + 2] = qz;
-            survive = true;
-          }
-        }
+        survive = iso_step_finish(a, idx, f, r.y, r.z, r.w);
       }
     }
     if (!a.eval_only && a.do_move) {
@@ -684,12 +677,12 @@ int launch_x3p(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
   return 0;
 }
 
-template <int H, int NW, int NB, int MINB>
+template <int H, int NW, int NB, int MINB, bool FWD>
 int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
   using S = X3Shape<H, NW, NB>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_siren_step_x3<H, NW, NB, MINB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_siren_step_x3<H, NW, NB, MINB, FWD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
     attr_done = true;
   }
@@ -700,7 +693,7 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
   const int64_t cap = 256 * MINB;
 #endif
   const int blocks = (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
-  hipLaunchKernelGGL((k_siren_step_x3<H, NW, NB, MINB>), dim3(blocks), dim3(64 * NW), S::kLds, s, a);
+  hipLaunchKernelGGL((k_siren_step_x3<H, NW, NB, MINB, FWD>), dim3(blocks), dim3(64 * NW), S::kLds, s, a);
   return 0;
 }
 
@@ -732,8 +725,12 @@ int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
 #if X3_PIPE
   if (H == 256) return launch_x3p<256, 4, 3, 1>(a, n_upper, s);
 #else
-  if (H == 256) return launch_x3<256, X3_NW, 3, 1>(a, n_upper, s);
+  if (a.fwd_only) {
+    if (H == 256) return launch_x3<256, X3_NW, 3, 1, true>(a, n_upper, s);
+    if (H == 128) return launch_x3<128, 4, 3, X3_MINB128, true>(a, n_upper, s);
+  }
+  if (H == 256) return launch_x3<256, X3_NW, 3, 1, false>(a, n_upper, s);
 #endif
-  if (H == 128) return launch_x3<128, 4, 3, X3_MINB128>(a, n_upper, s);
+  if (H == 128) return launch_x3<128, 4, 3, X3_MINB128, false>(a, n_upper, s);
   return -1;
 }

@@ -6,6 +6,8 @@ types and error behaviour; the arithmetic runs in libisopoints_hip.so.
   UniformProjection.resample          levelset_sampling.py:239-288
   UniformProjection._create_tree      levelset_sampling.py:110-140
   UniformProjection.project_points    levelset_sampling.py:353-439
+  SphereTracing.project_points        levelset_sampling.py:663-808
+  find_zero_crossing_between_point_pairs / run_Secant_method   levelset_sampling.py:1210-1367
 
 Model dispatch: an analytic sphere and SIREN networks run in the fused
 HIP kernels; any other nn.Module takes the generic route -- the reference's own
@@ -19,7 +21,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from . import frnn
-from .sdf_models import PackedIdr, PackedSiren, idr_spec, siren_spec
+from .sdf_models import FusedSdf, PackedIdr, PackedSiren, idr_spec, siren_spec
 
 ProjectionResult = namedtuple("ProjectionResult", ("points", "normals", "mask"))
 
@@ -401,6 +403,169 @@ class UniformProjection(LevelSetProjection):
                     model, points_projected, num_points, proj_max_iters=10, **forward_kwargs)
             return {"levelset_points": points_projected, "levelset_normals": normals_projected,
                     "mask": valid_projection}
+
+
+class SphereTracing(LevelSetProjection):
+    """Sphere tracing along given rays (levelset_sampling.py:663-808): same constructor, same
+    `project_points(ray0, ray_direction, model, latent=None)` and the same result dictionary.
+    The whole loop -- value-only network evaluation, clamped advance, bounding-sphere test,
+    compaction of the still-active rays -- runs in iso_trace_{sphere,siren,idr}; the reference's
+    `max_points_per_pass` chunking is unnecessary (nothing is materialised per layer)."""
+
+    def __init__(self, proj_max_iters=10, proj_tolerance=5e-5, max_points_per_pass=120000,
+                 alpha=1.0, radius=1.0, padding=0.1, **kwargs):
+        super().__init__(proj_max_iters=proj_max_iters, proj_tolerance=proj_tolerance,
+                         max_points_per_pass=max_points_per_pass)
+        self.alpha = alpha
+        self.radius = radius
+        self.padding = padding
+
+    def _trace_packed(self, model, ray0, dirs):
+        n, dev = ray0.shape[0], ray0.device
+        out = torch.empty_like(ray0)
+        sdf = torch.zeros((n,), dtype=torch.float32, device=dev)
+        mask = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        p = _lib.ptr
+        bound = float(self.padding + self.radius)
+        T, tol, alpha = int(self.proj_max_iters), float(self.proj_tolerance), float(self.alpha)
+        if getattr(model, "iso_analytic", None) == "sphere":
+            c = [float(x) for x in model.center.tolist()]
+            _lib.call("iso_trace_sphere", p(ray0), p(dirs), p(out), p(sdf), p(mask), n, c[0], c[1], c[2],
+                      float(model.radius), alpha, bound, T, tol, _lib.stream())
+        elif siren_spec(model) is not None:
+            ps = PackedSiren(model, dev)
+            ws = ps.workspace(n)
+            _lib.call("iso_trace_siren", p(ray0), p(dirs), p(out), p(sdf), p(mask), n, p(ps.packed), ps.hidden,
+                      ps.n_hidden, ps.omega_first, ps.omega_hidden, alpha, bound, T, tol, p(ws), ws.numel(),
+                      _lib.stream())
+            self._packed_cache = ps
+        elif idr_spec(model) is not None:
+            pk = PackedIdr(model, dev)
+            ws = pk.workspace(n)
+            _lib.call("iso_trace_idr", p(ray0), p(dirs), p(out), p(sdf), p(mask), n, p(pk.packed), pk.hidden,
+                      pk.n_layers, pk.skip, pk.n_freq, 100.0, alpha, bound, T, tol, p(ws), ws.numel(),
+                      _lib.stream())
+            self._packed_cache = pk
+        else:
+            return self._trace_packed_generic(model, ray0, dirs)
+        return out, sdf, mask.bool()
+
+    def _trace_packed_generic(self, model, ray0, dirs):
+        """The reference's loop (levelset_sampling.py:735-779) for models without a fused kernel."""
+        cur = ray0.clone()
+        n = cur.shape[0]
+        active = torch.ones((n,), dtype=torch.bool, device=cur.device)
+        inside = torch.ones((n,), dtype=torch.bool, device=cur.device)
+        val = torch.zeros((n,), dtype=torch.float32, device=cur.device)
+        trials = 0
+        with torch.no_grad():
+            model.eval()
+            while True:
+                val[active] = model.forward(cur[active]).sdf.reshape(-1)
+                active = (val.abs() > 1e-1 * self.proj_tolerance) & inside
+                if not (bool(active.any()) and trials < self.proj_max_iters):
+                    break
+                move = self.alpha * val[active].unsqueeze(-1) * dirs[active]
+                move = F.normalize(move, dim=-1, eps=1e-15) * move.norm(dim=-1, keepdim=True).clamp_max(0.1)
+                pts_active = cur[active] + move
+                still = pts_active.norm(dim=-1) < (self.padding + self.radius)
+                ins = inside.clone()
+                ins[active] = still
+                inside = ins
+                cur[active & inside] = pts_active[still]
+                trials += 1
+        return cur, val, val.abs() <= self.proj_tolerance
+
+    def project_points(self, ray0, ray_direction, model, latent=None, **forward_kwargs):
+        """ray0, ray_direction (N,*,3) -> dict(levelset_points, network_eval_on_levelset_points,
+        levelset_points_Dx, mask); `levelset_points_Dx` is the point tensor itself, as in the
+        reference (:806)."""
+        if latent is not None and latent.nelement() > 0:
+            raise NotImplementedError("iso_points_amd: latent-conditioned networks are outside the hot path (c_dim=0)")
+        if not ray0.is_cuda:
+            raise RuntimeError("iso_points_amd: rays must be on the GPU; there is no CPU path")
+        shp = ray0.shape
+        r0 = ray0.detach().reshape(-1, 3).float().contiguous()
+        rd = ray_direction.detach().reshape(-1, 3).float().contiguous()
+        with torch.no_grad():
+            if forward_kwargs:
+                pts, val, mask = self._trace_packed_generic(
+                    _KwModel(model, forward_kwargs), r0, rd)
+            else:
+                pts, val, mask = self._trace_packed(model, r0, rd)
+        pts = pts.view(shp)
+        return {"levelset_points": pts,
+                "network_eval_on_levelset_points": val.view(shp[:-1]),
+                "levelset_points_Dx": pts,
+                "mask": mask.view(shp[:-1])}
+
+
+class _KwModel(object):
+    def __init__(self, model, kw):
+        self.model, self.kw = model, kw
+
+    def eval(self):
+        self.model.eval()
+
+    def forward(self, x):
+        return self.model.forward(x, **self.kw)
+
+
+def run_Secant_method(f_start, f_end, d_start, d_end, n_secant_steps, p0, ray_direction, decoder, c=None,
+                      **forward_kwargs):
+    """levelset_sampling.py:1331-1367.  `decoder` is an nn.Module (a FusedSdf is built for it) or
+    a FusedSdf; every step is one value-only evaluation of the fused kernel."""
+    sdf = decoder if isinstance(decoder, FusedSdf) else FusedSdf(decoder, p0.device)
+    d_pred = -f_start * (d_end - d_start) / (f_end - f_start) + d_start
+    for _ in range(n_secant_steps):
+        p_mid = p0 + d_pred.unsqueeze(-1) * ray_direction
+        f_mid = sdf(p_mid, **forward_kwargs)
+        ind_start = torch.eq(torch.sign(f_mid), torch.sign(f_start))
+        d_start = torch.where(ind_start, d_pred, d_start)
+        f_start = torch.where(ind_start, f_mid, f_start)
+        d_end = torch.where(ind_start, d_end, d_pred)
+        f_end = torch.where(ind_start, f_end, f_mid)
+        d_pred = -f_start * (d_end - d_start) / (f_end - f_start) + d_start
+    return p0 + d_pred.unsqueeze(-1) * ray_direction
+
+
+def find_zero_crossing_between_point_pairs(p0, p1, network, n_secant_steps=8, n_steps=100, is_occupancy=True,
+                                           max_points=80000, c=None, allow_in_to_out=False, **forward_kwargs):
+    """First sign change of the network value between point pairs + secant refinement
+    (levelset_sampling.py:1210-1328).  p0, p1 (N,*,3) -> pt_pred (N,*,3), mask (N,*).
+    The n_steps proposals per pair are evaluated by the value-only fused kernel in one call
+    (`max_points` chunking is unnecessary); no host synchronisation before the secant loop:
+    it runs over all pairs and the mask is applied at the end (the per-pair arithmetic is the same)."""
+    if c is not None and c.nelement() > 0:
+        raise NotImplementedError("iso_points_amd: latent-conditioned networks are outside the hot path (c_dim=0)")
+    if not p0.is_cuda:
+        raise RuntimeError("iso_points_amd: points must be on the GPU; there is no CPU path")
+    sdf = network if isinstance(network, FusedSdf) else FusedSdf(network, p0.device)
+    device, shp = p0.device, p0.shape
+    p0 = p0.detach().reshape(-1, 3).float()
+    p1 = p1.detach().reshape(-1, 3).float()
+    n_pts = p0.shape[0]
+    ray_direction = F.normalize(p1 - p0, p=2, dim=-1, eps=1e-10)
+    d_proposal = torch.linspace(0, 1, steps=n_steps, device=device).view(1, n_steps) * \
+        torch.norm(p1 - p0, p=2, dim=-1).unsqueeze(-1)
+    p_proposal = p0.unsqueeze(-2) + ray_direction.unsqueeze(-2) * d_proposal.unsqueeze(-1)
+    val = sdf(p_proposal.reshape(-1, 3), **forward_kwargs).view(n_pts, n_steps)
+    compare = (lambda d: d < 0.0) if is_occupancy else (lambda d: d > 0.0)
+    sign_matrix = torch.cat([torch.sign(val[..., :-1] * val[..., 1:]),
+                             torch.ones(n_pts, 1, device=device)], dim=-1)
+    cost_matrix = sign_matrix * torch.arange(n_steps, 0, -1, device=device).float()
+    values, indices = torch.min(cost_matrix, -1)
+    mask_sign_change = values < 0
+    rows = torch.arange(n_pts, device=device)
+    mask_out_to_in = compare(val[rows, indices])
+    mask = mask_sign_change if allow_in_to_out else (mask_sign_change & mask_out_to_in)
+    d_start, f_start = d_proposal[rows, indices], val[rows, indices]
+    nxt = torch.clamp(indices + 1, max=n_steps - 1)
+    d_end, f_end = d_proposal[rows, nxt], val[rows, nxt]
+    p_pred = run_Secant_method(f_start, f_end, d_start, d_end, n_secant_steps, p0, ray_direction, sdf, None,
+                               **forward_kwargs)
+    pt_pred = torch.where(mask.unsqueeze(-1), p_pred, torch.ones_like(p_pred))
+    return pt_pred.view(shp), mask.view(shp[:-1])
 
 
 def mask_padded_to_list(values, mask):

@@ -144,20 +144,21 @@ class PackedSiren(object):
         return self._ws
 
 
-def siren_sdf_and_grad(model, points):
+def siren_sdf_and_grad(model, points, need_grad=True, packed=None):
     """One fused SDF + gradient evaluation (UniformProjection._compute_sdf_and_grad,
-    levelset_sampling.py:142-170) for a SIREN.  points (...,3) -> sdf (...), grad (...,3)."""
+    levelset_sampling.py:142-170) for a SIREN.  points (...,3) -> sdf (...), grad (...,3).
+    need_grad=False: value only (forward sweep only), grad is None."""
     shp = points.shape
     pts = points.detach().reshape(-1, 3).float().contiguous()
-    ps = PackedSiren(model, pts.device)
+    ps = packed if packed is not None else PackedSiren(model, pts.device)
     n = pts.shape[0]
     sdf = torch.empty((n,), dtype=torch.float32, device=pts.device)
-    grad = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    grad = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if need_grad else None
     ws = ps.workspace(n)
     _lib.call("iso_siren_sdf_grad", _lib.ptr(pts), _lib.ptr(sdf), _lib.ptr(grad), n,
               _lib.ptr(ps.packed), ps.hidden, ps.n_hidden, ps.omega_first, ps.omega_hidden,
               _lib.ptr(ws), ws.numel(), _lib.stream())
-    return sdf.view(shp[:-1]), grad.view(shp)
+    return sdf.view(shp[:-1]), (grad.view(shp) if need_grad else None)
 
 
 # ----------------------------------------------------------------------------- IDR-style SDF
@@ -243,14 +244,42 @@ class PackedIdr(object):
         return self._ws
 
 
-def idr_sdf_and_grad(model, points):
+def idr_sdf_and_grad(model, points, need_grad=True, packed=None):
     shp = points.shape
     pts = points.detach().reshape(-1, 3).float().contiguous()
-    pk = PackedIdr(model, pts.device)
+    pk = packed if packed is not None else PackedIdr(model, pts.device)
     n = pts.shape[0]
     sdf = torch.empty((n,), dtype=torch.float32, device=pts.device)
-    grad = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+    grad = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if need_grad else None
     ws = pk.workspace(n)
     _lib.call("iso_idr_sdf_grad", _lib.ptr(pts), _lib.ptr(sdf), _lib.ptr(grad), n, _lib.ptr(pk.packed), pk.hidden,
               pk.n_layers, pk.skip, pk.n_freq, 100.0, _lib.ptr(ws), ws.numel(), _lib.stream())
-    return sdf.view(shp[:-1]), grad.view(shp)
+    return sdf.view(shp[:-1]), (grad.view(shp) if need_grad else None)
+
+
+class FusedSdf(object):
+    """`sdf(points) -> values` for the callers that only need the value: the `sdf` callable of
+    RayTracing (levelset_sampling.py:831-1167), the proposal / secant evaluations of
+    find_zero_crossing_between_point_pairs (:1262-1267, :1350-1353) and the ray candidates of
+    combined_modeling.py:376-380.  The weight image is packed once per instance (build one per
+    optimiser step); SIREN and IDR-style networks run forward-only fused kernels, an analytic
+    sphere or any other nn.Module is evaluated with model.forward on the GPU."""
+
+    def __init__(self, model, device):
+        self.model = model
+        self.kind, self.packed = "generic", None
+        if siren_spec(model) is not None:
+            self.kind, self.packed = "siren", PackedSiren(model, device)
+        elif idr_spec(model) is not None:
+            self.kind, self.packed = "idr", PackedIdr(model, device)
+
+    def __call__(self, points, **forward_kwargs):
+        """points (...,3) -> sdf (...)"""
+        if not points.is_cuda:
+            raise RuntimeError("iso_points_amd: points must be on the GPU; there is no CPU path")
+        if forward_kwargs or self.kind == "generic":
+            with torch.no_grad():
+                return self.model.forward(points.reshape(-1, 3), **forward_kwargs).sdf.reshape(points.shape[:-1])
+        if self.kind == "siren":
+            return siren_sdf_and_grad(self.model, points, need_grad=False, packed=self.packed)[0]
+        return idr_sdf_and_grad(self.model, points, need_grad=False, packed=self.packed)[0]

@@ -536,3 +536,87 @@ class IdrSDF(torch.nn.Module):
         for l in range(self.num_layers - 1):
             parts += [self.weight(l).detach().reshape(-1), self.b[l].detach().reshape(-1)]
         return torch.cat(parts).float().contiguous()
+
+
+# --------------------------------------------------------------------------- G. ray queries
+def sphere_trace(model, ray0, ray_direction, proj_max_iters=10, proj_tolerance=5e-5, alpha=1.0,
+                 radius=1.0, padding=0.1):
+    """SphereTracing.project_points, levelset_sampling.py:679-808, for one sub-batch (the
+    max_points_per_pass split does not change per-ray results).  ray0, ray_direction (...,3) ->
+    dict with the reference's keys (`levelset_points_Dx` is the point tensor, :806)."""
+    shp = ray0.shape
+    cur = ray0.reshape(-1, 3).clone().float()
+    dirs = ray_direction.reshape(-1, 3).float()
+    n = cur.shape[0]
+    active = torch.ones(n, dtype=torch.bool)
+    inside = torch.ones(n, dtype=torch.bool)
+    val = torch.zeros(n, 1)
+    trials = 0
+    with torch.no_grad():
+        while True:
+            val[active] = model.forward(cur[active]).sdf.reshape(-1, 1)            # :741-760 (value only)
+            active = (val.abs() > 1e-1 * proj_tolerance).squeeze(1) & inside        # :764-765
+            if not (bool(active.any()) and trials < proj_max_iters):                # :768
+                break
+            pts_active = cur[active]
+            move = alpha * val[active] * dirs[active]                               # :773-774
+            move = F.normalize(move, dim=-1, eps=1e-15) * move.norm(dim=-1, keepdim=True).clamp_max(0.1)
+            pts_active = pts_active + move
+            still = pts_active.norm(dim=-1) < (padding + radius)                    # :778-779
+            ins = inside.clone()
+            ins[active] = still
+            inside = ins
+            cur[active & inside] = pts_active[still]                                # :780-781
+            trials += 1
+    valid = val.abs() <= proj_tolerance                                             # :790
+    pts = cur.view(shp)
+    return {"levelset_points": pts, "network_eval_on_levelset_points": val.view(shp[:-1]),
+            "levelset_points_Dx": pts, "mask": valid.view(shp[:-1])}
+
+
+def run_secant(f_start, f_end, d_start, d_end, n_secant_steps, p0, ray_direction, model):
+    """run_Secant_method, levelset_sampling.py:1331-1367 (inputs are cloned, the reference updates
+    them in place)."""
+    f_start, f_end, d_start, d_end = f_start.clone(), f_end.clone(), d_start.clone(), d_end.clone()
+    d_pred = -f_start * (d_end - d_start) / (f_end - f_start) + d_start
+    for _ in range(n_secant_steps):
+        p_mid = p0 + d_pred.unsqueeze(-1) * ray_direction
+        with torch.no_grad():
+            f_mid = model.forward(p_mid).sdf.squeeze(-1)
+        ind_start = torch.eq(torch.sign(f_mid), torch.sign(f_start))
+        d_start[ind_start] = d_pred[ind_start]
+        f_start[ind_start] = f_mid[ind_start]
+        d_end[~ind_start] = d_pred[~ind_start]
+        f_end[~ind_start] = f_mid[~ind_start]
+        d_pred = -f_start * (d_end - d_start) / (f_end - f_start) + d_start
+    return p0 + d_pred.unsqueeze(-1) * ray_direction
+
+
+def find_zero_crossing(p0, p1, model, n_secant_steps=8, n_steps=100, is_occupancy=True, allow_in_to_out=False):
+    """find_zero_crossing_between_point_pairs, levelset_sampling.py:1210-1328 (c = None)."""
+    shp = p0.shape
+    p0 = p0.reshape(-1, 3).float()
+    p1 = p1.reshape(-1, 3).float()
+    n_pts = p0.shape[0]
+    compare = (lambda d: d < 0.0) if is_occupancy else (lambda d: d > 0.0)
+    ray_direction = F.normalize(p1 - p0, p=2, dim=-1, eps=1e-10)
+    d_proposal = torch.linspace(0, 1, steps=n_steps).view(1, n_steps) * torch.norm(p1 - p0, p=2, dim=-1).unsqueeze(-1)
+    p_proposal = p0.unsqueeze(-2) + ray_direction.unsqueeze(-2) * d_proposal.unsqueeze(-1)
+    with torch.no_grad():
+        val = model.forward(p_proposal.view(-1, 3)).sdf.view(n_pts, n_steps)
+    sign_matrix = torch.cat([torch.sign(val[..., :-1] * val[..., 1:]), torch.ones(n_pts, 1)], dim=-1)
+    cost_matrix = sign_matrix * torch.arange(n_steps, 0, -1).float()
+    values, indices = torch.min(cost_matrix, -1)
+    mask_sign_change = values < 0
+    rows = torch.arange(n_pts)
+    mask_out_to_in = compare(val[rows, indices])
+    mask = mask_sign_change if allow_in_to_out else (mask_sign_change & mask_out_to_in)
+    d_start = d_proposal[rows, indices][mask]
+    f_start = val[rows, indices][mask]
+    nxt = torch.clamp(indices + 1, max=n_steps - 1)
+    d_end = d_proposal[rows, nxt][mask]
+    f_end = val[rows, nxt][mask]
+    p_pred = run_secant(f_start, f_end, d_start, d_end, n_secant_steps, p0[mask], ray_direction[mask], model)
+    pt_pred = torch.ones(mask.shape + (3,))
+    pt_pred[mask] = p_pred
+    return pt_pred.view(shp), mask.view(shp[:-1])

@@ -117,6 +117,17 @@ def install_shims():
         return O.frnn_grid_points(p1, p2, lengths1, lengths2, K=K, r=r, return_nn=return_nn)
 
     frnn.frnn_grid_points = frnn_grid_points
+
+    import pytorch3d.renderer.utils as ru
+
+    def convert_to_tensors_and_broadcast(*args, dtype=torch.float32, device="cpu"):
+        """pytorch3d semantics: tensors of batch size 1 or N, expanded along dim 0 to N."""
+        ts = [a if torch.is_tensor(a) else torch.tensor(a, dtype=dtype, device=device) for a in args]
+        n = max(t.shape[0] for t in ts)
+        assert all(t.shape[0] in (1, n) for t in ts)
+        return [t.expand((n,) + tuple(t.shape[1:])) if t.shape[0] != n else t for t in ts]
+
+    ru.convert_to_tensors_and_broadcast = convert_to_tensors_and_broadcast
     frnn.frnn_gather = lambda x, idx, lengths=None: O.frnn_gather(x, idx)
 
 
@@ -235,6 +246,9 @@ def main():
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "idr"):
         from make_golden_pp import gen_idr
         gen_idr(L)
+    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "trace"):
+        from make_golden_trace import gen_trace
+        gen_trace(L)
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "splat"):
         from make_golden_splat import gen_splat
         gen_splat()

@@ -198,3 +198,53 @@ def test_idr_sdf_restatement():
     r = O.project_points(m, g["points"], torch.tensor([g["points"].shape[1]]), proj_max_iters=int(g["T"]),
                          proj_tolerance=1e-30)
     assert rel_err(r.points, g["fixed_points"]) < 1e-4
+
+
+def idr_from_trace(g):
+    return idr_from({"hidden": g["idr_hidden"], "n_layers": g["idr_layers"], "skip": g["idr_skip"],
+                     "n_freq": g["idr_freq"], "raw": g["idr_raw"]})
+
+
+def assert_trace_close(out, pts, val, mask, tol=TIGHT, stop_tol=5e-6):
+    """positions / values of a sphere trace: every ray to `tol`, except rays whose |sdf| sits at the
+    0.1 * 5e-5 stopping threshold (one advance of that size more or less), which must be rare.
+    (`stop_tol` is raised for networks that are not 1-Lipschitz everywhere: where |grad| > 2 along
+    the ray the advance p += f d amplifies rounding differences instead of damping them.)"""
+    assert_projection_close(out["levelset_points"], pts, stop_tol=stop_tol, tol=tol)
+    dv = (out["network_eval_on_levelset_points"].detach().cpu() - val).abs()
+    assert (dv > 1e-5).float().mean() < 5e-3 and dv.max() < 4 * stop_tol
+    assert (out["mask"].cpu() == mask).float().mean() > 0.995
+    assert out["levelset_points_Dx"].shape == pts.shape
+
+
+def test_sphere_trace_restatement():
+    """oracle sphere_trace vs the reference's SphereTracing.project_points (levelset_sampling.py:679-808)."""
+    from oracle import iso_oracle as O
+    g = load("trace_sphere.npz")
+    sph = O.SphereSDF(tuple(g["center"].tolist()), float(g["radius"]))
+    out = O.sphere_trace(sph, g["ray0"], g["dirs"], proj_max_iters=10)
+    assert_trace_close(out, g["T10_points"], g["T10_eval"], g["T10_mask"])
+    assert 0.3 < g["T10_mask"].float().mean() < 0.95          # hits and misses are both present
+    out = O.sphere_trace(sph, g["ray0"], g["dirs"], proj_max_iters=3, alpha=0.8)
+    assert_trace_close(out, g["T3_points"], g["T3_eval"], g["T3_mask"])
+    g = load("trace_siren.npz")
+    out = O.sphere_trace(siren_from(g), g["ray0"], g["dirs"], proj_max_iters=10)
+    assert_trace_close(out, g["T10_points"], g["T10_eval"], g["T10_mask"])
+    g = load("trace_idr.npz")
+    out = O.sphere_trace(idr_from_trace(g), g["ray0"], g["dirs"], proj_max_iters=int(g["T"]))
+    assert_trace_close(out, g["out_points"], g["out_eval"], g["out_mask"])
+
+
+def test_zero_crossing_restatement():
+    """oracle find_zero_crossing vs the reference's find_zero_crossing_between_point_pairs + run_Secant_method
+    (levelset_sampling.py:1210-1367)."""
+    from oracle import iso_oracle as O
+    g = load("trace_siren.npz")
+    pt, mask = O.find_zero_crossing(g["ray0"], g["zc_p1"], siren_from(g), is_occupancy=False)
+    assert torch.equal(mask, g["zc_mask"]) and 0.2 < mask.float().mean() < 1.0
+    assert rel_err(pt, g["zc_points"]) < 1e-5
+    sph = O.SphereSDF(tuple(g["center"].tolist()), float(g["radius"]))
+    pt, mask = O.find_zero_crossing(g["ray0"][:, :500], g["zc_p1"][:, :500], sph, is_occupancy=False, n_steps=64,
+                                    n_secant_steps=6)
+    assert torch.equal(mask, g["zc_sphere_mask"])
+    assert rel_err(pt, g["zc_sphere_points"]) < TIGHT
