@@ -134,6 +134,18 @@ int iso_trace_idr(const float* ray0, const float* dirs, float* pts_out, float* s
                   int skip_layer, int n_freq, float beta, float alpha, float bound, int max_iters,
                   float tol, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Nearest point to each ray (brute force, fused): the (R,M) point-to-ray search of
+ * CombinedModel.sample_offsurface_using_isopoints, DSS/models/combined_modeling.py:336-352.
+ *   pC = p - origin;  ray_sq = (pC . ray)^2;  dist = |pC|^2 - ray_sq;  nn = argmin_m dist
+ *   idx_out (R) i32 = nn (lowest index among equal distances; -1 when there are no points),
+ *   raysq_out (R) = ray_sq[r, nn] (the reference's `ray_len` before eps_sqrt().sqrt(), :345,:353),
+ *   dist_out (R, may be NULL) = dist[r, nn].  rays (R,3) unit directions, points (M,3).       */
+int64_t iso_ray_nearest_point_workspace_bytes(int64_t n_rays);
+int iso_ray_nearest_point(const float* rays, int64_t n_rays, float ox, float oy, float oz,
+                          const float* points, int64_t n_points, int32_t* idx_out,
+                          float* raysq_out, float* dist_out, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * B. Fixed-radius nearest neighbours on a uniform grid
  *    replaces the third-party `frnn` / `prefix_sum` extensions the reference

@@ -40,6 +40,8 @@ SIGNATURES = {
     "iso_trace_sphere": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _F, _P]),
     "iso_trace_siren": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _F, _F, _F, _F, _I, _F, _P, _L, _P]),
     "iso_trace_idr": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _F, _F, _I, _F, _P, _L, _P]),
+    "iso_ray_nearest_point_workspace_bytes": (_L, [_L]),
+    "iso_ray_nearest_point": (_I, [_P, _L, _F, _F, _F, _P, _L, _P, _P, _P, _P, _L, _P]),
     "iso_points_bbox": (_I, [_P, _P, _I, _L, _P, _P]),
     "iso_frnn_make_grid": (_I, [_P, _P, _P, _I, _L, _I, _P, _P]),
     "iso_frnn_insert_points": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),

@@ -620,3 +620,31 @@ def find_zero_crossing(p0, p1, model, n_secant_steps=8, n_steps=100, is_occupanc
     pt_pred = torch.ones(mask.shape + (3,))
     pt_pred[mask] = p_pred
     return pt_pred.view(shp), mask.view(shp[:-1])
+
+
+def ray_nearest_point(ray0, cam_pos, points):
+    """combined_modeling.py:340-345: dense (R,M) point-to-ray distances + topk(k=1, smallest)."""
+    pC = points - cam_pos.view(1, 3)
+    ray_sq = (pC[None, :, :] * ray0[:, None, :]).sum(-1) ** 2
+    dist_to_ray = (pC ** 2).sum(-1).unsqueeze(0) - ray_sq
+    d, nn_idx = torch.topk(dist_to_ray, k=1, dim=1, largest=False)
+    return torch.gather(ray_sq, 1, nn_idx).view(-1), nn_idx.view(-1), d.view(-1), dist_to_ray
+
+
+def insurface_segments(cam_pos, ray0, frontal_points, occluded_points):
+    """combined_modeling.py:336-357 for one batch element."""
+    sq1 = ray_nearest_point(ray0, cam_pos, occluded_points)[0]
+    sq0 = ray_nearest_point(ray0, cam_pos, frontal_points)[0]
+    valid = sq0 < sq1
+    return eps_sqrt(sq0).sqrt(), eps_sqrt(sq1).sqrt(), valid
+
+
+def lowest_sdf_on_segments(model, cam_pos, cam_ray, ray_len0, ray_len1, n_points_per_ray=64):
+    """combined_modeling.py:366-386."""
+    lin = torch.linspace(0, 1.0, n_points_per_ray + 2)[1:-1]
+    lengths = lin * (ray_len1 - ray_len0).view(-1, 1) + ray_len0.view(-1, 1)
+    cand = lengths.unsqueeze(-1) * cam_ray.unsqueeze(-2) + cam_pos.reshape(-1, 1, 3)
+    with torch.no_grad():
+        val = model.forward(cand.view(-1, 3)).sdf.view(-1, n_points_per_ray)
+    p_idx = torch.argmin(val, dim=-1, keepdim=True)
+    return torch.gather(cand, -2, p_idx.unsqueeze(-1).expand(-1, -1, 3)).squeeze(-2), val
