@@ -281,7 +281,7 @@ def main():
                        "points (per-point stages) and tile-row bands (per-pixel stages) sharded x%d, RCCL "
                        "all-gather/all-reduce" % world},
             "roofline": {"bound": "mfma",
-                         "kernel": ("k_siren_step_x3<256,8,3,1> (fused SIREN SDF+grad Newton step, 3xbf16 MFMA)" if x3
+                         "kernel": ("k_siren_step_x3<256,8,3,1,false> (fused SIREN SDF+grad Newton step, 3xbf16 MFMA)" if x3
                                     else "k_siren_step<16> (fused SIREN SDF+grad Newton step, f32 MFMA)"),
                          "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),
