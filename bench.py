@@ -223,6 +223,11 @@ def main():
     from iso_points_amd.dist import Comm
     comm = Comm(enabled=(world > 1))
     model = fitted_siren(dev)
+    if dist is not None:
+        # replicated weights = rank 0's (broadcast once per optimiser step); the per-rank
+        # fits agree only up to the GEMM library's reduction order
+        for prm in model.parameters():
+            dist.broadcast(prm.data, src=0)
     cyc = Cycle(dev, model, comm)
 
     for _ in range(args.warmup):
