@@ -212,13 +212,19 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py: --gpus %d needs torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
         sys.exit(2)
+    if os.environ.get("ISO_BENCH_ONE_DEVICE"):     # test hook: all ranks on cuda:0 (with ISO_BENCH_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("ISO_BENCH_BACKEND", "nccl")       # "nccl" = RCCL; gloo only for the 1-GPU dry run
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from iso_points_amd.dist import Comm
     comm = Comm(enabled=(world > 1))
@@ -273,7 +279,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong",            # 1 M points in total for every N (BASELINE.json: the same cycle at 1 and 8 GPUs)
             "vs_baseline": None,
             "dtype": "f32 (hidden-layer products: exact 3-way bf16 split of both operands, 6 bf16 MFMA passes, "
                      "f32 accumulate)" if x3 else "f32",
