@@ -89,20 +89,68 @@ __device__ __forceinline__ void iso_sincos_core2(iso_f32x2 x, iso_f32x2& s, iso_
   c = __builtin_elementwise_fma(a, cr, -(b * sr));
 }
 
+// Four pairs at once, STEP-major: a packed f32 op whose result feeds the next instruction costs a
+// wait state on gfx950 (the compiler pads the chain of one pair with s_nop: 40 per 8 values, 20 %
+// of the issue slots of the activation stage), so every step is written across the four
+// independent pairs.  Per element exactly the operations of iso_sincos_core2, same order.
+#ifndef ISO_SINCOS_STEP_BARRIER
+#define ISO_SINCOS_STEP_BARRIER 1
+#endif
+#if ISO_SINCOS_STEP_BARRIER
+#define ISO_STEP() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ISO_STEP() do {} while (0)
+#endif
+#define ISO_X4(expr) _Pragma("unroll") for (int p = 0; p < 4; ++p) { expr; } ISO_STEP()
+__device__ __forceinline__ void iso_sincos_core2x4(const iso_f32x2 (&x)[4], iso_f32x2 (&s)[4], iso_f32x2 (&c)[4]) {
+  auto splat = [](float v) { return (iso_f32x2){v, v}; };
+  const iso_f32x2 two_over_pi = splat(0.636619772367581343f);
+  const iso_f32x2 p1 = splat(1.57079637050628662109375f);
+  const iso_f32x2 p2 = splat(-4.37113882867379288655e-8f);
+  const iso_f32x2 p3 = splat(-1.71512451000588187280e-15f);
+  iso_f32x2 n[4], r[4], r2[4], ps[4], sr[4], pc[4], cr[4], t[4], u[4];
+  ISO_X4(t[p] = x[p] * two_over_pi);
+  ISO_X4(n[p] = ((iso_f32x2){rintf(t[p].x), rintf(t[p].y)}));
+  ISO_X4(r[p] = __builtin_elementwise_fma(-n[p], p1, x[p]));
+  ISO_X4(r[p] = __builtin_elementwise_fma(-n[p], p2, r[p]));
+  ISO_X4(r[p] = __builtin_elementwise_fma(-n[p], p3, r[p]));
+  ISO_X4(r2[p] = r[p] * r[p]);
+  ISO_X4(ps[p] = __builtin_elementwise_fma(r2[p], splat(-1.9515295891e-4f), splat(8.3321608736e-3f)));
+  ISO_X4(pc[p] = __builtin_elementwise_fma(r2[p], splat(2.443315711809948e-5f), splat(-1.388731625493765e-3f)));
+  ISO_X4(ps[p] = __builtin_elementwise_fma(ps[p], r2[p], splat(-1.6666654611e-1f)));
+  ISO_X4(pc[p] = __builtin_elementwise_fma(pc[p], r2[p], splat(4.166664568298827e-2f)));
+  ISO_X4(t[p] = ps[p] * r2[p]);
+  ISO_X4(u[p] = __builtin_elementwise_fma(splat(-0.5f), r2[p], splat(1.0f)));
+  ISO_X4(sr[p] = __builtin_elementwise_fma(t[p], r[p], r[p]));
+  ISO_X4(t[p] = r2[p] * r2[p]);
+  ISO_X4(cr[p] = __builtin_elementwise_fma(pc[p], t[p], u[p]));
+  // quadrant rotation (see iso_sincos_core2)
+  iso_f32x2 m[4], a[4], b[4];
+  ISO_X4(t[p] = n[p] * splat(0.25f));
+  ISO_X4(u[p] = ((iso_f32x2){rintf(t[p].x), rintf(t[p].y)}));
+  ISO_X4(m[p] = __builtin_elementwise_fma(splat(-4.0f), u[p], n[p]));
+  ISO_X4(a[p] = splat(1.0f) - ((iso_f32x2){__builtin_fabsf(m[p].x), __builtin_fabsf(m[p].y)}));
+  ISO_X4(b[p] = __builtin_elementwise_fma(m[p], a[p], m[p]));
+  ISO_X4(t[p] = b[p] * cr[p]);
+  ISO_X4(u[p] = -(b[p] * sr[p]));
+  ISO_X4(s[p] = __builtin_elementwise_fma(a[p], sr[p], t[p]));
+  ISO_X4(c[p] = __builtin_elementwise_fma(a[p], cr[p], u[p]));
+}
+
 // Eight arguments at once: the polynomial path for all, then ONE wave-uniform branch for the
 // (practically never taken) large-argument fix-up.  s = sin(w*z), c = w*cos(w*z).
 __device__ __forceinline__ void iso_sin_wcos8(float w, const float (&z)[8], float (&s)[8], float (&c)[8]) {
-  float amax = 0.f;
   const iso_f32x2 w2 = {w, w};
+  iso_f32x2 x[4], s2[4], c2[4];
+  ISO_X4(x[p] = ((iso_f32x2){z[2 * p], z[2 * p + 1]}) * w2);
+  iso_sincos_core2x4(x, s2, c2);
+  ISO_X4(c2[p] = c2[p] * w2);
+  float amax = 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; e += 2) {
-    const iso_f32x2 x = (iso_f32x2){z[e], z[e + 1]} * w2;
-    iso_f32x2 s2, c2;
-    iso_sincos_core2(x, s2, c2);
-    c2 = c2 * w2;
-    s[e] = s2.x; s[e + 1] = s2.y;
-    c[e] = c2.x; c[e + 1] = c2.y;
-    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)));   // one v_max3
+  for (int p = 0; p < 4; ++p) {
+    s[2 * p] = s2[p].x; s[2 * p + 1] = s2[p].y;
+    c[2 * p] = c2[p].x; c[2 * p + 1] = c2[p].y;
+    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[p].x), __builtin_fabsf(x[p].y)));   // one v_max3
   }
   const bool big = !(amax < 1.0e4f);                 // also true for NaN arguments
   if (__builtin_expect(__any(big), 0)) {

@@ -60,12 +60,24 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+// step-major over the four pairs, for the same reason as iso_sincos_core2x4 (mlp_common.h):
+// per pair exactly split_pair
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+  f32x2 x[4], f[4];
+  bf16x2 h[4], m[4], l[4];
+  ISO_X4(x[p] = ((f32x2){v[2 * p], v[2 * p + 1]}));
+  ISO_X4(h[p] = __builtin_convertvector(x[p], bf16x2));
+  ISO_X4(f[p] = __builtin_convertvector(h[p], f32x2));
+  ISO_X4(x[p] = x[p] - f[p]);
+  ISO_X4(m[p] = __builtin_convertvector(x[p], bf16x2));
+  ISO_X4(f[p] = __builtin_convertvector(m[p], f32x2));
+  ISO_X4(x[p] = x[p] - f[p]);
+  ISO_X4(l[p] = __builtin_convertvector(x[p], bf16x2));
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    unsigned a, b, c;
-    split_pair(v[2 * d], v[2 * d + 1], a, b, c);
-    hi[d] = a; mid[d] = b; lo[d] = c;
+    hi[d] = __builtin_bit_cast(unsigned, h[d]);
+    mid[d] = __builtin_bit_cast(unsigned, m[d]);
+    lo[d] = __builtin_bit_cast(unsigned, l[d]);
   }
 }
 
