@@ -275,8 +275,11 @@ int iso_upsample_candidates(const float* points, const float* knn, int64_t n, in
 /* Farthest-point sampling = torch_cluster.fps as wlop uses it
  * (DSS/utils/point_processing.py:473-499): per cloud n, out_idx[n, 0..n_samples[n]) =
  * start[n], then repeatedly the point farthest from the chosen set (squared f32 distances,
- * ties -> lowest index).  work: (N, p_stride) f32 scratch.  out_idx rows are left
- * untouched beyond n_samples[n].                                                  */
+ * ties -> lowest index).  work: iso_farthest_point_sampling_work_floats(N, p_stride) f32 of
+ * scratch.  out_idx rows are left untouched beyond n_samples[n].  Clouds of >= 8 k points
+ * (p_stride) run grid-wide (cooperative launch, points held in registers), smaller ones in one
+ * workgroup per cloud; the sample sequence is the same.                              */
+int64_t iso_farthest_point_sampling_work_floats(int n_clouds, int64_t p_stride);
 int iso_farthest_point_sampling(const float* points, const int64_t* lengths,
                                 const int64_t* n_samples, const int64_t* start, int n_clouds,
                                 int64_t p_stride, int64_t out_stride, float* work,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "iso_frnn_gather": (_I, [_P, _P, _P, _I, _L, _L, _I, _I, _P]),
     "iso_repulse": (_I, [_P, _P, _P, _L, _P, _L, _L, _I, _P, _P]),
     "iso_upsample_candidates": (_I, [_P, _P, _L, _I, _P, _P, _P]),
+    "iso_farthest_point_sampling_work_floats": (_L, [_I, _L]),
     "iso_farthest_point_sampling": (_I, [_P, _P, _P, _P, _I, _L, _L, _P, _P, _P]),
     "iso_splat_view_flags": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _I, _P]),
     "iso_compact_rows": (_I, [_P, _P, _P, _P, _L, _L, _I, _P]),

@@ -1,10 +1,17 @@
-// Farthest-point sampling (exact, sequential by nature): one 1024-lane workgroup per cloud.
-// Stands in for torch_cluster.fps as the reference's wlop calls it
-// (DSS/utils/point_processing.py:473-499, :51).  Every iteration updates the running
-// min-distance of all points to the sample set and takes the arg-max (ties -> lowest index)
-// by wave shuffles + one LDS exchange.  The min-distance array lives in a caller workspace
-// (L2 resident for the reference's cloud sizes, 5k-50k points).
+// Farthest-point sampling (exact, sequential by nature).  Stands in for torch_cluster.fps as the
+// reference's wlop calls it (DSS/utils/point_processing.py:473-499, :51).  Every iteration updates
+// the running min-distance of all points to the sample set and takes the arg-max (ties -> lowest
+// index).  Two kernels, same arithmetic, same result:
+//   * k_fps: one 1024-lane workgroup per cloud, min-distances in a caller workspace (L2 resident
+//     for the reference's cloud sizes, 5k-50k points); an iteration costs ~16 B x len through ONE
+//     CU, so it is the small-cloud form.
+//   * k_fps_grid (clouds of >= 8 k points): a cooperative launch of up to 256 workgroups; every
+//     thread keeps its <= 16 points AND their min-distances in registers (nothing is read from
+//     memory inside the loop except the winner's coordinates), the workgroup maxima meet in one
+//     64-bit atomicMax on (distance bits, ~index) and a counter barrier: ~2 device-scope atomics
+//     per workgroup and iteration instead of 16 B x len of traffic.
 #include <float.h>
+#include <stdlib.h>
 #include "iso_common.h"
 
 #pragma clang fp contract(off)
@@ -66,7 +73,97 @@ __global__ __launch_bounds__(FPS_BLOCK) void k_fps(const float* __restrict__ pts
   }
 }
 
+// ---- grid-wide form ----------------------------------------------------------------------------
+// control block (device memory, zeroed before the launch): [0] arrival counter (u32, monotone),
+// [8..32) three rotating 64-bit maximum slots (iteration s uses slot s % 3; workgroup 0 clears
+// slot (s+2) % 3 after barrier s -- it was last read before barrier s and is next written after
+// barrier s+1).
+struct FpsCtl { unsigned int arrived; unsigned int pad; unsigned long long slot[3]; };
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_BLOCK) void k_fps_grid(const float* __restrict__ p, const int64_t* __restrict__ lengths,
+                                                        const int64_t* __restrict__ n_samples,
+                                                        const int64_t* __restrict__ start, int n, int64_t p_stride,
+                                                        FpsCtl* ctl, int64_t* __restrict__ out) {
+  __shared__ unsigned long long s_key[FPS_BLOCK / 64];
+  __shared__ int s_cur;
+  const int64_t len = lengths ? lengths[n] : p_stride;
+  const int64_t ns = n_samples[n] < len ? n_samples[n] : len;
+  if (len <= 0 || ns <= 0) return;                      // uniform over the grid
+  const int t = threadIdx.x;
+  const unsigned nb = gridDim.x;
+  const int64_t stride = (int64_t)nb * FPS_BLOCK;
+  const int64_t first = (int64_t)blockIdx.x * FPS_BLOCK + t;
+  float px[PPT], py[PPT], pz[PPT], mind[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int64_t i = first + k * stride;
+    px[k] = py[k] = pz[k] = 0.f;
+    mind[k] = -1.0f;                                    // beyond the cloud: never the maximum
+    if (i < len) { px[k] = p[i * 3]; py[k] = p[i * 3 + 1]; pz[k] = p[i * 3 + 2]; mind[k] = FLT_MAX; }
+  }
+  int cur = (int)(start[n] < len ? (start[n] < 0 ? 0 : start[n]) : len - 1);
+  for (int64_t s = 0; s < ns; ++s) {
+    if (blockIdx.x == 0 && t == 0) out[s] = cur;
+    if (s + 1 == ns) break;
+    const float cx = p[(int64_t)cur * 3], cy = p[(int64_t)cur * 3 + 1], cz = p[(int64_t)cur * 3 + 2];
+    unsigned long long key = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      const float m = fminf(mind[k], d);
+      mind[k] = m;
+      // (distance bits, ~index): the largest key is the largest distance, lowest index among equals
+      const unsigned long long kk = m < 0.f ? 0ull
+          : (((unsigned long long)__float_as_uint(m) << 32) | (unsigned)(0xffffffffu - (unsigned)(first + k * stride)));
+      key = kk > key ? kk : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long ok = __shfl_xor(key, o);
+      key = ok > key ? ok : key;
+    }
+    if ((t & 63) == 0) s_key[t >> 6] = key;
+    __syncthreads();
+    if (t == 0) {
+      unsigned long long best = s_key[0];
+      for (int w = 1; w < FPS_BLOCK / 64; ++w) best = s_key[w] > best ? s_key[w] : best;
+      unsigned long long* slot = &ctl->slot[s % 3];
+      __hip_atomic_fetch_max(slot, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = nb * (unsigned)(s + 1);
+      while (__hip_atomic_load(&ctl->arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+        __builtin_amdgcn_s_sleep(1);
+      const unsigned long long win = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (blockIdx.x == 0)
+        __hip_atomic_store(&ctl->slot[(s + 2) % 3], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_cur = (int)(0xffffffffu - (unsigned)(win & 0xffffffffull));
+    }
+    __syncthreads();
+    cur = s_cur;
+    __syncthreads();
+  }
+}
+
+template <int PPT>
+hipError_t launch_fps_grid(int nb, const float* p, const int64_t* lengths, const int64_t* n_samples,
+                           const int64_t* start, int n, int64_t p_stride, FpsCtl* ctl, int64_t* out, hipStream_t s) {
+  void* args[] = {(void*)&p, (void*)&lengths, (void*)&n_samples, (void*)&start, (void*)&n, (void*)&p_stride,
+                  (void*)&ctl, (void*)&out};
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_fps_grid<PPT>), dim3(nb), dim3(FPS_BLOCK), args,
+                                    0, s);
+}
+
+constexpr int64_t kFpsGridMin = 8192;     // below: one workgroup is faster than grid-wide barriers
+constexpr int kFpsCtlFloats = 16;          // control block at the end of the workspace
+
 }  // namespace
+
+extern "C" int64_t iso_farthest_point_sampling_work_floats(int n_clouds, int64_t p_stride) {
+  if (n_clouds < 0 || p_stride < 0) return 0;
+  return (int64_t)n_clouds * p_stride + kFpsCtlFloats;
+}
 
 extern "C" int iso_farthest_point_sampling(const float* points, const int64_t* lengths,
                                            const int64_t* n_samples, const int64_t* start,
@@ -78,7 +175,38 @@ extern "C" int iso_farthest_point_sampling(const float* points, const int64_t* l
   ISO_REQUIRE(points && n_samples && start && work && out_idx, ISO_ERR_INVALID,
               "iso_farthest_point_sampling: null pointer");
   ISO_REQUIRE(p_stride < (1ll << 31), ISO_ERR_UNSUPPORTED, "iso_farthest_point_sampling: cloud too large");
-  hipLaunchKernelGGL(k_fps, dim3(n_clouds), dim3(FPS_BLOCK), 0, (hipStream_t)stream, points, lengths,
+  hipStream_t st = (hipStream_t)stream;
+  if (p_stride >= kFpsGridMin && p_stride <= (int64_t)256 * FPS_BLOCK * 16 && !getenv("ISO_FPS_ONE_WORKGROUP")) {
+    // grid-wide form, cloud after cloud; the smallest grid that keeps <= 8 points per thread
+    // (measured: 2.8 us per sample up to 50 k points, 5.0 at 500 k, 7.1 at 1 M -- the barrier's atomic
+    // round trips, not the arithmetic; fewer, fatter workgroups are not faster)
+    int64_t nb = (p_stride + FPS_BLOCK * 8 - 1) / (FPS_BLOCK * 8);
+    nb = nb < 2 ? 2 : (nb > 256 ? 256 : nb);
+    const int64_t ppt = (p_stride + nb * FPS_BLOCK - 1) / (nb * FPS_BLOCK);
+    FpsCtl* ctl = reinterpret_cast<FpsCtl*>(work + (int64_t)n_clouds * p_stride);
+    bool refused = false;
+    for (int n = 0; n < n_clouds; ++n) {
+      (void)hipMemsetAsync(ctl, 0, sizeof(FpsCtl), st);
+      const float* p = points + (int64_t)n * p_stride * 3;
+      int64_t* out = out_idx + (int64_t)n * out_stride;
+      hipError_t e;
+      if (ppt <= 1) e = launch_fps_grid<1>((int)nb, p, lengths, n_samples, start, n, p_stride, ctl, out, st);
+      else if (ppt <= 2) e = launch_fps_grid<2>((int)nb, p, lengths, n_samples, start, n, p_stride, ctl, out, st);
+      else if (ppt <= 4) e = launch_fps_grid<4>((int)nb, p, lengths, n_samples, start, n, p_stride, ctl, out, st);
+      else if (ppt <= 8) e = launch_fps_grid<8>((int)nb, p, lengths, n_samples, start, n, p_stride, ctl, out, st);
+      else e = launch_fps_grid<16>((int)nb, p, lengths, n_samples, start, n, p_stride, ctl, out, st);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ISO_REQUIRE(n == 0, ISO_ERR_LAUNCH, "iso_farthest_point_sampling: cooperative launch failed: %s",
+                    hipGetErrorString(e));
+        refused = true;
+        break;
+      }
+    }
+    if (!refused) { ISO_CHECK_LAUNCH("iso_farthest_point_sampling"); return ISO_OK; }
+    // the device cannot co-schedule the grid (first cloud refused): the one-workgroup form below
+  }
+  hipLaunchKernelGGL(k_fps, dim3(n_clouds), dim3(FPS_BLOCK), 0, st, points, lengths,
                      n_samples, start, p_stride, out_stride, work, out_idx);
   ISO_CHECK_LAUNCH("iso_farthest_point_sampling");
   return ISO_OK;

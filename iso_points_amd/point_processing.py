@@ -124,7 +124,7 @@ def farthest_sampling(points, num_points, ratio, random_start=False, generator=N
         start = (u * torch.tensor(lens, dtype=torch.float32)).long().clamp(max=max(max(lens) - 1, 0)).to(dev)
     out_idx = torch.full((N, max(mx, 1)), -1, dtype=torch.int64, device=dev)
     nsamp = with_host_lengths(torch.tensor(ns, dtype=torch.int64, device=dev), ns)
-    work = torch.empty((N, max(P, 1)), dtype=torch.float32, device=dev)
+    work = torch.empty((_lib.load().iso_farthest_point_sampling_work_floats(N, P),), dtype=torch.float32, device=dev)
     if mx > 0:
         _lib.call("iso_farthest_point_sampling", _lib.ptr(pts), _lib.ptr(num_points.to(torch.int64).contiguous()),
                   _lib.ptr(nsamp), _lib.ptr(start), N, P, out_idx.shape[1], _lib.ptr(work), _lib.ptr(out_idx),

@@ -78,6 +78,35 @@ def test_fps(dev):
     assert d < 0.12
 
 
+def test_fps_grid_wide_form(dev, monkeypatch):
+    """clouds of >= 8 k points take the cooperative grid-wide kernel: same sample sequence as the
+    oracle and as the one-workgroup kernel, ragged batch, duplicated points (ties -> lowest index)."""
+    O = _O()
+    from iso_points_amd.point_processing import farthest_sampling
+    from iso_points_amd.levelset_sampling import with_host_lengths
+    pb = torch.cat([sphere_cloud(20000, seed=21), sphere_cloud(20000, seed=22)], dim=0)
+    pb[1, 5000:10000] = pb[1, :5000]                       # exact duplicates: equal distances
+    lens = [20000, 12345]
+    num = with_host_lengths(torch.tensor(lens, device=dev), lens)
+    smp, ns, idx = farthest_sampling(pb.to(dev), num, 0.02)
+    for b in range(2):
+        n = int(ns[b])
+        ref = O.farthest_point_sampling(pb[b, :lens[b]], n, start=0)
+        assert torch.equal(idx[b, :n].cpu(), ref)
+    monkeypatch.setenv("ISO_FPS_ONE_WORKGROUP", "1")
+    smp1, ns1, idx1 = farthest_sampling(pb.to(dev), num, 0.02)
+    monkeypatch.delenv("ISO_FPS_ONE_WORKGROUP")
+    assert torch.equal(idx, idx1) and torch.equal(smp, smp1)
+    # a large cloud (several workgroups, 8 points per thread): grid form == one-workgroup form
+    big = torch.nn.functional.normalize(sphere_cloud(300000, seed=23), dim=-1).to(dev)
+    nb = torch.tensor([300000], device=dev)
+    a = farthest_sampling(big, nb, 0.002)[2]
+    monkeypatch.setenv("ISO_FPS_ONE_WORKGROUP", "1")
+    b = farthest_sampling(big, nb, 0.002)[2]
+    monkeypatch.delenv("ISO_FPS_ONE_WORKGROUP")
+    assert torch.equal(a, b) and a.shape[1] == 600 and len(set(a[0].tolist())) == 600
+
+
 def test_wlop_golden_and_subsample(dev):
     O = _O()
     from iso_points_amd.point_processing import wlop
