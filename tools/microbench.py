@@ -12,6 +12,10 @@ from iso_points_amd.levelset_sampling import UniformProjection, full_lengths  # 
 from iso_points_amd.sdf_models import SphereSDF, Siren  # noqa: E402
 
 
+if os.environ.get("ISO_DEV_LIB"):
+    from iso_points_amd import _lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["ISO_DEV_LIB"])
+
 def timeit(fn, warm=2, rep=10):
     for _ in range(warm):
         fn()
