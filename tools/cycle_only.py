@@ -1,0 +1,19 @@
+"""The cfg-3a cycle (analytic sphere SDF) alone, for kernel traces: no network fit, no CPU baseline.
+usage: python tools/cycle_only.py [steps]"""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from iso_points_amd.dist import Comm
+from iso_points_amd.sdf_models import SphereSDF
+dev = torch.device("cuda:0")
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+cyc = bench.Cycle(dev, SphereSDF().to(dev), Comm(enabled=False))
+for _ in range(2):
+    cyc.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    cyc.step()
+torch.cuda.synchronize()
+print("cfg3a cycle: %.3f ms" % ((time.perf_counter() - t0) / steps * 1e3))

@@ -50,6 +50,15 @@ BODY(cvt_i32, "v_cvt_i32_f32 %0, %1", "=v"(u[r]) : "v"(f[r]))
 BODY(med3, "v_med3_f32 %0, %0, %1, %2", "+v"(f[r]) : "v"(c1), "v"(c2))
 BODY(ldexp, "v_ldexp_f32 %0, %0, %1", "+v"(f[r]) : "v"(u[(r + 1) & 7]))
 BODY(mov, "v_mov_b32 %0, %1", "=v"(f[r]) : "v"(c1))
+BODY(mov_self, "v_mov_b32 %0, %1", "=v"(f[r]) : "v"(f[(r + 1) & 7]))
+BODY(cmp_u64, "v_cmp_lt_u64 vcc, %0, %1", : "v"(p[r]), "v"(p[(r + 1) & 7]) : "vcc")
+BODY(cmp_u64_s, "v_cmp_lt_u64 %0, %1, %2", "=s"(sm) : "v"(p[r]), "v"(p[(r + 1) & 7]))
+BODY(cmp_f32_s, "v_cmp_lt_f32 %0, %1, %2", "=s"(sm) : "v"(f[r]), "v"(f[(r + 1) & 7]))
+BODY(cmp_u32, "v_cmp_lt_u32 vcc, %0, %1", : "v"(u[r]), "v"(u[(r + 1) & 7]) : "vcc")
+BODY(min_f32, "v_min_f32 %0, %0, %1", "+v"(f[r]) : "v"(c1))
+BODY(min_u32, "v_min_u32 %0, %0, %1", "+v"(u[r]) : "v"(u[(r + 1) & 7]))
+BODY(swap, "v_swap_b32 %0, %1", "+v"(f[r]), "+v"(f[(r + 4) & 7]) :)
+BODY(mov_b64, "v_mov_b64 %0, %1", "=v"(p[r]) : "v"(p[(r + 1) & 7]))
 
 template <class K> void run(const char* name, K kern, long long* d_out, float* d_sink) {
   const int iters = 2000;
@@ -66,6 +75,6 @@ int main() {
   hipMalloc((void**)&d_out, 256 * 8 * 8); hipMalloc((void**)&d_sink, 64);
 #define R(N) run(#N, k_##N, d_out, d_sink);
   R(fma) R(mul) R(pk_fma) R(pk_mul) R(pk_add) R(cvt_pk_bf16) R(rndne) R(and_b32) R(lshl) R(perm) R(max3)
-  R(cndmask_vcc) R(cndmask_sgpr) R(cmp) R(cmp_cnd) R(exp) R(log) R(rcp) R(sin) R(add3) R(bfe) R(cvt_i32) R(med3) R(ldexp) R(mov)
+  R(cndmask_vcc) R(cndmask_sgpr) R(cmp) R(cmp_cnd) R(exp) R(log) R(rcp) R(sin) R(add3) R(bfe) R(cvt_i32) R(med3) R(ldexp) R(mov) R(mov_self) R(cmp_u64) R(cmp_u64_s) R(cmp_f32_s) R(cmp_u32) R(min_f32) R(min_u32) R(swap) R(mov_b64)
   return 0;
 }
