@@ -102,48 +102,57 @@ __device__ __forceinline__ void iso_sincos_core2(iso_f32x2 x, iso_f32x2& s, iso_
 #define ISO_STEP() do {} while (0)
 #endif
 #define ISO_X4(expr) _Pragma("unroll") for (int p = 0; p < 4; ++p) { expr; } ISO_STEP()
-__device__ __forceinline__ void iso_sincos_core2x4(const iso_f32x2 (&x)[4], iso_f32x2 (&s)[4], iso_f32x2 (&c)[4]) {
+#define ISO_XN(expr) _Pragma("unroll") for (int p = 0; p < NP; ++p) { expr; } ISO_STEP()
+template <int NP>
+__device__ __forceinline__ void iso_sincos_core2xN(const iso_f32x2* x, iso_f32x2* s, iso_f32x2* c) {
   auto splat = [](float v) { return (iso_f32x2){v, v}; };
   const iso_f32x2 two_over_pi = splat(0.636619772367581343f);
   const iso_f32x2 p1 = splat(1.57079637050628662109375f);
   const iso_f32x2 p2 = splat(-4.37113882867379288655e-8f);
   const iso_f32x2 p3 = splat(-1.71512451000588187280e-15f);
-  iso_f32x2 n[4], r[4], r2[4], ps[4], sr[4], pc[4], cr[4], t[4], u[4];
-  ISO_X4(t[p] = x[p] * two_over_pi);
-  ISO_X4(n[p] = ((iso_f32x2){rintf(t[p].x), rintf(t[p].y)}));
-  ISO_X4(r[p] = __builtin_elementwise_fma(-n[p], p1, x[p]));
-  ISO_X4(r[p] = __builtin_elementwise_fma(-n[p], p2, r[p]));
-  ISO_X4(r[p] = __builtin_elementwise_fma(-n[p], p3, r[p]));
-  ISO_X4(r2[p] = r[p] * r[p]);
-  ISO_X4(ps[p] = __builtin_elementwise_fma(r2[p], splat(-1.9515295891e-4f), splat(8.3321608736e-3f)));
-  ISO_X4(pc[p] = __builtin_elementwise_fma(r2[p], splat(2.443315711809948e-5f), splat(-1.388731625493765e-3f)));
-  ISO_X4(ps[p] = __builtin_elementwise_fma(ps[p], r2[p], splat(-1.6666654611e-1f)));
-  ISO_X4(pc[p] = __builtin_elementwise_fma(pc[p], r2[p], splat(4.166664568298827e-2f)));
-  ISO_X4(t[p] = ps[p] * r2[p]);
-  ISO_X4(u[p] = __builtin_elementwise_fma(splat(-0.5f), r2[p], splat(1.0f)));
-  ISO_X4(sr[p] = __builtin_elementwise_fma(t[p], r[p], r[p]));
-  ISO_X4(t[p] = r2[p] * r2[p]);
-  ISO_X4(cr[p] = __builtin_elementwise_fma(pc[p], t[p], u[p]));
+  iso_f32x2 n[NP], r[NP], r2[NP], ps[NP], sr[NP], pc[NP], cr[NP], t[NP], u[NP];
+  ISO_XN(t[p] = x[p] * two_over_pi);
+  ISO_XN(n[p] = ((iso_f32x2){rintf(t[p].x), rintf(t[p].y)}));
+  ISO_XN(r[p] = __builtin_elementwise_fma(-n[p], p1, x[p]));
+  ISO_XN(r[p] = __builtin_elementwise_fma(-n[p], p2, r[p]));
+  ISO_XN(r[p] = __builtin_elementwise_fma(-n[p], p3, r[p]));
+  ISO_XN(r2[p] = r[p] * r[p]);
+  ISO_XN(ps[p] = __builtin_elementwise_fma(r2[p], splat(-1.9515295891e-4f), splat(8.3321608736e-3f)));
+  ISO_XN(pc[p] = __builtin_elementwise_fma(r2[p], splat(2.443315711809948e-5f), splat(-1.388731625493765e-3f)));
+  ISO_XN(ps[p] = __builtin_elementwise_fma(ps[p], r2[p], splat(-1.6666654611e-1f)));
+  ISO_XN(pc[p] = __builtin_elementwise_fma(pc[p], r2[p], splat(4.166664568298827e-2f)));
+  ISO_XN(t[p] = ps[p] * r2[p]);
+  ISO_XN(u[p] = __builtin_elementwise_fma(splat(-0.5f), r2[p], splat(1.0f)));
+  ISO_XN(sr[p] = __builtin_elementwise_fma(t[p], r[p], r[p]));
+  ISO_XN(t[p] = r2[p] * r2[p]);
+  ISO_XN(cr[p] = __builtin_elementwise_fma(pc[p], t[p], u[p]));
   // quadrant rotation (see iso_sincos_core2)
-  iso_f32x2 m[4], a[4], b[4];
-  ISO_X4(t[p] = n[p] * splat(0.25f));
-  ISO_X4(u[p] = ((iso_f32x2){rintf(t[p].x), rintf(t[p].y)}));
-  ISO_X4(m[p] = __builtin_elementwise_fma(splat(-4.0f), u[p], n[p]));
-  ISO_X4(a[p] = splat(1.0f) - ((iso_f32x2){__builtin_fabsf(m[p].x), __builtin_fabsf(m[p].y)}));
-  ISO_X4(b[p] = __builtin_elementwise_fma(m[p], a[p], m[p]));
-  ISO_X4(t[p] = b[p] * cr[p]);
-  ISO_X4(u[p] = -(b[p] * sr[p]));
-  ISO_X4(s[p] = __builtin_elementwise_fma(a[p], sr[p], t[p]));
-  ISO_X4(c[p] = __builtin_elementwise_fma(a[p], cr[p], u[p]));
+  iso_f32x2 m[NP], a[NP], b[NP];
+  ISO_XN(t[p] = n[p] * splat(0.25f));
+  ISO_XN(u[p] = ((iso_f32x2){rintf(t[p].x), rintf(t[p].y)}));
+  ISO_XN(m[p] = __builtin_elementwise_fma(splat(-4.0f), u[p], n[p]));
+  ISO_XN(a[p] = splat(1.0f) - ((iso_f32x2){__builtin_fabsf(m[p].x), __builtin_fabsf(m[p].y)}));
+  ISO_XN(b[p] = __builtin_elementwise_fma(m[p], a[p], m[p]));
+  ISO_XN(t[p] = b[p] * cr[p]);
+  ISO_XN(u[p] = -(b[p] * sr[p]));
+  ISO_XN(s[p] = __builtin_elementwise_fma(a[p], sr[p], t[p]));
+  ISO_XN(c[p] = __builtin_elementwise_fma(a[p], cr[p], u[p]));
 }
 
 // Eight arguments at once: the polynomial path for all, then ONE wave-uniform branch for the
-// (practically never taken) large-argument fix-up.  s = sin(w*z), c = w*cos(w*z).
-__device__ __forceinline__ void iso_sin_wcos8(float w, const float (&z)[8], float (&s)[8], float (&c)[8]) {
-  const iso_f32x2 w2 = {w, w};
+// (practically never taken) large-argument fix-up.  s = sin(w_in*z), c = w*cos(w_in*z)
+// (w_in = w except where z carries a power-of-two scale that w_in takes out again).
+__device__ __forceinline__ void iso_sin_wcos8(float w_in, float w, const float (&z)[8], float (&s)[8], float (&c)[8]) {
+  const iso_f32x2 w2 = {w, w}, wi2 = {w_in, w_in};
   iso_f32x2 x[4], s2[4], c2[4];
-  ISO_X4(x[p] = ((iso_f32x2){z[2 * p], z[2 * p + 1]}) * w2);
-  iso_sincos_core2x4(x, s2, c2);
+  ISO_X4(x[p] = ((iso_f32x2){z[2 * p], z[2 * p + 1]}) * wi2);
+  // ISO_SINCOS_WIDTH pairs step-major at a time: 4 removes every wait state, 2 keeps the register
+  // footprint of the temporaries at half (two chains already separate dependent packed ops)
+#ifndef ISO_SINCOS_WIDTH
+#define ISO_SINCOS_WIDTH 2
+#endif
+#pragma unroll
+  for (int q = 0; q < 4; q += ISO_SINCOS_WIDTH) iso_sincos_core2xN<ISO_SINCOS_WIDTH>(x + q, s2 + q, c2 + q);
   ISO_X4(c2[p] = c2[p] * w2);
   float amax = 0.f;
 #pragma unroll
@@ -157,7 +166,7 @@ __device__ __forceinline__ void iso_sin_wcos8(float w, const float (&z)[8], floa
     // |x| >= 1e4 (never seen with trained SIRENs): libm's Payne-Hanek path, one rolled copy
     float xs[8], ss[8], cs[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { xs[e] = w * z[e]; ss[e] = s[e]; cs[e] = c[e]; }
+    for (int e = 0; e < 8; ++e) { xs[e] = w_in * z[e]; ss[e] = s[e]; cs[e] = c[e]; }
 #pragma unroll 1
     for (int e = 0; e < 8; ++e) {
       float x = xs[0], s0, c0;

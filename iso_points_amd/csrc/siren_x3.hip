@@ -38,6 +38,10 @@
 #include "iso_newton.h"
 #include "mlp_common.h"
 
+#ifndef X3_PIPE
+#define X3_PIPE 0      // 1: software-pipelined kernel (siren_x3_pipe.h, NW == 4; measured: no gain); 0: plain stages
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -45,6 +49,23 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// Forward products on split fp16 instead of split bf16 (X3_FWD_F16, default on): an f32 number cut
+// into TWO fp16 numbers (11 + 11 significant bits, round-to-nearest at each cut) is represented to
+// 2^-24 relative -- the f32 rounding level -- so W.x needs THREE partial products
+// (W_h x_l + W_l x_h + W_h x_h; the dropped W_l x_l is 2^-24 relative) instead of six: half the
+// MFMAs of a forward layer.  fp16 has a 5-bit exponent, so both operands are brought into range by
+// exact power-of-two scales: activations (|sin| <= 1) by 2^12 (the low part then stays a normal
+// number down to contributions of 2^-26), the weights of layer l by 2^s_l with
+// max|2^s_l W| in [512, 1024); the bias enters the accumulator scaled by 2^(s_l + 12) and the
+// scale is taken out again, exactly, in the multiplication by omega that follows.  The reverse
+// sweep keeps the three-way bf16 cut: adjoint values have no a-priori range.
+#ifndef X3_FWD_F16
+#define X3_FWD_F16 1
+#endif
+constexpr float kActScale = 4096.0f;             // 2^12
 
 // exact three-way cut of two floats; element 0 in the low half of each word
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid,
@@ -81,14 +102,32 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mi
   }
 }
 
+// two-way fp16 cut of 2^12 * v (step-major as split8)
+__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo) {
+  f32x2 x[4], f[4];
+  f16x2 h[4], l[4];
+  const f32x2 sc = {kActScale, kActScale};
+  ISO_X4(x[p] = ((f32x2){v[2 * p], v[2 * p + 1]}) * sc);
+  ISO_X4(h[p] = __builtin_convertvector(x[p], f16x2));
+  ISO_X4(f[p] = __builtin_convertvector(h[p], f32x2));
+  ISO_X4(x[p] = x[p] - f[p]);
+  ISO_X4(l[p] = __builtin_convertvector(x[p], f16x2));
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    hi[d] = __builtin_bit_cast(unsigned, h[d]);
+    lo[d] = __builtin_bit_cast(unsigned, l[d]);
+  }
+}
+
 // Timing experiments only (tools/build_variant.sh): -DX3_DBG_NOSINCOS / NOMMA / NOSTASH knock out
 // one ingredient each; results are then wrong by construction.
-__device__ __forceinline__ void x3_sin_wcos8(float w, const float (&z)[8], float (&s)[8], float (&c)[8]) {
+// s = sin(w_in * z), c = w * cos(w_in * z); w_in = w / (accumulator scale), an exact power-of-two quotient
+__device__ __forceinline__ void x3_sin_wcos8(float w_in, float w, const float (&z)[8], float (&s)[8], float (&c)[8]) {
 #ifdef X3_DBG_NOSINCOS
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { s[e] = w * z[e]; c[e] = w; }
+  for (int e = 0; e < 8; ++e) { s[e] = w_in * z[e]; c[e] = w; }
 #else
-  iso_sin_wcos8(w, z, s, c);
+  iso_sin_wcos8(w_in, w, z, s, c);
 #endif
 }
 
@@ -98,7 +137,7 @@ __device__ __forceinline__ u32x4 as_u32x4(const f32x4& v) { return __builtin_bit
 // ---- packing -------------------------------------------------------------------------------
 // raw layout: W0[H*3] b0[H] {Wi[H*H] bi[H]}*L WL[H] bL[1]
 __global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict__ packed, int H, int L) {
-  const int64_t base = x3_base(H, L), total = siren_packed_total(H, L);
+  const int64_t base = x3_base(H, L), total = x16_base(H, L);
   const int64_t HH = (int64_t)H * H;
   const int NTO = H / 32;
   const float* b0 = raw + (int64_t)H * 3;
@@ -143,9 +182,64 @@ __global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict
   }
 }
 
+// power-of-two scale of every hidden layer: max |2^s W| in [512, 1024)
+__global__ void k_siren_wscale(const float* __restrict__ raw, float* __restrict__ packed, int H, int L) {
+  __shared__ float s_m[256];
+  const int l = blockIdx.x;
+  const int64_t HH = (int64_t)H * H;
+  const float* Wl = raw + (int64_t)H * 4 + (int64_t)l * (HH + H);
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < HH; i += 256) {
+    const float a = fabsf(Wl[i]);
+    m = (a == a && a > m) ? a : m;
+  }
+  s_m[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_m[threadIdx.x] = fmaxf(s_m[threadIdx.x], s_m[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float mx = s_m[0];
+    int e = 0;
+    float sc = 1.0f;
+    if (mx > 0.f && mx < 3.0e38f) {
+      (void)frexpf(mx, &e);                    // mx = f * 2^e, f in [0.5, 1)
+      int k = 10 - e;                          // 2^k * mx in [512, 1024)
+      k = k > 100 ? 100 : (k < -100 ? -100 : k);
+      sc = ldexpf(1.0f, k);
+    }
+    packed[x16_base(H, L) + l] = sc;
+  }
+}
+
+__global__ void k_siren_pack_f16(const float* __restrict__ raw, float* __restrict__ packed, int H, int L) {
+  const int64_t HH = (int64_t)H * H;
+  const int NTO = H / 32;
+  const int64_t total = (int64_t)L * HH;
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(o / HH);
+    const int64_t q = o % HH;
+    const float* Wl = raw + (int64_t)H * 4 + (int64_t)l * (HH + H);
+    const float sc = packed[x16_base(H, L) + l];
+    const int d = (int)(q & 3), lane = (int)((q >> 2) & 63);
+    const int64_t blk = q >> 8;                 // (s*NTO + To)*2 + part
+    const int part = (int)(blk & 1);
+    const int To = (int)((blk >> 1) % NTO), s = (int)(blk / (2 * NTO));
+    const int fo = 32 * To + (lane & 31);
+    f32x2 v;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = Wl[(int64_t)fo * H + x3_feat(s, 8 * (lane >> 5) + 2 * d + u)] * sc;
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), f16x2);
+    reinterpret_cast<unsigned*>(packed + x16_off_layer(H, L, 0))[o] =
+        part == 0 ? __builtin_bit_cast(unsigned, h) : __builtin_bit_cast(unsigned, lo);
+  }
+}
+
 // ---- the layer GEMM --------------------------------------------------------------------------
 // acc[t][n] (32 features x 32 points each) += W[tiles of this wave] . act, K-steps 0..NS-1.
-// imgw = image + (TW*w*3)*64 + lane ;  actl = act + lane ;  bias_h = bias_k + h*8 (K-order)
+// imgw = image + (TW*w*3)*64 + lane ;  actl = act + lane ;  bias_h = bias_k (K-order, wave-uniform)
 
 // Weight-fragment pipeline: 4 register sets, requested kAD = 3 K-steps ahead (an L2 hit under
 // load takes longer than one K-step of MFMAs).  The fragments of the first kAD K-steps are
@@ -159,24 +253,25 @@ constexpr int kAD = X3_KAD;
 
 // imgw is WAVE-UNIFORM (no lane term): the loads take the scalar-base + 32-bit lane-offset form,
 // so no 64-bit per-lane address registers are needed.
-template <int TW, int NTO>
+// PARTS = 3: split-bf16 image, 2: split-fp16 image (imgw then points TW*w*PARTS*64 into it)
+template <int TW, int NTO, int PARTS>
 __device__ __forceinline__ void x3_load_a(u32x4 (&Ar)[TW][3], const u32x4* __restrict__ imgw, int s,
                                           unsigned lane) {
-  const char* p = reinterpret_cast<const char*>(imgw + (int64_t)s * (NTO * 3 * 64));
+  const char* p = reinterpret_cast<const char*>(imgw + (int64_t)s * (NTO * PARTS * 64));
   const unsigned lane_off = lane * 16u;      // 32-bit byte offset: keeps the scalar-base form
 #pragma unroll
   for (int t = 0; t < TW; ++t) {
-    const char* pt = p + t * 3072;          // scalar; the three parts are immediate offsets
+    const char* pt = p + t * (PARTS * 1024);   // scalar; the parts are immediate offsets
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Ar[t][c] = *reinterpret_cast<const u32x4*>(pt + lane_off + c * 1024);
+    for (int c = 0; c < PARTS; ++c) Ar[t][c] = *reinterpret_cast<const u32x4*>(pt + lane_off + c * 1024);
   }
 }
 
-template <int TW, int NTO>
+template <int TW, int NTO, int PARTS>
 __device__ __forceinline__ void x3_prefetch_a(u32x4 (&A)[4][TW][3], const u32x4* __restrict__ imgw, int s,
                                               unsigned lane) {
 #pragma unroll
-  for (int d = 0; d < kAD; ++d) x3_load_a<TW, NTO>(A[d], imgw, s + d, lane);
+  for (int d = 0; d < kAD; ++d) x3_load_a<TW, NTO, PARTS>(A[d], imgw, s + d, lane);
 }
 
 enum { kAccumulate = 0, kZero = 1, kBias = 2 };
@@ -186,19 +281,22 @@ enum { kAccumulate = 0, kZero = 1, kBias = 2 };
 // a later LDS / global load that writes them: when the operand requests of the next K-steps are
 // scheduled between the MFMAs, the allocator would otherwise hand a just-read fragment register to
 // the very next load (seen: results changing from run to run).
-template <int N>
+template <int N, int PARTS>
 __device__ __forceinline__ void x3_keep_alive(const u32x4 (&X)[N][3]) {
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) asm volatile("" ::"v"(X[i][c]));
+    for (int c = 0; c < PARTS; ++c) asm volatile("" ::"v"(X[i][c]));
 }
 
-template <int TW, int NB, int NTO, int KS, int INIT, bool IL>
+// PARTS / NEXT_PARTS: operand format of this stage / of the stage whose first fragments are
+// requested at the end (3 = split bf16, six products; 2 = split fp16, three products).
+// bias_scale multiplies the bias (the accumulator scale of a split-fp16 stage; 1 otherwise).
+template <int TW, int NB, int NTO, int KS, int INIT, bool IL, int PARTS = 3, int NEXT_PARTS = 3>
 __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const float* __restrict__ bias_h,
                                         const u32x4* actl, f32x16 (&acc)[TW][NB], int w, int s0,
                                         u32x4 (&A)[4][TW][3], const u32x4* __restrict__ next_imgw, int next_s,
-                                        unsigned lane) {
+                                        unsigned lane, float bias_scale = 1.0f) {
   static_assert(KS % 4 == 0, "K-steps are processed in groups of four");
   if constexpr (INIT != kAccumulate) {
 #pragma unroll
@@ -207,11 +305,11 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
       if constexpr (INIT == kBias) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          const float* bp = bias_h + (2 * (TW * w + t) + p) * 16;
+          const float* bp = bias_h + (2 * (TW * w + t) + p) * 16 + 8 * (lane >> 5);   // uniform base + lane-half offset
           const f32x4 lo = *reinterpret_cast<const f32x4*>(bp);
           const f32x4 hi = *reinterpret_cast<const f32x4*>(bp + 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { init[8 * p + e] = lo[e]; init[8 * p + 4 + e] = hi[e]; }
+          for (int e = 0; e < 4; ++e) { init[8 * p + e] = lo[e] * bias_scale; init[8 * p + 4 + e] = hi[e] * bias_scale; }
         }
       } else {
 #pragma unroll
@@ -227,7 +325,7 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Br[n][c] = p[(n * 3 + c) * 64];
+      for (int c = 0; c < PARTS; ++c) Br[n][c] = p[(n * 3 + c) * 64];
   };
   auto mma = [&](const u32x4 (&Ar)[TW][3], const u32x4 (&Br)[NB][3]) {
 #ifdef X3_DBG_NOMMA
@@ -239,6 +337,21 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
         for (int c = 0; c < 3; ++c) acc[t][n][c] += __builtin_bit_cast(f32x4, Ar[t][c]).x * __builtin_bit_cast(f32x4, Br[n][c]).y;
     return;
 #endif
+    if constexpr (PARTS == 2) {
+      // W_l x_h + W_h x_l + W_h x_h
+      constexpr int QA[3] = {1, 0, 0};
+      constexpr int QB[3] = {0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+            acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ar[t][QA[q]]),
+                                                               __builtin_bit_cast(f16x8, Br[n][QB[q]]),
+                                                               acc[t][n], 0, 0, 0);
+      return;
+    }
     // smallest terms first; consecutive MFMAs go to different accumulators
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
     constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
@@ -265,8 +378,8 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
     for (int jj = 0; jj < 4; ++jj) {
       const int k = i + jj;                       // K-step of this stage being multiplied
       // set (jj+3)%4 was consumed one K-step ago: refill it with K-step k+3 (or the next stage's)
-      if (k + kAD < KS) x3_load_a<TW, NTO>(A[(jj + kAD) & 3], imgw, s0 + k + kAD, lane);
-      else x3_load_a<TW, NTO>(A[(jj + kAD) & 3], next_imgw, next_s + (k + kAD - KS), lane);
+      if (k + kAD < KS) x3_load_a<TW, NTO, PARTS>(A[(jj + kAD) & 3], imgw, s0 + k + kAD, lane);
+      else x3_load_a<TW, NTO, NEXT_PARTS>(A[(jj + kAD) & 3], next_imgw, next_s + (k + kAD - KS), lane);
       if (k + 1 < KS) ldB(B[(jj + 1) & 1], s0 + k + 1);
 #ifndef X3_INTERLEAVE_LOADS
 #define X3_INTERLEAVE_LOADS 1
@@ -284,22 +397,22 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
 #endif
 #if X3_IL_DS
 #pragma unroll
-      for (int g = 0; g < NB * 3; ++g) {
+      for (int g = 0; g < NB * PARTS; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
 #endif
 #if X3_IL_VM
 #pragma unroll
-      for (int g = 0; g < TW * 3; ++g) {
+      for (int g = 0; g < TW * (PARTS > NEXT_PARTS ? PARTS : NEXT_PARTS) && g < TW * NB * (PARTS == 2 ? 3 : 6) - NB * PARTS; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
 #ifndef X3_NO_KEEPALIVE
-      x3_keep_alive<TW>(A[jj]);
-      x3_keep_alive<NB>(B[jj & 1]);
+      x3_keep_alive<TW, PARTS>(A[jj]);
+      x3_keep_alive<NB, PARTS>(B[jj & 1]);
 #endif
       } else {
       __builtin_amdgcn_sched_barrier(0);
@@ -381,11 +494,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   const int team = SKEW ? (w >= NW / 2) : 0;
   const int L = a.L;
   const float* X = a.packed + x3_base(H, L);
-  const f32x4* W0k = reinterpret_cast<const f32x4*>(X) + (SL * w * 2 + h) * 8;
-  const float* WLk = X + 4 * H + (SL * w * 2 + h) * 8;
+  // wave-uniform bases (SGPRs) + small per-lane offsets: no 64-bit per-lane pointers are kept live
+  const f32x4* W0u = reinterpret_cast<const f32x4*>(X) + SL * w * 16;       // + h*8 + ...
+  const float* WLu = X + 4 * H + SL * w * 16;                               // + h*8 + ...
+  const int h8 = h * 8;
   const float bL = a.packed[off_bl(H)];
   f32x4* stash = reinterpret_cast<f32x4*>(a.stash) +
-                 ((int64_t)blockIdx.x * NW + w) * (int64_t)(L + 1) * NG * 128 + lane;
+                 ((int64_t)blockIdx.x * NW + w) * (int64_t)(L + 1) * NG * 128;   // + lane
 
   // weight images of this wave: forward / transposed image of hidden layer l
   auto fw_img = [&](int l) {
@@ -394,8 +509,18 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   auto bw_img = [&](int l) {
     return reinterpret_cast<const u32x4*>(a.packed + x3_off_layer(H, L, l) + H + 3 * (H * H / 2)) + (TW * w * 3) * 64;
   };
+  constexpr int FP = X3_FWD_F16 ? 2 : 3;      // operand parts of the forward stages
+  // forward image of hidden layer l in the forward format
+  auto fwd_img = [&](int l) {
+    if constexpr (X3_FWD_F16)
+      return reinterpret_cast<const u32x4*>(a.packed + x16_off_layer(H, L, l)) + (TW * w * 2) * 64;
+    else
+      return fw_img(l);
+  };
+  // accumulator scale of forward layer l: 2^12 (activations) * 2^s_l (weights)
+  auto fwd_scale = [&](int l) { return X3_FWD_F16 ? kActScale * a.packed[x16_base(H, L) + l] : 1.0f; };
   u32x4 A[4][TW][3];                     // weight-fragment pipeline, carried across stages
-  x3_prefetch_a<TW, NTO>(A, fw_img(0), 0, lane);
+  x3_prefetch_a<TW, NTO, FP>(A, fwd_img(0), 0, lane);
 
   const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
   const int64_t n_tiles = (count + P - 1) / P;
@@ -409,9 +534,11 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 #endif
     X3_STAMP();
     float px[NB], py[NB], pz[NB];
+    int j_e = j;
+    asm volatile("" : "+v"(j_e));
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-      const int64_t slot = tile * P + 32 * n + j;
+      const int64_t slot = tile * P + 32 * n + j_e;
       px[n] = py[n] = pz[n] = 0.f;
       if (slot < count) {
         const int64_t idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
@@ -425,21 +552,27 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     for (int sl = 0; sl < SL; ++sl) {
       f32x4 wv[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) wv[e] = W0k[sl * 16 + e];
+      for (int e = 0; e < 8; ++e) wv[e] = W0u[sl * 16 + h8 + e];
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
         float zz[8], hv[8], sv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) zz[e] = ((wv[e].x * px[n] + wv[e].y * py[n]) + wv[e].z * pz[n]) + wv[e].w;
-        x3_sin_wcos8(a.w0, zz, hv, sv);
+        x3_sin_wcos8(a.w0, a.w0, zz, hv, sv);
         const int k = sl * NB + n;
-        u32x4 p0, p1, p2;
-        split8(hv, p0, p1, p2);
-        own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+        if constexpr (X3_FWD_F16) {
+          u32x4 p0, p1;
+          split8_f16(hv, p0, p1);
+          own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1;
+        } else {
+          u32x4 p0, p1, p2;
+          split8(hv, p0, p1, p2);
+          own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+        }
 #ifndef X3_DBG_NOSTASH
         if constexpr (!FWD) {
-          stash[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
-          stash[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+          stash[(k * 2 + 0) * 64 + lane] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+          stash[(k * 2 + 1) * 64 + lane] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
         }
 #endif
       }
@@ -455,16 +588,24 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     // ---- hidden layers, forward --------------------------------------------------------------
     for (int l = 0; l < L; ++l) {
       const float* lay = a.packed + x3_off_layer(H, L, l);
-      const u32x4* img = fw_img(l);
-      const u32x4* nxt = l + 1 < L ? fw_img(l + 1) : (FWD ? fw_img(0) : bw_img(L - 1));
+      const u32x4* img = fwd_img(l);
+      const float zscale = fwd_scale(l);             // the accumulators hold zscale * (W h + b)
+      const float w_in = a.wh / zscale;              // exact: zscale is a power of two
+      static_assert(!SKEW || !X3_FWD_F16, "the two-team experiment is written for the split-bf16 forward");
       if constexpr (SKEW) {
-        gemm_x3<TW, NB, NTO, KH, kBias, IL>(img, lay + h * 8, act + lane, acc, w, 0, A, img, KH, lane);
+        const u32x4* nxt = l + 1 < L ? fw_img(l + 1) : (FWD ? fw_img(0) : bw_img(L - 1));
+        gemm_x3<TW, NB, NTO, KH, kBias, IL>(img, lay, act + lane, acc, w, 0, A, img, KH, lane);
         X3_STAMP();
         __syncthreads();
         X3_STAMP();
         gemm_x3<TW, NB, NTO, KH, kAccumulate, IL>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0, lane);
+      } else if (l + 1 < L || FWD) {
+        // the next stage is a forward one again (layer l+1, or layer 0 of the next tile)
+        gemm_x3<TW, NB, NTO, NS, kBias, IL, FP, FP>(img, lay, act + lane, acc, w, 0, A,
+                                                    l + 1 < L ? fwd_img(l + 1) : fwd_img(0), 0, lane, zscale);
       } else {
-        gemm_x3<TW, NB, NTO, NS, kBias, IL>(img, lay + h * 8, act + lane, acc, w, 0, A, nxt, 0, lane);
+        gemm_x3<TW, NB, NTO, NS, kBias, IL, FP, 3>(img, lay, act + lane, acc, w, 0, A, bw_img(L - 1), 0, lane,
+                                                   zscale);
       }
       X3_STAMP();
       __syncthreads();                      // both teams have read this team's K-half
@@ -474,11 +615,11 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       // one 8-value group: sin / w cos, head or stash, split, store as the next layer's B entry
       auto act_group = [&](int k, int sl, const float (&zz)[8], float& fp) {
         float hv[8], sv[8];
-        x3_sin_wcos8(a.wh, zz, hv, sv);
+        x3_sin_wcos8(w_in, a.wh, zz, hv, sv);
         if (top) {
           // adjoint seed of the top sine layer = head weight * w cos(w z); head dot product here
-          const f32x4 wl0 = *reinterpret_cast<const f32x4*>(WLk + sl * 16);
-          const f32x4 wl1 = *reinterpret_cast<const f32x4*>(WLk + sl * 16 + 4);
+          const f32x4 wl0 = *reinterpret_cast<const f32x4*>(WLu + sl * 16 + h8);
+          const f32x4 wl1 = *reinterpret_cast<const f32x4*>(WLu + sl * 16 + h8 + 4);
           const float f0 = (wl0.x * hv[0] + wl0.y * hv[1]) + (wl0.z * hv[2] + wl0.w * hv[3]);
           const float f1 = (wl1.x * hv[4] + wl1.y * hv[5]) + (wl1.z * hv[6] + wl1.w * hv[7]);
           fp += f0 + f1;
@@ -488,14 +629,20 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         } else {
 #ifndef X3_DBG_NOSTASH
           if constexpr (!FWD) {
-            st_l[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
-            st_l[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+            st_l[(k * 2 + 0) * 64 + lane] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+            st_l[(k * 2 + 1) * 64 + lane] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
           }
 #endif
         }
-        u32x4 p0, p1, p2;
-        split8(hv, p0, p1, p2);
-        own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+        if (X3_FWD_F16 && !top) {               // input of the next forward layer
+          u32x4 p0, p1;
+          split8_f16(hv, p0, p1);
+          own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1;
+        } else {                                // seed of the reverse sweep
+          u32x4 p0, p1, p2;
+          split8(hv, p0, p1, p2);
+          own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+        }
       };
 #ifndef X3_DIRECT_ACT
 #define X3_DIRECT_ACT 1
@@ -568,21 +715,23 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 #ifdef X3_DBG_NOSTASH
           sv[k][0] = sv[k][1] = (f32x4){1.f, 1.f, 1.f, (float)l};
 #else
-          sv[k][0] = st_l[(k * 2) * 64]; sv[k][1] = st_l[(k * 2 + 1) * 64];
+          sv[k][0] = st_l[(k * 2) * 64 + lane]; sv[k][1] = st_l[(k * 2 + 1) * 64 + lane];
 #endif
         }
       };
       // w cos(w z) of the layer below: requested before the GEMM when the registers allow it
       if constexpr (NG <= 6 && X3_EARLY_STASH) ld_stash();
-      const u32x4* nxt = l > 0 ? bw_img(l - 1) : fw_img(0);
       if constexpr (SKEW) {
+        const u32x4* nxt = l > 0 ? bw_img(l - 1) : fw_img(0);
         gemm_x3<TW, NB, NTO, KH, kZero, IL>(img, nullptr, act + lane, acc, w, 0, A, img, KH, lane);
         X3_STAMP();
         __syncthreads();
         X3_STAMP();
         gemm_x3<TW, NB, NTO, KH, kAccumulate, IL>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0, lane);
+      } else if (l > 0) {
+        gemm_x3<TW, NB, NTO, NS, kZero, IL, 3, 3>(img, nullptr, act + lane, acc, w, 0, A, bw_img(l - 1), 0, lane);
       } else {
-        gemm_x3<TW, NB, NTO, NS, kZero, IL>(img, nullptr, act + lane, acc, w, 0, A, nxt, 0, lane);
+        gemm_x3<TW, NB, NTO, NS, kZero, IL, 3, FP>(img, nullptr, act + lane, acc, w, 0, A, fwd_img(0), 0, lane);
       }
       if constexpr (NG > 6 || !X3_EARLY_STASH) ld_stash();
       X3_STAMP();
@@ -595,7 +744,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
           f32x4 wv[8];
           if (l == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) wv[e] = W0k[(2 * t + p) * 16 + e];
+            for (int e = 0; e < 8; ++e) wv[e] = W0u[(2 * t + p) * 16 + h8 + e];
           }
 #pragma unroll
           for (int n = 0; n < NB; ++n) {
@@ -636,15 +785,20 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     __syncthreads();
     X3_STAMP();
     // ---- epilogue: thread tid handles point `tid` of the tile ----------------------------------
+    // (the thread / lane ids are made opaque here: everything derived from them -- LDS addresses,
+    // the rank mask of the compaction -- is recomputed per tile instead of being kept live, and
+    // spilled, across the whole tile)
     bool survive = false;
     int64_t idx = -1;
+    int tid_e = tid, lane_e = lane;
+    asm volatile("" : "+v"(tid_e), "+v"(lane_e));
     {
-      const int64_t slot = tile * P + tid;
-      if (tid < P && slot < count) {
-        f32x4 r = red[tid];
+      const int64_t slot = tile * P + tid_e;
+      if (tid_e < P && slot < count) {
+        f32x4 r = red[tid_e];
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) {
-          const f32x4 q = red[ww * P + tid];
+          const f32x4 q = red[ww * P + tid_e];
           r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
         }
         const float f = r.x + bL;
@@ -657,10 +811,10 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       if (bal) {
         int base = 0;
         const int leader = __ffsll((long long)bal) - 1;
-        if (lane == leader) base = atomicAdd(a.count_out, __popcll(bal));
+        if (lane_e == leader) base = atomicAdd(a.count_out, __popcll(bal));
         base = __shfl(base, leader);
         if (survive) {
-          const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+          const int rank = __popcll(bal & ((1ull << lane_e) - 1ull));
           a.idx_out[base + rank] = (int32_t)idx;
         }
       }
@@ -671,8 +825,11 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   }
 }
 
-#include "siren_x3_pipe.h"
+#if X3_PIPE
+#include "siren_x3_pipe.h"      // (written against the split-bf16-only gemm_x3: build with -DX3_FWD_F16=0)
+#endif
 
+#if X3_PIPE
 template <int H, int NW, int NB, int MINB>
 int launch_x3p(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
   using S = X3Shape<H, NW, NB>;
@@ -688,6 +845,8 @@ int launch_x3p(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
   hipLaunchKernelGGL((k_siren_step_x3p<H, NW, NB, MINB>), dim3(blocks), dim3(64 * NW), S::kLds, s, a);
   return 0;
 }
+
+#endif
 
 template <int H, int NW, int NB, int MINB, bool FWD>
 int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
@@ -715,10 +874,8 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 #define X3_NW 8
 #endif
 #ifndef X3_MINB128
-#define X3_MINB128 2   // workgroups per CU for H = 128 (78 KiB LDS each)
-#endif
-#ifndef X3_PIPE
-#define X3_PIPE 0      // 1: software-pipelined kernel (siren_x3_pipe.h, NW == 4; measured: no gain); 0: plain stages
+#define X3_MINB128 1   // workgroups per CU for H = 128: 2 would fit (78 KiB LDS each) but the 256-VGPR budget then forces
+                       // scratch spills, and that build is not repeatable from run to run (tools/siren_repeat_check.py)
 #endif
 bool siren_x3_supported(int H, int L) { return (H == 256 || H == 128) && L >= 1 && L <= 8; }
 
@@ -729,8 +886,12 @@ int64_t siren_x3_stash_floats(int H, int L) {
 }
 
 void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s) {
-  const int64_t words = siren_packed_total(H, L) - x3_base(H, L);
+  const int64_t words = x16_base(H, L) - x3_base(H, L);
   hipLaunchKernelGGL(k_siren_pack_x3, dim3(iso_stream_grid(words, 256)), dim3(256), 0, s, raw, packed, H, L);
+  if (L > 0) {
+    hipLaunchKernelGGL(k_siren_wscale, dim3(L), dim3(256), 0, s, raw, packed, H, L);
+    hipLaunchKernelGGL(k_siren_pack_f16, dim3(iso_stream_grid((int64_t)L * H * H, 256)), dim3(256), 0, s, raw, packed, H, L);
+  }
 }
 
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
