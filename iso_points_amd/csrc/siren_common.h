@@ -54,13 +54,18 @@ __host__ __device__ inline int64_t x3_off_wl(int H, int L) { return x3_base(H, L
 __host__ __device__ inline int64_t x3_off_layer(int H, int L, int l) {
   return x3_base(H, L) + 5 * (int64_t)H + (int64_t)l * ((int64_t)H + 3 * (int64_t)H * H);
 }
-// ---- forward images in split fp16 (siren_x3.hip), appended to the split-bf16 section ------------
-//   [8 floats: 2^s_l, the power-of-two scale of hidden layer l][ per hidden layer: FW16 H*H ]   (float units)
-// FW16: uint4 index ((s*NTO + To)*2 + part)*64 + lane, 8 fp16 each (part 0/1 = high / low 11+11 bits
-// of 2^s_l * W), same (s, To, lane, element) -> (row, feature) map as FWx3.
+// ---- images in split fp16 (siren_x3.hip), appended to the split-bf16 section --------------------
+//   [24 floats: 0..7  2^s_l, the power-of-two scale of hidden layer l
+//               8..15 c_l = max over input features f of sum_k |W_l[k][f]|  (growth bound of the adjoint)
+//               16    max |W_head| ]
+//   [ per hidden layer: FW16 H*H ][ per hidden layer: BW16 H*H ]                       (float units)
+// FW16 / BW16: uint4 index ((s*NTO + To)*2 + part)*64 + lane, 8 fp16 each (part 0/1 = high / low
+// 11+11 bits of 2^s_l * W resp. its transpose), same (s, To, lane, element) map as FWx3 / BWx3.
+constexpr int kX16Header = 24;
 __host__ __device__ inline int64_t x16_base(int H, int L) { return x3_off_layer(H, L, L); }
-__host__ __device__ inline int64_t x16_off_layer(int H, int L, int l) { return x16_base(H, L) + 8 + (int64_t)l * H * H; }
-__host__ __device__ inline int64_t siren_packed_total(int H, int L) { return x16_off_layer(H, L, L); }
+__host__ __device__ inline int64_t x16_off_layer(int H, int L, int l) { return x16_base(H, L) + kX16Header + (int64_t)l * H * H; }
+__host__ __device__ inline int64_t x16_off_bw(int H, int L, int l) { return x16_off_layer(H, L, L) + (int64_t)l * H * H; }
+__host__ __device__ inline int64_t siren_packed_total(int H, int L) { return x16_off_bw(H, L, L); }
 
 // ---- siren_x3.hip entry points -----------------------------------------------------------
 bool siren_x3_supported(int H, int L);

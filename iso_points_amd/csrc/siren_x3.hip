@@ -65,6 +65,29 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifndef X3_FWD_F16
 #define X3_FWD_F16 1
 #endif
+// The reverse sweep on split fp16 as well (X3_BWD_F16, needs X3_FWD_F16): the adjoint has no
+// a-priori range, so every POINT carries its own power-of-two scale.  max_f |a_l[f][p]| is exchanged
+// between the waves through LDS (it rides on the barrier that already ends the stage), and the
+// scale of the next adjoint is taken from the rigorous bound
+//   |a_{l-1}[f][p]| <= omega * (max_f sum_k |W_l[k][f]|) * max_k |a_l[k][p]|
+// (column sums prepared at pack time), scaled to below 2^14: no overflow whatever the weights, and
+// since every element keeps 22 significant bits of its own, the ~20x slack of the bound only
+// moves the subnormal floor (elements below 2^-13 of the largest one) -- contributions at the f32
+// rounding level of the dot product.
+#ifndef X3_BWD_F16
+#define X3_BWD_F16 1
+#endif
+static_assert(!X3_BWD_F16 || X3_FWD_F16, "the split-fp16 reverse sweep shares the fp16 activation layout");
+
+// 2^E with bound * 2^E in [2^13, 2^14) (1 for a zero / non-finite bound)
+__device__ __forceinline__ float x3_scale_for(float bound) {
+  if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.0f;
+  int e;
+  (void)frexpf(bound, &e);
+  int k = 14 - e;
+  k = k > 120 ? 120 : (k < -120 ? -120 : k);
+  return ldexpf(1.0f, k);
+}
 constexpr float kActScale = 4096.0f;             // 2^12
 
 // exact three-way cut of two floats; element 0 in the low half of each word
@@ -102,11 +125,11 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mi
   }
 }
 
-// two-way fp16 cut of 2^12 * v (step-major as split8)
-__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo) {
+// two-way fp16 cut of scale * v (step-major as split8); scale is a power of two
+__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, float scale = kActScale) {
   f32x2 x[4], f[4];
   f16x2 h[4], l[4];
-  const f32x2 sc = {kActScale, kActScale};
+  const f32x2 sc = {scale, scale};
   ISO_X4(x[p] = ((f32x2){v[2 * p], v[2 * p + 1]}) * sc);
   ISO_X4(h[p] = __builtin_convertvector(x[p], f16x2));
   ISO_X4(f[p] = __builtin_convertvector(h[p], f32x2));
@@ -211,14 +234,43 @@ __global__ void k_siren_wscale(const float* __restrict__ raw, float* __restrict_
     }
     packed[x16_base(H, L) + l] = sc;
   }
+  __syncthreads();
+  // c_l = max_f sum_k |W_l[k][f]|: |(W_l^T a)[f]| <= c_l max|a|
+  float cs = 0.f;
+  for (int f = threadIdx.x; f < H; f += 256) {
+    float t = 0.f;
+    for (int k = 0; k < H; ++k) t += fabsf(Wl[(int64_t)k * H + f]);
+    cs = fmaxf(cs, t);
+  }
+  s_m[threadIdx.x] = cs;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_m[threadIdx.x] = fmaxf(s_m[threadIdx.x], s_m[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) packed[x16_base(H, L) + 8 + l] = s_m[0];
+  if (l == 0) {
+    __syncthreads();
+    const float* WLh = raw + (int64_t)H * 4 + (int64_t)L * (HH + H);
+    float mh = 0.f;
+    for (int f = threadIdx.x; f < H; f += 256) mh = fmaxf(mh, fabsf(WLh[f]));
+    s_m[threadIdx.x] = mh;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) s_m[threadIdx.x] = fmaxf(s_m[threadIdx.x], s_m[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) packed[x16_base(H, L) + 16] = s_m[0];
+  }
 }
 
 __global__ void k_siren_pack_f16(const float* __restrict__ raw, float* __restrict__ packed, int H, int L) {
   const int64_t HH = (int64_t)H * H;
   const int NTO = H / 32;
-  const int64_t total = (int64_t)L * HH;
+  const int64_t total = 2 * (int64_t)L * HH;       // forward images, then transposed ones
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-    const int l = (int)(o / HH);
+    const bool bwd = o >= (int64_t)L * HH;
+    const int l = (int)((o / HH) % L);
     const int64_t q = o % HH;
     const float* Wl = raw + (int64_t)H * 4 + (int64_t)l * (HH + H);
     const float sc = packed[x16_base(H, L) + l];
@@ -229,7 +281,10 @@ __global__ void k_siren_pack_f16(const float* __restrict__ raw, float* __restric
     const int fo = 32 * To + (lane & 31);
     f32x2 v;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) v[u] = Wl[(int64_t)fo * H + x3_feat(s, 8 * (lane >> 5) + 2 * d + u)] * sc;
+    for (int u = 0; u < 2; ++u) {
+      const int fi = x3_feat(s, 8 * (lane >> 5) + 2 * d + u);
+      v[u] = (bwd ? Wl[(int64_t)fi * H + fo] : Wl[(int64_t)fo * H + fi]) * sc;
+    }
     const f16x2 h = __builtin_convertvector(v, f16x2);
     const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), f16x2);
     reinterpret_cast<unsigned*>(packed + x16_off_layer(H, L, 0))[o] =
@@ -519,6 +574,25 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   };
   // accumulator scale of forward layer l: 2^12 (activations) * 2^s_l (weights)
   auto fwd_scale = [&](int l) { return X3_FWD_F16 ? kActScale * a.packed[x16_base(H, L) + l] : 1.0f; };
+  constexpr int BP = X3_BWD_F16 ? 2 : 3;      // operand parts of the reverse stages
+  auto rev_img = [&](int l) {
+    if constexpr (X3_BWD_F16)
+      return reinterpret_cast<const u32x4*>(a.packed + x16_off_bw(H, L, l)) + (TW * w * 2) * 64;
+    else
+      return bw_img(l);
+  };
+  // per-point maxima of the adjoint, exchanged between the waves: [2][P][NW] floats in the (otherwise
+  // idle until the final reduction) `red` region
+  float* redm = reinterpret_cast<float*>(red);
+  float bscale[NB];                           // scale carried by the adjoint that sits in LDS, per point of this lane
+  float amax[NB];                             // max |adjoint| over this lane's features, per point
+  auto put_amax = [&](int buf) {              // before the barrier that ends the stage
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const float m = __builtin_fmaxf(amax[n], __shfl_xor(amax[n], 32));
+      if (h == 0) redm[(buf * P + 32 * n + j) * NW + w] = m;
+    }
+  };
   u32x4 A[4][TW][3];                     // weight-fragment pipeline, carried across stages
   x3_prefetch_a<TW, NTO, FP>(A, fwd_img(0), 0, lane);
 
@@ -604,8 +678,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         gemm_x3<TW, NB, NTO, NS, kBias, IL, FP, FP>(img, lay, act + lane, acc, w, 0, A,
                                                     l + 1 < L ? fwd_img(l + 1) : fwd_img(0), 0, lane, zscale);
       } else {
-        gemm_x3<TW, NB, NTO, NS, kBias, IL, FP, 3>(img, lay, act + lane, acc, w, 0, A, bw_img(L - 1), 0, lane,
-                                                   zscale);
+        gemm_x3<TW, NB, NTO, NS, kBias, IL, FP, BP>(img, lay, act + lane, acc, w, 0, A, rev_img(L - 1), 0, lane,
+                                                    zscale);
       }
       X3_STAMP();
       __syncthreads();                      // both teams have read this team's K-half
@@ -613,7 +687,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       const bool top = (l == L - 1);
       f32x4* st_l = stash + (int64_t)(l + 1) * NG * 128;
       // one 8-value group: sin / w cos, head or stash, split, store as the next layer's B entry
-      auto act_group = [&](int k, int sl, const float (&zz)[8], float& fp) {
+      // scale of the adjoint seed (uniform): |W_head[f] * w cos| <= max|W_head| * w
+      const float seed_scale = X3_BWD_F16 ? x3_scale_for(a.packed[x16_base(H, L) + 16] * a.wh * 1.01f) : 1.0f;
+      if (top) {
+#pragma unroll
+        for (int n = 0; n < NB; ++n) { amax[n] = 0.f; bscale[n] = seed_scale; }
+      }
+      auto act_group = [&](int k, int n, int sl, const float (&zz)[8], float& fp) {
         float hv[8], sv[8];
         x3_sin_wcos8(w_in, a.wh, zz, hv, sv);
         if (top) {
@@ -626,6 +706,16 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
           if constexpr (FWD) return;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { hv[e] = wl0[e] * sv[e]; hv[4 + e] = wl1[e] * sv[4 + e]; }
+          if constexpr (X3_BWD_F16) {
+            float m = amax[n];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(hv[e]), __builtin_fabsf(hv[e + 1])));
+            amax[n] = m;
+            u32x4 p0, p1;
+            split8_f16(hv, p0, p1, seed_scale);
+            own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1;
+            return;
+          }
         } else {
 #ifndef X3_DBG_NOSTASH
           if constexpr (!FWD) {
@@ -664,7 +754,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
               float zz[8];
 #pragma unroll
               for (int e = 0; e < 8; ++e) zz[e] = acc[t][n][8 * p + e];
-              act_group((2 * t + p) * NB + n, 2 * t + p, zz, fpart[n]);
+              act_group((2 * t + p) * NB + n, n, 2 * t + p, zz, fpart[n]);
               __builtin_amdgcn_sched_barrier(0);     // one group at a time: bounds register pressure
             }
       } else {
@@ -693,10 +783,11 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
             float zz[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) zz[e] = z[n][e >> 2][e & 3];
-            act_group(sl * NB + n, sl, zz, fpart[n]);
+            act_group(sl * NB + n, n, sl, zz, fpart[n]);
           }
         }
       }
+      if constexpr (X3_BWD_F16 && !FWD) { if (top) put_amax(0); }
       X3_STAMP();
       __syncthreads();                      // the next layer's inputs are complete
       X3_STAMP();
@@ -705,8 +796,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     float gx[NB], gy[NB], gz[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) gx[n] = gy[n] = gz[n] = 0.f;
+    int mbuf = 0;                             // exchange buffer that holds max |a_l| of the adjoint in LDS
     for (int l = FWD ? -1 : L - 1; l >= 0; --l) {
-      const u32x4* img = bw_img(l);
+      const u32x4* img = rev_img(l);
       const f32x4* st_l = stash + (int64_t)l * NG * 128;
       f32x4 sv[NG][2];
       auto ld_stash = [&]() {
@@ -719,6 +811,17 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 #endif
         }
       };
+      // max_k |a_l[k][p]| of this lane's points (written before the barrier that ended the last stage)
+      float Mp[NB];
+      if constexpr (X3_BWD_F16) {
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          float m = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < NW; ++ww) m = __builtin_fmaxf(m, redm[(mbuf * P + 32 * n + j) * NW + ww]);
+          Mp[n] = m;
+        }
+      }
       // w cos(w z) of the layer below: requested before the GEMM when the registers allow it
       if constexpr (NG <= 6 && X3_EARLY_STASH) ld_stash();
       if constexpr (SKEW) {
@@ -729,14 +832,29 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         X3_STAMP();
         gemm_x3<TW, NB, NTO, KH, kAccumulate, IL>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0, lane);
       } else if (l > 0) {
-        gemm_x3<TW, NB, NTO, NS, kZero, IL, 3, 3>(img, nullptr, act + lane, acc, w, 0, A, bw_img(l - 1), 0, lane);
+        gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, BP>(img, nullptr, act + lane, acc, w, 0, A, rev_img(l - 1), 0, lane);
       } else {
-        gemm_x3<TW, NB, NTO, NS, kZero, IL, 3, FP>(img, nullptr, act + lane, acc, w, 0, A, fwd_img(0), 0, lane);
+        gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, FP>(img, nullptr, act + lane, acc, w, 0, A, fwd_img(0), 0, lane);
       }
       if constexpr (NG > 6 || !X3_EARLY_STASH) ld_stash();
       X3_STAMP();
       __syncthreads();
       X3_STAMP();
+      // split-fp16 reverse: the accumulators hold 2^s_l * bscale[p] * (W_l^T a_l); the scale comes out
+      // exactly, the next adjoint gets the scale its bound allows
+      float inv[NB], nscale[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) { inv[n] = 1.0f; nscale[n] = 1.0f; }
+      if constexpr (X3_BWD_F16) {
+        const float iw = 1.0f / a.packed[x16_base(H, L) + l];
+        const float grow = a.packed[x16_base(H, L) + 8 + l] * a.wh * 1.01f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          inv[n] = iw / bscale[n];
+          if (l > 0) nscale[n] = x3_scale_for(Mp[n] * grow);
+          amax[n] = 0.f;
+        }
+      }
 #pragma unroll
       for (int t = 0; t < TW; ++t)
 #pragma unroll
@@ -751,11 +869,24 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
             const int k = (2 * t + p) * NB + n;
             float av[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) av[e] = acc[t][n][8 * p + e] * sv[k][e >> 2][e & 3];
+            for (int e = 0; e < 8; ++e) {
+              if constexpr (X3_BWD_F16) av[e] = (acc[t][n][8 * p + e] * inv[n]) * sv[k][e >> 2][e & 3];
+              else av[e] = acc[t][n][8 * p + e] * sv[k][e >> 2][e & 3];
+            }
             if (l > 0) {
-              u32x4 p0, p1, p2;
-              split8(av, p0, p1, p2);
-              own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+              if constexpr (X3_BWD_F16) {
+                float m = amax[n];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(av[e]), __builtin_fabsf(av[e + 1])));
+                amax[n] = m;
+                u32x4 p0, p1;
+                split8_f16(av, p0, p1, nscale[n]);
+                own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1;
+              } else {
+                u32x4 p0, p1, p2;
+                split8(av, p0, p1, p2);
+                own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+              }
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
@@ -766,6 +897,14 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
             }
           }
         }
+      if constexpr (X3_BWD_F16) {
+        if (l > 0) {
+#pragma unroll
+          for (int n = 0; n < NB; ++n) bscale[n] = nscale[n];
+          put_amax(mbuf ^ 1);
+          mbuf ^= 1;
+        }
+      }
       X3_STAMP();
       __syncthreads();
       X3_STAMP();
@@ -890,7 +1029,7 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
   hipLaunchKernelGGL(k_siren_pack_x3, dim3(iso_stream_grid(words, 256)), dim3(256), 0, s, raw, packed, H, L);
   if (L > 0) {
     hipLaunchKernelGGL(k_siren_wscale, dim3(L), dim3(256), 0, s, raw, packed, H, L);
-    hipLaunchKernelGGL(k_siren_pack_f16, dim3(iso_stream_grid((int64_t)L * H * H, 256)), dim3(256), 0, s, raw, packed, H, L);
+    hipLaunchKernelGGL(k_siren_pack_f16, dim3(iso_stream_grid(2 * (int64_t)L * H * H, 256)), dim3(256), 0, s, raw, packed, H, L);
   }
 }
 
