@@ -35,9 +35,9 @@ HIDDEN, LAYERS = 256, 3
 FLOP_PER_EVAL = 2.0 * (2 * LAYERS * HIDDEN * HIDDEN + 2 * 3 * HIDDEN + 2 * HIDDEN)   # 0.79 MFLOP
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA
 PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md: dense bf16 MFMA (2.5 PF); 16x the f32 rate
-X3_PASSES = 4.5                    # 16-bit MFMA passes per f32 product in the split-operand mode (siren_x3.hip):
-                                   # 3 (two-way fp16 cut) in the forward sweep, 6 (three-way bf16 cut) in the reverse
-                                   # sweep, each half of the algorithmic flops; fp16 and bf16 MFMA peaks are equal
+X3_PASSES = 3                      # fp16 MFMA passes per f32 product in the split-operand mode (siren_x3.hip): both
+                                   # operands cut into two fp16 numbers, W_l x_h + W_h x_l + W_h x_h; the fp16 and bf16
+                                   # MFMA peaks are equal
 PEAK_HBM_TBS = 8.0
 
 
@@ -270,9 +270,8 @@ def main():
     from iso_points_amd import _lib
     x3 = _lib.load().iso_siren_get_gemm_mode() == 1
     # roofline peak for ALGORITHMIC (f32-equivalent) flops: the f32 MFMA peak for the f32 kernel;
-    # for the split-operand kernel an algorithmic flop costs 3 (forward) or 6 (reverse) 16-bit MFMA flops,
-    # 4.5 on average, so the ceiling is the 16-bit dense peak / 4.5 = 559 TFLOP/s (executed 16-bit
-    # flops = 4.5 x achieved, reported alongside).
+    # for the split-operand kernel an algorithmic flop costs 3 fp16 MFMA flops, so the ceiling is the
+    # fp16 dense peak / 3 = 839 TFLOP/s (executed fp16 flops = 3 x achieved, reported alongside).
     peak = PEAK_BF16_MFMA_TFLOPS / X3_PASSES if x3 else PEAK_F32_MFMA_TFLOPS
     if rank == 0:
         out = {
@@ -284,8 +283,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",            # 1 M points in total for every N (BASELINE.json: the same cycle at 1 and 8 GPUs)
             "vs_baseline": None,
-            "dtype": "f32 (hidden-layer products from split operands on the 16-bit matrix cores, f32 accumulate: "
-                     "forward 2 fp16 parts / 3 MFMA passes, reverse 3 bf16 parts / 6 passes)" if x3 else "f32",
+            "dtype": "f32 (hidden-layer products from split operands on the fp16 matrix cores, f32 accumulate: every "
+                     "f32 operand = 2 fp16 parts under an exact power-of-two scale, 3 MFMA passes)" if x3 else "f32",
             "data": "synthetic",
             "config": {"workload": "configs[2]: 1M points project(T=10)+resample(FRNN K=9, repulsion, T=3) + EWA "
                                    "splat fwd/bwd 512x512x4 views, K=8",
@@ -295,7 +294,7 @@ def main():
                        "points (per-point stages) and tile-row bands (per-pixel stages) sharded x%d, RCCL "
                        "all-gather/all-reduce" % world},
             "roofline": {"bound": "mfma",
-                         "kernel": ("k_siren_step_x3<256,8,3,1,false> (fused SIREN SDF+grad Newton step, split-fp16 / split-bf16 MFMA)" if x3
+                         "kernel": ("k_siren_step_x3<256,8,3,1,false> (fused SIREN SDF+grad Newton step, split-fp16 MFMA)" if x3
                                     else "k_siren_step<16> (fused SIREN SDF+grad Newton step, f32 MFMA)"),
                          "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),
@@ -307,8 +306,8 @@ def main():
                          "traffic_note": "bytes/launch, PMC (2*FETCH_SIZE+WRITE_SIZE) from profiles/; algorithmic point "
                                          "I/O is %.1f MB/launch -- the rest is the w*cos stash round trip"
                                          % (evals_per_step / max(launches_per_step, 1) * 37 / 1e6),
-                         "peak_note": ("16-bit dense MFMA peak 2516.6 / 4.5 passes per f32 product (3 forward, 6 "
-                                       "reverse); executed 16-bit rate = %.1f TFLOP/s" % (ach * X3_PASSES)) if x3
+                         "peak_note": ("fp16 dense MFMA peak 2516.6 / 3 passes per f32 product; executed fp16 "
+                                       "rate = %.1f TFLOP/s" % (ach * X3_PASSES)) if x3
                          else "f32 dense MFMA peak",
                          "launches_per_step": launches_per_step,
                          "avg_launch_ms": round(siren_ms / max(siren_launches, 1), 4),

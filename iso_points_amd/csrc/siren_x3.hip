@@ -78,6 +78,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define X3_BWD_F16 1
 #endif
 static_assert(!X3_BWD_F16 || X3_FWD_F16, "the split-fp16 reverse sweep shares the fp16 activation layout");
+// parts per (K-step, point tile) entry of the activation buffer in LDS: two when no stage uses the
+// three-way bf16 cut (a third less LDS: room for four point tiles per workgroup)
+constexpr int kAP = (X3_FWD_F16 && X3_BWD_F16) ? 2 : 3;
 
 // 2^E with bound * 2^E in [2^13, 2^14) (1 for a zero / non-finite bound)
 __device__ __forceinline__ float x3_scale_for(float bound) {
@@ -376,11 +379,11 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
   }
   u32x4 B[2][NB][3];
   auto ldB = [&](u32x4 (&Br)[NB][3], int s) {
-    const u32x4* p = actl + s * (NB * 3 * 64);
+    const u32x4* p = actl + s * (NB * kAP * 64);
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
-      for (int c = 0; c < PARTS; ++c) Br[n][c] = p[(n * 3 + c) * 64];
+      for (int c = 0; c < PARTS; ++c) Br[n][c] = p[(n * kAP + c) * 64];
   };
   auto mma = [&](const u32x4 (&Ar)[TW][3], const u32x4 (&Br)[NB][3]) {
 #ifdef X3_DBG_NOMMA
@@ -489,7 +492,7 @@ struct X3Shape {
   static constexpr int SL = 2 * TW;        // K-steps of the next layer produced by one wave
   static constexpr int NG = SL * NB;       // 8-value groups per lane
   static constexpr int P = 32 * NB;        // points per workgroup
-  static constexpr size_t kActBytes = (size_t)NS * NB * 3 * 1024;
+  static constexpr size_t kActBytes = (size_t)NS * NB * kAP * 1024;
   static constexpr size_t kLds = kActBytes + (size_t)NW * P * 16;
   static constexpr int64_t kStashPerWg(int L) { return (int64_t)NW * (L + 1) * NG * 512; }  // floats
   static_assert(NTO % NW == 0 && TW >= 1, "features must split evenly over the waves");
@@ -520,8 +523,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   // stash bases) lives in SGPRs; loads then use the scalar-base + lane-offset form
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, h = lane >> 5, j = lane & 31;
-  u32x4* own = act + (size_t)(SL * w) * NB * 3 * 64 + lane;      // this wave's K-steps (+lane)
-  u32x4* park = own + (size_t)NG * 64;                           // last NG*2 KiB of the region
+  u32x4* own = act + (size_t)(SL * w) * NB * kAP * 64 + lane;    // this wave's K-steps (+lane)
+  u32x4* park = own + (size_t)(kAP - 2) * NG * 64;               // last NG*2 KiB of the region
   // Two teams (NW == 8): waves 0..NW/2-1 own the lower half of the features (K-steps 0..NS/2-1 of
   // the next layer), the others the upper half, one wave of each team per SIMD.  Team 1 runs the
   // same sequence of stages ONE STAGE BEHIND team 0 (it takes one extra barrier first, team 0
@@ -637,11 +640,11 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         if constexpr (X3_FWD_F16) {
           u32x4 p0, p1;
           split8_f16(hv, p0, p1);
-          own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1;
+          own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
         } else {
           u32x4 p0, p1, p2;
           split8(hv, p0, p1, p2);
-          own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+          own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1; own[(k * kAP + 2) * 64] = p2;
         }
 #ifndef X3_DBG_NOSTASH
         if constexpr (!FWD) {
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
             amax[n] = m;
             u32x4 p0, p1;
             split8_f16(hv, p0, p1, seed_scale);
-            own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1;
+            own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
             return;
           }
         } else {
@@ -727,11 +730,11 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         if (X3_FWD_F16 && !top) {               // input of the next forward layer
           u32x4 p0, p1;
           split8_f16(hv, p0, p1);
-          own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1;
+          own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
         } else {                                // seed of the reverse sweep
           u32x4 p0, p1, p2;
           split8(hv, p0, p1, p2);
-          own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+          own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1; own[(k * kAP + 2) * 64] = p2;
         }
       };
 #ifndef X3_DIRECT_ACT
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 #define X3_EARLY_STASH 0
 #endif
 #ifndef X3_DIRECT_NG
-#define X3_DIRECT_NG 6
+#define X3_DIRECT_NG 8
 #endif
       if constexpr (NG <= X3_DIRECT_NG && X3_DIRECT_ACT) {
         // few enough values per lane to walk the accumulators with static indices
@@ -881,11 +884,11 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
                 amax[n] = m;
                 u32x4 p0, p1;
                 split8_f16(av, p0, p1, nscale[n]);
-                own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1;
+                own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
               } else {
                 u32x4 p0, p1, p2;
                 split8(av, p0, p1, p2);
-                own[(k * 3 + 0) * 64] = p0; own[(k * 3 + 1) * 64] = p1; own[(k * 3 + 2) * 64] = p2;
+                own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1; own[(k * kAP + 2) * 64] = p2;
               }
             } else {
 #pragma unroll
@@ -1012,6 +1015,10 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 #ifndef X3_NW
 #define X3_NW 8
 #endif
+#ifndef X3_NB256
+#define X3_NB256 3   // point tiles of 32 per workgroup at H = 256 (4 would fit LDS with the two-part layout, but needs
+                     // 64 + 64 + 32 accumulator / operand registers: 101 spilled VGPRs, 3.63 instead of 3.26 ms)
+#endif
 #ifndef X3_MINB128
 #define X3_MINB128 1   // workgroups per CU for H = 128: 2 would fit (78 KiB LDS each) but the 256-VGPR budget then forces
                        // scratch spills, and that build is not repeatable from run to run (tools/siren_repeat_check.py)
@@ -1019,7 +1026,7 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 bool siren_x3_supported(int H, int L) { return (H == 256 || H == 128) && L >= 1 && L <= 8; }
 
 int64_t siren_x3_stash_floats(int H, int L) {
-  if (H == 256) return 256 * X3Shape<256, X3_NW, 3>::kStashPerWg(L);
+  if (H == 256) return 256 * X3Shape<256, X3_NW, X3_NB256>::kStashPerWg(L);
   if (H == 128) return 256 * X3_MINB128 * X3Shape<128, 4, 3>::kStashPerWg(L);
   return 0;
 }
@@ -1038,10 +1045,10 @@ int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
   if (H == 256) return launch_x3p<256, 4, 3, 1>(a, n_upper, s);
 #else
   if (a.fwd_only) {
-    if (H == 256) return launch_x3<256, X3_NW, 3, 1, true>(a, n_upper, s);
+    if (H == 256) return launch_x3<256, X3_NW, X3_NB256, 1, true>(a, n_upper, s);
     if (H == 128) return launch_x3<128, 4, 3, X3_MINB128, true>(a, n_upper, s);
   }
-  if (H == 256) return launch_x3<256, X3_NW, 3, 1, false>(a, n_upper, s);
+  if (H == 256) return launch_x3<256, X3_NW, X3_NB256, 1, false>(a, n_upper, s);
 #endif
   if (H == 128) return launch_x3<128, 4, 3, X3_MINB128, false>(a, n_upper, s);
   return -1;
