@@ -66,10 +66,12 @@ int64_t iso_siren_packed_floats(int hidden, int n_hidden);
 int iso_siren_pack_weights(const float* raw, float* packed, int hidden,
                            int n_hidden, void* stream);
 /* How the H x H products of the hidden layers are formed (process-wide switch):
- *   1 (default)  bf16 matrix cores at f32 accuracy: every f32 operand is cut exactly into
- *                three bf16 numbers and six of the nine partial products (all terms >= 2^-16
- *                relative) are accumulated in f32 -- same error level as an f32 GEMM (the
- *                accumulation dominates), 2.7x the MFMA rate.  H in {128,256}, n_hidden >= 1.
+ *   1 (default)  fp16 matrix cores at f32 accuracy: every f32 operand is cut into two fp16
+ *                numbers (11 + 11 significant bits) under an exact power-of-two scale -- per layer
+ *                for the weights, 2^12 for the activations, per point for the adjoint of the reverse
+ *                sweep -- and three partial products are accumulated in f32: same error level as an
+ *                f32 GEMM (the accumulation dominates), 5.3x the MFMA rate.  H in {128,256},
+ *                n_hidden >= 1.
  *   0            f32 matrix cores (v_mfma_f32_16x16x4_f32; bitwise an fmaf chain).
  * Shapes mode 1 does not cover run in mode 0.  ISO_SIREN_GEMM=f32 in the environment selects 0. */
 int iso_siren_set_gemm_mode(int mode);
