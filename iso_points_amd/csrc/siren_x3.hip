@@ -1015,6 +1015,9 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 #ifndef X3_NW
 #define X3_NW 8
 #endif
+#ifndef X3_MINB256
+#define X3_MINB256 1   // workgroups per CU at H = 256
+#endif
 #ifndef X3_NB256
 #define X3_NB256 3   // point tiles of 32 per workgroup at H = 256 (4 would fit LDS with the two-part layout, but needs
                      // 64 + 64 + 32 accumulator / operand registers: 101 spilled VGPRs, 3.63 instead of 3.26 ms)
@@ -1026,7 +1029,7 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 bool siren_x3_supported(int H, int L) { return (H == 256 || H == 128) && L >= 1 && L <= 8; }
 
 int64_t siren_x3_stash_floats(int H, int L) {
-  if (H == 256) return 256 * X3Shape<256, X3_NW, X3_NB256>::kStashPerWg(L);
+  if (H == 256) return 256 * X3_MINB256 * X3Shape<256, X3_NW, X3_NB256>::kStashPerWg(L);
   if (H == 128) return 256 * X3_MINB128 * X3Shape<128, 4, 3>::kStashPerWg(L);
   return 0;
 }
@@ -1045,10 +1048,10 @@ int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
   if (H == 256) return launch_x3p<256, 4, 3, 1>(a, n_upper, s);
 #else
   if (a.fwd_only) {
-    if (H == 256) return launch_x3<256, X3_NW, X3_NB256, 1, true>(a, n_upper, s);
+    if (H == 256) return launch_x3<256, X3_NW, X3_NB256, X3_MINB256, true>(a, n_upper, s);
     if (H == 128) return launch_x3<128, 4, 3, X3_MINB128, true>(a, n_upper, s);
   }
-  if (H == 256) return launch_x3<256, X3_NW, X3_NB256, 1, false>(a, n_upper, s);
+  if (H == 256) return launch_x3<256, X3_NW, X3_NB256, X3_MINB256, false>(a, n_upper, s);
 #endif
   if (H == 128) return launch_x3<128, 4, 3, X3_MINB128, false>(a, n_upper, s);
   return -1;
