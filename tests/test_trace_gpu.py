@@ -34,14 +34,14 @@ def test_trace_sphere_golden(dev):
     assert out["levelset_points"].shape == g["ray0"].shape and out["mask"].dtype == torch.bool
 
 
-@pytest.mark.parametrize("mode", ["3xbf16", "f32"])
+@pytest.mark.parametrize("mode", ["split16", "f32"])
 def test_trace_siren_golden(dev, mode):
     from iso_points_amd import _lib
     from iso_points_amd.levelset_sampling import SphereTracing
     g = load("trace_siren.npz")
     m = siren_from(g).to(dev)
     old = _lib.load().iso_siren_get_gemm_mode()
-    _lib.call("iso_siren_set_gemm_mode", 1 if mode == "3xbf16" else 0)
+    _lib.call("iso_siren_set_gemm_mode", 1 if mode == "split16" else 0)
     try:
         out = SphereTracing(proj_max_iters=10).project_points(g["ray0"].to(dev), g["dirs"].to(dev), m)
     finally:
