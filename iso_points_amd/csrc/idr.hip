@@ -20,6 +20,7 @@
 //   * backward of layer 0 (H -> D0) and the encoding Jacobian run on the VALU;
 //   * tanh' is a per-point scalar: the adjoint seed is W_n * s_{n-1} and the final gradient is
 //     multiplied by 1 - tanh^2.
+#include <stdlib.h>
 #include "iso_common.h"
 #include "iso_newton.h"
 #include "mlp_common.h"
@@ -30,41 +31,9 @@
 #define IDR_GEMM gemm_pass_pipe
 #endif
 
+#include "idr_common.h"
+
 namespace {
-
-constexpr int kD0Pad = 64;          // padded encoding width (D0 = 3 + 6F <= 63)
-constexpr int kW0Row = 64;          // floats per feature row of the VALU backward image
-
-struct IdrShape {
-  int H, n_layers, skip, F, D0;     // skip < 0: no skip connection
-};
-
-// packed buffer (floats):
-//   [b0 H][FW0 (kD0Pad/16)*NT*256][W0v 4*(H/4)*kW0Row]
-//   per l = 1..n_layers-1: [b_l H][FW_l H*H][BW_l H*H]
-//   [WLimg H][b_last, pad 4]
-__host__ __device__ inline int64_t idr_off_b0() { return 0; }
-__host__ __device__ inline int64_t idr_off_fw0(int H) { return H; }
-__host__ __device__ inline int64_t idr_off_w0v(int H) { return H + (int64_t)(kD0Pad / 16) * (H / 16) * 256; }
-__host__ __device__ inline int64_t idr_off_layer(int H, int l) {   // l >= 1
-  return idr_off_w0v(H) + (int64_t)H * kW0Row + (int64_t)(l - 1) * ((int64_t)H + 2 * (int64_t)H * H);
-}
-__host__ __device__ inline int64_t idr_off_wl(int H, int n_layers) { return idr_off_layer(H, n_layers); }
-__host__ __device__ inline int64_t idr_total(int H, int n_layers) { return idr_off_wl(H, n_layers) + H + 4; }
-
-// raw layout (effective weights, torch row-major [out][in]):
-//   for l = 0..n_layers: W_l[out_l*in_l] b_l[out_l];
-//   in_0 = D0, out_l = H (H - D0 for l == skip-1), last layer in = H, out = 1
-__host__ __device__ inline int idr_out_dim(const IdrShape& s, int l) {
-  if (l == s.n_layers) return 1;
-  return (s.skip >= 1 && l == s.skip - 1) ? s.H - s.D0 : s.H;
-}
-__host__ __device__ inline int idr_in_dim(const IdrShape& s, int l) { return l == 0 ? s.D0 : s.H; }
-__host__ __device__ inline int64_t idr_raw_off(const IdrShape& s, int l) {
-  int64_t o = 0;
-  for (int k = 0; k < l; ++k) o += (int64_t)idr_out_dim(s, k) * idr_in_dim(s, k) + idr_out_dim(s, k);
-  return o;
-}
 
 __global__ void k_idr_pack(const float* __restrict__ raw, float* __restrict__ packed, IdrShape s) {
   const int H = s.H, NT = H / 16;
@@ -122,50 +91,6 @@ __global__ void k_idr_pack(const float* __restrict__ raw, float* __restrict__ pa
   }
 }
 
-// positional-encoding feature `f` (< D0) of a point, its coordinate and derivative
-__device__ __forceinline__ void posenc(int f, float x0, float x1, float x2, float& val, int& coord,
-                                       float& dval) {
-  if (f < 3) {
-    coord = f;
-    val = f == 0 ? x0 : (f == 1 ? x1 : x2);
-    dval = 1.0f;
-    return;
-  }
-  const int m = f - 3, k = m / 6, r = m % 6;
-  coord = r % 3;
-  const float xc = coord == 0 ? x0 : (coord == 1 ? x1 : x2);
-  const float fr = (float)(1 << k);               // 2^k exactly (get_embedder: 2**linspace(0, F-1, F))
-  float sn, cs;
-  iso_sincos(xc * fr, sn, cs);
-  if (r < 3) { val = sn; dval = fr * cs; }
-  else { val = cs; dval = -fr * sn; }
-}
-
-__device__ __forceinline__ void softplus_b(float z, float beta, float& y, float& dy) {
-  // torch.nn.Softplus(beta, threshold=20) and its derivative (sigmoid)
-#ifdef IDR_DBG_NOACT      // timing experiment: results wrong by construction
-  y = z; dy = beta; return;
-#endif
-  const float t = z * beta;
-  if (t > 20.0f) { y = z; dy = 1.0f; return; }
-  const float e = expf(t);
-  y = log1pf(e) / beta;
-  dy = e / (e + 1.0f);
-}
-
-struct IdrArgs {
-  float* pts; float* normals; uint8_t* mask; float* sdf_out; float* grad_out;
-  const int32_t* idx_in; const int32_t* count_in; int32_t* idx_out; int32_t* count_out;
-  const float* packed; float* stash;
-  int64_t n;
-  IdrShape s;
-  float beta, tol;
-  int do_move, eval_only;
-  // sphere tracing (iso_trace_idr): unit ray directions (n,3); null = Newton / evaluation
-  const float* dirs = nullptr;
-  float alpha = 1.f, bound = 0.f, tol_valid = 0.f;
-  int fwd_only = 0;          // 1: the gradient is not needed
-};
 
 template <int NT>
 __global__ __launch_bounds__(256, 1) void k_idr_step(IdrArgs a) {
@@ -632,7 +557,11 @@ __global__ __launch_bounds__(256, 1) void k_idr_step_fs(IdrArgs a) {
 
 constexpr int kIdrBlocks = 256;   // one 160 KiB workgroup per CU at H = 512
 
-inline int64_t idr_stash_floats(int H, int n_layers) { return (int64_t)kIdrBlocks * 4 * n_layers * H * 16; }
+inline int64_t idr_stash_floats(int H, int n_layers) {
+  const int64_t f32k = (int64_t)kIdrBlocks * 4 * n_layers * H * 16;
+  const int64_t x16 = idr_x16_stash_floats(H, n_layers);
+  return f32k > x16 ? f32k : x16;
+}
 
 template <int NT, bool FWD>
 void idr_launch_fs(const IdrArgs& a, int blocks, hipStream_t st) {
@@ -695,7 +624,21 @@ extern "C" int64_t iso_idr_raw_floats(int hidden, int n_layers, int skip_layer, 
   IdrShape s = mk_shape(hidden, n_layers, skip_layer, n_freq);
   return idr_raw_off(s, n_layers + 1);
 }
-extern "C" int64_t iso_idr_packed_floats(int hidden, int n_layers) { return idr_total(hidden, n_layers); }
+// The split-fp16 kernel (idr_x16.hip) serves H = 256 / 512 with encodings of <= 39 slots; ISO_IDR_GEMM=f32 in
+// the environment keeps the f32-MFMA kernels of this file for every shape.
+static bool idr_use_x16(int H, int n_layers, int skip, int F) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("ISO_IDR_GEMM");
+    forced = (e && e[0] == 'f') ? 1 : 0;
+  }
+  return !forced && idr_x16_supported(H, n_layers, skip, F);
+}
+
+// (the packed buffer always has room for the split-fp16 images: its size may not depend on the environment)
+extern "C" int64_t iso_idr_packed_floats(int hidden, int n_layers) {
+  return idr_total(hidden, n_layers) + idr_x16_floats(hidden, n_layers);
+}
 
 extern "C" int iso_idr_pack_weights(const float* raw, float* packed, int hidden, int n_layers,
                                     int skip_layer, int n_freq, void* stream) {
@@ -705,6 +648,8 @@ extern "C" int iso_idr_pack_weights(const float* raw, float* packed, int hidden,
   IdrShape s = mk_shape(hidden, n_layers, skip_layer, n_freq);
   hipLaunchKernelGGL(k_idr_pack, dim3(iso_stream_grid(idr_total(hidden, n_layers), 256)), dim3(256), 0,
                      (hipStream_t)stream, raw, packed, s);
+  if (idr_x16_supported(hidden, n_layers, skip_layer, n_freq))
+    idr_x16_pack(raw, packed, hidden, n_layers, skip_layer, n_freq, (hipStream_t)stream);
   ISO_CHECK_LAUNCH("iso_idr_pack_weights");
   return ISO_OK;
 }
@@ -736,6 +681,8 @@ static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint
   int32_t* counts = idxB + n;
   int64_t tiles = (n + 63) / 64;
   int blocks = (int)(tiles < kIdrBlocks ? tiles : kIdrBlocks);
+  const bool x16 = idr_use_x16(hidden, n_layers, skip_layer, n_freq);
+  auto run = [&](const IdrArgs& args) { return x16 ? idr_x16_launch(&args, n, st) : idr_dispatch(args, blocks, st); };
   IdrArgs a;
   a.packed = packed; a.stash = stash; a.n = n; a.s = mk_shape(hidden, n_layers, skip_layer, n_freq);
   a.beta = beta; a.tol = tol;
@@ -745,7 +692,7 @@ static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint
     a.idx_in = nullptr; a.count_in = nullptr; a.idx_out = nullptr; a.count_out = nullptr;
     a.do_move = 0; a.eval_only = 1;
     a.fwd_only = grad_out ? 0 : 1;
-    ISO_REQUIRE(idr_dispatch(a, blocks, st) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size", who);
+    ISO_REQUIRE(run(a) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size", who);
   } else {
     if (pts_out != pts_in) (void)hipMemcpyAsync(pts_out, pts_in, (size_t)n * 12, hipMemcpyDeviceToDevice, st);
     hipLaunchKernelGGL(k_idr_zero, dim3(1), dim3(64), 0, st, counts, 64);
@@ -761,7 +708,7 @@ static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint
       a.count_out = counts + it + 1;
       a.do_move = (it < max_iters) ? 1 : 0;
       a.eval_only = 0;
-      ISO_REQUIRE(idr_dispatch(a, blocks, st) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size", who);
+      ISO_REQUIRE(run(a) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size", who);
     }
   }
   ISO_CHECK_LAUNCH(who);
