@@ -60,16 +60,51 @@ __device__ __forceinline__ void posenc(int f, float x0, float x1, float x2, floa
   else { val = cs; dval = -fr * sn; }
 }
 
+// softplus(beta, threshold 20) and its derivative (the sigmoid) in ~40 issue slots instead of the
+// ~150 of expf + log1pf + two IEEE divisions (the activation is what bounds the split-fp16 kernel:
+// PMC, VALU busy 55 % vs MFMA 24 %):
+//   u = exp(-|t|)            two-term log2(e) reduction + v_exp_f32 on [-1/2, 1/2] + exact 2^n
+//   softplus(t) = max(t, 0) + log1p(u),   log1p(u) = ln(w) * u / (w - 1),  w = fl(1 + u)   (Kahan)
+//   sigmoid(t)  = t >= 0 ? 1/w : u/w      reciprocals by v_rcp_f32 + one Newton step
+// every piece is good to 1-2 ulp; -DISO_SOFTPLUS_LIBM restores the libm form.
+__device__ __forceinline__ float iso_rcp_nr(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+
 __device__ __forceinline__ void softplus_b(float z, float beta, float& y, float& dy) {
   // torch.nn.Softplus(beta, threshold=20) and its derivative (sigmoid)
 #ifdef IDR_DBG_NOACT      // timing experiment: results wrong by construction
   y = z; dy = beta; return;
 #endif
+#ifdef ISO_SOFTPLUS_LIBM
   const float t = z * beta;
   if (t > 20.0f) { y = z; dy = 1.0f; return; }
   const float e = expf(t);
   y = log1pf(e) / beta;
   dy = e / (e + 1.0f);
+#else
+  const float t = z * beta;
+  const float at = __builtin_fabsf(t);
+  const float L2E_hi = 1.44269502162933349609375f, L2E_lo = 1.925963033500011e-08f;
+  const float n = __builtin_rintf(-at * L2E_hi);
+  float f = __builtin_fmaf(-at, L2E_hi, -n);
+  f = __builtin_fmaf(-at, L2E_lo, f);
+  const float u = __builtin_amdgcn_exp2f(f) * __builtin_amdgcn_exp2f(__builtin_fmaxf(n, -126.0f));   // exp(-|t|) in (0, 1]
+  const float w = 1.0f + u;
+  const float d = w - 1.0f;                                        // exact
+  const float rw = iso_rcp_nr(w);
+  const float lnw = __builtin_amdgcn_logf(w) * 0.693147180559945309f;
+  const float rd = __builtin_amdgcn_rcpf(d);
+  float q = u * rd;                                                // u / (w - 1), one Newton step
+  q = __builtin_fmaf(__builtin_fmaf(-q, d, u), rd, q);
+  const float l1p = d == 0.0f ? u : lnw * q;
+  const float sp = (__builtin_fmaxf(t, 0.0f) + l1p) / beta;
+  const float sg = t >= 0.0f ? rw : u * rw;
+  const bool lin = t > 20.0f;
+  y = lin ? z : sp;
+  dy = lin ? 1.0f : sg;
+#endif
 }
 
 struct IdrArgs {

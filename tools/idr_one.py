@@ -1,0 +1,11 @@
+import os, sys, torch
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+from oracle import iso_oracle as O
+from iso_points_amd.sdf_models import idr_sdf_and_grad
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+m = O.IdrSDF(hidden_size=512, n_layers=8, skip_in=(4,), num_frequencies=6).to(dev)
+pts = (torch.nn.functional.normalize(torch.randn(300000, 3), dim=-1) * 0.6).to(dev)
+for _ in range(4):
+    idr_sdf_and_grad(m, pts)
+torch.cuda.synchronize()
