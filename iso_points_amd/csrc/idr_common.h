@@ -85,6 +85,7 @@ __device__ __forceinline__ void softplus_b(float z, float beta, float& y, float&
   dy = e / (e + 1.0f);
 #else
   const float t = z * beta;
+  const float inv_beta = 1.0f / beta;                             // beta is uniform: one division per wave, hoisted
   const float at = __builtin_fabsf(t);
   const float L2E_hi = 1.44269502162933349609375f, L2E_lo = 1.925963033500011e-08f;
   const float n = __builtin_rintf(-at * L2E_hi);
@@ -99,7 +100,7 @@ __device__ __forceinline__ void softplus_b(float z, float beta, float& y, float&
   float q = u * rd;                                                // u / (w - 1), one Newton step
   q = __builtin_fmaf(__builtin_fmaf(-q, d, u), rd, q);
   const float l1p = d == 0.0f ? u : lnw * q;
-  const float sp = (__builtin_fmaxf(t, 0.0f) + l1p) / beta;
+  const float sp = (__builtin_fmaxf(t, 0.0f) + l1p) * inv_beta;
   const float sg = t >= 0.0f ? rw : u * rw;
   const bool lin = t > 20.0f;
   y = lin ? z : sp;

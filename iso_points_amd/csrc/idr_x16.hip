@@ -170,6 +170,14 @@ struct I16Shape {
   static_assert(kLds <= 160 * 1024, "LDS budget");
 };
 
+// -DI16_DBG_TIMES (timing experiment): waves 0 and 4 of workgroup 0 stamp the shader clock at every stage
+// boundary of their second tile into the tail of the stash workspace (tools/idr_stage_times.py).
+#ifdef I16_DBG_TIMES
+#define I16_STAMP() do { if (dbg_on && lane == 0 && dbg_i < 128) dbg[w * 128 + dbg_i] = (long long)__builtin_amdgcn_s_memtime(); ++dbg_i; } while (0)
+#else
+#define I16_STAMP() do {} while (0)
+#endif
+
 template <int H, int NB, bool FWD>
 __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
   using S = I16Shape<H, NB>;
@@ -224,7 +232,15 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
 
   const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
   const int64_t n_tiles = (count + P - 1) / P;
+#ifdef I16_DBG_TIMES
+  long long* dbg = reinterpret_cast<long long*>(a.stash + (int64_t)gridDim.x * S::kStashPerWg(nL)) - NW * 128;
+#endif
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#ifdef I16_DBG_TIMES
+    const bool dbg_on = blockIdx.x == 0 && tile == (int64_t)gridDim.x;
+    int dbg_i = 0;
+#endif
+    I16_STAMP();
     // ---- encoding table: thread (k-row, point) pairs, value and d/dx_c -------------------------
     if (tid < (512 / P) * P) {
       const int pt = tid % P;
@@ -273,6 +289,7 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
     }
     __syncthreads();
 
+    I16_STAMP();
     f32x16 acc[TW][NB];
     float fsum[NB];
 #pragma unroll
@@ -295,7 +312,9 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
       } else {
         gemm_x3<TW, NB, NTO, NS, kBias, true, 2, 2>(img, bias, act + lane, acc, w, 0, A, rev_img(nL - 1), 0, lane, 1.0f, zs);
       }
+      I16_STAMP();
       __syncthreads();                                   // every wave has read the activations
+      I16_STAMP();
       // bound of this layer's output per point -> scale of the next operand
       const bool narrow = (s.skip >= 1 && l == s.skip - 1);
       float nscale[NB], iz[NB];
@@ -353,7 +372,9 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
 #pragma unroll
       for (int n = 0; n < NB; ++n) bscale[n] = nscale[n];
       if (!(top && FWD)) { mbuf ^= 1; put_amax(mbuf); }
+      I16_STAMP();
       __syncthreads();                                   // the next stage's inputs (and maxima) are complete
+      I16_STAMP();
       if (!(top && FWD)) get_max(mbuf, Mp);
     }
     // ---- reverse (the seed W_n * sigma'_top is in LDS) -----------------------------------------
@@ -368,7 +389,9 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
       f32x4 sv[NG][2];
 #pragma unroll
       for (int k = 0; k < NG; ++k) { sv[k][0] = st_p[(k * 2) * 64 + lane]; sv[k][1] = st_p[(k * 2 + 1) * 64 + lane]; }
+      I16_STAMP();
       __syncthreads();
+      I16_STAMP();
       const bool cat = (l == s.skip);
       float inv[NB], nscale[NB];
       const float iw = 1.0f / hdr[l];
@@ -421,12 +444,28 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
         mbuf ^= 1;
         put_amax(mbuf);
       }
+      I16_STAMP();
       __syncthreads();
+      I16_STAMP();
       if (l > 1) get_max(mbuf, Mp);
     }
     // ---- layer 0 reverse on the VALU: acc holds a0 = adjoint of z0 for this lane's features -------
+#ifdef I16_DBG_NOL0REV
+    if (false) {
+#else
     if constexpr (!FWD) {
-      for (int k = 0; k < s.D0; ++k) {
+#endif
+      // weight rows of k+1 are requested while row k is multiplied (39 dependent L2 round trips otherwise)
+      f32x4 wq[2][TW * 2][2];
+      auto ldw = [&](f32x4 (&dst)[TW * 2][2], int k) {
+#pragma unroll
+        for (int g2 = 0; g2 < TW * 2; ++g2) {
+          const float* wp = W0u + (int64_t)k * H + g2 * 16 + h8;
+          dst[g2][0] = *reinterpret_cast<const f32x4*>(wp);
+          dst[g2][1] = *reinterpret_cast<const f32x4*>(wp + 4);
+        }
+      };
+      auto row = [&](const f32x4 (&wr)[TW * 2][2], int k) {
         const int c = k < 3 ? k : (k - 3) % 3;
         float pk[NB];
 #pragma unroll
@@ -435,9 +474,7 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
         for (int t = 0; t < TW; ++t)
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
-            const float* wp = W0u + (int64_t)k * H + (2 * t + p) * 16 + h8;
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+            const f32x4 w0 = wr[2 * t + p][0], w1 = wr[2 * t + p][1];
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
               const f32x16& v = acc[t][n];
@@ -452,8 +489,22 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
           gy[n] += c == 1 ? contrib : 0.f;
           gz[n] += c == 2 ? contrib : 0.f;
         }
+      };
+      if constexpr (TW == 1) {
+        ldw(wq[0], 0);
+        for (int k = 0; k < s.D0; k += 2) {
+          if (k + 1 < s.D0) ldw(wq[1], k + 1);
+          row(wq[0], k);
+          if (k + 1 < s.D0) {
+            if (k + 2 < s.D0) ldw(wq[0], k + 2);
+            row(wq[1], k + 1);
+          }
+        }
+      } else {               // two tiles per wave: the second register set would be spilled
+        for (int k = 0; k < s.D0; ++k) { ldw(wq[0], k); row(wq[0], k); }
       }
     }
+    I16_STAMP();
     // ---- reduce over the lane halves and the waves ---------------------------------------------
 #pragma unroll
     for (int n = 0; n < NB; ++n) {

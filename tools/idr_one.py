@@ -1,6 +1,9 @@
 import os, sys, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
 from oracle import iso_oracle as O
+from iso_points_amd import _lib
+if os.environ.get("ISO_DEV_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["ISO_DEV_LIB"])
 from iso_points_amd.sdf_models import idr_sdf_and_grad
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -9,3 +12,5 @@ pts = (torch.nn.functional.normalize(torch.randn(300000, 3), dim=-1) * 0.6).to(d
 for _ in range(4):
     idr_sdf_and_grad(m, pts)
 torch.cuda.synchronize()
+from tools_common import timeit
+print("IDR 8x512 300k: %.2f ms" % timeit(lambda: idr_sdf_and_grad(m, pts), warm=1, rep=5))
