@@ -97,7 +97,10 @@ int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_out,
  * frequencies (D0 = 3 + 6*n_freq <= 63), n_layers softplus(beta) layers of width `hidden`
  * (128/256/512), optional skip connection [h, e(x)]/sqrt(2) into layer skip_layer (< 0: none;
  * layer skip_layer-1 is then hidden-D0 wide), linear head, tanh.  Weight-norm must already be
- * folded into the weights.  raw = for l = 0..n_layers: W_l (row-major [out][in]) then b_l.     */
+ * folded into the weights.  raw = for l = 0..n_layers: W_l (row-major [out][in]) then b_l.
+ * hidden 256 / 512 with n_freq <= 6 run on the fp16 matrix cores at f32 accuracy (two fp16 parts
+ * per operand under exact power-of-two scales, as iso_siren_set_gemm_mode(1)); ISO_IDR_GEMM=f32 in
+ * the environment, hidden 128 and wider encodings use the f32 matrix cores.                     */
 int64_t iso_idr_raw_floats(int hidden, int n_layers, int skip_layer, int n_freq);
 int64_t iso_idr_packed_floats(int hidden, int n_layers);
 int iso_idr_pack_weights(const float* raw, float* packed, int hidden, int n_layers,
