@@ -139,6 +139,9 @@ __device__ __forceinline__ void iso_sincos_core2xN(const iso_f32x2* x, iso_f32x2
   ISO_XN(c[p] = __builtin_elementwise_fma(a[p], cr[p], u[p]));
 }
 
+#ifndef ISO_SINCOS_HW
+#define ISO_SINCOS_HW 1
+#endif
 // Eight arguments at once: the polynomial path for all, then ONE wave-uniform branch for the
 // (practically never taken) large-argument fix-up.  s = sin(w_in*z), c = w*cos(w_in*z)
 // (w_in = w except where z carries a power-of-two scale that w_in takes out again).
@@ -146,6 +149,23 @@ __device__ __forceinline__ void iso_sin_wcos8(float w_in, float w, const float (
   const iso_f32x2 w2 = {w, w}, wi2 = {w_in, w_in};
   iso_f32x2 x[4], s2[4], c2[4];
   ISO_X4(x[p] = ((iso_f32x2){z[2 * p], z[2 * p + 1]}) * wi2);
+#if ISO_SINCOS_HW
+  // v_sin_f32 / v_cos_f32 take revolutions and are good to 1.25e-7 absolute on [-1/2, 1/2]
+  // (tools/probes/hw_sincos_accuracy.hip: mean error 2.8e-8, a correctly rounded result has 1.5e-8), so
+  // only the reduction is done in software: f = x/(2 pi) - rint(x/(2 pi)) with a two-term 1/(2 pi)
+  // (the product x * hi is exact inside the fma).  7 issue slots per value instead of 15.5.
+  {
+    const iso_f32x2 hi = {0.159154936671257019043f, 0.159154936671257019043f};
+    const iso_f32x2 lo = {6.4206383167e-9f, 6.4206383167e-9f};
+    iso_f32x2 t[4], n[4], f[4];
+    ISO_X4(t[p] = x[p] * hi);
+    ISO_X4(n[p] = ((iso_f32x2){rintf(t[p].x), rintf(t[p].y)}));
+    ISO_X4(f[p] = __builtin_elementwise_fma(x[p], hi, -n[p]));
+    ISO_X4(f[p] = __builtin_elementwise_fma(x[p], lo, f[p]));
+    ISO_X4(s2[p] = ((iso_f32x2){__builtin_amdgcn_sinf(f[p].x), __builtin_amdgcn_sinf(f[p].y)}));
+    ISO_X4(c2[p] = ((iso_f32x2){__builtin_amdgcn_cosf(f[p].x), __builtin_amdgcn_cosf(f[p].y)}));
+  }
+#else
   // ISO_SINCOS_WIDTH pairs step-major at a time: 4 removes every wait state, 2 keeps the register
   // footprint of the temporaries at half (two chains already separate dependent packed ops)
 #ifndef ISO_SINCOS_WIDTH
@@ -153,6 +173,7 @@ __device__ __forceinline__ void iso_sin_wcos8(float w_in, float w, const float (
 #endif
 #pragma unroll
   for (int q = 0; q < 4; q += ISO_SINCOS_WIDTH) iso_sincos_core2xN<ISO_SINCOS_WIDTH>(x + q, s2 + q, c2 + q);
+#endif
   ISO_X4(c2[p] = c2[p] * w2);
   float amax = 0.f;
 #pragma unroll
