@@ -300,7 +300,7 @@ def main():
                          "frac": round(ach / peak, 4),
                          "frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                          # HBM-side bytes per launch from the PMC passes of this same command
-                         # (profiles/r01_v11_pmc_3.txt, _4.txt: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction);
+                         # (profiles/r01_v12_pmc_3.txt, _4.txt: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction);
                          # bench.py cannot run rocprofv3 on itself, so this is the committed measurement
                          "traffic": 2.047e9 if x3 else 2.47e9,
                          "traffic_note": "bytes/launch, PMC (2*FETCH_SIZE+WRITE_SIZE) from profiles/; algorithmic point "
