@@ -368,6 +368,9 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
             u32x4 p0, p1;
             split8_f16(hv, p0, p1, nscale[n]);
             own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
+#ifndef I16_NO_GROUP_BARRIER
+            __builtin_amdgcn_sched_barrier(0);     // one group at a time: bounds register pressure
+#endif
           }
 #pragma unroll
       for (int n = 0; n < NB; ++n) bscale[n] = nscale[n];
@@ -386,9 +389,9 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
       if (l > 1) gemm_x3<TW, NB, NTO, NS, kZero, true, 2, 2>(img, nullptr, act + lane, acc, w, 0, A, rev_img(l - 1), 0, lane);
       else gemm_x3<TW, NB, NTO, NS, kZero, true, 2, 2>(img, nullptr, act + lane, acc, w, 0, A, fwd_img(0), 0, lane);
       const f32x4* st_p = stash + (int64_t)(l - 1) * NG * 128;
-      f32x4 sv[NG][2];
-#pragma unroll
-      for (int k = 0; k < NG; ++k) { sv[k][0] = st_p[(k * 2) * 64 + lane]; sv[k][1] = st_p[(k * 2 + 1) * 64 + lane]; }
+      // sigma' of the layer below: two groups in flight (all NG at once would cost 64 registers)
+      f32x4 svq[2][2];
+      svq[0][0] = st_p[lane]; svq[0][1] = st_p[64 + lane];
       I16_STAMP();
       __syncthreads();
       I16_STAMP();
@@ -409,6 +412,11 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
 #pragma unroll
           for (int n = 0; n < NB; ++n) {
             const int k = (2 * t + p) * NB + n;
+            if (k + 1 < NG) {
+              svq[(k + 1) & 1][0] = st_p[((k + 1) * 2) * 64 + lane];
+              svq[(k + 1) & 1][1] = st_p[((k + 1) * 2 + 1) * 64 + lane];
+            }
+            const f32x4 (&svk)[2] = svq[k & 1];
             float av[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
                   gz[n] += c == 2 ? contrib : 0.f;
                 }
               }
-              av[e] = v * sv[k][e >> 2][e & 3];
+              av[e] = v * svk[e >> 2][e & 3];
               acc[t][n][8 * p + e] = av[e];              // kept for the layer-0 reverse (l == 1)
             }
             if (l > 1) {
