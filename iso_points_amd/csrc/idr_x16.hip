@@ -205,10 +205,18 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
   const float ln2_beta = 0.6931472f / a.beta;
 
   auto fwd_img = [&](int l) {
+#ifdef I16_DBG_ONEIMG      // timing experiment (results wrong): every hidden layer streams the SAME image (L2 resident)
+    if (l > 1) l = 1;
+#endif
     const float* base = a.packed + (l == 0 ? x16i_fw0(H, nL) : x16i_fw(H, nL, l));
     return reinterpret_cast<const u32x4*>(base) + (TW * w * 2) * 64;
   };
-  auto rev_img = [&](int l) { return reinterpret_cast<const u32x4*>(a.packed + x16i_bw(H, nL, l)) + (TW * w * 2) * 64; };
+  auto rev_img = [&](int l) {
+#ifdef I16_DBG_ONEIMG
+    l = 1;
+#endif
+    return reinterpret_cast<const u32x4*>(a.packed + x16i_bw(H, nL, l)) + (TW * w * 2) * 64;
+  };
   u32x4 A[4][TW][3];
   x3_prefetch_a<TW, NTO, 2>(A, fwd_img(0), 0, lane);
 
