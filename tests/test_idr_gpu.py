@@ -116,3 +116,39 @@ def test_reference_style_module_is_recognised(dev):
     sdf_ref, grad_ref = O.compute_sdf_and_grad(pts, m)
     sdf, grad = idr_sdf_and_grad(m.to(dev), pts.to(dev))
     assert rel_err(sdf, sdf_ref) < 1e-5 and rel_err(grad, grad_ref) < 2e-5
+
+
+@pytest.mark.parametrize("w_scale,head_scale,in_scale,bias_add", [(1.0, 1.0, 1.0, 0.0), (2.5, 0.2, 1.0, 0.0), (1.0, 30.0, 1.0, 0.0),
+                                                                    (1.0, 1.0e-8, 1.0, 0.0), (0.05, 1.0, 1.0, 0.0), (2.0, 1.0e-2, 4.0, 3.0)])
+@pytest.mark.parametrize("H,NL,skip,NF", [(512, 8, (4,), 6), (256, 5, (), 4)])
+def test_idr_split16_operand_ranges(dev, H, NL, skip, NF, w_scale, head_scale, in_scale, bias_add):
+    """The split-fp16 IDR kernel carries a per-point power-of-two scale through BOTH sweeps (softplus outputs
+    and adjoints have no a-priori range).  Hidden weights 6x larger / 20x smaller than the geometric
+    initialisation, large biases, heads that scale the pre-tanh value by 30 or 1e-8 (tanh may saturate:
+    zero gradient), inputs outside the unit cube: value and gradient stay finite and as close to
+    float64 as torch's float32 path is."""
+    O = _O()
+    from iso_points_amd.sdf_models import idr_sdf_and_grad
+    torch.manual_seed(H + NL)
+    m = O.IdrSDF(hidden_size=H, n_layers=NL, skip_in=skip, num_frequencies=NF)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+        for l in range(1, m.num_layers - 2):
+            m.g[l].mul_(w_scale)
+            m.b[l].add_(bias_add * torch.randn_like(m.b[l]))
+        m.g[m.num_layers - 2].mul_(head_scale)
+        m.b[m.num_layers - 2].mul_(head_scale)
+    pts = cube_cloud(1200, seed=NL)[0] * in_scale
+    sdf32, grad32 = O.compute_sdf_and_grad(pts, m)
+    sdf64, grad64 = O.compute_sdf_and_grad(pts.double(), copy.deepcopy(m).double())
+    sdf, grad = idr_sdf_and_grad(m.to(dev), pts.to(dev))
+    assert bool(torch.isfinite(sdf).all()) and bool(torch.isfinite(grad).all())
+    gs = max(grad64.abs().max().item(), 1e-300)
+    e_ref = (grad32.double() - grad64).abs().max().item() / gs
+    e_hip = (grad.cpu().double() - grad64).abs().max().item() / gs
+    s_ref = (sdf32.double() - sdf64).abs().max().item()
+    s_hip = (sdf.cpu().double() - sdf64).abs().max().item()
+    print("H=%d ws=%g hs=%g: grad err/max vs f64: torch-f32 %.3g hip %.3g; sdf %.3g / %.3g" % (H, w_scale, head_scale, e_ref, e_hip, s_ref, s_hip))
+    assert e_hip <= 3.0 * e_ref + 2e-6
+    assert s_hip <= 3.0 * s_ref + 1e-6 * max(sdf64.abs().max().item(), 1e-30)
