@@ -33,6 +33,7 @@
 //     front to back.
 //   * reverse sweep: same GEMM on the transposed image; w*cos(w z) comes back from the
 //     per-lane global stash (written in the forward sweep by the same lane).
+#include <stdlib.h>
 #include <type_traits>
 #include "siren_common.h"
 #include "iso_newton.h"
@@ -738,7 +739,11 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 bool siren_x3_supported(int H, int L) { return (H == 256 || H == 128) && L >= 1 && L <= 8; }
 
 int64_t siren_x3_stash_floats(int H, int L) {
-  if (H == 256) return 256 * X3_MINB256 * X3Shape<256, X3_NW, X3_NB256>::kStashPerWg(L);
+  if (H == 256) {
+    const int64_t plain = 256 * X3_MINB256 * X3Shape<256, X3_NW, X3_NB256>::kStashPerWg(L);
+    const int64_t pp = siren_pp_stash_floats(L);
+    return plain > pp ? plain : pp;
+  }
   if (H == 128) return 256 * X3_MINB128 * X3Shape<128, 4, 3>::kStashPerWg(L);
   return 0;
 }
@@ -752,7 +757,15 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
   }
 }
 
+// ISO_SIREN_PP=1 in the environment: the ping-pong kernel of siren_pp.hip for H = 256
+static bool use_pp() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ISO_SIREN_PP"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
+  if (use_pp() && siren_pp_supported(H, a.L)) return siren_pp_launch(a, n_upper, s);
 #if X3_PIPE
   if (H == 256) return launch_x3p<256, 4, 3, 1>(a, n_upper, s);
 #else
