@@ -60,7 +60,8 @@ __device__ __forceinline__ void x3_sin_wcos8(float w_in, float w, const float (&
 
 // ---- packing -------------------------------------------------------------------------------
 // raw layout: W0[H*3] b0[H] {Wi[H*H] bi[H]}*L WL[H] bL[1]
-__global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict__ packed, int H, int L) {
+// with_images = 0: only the K-order vectors (W0k, WLk, biases); the split-bf16 images are left alone
+__global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict__ packed, int H, int L, int with_images) {
   const int64_t base = x3_base(H, L), total = x16_base(H, L);
   const int64_t HH = (int64_t)H * H;
   const int NTO = H / 32;
@@ -83,7 +84,7 @@ __global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict
       const float* Wl = raw + (int64_t)H * 4 + (int64_t)l * (HH + H);
       if (q < H) {
         packed[o] = Wl[HH + feat_of(q)];
-      } else {
+      } else if (with_images) {
         q -= H;
         const bool bwd = q >= 3 * HH / 2;
         if (bwd) q -= 3 * HH / 2;
@@ -750,7 +751,9 @@ int64_t siren_x3_stash_floats(int H, int L) {
 
 void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s) {
   const int64_t words = x16_base(H, L) - x3_base(H, L);
-  hipLaunchKernelGGL(k_siren_pack_x3, dim3(iso_stream_grid(words, 256)), dim3(256), 0, s, raw, packed, H, L);
+  // the three-way bf16 images are only read by the -DX3_FWD_F16=0 / -DX3_BWD_F16=0 builds
+  hipLaunchKernelGGL(k_siren_pack_x3, dim3(iso_stream_grid(words, 256)), dim3(256), 0, s, raw, packed, H, L,
+                     (X3_FWD_F16 && X3_BWD_F16) ? 0 : 1);
   if (L > 0) {
     hipLaunchKernelGGL(k_siren_wscale, dim3(L), dim3(256), 0, s, raw, packed, H, L);
     hipLaunchKernelGGL(k_siren_pack_f16, dim3(iso_stream_grid(2 * (int64_t)L * H * H, 256)), dim3(256), 0, s, raw, packed, H, L);
