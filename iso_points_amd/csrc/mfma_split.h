@@ -131,22 +131,26 @@ constexpr int kAD = X3_KAD;
 // imgw is WAVE-UNIFORM (no lane term): the loads take the scalar-base + 32-bit lane-offset form,
 // so no 64-bit per-lane address registers are needed.
 // PARTS = 3: split-bf16 image, 2: split-fp16 image (imgw then points TW*w*PARTS*64 into it)
-template <int TW, int NTO, int PARTS>
-__device__ __forceinline__ void x3_load_a(u32x4 (&Ar)[TW][3], const u32x4* __restrict__ imgw, int s,
-                                          unsigned lane) {
-  const char* p = reinterpret_cast<const char*>(imgw + (int64_t)s * (NTO * PARTS * 64));
+// IP: `const u32x4*`, or the same with an explicit global address space (siren_pp.hip)
+typedef const __attribute__((address_space(1))) u32x4* gimg_t;
+template <class IP> struct x3_byte_ptr { typedef const char* type; };
+template <> struct x3_byte_ptr<gimg_t> { typedef const __attribute__((address_space(1))) char* type; };
+
+template <int TW, int NTO, int PARTS, class IP>
+__device__ __forceinline__ void x3_load_a(u32x4 (&Ar)[TW][3], IP imgw, int s, unsigned lane) {
+  typedef typename x3_byte_ptr<IP>::type BP;
+  const BP p = (BP)(imgw + (int64_t)s * (NTO * PARTS * 64));
   const unsigned lane_off = lane * 16u;      // 32-bit byte offset: keeps the scalar-base form
 #pragma unroll
   for (int t = 0; t < TW; ++t) {
-    const char* pt = p + t * (PARTS * 1024);   // scalar; the parts are immediate offsets
+    const BP pt = p + t * (PARTS * 1024);   // scalar; the parts are immediate offsets
 #pragma unroll
-    for (int c = 0; c < PARTS; ++c) Ar[t][c] = *reinterpret_cast<const u32x4*>(pt + lane_off + c * 1024);
+    for (int c = 0; c < PARTS; ++c) Ar[t][c] = *(IP)(pt + lane_off + c * 1024);
   }
 }
 
-template <int TW, int NTO, int PARTS>
-__device__ __forceinline__ void x3_prefetch_a(u32x4 (&A)[4][TW][3], const u32x4* __restrict__ imgw, int s,
-                                              unsigned lane) {
+template <int TW, int NTO, int PARTS, class IP>
+__device__ __forceinline__ void x3_prefetch_a(u32x4 (&A)[4][TW][3], IP imgw, int s, unsigned lane) {
 #pragma unroll
   for (int d = 0; d < kAD; ++d) x3_load_a<TW, NTO, PARTS>(A[d], imgw, s + d, lane);
 }
@@ -169,10 +173,10 @@ __device__ __forceinline__ void x3_keep_alive(const u32x4 (&X)[N][3]) {
 // PARTS / NEXT_PARTS: operand format of this stage / of the stage whose first fragments are
 // requested at the end (3 = split bf16, six products; 2 = split fp16, three products).
 // bias_scale multiplies the bias (the accumulator scale of a split-fp16 stage; 1 otherwise).
-template <int TW, int NB, int NTO, int KS, int INIT, bool IL, int PARTS = 3, int NEXT_PARTS = 3>
-__device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const float* __restrict__ bias_h,
+template <int TW, int NB, int NTO, int KS, int INIT, bool IL, int PARTS = 3, int NEXT_PARTS = 3, class IP = const u32x4*>
+__device__ __forceinline__ void gemm_x3(IP imgw, const float* __restrict__ bias_h,
                                         const u32x4* actl, f32x16 (&acc)[TW][NB], int w, int s0,
-                                        u32x4 (&A)[4][TW][3], const u32x4* __restrict__ next_imgw, int next_s,
+                                        u32x4 (&A)[4][TW][3], IP next_imgw, int next_s,
                                         unsigned lane, float bias_scale = 1.0f,
                                         const float* bias_scale_n = nullptr) {   // per point tile, on top of bias_scale
   static_assert(KS % 4 == 0, "K-steps are processed in groups of four");
@@ -298,6 +302,10 @@ __device__ __forceinline__ void gemm_x3(const u32x4* __restrict__ imgw, const fl
 #ifndef X3_NO_KEEPALIVE
       x3_keep_alive<TW, PARTS>(A[jj]);
       x3_keep_alive<NB, PARTS>(B[jj & 1]);
+#endif
+#ifdef X3_IL_GUARD_NOP      // experiment: wait states between the end of a K-step and the first MFMA of the next
+      asm volatile("s_nop %0" ::"n"(X3_IL_GUARD_NOP));
+      __builtin_amdgcn_sched_barrier(0);
 #endif
       } else {
       __builtin_amdgcn_sched_barrier(0);

@@ -39,8 +39,27 @@ constexpr size_t kPpRedm = (size_t)2 * 2 * PPS * 4 * 4;        // [set][buffer][
 constexpr size_t kPpLds = kPpAct + kPpRed + kPpRedm;
 __host__ __device__ constexpr int64_t pp_stash_per_wg(int L) { return (int64_t)4 * 2 * (L + 1) * PNG * 512; }   // floats
 
+// The generic lambdas below capture the argument block by reference, which hides from the compiler that
+// its pointers are global memory: without these casts every access becomes a FLAT instruction (which
+// counts on both the vector-memory and the LDS counter and forces a full drain before every K-step).
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {
+  return (T*)(__attribute__((address_space(1))) T*)p;
+}
+
 template <bool FWD>
-__global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
+__global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a_in) {
+  SirenArgs a = a_in;
+  a.pts = as_global(a_in.pts); a.normals = as_global(a_in.normals); a.mask = as_global(a_in.mask);
+  a.sdf_out = as_global(a_in.sdf_out); a.grad_out = as_global(a_in.grad_out);
+  a.idx_in = as_global(a_in.idx_in); a.count_in = as_global(a_in.count_in);
+  a.idx_out = as_global(a_in.idx_out); a.count_out = as_global(a_in.count_out);
+  a.packed = as_global(a_in.packed); a.stash = as_global(a_in.stash); a.dirs = as_global(a_in.dirs);
+  const float* const packed_g = as_global(a_in.packed);
+  float* const stash_g = as_global(a_in.stash);
+  float* const pts_g = as_global(a_in.pts);
+  const int32_t* const idxin_g = as_global(a_in.idx_in);
+  const float w0_s = a_in.w0, wh_s = a_in.wh;
   constexpr int H = PH, NS = PNS, NTO = PNTO, TW = PTW, NB = PNB, SL = PSL, NG = PNG, PS = PPS, P = PPP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* act = reinterpret_cast<u32x4*>(smem_raw);
@@ -53,17 +72,17 @@ __global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
   const int lane = tid & 63, h = lane >> 5, j = lane & 31, h8 = h * 8;
   const int L = a.L;
   const int NPH = FWD ? 2 * L + 2 : 4 * L + 2;                 // phases per pair of sets
-  const float* X = a.packed + x3_base(H, L);
+  const float* X = packed_g + x3_base(H, L);
   const f32x4* W0u = reinterpret_cast<const f32x4*>(X) + SL * m * 16;
   const float* WLu = X + 4 * H + SL * m * 16;
-  const float bL = a.packed[off_bl(H)];
-  const float* hdr = a.packed + x16_base(H, L);
+  const float bL = packed_g[off_bl(H)];
+  const float* hdr = packed_g + x16_base(H, L);
   // this lane's entries of set S: K-steps SL*m .. SL*m+SL-1, entry k = sl*NB + n, parts 0/1
   u32x4* own0 = act + (size_t)(SL * m) * NB * 2 * 64 + lane;
-  f32x4* stash = reinterpret_cast<f32x4*>(a.stash) + ((int64_t)blockIdx.x * 4 + m) * (int64_t)2 * (L + 1) * NG * 128;   // + lane
+  f32x4* stash = reinterpret_cast<f32x4*>(stash_g) + ((int64_t)blockIdx.x * 4 + m) * (int64_t)2 * (L + 1) * NG * 128;   // + lane
 
-  auto fwd_img = [&](int l) { return reinterpret_cast<const u32x4*>(a.packed + x16_off_layer(H, L, l)) + (TW * m * 2) * 64; };
-  auto rev_img = [&](int l) { return reinterpret_cast<const u32x4*>(a.packed + x16_off_bw(H, L, l)) + (TW * m * 2) * 64; };
+  auto fwd_img = [&](int l) { return (gimg_t)(packed_g + x16_off_layer(H, L, l)) + (TW * m * 2) * 64; };
+  auto rev_img = [&](int l) { return (gimg_t)(packed_g + x16_off_bw(H, L, l)) + (TW * m * 2) * 64; };
   // image of GEMM stage g of a set: forward layers 0..L-1, then reverse layers L-1..0
   auto stage_img = [&](int g) { return g < L ? fwd_img(g) : rev_img(2 * L - 1 - g); };
   const int NGS = FWD ? L : 2 * L;                             // GEMM stages per set
@@ -83,14 +102,14 @@ __global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
       for (int n = 0; n < NB; ++n) { fpart[S][n] = gx[S][n] = gy[S][n] = gz[S][n] = 0.f; bscale[S][n] = 1.f; }
 
     // ---- one activation stage of set S (vector role) -------------------------------------------
-    auto valu_stage = [&](auto SC, int v) {
+    auto valu_stage = [&](auto SC, int v) __attribute__((always_inline)) {
       constexpr int S = decltype(SC)::value;
       u32x4* own = own0 + S * kSetU4;
       f32x4* stS = stash + (int64_t)S * (L + 1) * NG * 128;
       float amax[NB];
 #pragma unroll
       for (int n = 0; n < NB; ++n) amax[n] = 0.f;
-      auto put_amax = [&]() {
+      auto put_amax = [&]() __attribute__((always_inline)) {
         const int buf = mbuf[S] ^ 1;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
@@ -107,8 +126,8 @@ __global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
           const int64_t slot = tile * P + S * PS + 32 * n + j;
           px[n] = py[n] = pz[n] = 0.f;
           if (slot < count) {
-            const int64_t idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
-            px[n] = a.pts[idx * 3]; py[n] = a.pts[idx * 3 + 1]; pz[n] = a.pts[idx * 3 + 2];
+            const int64_t idx = idxin_g ? (int64_t)idxin_g[slot] : slot;
+            px[n] = pts_g[idx * 3]; py[n] = pts_g[idx * 3 + 1]; pz[n] = pts_g[idx * 3 + 2];
           }
         }
         for (int sl = 0; sl < SL; ++sl) {
@@ -120,7 +139,7 @@ __global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
             float zz[8], hv[8], sv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) zz[e] = ((wv[e].x * px[n] + wv[e].y * py[n]) + wv[e].z * pz[n]) + wv[e].w;
-            iso_sin_wcos8(a.w0, a.w0, zz, hv, sv);
+            iso_sin_wcos8(w0_s, w0_s, zz, hv, sv);
             const int k = sl * NB + n;
             u32x4 p0, p1;
             split8_f16(hv, p0, p1);
@@ -138,8 +157,8 @@ __global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
         const int l = v - 1;
         const bool top = (l == L - 1);
         const float zscale = kActScale * hdr[l];
-        const float w_in = a.wh / zscale;
-        const float seed_scale = x3_scale_for(hdr[16] * a.wh * 1.01f);
+        const float w_in = wh_s / zscale;
+        const float seed_scale = x3_scale_for(hdr[16] * wh_s * 1.01f);
         f32x4* st_l = stS + (int64_t)(l + 1) * NG * 128;
         for (int sl = 0; sl < SL; ++sl) {
 #pragma unroll
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
             const f32x4 z0 = as_f32x4(own[(k * 2 + 0) * 64]), z1 = as_f32x4(own[(k * 2 + 1) * 64]);
             const float zz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
             float hv[8], sv[8];
-            iso_sin_wcos8(w_in, a.wh, zz, hv, sv);
+            iso_sin_wcos8(w_in, wh_s, zz, hv, sv);
             if (top) {
               const f32x4 wl0 = *reinterpret_cast<const f32x4*>(WLu + sl * 16 + h8);
               const f32x4 wl1 = *reinterpret_cast<const f32x4*>(WLu + sl * 16 + h8 + 4);
@@ -188,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
       float Mp[NB], inv[NB], nscale[NB];
       {
         const float iw = 1.0f / hdr[lr];
-        const float grow = hdr[8 + lr] * a.wh * 1.01f;
+        const float grow = hdr[8 + lr] * wh_s * 1.01f;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
           const f32x4 mm = *reinterpret_cast<const f32x4*>(redm + (((S * 2 + mbuf[S]) * PS) + 32 * n + j) * 4);
@@ -238,21 +257,21 @@ __global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
     };
 
     // ---- one GEMM stage of set S (matrix role); the accumulators stay in registers ----------------
-    auto mfma_stage = [&](auto SC, int g, int gi_next_valid) {
+    auto mfma_stage = [&](auto SC, int g, int gi_next_valid) __attribute__((always_inline)) {
       constexpr int S = decltype(SC)::value;
       const u32x4* actS = act + S * kSetU4 + lane;
-      const u32x4* img = stage_img(g);
+      const gimg_t img = stage_img(g);
       // the stage that follows in this wave's sequence: the other set on the same image, or the next image
       const int gn = (S == 0) ? g : g + 1;
-      const u32x4* nxt = (gi_next_valid && gn < NGS) ? stage_img(gn) : fwd_img(0);
+      const gimg_t nxt = (gi_next_valid && gn < NGS) ? stage_img(gn) : fwd_img(0);
       if (g < L) {
-        const float* bias = a.packed + x3_off_layer(H, L, g);
+        const float* bias = packed_g + x3_off_layer(H, L, g);
         gemm_x3<TW, NB, NTO, NS, kBias, PP_IL, 2, 2>(img, bias, actS, acc, m, 0, A, nxt, 0, lane, kActScale * hdr[g]);
       } else {
         gemm_x3<TW, NB, NTO, NS, kZero, PP_IL, 2, 2>(img, nullptr, actS, acc, m, 0, A, nxt, 0, lane);
       }
     };
-    auto write_acc = [&](auto SC) {
+    auto write_acc = [&](auto SC) __attribute__((always_inline)) {
       constexpr int S = decltype(SC)::value;
       u32x4* own = own0 + S * kSetU4;
       // the results of the last MFMAs must have landed before an LDS store reads them: the barrier in
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
 
     // ---- the phases: vector role works on set (ph & 1), matrix role on the other one ---------------
     // matrix stage index gi = ph - 1 (set gi & 1, stage gi >> 1), vector stage index vi = ph
-    auto phase = [&](auto QC, int ph) {
+    auto phase = [&](auto QC, int ph) __attribute__((always_inline)) {
       constexpr int Q = decltype(QC)::value;                  // ph & 1
       using SV = std::integral_constant<int, Q>;
       using SG = std::integral_constant<int, 1 - Q>;
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(512, 1) void k_siren_step_pp(SirenArgs a) {
           r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
         }
         const float f = r.x + bL;
-        idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
+        idx = idxin_g ? (int64_t)idxin_g[slot] : slot;
         survive = iso_step_finish(a, idx, f, r.y, r.z, r.w);
       }
     }
