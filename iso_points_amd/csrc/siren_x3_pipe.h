@@ -1,3 +1,5 @@
+// NOTE: historical experiment.  Builds with -DX3_PIPE=1 -DX3_FWD_F16=0 -DX3_BWD_F16=0 -fno-slp-vectorize; it was
+// last validated and measured on the split-bf16 form of the kernel (profiles v8), before the fp16 products.
 // Included by siren_x3.hip (inside its anonymous namespace): the software-pipelined variant of
 // the split-bf16 SIREN step kernel.  EXPERIMENT, not the default (build siren_x3.hip with
 // -DX3_PIPE=1 -fno-slp-vectorize): it passes the same tests and runs as fast as the plain kernel
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3p(SirenArgs a) {
   static_assert(NW % kSets == 0 && NS % kSets == 0, "register-set rotation must align with rounds");
   u32x4 A[kSets][TW][3];                 // weight-fragment pipeline, carried across stages
 #pragma unroll
-  for (int d = 0; d < kPD; ++d) x3_load_a<TW, NTO>(A[d], fw_img(0), s_of(d), lane);
+  for (int d = 0; d < kPD; ++d) x3_load_a<TW, NTO, 3>(A[d], fw_img(0), s_of(d), lane);
 
   const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
   const int64_t n_tiles = (count + P - 1) / P;
@@ -241,8 +243,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3p(SirenArgs a) {
 #pragma unroll
         for (int jj = 0; jj < NW; ++jj) {
           const int q = r * NW + jj;
-          if (q + kPD < NS) x3_load_a<TW, NTO>(A[(jj + kPD) % kSets], img, s_of(q + kPD), lane);
-          else x3_load_a<TW, NTO>(A[(jj + kPD) % kSets], nxt, s_of(q + kPD - NS), lane);
+          if (q + kPD < NS) x3_load_a<TW, NTO, 3>(A[(jj + kPD) % kSets], img, s_of(q + kPD), lane);
+          else x3_load_a<TW, NTO, 3>(A[(jj + kPD) % kSets], nxt, s_of(q + kPD - NS), lane);
           if (jj + 1 < NW) ldB(B[(jj + 1) & 1], s_of(q + 1));
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (decltype(with_prod)::value) {
