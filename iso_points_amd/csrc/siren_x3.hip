@@ -1,18 +1,20 @@
 // Fused SIREN SDF + gradient evaluation and Newton step with the hidden-layer GEMMs on the
-// bf16 matrix cores at f32 accuracy (v_mfma_f32_32x32x16_bf16, gfx950).
+// 16-bit matrix cores at f32 accuracy (v_mfma_f32_32x32x16_f16 / _bf16, gfx950).
 //
 // Reference semantics are those of siren.hip (Siren.forward DSS/models/common.py:140-165 under
 // autograd.grad in UniformProjection._compute_sdf_and_grad, levelset_sampling.py:142-170, iterated
 // by _project_points :313-342); this file only changes how the H x H products are formed.
 //
-// f32 product from bf16 MFMAs.  Every f32 operand is cut exactly into three bf16 numbers
-// (x = xh + xm + xl: 8+8+8 mantissa bits, round-to-nearest at each cut, the remainders are
-// exact), and W.x is accumulated in f32 from the six products whose weight is >= 2^-16:
-//     Wl.xh + Wh.xl + Wm.xm + Wm.xh + Wh.xm + Wh.xh
-// bf16 x bf16 products are exact in f32, so the only approximation is the three dropped terms
-// (<= 2^-23 relative, below the f32 accumulation error of a 256-term dot product; measured
-// against float64 in tests/test_projection_gpu.py next to the f32-MFMA kernel).  The bf16 pipe
-// runs 16x the f32 MFMA rate, so six passes are 2.7x faster than one f32 pass.
+// f32 product from 16-bit MFMAs (mfma_split.h).  Default (X3_FWD_F16 = X3_BWD_F16 = 1): every f32
+// operand is cut into TWO fp16 numbers (11 + 11 significant bits, round-to-nearest at each cut:
+// exact to 2^-24 relative) under an exact power-of-two scale -- per layer for the weights, 2^12 for
+// the activations, per point for the adjoint of the reverse sweep -- and W.x is accumulated in f32
+// from three products  Wl.xh + Wh.xl + Wh.xh  (fp16 x fp16 is exact in f32; the dropped Wl.xl is
+// 2^-24 relative).  The fp16 pipe runs 16x the f32 MFMA rate, so three passes are 5.3x faster than
+// one f32 pass; measured against float64 in tests/test_projection_gpu.py next to the f32-MFMA
+// kernel.  With X3_FWD_F16 = X3_BWD_F16 = 0 the operands are cut exactly into three bf16 numbers
+// instead (no scales needed, six products, three parts per LDS entry): the form this file started
+// with (hence the x3 in the names).
 //
 // Work decomposition (differs from siren.hip: weights are NOT staged through LDS)
 //   * one workgroup = P = 32*NB points (NB = 3), NW = 8 waves (two per SIMD; NW = 4 also builds).
@@ -22,15 +24,14 @@
 //     load per lane per (K-step, tile, part)), three K-steps ahead through four rotating register
 //     sets that run on across layers and tiles; with 8 waves the operand requests are pinned one
 //     behind each of the first MFMAs of a K-step (gemm_x3).
-//   * the activations of all P points live in LDS, already split (3 x 8 bf16 per lane entry,
+//   * the activations of all P points live in LDS, already split (2 x 8 fp16 per lane entry,
 //     [K-step][point tile][part][lane]: every B operand is one conflict-free ds_read_b128).
 //     Each wave reads all of them, and after the GEMM writes the K-steps made of its own output
 //     features.  Two workgroup barriers per layer (readers done / writers done) replace the
 //     per-chunk staging barriers of the f32 kernel.
-//   * sin/cos (packed f32 ops): with 8 waves a lane holds 48 values and walks its accumulators with
-//     static indices; with 4 waves (96 values) they are first parked (f32) in the tail of the wave's
-//     own, now dead, LDS region so that a rolled loop can walk them, results overwriting the region
-//     front to back.
+//   * sin/cos: software reduction to [-1/2, 1/2] revolutions on packed f32 ops, then v_sin_f32 /
+//     v_cos_f32 (mlp_common.h); a lane walks its accumulators with static indices, eight values at a
+//     time (shapes with more than 8 groups per lane park them in LDS first).
 //   * reverse sweep: same GEMM on the transposed image; w*cos(w z) comes back from the
 //     per-lane global stash (written in the forward sweep by the same lane).
 #include <stdlib.h>
