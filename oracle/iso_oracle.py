@@ -648,3 +648,184 @@ def lowest_sdf_on_segments(model, cam_pos, cam_ray, ray_len0, ray_len1, n_points
         val = model.forward(cand.view(-1, 3)).sdf.view(-1, n_points_per_ray)
     p_idx = torch.argmin(val, dim=-1, keepdim=True)
     return torch.gather(cand, -2, p_idx.unsqueeze(-1).expand(-1, -1, 3)).squeeze(-2), val
+
+
+# --------------------------------------------------------------------------- H. IDR ray tracing
+def sphere_entry_exit(cam_pos, cam_rays, radius=1.0):
+    """intersection_with_unit_sphere, DSS/utils/__init__.py:484-545.  cam_pos (B,1,3) or (B,3),
+    cam_rays (B,R,3) unit -> entry (B,R,3), exit (B,R,3), hit (B,R).  Rays that miss get the
+    tangent-plane depths (cam_dist -+ radius) / (-p.q / cam_dist)  (:533-541)."""
+    q = cam_rays.reshape(cam_rays.shape[0], -1, 3)
+    p = cam_pos.reshape(cam_pos.shape[0], 1, 3)
+    pq = (p * q).sum(-1)                                        # :506
+    foot = p - pq[..., None] * q                                # :508  closest point of the line to 0
+    dist = foot.norm(p=2, dim=-1)
+    cam_dist = p.norm(dim=-1)                                   # (B,1)
+    hit = dist <= radius                                        # :511
+    chord = torch.full_like(dist, 10.0)                         # :517-518
+    chord[hit] = 2 * torch.sqrt((radius ** 2 - dist ** 2)[hit])
+    z0 = torch.zeros_like(dist)
+    z0[hit] = torch.sqrt(cam_dist.expand_as(dist)[hit] ** 2 - dist[hit] ** 2) - chord[hit] / 2.0    # :528-530
+    z0[~hit] = ((cam_dist - radius) / eps_denom(-pq / cam_dist))[~hit]                                # :533-534
+    entry = z0.unsqueeze(-1) * q + p
+    exit_ = chord[..., None] * q + entry                        # :537-538
+    z_far = ((radius + cam_dist) / eps_denom(-pq / cam_dist))[~hit]
+    exit_[~hit] = z_far.unsqueeze(-1) * q[~hit] + p.expand_as(q)[~hit]
+    return entry, exit_, hit
+
+
+def _rt_two_ended_trace(sdf, cam, dirs, hit, z_in, z_out, thr, max_iters, line_step, line_iters):
+    """RayTracing.sphere_tracing, levelset_sampling.py:920-1032, on flattened rays: cam, dirs (R,3),
+    hit (R,), z_in / z_out (R,) depths of the bounding-sphere entry / exit."""
+    R = dirs.shape[0]
+    live = [hit.clone(), hit.clone()]                           # 0: marching forward from the entry, 1: back from the exit
+    z = [torch.where(hit, z_in, torch.zeros(R)), torch.where(hit, z_out, torch.zeros(R))]      # :933-944
+    pts = [torch.zeros(R, 3), torch.zeros(R, 3)]
+    for e in (0, 1):
+        pts[e][hit] = (cam + z[e].unsqueeze(-1) * dirs)[hit]
+    z_min, z_max = z[0].clone(), z[1].clone()                   # :947-948
+    step_sign = (1.0, -1.0)
+
+    def masked_eval(e, m, into=None):
+        out = torch.zeros(R) if into is None else into
+        if bool(m.any()):
+            out[m] = sdf(pts[e][m])
+        return out
+
+    nxt = [masked_eval(e, live[e]) for e in (0, 1)]             # :953-959
+    iters = 0
+    while True:
+        cur = []
+        for e in (0, 1):                                        # :963-975
+            c = torch.zeros(R)
+            c[live[e]] = nxt[e][live[e]]
+            c[c <= thr] = 0
+            cur.append(c)
+            live[e] = live[e] & (c > thr)
+        if (not bool(live[0].any()) and not bool(live[1].any())) or iters == max_iters:   # :977
+            break
+        iters += 1
+        for e in (0, 1):                                        # :983-990
+            z[e] = z[e] + step_sign[e] * cur[e]
+            pts[e] = cam + z[e].unsqueeze(-1) * dirs
+            nxt[e] = masked_eval(e, live[e])                    # :993-999
+        over = [nxt[0] < 0, nxt[1] < 0]                         # :1001-1002
+        k = 0
+        while (bool(over[0].any()) or bool(over[1].any())) and k < line_iters:            # :1004
+            back = (1 - line_step) / (2 ** k)
+            for e in (0, 1):                                    # :1006-1021
+                m = over[e]
+                z[e][m] = z[e][m] - step_sign[e] * (back * cur[e][m])
+                pts[e][m] = (cam + z[e].unsqueeze(-1) * dirs)[m]
+                nxt[e] = masked_eval(e, m, into=nxt[e])
+            over = [nxt[0] < 0, nxt[1] < 0]
+            k += 1
+        ordered = z[0] < z[1]                                   # :1027-1030
+        live = [live[0] & ordered, live[1] & ordered]
+    return pts[0], live[0], z[0], z[1], z_min, z_max
+
+
+def _rt_secant(sdf, f_lo, f_hi, z_lo, z_hi, cam, dirs, n_secant_steps):
+    """RayTracing.secant, levelset_sampling.py:1114-1133 (f_lo > 0 outside, f_hi < 0 inside)."""
+    f_lo, f_hi, z_lo, z_hi = f_lo.clone(), f_hi.clone(), z_lo.clone(), z_hi.clone()
+    z = -f_lo * (z_hi - z_lo) / (f_hi - f_lo) + z_lo
+    for _ in range(n_secant_steps):
+        f_mid = sdf(cam + z.unsqueeze(-1) * dirs)
+        pos, neg = f_mid > 0, f_mid < 0
+        z_lo[pos], f_lo[pos] = z[pos], f_mid[pos]
+        z_hi[neg], f_hi[neg] = z[neg], f_mid[neg]
+        z = -f_lo * (z_hi - z_lo) / (f_hi - f_lo) + z_lo
+    return z
+
+
+def _rt_ray_sampler(sdf, cam, dirs, object_mask, z_lo, z_hi, todo, n_steps, n_secant_steps, training):
+    """RayTracing.ray_sampler, levelset_sampling.py:1034-1112: n_steps uniform samples between
+    z_lo and z_hi on the `todo` rays, first sign change -> secant; rays without one (or, when
+    training, outside the ground-truth mask) take the sample of lowest value."""
+    R = dirs.shape[0]
+    out_pts, out_z = torch.zeros(R, 3), torch.zeros(R)
+    rows = torch.nonzero(todo, as_tuple=False).flatten()
+    n = rows.numel()
+    lin = torch.linspace(0, 1, steps=n_steps).view(1, -1)
+    zs = (z_lo.unsqueeze(-1) + lin * (z_hi - z_lo).unsqueeze(-1))[todo]                  # (n, n_steps)  :1045-1046
+    P = cam[todo].unsqueeze(1) + zs.unsqueeze(-1) * dirs[todo].unsqueeze(1)
+    val = torch.cat([sdf(c) for c in torch.split(P.reshape(-1, 3), 80000, dim=0)]).reshape(n, n_steps)
+    first_neg = torch.argmin(torch.sign(val) * torch.arange(n_steps, 0, -1).float().view(1, -1), -1)     # :1061-1063
+    ar = torch.arange(n)
+    out_pts[rows] = P[ar, first_neg]
+    out_z[rows] = zs[ar, first_neg]
+    in_gt = object_mask[todo]
+    in_net = val[ar, first_neg] < 0                                                        # :1070-1071
+    lowest = ~(in_gt & in_net)                                                             # :1074
+    if bool(lowest.any()):
+        j = torch.argmin(val[lowest], -1)
+        out_pts[rows[lowest]] = P[lowest][torch.arange(j.numel()), j]
+        out_z[rows[lowest]] = zs[lowest][torch.arange(j.numel()), j]
+    net_mask = todo.clone()                                                                # :1084-1085
+    net_mask[rows[~in_net]] = False
+    sec = (in_net & in_gt) if training else in_net                                         # :1088
+    if bool(sec.any()):
+        k = first_neg[sec]
+        m = torch.arange(k.numel())
+        z = _rt_secant(sdf, val[sec][m, k - 1], val[sec][m, k], zs[sec][m, k - 1], zs[sec][m, k],
+                       cam[rows[sec]], dirs[rows[sec]], n_secant_steps)
+        out_pts[rows[sec]] = cam[rows[sec]] + z.unsqueeze(-1) * dirs[rows[sec]]
+        out_z[rows[sec]] = z
+    return out_pts, net_mask, out_z
+
+
+def _rt_minimal_sdf(sdf, cam, dirs, sel, z_min, z_max, n_steps, uniform_steps):
+    """RayTracing.minimal_sdf_points, levelset_sampling.py:1135-1167: the lowest of n_steps
+    samples at depths drawn once (shared by all rays) from U(0,1), scaled to [z_min, z_max]."""
+    u = torch.empty(n_steps).uniform_(0.0, 1.0) if uniform_steps is None else uniform_steps
+    lo, hi = z_min[sel].unsqueeze(-1), z_max[sel].unsqueeze(-1)
+    zs = u.unsqueeze(0).repeat(lo.shape[0], 1) * (hi - lo) + lo
+    P = cam[sel].unsqueeze(1).repeat(1, n_steps, 1) + zs.unsqueeze(-1) * dirs[sel].unsqueeze(1).repeat(1, n_steps, 1)
+    val = torch.cat([sdf(c) for c in torch.split(P.reshape(-1, 3), 100000, dim=0)]).reshape(-1, n_steps)
+    j = val.min(-1)[1]
+    ar = torch.arange(j.numel())
+    return P[ar, j], zs[ar, j]
+
+
+def ray_tracing(sdf, cam_loc, object_mask, ray_directions, training=False, object_bounding_sphere=1.0,
+                sdf_threshold=5.0e-5, line_search_step=0.5, line_step_iters=1, sphere_tracing_iters=10,
+                n_steps=100, n_secant_steps=8, uniform_steps=None):
+    """RayTracing.forward, levelset_sampling.py:831-918.  sdf: (M,3) -> (M,); cam_loc (B,3);
+    object_mask (B*R,) bool; ray_directions (B,R,3) unit.  Returns points (B*R,3), network mask
+    (B*R,), depth (B*R,).  `uniform_steps` replaces the U(0,1) draw of :1142 (training only)."""
+    B, R, _ = ray_directions.shape
+    with torch.no_grad():
+        entry, exit_, hit = sphere_entry_exit(cam_loc, ray_directions, radius=object_bounding_sphere)
+        span = (torch.stack([entry, exit_], dim=-2) - cam_loc.view(B, 1, 3).unsqueeze(-2)).norm(dim=-1) \
+            / ray_directions.unsqueeze(-2).norm(dim=-1)                                    # :846-847
+        cam = cam_loc.unsqueeze(1).repeat(1, R, 1).reshape(-1, 3)
+        dirs = ray_directions.reshape(-1, 3)
+        hit = hit.reshape(-1)
+        span = span.reshape(-1, 2)
+        pts, todo, z0, z1, z_min, z_max = _rt_two_ended_trace(
+            sdf, cam, dirs, hit, span[:, 0], span[:, 1], sdf_threshold, sphere_tracing_iters,
+            line_search_step, line_step_iters)
+        net_mask = z0 < z1                                                                 # :853
+        if bool(todo.any()):                                                               # :856-875
+            lo = torch.where(todo, z0, torch.zeros_like(z0))
+            hi = torch.where(todo, z1, torch.zeros_like(z1))
+            s_pts, s_mask, s_z = _rt_ray_sampler(sdf, cam, dirs, object_mask, lo, hi, todo, n_steps,
+                                                 n_secant_steps, training)
+            pts[todo] = s_pts[todo]
+            z0[todo] = s_z[todo]
+            net_mask[todo] = s_mask[todo]
+        if not training:                                                                   # :883-886
+            return pts, net_mask, z0
+        in_mask = ~net_mask & object_mask & ~todo                                          # :892-894
+        out_mask = ~object_mask & ~todo
+        left_out = (in_mask | out_mask) & ~hit                                             # :896-904
+        if bool(left_out.any()):
+            z0[left_out] = -(dirs[left_out] * cam[left_out]).sum(-1)
+            pts[left_out] = cam[left_out] + z0[left_out].unsqueeze(1) * dirs[left_out]
+        sel = (in_mask | out_mask) & hit                                                   # :906-916
+        if bool(sel.any()):
+            z_min[net_mask & out_mask] = z0[net_mask & out_mask]
+            m_pts, m_z = _rt_minimal_sdf(sdf, cam, dirs, sel, z_min, z_max, n_steps, uniform_steps)
+            pts[sel] = m_pts
+            z0[sel] = m_z
+        return pts, net_mask, z0

@@ -249,6 +249,9 @@ def main():
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "trace"):
         from make_golden_trace import gen_trace
         gen_trace(L)
+    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "raytrace"):
+        from make_golden_raytrace import gen_raytrace
+        gen_raytrace(L)
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "splat"):
         from make_golden_splat import gen_splat
         gen_splat()

@@ -248,3 +248,52 @@ def test_zero_crossing_restatement():
                                     n_secant_steps=6)
     assert torch.equal(mask, g["zc_sphere_mask"])
     assert rel_err(pt, g["zc_sphere_points"]) < TIGHT
+
+
+RT_CASES = {"eval": (False, {}), "train": (True, {}),
+            "short_eval": (False, {"sphere_tracing_iters": 2, "n_steps": 40, "n_secant_steps": 5}),
+            "short_train": (True, {"sphere_tracing_iters": 2, "n_steps": 40, "line_step_iters": 2})}
+RT_CASES_SIREN = {"eval": (False, {}), "train": (True, {}),
+                  "short_eval": (False, {"sphere_tracing_iters": 3, "n_steps": 64})}
+
+
+def assert_raytrace_close(got, g, tag, tol=TIGHT, flip=0.0, frac=1.0):
+    """points / mask / depth of RayTracing.forward.  `flip`: fraction of rays allowed a different
+    network mask (a value within rounding of 0 or of the 5e-5 threshold decides the branch);
+    `frac`: fraction of the mask-agreeing rays whose points and depth must agree to `tol`."""
+    pts, mask, z = [t.detach().cpu() for t in got]
+    same = mask == g[tag + "_mask"]
+    assert (~same).float().mean() <= flip, (~same).sum()
+    scale = 3.0                                              # camera distance: depths are O(3)
+    dp = (pts - g[tag + "_points"]).abs().max(-1)[0] / scale
+    dz = (z - g[tag + "_dist"]).abs() / scale
+    ok = (dp <= tol) & (dz <= tol)
+    assert ok[same].float().mean() >= frac, (tag, (~ok[same]).sum().item(), dp[same].max().item(), dz[same].max().item())
+
+
+def test_ray_tracing_restatement_sphere():
+    """oracle ray_tracing vs the reference's RayTracing.forward (levelset_sampling.py:831-918):
+    all four branches (trace from both ends, sampler + secant, tangent-plane left-outs, minimal
+    sdf samples) on an analytic sphere; every ray, bit-tight."""
+    from oracle import iso_oracle as O
+    g = load("raytrace_sphere.npz")
+    sph = O.SphereSDF(tuple(g["center"].tolist()), float(g["radius"]))
+    sdf = lambda x: sph.forward(x).sdf.reshape(-1)
+    for tag, (training, kw) in RT_CASES.items():
+        got = O.ray_tracing(sdf, g["cam"], g["gt"], g["dirs"], training=training,
+                            uniform_steps=g[tag + "_uniform"], **kw)
+        assert_raytrace_close(got, g, tag)
+    m = g["eval_mask"]
+    assert 0.1 < m.float().mean() < 0.6 and (g["gt"] != m).any()      # hits, misses and mask mismatches
+
+
+def test_ray_tracing_restatement_siren():
+    from oracle import iso_oracle as O
+    g = load("raytrace_siren.npz")
+    w = load("trace_siren.npz")
+    net = siren_from(w)
+    sdf = lambda x: net.forward(x).sdf.reshape(-1)
+    for tag, (training, kw) in RT_CASES_SIREN.items():
+        got = O.ray_tracing(sdf, g["cam"], g["gt"], g["dirs"], training=training,
+                            uniform_steps=g[tag + "_uniform"], **kw)
+        assert_raytrace_close(got, g, tag)
