@@ -4,12 +4,13 @@ call signature and three results (DSS/models/levelset_sampling.py:810-1167).
 Every network evaluation goes through the `sdf` callable the caller passes -- build it with
 `sdf_models.FusedSdf(model, device)` to run the forward-only fused HIP kernels (SIREN split-fp16
 MFMA, IDR x16).  What differs from the reference is the shape of the work handed to that callable:
-the reference compacts the unfinished rays of each end with boolean masks before every call
-(2 calls + 2 scatter/gathers + several host syncs per iteration); here both ends of ALL rays are one
-(2R,3) batch per iteration and finished rays are held with `where`, so an iteration is one kernel
-launch of the network plus element-wise updates, and the only host reads are the two loop
-conditions the reference also evaluates (`any unfinished`, `any overshoot`).  Per ray the
-arithmetic is the same statement for statement, so results do not depend on batch composition.
+the reference treats the two marching ends separately and compacts each with boolean masks before
+every call (2 network calls, 2 masked scatters and several host syncs per iteration); here both
+ends are one (2,R) state, finished rays are held with `where`, and each iteration makes ONE network
+call on the still-unfinished rows of the (2R,3) batch (listed by one `nonzero`, whose row count is
+also the loop condition the reference reads with `.sum() == 0`).  Per ray the arithmetic is the
+same statement for statement and the fused kernels' per-point results do not depend on which
+other points share the launch, so the results do not depend on this regrouping.
 The interval sampler and the minimal-value search only touch the (few) unfinished / mismatched
 rays and keep the reference's compaction.
 """
@@ -107,32 +108,43 @@ class RayTracing(nn.Module):
         toward = torch.tensor([[1.0], [-1.0]], device=dirs.device)       # end 1 walks backwards
         zero = torch.zeros((), device=dirs.device)
 
-        def evaluate(points):
-            return sdf(points.reshape(-1, 3)).reshape(2, R)
+        def evaluate(points, rows, into):
+            """network values of the listed rows of the (2R,3) batch, scattered into a copy of `into`"""
+            out = into.reshape(-1).clone()
+            if rows.numel() > 0:
+                out[rows] = sdf(points.reshape(-1, 3)[rows])
+            return out.view(2, R)
+
+        def listed(mask):
+            return torch.nonzero(mask.reshape(-1), as_tuple=False).flatten()     # (host read: the row count)
 
         live = hit.unsqueeze(0).expand(2, R).clone()
         z = torch.where(live, span.t(), zero)
         pts = torch.where(live.unsqueeze(-1), cam + z.unsqueeze(-1) * dirs, zero)
         z_min, z_max = z[0].clone(), z[1].clone()
-        nxt = torch.where(live, evaluate(pts), zero)
+        nxt = evaluate(pts, listed(live), torch.zeros_like(z))
         iters = 0
         while True:
             cur = torch.where(live, nxt, zero)
             cur = torch.where(cur <= thr, zero, cur)
             live = live & (cur > thr)
-            if iters == self.sphere_tracing_iters or not bool(live.any()):
+            rows = listed(live)
+            if iters == self.sphere_tracing_iters or rows.numel() == 0:
                 break
             iters += 1
             z = z + toward * cur
             pts = cam + z.unsqueeze(-1) * dirs
-            nxt = torch.where(live, evaluate(pts), zero)
+            nxt = evaluate(pts, rows, torch.zeros_like(z))
             over = nxt < 0                                               # stepped through the surface
             k = 0
-            while k < self.line_step_iters and bool(over.any()):
+            while k < self.line_step_iters:
+                rows = listed(over)
+                if rows.numel() == 0:
+                    break
                 back = (1 - self.line_search_step) / (2 ** k)
                 z = torch.where(over, z - toward * (back * cur), z)
                 pts = torch.where(over.unsqueeze(-1), cam + z.unsqueeze(-1) * dirs, pts)
-                nxt = torch.where(over, evaluate(pts), nxt)
+                nxt = evaluate(pts, rows, nxt)
                 over = nxt < 0
                 k += 1
             live = live & (z[0] < z[1]).unsqueeze(0)
