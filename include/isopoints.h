@@ -151,6 +151,34 @@ int iso_ray_nearest_point(const float* rays, int64_t n_rays, float ox, float oy,
                           float* raysq_out, float* dist_out, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* State updates of IDR's two-ended ray marcher between two network evaluations
+ * (RayTracing.sphere_tracing / .secant, DSS/models/levelset_sampling.py:920-1032, :1114-1133).
+ * Per ray two marching ends: arrays of shape (2,R) hold end 0 (forward from the bounding-sphere
+ * entry) in [0,R) and end 1 (backward from the exit) in [R,2R).  cam, dirs (R,3) are the ray
+ * origin and unit direction.  Each call writes `list` (<= 2R,3): the points that need a network
+ * value next, `slot` (2,R) i32: their position in the list (-1: none), and `*count` (device i32):
+ * how many there are -- the caller reads it, evaluates list[0:count] and passes the values on.
+ *
+ * iso_raymarch_settle (:962-990 and, with check_order, the z0 < z1 test of :1027-1030 that ends
+ *   the previous iteration): cur = live ? nxt : 0;  cur <= thr -> 0;  live &= cur > thr;
+ *   *count = unfinished ends; when `step`: z0 += cur0, z1 -= cur1, list <- cam + z d of those ends.
+ * iso_raymarch_overshoot (:993-1025): nxt <- values (first: ends without a slot get 0; later:
+ *   they keep theirs); ends with nxt < 0 stepped through the surface: when `may_backstep`
+ *   z0 -= back cur0 / z1 += back cur1, list <- their new points, *count = how many (else 0).
+ * iso_raymarch_secant (:1114-1133) on n compacted rays: with f_mid = values at z_pred, move the
+ *   bracket end of matching sign (f_mid > 0 -> lo, < 0 -> hi); then (also when f_mid is NULL: the
+ *   first call) z_pred = -f_lo (z_hi - z_lo) / (f_hi - f_lo) + z_lo, pts_out = cam + z_pred d.  */
+int iso_raymarch_settle(const float* cam, const float* dirs, int64_t n_rays, float* z, float* cur,
+                        const float* nxt, uint8_t* live, float sdf_threshold, int check_order,
+                        int step, int32_t* slot, float* list, int32_t* count, void* stream);
+int iso_raymarch_overshoot(const float* cam, const float* dirs, int64_t n_rays, float* z,
+                           const float* cur, float* nxt, const float* values, int first,
+                           int may_backstep, float back, int32_t* slot, float* list,
+                           int32_t* count, void* stream);
+int iso_raymarch_secant(const float* cam, const float* dirs, int64_t n, float* f_lo, float* f_hi,
+                        float* z_lo, float* z_hi, float* z_pred, const float* f_mid,
+                        float* pts_out, void* stream);
+
 /* ------------------------------------------------------------------------
  * B. Fixed-radius nearest neighbours on a uniform grid
  *    replaces the third-party `frnn` / `prefix_sum` extensions the reference

@@ -42,6 +42,9 @@ SIGNATURES = {
     "iso_trace_idr": (_I, [_P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _F, _F, _I, _F, _P, _L, _P]),
     "iso_ray_nearest_point_workspace_bytes": (_L, [_L]),
     "iso_ray_nearest_point": (_I, [_P, _L, _F, _F, _F, _P, _L, _P, _P, _P, _P, _L, _P]),
+    "iso_raymarch_settle": (_I, [_P, _P, _L, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P]),
+    "iso_raymarch_overshoot": (_I, [_P, _P, _L, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "iso_raymarch_secant": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "iso_points_bbox": (_I, [_P, _P, _I, _L, _P, _P]),
     "iso_frnn_make_grid": (_I, [_P, _P, _P, _I, _L, _I, _P, _P]),
     "iso_frnn_insert_points": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),

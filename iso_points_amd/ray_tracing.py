@@ -8,7 +8,10 @@ the reference treats the two marching ends separately and compacts each with boo
 every call (2 network calls, 2 masked scatters and several host syncs per iteration); here both
 ends are one (2,R) state, finished rays are held with `where`, and each iteration makes ONE network
 call on the still-unfinished rows of the (2R,3) batch (listed by one `nonzero`, whose row count is
-also the loop condition the reference reads with `.sum() == 0`).  Per ray the arithmetic is the
+also the loop condition the reference reads with `.sum() == 0`).  The statements between two
+network calls -- threshold, masks, advance, overshoot back-step, the next call's point list and
+its length -- are one HIP kernel each (csrc/raymarch.hip: iso_raymarch_settle / _overshoot, and
+iso_raymarch_secant for the false-position update).  Per ray the arithmetic is the
 same statement for statement and the fused kernels' per-point results do not depend on which
 other points share the launch, so the results do not depend on this regrouping.
 The interval sampler and the minimal-value search only touch the (few) unfinished / mismatched
@@ -17,6 +20,7 @@ rays and keep the reference's compaction.
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .levelset_sampling import eps_denom
 
 
@@ -103,52 +107,57 @@ class RayTracing(nn.Module):
         |sdf| <= threshold, the ends cross, or the iteration cap.  cam, dirs (R,3), hit (R,), span
         (R,2).  Returns the end-0 points (R,3), the unfinished end-0 mask (R,), depths (2,R) and
         the initial (min, max) depths."""
-        R = dirs.shape[0]
-        thr = self.sdf_threshold
-        toward = torch.tensor([[1.0], [-1.0]], device=dirs.device)       # end 1 walks backwards
-        zero = torch.zeros((), device=dirs.device)
+        R, dev = dirs.shape[0], dirs.device
+        p, st = _lib.ptr, _lib.stream()
+        cam, dirs = cam.contiguous(), dirs.contiguous()
+        zero = torch.zeros((), device=dev)
+        z = torch.where(hit.unsqueeze(0), span.t(), zero).contiguous()              # :933-944
+        first_pts = torch.where(hit.unsqueeze(-1), cam + z[0].unsqueeze(-1) * dirs, zero)
+        z_min, z_max = z[0].clone(), z[1].clone()                                    # :947-948
+        live = hit.unsqueeze(0).expand(2, R).to(torch.uint8).contiguous()
+        nxt = torch.zeros((2, R), dtype=torch.float32, device=dev)
+        rows = torch.nonzero(hit, as_tuple=False).flatten()
+        if rows.numel() > 0:                                                         # :953-959, one call
+            both = torch.cat([cam[rows] + z[0][rows].unsqueeze(-1) * dirs[rows],
+                              cam[rows] + z[1][rows].unsqueeze(-1) * dirs[rows]])
+            nxt[:, rows] = sdf(both).reshape(2, -1)
+        cur = torch.empty_like(z)
+        slot = torch.empty((2, R), dtype=torch.int32, device=dev)
+        todo = torch.empty((2 * R, 3), dtype=torch.float32, device=dev)             # next evaluation's input
+        count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        no_values = torch.empty((0,), dtype=torch.float32, device=dev)
 
-        def evaluate(points, rows, into):
-            """network values of the listed rows of the (2R,3) batch, scattered into a copy of `into`"""
-            out = into.reshape(-1).clone()
-            if rows.numel() > 0:
-                out[rows] = sdf(points.reshape(-1, 3)[rows])
-            return out.view(2, R)
+        def values_of(n):
+            return sdf(todo[:n]).reshape(-1).float().contiguous() if n > 0 else no_values
 
-        def listed(mask):
-            return torch.nonzero(mask.reshape(-1), as_tuple=False).flatten()     # (host read: the row count)
-
-        live = hit.unsqueeze(0).expand(2, R).clone()
-        z = torch.where(live, span.t(), zero)
-        pts = torch.where(live.unsqueeze(-1), cam + z.unsqueeze(-1) * dirs, zero)
-        z_min, z_max = z[0].clone(), z[1].clone()
-        nxt = evaluate(pts, listed(live), torch.zeros_like(z))
-        iters = 0
+        iters, later = 0, 0
         while True:
-            cur = torch.where(live, nxt, zero)
-            cur = torch.where(cur <= thr, zero, cur)
-            live = live & (cur > thr)
-            rows = listed(live)
-            if iters == self.sphere_tracing_iters or rows.numel() == 0:
+            step = 1 if iters < self.sphere_tracing_iters else 0
+            _lib.call("iso_raymarch_settle", p(cam), p(dirs), R, p(z), p(cur), p(nxt), p(live),
+                      float(self.sdf_threshold), later, step, p(slot), p(todo), p(count), st)
+            n = int(count.item())                                                    # :977 (the one host read)
+            if not step or n == 0:
                 break
             iters += 1
-            z = z + toward * cur
-            pts = cam + z.unsqueeze(-1) * dirs
-            nxt = evaluate(pts, rows, torch.zeros_like(z))
-            over = nxt < 0                                               # stepped through the surface
+            later = 1
             k = 0
-            while k < self.line_step_iters:
-                rows = listed(over)
-                if rows.numel() == 0:
+            val = values_of(n)
+            _lib.call("iso_raymarch_overshoot", p(cam), p(dirs), R, p(z), p(cur), p(nxt), p(val), 1,
+                      1 if k < self.line_step_iters else 0, float(1 - self.line_search_step), p(slot), p(todo),
+                      p(count), st)
+            while k < self.line_step_iters:                                          # :1004-1025
+                n = int(count.item())
+                if n == 0:
                     break
-                back = (1 - self.line_search_step) / (2 ** k)
-                z = torch.where(over, z - toward * (back * cur), z)
-                pts = torch.where(over.unsqueeze(-1), cam + z.unsqueeze(-1) * dirs, pts)
-                nxt = evaluate(pts, rows, nxt)
-                over = nxt < 0
+                val = values_of(n)
                 k += 1
-            live = live & (z[0] < z[1]).unsqueeze(0)
-        return pts[0].clone(), live[0], z.clone(), z_min, z_max
+                _lib.call("iso_raymarch_overshoot", p(cam), p(dirs), R, p(z), p(cur), p(nxt), p(val), 0,
+                          1 if k < self.line_step_iters else 0,
+                          float((1 - self.line_search_step) / (2 ** k)), p(slot), p(todo), p(count), st)
+        # every statement that touches the points writes cam + z d (:987-990, :1008-1014); before the
+        # first step they are the entry points, zero for the rays that miss the sphere (:927-931)
+        pts0 = cam + z[0].unsqueeze(-1) * dirs if iters > 0 else first_pts
+        return pts0, live[0].bool(), z, z_min, z_max
 
     # -- :1034-1112 ------------------------------------------------------------------------
     def ray_sampler(self, sdf, cam, dirs, in_gt, z_lo, z_hi):
@@ -184,13 +193,20 @@ class RayTracing(nn.Module):
 
     # -- :1114-1133 ------------------------------------------------------------------------
     def secant(self, sdf, f_lo, f_hi, z_lo, z_hi, cam, dirs):
-        z = -f_lo * (z_hi - z_lo) / (f_hi - f_lo) + z_lo
-        for _ in range(self.n_secant_steps):
-            f_mid = sdf(cam + z.unsqueeze(-1) * dirs)
-            pos, neg = f_mid > 0, f_mid < 0
-            z_lo, f_lo = torch.where(pos, z, z_lo), torch.where(pos, f_mid, f_lo)
-            z_hi, f_hi = torch.where(neg, z, z_hi), torch.where(neg, f_mid, f_hi)
-            z = -f_lo * (z_hi - z_lo) / (f_hi - f_lo) + z_lo
+        """false position on n compacted rays (f_lo > 0 outside, f_hi < 0 inside): one fused
+        update (bracket move + next depth + next point) between two network evaluations."""
+        p, st = _lib.ptr, _lib.stream()
+        n = dirs.shape[0]
+        f_lo, f_hi, z_lo, z_hi = [t.float().contiguous().clone() for t in (f_lo, f_hi, z_lo, z_hi)]
+        cam, dirs = cam.contiguous(), dirs.contiguous()
+        z = torch.empty_like(z_lo)
+        mid = torch.empty((n, 3), dtype=torch.float32, device=dirs.device)
+        f_mid = None
+        for it in range(self.n_secant_steps + 1):
+            _lib.call("iso_raymarch_secant", p(cam), p(dirs), n, p(f_lo), p(f_hi), p(z_lo), p(z_hi), p(z),
+                      p(f_mid) if f_mid is not None else None, p(mid), st)
+            if it < self.n_secant_steps:
+                f_mid = sdf(mid).reshape(-1).float().contiguous()
         return z
 
     # -- :1135-1167 ------------------------------------------------------------------------
