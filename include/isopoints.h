@@ -179,6 +179,14 @@ int iso_raymarch_secant(const float* cam, const float* dirs, int64_t n, float* f
                         float* z_lo, float* z_hi, float* z_pred, const float* f_mid,
                         float* pts_out, void* stream);
 
+/* Image values at projected points: get_tensor_values, DSS/utils/__init__.py:325-375
+ * (= grid_sample(image (B,C,H,W), p, mode, padding_mode='reflection', align_corners=False),
+ * squeezed and permuted).  p (B,n,2) in [-1,1] (x, y); out (B,n,C).
+ * mode 0 bilinear, 1 nearest, 2 integer indexing trunc((p + 1)(size - 1)/2) (`grid_sample=False`,
+ * :357-363; an index outside the image -- an IndexError in the reference -- gives NaN).          */
+int iso_image_sample(const float* image, int batch, int channels, int height, int width,
+                     const float* p, int64_t n, int mode, float* out, void* stream);
+
 /* ------------------------------------------------------------------------
  * B. Fixed-radius nearest neighbours on a uniform grid
  *    replaces the third-party `frnn` / `prefix_sum` extensions the reference

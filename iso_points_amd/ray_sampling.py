@@ -83,3 +83,33 @@ def get_visible_points(points, normals, cameras, depth_merge_threshold=0.05, ret
         mask[f["flags"].reshape(-1).bool()] = vis
         mask = mask.view(N, P)
     return (vis_list, mask) if return_mask else vis_list
+
+
+def get_tensor_values(tensor, p, grid_sample=True, mode="bilinear", with_mask=False, squeeze_channel_dim=False):
+    """Image values at projected points (DSS/utils/__init__.py:325-375): tensor (B,C,H,W), p (B,N,2)
+    in [-1,1] -> (B,N,C) [(B,N) with squeeze_channel_dim], optionally with the finite-value mask.
+    `grid_sample=True` is grid_sample(..., mode, padding_mode='reflection') in one kernel
+    (iso_image_sample) that writes (B,N,C) directly; `grid_sample=False` is the integer indexing of
+    :357-363 (the reference also overwrites the caller's `p` with the pixel coordinates there --
+    that side effect is not reproduced)."""
+    if not tensor.is_cuda:
+        raise RuntimeError("iso_points_amd: the image must be on the GPU; there is no CPU path")
+    if mode not in ("bilinear", "nearest"):
+        raise ValueError("get_tensor_values: mode must be 'bilinear' or 'nearest', got %r" % (mode,))
+    B, C, H, W = tensor.shape
+    if not grid_sample:
+        assert H == W                                               # :358
+    img = tensor.detach().float().contiguous()
+    pts = p.detach().float().contiguous()
+    assert pts.shape[0] == B and pts.shape[-1] == 2 and pts.dim() == 3
+    N = pts.shape[1]
+    values = torch.empty((B, N, C), dtype=torch.float32, device=img.device)
+    _lib.call("iso_image_sample", _lib.ptr(img), B, C, H, W, _lib.ptr(pts), N,
+              (0 if mode == "bilinear" else 1) if grid_sample else 2, _lib.ptr(values), _lib.stream())
+    if not grid_sample and bool(torch.isnan(values).any()) and not bool(torch.isnan(img).any()):
+        raise IndexError("get_tensor_values: index out of the image (grid_sample=False needs p in [-1,1])")
+    mask = torch.isfinite(values) if with_mask else None
+    if squeeze_channel_dim:
+        values = values.squeeze(-1)
+        mask = mask.squeeze(-1) if with_mask else None
+    return (values, mask) if with_mask else values

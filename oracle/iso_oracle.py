@@ -829,3 +829,40 @@ def ray_tracing(sdf, cam_loc, object_mask, ray_directions, training=False, objec
             pts[sel] = m_pts
             z0[sel] = m_z
         return pts, net_mask, z0
+
+
+# --------------------------------------------------------------------------- I. image look-up
+def get_tensor_values(tensor, p, grid_sample=True, mode="bilinear", with_mask=False, squeeze_channel_dim=False):
+    """get_tensor_values, DSS/utils/__init__.py:325-375, with grid_sample(padding_mode='reflection',
+    align_corners=False) written out (ATen GridSampler: unnormalise, reflect about the pixel edges,
+    clip, 4 corners nw/ne/sw/se).  tensor (B,C,H,W), p (B,N,2) -> (B,N,C)."""
+    B, C, H, W = tensor.shape
+    bi = torch.arange(B).view(B, 1)
+    if not grid_sample:                                           # :357-363 (p is not modified here)
+        x = ((p[..., 0] + 1) * (W - 1) / 2).long()
+        y = ((p[..., 1] + 1) * (H - 1) / 2).long()
+        values = tensor[bi, :, y, x]
+    else:
+        def src(c, size):
+            x = ((c + 1) * size - 1) / 2
+            x = (x + 0.5).abs()
+            extra, flips = torch.fmod(x, float(size)), torch.floor(x / size)
+            x = torch.where(flips % 2 == 0, extra - 0.5, (size - extra) - 0.5)
+            return x.clamp(0, size - 1)
+        x, y = src(p[..., 0].float(), W), src(p[..., 1].float(), H)
+        if mode == "nearest":
+            values = tensor[bi, :, torch.round(y).long(), torch.round(x).long()]
+        else:
+            x0, y0 = torch.floor(x), torch.floor(y)
+            values = torch.zeros(B, p.shape[1], C)
+            for dx, dy in ((0, 0), (1, 0), (0, 1), (1, 1)):      # nw, ne, sw, se
+                wx = (x0 + 1 - x) if dx == 0 else (x - x0)
+                wy = (y0 + 1 - y) if dy == 0 else (y - y0)
+                xi, yi = (x0 + dx).long(), (y0 + dy).long()
+                ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+                v = tensor[bi, :, yi.clamp(0, H - 1), xi.clamp(0, W - 1)]
+                values = values + torch.where(ok.unsqueeze(-1), v * (wx * wy).unsqueeze(-1), torch.zeros(()))
+    mask = torch.isfinite(values) & ~torch.isnan(values)          # valid_value_mask, :15-16
+    if squeeze_channel_dim:
+        values, mask = values.squeeze(-1), mask.squeeze(-1)
+    return (values, mask) if with_mask else values

@@ -252,6 +252,9 @@ def main():
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "raytrace"):
         from make_golden_raytrace import gen_raytrace
         gen_raytrace(L)
+    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "image"):
+        from make_golden_image import gen_image
+        gen_image(L)
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "splat"):
         from make_golden_splat import gen_splat
         gen_splat()

@@ -297,3 +297,19 @@ def test_ray_tracing_restatement_siren():
         got = O.ray_tracing(sdf, g["cam"], g["gt"], g["dirs"], training=training,
                             uniform_steps=g[tag + "_uniform"], **kw)
         assert_raytrace_close(got, g, tag)
+
+
+def test_get_tensor_values_restatement():
+    """oracle get_tensor_values (grid_sample written out) vs the reference's own function
+    (utils/__init__.py:325-375): bilinear / nearest / integer indexing, samples inside, on the
+    border and outside [-1,1] (reflection padding)."""
+    from oracle import iso_oracle as O
+    g = load("image_values.npz")
+    v, m = O.get_tensor_values(g["mask"], g["p"], with_mask=True, squeeze_channel_dim=True)
+    assert v.shape == g["mask_bilinear"].shape and (v - g["mask_bilinear"]).abs().max() < 1e-6
+    assert torch.equal(m, g["mask_valid"])
+    assert (O.get_tensor_values(g["rgb"], g["p"]) - g["rgb_bilinear"]).abs().max() < 1e-6
+    near = O.get_tensor_values(g["rgb"], g["p"], mode="nearest")
+    assert (near != g["rgb_nearest"]).any(-1).float().mean() < 2e-3     # x.5 ties after float rounding
+    assert torch.equal(O.get_tensor_values(g["sq"], g["p_in"], grid_sample=False), g["sq_index"])
+    assert ((g["p"].abs() > 1).any(-1)).float().mean() > 0.2

@@ -122,3 +122,40 @@ def test_get_visible_points(dev):
     views_b = torch.stack([look_at_view(3.0, 20.0, 0.0), look_at_view(3.0, -20.0, 180.0)]).to(dev)
     vis_b, mask_b = get_visible_points(pts, nrm, (views_b, views_b @ perspective(30.0).to(dev)), return_mask=True)
     assert int((mask_b[0] & mask_b[1]).sum()) == 0
+
+
+def test_get_tensor_values_golden(dev):
+    """iso_image_sample vs the reference's own get_tensor_values (tests/golden/make_golden_image.py)."""
+    from test_oracle_golden import load
+    from iso_points_amd.ray_sampling import get_tensor_values
+    g = load("image_values.npz")
+    v, m = get_tensor_values(g["mask"].to(dev), g["p"].to(dev), with_mask=True, squeeze_channel_dim=True)
+    assert v.shape == g["mask_bilinear"].shape and m.dtype == torch.bool
+    assert (v.cpu() - g["mask_bilinear"]).abs().max() < 1e-6 and torch.equal(m.cpu(), g["mask_valid"])
+    out = get_tensor_values(g["rgb"].to(dev), g["p"].to(dev))
+    assert out.shape == g["rgb_bilinear"].shape and (out.cpu() - g["rgb_bilinear"]).abs().max() < 1e-6
+    near = get_tensor_values(g["rgb"].to(dev), g["p"].to(dev), mode="nearest").cpu()
+    assert (near != g["rgb_nearest"]).any(-1).float().mean() < 2e-3     # x.5 ties after float rounding
+    p_in = g["p_in"].to(dev)
+    keep = p_in.clone()
+    assert torch.equal(get_tensor_values(g["sq"].to(dev), p_in, grid_sample=False).cpu(), g["sq_index"])
+    assert torch.equal(p_in, keep)
+    with pytest.raises(IndexError):
+        get_tensor_values(g["sq"].to(dev), p_in * 3, grid_sample=False)
+    with pytest.raises(RuntimeError):
+        get_tensor_values(g["sq"], g["p_in"])
+
+
+def test_get_tensor_values_vs_oracle_large(dev):
+    """a 512 x 512 mask sampled at 1 M points (the look-up of every iso-point of cfg 3), bool source"""
+    from oracle import iso_oracle as O
+    from iso_points_amd.ray_sampling import get_tensor_values
+    gen = torch.Generator().manual_seed(8)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 512), torch.linspace(-1, 1, 512), indexing="ij")
+    mask = ((xx * xx + yy * yy) < 0.6).view(1, 1, 512, 512).repeat(4, 1, 1, 1)
+    p = (torch.rand(4, 250000, 2, generator=gen) - 0.5) * 2.2
+    ref = O.get_tensor_values(mask.float(), p, squeeze_channel_dim=True)
+    got = get_tensor_values(mask.to(dev).float(), p.to(dev), squeeze_channel_dim=True)
+    assert got.shape == (4, 250000) and (got.cpu() - ref).abs().max() < 2e-5
+    empty = get_tensor_values(mask.to(dev).float(), torch.zeros(4, 0, 2, device=dev))
+    assert empty.shape == (4, 0, 1)

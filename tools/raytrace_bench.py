@@ -65,5 +65,16 @@ for name, net in (("siren4x256", siren), ("idr8x512", idr)):
             "cpu_oracle": {"rays": ns, "s": tc, "Mrays_s": ns / tc / 1e6, "threads": torch.get_num_threads(),
                            "mask_agreement_on_sample": agree}}
         print(name, case, res["%s_%s" % (name, case)], flush=True)
+# image look-up (get_tensor_values): 4 masks of 512 x 512, 250 k iso-points each
+from iso_points_amd.ray_sampling import get_tensor_values
+yy, xx = torch.meshgrid(torch.linspace(-1, 1, 512), torch.linspace(-1, 1, 512), indexing="ij")
+img = ((xx * xx + yy * yy) < 0.6).float().view(1, 1, 512, 512).repeat(4, 1, 1, 1).to(dev)
+pp = ((torch.rand(4, 250000, 2, generator=torch.Generator().manual_seed(3)) - 0.5) * 2.2).to(dev)
+t_ours = timeit(lambda: get_tensor_values(img, pp, squeeze_channel_dim=True), warm=2, rep=10)
+t_torch = timeit(lambda: torch.nn.functional.grid_sample(img, pp.unsqueeze(1), mode="bilinear", padding_mode="reflection",
+                                                         align_corners=False).squeeze(2).permute(0, 2, 1).squeeze(-1), warm=2, rep=10)
+res["get_tensor_values_4x512x512_1M"] = {"ms": t_ours, "torch_grid_sample_same_gpu_ms": t_torch,
+                                          "GB_s": (1e6 * 12) / t_ours / 1e6}
+print("get_tensor_values", res["get_tensor_values_4x512x512_1M"], flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "raytrace_bench.json"), "w"), indent=1)
