@@ -109,3 +109,18 @@ def test_ray_tracing_edge_cases(dev):
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
     with pytest.raises(RuntimeError):
         rt(sdf=fused, cam_loc=cam, object_mask=gt, ray_directions=dirs)
+    # no rays; rays that all miss the bounding sphere; a camera inside the bounding sphere
+    for training in (False, True):
+        rt = RayTracing().train(training)
+        pts, mask, z = rt(sdf=fused, cam_loc=cam.to(dev), object_mask=gt[:0].to(dev),
+                          ray_directions=dirs[:, :0].to(dev))
+        assert pts.shape == (0, 3) and mask.shape == (0,) and z.shape == (0,)
+        away = torch.nn.functional.normalize(torch.tensor([[[0.0, 1.0, 0.2], [1.0, 0.0, 0.1]]]), dim=-1)
+        u = torch.linspace(0.05, 0.95, 100)
+        for c, d, m in ((cam, away, torch.tensor([True, False])),
+                        (torch.tensor([[0.1, 0.0, -0.8]]), dirs, gt)):
+            got = rt(sdf=fused, cam_loc=c.to(dev), object_mask=m.to(dev), ray_directions=d.to(dev), uniform_steps=u)
+            ref = O.ray_tracing(lambda x: O.SphereSDF(radius=0.5).forward(x).sdf.reshape(-1), c, m, d,
+                                training=training, uniform_steps=u)
+            assert got[1].tolist() == ref[1].tolist()
+            assert (got[0].cpu() - ref[0]).abs().max() < 5e-6 and (got[2].cpu() - ref[2]).abs().max() < 5e-6
