@@ -17,6 +17,7 @@ from collections import namedtuple
 from typing import Optional
 
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
@@ -498,6 +499,65 @@ class SphereTracing(LevelSetProjection):
                 "network_eval_on_levelset_points": val.view(shp[:-1]),
                 "levelset_points_Dx": pts,
                 "mask": mask.view(shp[:-1])}
+
+
+def _value_gradient(network, points):
+    """D_x F at `points` (..., 3), detached: the fused SDF+gradient kernels for SIREN / IDR-style
+    networks, autograd for anything else.  (No model.eval() here: the sampling layers below run
+    inside the training step.)"""
+    flat = points.detach().reshape(-1, 3)
+    if flat.is_cuda and siren_spec(network) is not None:
+        from .sdf_models import siren_sdf_and_grad
+        return siren_sdf_and_grad(network, flat.float().contiguous())[1].view(points.shape)
+    if flat.is_cuda and idr_spec(network) is not None:
+        from .sdf_models import idr_sdf_and_grad
+        return idr_sdf_and_grad(network, flat.float().contiguous())[1].view(points.shape)
+    with torch.enable_grad():
+        x = points.detach().requires_grad_(True)
+        f = network.forward(x).sdf
+        (g,) = torch.autograd.grad([f], [x], torch.ones_like(f))
+    return g.detach()
+
+
+class SampleNetwork(nn.Module):
+    """Eq. 13 (levelset_sampling.py:1170-1207): iso-points as a differentiable function of the
+    network parameters, p - (F(p; theta) - F(p; theta_0)) D_xF^+ .  The value is p; what matters is
+    d/d theta.  D_xF (theta-independent, detached in the reference too) comes from the fused
+    value+gradient kernel instead of an autograd pass with retain_graph; F(p; theta) is the caller's
+    module under autograd, since its graph IS the result."""
+
+    def forward(self, network, levelset_points, return_eval=False):
+        if not levelset_points.is_cuda:
+            raise RuntimeError("iso_points_amd: points must be on the GPU; there is no CPU path")
+        levelset_points = levelset_points.detach()
+        levelset_points_Dx = _value_gradient(network, levelset_points)
+        network_eval = network.forward(levelset_points).sdf
+        sum_square_grad = torch.sum(levelset_points_Dx ** 2, dim=-1, keepdim=True)
+        sampled_points = levelset_points - (network_eval - network_eval.detach()).view(
+            levelset_points.shape[:-1] + (1,)) * (levelset_points_Dx / eps_denom(sum_square_grad, 1e-17))
+        if return_eval:
+            return sampled_points, network_eval
+        return sampled_points
+
+
+class DirectionalSamplingNetwork(SampleNetwork):
+    """levelset_sampling.py:1370-1403: the same along a viewing ray -- depth
+    t(theta) = t - (F - F_0) / (D_xF . v), point = cam_pos + t(theta) v."""
+
+    def forward(self, network, iso_points, ray, cam_pos, c=None, return_eval=False):
+        if not iso_points.is_cuda:
+            raise RuntimeError("iso_points_amd: points must be on the GPU; there is no CPU path")
+        iso_points = iso_points.detach()
+        iso_points_Dx = _value_gradient(network, iso_points)
+        surface_dists = (iso_points - cam_pos).norm(dim=-1, keepdim=True)
+        network_eval = network.forward(iso_points).sdf
+        ray = F.normalize(ray, dim=-1, p=2)
+        surface_points_dot = torch.sum(iso_points_Dx * ray.detach(), dim=-1, keepdim=True)
+        surface_dists_theta = surface_dists - (network_eval - network_eval.detach()) / eps_denom(surface_points_dot, 1e-10)
+        surface_points_theta_c_v = cam_pos + surface_dists_theta * ray
+        if return_eval:
+            return surface_points_theta_c_v, network_eval
+        return surface_points_theta_c_v
 
 
 class _KwModel(object):

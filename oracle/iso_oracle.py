@@ -866,3 +866,37 @@ def get_tensor_values(tensor, p, grid_sample=True, mode="bilinear", with_mask=Fa
     if squeeze_channel_dim:
         values, mask = values.squeeze(-1), mask.squeeze(-1)
     return (values, mask) if with_mask else values
+
+
+# --------------------------------------------------------------------------- J. differentiable samples
+def _value_gradient(network, pts):
+    with torch.enable_grad():
+        x = pts.detach().requires_grad_(True)
+        f = network.forward(x).sdf
+        (g,) = torch.autograd.grad([f], [x], torch.ones_like(f))
+    return g.detach()
+
+
+def sample_network(network, levelset_points, return_eval=False):
+    """SampleNetwork.forward, levelset_sampling.py:1175-1207 (Eq. 13): p - (F(p;theta) - F(p;theta0))
+    D_xF / |D_xF|^2 -- the value is p, the derivative w.r.t. theta is that of the level set."""
+    p = levelset_points.detach()
+    Dx = _value_gradient(network, p)
+    f = network.forward(p).sdf
+    ssg = torch.sum(Dx ** 2, dim=-1, keepdim=True)
+    out = p - (f - f.detach()).view(p.shape[:-1] + (1,)) * (Dx / eps_denom(ssg, 1e-17))
+    return (out, f) if return_eval else out
+
+
+def directional_sample(network, iso_points, ray, cam_pos, return_eval=False):
+    """DirectionalSamplingNetwork.forward, levelset_sampling.py:1371-1403: the depth along the
+    viewing ray as a function of theta, t - (F - F0) / (D_xF . v)."""
+    p = iso_points.detach()
+    Dx = _value_gradient(network, p)
+    t = (p - cam_pos).norm(dim=-1, keepdim=True)
+    f = network.forward(p).sdf
+    ray = F.normalize(ray, dim=-1, p=2)
+    along = torch.sum(Dx * ray.detach(), dim=-1, keepdim=True)
+    t_theta = t - (f - f.detach()) / eps_denom(along, 1e-10)
+    out = cam_pos + t_theta * ray
+    return (out, f) if return_eval else out

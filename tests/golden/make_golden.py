@@ -255,6 +255,9 @@ def main():
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "image"):
         from make_golden_image import gen_image
         gen_image(L)
+    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "sample"):
+        from make_golden_sample import gen_sample
+        gen_sample(L)
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "splat"):
         from make_golden_splat import gen_splat
         gen_splat()

@@ -313,3 +313,27 @@ def test_get_tensor_values_restatement():
     assert (near != g["rgb_nearest"]).any(-1).float().mean() < 2e-3     # x.5 ties after float rounding
     assert torch.equal(O.get_tensor_values(g["sq"], g["p_in"], grid_sample=False), g["sq_index"])
     assert ((g["p"].abs() > 1).any(-1)).float().mean() > 0.2
+
+
+SAMPLE_PARAMS = ((0, "weight"), (2, "bias"), (-1, "weight"), (-1, "bias"))
+
+
+def sample_grads(net, value):
+    net.zero_grad()
+    value.backward()
+    return torch.cat([getattr(net.lins[i], n).grad.reshape(-1) for i, n in SAMPLE_PARAMS]).cpu()
+
+
+def test_sample_network_restatement():
+    """oracle sample_network / directional_sample vs the reference's SampleNetwork /
+    DirectionalSamplingNetwork (levelset_sampling.py:1170-1207, :1370-1403): sampled points and
+    the gradient of a linear functional of them w.r.t. network parameters."""
+    from oracle import iso_oracle as O
+    g = load("sample_network.npz")
+    net = siren_from(load("trace_siren.npz"))
+    out, ev = O.sample_network(net, g["points"], return_eval=True)
+    assert torch.equal(out.detach(), g["sn_points"]) and rel_err(ev.detach(), g["sn_eval"]) < TIGHT
+    assert rel_err(sample_grads(net, (out * g["w"]).sum()), g["sn_grads"]) < 1e-5
+    out, ev = O.directional_sample(net, g["points"], g["ray"], g["cam"], return_eval=True)
+    assert rel_err(out.detach(), g["dn_points"]) < TIGHT and rel_err(ev.detach(), g["dn_eval"]) < TIGHT
+    assert rel_err(sample_grads(net, (out * g["w"]).sum()), g["dn_grads"]) < 1e-5

@@ -176,3 +176,36 @@ def test_zero_crossing_golden(dev):
                                                       is_occupancy=False, n_steps=64, n_secant_steps=6)
     assert torch.equal(mask.cpu(), g["zc_sphere_mask"])
     assert rel_err(pt, g["zc_sphere_points"]) < 1e-5
+
+
+def test_sample_networks_golden(dev):
+    """SampleNetwork / DirectionalSamplingNetwork (Eq. 13) with D_xF from the fused kernel: sampled
+    points and parameter gradients vs the reference's own layers (tests/golden/make_golden_sample.py)."""
+    from test_oracle_golden import sample_grads
+    from iso_points_amd.levelset_sampling import DirectionalSamplingNetwork, SampleNetwork
+    g = load("sample_network.npz")
+    net = siren_from(load("trace_siren.npz")).to(dev)
+    w = g["w"].to(dev)
+    out, ev = SampleNetwork()(net, g["points"].to(dev), return_eval=True)
+    assert torch.equal(out.detach().cpu(), g["sn_points"]) and rel_err(ev.detach().cpu(), g["sn_eval"]) < 1e-5
+    assert rel_err(sample_grads(net, (out * w).sum()), g["sn_grads"]) < 2e-5
+    out, ev = DirectionalSamplingNetwork()(net, g["points"].to(dev), g["ray"].to(dev), g["cam"].to(dev), return_eval=True)
+    assert rel_err(out.detach().cpu(), g["dn_points"]) < 2e-6 and rel_err(ev.detach().cpu(), g["dn_eval"]) < 1e-5
+    # the parameter gradient is a cancelling sum over points of 1 / (D_xF . v) terms: any two f32
+    # evaluations of it (the reference on the CPU, torch autograd on this GPU, the fused kernel)
+    # differ by a few 1e-5.  Judge against the float64 value of the same statement: no farther
+    # from it than twice the reference's own f32 result is.
+    got = sample_grads(net, (out * w).sum())
+    assert rel_err(got, g["dn_grads"]) < 1e-4
+    import copy
+    net64 = copy.deepcopy(net).cpu().double()
+    o64 = _O().directional_sample(net64, g["points"].double(), g["ray"].double(), g["cam"].double())
+    truth = sample_grads(net64, (o64 * g["w"].double()).sum())
+    err_ref = rel_err(g["dn_grads"].double(), truth)
+    assert rel_err(got.double(), truth) < max(2 * err_ref, 2e-5), (rel_err(got.double(), truth), err_ref)
+    # a module without a fused kernel goes through autograd
+    sph = _sphere(dev, center=(0.0, 0.0, 0.0), radius=0.7)
+    out = SampleNetwork()(sph, g["points"].to(dev))
+    assert torch.equal(out.cpu(), g["points"])
+    with pytest.raises(RuntimeError):
+        SampleNetwork()(net, g["points"])
