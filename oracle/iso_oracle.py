@@ -900,3 +900,103 @@ def directional_sample(network, iso_points, ray, cam_pos, return_eval=False):
     t_theta = t - (f - f.detach()) / eps_denom(along, 1e-10)
     out = cam_pos + t_theta * ray
     return (out, f) if return_eval else out
+
+
+# --------------------------------------------------------------------------- K. edge-aware resampling
+class BoxSDF(torch.nn.Module):
+    """Exact SDF of an axis-aligned box (half extents b): a shape WITH edges for the edge-aware
+    tests.  Not from the reference -- test input only."""
+
+    def __init__(self, half=(0.5, 0.4, 0.3)):
+        super().__init__()
+        self.register_buffer("half_extent", torch.tensor(half, dtype=torch.float32))
+
+    def forward(self, x, **kwargs):
+        q = x.abs() - self.half_extent
+        out = q.clamp_min(0).norm(dim=-1) + q.max(dim=-1)[0].clamp_max(0)
+        return SdfOut(out.unsqueeze(-1))
+
+
+def knn_gather(x, idx, lengths=None):
+    """pytorch3d.ops.knn_gather: x (N,M,U), idx (N,P,K) -> (N,P,K,U); slots beyond a cloud's
+    length hold index 0 there."""
+    N, P, K = idx.shape
+    return torch.gather(x.unsqueeze(1).expand(N, P, x.shape[1], x.shape[2]), 2,
+                        idx.clamp_min(0).unsqueeze(-1).expand(N, P, K, x.shape[2]))
+
+
+def ear_tree(points, num_points, knn_k):
+    """EdgeAwareProjection._create_tree, levelset_sampling.py:471-498: K+1 nearest, self dropped."""
+    r = knn_points(points, points, num_points, num_points, K=knn_k + 1, return_nn=True)
+    return KNN(dists=r.dists[..., 1:], idx=r.idx[..., 1:], knn=r.knn[..., 1:, :])
+
+
+def ear_denoise_normals(points, normals, num_points, tree, sharpness_sigma):
+    """EdgeAwareProjection.denoise_normals, levelset_sampling.py:500-526 (bilateral normal filter)."""
+    normals = F.normalize(normals, dim=-1)
+    knn_normals = knn_gather(normals, tree.idx, num_points)
+    weights_n = torch.exp(-((1 - torch.sum(knn_normals * normals[:, :, None, :], dim=-1)) / sharpness_sigma) ** 2)
+    inv_sigma = num_points / 2.0
+    spatial_dist = 16 / inv_sigma
+    deltap = tree.knn - points[:, :, None, :]
+    deltap = torch.sum(deltap * deltap, dim=-1)
+    weights_p = torch.exp(-deltap * inv_sigma)
+    weights_p[deltap > spatial_dist] = 0
+    weights = weights_p * weights_n
+    out = torch.sum(knn_normals * weights[:, :, :, None], dim=-2) / eps_denom(torch.sum(weights, dim=-1, keepdim=True))
+    return F.normalize(out, dim=-1), weights_p, weights_n
+
+
+def ear_upsample(points, n_points, model, num_points=None, knn_k=31, repulsion_mu=0.5, sharpness_angle=15,
+                 edge_sensitivity=1, upsample_ratio=1.5):
+    """EdgeAwareProjection.upsample, levelset_sampling.py:528-661, one cloud (the reference's
+    `num_points / 2.0` broadcasts are only valid for batch size 1).  Kept as written there,
+    including F.normalize(move) over dim=1 -- the POINT axis -- at :582-585."""
+    n_points = int(math.ceil(n_points * upsample_ratio))
+    B, P = points.shape[:2]
+    assert B == 1
+    if num_points is None:
+        num_points = torch.full((B,), P, dtype=torch.long)
+    sharp = 1 - math.cos(sharpness_angle / 180 * math.pi)
+    tree = ear_tree(points, num_points, knn_k)                                            # :548
+    inv_sigma = num_points / 2.0
+    spatial_dist = 16 / inv_sigma
+    _, normals = compute_sdf_and_grad(points, model)                                       # :555-557
+    normals = F.normalize(normals, dim=-1, eps=1e-15)
+    normals, _, _ = ear_denoise_normals(points, normals, num_points, tree, sharp)
+    move_clip = tree.dists[..., 0].mean().sqrt()                                           # :568
+    diff = points[:, :, None, :] - tree.knn
+    weight_lop = torch.exp(-torch.sum(normals[:, :, None, :] * diff, dim=-1) ** 2 * inv_sigma)
+    weight_lop[tree.dists > spatial_dist] = 0
+    spatial_w = torch.exp(-tree.dists * inv_sigma)
+    spatial_w[tree.dists > spatial_dist] = 0
+    density_w = torch.sum(spatial_w, dim=-1) + 1.0
+    move_data = torch.sum(weight_lop[..., None] * diff, dim=-2) / eps_denom(torch.sum(weight_lop, dim=-1, keepdim=True))
+    move_repul = repulsion_mu * density_w[..., None] * torch.sum(spatial_w[..., None] * (-diff), dim=-2) / \
+        eps_denom(torch.sum(spatial_w, dim=-1, keepdim=True))
+    move_repul = F.normalize(move_repul) * move_repul.norm(dim=-1, keepdim=True).clamp_max(move_clip)
+    move_data = F.normalize(move_data) * move_data.norm(dim=-1, keepdim=True).clamp_max(move_clip)
+    points = points - (move_data + move_repul)                                             # :596
+    n_remaining = n_points - num_points
+    max_P = P // 10
+    while not bool((n_remaining == 0).all()):                                              # :601-659
+        knn_pts = knn_gather(points, tree.idx, num_points)
+        knn_normals = knn_gather(normals, tree.idx, num_points)
+        mid = (knn_pts + 2 * points[..., None, :]) / 3
+        d = mid.unsqueeze(-2) - knn_pts.unsqueeze(-3)                                      # (1,P,K,K,3)
+        edge = (2 - torch.sum(normals.unsqueeze(-2) * knn_normals, dim=-1)) ** edge_sensitivity
+        m = torch.norm(d, dim=-1) - torch.sum((d * knn_normals.unsqueeze(-2)) ** 2, dim=-1)
+        m = eps_sqrt(m.min(dim=-1)[0]).sqrt()
+        sparsity, father_nb = (edge * m).max(dim=-1)
+        order = sparsity.sort(dim=1).indices[:, -max_P:]
+        n_new = n_remaining.clone()
+        n_new[n_new > max_P] = max_P
+        cand = mid[torch.arange(B), torch.arange(mid.shape[1]), father_nb]                 # :632 (B = 1)
+        new_pts = torch.gather(cand, 1, order.unsqueeze(-1).expand(-1, -1, 3))
+        points = torch.cat([new_pts[0][-int(n_new[0]):], points[0, :int(num_points[0])]], dim=0).unsqueeze(0)
+        n_remaining = n_remaining - n_new
+        num_points = n_new + num_points
+        tree = ear_tree(points, num_points, knn_k)
+        _, normals = compute_sdf_and_grad(points, model)
+        normals = F.normalize(normals, dim=-1)
+    return points, num_points

@@ -258,6 +258,9 @@ def main():
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "sample"):
         from make_golden_sample import gen_sample
         gen_sample(L)
+    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "ear"):
+        from make_golden_ear import gen_ear
+        gen_ear(L)
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "splat"):
         from make_golden_splat import gen_splat
         gen_splat()

@@ -337,3 +337,26 @@ def test_sample_network_restatement():
     out, ev = O.directional_sample(net, g["points"], g["ray"], g["cam"], return_eval=True)
     assert rel_err(out.detach(), g["dn_points"]) < TIGHT and rel_err(ev.detach(), g["dn_eval"]) < TIGHT
     assert rel_err(sample_grads(net, (out * g["w"]).sum()), g["dn_grads"]) < 1e-5
+
+
+EAR_CASES = {"K16": dict(knn_k=16),
+             "K31_sharp": dict(knn_k=31, sharpness_angle=30, edge_sensitivity=2, upsample_ratio=1.3, repulsion_mu=0.3)}
+
+
+def test_edge_aware_restatement():
+    """oracle ear_tree / ear_denoise_normals / ear_upsample vs the reference's EdgeAwareProjection
+    (levelset_sampling.py:442-661) on a box (a shape with edges)."""
+    import math
+    from oracle import iso_oracle as O
+    box = O.BoxSDF()
+    for tag, kw in EAR_CASES.items():
+        g = load("ear_%s.npz" % tag)
+        num = torch.tensor([g["points"].shape[1]])
+        tree = O.ear_tree(g["points"], num, kw["knn_k"])
+        sharp = 1 - math.cos(kw.get("sharpness_angle", 15) / 180 * math.pi)
+        nd, wp, wn = O.ear_denoise_normals(g["points"], g["normals"], num, tree, sharp)
+        assert rel_err(nd, g["denoised"]) < TIGHT and rel_err(wp, g["weights_p"]) < TIGHT
+        assert rel_err(wn, g["weights_n"]) < TIGHT
+        up, n = O.ear_upsample(g["points"], g["points"].shape[1], box, num.clone(), **kw)
+        assert torch.equal(n, g["out_num"]) and up.shape == g["out_points"].shape
+        assert rel_err(up, g["out_points"]) < TIGHT
