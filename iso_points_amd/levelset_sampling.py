@@ -13,6 +13,7 @@ Model dispatch: an analytic sphere and SIREN networks run in the f
 HIP kernels; any other nn.Module takes the generic route -- the reference's own
 algorithm (model.forward + autograd.grad on compacted active points) on the GPU.
 """
+import math
 from collections import namedtuple
 from typing import Optional
 
@@ -404,6 +405,128 @@ class UniformProjection(LevelSetProjection):
                     model, points_projected, num_points, proj_max_iters=10, **forward_kwargs)
             return {"levelset_points": points_projected, "levelset_normals": normals_projected,
                     "mask": valid_projection}
+
+
+class EdgeAwareProjection(UniformProjection):
+    """Sample and project away from the edges (levelset_sampling.py:442-661): UniformProjection
+    with an exact K-nearest tree, a bilateral normal filter and an upsampling step that inserts
+    points where the sampling is sparse ACROSS normal discontinuities.  Same constructor, same
+    `_create_tree` / `denoise_normals` / `upsample` signatures and results.  The neighbour search
+    (iso_frnn_* with an unbounded radius), the gathers and D_xF (fused SDF kernels) are the
+    library's; the O(P K^2) sparsity statement keeps the reference's tensor form on the GPU.
+    One cloud per call: the reference's `num_points / 2.0` broadcasts (:515,:551) only hold for
+    batch size 1."""
+
+    def __init__(self, proj_max_iters=10, proj_tolerance=5e-5, max_points_per_pass=120000, knn_k=31,
+                 repulsion_mu=0.5, sample_iters=5, total_iters=1, sharpness_angle=15, edge_sensitivity=1,
+                 resampling_clip=0.02, upsample_ratio=1.5, **kwargs):
+        super().__init__(sample_iters=sample_iters, total_iters=total_iters, resampling_clip=resampling_clip,
+                         knn_k=knn_k, proj_max_iters=proj_max_iters, proj_tolerance=proj_tolerance,
+                         max_points_per_pass=max_points_per_pass)
+        self.sharpness_sigma = 1 - math.cos(sharpness_angle / 180 * math.pi)
+        self.repulsion_mu = repulsion_mu
+        self.edge_sensitivity = edge_sensitivity
+        self.upsample_ratio = upsample_ratio
+
+    def _create_tree(self, points_padded, refresh_tree=True, num_points_per_cloud=None):
+        """:471-498 -- K+1 nearest neighbours of every point among the cloud, self dropped."""
+        from .point_processing import knn_points
+        if not refresh_tree and getattr(self, "_knn_idx", None) is not None:
+            return self._knn_idx
+        assert points_padded.ndim == 3
+        if num_points_per_cloud is None:
+            num_points_per_cloud = full_lengths(points_padded)
+        res = knn_points(points_padded, points_padded, num_points_per_cloud, num_points_per_cloud,
+                         K=self.knn_k + 1, return_nn=True, return_sorted=True)
+        self._knn_idx = res.idx[..., 1:]
+        self._knn_dists = res.dists[..., 1:]
+        self._knn_nn = res.knn[..., 1:, :]
+        self.knn_gather = frnn.frnn_gather
+        return self._knn_idx
+
+    def denoise_normals(self, points, normals, num_points, **kwargs):
+        """:500-526 -- weights exp(-((1 - <n, n_i>) / sigma)^2) exp(-|p - p_i|^2 P/2), cut at 32/P."""
+        if points.shape[0] != 1:
+            raise NotImplementedError("EdgeAwareProjection: one cloud per call (the reference's "
+                                      "num_points / 2.0 broadcast is only valid for batch size 1, :515)")
+        normals = F.normalize(normals, dim=-1)
+        knn_normals = self.knn_gather(normals, self._knn_idx, num_points)
+        self.sharpness_sigma = kwargs.get("sharpness_sigma", self.sharpness_sigma)
+        weights_n = ((1 - torch.sum(knn_normals * normals[:, :, None, :], dim=-1)) / self.sharpness_sigma) ** 2
+        weights_n = torch.exp(-weights_n)
+        inv_sigma_spatial = num_points / 2.0
+        spatial_dist = 16 / inv_sigma_spatial
+        deltap = self._knn_nn - points[:, :, None, :]
+        deltap = torch.sum(deltap * deltap, dim=-1)
+        weights_p = torch.exp(-deltap * inv_sigma_spatial)
+        weights_p = torch.where(deltap > spatial_dist, torch.zeros_like(weights_p), weights_p)
+        weights = weights_p * weights_n
+        normals_denoised = torch.sum(knn_normals * weights[:, :, :, None], dim=-2) / \
+            eps_denom(torch.sum(weights, dim=-1, keepdim=True))
+        return F.normalize(normals_denoised, dim=-1), weights_p, weights_n
+
+    def upsample(self, points, n_points, model, num_points=None, **forward_kwargs):
+        """:528-661.  points (1,P,3) on the level set; returns (points (1,P',3), num_points (1,))
+        with P' = ceil(n_points * upsample_ratio); the new points are NOT yet projected (the
+        driver does that, :429-434)."""
+        upsample_ratio = forward_kwargs.pop("upsample_ratio", self.upsample_ratio)
+        n_points = n_points * upsample_ratio
+        n_points = n_points.ceil().long() if isinstance(n_points, torch.Tensor) else int(math.ceil(n_points))
+        batch_size, P = points.shape[:2]
+        if batch_size != 1:
+            raise NotImplementedError("EdgeAwareProjection: one cloud per call (:515,:551)")
+        if num_points is None:
+            num_points = full_lengths(points)
+        self._create_tree(points, refresh_tree=True, num_points_per_cloud=num_points)
+        inv_sigma_spatial = num_points / 2.0
+        spatial_dist = 16 / inv_sigma_spatial
+        _, normals = self._compute_sdf_and_grad(points, model, **forward_kwargs)
+        normals = F.normalize(normals, dim=-1, eps=1e-15)
+        normals, _, _ = self.denoise_normals(points, normals, num_points)
+        # LOP step (:559-596): data term along the filtered normal + density-weighted repulsion.
+        dists, knn = self._knn_dists, self._knn_nn
+        move_clip = dists[..., 0].mean().sqrt()
+        diff = points[:, :, None, :] - knn
+        zero = torch.zeros((), device=points.device)
+        weight_lop = torch.exp(-torch.sum(normals[:, :, None, :] * diff, dim=-1) ** 2 * inv_sigma_spatial)
+        weight_lop = torch.where(dists > spatial_dist, zero, weight_lop)
+        spatial_w = torch.where(dists > spatial_dist, zero, torch.exp(-dists * inv_sigma_spatial))
+        density_w = torch.sum(spatial_w, dim=-1) + 1.0
+        move_data = torch.sum(weight_lop[..., None] * diff, dim=-2) / eps_denom(torch.sum(weight_lop, dim=-1, keepdim=True))
+        move_repul = self.repulsion_mu * density_w[..., None] * torch.sum(spatial_w[..., None] * (knn - points[:, :, None, :]),
+                                                                         dim=-2) / \
+            eps_denom(torch.sum(spatial_w, dim=-1, keepdim=True))
+        # (F.normalize without dim normalises over dim=1, the POINT axis: kept, :582-585)
+        move_repul = F.normalize(move_repul) * move_repul.norm(dim=-1, keepdim=True).clamp_max(move_clip)
+        move_data = F.normalize(move_data) * move_data.norm(dim=-1, keepdim=True).clamp_max(move_clip)
+        points = points - (move_data + move_repul)
+        n_remaining = n_points - num_points
+        max_P = P // 10
+        idx = self._knn_idx
+        while True:
+            if bool((n_remaining == 0).all()):
+                break
+            knn_pts = self.knn_gather(points, idx, num_points)
+            knn_normals = self.knn_gather(normals, idx, num_points)
+            mid_points = (knn_pts + 2 * points[..., None, :]) / 3
+            mid_nn_diff = mid_points.unsqueeze(-2) - knn_pts.unsqueeze(-3)                   # (1,P,K,K,3)
+            dot_product = (2 - torch.sum(normals.unsqueeze(-2) * knn_normals, dim=-1)) ** self.edge_sensitivity
+            min_dist2 = torch.norm(mid_nn_diff, dim=-1) - torch.sum((mid_nn_diff * knn_normals.unsqueeze(-2)) ** 2, dim=-1)
+            min_dist2 = min_dist2.min(dim=-1)[0].abs().clamp_min(1e-17).sqrt()              # eps_sqrt(.).sqrt()
+            father_sparsity, father_nb = (dot_product * min_dist2).max(dim=-1)
+            sparsity_sorted = father_sparsity.sort(dim=1).indices[:, -max_P:]
+            n_new_points = n_remaining.clamp(max=max_P)
+            cand = torch.gather(mid_points, 2, father_nb[..., None, None].expand(-1, -1, 1, 3)).squeeze(2)
+            new_pts = torch.gather(cand, 1, sparsity_sorted.unsqueeze(-1).expand(-1, -1, 3))
+            n_new, n_old = int(n_new_points[0]), int(num_points[0])
+            points = torch.cat([new_pts[0][-n_new:], points[0, :n_old]], dim=0).unsqueeze(0)   # ([-0:] = all, as :642)
+            n_remaining = n_remaining - n_new_points
+            num_points = n_new_points + num_points
+            self._create_tree(points, num_points_per_cloud=num_points, refresh_tree=True)
+            idx = self._knn_idx
+            _, normals = self._compute_sdf_and_grad(points, model, **forward_kwargs)
+            normals = F.normalize(normals, dim=-1)
+        return points, num_points
 
 
 class SphereTracing(LevelSetProjection):

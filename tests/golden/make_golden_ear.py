@@ -38,7 +38,7 @@ def gen_ear(L):
     p = (torch.rand(1, 900, 3, generator=g) - 0.5) * 1.3
     num = torch.tensor([900])
     pts = O.project_points(box, p, num, proj_max_iters=10).points
-    for tag, kw in (("K16", dict(knn_k=16)), ("K31_sharp", dict(knn_k=31, sharpness_angle=30, edge_sensitivity=2,
+    for tag, kw in (("K16", dict(knn_k=16, upsample_ratio=1.2)), ("K31_sharp", dict(knn_k=31, sharpness_angle=30, edge_sensitivity=2,
                                                                upsample_ratio=1.3, repulsion_mu=0.3))):
         ear = L.EdgeAwareProjection(**kw)
         ear._create_tree(pts.clone(), refresh_tree=True, num_points_per_cloud=num)

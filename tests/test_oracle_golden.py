@@ -339,7 +339,7 @@ def test_sample_network_restatement():
     assert rel_err(sample_grads(net, (out * g["w"]).sum()), g["dn_grads"]) < 1e-5
 
 
-EAR_CASES = {"K16": dict(knn_k=16),
+EAR_CASES = {"K16": dict(knn_k=16, upsample_ratio=1.2),
              "K31_sharp": dict(knn_k=31, sharpness_angle=30, edge_sensitivity=2, upsample_ratio=1.3, repulsion_mu=0.3)}
 
 
