@@ -313,6 +313,15 @@ int iso_repulse(const float* points, const float* normals, const int64_t* idx,
 int iso_upsample_candidates(const float* points, const float* knn, int64_t n, int K,
                             float* sparsity_out, float* candidates_out, void* stream);
 
+/* Edge-aware candidates of EdgeAwareProjection.upsample (DSS/models/levelset_sampling.py:609-628):
+ * per point p (unit normal n) with neighbours nn_k (knn (n,K,3)) of unit normals u_k (knn_normals):
+ * mid_k = (nn_k + 2p)/3, d_kj = mid_k - nn_j,
+ * m_k = sqrt(max(|min_j (|d_kj| - sum_c (d_kj,c u_k,c)^2)|, 1e-17)), edge_k = (2 - n.u_k)^edge_sensitivity,
+ * sparsity = max_k edge_k m_k, candidate = mid_argmax (first maximum).  K <= 64.             */
+int iso_ear_candidates(const float* points, const float* normals, const float* knn,
+                       const float* knn_normals, int64_t n, int K, float edge_sensitivity,
+                       float* sparsity_out, float* candidates_out, void* stream);
+
 /* Farthest-point sampling = torch_cluster.fps as wlop uses it
  * (DSS/utils/point_processing.py:473-499): per cloud n, out_idx[n, 0..n_samples[n]) =
  * start[n], then repeatedly the point farthest from the chosen set (squared f32 distances,

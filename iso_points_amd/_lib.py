@@ -46,6 +46,7 @@ SIGNATURES = {
     "iso_raymarch_overshoot": (_I, [_P, _P, _L, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
     "iso_raymarch_secant": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "iso_image_sample": (_I, [_P, _I, _I, _I, _I, _P, _L, _I, _P, _P]),
+    "iso_ear_candidates": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "iso_points_bbox": (_I, [_P, _P, _I, _L, _P, _P]),
     "iso_frnn_make_grid": (_I, [_P, _P, _P, _I, _L, _I, _P, _P]),
     "iso_frnn_insert_points": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),

@@ -143,3 +143,89 @@ extern "C" int iso_upsample_candidates(const float* points, const float* knn, in
   ISO_CHECK_LAUNCH("iso_upsample_candidates");
   return ISO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Edge-aware candidates of EdgeAwareProjection.upsample (DSS/models/levelset_sampling.py:609-628):
+// for every point p (normal n) with neighbours nn_k (normals u_k):
+//   mid_k    = (nn_k + 2 p) / 3 ,  d_kj = mid_k - nn_j
+//   m_k      = sqrt(max(| min_j ( |d_kj| - sum_c (d_kj,c u_k,c)^2 ) |, 1e-17))    (as written at :620-625:
+//              the norm minus the sum of SQUARED COMPONENT PRODUCTS with the normal of neighbour k --
+//              `knn_normals.unsqueeze(-2)` broadcasts over j -- not a squared dot product)
+//   edge_k   = (2 - n . u_k) ^ edge_sensitivity
+//   sparsity = max_k edge_k m_k ,  candidate = mid_argmax (first maximum)
+// Same lane-owns-a-point layout as k_upsample_candidates with the neighbour normals next to the
+// neighbour positions in LDS (K*24 B per lane).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_ear_candidates(
+    const float* __restrict__ pts, const float* __restrict__ nrm, const float* __restrict__ knn,
+    const float* __restrict__ knn_nrm, int64_t n, int K, float edge_sensitivity,
+    float* __restrict__ sparsity, float* __restrict__ cand) {
+  extern __shared__ float s_ear[];   // [K*3][BLOCK] positions, then [K*3][BLOCK] normals
+  float* s_p = s_ear;
+  float* s_u = s_ear + (size_t)K * 3 * BLOCK;
+  const int t = threadIdx.x;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + t; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+    const float nx = nrm[i * 3], ny = nrm[i * 3 + 1], nz = nrm[i * 3 + 2];
+    for (int k = 0; k < K * 3; ++k) {
+      s_p[k * BLOCK + t] = knn[i * K * 3 + k];
+      s_u[k * BLOCK + t] = knn_nrm[i * K * 3 + k];
+    }
+    float best = -__builtin_inff();
+    float bx = px, by = py, bz = pz;
+    for (int k = 0; k < K; ++k) {
+      const float mx = (s_p[(k * 3) * BLOCK + t] + 2.0f * px) / 3.0f;
+      const float my = (s_p[(k * 3 + 1) * BLOCK + t] + 2.0f * py) / 3.0f;
+      const float mz = (s_p[(k * 3 + 2) * BLOCK + t] + 2.0f * pz) / 3.0f;
+      const float ux = s_u[(k * 3) * BLOCK + t], uy = s_u[(k * 3 + 1) * BLOCK + t], uz = s_u[(k * 3 + 2) * BLOCK + t];
+      float mn = __builtin_inff();
+      for (int j = 0; j < K; ++j) {
+        const float dx = mx - s_p[(j * 3) * BLOCK + t], dy = my - s_p[(j * 3 + 1) * BLOCK + t],
+                    dz = mz - s_p[(j * 3 + 2) * BLOCK + t];
+        const float ax = dx * ux, ay = dy * uy, az = dz * uz;
+        const float v = sqrtf((dx * dx + dy * dy) + dz * dz) - ((ax * ax + ay * ay) + az * az);
+        mn = v < mn ? v : mn;
+      }
+      mn = fabsf(mn);
+      mn = sqrtf(mn > 1.0e-17f ? mn : 1.0e-17f);
+      const float dotn = (nx * ux + ny * uy) + nz * uz;
+      float edge = 2.0f - dotn;
+      if (edge_sensitivity == 2.0f) edge = edge * edge;
+      else if (edge_sensitivity != 1.0f) edge = powf(edge, edge_sensitivity);
+      const float val = edge * mn;
+      if (val > best) { best = val; bx = mx; by = my; bz = mz; }
+    }
+    sparsity[i] = best;
+    cand[i * 3] = bx; cand[i * 3 + 1] = by; cand[i * 3 + 2] = bz;
+  }
+}
+
+}  // namespace
+
+extern "C" int iso_ear_candidates(const float* points, const float* normals, const float* knn,
+                                  const float* knn_normals, int64_t n, int K, float edge_sensitivity,
+                                  float* sparsity_out, float* candidates_out, void* stream) {
+  ISO_REQUIRE(n >= 0 && K >= 1 && K <= 64, ISO_ERR_INVALID, "iso_ear_candidates: bad sizes (1 <= K <= 64)");
+  if (n == 0) return ISO_OK;
+  ISO_REQUIRE(points && normals && knn && knn_normals && sparsity_out && candidates_out, ISO_ERR_INVALID,
+              "iso_ear_candidates: null pointer");
+  constexpr int BLOCK = 64;
+  const size_t lds = (size_t)K * 6 * BLOCK * sizeof(float);   // <= 96 KiB at K = 64
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute((const void*)k_ear_candidates<BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            64 * 6 * BLOCK * (int)sizeof(float)) != hipSuccess) {
+      iso_set_error("iso_ear_candidates: cannot raise the dynamic LDS limit");
+      return ISO_ERR_LAUNCH;
+    }
+    raised = true;
+  }
+  hipLaunchKernelGGL(k_ear_candidates<BLOCK>, dim3(iso_stream_grid(n, BLOCK)), dim3(BLOCK), lds,
+                     (hipStream_t)stream, points, normals, knn, knn_normals, n, K, edge_sensitivity,
+                     sparsity_out, candidates_out);
+  ISO_CHECK_LAUNCH("iso_ear_candidates");
+  return ISO_OK;
+}

@@ -413,7 +413,7 @@ class EdgeAwareProjection(UniformProjection):
     points where the sampling is sparse ACROSS normal discontinuities.  Same constructor, same
     `_create_tree` / `denoise_normals` / `upsample` signatures and results.  The neighbour search
     (iso_frnn_* with an unbounded radius), the gathers and D_xF (fused SDF kernels) are the
-    library's; the O(P K^2) sparsity statement keeps the reference's tensor form on the GPU.
+    library's; the O(P K^2) sparsity statement is one kernel (iso_ear_candidates).
     One cloud per call: the reference's `num_points / 2.0` broadcasts (:515,:551) only hold for
     batch size 1."""
 
@@ -508,15 +508,15 @@ class EdgeAwareProjection(UniformProjection):
                 break
             knn_pts = self.knn_gather(points, idx, num_points)
             knn_normals = self.knn_gather(normals, idx, num_points)
-            mid_points = (knn_pts + 2 * points[..., None, :]) / 3
-            mid_nn_diff = mid_points.unsqueeze(-2) - knn_pts.unsqueeze(-3)                   # (1,P,K,K,3)
-            dot_product = (2 - torch.sum(normals.unsqueeze(-2) * knn_normals, dim=-1)) ** self.edge_sensitivity
-            min_dist2 = torch.norm(mid_nn_diff, dim=-1) - torch.sum((mid_nn_diff * knn_normals.unsqueeze(-2)) ** 2, dim=-1)
-            min_dist2 = min_dist2.min(dim=-1)[0].abs().clamp_min(1e-17).sqrt()              # eps_sqrt(.).sqrt()
-            father_sparsity, father_nb = (dot_product * min_dist2).max(dim=-1)
+            # :609-633 -- sparsest candidate per point across normal discontinuities: one fused
+            # O(K^2)-per-point kernel instead of the (1,P,K,K,3) tensor (11.5 kB/point at K = 31)
+            father_sparsity = torch.empty(points.shape[:2], dtype=torch.float32, device=points.device)
+            cand = torch.empty_like(points)
+            args = [t.float().contiguous() for t in (points, normals, knn_pts, knn_normals)]
+            _lib.call("iso_ear_candidates", *[_lib.ptr(t) for t in args], points.shape[1], idx.shape[-1],
+                      float(self.edge_sensitivity), _lib.ptr(father_sparsity), _lib.ptr(cand), _lib.stream())
             sparsity_sorted = father_sparsity.sort(dim=1).indices[:, -max_P:]
             n_new_points = n_remaining.clamp(max=max_P)
-            cand = torch.gather(mid_points, 2, father_nb[..., None, None].expand(-1, -1, 1, 3)).squeeze(2)
             new_pts = torch.gather(cand, 1, sparsity_sorted.unsqueeze(-1).expand(-1, -1, 3))
             n_new, n_old = int(n_new_points[0]), int(num_points[0])
             points = torch.cat([new_pts[0][-n_new:], points[0, :n_old]], dim=0).unsqueeze(0)   # ([-0:] = all, as :642)

@@ -61,3 +61,29 @@ def test_edge_aware_siren_vs_oracle(dev):
     assert res.mask.float().mean() > 0.99
     with pytest.raises(NotImplementedError):
         ear.upsample(torch.cat([pts, pts]).to(dev), 1500, net, None)
+
+
+@pytest.mark.parametrize("sens", [1, 2, 1.5])
+def test_ear_candidates_kernel(dev, sens):
+    """The fused K^2 scan == the reference's (N,P,K,K,3) tensor expression (:609-628)."""
+    from iso_points_amd import _lib
+    gen = torch.Generator().manual_seed(4)
+    P, K = 3000, 31
+    pts = torch.rand(1, P, 3, generator=gen)
+    nrm = torch.nn.functional.normalize(torch.randn(1, P, 3, generator=gen), dim=-1)
+    knn = pts[:, :, None, :] + 0.05 * torch.randn(1, P, K, 3, generator=gen)
+    knn_n = torch.nn.functional.normalize(nrm[:, :, None, :] + 0.5 * torch.randn(1, P, K, 3, generator=gen), dim=-1)
+    mid = (knn + 2 * pts[..., None, :]) / 3
+    d = mid.unsqueeze(-2) - knn.unsqueeze(-3)
+    edge = (2 - torch.sum(nrm.unsqueeze(-2) * knn_n, dim=-1)) ** sens
+    m = torch.norm(d, dim=-1) - torch.sum((d * knn_n.unsqueeze(-2)) ** 2, dim=-1)
+    m = m.min(dim=-1)[0].abs().clamp_min(1e-17).sqrt()
+    sp_ref, nb = (edge * m).max(dim=-1)
+    cand_ref = torch.gather(mid, 2, nb[..., None, None].expand(-1, -1, 1, 3)).squeeze(2)
+    sp = torch.empty(1, P, device=dev)
+    cand = torch.empty(1, P, 3, device=dev)
+    a = [t.to(dev).contiguous() for t in (pts, nrm, knn, knn_n)]
+    _lib.call("iso_ear_candidates", *[_lib.ptr(t) for t in a], P, K, float(sens), _lib.ptr(sp), _lib.ptr(cand),
+              _lib.stream())
+    assert rel_err(sp, sp_ref) < 2e-6
+    assert ((cand.cpu() - cand_ref).abs().amax(-1) > 1e-6).float().mean() < 2e-3     # near-equal maxima
