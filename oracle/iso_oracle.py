@@ -952,7 +952,8 @@ def ear_upsample(points, n_points, model, num_points=None, knn_k=31, repulsion_m
     """EdgeAwareProjection.upsample, levelset_sampling.py:528-661, one cloud (the reference's
     `num_points / 2.0` broadcasts are only valid for batch size 1).  Kept as written there,
     including F.normalize(move) over dim=1 -- the POINT axis -- at :582-585."""
-    n_points = int(math.ceil(n_points * upsample_ratio))
+    n_points = n_points * upsample_ratio                                                    # :535-540
+    n_points = n_points.ceil().long() if torch.is_tensor(n_points) else int(math.ceil(n_points))
     B, P = points.shape[:2]
     assert B == 1
     if num_points is None:
@@ -1000,3 +1001,24 @@ def ear_upsample(points, n_points, model, num_points=None, knn_k=31, repulsion_m
         _, normals = compute_sdf_and_grad(points, model)
         normals = F.normalize(normals, dim=-1)
     return points, num_points
+
+
+def ear_project_points(points, model, knn_k=31, sample_iters=5, proj_max_iters=10, **ear_kw):
+    """LevelSetProjection driver (levelset_sampling.py:353-440) as EdgeAwareProjection runs it, one
+    cloud, no ref_pcl: project, drop the unconverged, resample on the K-nearest tree, edge-aware
+    upsample to ceil(P * ratio), project."""
+    num_init = torch.tensor([points.shape[1]])
+    r = project_points(model, points, num_init, proj_max_iters=proj_max_iters)
+    keep = r.mask[0]
+    pts, nrm = r.points[:, keep], r.normals[:, keep]
+    num = keep.sum().view(1)
+
+    def tree(p1, p2, l1, l2, K, r):
+        t = knn_points(p1, p2, l1, l2, K=K, return_nn=True)
+        return t.dists, t.idx, t.knn, None
+    r = resample(model, pts, nrm, num, sample_iters=sample_iters, knn_k=knn_k, frnn_fn=tree)
+    keep = r.mask[0]
+    pts = r.points[:, keep]
+    num = keep.sum().view(1)
+    up, num = ear_upsample(pts, num_init, model, num, knn_k=knn_k, **ear_kw)
+    return project_points(model, up, num, proj_max_iters=10)

@@ -47,3 +47,10 @@ def gen_ear(L):
         up, n_up = ear.upsample(pts.clone(), 900, box, num.clone())
         npz("ear_%s.npz" % tag, points=pts, normals=n0, denoised=nd, weights_p=wp, weights_n=wn, out_points=up, out_num=n_up,
             **{"kw_" + k: v for k, v in kw.items()})
+    # the inherited driver (project -> resample on the K-nearest tree -> edge-aware upsample -> project)
+    sph = O.SphereSDF()
+    far = torch.nn.functional.normalize(torch.randn(1, 1200, 3, generator=g), dim=-1) * (1 + 0.1 * (torch.rand(1, 1200, 1, generator=g) - 0.5))
+    kw = dict(knn_k=12, sample_iters=2, upsample_ratio=1.1)
+    out = L.EdgeAwareProjection(**kw).project_points(far.clone(), sph)
+    npz("ear_driver.npz", points=far, levelset_points=out["levelset_points"], levelset_normals=out["levelset_normals"],
+        mask=out["mask"], **{"kw_" + k: v for k, v in kw.items()})

@@ -87,3 +87,19 @@ def test_ear_candidates_kernel(dev, sens):
               _lib.stream())
     assert rel_err(sp, sp_ref) < 2e-6
     assert ((cand.cpu() - cand_ref).abs().amax(-1) > 1e-6).float().mean() < 2e-3     # near-equal maxima
+
+
+def test_edge_aware_driver_golden(dev):
+    """EdgeAwareProjection.project_points (inherited driver: project -> resample on the K-nearest
+    tree -> edge-aware upsample -> project) vs the reference's own run."""
+    from iso_points_amd.levelset_sampling import EdgeAwareProjection
+    from iso_points_amd.sdf_models import SphereSDF
+    g = load("ear_driver.npz")
+    ear = EdgeAwareProjection(knn_k=12, sample_iters=2, upsample_ratio=1.1)
+    out = ear.project_points(g["points"].to(dev), SphereSDF().to(dev))
+    assert out["levelset_points"].shape == g["levelset_points"].shape
+    assert torch.equal(out["mask"].cpu(), g["mask"])
+    P = g["points"].shape[1]
+    d = (out["levelset_points"][0].cpu() - g["levelset_points"][0]).abs().amax(-1)
+    assert (d[-P:] > 1e-5).float().mean() < 5e-3            # the resampled input points
+    assert (d[:-P] > 1e-5).float().mean() < 0.03            # the inserted ones (a cut in a sorted list)

@@ -360,3 +360,14 @@ def test_edge_aware_restatement():
         up, n = O.ear_upsample(g["points"], g["points"].shape[1], box, num.clone(), **kw)
         assert torch.equal(n, g["out_num"]) and up.shape == g["out_points"].shape
         assert rel_err(up, g["out_points"]) < TIGHT
+
+
+def test_edge_aware_driver_restatement():
+    """project -> resample (K-nearest tree) -> edge-aware upsample -> project, as the reference's
+    EdgeAwareProjection.project_points runs it."""
+    from oracle import iso_oracle as O
+    g = load("ear_driver.npz")
+    res = O.ear_project_points(g["points"], O.SphereSDF(), knn_k=12, sample_iters=2, upsample_ratio=1.1)
+    assert res.points.shape == g["levelset_points"].shape
+    assert_projection_close(res.points, g["levelset_points"], tol=TIGHT)
+    assert torch.equal(res.mask, g["mask"])
