@@ -5,6 +5,7 @@
   wlop                point_processing.py:35-122    FPS subsample + 3 LOP iterations
   farthest_sampling   point_processing.py:473-499   (torch_cluster.fps)
   knn_points          pytorch3d.ops.knn_points as upsample uses it (:315,:358)
+  denoise_normals     point_processing.py:241-278   bilateral normal filter on the FRNN neighbourhood
 
 Inputs are padded tensors (N,P,3) + lengths (pytorch3d's Pointclouds container is out of scope;
 objects exposing points_padded()/num_points_per_cloud() are accepted).  Neighbour search, the
@@ -204,3 +205,39 @@ def resample_uniformly(points, num_points=None, neighborhood_size=8, shrink_rati
         num = num_points
     X, num_X = wlop(pts, num, ratio=shrink_ratio, repulsion_mu=repulsion_mu, generator=generator)
     return upsample(X, num, num_points=num_X)
+
+
+def denoise_normals(points, normals, sharpness_sigma=30, knn_result=None, neighborhood_size=16):
+    """Bilateral normal filter (point_processing.py:241-278), one cloud: weights
+    exp(-((1 - <n, n_i>) / sharpness_sigma)^2) exp(-|p - p_i|^2 P/2) cut at |p - p_i|^2 > 32/P, over
+    the FRNN neighbourhood of radius min(4 sqrt(diag/P) K, 0.2).  `sharpness_sigma` divides as given
+    (the reference does not convert the angle here, :263).  A `knn_result` must carry idx (and dists);
+    its `knn` is gathered when missing (the reference's own branch for a given `knn` reads an
+    unbound local, :269)."""
+    points, num_points = convert_pointclouds_to_tensor(points)
+    if not points.is_cuda:
+        raise RuntimeError("iso_points_amd: points must be on the GPU; there is no CPU path")
+    if points.shape[0] != 1:
+        raise NotImplementedError("denoise_normals: one cloud per call (math.sqrt(diag / P) at :249 "
+                                  "needs a single-element tensor)")
+    normals = torch.nn.functional.normalize(normals, dim=-1)
+    if knn_result is None:
+        diag = (points.max(dim=-2)[0] - points.min(dim=-2)[0]).norm(dim=-1)
+        avg_spacing = math.sqrt(diag / points.shape[1])
+        search_radius = min(4 * avg_spacing * neighborhood_size, 0.2)
+        dists, idxs, _, _ = frnn.frnn_grid_points(points, points, num_points, num_points,
+                                                  K=neighborhood_size + 1, r=search_radius, grid=None, return_nn=True)
+        knn_result = _KNN(dists=dists[..., 1:], idx=idxs[..., 1:], knn=None)
+    knn = knn_result.knn if knn_result.knn is not None else frnn.frnn_gather(points, knn_result.idx, num_points)
+    knn_normals = frnn.frnn_gather(normals, knn_result.idx, num_points)
+    weights_n = torch.exp(-((1 - torch.sum(knn_normals * normals[:, :, None, :], dim=-1)) / sharpness_sigma) ** 2)
+    inv_sigma_spatial = num_points / 2.0
+    spatial_dist = 16 / inv_sigma_spatial
+    deltap = knn - points[:, :, None, :]
+    deltap = torch.sum(deltap * deltap, dim=-1)
+    weights_p = torch.exp(-deltap * inv_sigma_spatial)
+    weights_p = torch.where(deltap > spatial_dist, torch.zeros_like(weights_p), weights_p)
+    weights = weights_p * weights_n
+    normals_denoised = torch.sum(knn_normals * weights[:, :, :, None], dim=-2) / \
+        eps_denom(torch.sum(weights, dim=-1, keepdim=True))
+    return torch.nn.functional.normalize(normals_denoised, dim=-1).view_as(normals)

@@ -1022,3 +1022,25 @@ def ear_project_points(points, model, knn_k=31, sample_iters=5, proj_max_iters=1
     num = keep.sum().view(1)
     up, num = ear_upsample(pts, num_init, model, num, knn_k=knn_k, **ear_kw)
     return project_points(model, up, num, proj_max_iters=10)
+
+
+def denoise_normals(points, normals, sharpness_sigma=30, neighborhood_size=16):
+    """point_processing.denoise_normals, DSS/utils/point_processing.py:241-278 (knn_result=None, one
+    cloud): FRNN neighbourhood of radius min(4 sqrt(diag/P) K, 0.2), bilateral weights."""
+    num_points = torch.tensor([points.shape[1]])
+    normals = F.normalize(normals, dim=-1)
+    diag = (points.max(dim=-2)[0] - points.min(dim=-2)[0]).norm(dim=-1)
+    r = min(4 * math.sqrt(diag / points.shape[1]) * neighborhood_size, 0.2)
+    _, idxs, _, _ = frnn_grid_points(points, points, num_points, num_points, K=neighborhood_size + 1, r=r)
+    idx = idxs[..., 1:]
+    knn = frnn_gather(points, idx, num_points)
+    knn_normals = frnn_gather(normals, idx, num_points)
+    weights_n = torch.exp(-((1 - torch.sum(knn_normals * normals[:, :, None, :], dim=-1)) / sharpness_sigma) ** 2)
+    inv_sigma = num_points / 2.0
+    deltap = knn - points[:, :, None, :]
+    deltap = torch.sum(deltap * deltap, dim=-1)
+    weights_p = torch.exp(-deltap * inv_sigma)
+    weights_p[deltap > 16 / inv_sigma] = 0
+    weights = weights_p * weights_n
+    out = torch.sum(knn_normals * weights[:, :, :, None], dim=-2) / eps_denom(torch.sum(weights, dim=-1, keepdim=True))
+    return F.normalize(out, dim=-1).view_as(normals)

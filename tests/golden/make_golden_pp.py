@@ -120,6 +120,14 @@ def gen_pp(L):
     out = PP.wlop(Clouds([P[0]]), ratio=1.0, neighborhood_size=16, iters=3, repulsion_mu=0.5)
     npz("wlop_ratio1.npz", points=P, seed=123, K=16, iters=3, mu=0.5, out_points=out.points_padded())
 
+    # bilateral normal filter (FRNN neighbourhood), noisy normals on a sphere
+    pn = sphere_cloud(2500, 91, jitter=0.0)
+    gn = torch.Generator().manual_seed(92)
+    noisy = torch.nn.functional.normalize(pn + 0.4 * torch.randn(1, 2500, 3, generator=gn), dim=-1) * 1.7
+    for K, sig in ((16, 30), (30, 0.5)):
+        dn = PP.denoise_normals(pn.clone(), noisy.clone(), sharpness_sigma=sig, neighborhood_size=K)
+        npz("denoise_normals_K%d.npz" % K, points=pn, normals=noisy, K=K, sigma=sig, out=dn)
+
     # insert
     pts = sphere_cloud(3000, 81, jitter=0.0)
     g = torch.Generator().manual_seed(82)

@@ -371,3 +371,13 @@ def test_edge_aware_driver_restatement():
     assert res.points.shape == g["levelset_points"].shape
     assert_projection_close(res.points, g["levelset_points"], tol=TIGHT)
     assert torch.equal(res.mask, g["mask"])
+
+
+@pytest.mark.parametrize("K", [16, 30])
+def test_denoise_normals_restatement(K):
+    """oracle denoise_normals vs the reference's point_processing.denoise_normals (:241-278)."""
+    from oracle import iso_oracle as O
+    g = load("denoise_normals_K%d.npz" % K)
+    out = O.denoise_normals(g["points"], g["normals"], sharpness_sigma=g["sigma"], neighborhood_size=K)
+    assert rel_err(out, g["out"]) < TIGHT
+    assert rel_err(torch.nn.functional.normalize(g["normals"], dim=-1), g["out"]) > 0.05    # it did something

@@ -187,3 +187,13 @@ def test_sample_uniform_iso_points(dev):
     d.fill_diagonal_(10.0)
     nn = d.min(dim=1).values
     assert (nn.std() / nn.mean()).item() < 0.35
+
+
+@pytest.mark.parametrize("K", [16, 30])
+def test_denoise_normals_golden(dev, K):
+    from iso_points_amd.point_processing import denoise_normals
+    g = load("denoise_normals_K%d.npz" % K)
+    out = denoise_normals(g["points"].to(dev), g["normals"].to(dev), sharpness_sigma=g["sigma"], neighborhood_size=K)
+    assert out.shape == g["out"].shape and rel_err(out, g["out"]) < 1e-5
+    with pytest.raises(NotImplementedError):
+        denoise_normals(torch.cat([g["points"], g["points"]]).to(dev), torch.cat([g["normals"], g["normals"]]).to(dev))
