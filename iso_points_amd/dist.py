@@ -149,23 +149,7 @@ class IsoCycle(object):
         if c.world == 1:
             ndc, info = ss.per_point_info(pts_f, nrm_f, first, num, self.views, self.projs)
         else:
-            # h: every rank queries rows [qlo, qhi) of each (padded) view cloud, then sum-reduce
-            mx = max(lens) if lens else 0
-            padded = torch.zeros((N, max(mx, 1), 3), dtype=torch.float32, device=dev)
-            for i in range(N):
-                padded[i, :lens[i]] = pts_f[fl[i]:fl[i] + lens[i]]
-            r7 = torch.full((N,), float(ss.frnn_radius), dtype=torch.float32, device=dev)
-            grid = frnn.build_grid(padded, num, r7)
-            qlo, qhi = shard_bounds(mx, c.world, c.rank)
-            qlens = [min(max(l - qlo, 0), qhi - qlo) for l in lens]
-            h = torch.zeros((tot,), dtype=torch.float32, device=dev)
-            if qhi > qlo:
-                qnum = with_host_lengths(torch.tensor(qlens, dtype=torch.int64, device=dev), qlens)
-                dists, _, _, _ = frnn.frnn_grid_points(padded[:, qlo:qhi].contiguous(), padded, qnum, num, K=7,
-                                                       r=r7, grid=grid)
-                qfirst = torch.tensor([f + qlo for f in fl], dtype=torch.int64, device=dev)
-                _lib.call("iso_splat_vrk_h", _lib.ptr(dists), _lib.ptr(qfirst), _lib.ptr(qnum), _lib.ptr(num),
-                          _lib.ptr(h), N, dists.shape[1], _lib.stream())
+            h = self._h_share(pts_f, lens, fl, num, tot)
             c.all_reduce_(h, "sum")
             ndc, info = self._setup_with_h(pts_f, nrm_f, h, first, num)
         T = _lib.load().iso_splat_tiles_per_side(S)
@@ -178,6 +162,50 @@ class IsoCycle(object):
         filt = {"points": pts_f, "normals": nrm_f, "features": feat_f, "ndc": ndc, "num_points": num,
                 "first_idx": first, **info}
         return frags, filt
+
+    def _h_share(self, pts_f, lens, fl, num, tot):
+        """This rank's part of h (rasterizer.py:367-386: K=7 self query per view cloud), zero
+        elsewhere -- the caller sum-reduces.  With at least as many ranks as views (and a multiple
+        of them) a view belongs to world/N ranks: each builds ONLY that view's grid and queries its
+        share of that view's rows.  Otherwise every rank builds all N grids and queries rows
+        [qlo, qhi) of each (padded) view cloud."""
+        c, ss = self.comm, self.splat
+        dev = pts_f.device
+        N = len(lens)
+        h = torch.zeros((tot,), dtype=torch.float32, device=dev)
+        if N > 0 and c.world >= N and c.world % N == 0:
+            per_view = c.world // N
+            v, part = c.rank // per_view, c.rank % per_view
+            lv = lens[v]
+            qlo, qhi = shard_bounds(lv, per_view, part)
+            if qhi > qlo:
+                cloud = pts_f[fl[v]:fl[v] + lv].view(1, lv, 3)
+                num_v = with_host_lengths(torch.tensor([lv], dtype=torch.int64, device=dev), [lv])
+                r7 = torch.full((1,), float(ss.frnn_radius), dtype=torch.float32, device=dev)
+                grid = frnn.build_grid(cloud, num_v, r7)
+                qnum = with_host_lengths(torch.tensor([qhi - qlo], dtype=torch.int64, device=dev), [qhi - qlo])
+                dists, _, _, _ = frnn.frnn_grid_points(cloud[:, qlo:qhi].contiguous(), cloud, qnum, num_v, K=7,
+                                                       r=r7, grid=grid)
+                qfirst = torch.tensor([fl[v] + qlo], dtype=torch.int64, device=dev)
+                _lib.call("iso_splat_vrk_h", _lib.ptr(dists), _lib.ptr(qfirst), _lib.ptr(qnum), _lib.ptr(num_v),
+                          _lib.ptr(h), 1, dists.shape[1], _lib.stream())
+            return h
+        mx = max(lens) if lens else 0
+        padded = torch.zeros((N, max(mx, 1), 3), dtype=torch.float32, device=dev)
+        for i in range(N):
+            padded[i, :lens[i]] = pts_f[fl[i]:fl[i] + lens[i]]
+        r7 = torch.full((N,), float(ss.frnn_radius), dtype=torch.float32, device=dev)
+        grid = frnn.build_grid(padded, num, r7)
+        qlo, qhi = shard_bounds(mx, c.world, c.rank)
+        qlens = [min(max(l - qlo, 0), qhi - qlo) for l in lens]
+        if qhi > qlo:
+            qnum = with_host_lengths(torch.tensor(qlens, dtype=torch.int64, device=dev), qlens)
+            dists, _, _, _ = frnn.frnn_grid_points(padded[:, qlo:qhi].contiguous(), padded, qnum, num, K=7,
+                                                   r=r7, grid=grid)
+            qfirst = torch.tensor([f + qlo for f in fl], dtype=torch.int64, device=dev)
+            _lib.call("iso_splat_vrk_h", _lib.ptr(dists), _lib.ptr(qfirst), _lib.ptr(qnum), _lib.ptr(num),
+                      _lib.ptr(h), N, dists.shape[1], _lib.stream())
+        return h
 
     def _setup_with_h(self, pts_f, nrm_f, h, first, num):
         rs = self.rs
