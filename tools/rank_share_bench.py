@@ -5,7 +5,7 @@ strong-scaling curve the driver measures, and a per-stage view of what does not 
 usage: python tools/rank_share_bench.py [--model sphere|siren]"""
 import argparse, json, os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import bench
 from iso_points_amd.dist import Comm, shard_bounds
 from iso_points_amd.sdf_models import SphereSDF
@@ -39,9 +39,7 @@ class ShareOfN(Comm):
 
 
 if args.model == "siren":
-    from oracle import iso_oracle as O          # model definition + fit only (as bench.py)
-    from util import fitted_siren
-    model = fitted_siren(O, 256, 3, seed=0, fit=200).to(dev)
+    model = bench.fitted_siren(dev)             # the bench's own network
 else:
     model = SphereSDF().to(dev)
 
