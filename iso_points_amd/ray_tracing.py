@@ -6,9 +6,9 @@ Every network evaluation goes through the `sdf` callable the caller passes -- bu
 MFMA, IDR x16).  What differs from the reference is the shape of the work handed to that callable:
 the reference treats the two marching ends separately and compacts each with boolean masks before
 every call (2 network calls, 2 masked scatters and several host syncs per iteration); here both
-ends are one (2,R) state, finished rays are held with `where`, and each iteration makes ONE network
-call on the still-unfinished rows of the (2R,3) batch (listed by one `nonzero`, whose row count is
-also the loop condition the reference reads with `.sum() == 0`).  The statements between two
+ends are one (2,R) state and each iteration makes ONE network call on the still-unfinished ends,
+compacted into a list by the kernel that updates the state (its length is the loop condition the
+reference reads with `.sum() == 0`, and the only host read).  The statements between two
 network calls -- threshold, masks, advance, overshoot back-step, the next call's point list and
 its length -- are one HIP kernel each (csrc/raymarch.hip: iso_raymarch_settle / _overshoot, and
 iso_raymarch_secant for the false-position update).  Per ray the arithmetic is the

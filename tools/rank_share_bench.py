@@ -13,6 +13,7 @@ from iso_points_amd.sdf_models import SphereSDF
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="siren")
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--world", type=int, default=0, help="only this N (for kernel traces); default 1,2,4,8")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 
@@ -85,7 +86,7 @@ r0 = one.cyc._project(one.cyc.pts0_local, 10)
 r1 = one.cyc.project_resample()
 full = [r0.points[0].clone(), r0.normals[0].clone(), r1.points[0].clone(), r1.normals[0].clone()]
 res = {}
-for world in (1, 2, 4, 8):
+for world in ((args.world,) if args.world else (1, 2, 4, 8)):
     comm = ShareOfN(world, full)
     cyc = bench.Cycle(dev, model, comm)
     for _ in range(2):
@@ -103,8 +104,9 @@ for world in (1, 2, 4, 8):
         st = {"error": repr(e)}
     res[world] = {"ms_per_step_rank0": ms, "ceiling_speedup": None, "stages_ms": st}
     print(world, "ms/step %.3f" % ms, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}, flush=True)
-for w in res:
-    res[w]["ceiling_speedup"] = res[1]["ms_per_step_rank0"] / res[w]["ms_per_step_rank0"]
-print({w: round(res[w]["ceiling_speedup"], 2) for w in res})
+if 1 in res:
+    for w in res:
+        res[w]["ceiling_speedup"] = res[1]["ms_per_step_rank0"] / res[w]["ms_per_step_rank0"]
+    print({w: round(res[w]["ceiling_speedup"], 2) for w in res})
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "rank_share_%s.json" % args.model), "w"), indent=1)
