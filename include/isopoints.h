@@ -228,6 +228,14 @@ int iso_points_bbox(const float* points, const int64_t* lengths, int n_clouds,
 int iso_frnn_make_grid(const float* points, const int64_t* lengths,
                        const float* radius, int n_clouds, int64_t p_stride,
                        int max_res, float* grid_params, void* stream);
+/* The same with the density target spelled out: about `points_per_cell` points per occupied cell
+ * on a surface (iso_frnn_make_grid = 8).  An exact K-nearest search (r = inf) finishes inside the
+ * 3x3x3 cell neighbourhood -- the fast path of the query -- when the K-th neighbour is closer
+ * than one cell; measured optimum points_per_cell ~ 0.75 K (K = 32, 150 k points on a surface:
+ * 0.9 ms instead of 3.7 ms); results do not depend on the choice.                           */
+int iso_frnn_make_grid_density(const float* points, const int64_t* lengths, const float* radius,
+                               int n_clouds, int64_t p_stride, int max_res, float points_per_cell,
+                               float* grid_params, void* stream);
 
 /* frnn._C.insert_points_cuda: cell id and arrival slot of each point;
  * cnt (N,G) must be zero on entry.  dim = 2 or 3 (points have `dim` floats).  */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "iso_ear_candidates": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "iso_points_bbox": (_I, [_P, _P, _I, _L, _P, _P]),
     "iso_frnn_make_grid": (_I, [_P, _P, _P, _I, _L, _I, _P, _P]),
+    "iso_frnn_make_grid_density": (_I, [_P, _P, _P, _I, _L, _I, _F, _P, _P]),
     "iso_frnn_insert_points": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _P]),
     "iso_prefix_sum_workspace_bytes": (_L, [_L, _I]),
     "iso_prefix_sum": (_I, [_P, _P, _L, _I, _L, _P, _L, _P]),

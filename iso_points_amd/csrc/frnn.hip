@@ -109,7 +109,8 @@ __global__ void k_bbox_decode(unsigned* __restrict__ keys, const int64_t* __rest
 __global__ void k_grid_finalize(float* __restrict__ params,
                                 const int64_t* __restrict__ lengths,
                                 int64_t p_stride,
-                                const float* __restrict__ radius, int n_clouds, int max_res) {
+                                const float* __restrict__ radius, int n_clouds, int max_res,
+                                float cells_per_point) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= n_clouds) return;
   unsigned* keys = reinterpret_cast<unsigned*>(params + n * 8);
@@ -125,8 +126,8 @@ __global__ void k_grid_finalize(float* __restrict__ params,
   float ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
   float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
   float r = radius[n];
-  // density-driven resolution: ~8 points per occupied cell on a 2-manifold
-  float nres = ceilf(sqrtf((float)len * 0.125f));
+  // density-driven resolution: ~1/cells_per_point (default 8) points per occupied cell on a 2-manifold
+  float nres = ceilf(sqrtf((float)len * cells_per_point));
   nres = fminf(fmaxf(nres, 1.f), (float)max_res);
   float cell = emax / nres;
   float half_r = 0.5f * r;
@@ -732,11 +733,13 @@ __global__ void k_gather(const float* __restrict__ x,
 }  // namespace
 
 // ---------------------------------------------------------------------------
-extern "C" int iso_frnn_make_grid(const float* points, const int64_t* lengths,
-                                  const float* radius, int n_clouds,
-                                  int64_t p_stride, int max_res, float* grid_params,
-                                  void* stream) {
+extern "C" int iso_frnn_make_grid_density(const float* points, const int64_t* lengths,
+                                          const float* radius, int n_clouds, int64_t p_stride,
+                                          int max_res, float points_per_cell, float* grid_params,
+                                          void* stream) {
   ISO_REQUIRE(n_clouds >= 0 && p_stride >= 0, ISO_ERR_INVALID, "iso_frnn_make_grid: bad sizes");
+  ISO_REQUIRE(points_per_cell >= 1.0f && points_per_cell <= 4096.0f, ISO_ERR_INVALID,
+              "iso_frnn_make_grid: points_per_cell must be in [1,4096], got %g", (double)points_per_cell);
   ISO_REQUIRE(max_res >= 1 && max_res <= ISO_GRID_MAX_RES, ISO_ERR_INVALID,
               "iso_frnn_make_grid: max_res must be in [1,%d], got %d", ISO_GRID_MAX_RES, max_res);
   if (n_clouds == 0) return ISO_OK;
@@ -751,9 +754,17 @@ extern "C" int iso_frnn_make_grid(const float* points, const int64_t* lengths,
     hipLaunchKernelGGL(k_bbox<256>, dim3(gx, n_clouds), dim3(256), 0, s, points, lengths, p_stride, keys);
   }
   hipLaunchKernelGGL(k_grid_finalize, dim3(iso_div_up(n_clouds, 64)), dim3(64), 0, s,
-                     grid_params, lengths, p_stride, radius, n_clouds, max_res);
+                     grid_params, lengths, p_stride, radius, n_clouds, max_res, 1.0f / points_per_cell);
   ISO_CHECK_LAUNCH("iso_frnn_make_grid");
   return ISO_OK;
+}
+
+extern "C" int iso_frnn_make_grid(const float* points, const int64_t* lengths,
+                                  const float* radius, int n_clouds,
+                                  int64_t p_stride, int max_res, float* grid_params,
+                                  void* stream) {
+  return iso_frnn_make_grid_density(points, lengths, radius, n_clouds, p_stride, max_res, 8.0f,
+                                    grid_params, stream);
 }
 
 extern "C" int iso_points_bbox(const float* points, const int64_t* lengths, int n_clouds,

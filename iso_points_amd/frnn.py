@@ -55,8 +55,9 @@ def _as_lengths(lengths, n, p, device):
     return lengths.to(device=device, dtype=torch.int64).contiguous()
 
 
-def build_grid(points2, lengths2, radius):
-    """Grid build: make_grid -> insert -> scan -> counting sort (4 stages, no host sync)."""
+def build_grid(points2, lengths2, radius, points_per_cell=8.0):
+    """Grid build: make_grid -> insert -> scan -> counting sort (4 stages, no host sync).
+    `points_per_cell`: density target of the cell size (see iso_frnn_make_grid_density)."""
     N, P2, D = points2.shape
     assert D == 3, "frnn_grid_points: only 3-D clouds are built here (2-D: use _C.*)"
     dev = points2.device
@@ -74,7 +75,8 @@ def build_grid(points2, lengths2, radius):
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     s = _lib.stream()
     p = _lib.ptr
-    _lib.call("iso_frnn_make_grid", p(points2), p(lengths2), p(radius), N, P2, max_res, p(params), s)
+    _lib.call("iso_frnn_make_grid_density", p(points2), p(lengths2), p(radius), N, P2, max_res,
+              float(points_per_cell), p(params), s)
     _lib.call("iso_frnn_insert_points", p(points2), p(lengths2), p(params), p(cnt), p(cell), p(slot),
               N, P2, G, 3, s)
     _lib.call("iso_frnn_scan_cells", p(cnt), p(off), p(params), N, G, 3, p(ws), ws_bytes, s)

@@ -51,6 +51,22 @@ fused()
 res = {"points": P, "K": 31, "upsample_ms": t_up, "out_points": int(n), "candidates_fused_ms": t_f,
        "candidates_tensor_form_same_gpu_ms": t_t,
        "candidates_max_rel_diff": ((sp - ref).abs().max() / ref.abs().max()).item()}
+# the exact K-nearest search underneath (K + 1 = 32), cell size from the default density target
+# (8 points per cell: most queries need the ring walk) and from the K-aware one knn_points uses
+from iso_points_amd import point_processing as PP
+r_inf = torch.full((1,), float("inf"), device=dev)
+for tag, ppc in (("knn32_ms_8_per_cell", 8.0), ("knn32_ms_0.75K_per_cell", 0.75 * 32)):
+    def run(ppc=ppc):
+        g = frnn.build_grid(up, n, r_inf, points_per_cell=ppc)
+        return frnn.frnn_grid_points(up, up, n, n, K=32, r=r_inf, grid=g, return_nn=True)
+    res[tag] = timeit(run, warm=1, rep=5)
+a, b = PP.knn_points(up, up, n, n, K=32, return_nn=True), None
+g8 = frnn.build_grid(up, n, r_inf, points_per_cell=8.0)
+d8, i8, _, _ = frnn.frnn_grid_points(up, up, n, n, K=32, r=r_inf, grid=g8)
+res["knn_same_result"] = bool(torch.equal(a.idx, i8.clamp_min(0)) and torch.equal(a.dists, d8.clamp_min(0)))
+# point_processing.upsample (sparsest-edge midpoints, K = 31 as UniformProjection.upsample) and wlop
+res["pp_upsample_100k_to_150k_ms"] = timeit(lambda: PP.upsample(pts, int(1.5 * P), num_points=num, neighborhood_size=31), warm=1, rep=3)
+res["wlop_100k_ratio0.5_ms"] = timeit(lambda: PP.wlop(pts, num, ratio=0.5), warm=1, rep=3)
 print(res)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "ear_bench.json"), "w"), indent=1)
