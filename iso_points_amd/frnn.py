@@ -10,6 +10,8 @@ All work is done by libisopoints_hip.so (include/isopoints.h section B).
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -75,6 +77,8 @@ def build_grid(points2, lengths2, radius, points_per_cell=8.0):
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     s = _lib.stream()
     p = _lib.ptr
+    if points_per_cell == 8.0 and os.environ.get("ISO_FRNN_PPC"):      # tuning hook (results do not depend on it)
+        points_per_cell = float(os.environ["ISO_FRNN_PPC"])
     _lib.call("iso_frnn_make_grid_density", p(points2), p(lengths2), p(radius), N, P2, max_res,
               float(points_per_cell), p(params), s)
     _lib.call("iso_frnn_insert_points", p(points2), p(lengths2), p(params), p(cnt), p(cell), p(slot),
