@@ -71,16 +71,16 @@ def _worker(rank, world, port, model_kind, P, S, outdir, n_views=3):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model_kind,n_views", [("sphere", 3), ("siren", 3), ("sphere", 2)])
-def test_two_rank_cycle_equals_single_gpu(dev, tmp_path, model_kind, n_views):
-    """3 views on 2 ranks: every rank queries a row range of every view; 2 views on 2 ranks: a
-    view belongs to one rank (the branch the 8-GPU x 4-view bench takes)."""
+@pytest.mark.parametrize("model_kind,n_views,world", [("sphere", 3, 2), ("siren", 3, 2), ("sphere", 2, 2),
+                                                      ("sphere", 2, 4)])
+def test_sharded_cycle_equals_single_gpu(dev, tmp_path, model_kind, n_views, world):
+    """3 views on 2 ranks: every rank queries a row range of every view; 2 views on 2 ranks: a view
+    belongs to one rank; 2 views on 4 ranks: to two ranks (what the 8-GPU x 4-view bench runs)."""
     from iso_points_amd.dist import Comm
     P, S = 30001, 80            # odd P: uneven shards; S not a multiple of 16*world
     cyc, (r1, img, grad, frags, filt) = _run(model_kind, dev, Comm(enabled=False), P, S, n_views)
     ref = {"pts": r1.points[0].cpu(), "idx": frags.idx.cpu(), "zbuf": frags.zbuf.cpu(), "img": img.cpu(),
            "gxy": grad[:, :2].cpu(), "gz": grad[:, 2].cpu()}
-    world = 2
     ctx = mp.get_context("spawn")
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, model_kind, P, S, str(tmp_path), n_views))
