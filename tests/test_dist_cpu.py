@@ -68,3 +68,20 @@ def test_shard_bounds_cover_range():
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
             assert b[w - 1] == shard_bounds(n, w, w - 1)
+
+
+def test_ray_bounds_host_logic():
+    """ray_tracing.sphere_entry_exit (torch glue of RayTracing, no kernel) == the oracle's restatement of
+    intersection_with_unit_sphere, hits and tangent-plane misses, cameras outside and inside."""
+    import torch
+    from oracle import iso_oracle as O
+    from iso_points_amd.ray_tracing import sphere_entry_exit
+    g = torch.Generator().manual_seed(0)
+    for cam in ([[0.0, 0.3, 2.5]], [[0.2, -0.1, 0.4]], [[0.0, 0.0, -3.0], [1.5, 1.5, 0.0]]):
+        c = torch.tensor(cam)
+        d = torch.nn.functional.normalize((torch.rand(c.shape[0], 500, 3, generator=g) - 0.5) * 2.5 - c[:, None], dim=-1)
+        for radius in (1.0, 0.7):
+            e0, e1, hit = sphere_entry_exit(c, d, radius)
+            r0, r1, rh = O.sphere_entry_exit(c, d, radius)
+            assert torch.equal(hit, rh) and 0 < int(hit.sum()) < hit.numel() or c.norm(dim=-1).min() < radius
+            assert torch.allclose(e0, r0, rtol=0, atol=2e-6) and torch.allclose(e1, r1, rtol=0, atol=2e-6)
