@@ -113,13 +113,14 @@ class IsoCycle(object):
         pts_all = c.all_gather_rows(r0.points[0], self.P).view(1, self.P, 3)
         nrm_all = c.all_gather_rows(r0.normals[0], self.P).view(1, self.P, 3)
         num_all = full_lengths(pts_all)
-        diag = cloud_diag(pts_all)[0]                                   # levelset_sampling.py:254-256
+        diag_all = cloud_diag(pts_all)                                  # one bounding-box pass for both uses
+        diag = diag_all[0]                                              # levelset_sampling.py:254-256
         inv_sigma = (num_all.float() / diag).reshape(1).contiguous()
         if c.world == 1:
             proj._create_tree(pts_all, refresh_tree=True, num_points_per_cloud=num_all)
             idx = proj._knn_idx
         else:
-            radius = (torch.sqrt(cloud_diag(pts_all) / num_all.float()) * proj.knn_k).contiguous()  # :129-131
+            radius = (torch.sqrt(diag_all / num_all.float()) * proj.knn_k).contiguous()              # :129-131
             grid = frnn.build_grid(pts_all, num_all, radius)
             own = pts_all[:, self.lo:self.hi].contiguous()
             _, idxs, _, _ = frnn.frnn_grid_points(own, pts_all, self.num_local, num_all, K=proj.knn_k + 1,
