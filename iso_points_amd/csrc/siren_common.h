@@ -73,7 +73,3 @@ int64_t siren_x3_stash_floats(int H, int L);
 void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s);
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s);
 
-// ---- siren_pp.hip: matrix and vector waves side by side (H = 256) -------------------------------
-bool siren_pp_supported(int H, int L);
-int64_t siren_pp_stash_floats(int L);
-int siren_pp_launch(const SirenArgs& a, int64_t n_upper, hipStream_t s);

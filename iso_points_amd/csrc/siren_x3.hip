@@ -40,10 +40,6 @@
 #include "iso_newton.h"
 #include "mlp_common.h"
 
-#ifndef X3_PIPE
-#define X3_PIPE 0      // 1: software-pipelined kernel (siren_x3_pipe.h, NW == 4; measured: no gain); 0: plain stages
-#endif
-
 #include "mfma_split.h"
 
 namespace {
@@ -679,29 +675,6 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   }
 }
 
-#if X3_PIPE
-#include "siren_x3_pipe.h"      // (written against the split-bf16-only gemm_x3: build with -DX3_FWD_F16=0)
-#endif
-
-#if X3_PIPE
-template <int H, int NW, int NB, int MINB>
-int launch_x3p(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
-  using S = X3Shape<H, NW, NB>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_siren_step_x3p<H, NW, NB, MINB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds);
-    attr_done = true;
-  }
-  const int64_t tiles = (n_upper + S::P - 1) / S::P;
-  const int64_t cap = 256 * MINB;
-  const int blocks = (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
-  hipLaunchKernelGGL((k_siren_step_x3p<H, NW, NB, MINB>), dim3(blocks), dim3(64 * NW), S::kLds, s, a);
-  return 0;
-}
-
-#endif
-
 template <int H, int NW, int NB, int MINB, bool FWD>
 int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
   using S = X3Shape<H, NW, NB>;
@@ -742,9 +715,7 @@ bool siren_x3_supported(int H, int L) { return (H == 256 || H == 128) && L >= 1 
 
 int64_t siren_x3_stash_floats(int H, int L) {
   if (H == 256) {
-    const int64_t plain = 256 * X3_MINB256 * X3Shape<256, X3_NW, X3_NB256>::kStashPerWg(L);
-    const int64_t pp = siren_pp_stash_floats(L);
-    return plain > pp ? plain : pp;
+    return 256 * X3_MINB256 * X3Shape<256, X3_NW, X3_NB256>::kStashPerWg(L);
   }
   if (H == 128) return 256 * X3_MINB128 * X3Shape<128, 4, 3>::kStashPerWg(L);
   return 0;
@@ -761,24 +732,12 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
   }
 }
 
-// ISO_SIREN_PP=1 in the environment: the ping-pong kernel of siren_pp.hip for H = 256
-static bool use_pp() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ISO_SIREN_PP"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
-
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
-  if (use_pp() && siren_pp_supported(H, a.L)) return siren_pp_launch(a, n_upper, s);
-#if X3_PIPE
-  if (H == 256) return launch_x3p<256, 4, 3, 1>(a, n_upper, s);
-#else
   if (a.fwd_only) {
     if (H == 256) return launch_x3<256, X3_NW, X3_NB256, X3_MINB256, true>(a, n_upper, s);
     if (H == 128) return launch_x3<128, 4, 3, X3_MINB128, true>(a, n_upper, s);
   }
   if (H == 256) return launch_x3<256, X3_NW, X3_NB256, X3_MINB256, false>(a, n_upper, s);
-#endif
   if (H == 128) return launch_x3<128, 4, 3, X3_MINB128, false>(a, n_upper, s);
   return -1;
 }
