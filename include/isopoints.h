@@ -459,6 +459,60 @@ int iso_splat_backward(const float* points, const float* radii, const uint8_t* v
 int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbuf, int64_t n_pixels,
                             int points_per_pixel, float* z_grad, void* stream);
 
+/* ------------------------------------------------------------------------
+ * E. Brick grid + fused neighbour kernels (the hot path of the iso-point cycle)
+ *
+ *    The stand-alone FRNN entry points of section B stay the general API.  The cycle itself
+ *    (UniformProjection.resample, levelset_sampling.py:239-288, and the K = 7 bandwidth query of
+ *    SurfaceSplatting._get_per_point_info, rasterizer.py:367-386) runs on a two-level grid:
+ *    coarse BRICKS of 4x4x4 fine cells in global memory (x-major brick id, so a range of brick
+ *    ids is an x-slab of space -- the unit the multi-GPU path shards by), fine cells only in LDS:
+ *    a workgroup stages its brick plus a one-cell halo, counting-sorted by fine cell, and every
+ *    query of the brick walks its 3x3x3 fine cells there.  Exact results (K nearest within r,
+ *    ties to the lower id): a query whose K-th distance is not covered by the staged block is
+ *    finished by a tail kernel that walks rings of bricks.
+ *
+ *    One workspace (iso_bricks_workspace_bytes(n_max), 256-B aligned) holds the grid; n_max =
+ *    n_own + import_max must be the same in every call on that workspace.
+ *
+ *    iso_bricks_build: bbox = [min xyz, 0, max xyz, 0] on the device (iso_points_bbox layout; N
+ *    ranks reduce it first so that every rank derives the same grid), n_total = points of the
+ *    WHOLE cloud.  radius > 0: fixed search radius; radius <= 0: r = sqrt(|bbox diag| / n_total)
+ *    * knn_k (levelset_sampling.py:129-131).  Fine cell = cell_scale * sqrt(diag / n_total),
+ *    clamped to [extent / (4 (cap-1)), 1.002 r].  Own points get ids id_base + i; the optional
+ *    imported records (halo cells of other ranks: rec0 = x,y,z,id-bits, rec1 = nx,ny,nz,payload,
+ *    count on the device) are searched but never queried.  payload: one int per own point
+ *    carried to the kernels (the view mask for iso_splat_h_fused), or NULL.
+ * ---------------------------------------------------------------------- */
+int64_t iso_bricks_workspace_bytes(int64_t n_max);
+int iso_bricks_build(const float* points, const float* normals, const int32_t* payload,
+                     int64_t n_own, int64_t id_base, const float* import_rec0,
+                     const float* import_rec1, const int32_t* import_count, int64_t import_max,
+                     const float* bbox, int64_t n_total, float radius, int knn_k,
+                     float cell_scale, void* workspace, int64_t workspace_bytes, void* stream);
+/* One resample move of every own point: K+1 = k_plus_one self-inclusive FRNN query (radius of
+ * the build), column 0 dropped, tangent-plane repulsion with inv_sigma = n_total / diag
+ * (levelset_sampling.py:254-284; same arithmetic as iso_frnn_query + iso_repulse).  `points`
+ * = the own points the grid was built from.  idx_out (n_own, K) int64 / d2_out (n_own, K)
+ * optional: the neighbour lists (UniformProjection._knn_idx / _knn_dists).            */
+int iso_resample_fused(void* workspace, int64_t n_max, const float* points, int64_t n_own,
+                       int k_plus_one, float* points_out, int64_t* idx_out, float* d2_out,
+                       void* stream);
+/* mask_out[i] bit v = point i is renderable in view v (z range + backface culling,
+ * rasterizer.py:184-254; = iso_splat_view_flags for up to 8 views at once);
+ * view_count_out[0..7] = points per view.                                            */
+int iso_splat_view_mask(const float* points, const float* normals, const float* views, int n_views,
+                        int64_t n, float znear, float zfar, int backface_culling,
+                        int32_t* mask_out, int32_t* view_count_out, void* stream);
+/* h_out[v * n_own + i] = clamp(max d2 of the 6 nearest OTHER points renderable in view v within
+ * the build radius / 2, 5e-5, 0.01) for every view v in which own point i is renderable
+ * (rasterizer.py:367-386; = iso_frnn_query K = 7 on each filtered view cloud + iso_splat_vrk_h),
+ * all views in one pass over the grid (payload = view mask).  view_total[v] = points of the
+ * whole cloud renderable in view v (< 7: the reference's 1e-3 branch).                */
+int iso_splat_h_fused(void* workspace, int64_t n_max, const float* points, const int32_t* mask,
+                      int64_t n_own, const int32_t* view_total, int n_views, float* h_out,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

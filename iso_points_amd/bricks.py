@@ -1,0 +1,104 @@
+"""Host side of the brick grid and its fused neighbour kernels (include/isopoints.h section E).
+
+The cycle's two neighbour searches run here:
+  resample_fused   UniformProjection.resample body, levelset_sampling.py:254-284
+                   (= _create_tree :110-140 + the repulsion :268-284 in one kernel)
+  splat_h_fused    K = 7 bandwidth of SurfaceSplatting._get_per_point_info, rasterizer.py:367-386,
+                   for all views of the cloud in one pass
+`frnn.frnn_grid_points` stays the general neighbour API.
+"""
+import torch
+
+from . import _lib
+
+RESAMPLE_CELL = 0.8        # fine cell = 0.8 r  (r = knn_k * sqrt(diag / P)): measured optimum at 1 M points
+H_CELL_SCALE = 5.0         # fine cell = 5 sqrt(diag / P) for the K = 7 bandwidth query
+
+
+def points_bbox(points):
+    """(8,) f32 [min xyz, 0, max xyz, 0] of a packed (n,3) cloud, on the device (no host sync)."""
+    pts = points.detach().float().contiguous().view(-1, 3)
+    mm = torch.empty((8,), dtype=torch.float32, device=pts.device)
+    _lib.call("iso_points_bbox", _lib.ptr(pts), None, 1, pts.shape[0], _lib.ptr(mm), _lib.stream())
+    return mm
+
+
+class BrickGrid(object):
+    """One workspace for clouds of up to n_own + import_max points on `device` (allocated once,
+    rebuilt in place every cycle)."""
+
+    def __init__(self, n_own, device, import_max=0):
+        self.n_own, self.import_max = int(n_own), int(import_max)
+        self.n_max = self.n_own + self.import_max
+        lib = _lib.load()
+        self.ws_bytes = lib.iso_bricks_workspace_bytes(self.n_max)
+        self.ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=device)
+        assert self.ws.data_ptr() % 256 == 0
+        self.points = None
+
+    def build(self, points, normals=None, payload=None, bbox=None, n_total=None, radius=-1.0, knn_k=8,
+              cell_scale=None, id_base=0, imports=None):
+        """points (n_own,3) f32 contiguous; imports = (rec0 (m,4), rec1 (m,4), count int32 (1,)) or None."""
+        assert points.shape == (self.n_own, 3) and points.dtype == torch.float32 and points.is_contiguous()
+        if bbox is None:
+            bbox = points_bbox(points)
+        if cell_scale is None:
+            cell_scale = RESAMPLE_CELL * knn_k
+        p = _lib.ptr
+        imp0 = imp1 = impc = None
+        if imports is not None and self.import_max > 0:
+            imp0, imp1, impc = imports
+            assert imp0.shape[0] >= self.import_max and imp1.shape[0] >= self.import_max
+        _lib.call("iso_bricks_build", p(points), p(normals), p(payload), self.n_own, int(id_base), p(imp0), p(imp1),
+                  p(impc), self.import_max if imports is not None else 0, p(bbox),
+                  int(n_total if n_total is not None else self.n_own), float(radius), int(knn_k), float(cell_scale),
+                  p(self.ws), self.ws_bytes, _lib.stream())
+        self.points = points
+        self._imports = imports          # keep alive until the stream has used them
+        return self
+
+    # -- diagnostics (host sync) -------------------------------------------------------------------
+    def header(self):
+        raw = self.ws[:128].cpu()
+        f = raw.view(torch.float32).tolist()
+        i = raw.view(torch.int32).tolist()
+        c = self.ws[256:320].cpu().view(torch.int32).tolist()
+        return {"f": f[8], "r": f[9], "inv_sigma": f[12], "diag": f[13], "nb": i[16:19], "n_bricks": i[19],
+                "n": i[23], "n_own": i[24], "id_base": i[25], "g_covers_r": i[26], "occupied": c[0],
+                "tail": c[1], "overflow_bricks": c[2], "tail_h": c[3]}
+
+
+def resample_fused(grid, k_plus_one, want_idx=False):
+    """One repulsion move of the grid's own points -> (moved (n,3), idx (n,K) int64 or None, d2 or None)."""
+    pts = grid.points
+    n = grid.n_own
+    out = torch.empty_like(pts)
+    idx = d2 = None
+    if want_idx:
+        idx = torch.empty((n, k_plus_one - 1), dtype=torch.int64, device=pts.device)
+        d2 = torch.empty((n, k_plus_one - 1), dtype=torch.float32, device=pts.device)
+    p = _lib.ptr
+    _lib.call("iso_resample_fused", p(grid.ws), grid.n_max, p(pts), n, int(k_plus_one), p(out), p(idx), p(d2),
+              _lib.stream())
+    return out, idx, d2
+
+
+def view_mask(points, normals, views, znear=1.0, zfar=100.0, backface_culling=True):
+    """-> mask (n,) int32 (bit v = renderable in view v), view_count (8,) int32 on the device."""
+    n, nv = points.shape[0], views.shape[0]
+    mask = torch.empty((n,), dtype=torch.int32, device=points.device)
+    cnt = torch.empty((8,), dtype=torch.int32, device=points.device)
+    p = _lib.ptr
+    _lib.call("iso_splat_view_mask", p(points), p(normals), p(views), nv, n, float(znear), float(zfar),
+              int(bool(backface_culling)), p(mask), p(cnt), _lib.stream())
+    return mask, cnt
+
+
+def splat_h_fused(grid, mask, view_total, n_views):
+    """h (n_views, n_own) f32: written where the mask bit is set, untouched elsewhere."""
+    pts = grid.points
+    h = torch.empty((n_views, grid.n_own), dtype=torch.float32, device=pts.device)
+    p = _lib.ptr
+    _lib.call("iso_splat_h_fused", p(grid.ws), grid.n_max, p(pts), p(mask), grid.n_own, p(view_total), int(n_views),
+              p(h), _lib.stream())
+    return h

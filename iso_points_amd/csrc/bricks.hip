@@ -1,0 +1,979 @@
+// Brick grid (bricks.h): build, the fused resample step (FRNN K+1 query + tangent-plane
+// repulsion, neighbour data staged in LDS) and the fused per-view splat bandwidth h
+// (K = 7 query of every view's visible cloud in ONE pass over the whole cloud).
+//
+// Reference semantics
+//   neighbour tree  : UniformProjection._create_tree, DSS/models/levelset_sampling.py:110-140
+//                     (r = sqrt(diag/P) * knn_k, K+1 self-inclusive FRNN query, column 0 dropped)
+//   repulsion       : UniformProjection.resample, levelset_sampling.py:254-284
+//   splat bandwidth : SurfaceSplatting._get_per_point_info, DSS/core/rasterizer.py:367-386
+//                     (K = 7 self query of the filtered view cloud, h = clamp(max d2 / 2, 5e-5, 0.01))
+//   renderable flags: SurfaceSplatting._filter_points_with_invalid_depth / backface culling,
+//                     rasterizer.py:184-254
+// The stand-alone iso_frnn_* entry points (frnn.hip) stay the general API (any K, any radius,
+// foreign query sets); these kernels are the hot path of the iso-point cycle.  Results are the same
+// exact "K nearest within r, ties to the lower index" lists; tests pin one against the other.
+//
+// Selection without per-candidate branches: a lane keeps the M = K + 3 smallest 32-bit keys
+// (d2 bits with the low 10 bits replaced by the candidate's LDS slot) in a sorted register list,
+// one v_med3_u32 per slot and candidate.  Truncated keys order like d2 up to 2^-13 relative, so the
+// exact (d2, id) order is restored afterwards on the M survivors; the list is certified complete
+// when the first key beyond the K-th differs from it in the kept bits (else: tail kernel).
+#include "bricks.h"
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------------
+BrickWs bricks_carve(void* ws, int64_t n_max) {
+  BrickWs w;
+  if (n_max < 1) n_max = 1;
+  w.nb_cap = bricks_nb_cap(n_max);
+  w.G = (int64_t)w.nb_cap * w.nb_cap * w.nb_cap + 1;
+  auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+  char* p = (char*)ws;
+  int64_t o = 0;
+  w.hdr = (BrickHdr*)(p + o); o += al(sizeof(BrickHdr));
+  w.counters = (int32_t*)(p + o); o += al(64);
+  w.cnt = (int32_t*)(p + o); o += al(4 * w.G);
+  w.off = (int32_t*)(p + o); o += al(4 * w.G);
+  w.slot = (int32_t*)(p + o); o += al(4 * n_max);
+  w.rec0 = (float4*)(p + o); o += al(16 * n_max);
+  w.rec1 = (float4*)(p + o); o += al(16 * n_max);
+  w.list = (int32_t*)(p + o); o += al(4 * (w.G < n_max ? w.G : n_max));
+  w.tail = (int32_t*)(p + o); o += al(4 * 8 * n_max);
+  w.scan_ws_bytes = iso_prefix_sum_workspace_bytes(w.G, 1);
+  w.scan_ws = (void*)(p + o); o += al(w.scan_ws_bytes);
+  w.bytes = o;
+  return w;
+}
+
+namespace {
+
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// ---- header ------------------------------------------------------------------------------------
+// bbox: [min xyz, 0, max xyz, 0] (iso_points_bbox layout; for N ranks the caller reduces it first)
+__global__ void k_bricks_params(const float* __restrict__ bbox, int64_t n_total, int64_t n_own, int64_t id_base,
+                                float radius, int knn_k, float cell_scale, int nb_cap, BrickHdr* __restrict__ h,
+                                int32_t* __restrict__ counters) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float mn[3], ext[3];
+  for (int a = 0; a < 3; ++a) { mn[a] = bbox[a]; ext[a] = bbox[4 + a] - bbox[a]; if (!(ext[a] >= 0.f)) ext[a] = 0.f; }
+  const float diag = sqrtf((ext[0] * ext[0] + ext[1] * ext[1]) + ext[2] * ext[2]);
+  const float np = (float)(n_total > 0 ? n_total : 1);
+  const float spacing = sqrtf(diag / np);
+  const float r = radius > 0.f ? radius : spacing * (float)knn_k;      // levelset_sampling.py:129-131
+  float f = cell_scale * spacing;
+  if (r > 0.f && f > r * 1.002f) f = r * 1.002f;                        // g = 0.999 f >= r: nothing to gain beyond
+  const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+  const float fmin = emax / (4.0f * (float)(nb_cap - 1)) * 1.0001f;
+  if (f < fmin) f = fmin;
+  if (!(f > 1e-20f)) f = 1.0f;                                          // degenerate cloud: one brick
+  const float inv_f = 1.0f / f;
+  int nb[3];
+  for (int a = 0; a < 3; ++a) {
+    int nf = (int)floorf(ext[a] * inv_f) + 1;
+    nb[a] = (nf + 3) / 4;
+    if (nb[a] > nb_cap) nb[a] = nb_cap;
+    if (nb[a] < 1) nb[a] = 1;
+    h->nb[a] = nb[a];
+    h->nf[a] = 4 * nb[a];
+    h->mn[a] = mn[a];
+  }
+  const int nbr = nb[0] * nb[1] * nb[2];
+  h->inv_f = inv_f;
+  h->nbx_f = (float)nb[0]; h->nby_f = (float)nb[1]; h->nbz_f = (float)nb[2];
+  h->total_f = (float)(nbr + 1);
+  h->f = f; h->r = r; h->r2 = r * r;
+  const float g = 0.999f * f;
+  h->g2 = g * g;
+  h->inv_sigma = np / diag;                                              // levelset_sampling.py:256
+  h->diag = diag; h->spacing = spacing; h->pad0 = 0.f;
+  h->n_bricks = nbr;
+  h->n = (int)n_own;                                                     // + imported, added by k_brick_count_recs
+  h->n_own = (int)n_own; h->id_base = (int)id_base;
+  h->g_covers_r = g >= r ? 1 : 0;
+  h->n_total = (int)n_total;
+  for (int i = 0; i < 16; ++i) counters[i] = 0;
+}
+
+__global__ void k_bricks_zero(const BrickHdr* __restrict__ h, int32_t* __restrict__ cnt) {
+  const int n = h->n_bricks + 1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cnt[i] = 0;
+}
+
+__device__ __forceinline__ int brick_of(const BrickHdr& h, float x, float y, float z) {
+  const int fx = bk_fine(x, h.mn[0], h.inv_f, h.nf[0]);
+  const int fy = bk_fine(y, h.mn[1], h.inv_f, h.nf[1]);
+  const int fz = bk_fine(z, h.mn[2], h.inv_f, h.nf[2]);
+  return ((fx >> 2) * h.nb[1] + (fy >> 2)) * h.nb[2] + (fz >> 2);
+}
+
+// own points (packed (n,3) f32): arrival slot inside the brick
+__global__ __launch_bounds__(256) void k_brick_count(const float* __restrict__ pts, int64_t n,
+                                                     const BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
+                                                     int32_t* __restrict__ slot) {
+  const BrickHdr h = *hp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = brick_of(h, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
+    slot[i] = atomicAdd(&cnt[b], 1);
+  }
+}
+
+// imported halo records (count on the device)
+__global__ __launch_bounds__(256) void k_brick_count_recs(const float4* __restrict__ imp0, const int32_t* __restrict__ imp_count,
+                                                          int64_t imp_max, BrickHdr* __restrict__ hp,
+                                                          int32_t* __restrict__ cnt, int32_t* __restrict__ slot) {
+  const BrickHdr h = *hp;
+  int64_t m = *imp_count;
+  if (m > imp_max) m = imp_max;
+  if (blockIdx.x == 0 && threadIdx.x == 0) hp->n = h.n_own + (int)m;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+    const float4 p = imp0[j];
+    slot[h.n_own + j] = atomicAdd(&cnt[brick_of(h, p.x, p.y, p.z)], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_brick_scatter(const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                       const int32_t* __restrict__ payload, int64_t n,
+                                                       const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off,
+                                                       const int32_t* __restrict__ slot, float4* __restrict__ rec0,
+                                                       float4* __restrict__ rec1) {
+  const BrickHdr h = *hp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    const int64_t dst = (int64_t)off[brick_of(h, x, y, z)] + slot[i];
+    rec0[dst] = make_float4(x, y, z, __int_as_float(h.id_base + (int)i));
+    float4 u = make_float4(0.f, 0.f, 0.f, __int_as_float(payload ? payload[i] : 0));
+    if (nrm) { u.x = nrm[i * 3]; u.y = nrm[i * 3 + 1]; u.z = nrm[i * 3 + 2]; }
+    rec1[dst] = u;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_brick_scatter_recs(const float4* __restrict__ imp0, const float4* __restrict__ imp1,
+                                                            const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off,
+                                                            const int32_t* __restrict__ slot, float4* __restrict__ rec0,
+                                                            float4* __restrict__ rec1) {
+  const BrickHdr h = *hp;
+  const int64_t m = h.n - h.n_own;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+    const float4 p = imp0[j];
+    const int64_t dst = (int64_t)off[brick_of(h, p.x, p.y, p.z)] + slot[h.n_own + j];
+    rec0[dst] = p;
+    rec1[dst] = imp1[j];
+  }
+}
+
+// occupied bricks (the order only affects scheduling)
+__global__ __launch_bounds__(256) void k_brick_list(const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off,
+                                                    int32_t* __restrict__ list, int32_t* __restrict__ counters) {
+  const int nb = hp->n_bricks;
+  const int lane = threadIdx.x & 63;
+  for (int b0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; b0 < nb; b0 += gridDim.x * blockDim.x) {
+    const int b = b0 + lane;
+    const bool occ = b < nb && off[b + 1] > off[b];
+    const unsigned long long bal = __ballot(occ);
+    int base = 0;
+    if (lane == 0 && bal) base = atomicAdd(&counters[0], __popcll(bal));
+    base = __shfl(base, 0);
+    if (occ) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = b;
+  }
+}
+
+// ---- staging of one brick + halo into LDS -------------------------------------------------------
+// WITH_NRM: rec1 (normals) staged next to rec0 (resample); otherwise one record per candidate whose
+// w is rec1's payload (the view mask) with bit 31 = "imported, not a query" (bandwidth kernel).
+template <bool WITH_NRM>
+struct BrickStage {
+  float4 rec0[BK_CAP];
+  float4 rec1[WITH_NRM ? BK_CAP : 1];
+  int gid[WITH_NRM ? 1 : BK_CAP];
+  int cstart[220];   // [217] used: local fine cell -> first staged slot
+  int ccur[216];
+  int run_i0[9];
+  int run_pre[10];
+  int qbeg[16];
+  int qpre[17];
+};
+
+struct BrickGeo { int bx, by, bz, ox, oy, oz; };
+
+// All threads of the workgroup.  Returns the number of staged records, or -1 when they do not fit.
+// The records of the 27 bricks are nine contiguous runs of the brick-sorted arrays; a thread takes
+// every BK_THREADS-th record of their concatenation and requests all of its records before it uses
+// the first (BK_RAW in flight: the staging is a chain of global-memory latencies otherwise).
+constexpr int BK_RAW = 8;
+
+template <bool WITH_NRM>
+__device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int32_t* __restrict__ off,
+                           const float4* __restrict__ rec0, const float4* __restrict__ rec1, int b, BrickGeo& g) {
+  const int tid = threadIdx.x;
+  const int nbx = h.nb[0], nby = h.nb[1], nbz = h.nb[2];
+  g.bz = b % nbz; g.by = (b / nbz) % nby; g.bx = b / (nbz * nby);
+  g.ox = 4 * g.bx - 1; g.oy = 4 * g.by - 1; g.oz = 4 * g.bz - 1;
+  __syncthreads();                                   // the previous brick's readers are done
+  if (tid < 216) S.ccur[tid] = 0;
+  if (tid < 9) {
+    const int x = g.bx + tid / 3 - 1, y = g.by + tid % 3 - 1;
+    int i0 = 0, len = 0;
+    if (x >= 0 && x < nbx && y >= 0 && y < nby) {
+      const int z0 = max(g.bz - 1, 0), z1 = min(g.bz + 1, nbz - 1);
+      i0 = off[(x * nby + y) * nbz + z0];
+      len = off[(x * nby + y) * nbz + z1 + 1] - i0;
+    }
+    S.run_i0[tid] = i0;
+    S.run_pre[tid + 1] = len;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    S.run_pre[0] = 0;
+    for (int k = 1; k <= 9; ++k) { run += S.run_pre[k]; S.run_pre[k] = run; }
+  }
+  __syncthreads();
+  const int total_raw = S.run_pre[9];
+  auto index_of = [&](int j) {
+    int run = 0;
+    while (j >= S.run_pre[run + 1]) ++run;
+    return S.run_i0[run] + (j - S.run_pre[run]);
+  };
+  auto cell_of = [&](const float4& p) {
+    const int lx = bk_fine(p.x, h.mn[0], h.inv_f, h.nf[0]) - g.ox;
+    const int ly = bk_fine(p.y, h.mn[1], h.inv_f, h.nf[1]) - g.oy;
+    const int lz = bk_fine(p.z, h.mn[2], h.inv_f, h.nf[2]) - g.oz;
+    return ((unsigned)lx < 6u && (unsigned)ly < 6u && (unsigned)lz < 6u) ? (lx * 6 + ly) * 6 + lz : -1;
+  };
+  auto store = [&](int pos, const float4& p, const float4& u) {
+    if (WITH_NRM) {
+      S.rec0[pos] = p;
+      S.rec1[pos] = u;
+    } else {
+      const int gid = __float_as_int(p.w);
+      const bool own = gid >= h.id_base && gid < h.id_base + h.n_own;
+      const int m = (__float_as_int(u.w) & 0xff) | (own ? 0 : (int)0x80000000);
+      S.rec0[pos] = make_float4(p.x, p.y, p.z, __int_as_float(m));
+      S.gid[pos] = gid;
+    }
+  };
+  auto scan_cells = [&]() {
+    if (tid < 64) {                                  // exclusive scan of the 216 counters by one wave
+      int v[4], s = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int c = tid * 4 + k; v[k] = c < 216 ? S.ccur[c] : 0; s += v[k]; }
+      int ex = wave_incl_scan_i(s) - s;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = tid * 4 + k;
+        if (c < 216) { S.cstart[c] = ex; S.ccur[c] = ex; }
+        ex += v[k];
+      }
+      if (tid == 53) S.cstart[216] = ex;
+    }
+  };
+  if (total_raw <= BK_THREADS * BK_RAW) {
+    int idx[BK_RAW], cell[BK_RAW];
+    float4 p[BK_RAW];
+#pragma unroll
+    for (int k = 0; k < BK_RAW; ++k) {
+      const int j = tid + k * BK_THREADS;
+      idx[k] = j < total_raw ? index_of(j) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < BK_RAW; ++k) p[k] = idx[k] >= 0 ? rec0[idx[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < BK_RAW; ++k) {
+      cell[k] = idx[k] >= 0 ? cell_of(p[k]) : -1;
+      if (cell[k] >= 0) atomicAdd(&S.ccur[cell[k]], 1);
+    }
+    __syncthreads();
+    scan_cells();
+    __syncthreads();
+    if (S.cstart[216] > BK_CAP) return -1;
+#pragma unroll
+    for (int h2 = 0; h2 < BK_RAW; h2 += 4) {         // the second records of the accepted candidates, four in flight
+      float4 u[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[k] = cell[h2 + k] >= 0 ? rec1[idx[h2 + k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (cell[h2 + k] >= 0) store(atomicAdd(&S.ccur[cell[h2 + k]], 1), p[h2 + k], u[k]);
+    }
+  } else {                                           // very dense neighbourhood: two passes over global memory
+    for (int j = tid; j < total_raw; j += BK_THREADS) {
+      const int c = cell_of(rec0[index_of(j)]);
+      if (c >= 0) atomicAdd(&S.ccur[c], 1);
+    }
+    __syncthreads();
+    scan_cells();
+    __syncthreads();
+    if (S.cstart[216] > BK_CAP) return -1;
+    for (int j = tid; j < total_raw; j += BK_THREADS) {
+      const int i = index_of(j);
+      const float4 p = rec0[i];
+      const int c = cell_of(p);
+      if (c >= 0) store(atomicAdd(&S.ccur[c], 1), p, rec1[i]);
+    }
+  }
+  if (tid < 16) {                                    // the brick's own 4x4x4 fine cells: 16 contiguous z-runs
+    // (cstart is final since the scan; ccur is being advanced by the scatter above)
+    const int c = ((1 + tid / 4) * 6 + (1 + tid % 4)) * 6 + 1;
+    S.qbeg[tid] = S.cstart[c];
+    S.qpre[tid + 1] = S.cstart[c + 4] - S.cstart[c];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    S.qpre[0] = 0;
+    for (int k = 1; k <= 16; ++k) { run += S.qpre[k]; S.qpre[k] = run; }
+  }
+  __syncthreads();
+  return S.cstart[216];
+}
+
+template <bool WITH_NRM>
+__device__ __forceinline__ int query_slot(const BrickStage<WITH_NRM>& S, int t) {
+  int r = 0;
+  while (t >= S.qpre[r + 1]) ++r;
+  return S.qbeg[r] + (t - S.qpre[r]);
+}
+
+// The 3x3x3 fine cells around local cell (lx,ly,lz) = nine contiguous slot ranges of the staged
+// block.  body(c0, i0, c1, i1, two): two candidates per trip (both LDS reads issued before either is
+// used; `two` false: the second is a repeat of the first and must be ignored); the bounds of the next
+// range are requested while the current one is walked.
+template <bool WITH_NRM, class Body>
+__device__ __forceinline__ void walk_candidates(const BrickStage<WITH_NRM>& S, int lx, int ly, int lz, Body&& body) {
+  auto cell0 = [&](int c9) { return ((lx + c9 / 3 - 1) * 6 + (ly + c9 % 3 - 1)) * 6 + (lz - 1); };
+  int a = S.cstart[cell0(0)], e = S.cstart[cell0(0) + 3];
+  for (int c9 = 0; c9 < 9; ++c9) {
+    int na = 0, ne = 0;
+    if (c9 < 8) { na = S.cstart[cell0(c9 + 1)]; ne = S.cstart[cell0(c9 + 1) + 3]; }
+    for (int i = a; i < e; i += 2) {
+      const bool two = i + 1 < e;
+      const int i1 = two ? i + 1 : i;
+      const float4 c0 = S.rec0[i];
+      const float4 c1 = S.rec0[i1];
+      body(c0, i, c1, i1, two);
+    }
+    a = na; e = ne;
+  }
+}
+
+// a brick whose neighbourhood does not fit LDS: its own points go to the tail kernel
+__device__ void brick_to_tail(const BrickHdr& h, const int32_t* __restrict__ off, const float4* __restrict__ rec0, int b,
+                              int32_t* __restrict__ tail, int32_t* __restrict__ counters, int tail_slot, int per_query) {
+  for (int i = off[b] + threadIdx.x; i < off[b + 1]; i += BK_THREADS) {
+    const int gid = __float_as_int(rec0[i].w);
+    if (gid >= h.id_base && gid < h.id_base + h.n_own) {
+      const int at = atomicAdd(&counters[tail_slot], per_query);
+      for (int v = 0; v < per_query; ++v) tail[at + v] = per_query > 1 ? (gid - h.id_base) * 8 + v : gid - h.id_base;
+    }
+  }
+  if (threadIdx.x == 0) atomicAdd(&counters[2], 1);
+}
+
+// ---- the repulsion of one point given its sorted neighbours (levelset_sampling.py:268-284) ------
+struct Repulse {
+  float px, py, pz, inv_sigma;
+  float sw = 0.f, mx = 0.f, my = 0.f, mz = 0.f;
+  __device__ __forceinline__ void add(float qx, float qy, float qz, float ux, float uy, float uz) {
+    float un = sqrtf((ux * ux + uy * uy) + uz * uz);        // F.normalize: v / max(|v|, 1e-12)
+    un = un > 1e-12f ? un : 1e-12f;
+    ux = ux / un; uy = uy / un; uz = uz / un;
+    const float dx = px - qx, dy = py - qy, dz = pz - qz;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    const float w = expf(-d2 * inv_sigma);
+    const float dn = (dx * ux + dy * uy) + dz * uz;
+    const float tx = dx - dn * ux, ty = dy - dn * uy, tz = dz - dn * uz;
+    sw += w;
+    mx += w * tx; my += w * ty; mz += w * tz;
+  }
+  __device__ __forceinline__ void finish(float* __restrict__ o) const {
+    const float dens = sw + 1.0f;
+    const float den = iso_eps_denom(sw, 1.0e-17f);
+    o[0] = px + dens * mx / den;
+    o[1] = py + dens * my / den;
+    o[2] = pz + dens * mz / den;
+  }
+};
+
+__device__ __forceinline__ bool pair_lt(float d1, int i1, float d2, int i2) {
+  return d1 < d2 || (d1 == d2 && i1 < i2);
+}
+
+// ---- fused resample step -------------------------------------------------------------------------
+// K = knn_k + 1 (self included), M = list length (>= K + 1).
+template <int M>
+__global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
+    const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off, const int32_t* __restrict__ list,
+    const float4* __restrict__ rec0, const float4* __restrict__ rec1, int K, float* __restrict__ out,
+    int64_t* __restrict__ idx_out, float* __restrict__ d2_out, int32_t* __restrict__ tail,
+    int32_t* __restrict__ counters) {
+  __shared__ BrickStage<true> S;
+  const BrickHdr h = *hp;
+  const int n_list = counters[0];
+  for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const int b = list[li];
+    BrickGeo g;
+    const int C = stage_brick<true>(S, h, off, rec0, rec1, b, g);
+    if (C < 0) { brick_to_tail(h, off, rec0, b, tail, counters, 1, 1); continue; }
+    const int nq = S.qpre[16];
+    for (int t = threadIdx.x; t < nq; t += BK_THREADS) {
+      const int pos = query_slot(S, t);
+      const float4 q = S.rec0[pos];
+      const int gid = __float_as_int(q.w);
+      if (gid < h.id_base || gid >= h.id_base + h.n_own) continue;          // imported halo point
+      const int lx = bk_fine(q.x, h.mn[0], h.inv_f, h.nf[0]) - g.ox;
+      const int ly = bk_fine(q.y, h.mn[1], h.inv_f, h.nf[1]) - g.oy;
+      const int lz = bk_fine(q.z, h.mn[2], h.inv_f, h.nf[2]) - g.oz;
+      unsigned key[M];
+#pragma unroll
+      for (int j = 0; j < M; ++j) key[j] = 0xffffffffu;
+      walk_candidates(S, lx, ly, lz, [&](const float4& c0, int i0, const float4& c1, int i1, bool two) {
+        const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
+        const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
+        const unsigned ka = (__float_as_uint(da) & ~1023u) | (unsigned)i0;
+        const unsigned kb = two ? ((__float_as_uint(db) & ~1023u) | (unsigned)i1) : 0xffffffffu;
+#pragma unroll
+        for (int j = M - 1; j >= 1; --j) key[j] = bk_med3u(key[j - 1], ka, key[j]);
+        key[0] = min(key[0], ka);
+#pragma unroll
+        for (int j = M - 1; j >= 1; --j) key[j] = bk_med3u(key[j - 1], kb, key[j]);
+        key[0] = min(key[0], kb);
+      });
+      // exact (d2, id) order of the survivors
+      float d[M];
+      int id[M], ps[M];
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const bool valid = key[j] != 0xffffffffu;
+        ps[j] = valid ? (int)(key[j] & 1023u) : pos;
+        const float4 c = S.rec0[ps[j]];
+        const float d2 = bk_d2(q.x, q.y, q.z, c.x, c.y, c.z);
+        const bool ok = valid && d2 < h.r2;
+        d[j] = ok ? d2 : FLT_MAX;
+        id[j] = ok ? __float_as_int(c.w) : 0x7fffffff;
+      }
+      bool swapped;
+      do {
+        swapped = false;
+#pragma unroll
+        for (int j = 0; j + 1 < M; ++j) {
+          if (pair_lt(d[j + 1], id[j + 1], d[j], id[j])) {
+            const float td = d[j]; d[j] = d[j + 1]; d[j + 1] = td;
+            const int ti = id[j]; id[j] = id[j + 1]; id[j + 1] = ti;
+            const int tp = ps[j]; ps[j] = ps[j + 1]; ps[j + 1] = tp;
+            swapped = true;
+          }
+        }
+      } while (swapped);
+      unsigned kK = 0xffffffffu;
+      float dK = FLT_MAX;
+#pragma unroll
+      for (int j = 0; j < M; ++j) if (j == K - 1) { kK = key[j]; dK = d[j]; }
+      const bool cert_list = key[M - 1] == 0xffffffffu || (key[M - 1] >> 10) > (kK >> 10);
+      const bool cert_geo = h.g_covers_r || (dK < FLT_MAX && dK <= h.g2);
+      const int row = gid - h.id_base;
+      if (!(cert_list && cert_geo)) { tail[atomicAdd(&counters[1], 1)] = row; continue; }
+      Repulse R;
+      R.px = q.x; R.py = q.y; R.pz = q.z; R.inv_sigma = h.inv_sigma;
+#pragma unroll
+      for (int j = 1; j < M; ++j) {
+        if (j < K && d[j] < FLT_MAX) {
+          const float4 c = S.rec0[ps[j]];
+          const float4 u = S.rec1[ps[j]];
+          R.add(c.x, c.y, c.z, u.x, u.y, u.z);
+        }
+      }
+      R.finish(out + (int64_t)row * 3);
+      if (idx_out) {
+#pragma unroll
+        for (int j = 1; j < M; ++j)
+          if (j < K) {
+            idx_out[(int64_t)row * (K - 1) + j - 1] = d[j] < FLT_MAX ? (int64_t)id[j] : (int64_t)-1;
+            if (d2_out) d2_out[(int64_t)row * (K - 1) + j - 1] = d[j] < FLT_MAX ? d[j] : -1.0f;
+          }
+      }
+    }
+  }
+}
+
+// ---- rings of bricks around a query (tail kernels: one wave per query) ---------------------------
+// All lanes walk the same column of bricks and split its records (a ring has as few as one
+// column).
+template <class Body>
+__device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz, int nbx, int nby, int nbz,
+                                             const int32_t* __restrict__ off, int lane, Body&& body) {
+  const int x0 = max(qbx - rho, 0), x1 = min(qbx + rho, nbx - 1);
+  const int y0 = max(qby - rho, 0), y1 = min(qby + rho, nby - 1);
+  for (int x = x0; x <= x1; ++x)
+    for (int y = y0; y <= y1; ++y) {
+      const bool edge = (x == qbx - rho) || (x == qbx + rho) || (y == qby - rho) || (y == qby + rho);
+      const int nseg = edge ? 1 : 2;
+      for (int sg = 0; sg < nseg; ++sg) {
+        int za, zb;
+        if (edge) { za = qbz - rho; zb = qbz + rho; }
+        else if (sg == 0) { za = qbz - rho; zb = qbz - rho; }
+        else { za = qbz + rho; zb = qbz + rho; }
+        za = max(za, 0); zb = min(zb, nbz - 1);
+        if (za > zb) continue;
+        const int c0 = (x * nby + y) * nbz + za, c1 = (x * nby + y) * nbz + zb;
+        const int e = off[c1 + 1];
+        for (int i = off[c0] + lane; i < e; i += 64) body(i);
+      }
+    }
+}
+
+template <int KMAX>
+struct Top3 {          // K smallest (d, id) with the sorted position of the record alongside
+  float d[KMAX];
+  int id[KMAX], at[KMAX];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) { d[j] = FLT_MAX; id[j] = 0x7fffffff; at[j] = 0; }
+  }
+  __device__ __forceinline__ void push(float cd, int ci, int ca, int K) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < K && pair_lt(cd, ci, d[j], id[j])) {
+        const float td = d[j]; const int ti = id[j], ta = at[j];
+        d[j] = cd; id[j] = ci; at[j] = ca;
+        cd = td; ci = ti; ca = ta;
+      }
+    }
+  }
+};
+
+// K rounds of a wave-wide arg-min over the lanes' list heads.  emit(k, d, id, at) is called with
+// wave-uniform arguments for k = 0..K-1 (d == FLT_MAX: no such neighbour); returns the K-th distance.
+template <int KMAX, class Emit>
+__device__ __forceinline__ float wave_merge3(const Top3<KMAX>& best, int K, Emit&& emit) {
+  int head = 0;
+  float kth = FLT_MAX;
+  for (int k = 0; k < K; ++k) {
+    float hd = FLT_MAX;
+    int hi = 0x7fffffff, ha = 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) if (j == head) { hd = best.d[j]; hi = best.id[j]; ha = best.at[j]; }
+    float md = hd;
+    int mi = hi, ma = ha;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float od = __shfl_xor(md, o);
+      const int oi = __shfl_xor(mi, o), oa = __shfl_xor(ma, o);
+      if (pair_lt(od, oi, md, mi)) { md = od; mi = oi; ma = oa; }
+    }
+    if (hd == md && hi == mi && md < FLT_MAX) ++head;
+    if (k == K - 1) kth = md;
+    emit(k, md, mi, ma);
+  }
+  return kth;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(64) void k_brick_resample_tail(
+    const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off, const float4* __restrict__ rec0,
+    const float4* __restrict__ rec1, const float* __restrict__ pts, int K, float* __restrict__ out,
+    int64_t* __restrict__ idx_out, float* __restrict__ d2_out, const int32_t* __restrict__ tail,
+    const int32_t* __restrict__ counters) {
+  const BrickHdr h = *hp;
+  const int lane = threadIdx.x;
+  const int count = counters[1];
+  const float B = 4.0f * h.f;
+  const int rho_max = max(h.nb[0], max(h.nb[1], h.nb[2]));
+  for (int w = blockIdx.x; w < count; w += gridDim.x) {
+    const int row = tail[w];
+    const float qx = pts[(int64_t)row * 3], qy = pts[(int64_t)row * 3 + 1], qz = pts[(int64_t)row * 3 + 2];
+    const int qbx = bk_fine(qx, h.mn[0], h.inv_f, h.nf[0]) >> 2;
+    const int qby = bk_fine(qy, h.mn[1], h.inv_f, h.nf[1]) >> 2;
+    const int qbz = bk_fine(qz, h.mn[2], h.inv_f, h.nf[2]) >> 2;
+    Top3<KMAX> best;
+    best.init();
+    float wd = FLT_MAX;
+    int wi = 0x7fffffff;
+    int found = 0;
+    for (int rho = 0; rho <= rho_max; ++rho) {
+      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, [&](int i) {
+        const float4 c = rec0[i];
+        const float d2 = bk_d2(qx, qy, qz, c.x, c.y, c.z);
+        if (d2 < h.r2) {
+          if (found < KMAX) ++found;
+          const int ci = __float_as_int(c.w);
+          if (pair_lt(d2, ci, wd, wi)) {
+            best.push(d2, ci, i, K);
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wd = best.d[j]; wi = best.id[j]; }
+          }
+        }
+      });
+      if (rho >= 1) {
+        const float gg = (float)rho * B * 0.999f;
+        if (gg >= h.r) break;
+        int tot = found;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        if (tot >= K) {
+          const float kth = wave_merge3<KMAX>(best, K, [](int, float, int, int) {});
+          if (kth < FLT_MAX && kth <= gg * gg) break;
+        }
+      }
+    }
+    Repulse R;
+    R.px = qx; R.py = qy; R.pz = qz; R.inv_sigma = h.inv_sigma;
+    wave_merge3<KMAX>(best, K, [&](int k, float md, int mi, int ma) {
+      if (k == 0) return;                                  // column 0 is dropped (levelset_sampling.py:136-138)
+      if (md < FLT_MAX) {
+        const float4 c = rec0[ma];
+        const float4 u = rec1[ma];
+        R.add(c.x, c.y, c.z, u.x, u.y, u.z);
+      }
+      if (idx_out && lane == 0) {
+        idx_out[(int64_t)row * (K - 1) + k - 1] = md < FLT_MAX ? (int64_t)mi : (int64_t)-1;
+        if (d2_out) d2_out[(int64_t)row * (K - 1) + k - 1] = md < FLT_MAX ? md : -1.0f;
+      }
+    });
+    if (lane == 0) R.finish(out + (int64_t)row * 3);
+  }
+}
+
+// ---- renderable flags of every point for up to 8 views (rasterizer.py:184-254) --------------------
+__global__ __launch_bounds__(256) void k_view_mask(const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                   const float* __restrict__ views, int n_views, int64_t n,
+                                                   float znear, float zfar, int backface,
+                                                   int32_t* __restrict__ mask, int32_t* __restrict__ view_count) {
+  __shared__ int s_cnt[8];
+  if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int local[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (backface) { nx = nrm[i * 3]; ny = nrm[i * 3 + 1]; nz = nrm[i * 3 + 2]; }
+    int m = 0;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      if (v < n_views) {
+        const float* V = views + v * 16;                    // row-vector convention: p_view = [p,1] @ V
+        const float zv = ((x * V[2] + y * V[6]) + z * V[10]) + V[14];
+        bool ok = (zv >= znear) && (zv <= zfar);
+        if (backface) ok = ok && (((nx * V[2] + ny * V[6]) + nz * V[10]) < 0.f);
+        if (ok) { m |= 1 << v; ++local[v]; }
+      }
+    }
+    mask[i] = m;
+  }
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    if (v < n_views) {
+      int c = local[v];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+      if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[v], c);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < n_views && s_cnt[threadIdx.x]) atomicAdd(&view_count[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+// ---- fused splat bandwidth -----------------------------------------------------------------------
+// h of a point in view v from the sorted 7 smallest d2 among the view's points within r (self
+// included): the stand-alone path takes max(dists[1..6]) of a -1-padded row (iso_splat_vrk_h).
+__device__ __forceinline__ float h_from_list(const float* d /*7 ascending, FLT_MAX = none*/, bool small_cloud) {
+  float m = -FLT_MAX;
+#pragma unroll
+  for (int k = 1; k < 7; ++k) {
+    const float v = small_cloud ? 1e-3f : (d[k] < FLT_MAX ? d[k] : -1.0f);
+    m = fmaxf(m, v);
+  }
+  return fminf(fmaxf(0.5f * m, 5e-5f), 0.01f);
+}
+
+template <int NV>
+__global__ __launch_bounds__(BK_THREADS, 4) void k_brick_h(
+    const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off, const int32_t* __restrict__ list,
+    const float4* __restrict__ rec0, const float4* __restrict__ rec1, const int32_t* __restrict__ view_total,
+    int n_views, float* __restrict__ h_out /*(n_views, n_own)*/, int32_t* __restrict__ tail,
+    int32_t* __restrict__ counters) {
+  __shared__ BrickStage<false> S;
+  const BrickHdr h = *hp;
+  const int n_list = counters[0];
+  bool small_cloud[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) small_cloud[v] = v < n_views && view_total[v] < 7;
+  // 0.5 d2 <= 5e-5 (the lower clamp of h) <=> d2 <= kT: seven such points settle h without their order
+  const float kT = 2.0f * 5e-5f;
+  const float t2 = fminf(kT, h.r2 > 0.f ? __uint_as_float(__float_as_uint(h.r2) - 1u) : 0.f);   // and d2 < r2
+  for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const int b = list[li];
+    BrickGeo g;
+    const int C = stage_brick<false>(S, h, off, rec0, rec1, b, g);
+    if (C < 0) { brick_to_tail(h, off, rec0, b, tail, counters, 3, 8); continue; }
+    const int nq = S.qpre[16];
+    for (int t0 = 0; t0 < nq; t0 += BK_THREADS) {
+      const int t = t0 + threadIdx.x;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      int qmask = 0, lx = 1, ly = 1, lz = 1, row = 0;
+      if (t < nq) {
+        const int pos = query_slot(S, t);
+        q = S.rec0[pos];
+        qmask = __float_as_int(q.w);
+        if (qmask < 0) qmask = 0;                                    // imported halo point: not a query
+        row = S.gid[pos] - h.id_base;
+        lx = bk_fine(q.x, h.mn[0], h.inv_f, h.nf[0]) - g.ox;
+        ly = bk_fine(q.y, h.mn[1], h.inv_f, h.nf[1]) - g.oy;
+        lz = bk_fine(q.z, h.mn[2], h.inv_f, h.nf[2]) - g.oz;
+      }
+      // pass 1: renderable neighbours within kT per view
+      int cnt[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) cnt[v] = 0;
+      if (qmask)
+        walk_candidates(S, lx, ly, lz, [&](const float4& c0, int, const float4& c1, int, bool two) {
+          const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
+          const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
+          const int ma = da <= t2 ? __float_as_int(c0.w) : 0;
+          const int mb = (two && db <= t2) ? __float_as_int(c1.w) : 0;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) cnt[v] += ((ma >> v) & 1) + ((mb >> v) & 1);
+        });
+      bool open_ = false;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) open_ = open_ || (((qmask >> v) & 1) && !small_cloud[v] && cnt[v] < 7);
+      // pass 2 (only the lanes with an open view; rare away from the terminator of a dense cloud):
+      // the 7 smallest d2 per view
+      float d[NV][7];
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) d[v][j] = FLT_MAX;
+      if (open_)
+        walk_candidates(S, lx, ly, lz, [&](const float4& c0, int, const float4& c1, int, bool two) {
+          float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
+          float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
+          da = da < h.r2 ? da : FLT_MAX;
+          db = (two && db < h.r2) ? db : FLT_MAX;
+          const int ma = __float_as_int(c0.w), mb = __float_as_int(c1.w);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            const float ka = (ma >> v) & 1 ? da : FLT_MAX;
+            const float kb = (mb >> v) & 1 ? db : FLT_MAX;
+#pragma unroll
+            for (int j = 6; j >= 1; --j) d[v][j] = __builtin_amdgcn_fmed3f(d[v][j - 1], ka, d[v][j]);
+            d[v][0] = fminf(d[v][0], ka);
+#pragma unroll
+            for (int j = 6; j >= 1; --j) d[v][j] = __builtin_amdgcn_fmed3f(d[v][j - 1], kb, d[v][j]);
+            d[v][0] = fminf(d[v][0], kb);
+          }
+        });
+      if (qmask) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          if (v < n_views && ((qmask >> v) & 1)) {
+            float hv;
+            bool cert = true;
+            if (small_cloud[v]) hv = fminf(fmaxf(0.5f * 1e-3f, 5e-5f), 0.01f);
+            else if (cnt[v] >= 7) hv = 5e-5f;
+            else {
+              cert = h.g_covers_r || (d[v][6] < FLT_MAX && d[v][6] <= h.g2);
+              hv = h_from_list(d[v], false);
+            }
+            if (cert) h_out[(int64_t)v * h.n_own + row] = hv;
+            else tail[atomicAdd(&counters[3], 1)] = row * 8 + v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int KMAX>
+struct TopF {
+  float d[KMAX];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) d[j] = FLT_MAX;
+  }
+  __device__ __forceinline__ void push(float k) {
+#pragma unroll
+    for (int j = KMAX - 1; j >= 1; --j) d[j] = __builtin_amdgcn_fmed3f(d[j - 1], k, d[j]);
+    d[0] = fminf(d[0], k);
+  }
+};
+
+// the 7 smallest values of the union of the lanes' sorted lists, wave-uniform
+__device__ __forceinline__ void wave_merge_f7(const TopF<7>& best, float* out7) {
+  int head = 0;
+  for (int k = 0; k < 7; ++k) {
+    float hd = FLT_MAX;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) if (j == head) hd = best.d[j];
+    float md = hd;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) md = fminf(md, __shfl_xor(md, o));
+    // exactly one of the lanes holding the minimum pops (the lowest lane)
+    const unsigned long long holders = __ballot(hd == md && md < FLT_MAX);
+    if (holders && (int)(__ffsll((long long)holders) - 1) == (int)(threadIdx.x & 63)) ++head;
+    out7[k] = md;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_brick_h_tail(
+    const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off, const float4* __restrict__ rec0,
+    const float4* __restrict__ rec1, const float* __restrict__ pts, const int32_t* __restrict__ mask,
+    const int32_t* __restrict__ view_total, int n_views, float* __restrict__ h_out,
+    const int32_t* __restrict__ tail, const int32_t* __restrict__ counters) {
+  const BrickHdr h = *hp;
+  const int lane = threadIdx.x;
+  const int count = counters[3];
+  const float B = 4.0f * h.f;
+  const int rho_max = max(h.nb[0], max(h.nb[1], h.nb[2]));
+  for (int w = blockIdx.x; w < count; w += gridDim.x) {
+    const int row = tail[w] >> 3, v = tail[w] & 7;
+    if (v >= n_views || !((mask[row] >> v) & 1)) continue;           // (a whole overflowing brick was queued)
+    const float qx = pts[(int64_t)row * 3], qy = pts[(int64_t)row * 3 + 1], qz = pts[(int64_t)row * 3 + 2];
+    const int qbx = bk_fine(qx, h.mn[0], h.inv_f, h.nf[0]) >> 2;
+    const int qby = bk_fine(qy, h.mn[1], h.inv_f, h.nf[1]) >> 2;
+    const int qbz = bk_fine(qz, h.mn[2], h.inv_f, h.nf[2]) >> 2;
+    const bool small_cloud = view_total[v] < 7;
+    TopF<7> best;
+    best.init();
+    float m7[7];
+    for (int rho = 0; rho <= rho_max; ++rho) {
+      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, [&](int i) {
+        const float4 c = rec0[i];
+        if (!((__float_as_int(rec1[i].w) >> v) & 1)) return;
+        const float d2 = bk_d2(qx, qy, qz, c.x, c.y, c.z);
+        if (d2 < h.r2) best.push(d2);
+      });
+      if (rho >= 1) {
+        const float gg = (float)rho * B * 0.999f;
+        if (gg >= h.r) break;
+        wave_merge_f7(best, m7);
+        if (m7[6] < FLT_MAX && m7[6] <= gg * gg) break;
+      }
+    }
+    wave_merge_f7(best, m7);
+    if (lane == 0) h_out[(int64_t)v * h.n_own + row] = h_from_list(m7, small_cloud);
+  }
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int64_t iso_bricks_workspace_bytes(int64_t n_max) {
+  return bricks_carve(nullptr, n_max).bytes;
+}
+
+extern "C" int iso_bricks_build(const float* points, const float* normals, const int32_t* payload,
+                                int64_t n_own, int64_t id_base, const float* import_rec0,
+                                const float* import_rec1, const int32_t* import_count, int64_t import_max,
+                                const float* bbox, int64_t n_total, float radius, int knn_k,
+                                float cell_scale, void* workspace, int64_t workspace_bytes, void* stream) {
+  ISO_REQUIRE(n_own >= 0 && import_max >= 0 && n_total >= 0, ISO_ERR_INVALID, "iso_bricks_build: bad sizes");
+  ISO_REQUIRE(bbox && workspace && (points || n_own == 0), ISO_ERR_INVALID, "iso_bricks_build: null pointer");
+  ISO_REQUIRE(import_max == 0 || (import_rec0 && import_rec1 && import_count), ISO_ERR_INVALID,
+              "iso_bricks_build: import buffers missing");
+  ISO_REQUIRE(cell_scale > 0.f && (radius > 0.f || knn_k > 0), ISO_ERR_INVALID,
+              "iso_bricks_build: cell_scale and radius / knn_k must be positive");
+  ISO_REQUIRE(((uintptr_t)workspace & 255) == 0, ISO_ERR_INVALID, "iso_bricks_build: workspace must be 256-B aligned");
+  const int64_t n_max = n_own + import_max;
+  ISO_REQUIRE(id_base + n_max < (1ll << 28), ISO_ERR_UNSUPPORTED, "iso_bricks_build: ids must stay below 2^28");
+  const BrickWs w = bricks_carve(workspace, n_max);
+  ISO_REQUIRE(workspace_bytes >= w.bytes, ISO_ERR_WORKSPACE, "iso_bricks_build: workspace too small (%lld < %lld)",
+              (long long)workspace_bytes, (long long)w.bytes);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, s, bbox, n_total, n_own, id_base, radius, knn_k,
+                     cell_scale, w.nb_cap, w.hdr, w.counters);
+  hipLaunchKernelGGL(k_bricks_zero, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, s, w.hdr, w.cnt);
+  if (n_own > 0)
+    hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, n_own, w.hdr, w.cnt,
+                       w.slot);
+  if (import_max > 0)
+    hipLaunchKernelGGL(k_brick_count_recs, dim3(iso_stream_grid(import_max, 256)), dim3(256), 0, s,
+                       (const float4*)import_rec0, import_count, import_max, w.hdr, w.cnt, w.slot);
+  int rc = iso_frnn_scan_cells(w.cnt, w.off, reinterpret_cast<const float*>(w.hdr), 1, w.G, 3, w.scan_ws,
+                               w.scan_ws_bytes, stream);
+  if (rc != ISO_OK) return rc;
+  if (n_own > 0)
+    hipLaunchKernelGGL(k_brick_scatter, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, normals, payload,
+                       n_own, w.hdr, w.off, w.slot, w.rec0, w.rec1);
+  if (import_max > 0)
+    hipLaunchKernelGGL(k_brick_scatter_recs, dim3(iso_stream_grid(import_max, 256)), dim3(256), 0, s,
+                       (const float4*)import_rec0, (const float4*)import_rec1, w.hdr, w.off, w.slot, w.rec0, w.rec1);
+  hipLaunchKernelGGL(k_brick_list, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, s, w.hdr, w.off, w.list, w.counters);
+  ISO_CHECK_LAUNCH("iso_bricks_build");
+  return ISO_OK;
+}
+
+static int fused_grid() { return 256 * 8; }
+
+extern "C" int iso_resample_fused(void* workspace, int64_t n_max, const float* points, int64_t n_own,
+                                  int k_plus_one, float* points_out, int64_t* idx_out, float* d2_out,
+                                  void* stream) {
+  ISO_REQUIRE(workspace && n_own >= 0 && n_max >= n_own, ISO_ERR_INVALID, "iso_resample_fused: bad arguments");
+  ISO_REQUIRE(k_plus_one >= 2 && k_plus_one <= 13, ISO_ERR_UNSUPPORTED,
+              "iso_resample_fused: K + 1 must be in [2,13], got %d", k_plus_one);
+  if (n_own == 0) return ISO_OK;
+  ISO_REQUIRE(points && points_out && points != points_out, ISO_ERR_INVALID, "iso_resample_fused: null / aliased pointer");
+  const BrickWs w = bricks_carve(workspace, n_max);
+  hipStream_t s = (hipStream_t)stream;
+  const int K = k_plus_one;
+#define ISO_RS(MM)                                                                                           \
+  hipLaunchKernelGGL(k_brick_resample<MM>, dim3(fused_grid()), dim3(BK_THREADS), 0, s, w.hdr, w.off, w.list, \
+                     w.rec0, w.rec1, K, points_out, idx_out, d2_out, w.tail, w.counters)
+  if (K <= 5) ISO_RS(8);
+  else if (K <= 9) ISO_RS(12);
+  else ISO_RS(16);
+#undef ISO_RS
+  int tb = (int)(n_own < 4096 ? n_own : 4096);
+  hipLaunchKernelGGL(k_brick_resample_tail<16>, dim3(tb), dim3(64), 0, s, w.hdr, w.off, w.rec0, w.rec1, points, K,
+                     points_out, idx_out, d2_out, w.tail, w.counters);
+  ISO_CHECK_LAUNCH("iso_resample_fused");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_view_mask(const float* points, const float* normals, const float* views, int n_views,
+                                   int64_t n, float znear, float zfar, int backface_culling, int32_t* mask_out,
+                                   int32_t* view_count_out, void* stream) {
+  ISO_REQUIRE(n >= 0 && n_views >= 1 && n_views <= 8, ISO_ERR_UNSUPPORTED, "iso_splat_view_mask: 1..8 views per call");
+  ISO_REQUIRE(views && mask_out && view_count_out && (points || n == 0) && (normals || !backface_culling),
+              ISO_ERR_INVALID, "iso_splat_view_mask: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(view_count_out, 0, 8 * sizeof(int32_t), s);
+  if (n > 0)
+    hipLaunchKernelGGL(k_view_mask, dim3(iso_stream_grid(n, 256 * 4)), dim3(256), 0, s, points, normals, views, n_views,
+                       n, znear, zfar, backface_culling, mask_out, view_count_out);
+  ISO_CHECK_LAUNCH("iso_splat_view_mask");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_h_fused(void* workspace, int64_t n_max, const float* points, const int32_t* mask,
+                                 int64_t n_own, const int32_t* view_total, int n_views, float* h_out,
+                                 void* stream) {
+  ISO_REQUIRE(workspace && n_own >= 0 && n_max >= n_own, ISO_ERR_INVALID, "iso_splat_h_fused: bad arguments");
+  ISO_REQUIRE(n_views >= 1 && n_views <= 8, ISO_ERR_UNSUPPORTED, "iso_splat_h_fused: 1..8 views per call");
+  if (n_own == 0) return ISO_OK;
+  ISO_REQUIRE(points && mask && view_total && h_out, ISO_ERR_INVALID, "iso_splat_h_fused: null pointer");
+  const BrickWs w = bricks_carve(workspace, n_max);
+  hipStream_t s = (hipStream_t)stream;
+#define ISO_H(NV)                                                                                            \
+  hipLaunchKernelGGL(k_brick_h<NV>, dim3(fused_grid()), dim3(BK_THREADS), 0, s, w.hdr, w.off, w.list, w.rec0, \
+                     w.rec1, view_total, n_views, h_out, w.tail, w.counters)
+  if (n_views <= 1) ISO_H(1);
+  else if (n_views <= 2) ISO_H(2);
+  else if (n_views <= 4) ISO_H(4);
+  else ISO_H(8);
+#undef ISO_H
+  hipLaunchKernelGGL(k_brick_h_tail, dim3(4096), dim3(64), 0, s, w.hdr, w.off, w.rec0, w.rec1, points, mask, view_total,
+                     n_views, h_out, w.tail, w.counters);
+  ISO_CHECK_LAUNCH("iso_splat_h_fused");
+  return ISO_OK;
+}
