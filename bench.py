@@ -86,9 +86,13 @@ class Cycle(object):
                                          depth_merging_threshold=0.05, radii_backward_scaler=10,
                                          backface_culling=True, Vrk_isotropic=True, bin_size=None)
         views, projs = cameras(device)
+        from iso_points_amd.dist import slab_order
         pts0 = sphere_cloud(P_TOTAL, seed=0, device=device)          # identical on every rank
+        pts0 = pts0[:, slab_order(pts0[0], comm.world)].contiguous()  # N ranks: the job's point order is x-slab major
         self.cyc = IsoCycle(model, pts0, views, projs, raster_settings=rs, knn_k=8, comm=comm,
                             target=sphere_silhouette(IMAGE, VIEWS, 3.0, 30.0, device))
+        if comm.world > 1:
+            self.cyc.calibrate()                                     # untimed: sizes of the exchange buffers
         self.cyc.project_hook = self._timed_project
         self.ev = []
         self.timed = False
@@ -129,7 +133,7 @@ class Cycle(object):
             counts.append([n] + c[1:T + 1])
             return r
         cyc.project_hook = hook
-        cyc.project_resample()
+        cyc.run(cyc.project_resample())
         cyc.project_hook = self._timed_project
         return counts
 
@@ -291,8 +295,8 @@ def main():
                        "sdf": "SIREN 3->256x4->1 (omega 30), fitted to the unit sphere (300 Adam steps, seed 0)",
                        "points": P_TOTAL,
                        "parallelism": "1 rank" if world == 1 else
-                       "points (per-point stages) and tile-row bands (per-pixel stages) sharded x%d, RCCL "
-                       "all-gather/all-reduce" % world},
+                       "x-slabs of the cloud (per-point stages; halo cells all-gathered) and tile-row bands "
+                       "(per-pixel stages; packed rows all-gathered) x%d ranks, RCCL" % world},
             "roofline": {"bound": "mfma",
                          "kernel": ("k_siren_step_x3<256,8,3,1,false> (fused SIREN SDF+grad Newton step, split-fp16 MFMA)" if x3
                                     else "k_siren_step<16> (fused SIREN SDF+grad Newton step, f32 MFMA)"),

@@ -490,6 +490,22 @@ int iso_bricks_build(const float* points, const float* normals, const int32_t* p
                      const float* import_rec1, const int32_t* import_count, int64_t import_max,
                      const float* bbox, int64_t n_total, float radius, int knn_k,
                      float cell_scale, void* workspace, int64_t workspace_bytes, void* stream);
+/* N ranks, one x-slab of the cloud each: every rank derives the SAME grid from the
+ * reduced bounding box (iso_bricks_params), exports the points other ranks' queries can reach
+ * (iso_halo_export: fine x-cell within one cell of another rank's local x-range; rank_boxes =
+ * (world, 8) floats, every rank's local iso_points_bbox), the export buffers are all-gathered
+ * (one RCCL all-gather of `export_buf`: float4[2][capacity + 1], word 0 = record count), and each
+ * rank keeps what its own queries can reach (iso_halo_import) as the imported records of
+ * iso_bricks_build (bbox = NULL: header already written).  Overflows are counted in the grid's
+ * counters (slot 4: an exporter ran out of capacity, slot 5: the import buffer did).          */
+int iso_bricks_params(const float* bbox, int64_t n_total, int64_t n_own, int64_t id_base, float radius,
+                      int knn_k, float cell_scale, void* workspace, int64_t n_max, void* stream);
+int iso_halo_export(void* workspace, const float* points, const float* normals, const int32_t* payload,
+                    int64_t n_own, const float* rank_boxes, int world, int rank, float* export_buf,
+                    int64_t capacity, void* stream);
+int iso_halo_import(void* workspace, int64_t n_max, const float* gathered, const float* rank_boxes, int world,
+                    int rank, int64_t capacity, float* import_rec0, float* import_rec1,
+                    int32_t* import_count, int64_t import_capacity, void* stream);
 /* One resample move of every own point: K+1 = k_plus_one self-inclusive FRNN query (radius of
  * the build), column 0 dropped, tangent-plane repulsion with inv_sigma = n_total / diag
  * (levelset_sampling.py:254-284; same arithmetic as iso_frnn_query + iso_repulse).  `points`
@@ -512,6 +528,46 @@ int iso_splat_view_mask(const float* points, const float* normals, const float* 
 int iso_splat_h_fused(void* workspace, int64_t n_max, const float* points, const int32_t* mask,
                       int64_t n_own, const int32_t* view_total, int n_views, float* h_out,
                       void* stream);
+/* Front end of the splat for ONE cloud seen by up to 8 cameras, on the unfiltered cloud and without a
+ * host read: mask (iso_splat_view_mask) + h (iso_splat_h_fused) -> the packed per-view arrays that
+ * _C.splat_points takes (SurfaceSplatting.forward, rasterizer.py:597-661: filter, extend to the
+ * cameras, _get_per_point_info, transform).  Packed order = view-major, points ascending (the
+ * reference's); first_idx_out / num_pts_out (n_views) int64 and view_total_out (8) int32 are written
+ * on the device; the per-point outputs must hold n_views * n_points rows (upper bound), rows beyond
+ * first[n_views-1] + num[n_views-1] stay untouched.  features (n_points, channels) -> features_out
+ * packed, or features_from_normals = 1: 0.5 (normalize(n) + 1) (3 channels); src_out: original point of
+ * every packed row (scatter of the row gradients back to the cloud).  Same arithmetic as
+ * iso_splat_view_flags + iso_compact_rows + iso_splat_setup.                                     */
+int64_t iso_splat_front_workspace_bytes(int64_t n_points);
+int iso_splat_front(const float* points, const float* normals, const float* features, int channels,
+                    int features_from_normals, const int32_t* mask, const float* h, int64_t n_points,
+                    const float* views, const float* projs, int n_views, int image_size, float sigma,
+                    float cutoff, void* workspace, int64_t workspace_bytes, int64_t* first_idx_out,
+                    int64_t* num_pts_out, int32_t* view_total_out, float* ndc_out, float* ellipse_out,
+                    float* cutoff_out, float* radii_out, float* scaler_out, float* features_out,
+                    int32_t* src_out, void* stream);
+/* The z gradient of iso_splat_backward in pieces, for N ranks that each own a band of tile rows:
+ * zscale (2 ints: bits of max |grad_zbuf|, exponent) <- iso_splat_z_absmax over the rank's pixels, MAX-
+ * reduced over the ranks (word 0); iso_splat_z_scatter derives the exponent and adds the rank's pixels
+ * into the zero-initialised 64-bit accumulators acc (total rows); acc is SUM-reduced over the ranks;
+ * iso_splat_z_finish converts rows [row0, row0 + n_rows) into grad_points[:, 2].  Exactly rounded and
+ * order independent like the single-GPU path (ZbufBackwardKernel, rasterize_points.cu:823-846).     */
+int iso_splat_z_absmax(const float* grad_zbuf, int64_t n, int32_t* zscale, void* stream);
+int iso_splat_z_scatter(const int32_t* idx, const float* grad_zbuf, int64_t n_pixels, int points_per_pixel,
+                        int image_size, int32_t* zscale, int64_t* acc, void* stream);
+int iso_splat_z_finish(const int64_t* acc, const int32_t* zscale, int64_t row0, int64_t n_rows,
+                       float* grad_points, void* stream);
+/* N ranks: the packed per-view arrays of the WHOLE cloud (view-major, then rank, then the rank's own
+ * order = the single-GPU order when the ranks hold consecutive ranges of the cloud) from the
+ * all-gathered per-rank outputs of iso_splat_front.  gathered: world blocks of 12 * capacity floats
+ * (ndc 3, ellipse 3, radii 2, scaler 1, features 3 -- the front end's outputs laid out in one
+ * buffer); counts (world, 8) int32: the ranks' view_total_out.  own_first / own_num: this rank's
+ * rows inside the global layout.                                                              */
+int iso_splat_repack(const float* gathered, int64_t capacity, int world, int rank, int n_views,
+                     const int32_t* counts, float cutoff, int64_t max_rows, float* ndc_out,
+                     float* ellipse_out, float* cutoff_out, float* radii_out, float* scaler_out,
+                     float* features_out, int64_t* first_idx_out, int64_t* num_pts_out,
+                     int64_t* own_first_out, int64_t* own_num_out, void* stream);
 
 #ifdef __cplusplus
 }

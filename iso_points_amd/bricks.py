@@ -37,10 +37,13 @@ class BrickGrid(object):
         self.points = None
 
     def build(self, points, normals=None, payload=None, bbox=None, n_total=None, radius=-1.0, knn_k=8,
-              cell_scale=None, id_base=0, imports=None):
-        """points (n_own,3) f32 contiguous; imports = (rec0 (m,4), rec1 (m,4), count int32 (1,)) or None."""
+              cell_scale=None, id_base=0, imports=None, params_done=False):
+        """points (n_own,3) f32 contiguous; imports = (rec0 (m,4), rec1 (m,4), count int32 (1,)) or None.
+        params_done: the header was already written by iso_bricks_params (N ranks)."""
         assert points.shape == (self.n_own, 3) and points.dtype == torch.float32 and points.is_contiguous()
-        if bbox is None:
+        if params_done:
+            bbox, radius, knn_k, cell_scale = None, 1.0, 1, 1.0
+        elif bbox is None:
             bbox = points_bbox(points)
         if cell_scale is None:
             cell_scale = RESAMPLE_CELL * knn_k

@@ -865,6 +865,90 @@ __global__ __launch_bounds__(64) void k_brick_h_tail(
   }
 }
 
+// ---- halo exchange between x-slabs (one rank per GPU) ---------------------------------------------
+// Every rank's LOCAL bounding box is known to all (ranges: (world, 8) floats, iso_points_bbox layout).
+// Rank k's queries live in fine x-cells [fx(min_k), fx(max_k)]; their 3x3x3 neighbourhoods reach one
+// fine cell further, so rank j exports exactly its points whose fine x-cell lies in that widened range
+// of some other rank, and rank k imports, from what all ranks exported, those in its own widened range.
+// Buffers: float4[2][cap + 1]; word 0 of record 0 is the record count (int bits).
+__device__ __forceinline__ void wave_append(bool take, int32_t* counter, int cap, int& slot) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long bal = __ballot(take);
+  int base = 0;
+  if (lane == 0 && bal) base = atomicAdd(counter, __popcll(bal));
+  base = __shfl(base, 0);
+  slot = take ? base + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
+  if (slot >= cap) slot = -1;
+}
+
+__global__ __launch_bounds__(256) void k_halo_export(const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                     const int32_t* __restrict__ payload, int64_t n_own,
+                                                     const BrickHdr* __restrict__ hp, const float* __restrict__ ranges,
+                                                     int world, int rank, float4* __restrict__ out, int cap) {
+  const BrickHdr h = *hp;
+  int32_t* counter = reinterpret_cast<int32_t*>(out);
+  const int64_t span = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n_own; i0 += span) {
+    const int64_t i = i0 + threadIdx.x;
+    bool take = false;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (i < n_own) {
+      x = pts[i * 3]; y = pts[i * 3 + 1]; z = pts[i * 3 + 2];
+      const int fx = bk_fine(x, h.mn[0], h.inv_f, h.nf[0]);
+      for (int k = 0; k < world; ++k) {
+        if (k == rank) continue;
+        const int lo = bk_fine(ranges[k * 8], h.mn[0], h.inv_f, h.nf[0]) - 1;
+        const int hi = bk_fine(ranges[k * 8 + 4], h.mn[0], h.inv_f, h.nf[0]) + 1;
+        take = take || (fx >= lo && fx <= hi);
+      }
+    }
+    int slot;
+    wave_append(take, counter, cap, slot);
+    if (slot >= 0) {
+      out[1 + slot] = make_float4(x, y, z, __int_as_float(h.id_base + (int)i));
+      float4 u = make_float4(0.f, 0.f, 0.f, __int_as_float(payload ? payload[i] : 0));
+      if (nrm) { u.x = nrm[i * 3]; u.y = nrm[i * 3 + 1]; u.z = nrm[i * 3 + 2]; }
+      out[(int64_t)cap + 1 + 1 + slot] = u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_halo_import(const float4* __restrict__ gathered, int world, int rank, int cap,
+                                                     const BrickHdr* __restrict__ hp, const float* __restrict__ ranges,
+                                                     float4* __restrict__ imp0, float4* __restrict__ imp1,
+                                                     int32_t* __restrict__ imp_count, int imp_cap,
+                                                     int32_t* __restrict__ counters) {
+  const int src = blockIdx.y;
+  if (src == rank) return;
+  const BrickHdr h = *hp;
+  const float4* blk = gathered + (int64_t)src * 2 * (cap + 1);
+  int cnt = __float_as_int(blk[0].x);
+  if (cnt > cap) { cnt = cap; if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[4], 1); }   // the exporter overflowed
+  const int lo = bk_fine(ranges[rank * 8], h.mn[0], h.inv_f, h.nf[0]) - 1;
+  const int hi = bk_fine(ranges[rank * 8 + 4], h.mn[0], h.inv_f, h.nf[0]) + 1;
+  const int span = gridDim.x * blockDim.x;
+  for (int j0 = blockIdx.x * blockDim.x; j0 < cnt; j0 += span) {
+    const int j = j0 + threadIdx.x;
+    bool take = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < cnt) {
+      p = blk[1 + j];
+      const int fx = bk_fine(p.x, h.mn[0], h.inv_f, h.nf[0]);
+      take = fx >= lo && fx <= hi;
+    }
+    const int lane = threadIdx.x & 63;
+    const unsigned long long bal = __ballot(take);
+    int base = 0;
+    if (lane == 0 && bal) base = atomicAdd(imp_count, __popcll(bal));
+    base = __shfl(base, 0);
+    if (take) {
+      const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+      if (slot < imp_cap) { imp0[slot] = p; imp1[slot] = blk[(int64_t)cap + 1 + 1 + j]; }
+      else atomicAdd(&counters[5], 1);                                                                // import overflow
+    }
+  }
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -878,7 +962,7 @@ extern "C" int iso_bricks_build(const float* points, const float* normals, const
                                 const float* bbox, int64_t n_total, float radius, int knn_k,
                                 float cell_scale, void* workspace, int64_t workspace_bytes, void* stream) {
   ISO_REQUIRE(n_own >= 0 && import_max >= 0 && n_total >= 0, ISO_ERR_INVALID, "iso_bricks_build: bad sizes");
-  ISO_REQUIRE(bbox && workspace && (points || n_own == 0), ISO_ERR_INVALID, "iso_bricks_build: null pointer");
+  ISO_REQUIRE(workspace && (points || n_own == 0), ISO_ERR_INVALID, "iso_bricks_build: null pointer");
   ISO_REQUIRE(import_max == 0 || (import_rec0 && import_rec1 && import_count), ISO_ERR_INVALID,
               "iso_bricks_build: import buffers missing");
   ISO_REQUIRE(cell_scale > 0.f && (radius > 0.f || knn_k > 0), ISO_ERR_INVALID,
@@ -890,8 +974,9 @@ extern "C" int iso_bricks_build(const float* points, const float* normals, const
   ISO_REQUIRE(workspace_bytes >= w.bytes, ISO_ERR_WORKSPACE, "iso_bricks_build: workspace too small (%lld < %lld)",
               (long long)workspace_bytes, (long long)w.bytes);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, s, bbox, n_total, n_own, id_base, radius, knn_k,
-                     cell_scale, w.nb_cap, w.hdr, w.counters);
+  if (bbox)        // NULL: the header was written by iso_bricks_params (N ranks: between it and here the halo exchange)
+    hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, s, bbox, n_total, n_own, id_base, radius, knn_k,
+                       cell_scale, w.nb_cap, w.hdr, w.counters);
   hipLaunchKernelGGL(k_bricks_zero, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, s, w.hdr, w.cnt);
   if (n_own > 0)
     hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, n_own, w.hdr, w.cnt,
@@ -910,6 +995,50 @@ extern "C" int iso_bricks_build(const float* points, const float* normals, const
                        (const float4*)import_rec0, (const float4*)import_rec1, w.hdr, w.off, w.slot, w.rec0, w.rec1);
   hipLaunchKernelGGL(k_brick_list, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, s, w.hdr, w.off, w.list, w.counters);
   ISO_CHECK_LAUNCH("iso_bricks_build");
+  return ISO_OK;
+}
+
+extern "C" int iso_bricks_params(const float* bbox, int64_t n_total, int64_t n_own, int64_t id_base, float radius,
+                                 int knn_k, float cell_scale, void* workspace, int64_t n_max, void* stream) {
+  ISO_REQUIRE(bbox && workspace && n_max >= n_own && n_own >= 0 && n_total >= 0, ISO_ERR_INVALID, "iso_bricks_params: bad arguments");
+  ISO_REQUIRE(cell_scale > 0.f && (radius > 0.f || knn_k > 0), ISO_ERR_INVALID,
+              "iso_bricks_params: cell_scale and radius / knn_k must be positive");
+  const BrickWs w = bricks_carve(workspace, n_max);
+  hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, (hipStream_t)stream, bbox, n_total, n_own, id_base, radius,
+                     knn_k, cell_scale, w.nb_cap, w.hdr, w.counters);
+  ISO_CHECK_LAUNCH("iso_bricks_params");
+  return ISO_OK;
+}
+
+extern "C" int iso_halo_export(void* workspace, const float* points, const float* normals, const int32_t* payload,
+                               int64_t n_own, const float* rank_boxes, int world, int rank, float* export_buf,
+                               int64_t capacity, void* stream) {
+  ISO_REQUIRE(workspace && rank_boxes && export_buf && world >= 1 && rank >= 0 && rank < world && capacity >= 0 &&
+                  capacity < (1ll << 30) && (points || n_own == 0),
+              ISO_ERR_INVALID, "iso_halo_export: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(export_buf, 0, 16, s);
+  if (n_own > 0)
+    hipLaunchKernelGGL(k_halo_export, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, normals, payload, n_own,
+                       (const BrickHdr*)workspace, rank_boxes, world, rank, (float4*)export_buf, (int)capacity);
+  ISO_CHECK_LAUNCH("iso_halo_export");
+  return ISO_OK;
+}
+
+extern "C" int iso_halo_import(void* workspace, int64_t n_max, const float* gathered, const float* rank_boxes, int world,
+                               int rank, int64_t capacity, float* import_rec0, float* import_rec1,
+                               int32_t* import_count, int64_t import_capacity, void* stream) {
+  ISO_REQUIRE(workspace && gathered && rank_boxes && import_rec0 && import_rec1 && import_count && world >= 1 &&
+                  rank >= 0 && rank < world && capacity >= 0 && import_capacity >= 0,
+              ISO_ERR_INVALID, "iso_halo_import: bad arguments");
+  const BrickWs w = bricks_carve(workspace, n_max);
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(import_count, 0, 4, s);
+  if (capacity > 0 && world > 1)
+    hipLaunchKernelGGL(k_halo_import, dim3(iso_stream_grid(capacity, 256) > 64 ? 64 : iso_stream_grid(capacity, 256), world),
+                       dim3(256), 0, s, (const float4*)gathered, world, rank, (int)capacity, w.hdr, rank_boxes,
+                       (float4*)import_rec0, (float4*)import_rec1, import_count, (int)import_capacity, w.counters);
+  ISO_CHECK_LAUNCH("iso_halo_import");
   return ISO_OK;
 }
 

@@ -111,6 +111,69 @@ struct SetupOut {
   float* scaler;   // (P)
 };
 
+// One point in one view (rasterizer.py:344-563; the arithmetic both set-up kernels share).
+struct SetupRes { float ndc[3], el[3], rad[2], scaler; };
+
+__device__ __forceinline__ SetupRes splat_setup_point(float x, float y, float z, float nx, float ny, float nz,
+                                                      float hk, const float* __restrict__ V,
+                                                      const float* __restrict__ M, int S, float sigma,
+                                                      float cutoffC) {
+  // [p,1] @ M columns 0,1,3 and view depth
+  const float xv = ((x * M[0] + y * M[4]) + z * M[8]) + M[12];
+  const float yv = ((x * M[1] + y * M[5]) + z * M[9]) + M[13];
+  const float t = ((x * M[3] + y * M[7]) + z * M[11]) + M[15];
+  const float zv = ((x * V[2] + y * V[6]) + z * V[10]) + V[14];
+  const float t2 = iso_eps_denom(t * t, 1e-17f);
+  const float td = iso_eps_denom(t, 1e-17f);
+  const float j00 = 1.0f / td;
+  const float j30 = -1.0f / t2 * xv, j31 = -1.0f / t2 * yv;
+  // WJk = M[:3,:] @ Jk  (3x2)
+  float w0[3], w1[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    w0[r] = M[r * 4 + 0] * j00 + M[r * 4 + 3] * j30;
+    w1[r] = M[r * 4 + 1] * j00 + M[r * 4 + 3] * j31;
+  }
+  // tangent frame: u0 = normalize(n x (n + e)), u1 = normalize(n x u0), e = axis least
+  // aligned with n (a deterministic instance of rasterizer.py:395-397)
+  float ex = 0.f, ey = 0.f, ez = 0.f;
+  const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+  if (ax <= ay && ax <= az) ex = 1.f; else if (ay <= az) ey = 1.f; else ez = 1.f;
+  const float mx = nx + ex, my = ny + ey, mz = nz + ez;
+  float ux = ny * mz - nz * my, uy = nz * mx - nx * mz, uz = nx * my - ny * mx;
+  float un = sqrtf((ux * ux + uy * uy) + uz * uz);
+  un = un > 1e-12f ? un : 1e-12f;
+  ux /= un; uy /= un; uz /= un;
+  float vx = ny * uz - nz * uy, vy = nz * ux - nx * uz, vz = nx * uy - ny * ux;
+  float vn = sqrtf((vx * vx + vy * vy) + vz * vz);
+  vn = vn > 1e-12f ? vn : 1e-12f;
+  vx /= vn; vy /= vn; vz /= vn;
+  // Mk = Sk @ WJk (2x2);  Vk = h * Mk^T Mk
+  const float m00 = (ux * w0[0] + uy * w0[1]) + uz * w0[2];
+  const float m01 = (ux * w1[0] + uy * w1[1]) + uz * w1[2];
+  const float m10 = (vx * w0[0] + vy * w0[1]) + vz * w0[2];
+  const float m11 = (vx * w1[0] + vy * w1[1]) + vz * w1[2];
+  const float ps = 2.0f / (float)S;
+  const float lp = sigma * (ps * ps);
+  const float g00 = hk * (m00 * m00 + m10 * m10) + lp;
+  const float g01 = hk * (m00 * m01 + m10 * m11);
+  const float g11 = hk * (m01 * m01 + m11 * m11) + lp;
+  const float detM = m00 * m11 - m01 * m10;
+  // det(h M^T M + lp I) = h^2 det(M)^2 + lp h |M|_F^2 + lp^2: all terms positive, so no
+  // cancellation (the textbook g00*g11 - g01^2 loses ~cond(G) digits on grazing splats)
+  const float fro = (m00 * m00 + m10 * m10) + (m01 * m01 + m11 * m11);
+  const float detG = (hk * hk) * (detM * detM) + (lp * hk * fro + lp * lp);
+  const float a = g11 / detG, c = g00 / detG, b = (-g01 / detG) + (-g01 / detG);
+  const float den = iso_eps_denom(4.0f * a * c - b * b, 1e-17f);
+  SetupRes o;
+  o.rad[1] = sqrtf(esqrt_arg(4.0f * a * cutoffC / den));
+  o.rad[0] = sqrtf(esqrt_arg(4.0f * c * cutoffC / den));
+  o.scaler = fabsf(detM) / iso_eps_denom(sqrtf(esqrt_arg(detG * 4.0f * 3.14159265358979323846f * 3.14159265358979323846f)), 1e-17f);
+  o.ndc[0] = xv / t; o.ndc[1] = yv / t; o.ndc[2] = zv;
+  o.el[0] = a; o.el[1] = b; o.el[2] = c;
+  return o;
+}
+
 __global__ void k_splat_setup(const float* __restrict__ pts, const float* __restrict__ nrm,
                               const float* __restrict__ h, const int64_t* __restrict__ first,
                               const int64_t* __restrict__ num, const float* __restrict__ views,
@@ -123,64 +186,158 @@ __global__ void k_splat_setup(const float* __restrict__ pts, const float* __rest
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = base + i;
-    const float x = pts[p * 3], y = pts[p * 3 + 1], z = pts[p * 3 + 2];
-    // [p,1] @ M columns 0,1,3 and view depth
-    const float xv = ((x * M[0] + y * M[4]) + z * M[8]) + M[12];
-    const float yv = ((x * M[1] + y * M[5]) + z * M[9]) + M[13];
-    const float t = ((x * M[3] + y * M[7]) + z * M[11]) + M[15];
-    const float zv = ((x * V[2] + y * V[6]) + z * V[10]) + V[14];
-    const float t2 = iso_eps_denom(t * t, 1e-17f);
-    const float td = iso_eps_denom(t, 1e-17f);
-    const float j00 = 1.0f / td;
-    const float j30 = -1.0f / t2 * xv, j31 = -1.0f / t2 * yv;
-    // WJk = M[:3,:] @ Jk  (3x2)
-    float w0[3], w1[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      w0[r] = M[r * 4 + 0] * j00 + M[r * 4 + 3] * j30;
-      w1[r] = M[r * 4 + 1] * j00 + M[r * 4 + 3] * j31;
-    }
-    // tangent frame: u0 = normalize(n x (n + e)), u1 = normalize(n x u0), e = axis least
-    // aligned with n (a deterministic instance of rasterizer.py:395-397)
-    const float nx = nrm[p * 3], ny = nrm[p * 3 + 1], nz = nrm[p * 3 + 2];
-    float ex = 0.f, ey = 0.f, ez = 0.f;
-    const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
-    if (ax <= ay && ax <= az) ex = 1.f; else if (ay <= az) ey = 1.f; else ez = 1.f;
-    const float mx = nx + ex, my = ny + ey, mz = nz + ez;
-    float ux = ny * mz - nz * my, uy = nz * mx - nx * mz, uz = nx * my - ny * mx;
-    float un = sqrtf((ux * ux + uy * uy) + uz * uz);
-    un = un > 1e-12f ? un : 1e-12f;
-    ux /= un; uy /= un; uz /= un;
-    float vx = ny * uz - nz * uy, vy = nz * ux - nx * uz, vz = nx * uy - ny * ux;
-    float vn = sqrtf((vx * vx + vy * vy) + vz * vz);
-    vn = vn > 1e-12f ? vn : 1e-12f;
-    vx /= vn; vy /= vn; vz /= vn;
-    // Mk = Sk @ WJk (2x2);  Vk = h * Mk^T Mk
-    const float m00 = (ux * w0[0] + uy * w0[1]) + uz * w0[2];
-    const float m01 = (ux * w1[0] + uy * w1[1]) + uz * w1[2];
-    const float m10 = (vx * w0[0] + vy * w0[1]) + vz * w0[2];
-    const float m11 = (vx * w1[0] + vy * w1[1]) + vz * w1[2];
-    const float hk = h[p];
-    const float ps = 2.0f / (float)S;
-    const float lp = sigma * (ps * ps);
-    const float g00 = hk * (m00 * m00 + m10 * m10) + lp;
-    const float g01 = hk * (m00 * m01 + m10 * m11);
-    const float g11 = hk * (m01 * m01 + m11 * m11) + lp;
-    const float detM = m00 * m11 - m01 * m10;
-    // det(h M^T M + lp I) = h^2 det(M)^2 + lp h |M|_F^2 + lp^2: all terms positive, so no
-    // cancellation (the textbook g00*g11 - g01^2 loses ~cond(G) digits on grazing splats)
-    const float fro = (m00 * m00 + m10 * m10) + (m01 * m01 + m11 * m11);
-    const float detG = (hk * hk) * (detM * detM) + (lp * hk * fro + lp * lp);
-    const float a = g11 / detG, c = g00 / detG, b = (-g01 / detG) + (-g01 / detG);
-    const float den = iso_eps_denom(4.0f * a * c - b * b, 1e-17f);
-    const float ry = sqrtf(esqrt_arg(4.0f * a * cutoffC / den));
-    const float rx = sqrtf(esqrt_arg(4.0f * c * cutoffC / den));
-    const float sc = fabsf(detM) / iso_eps_denom(sqrtf(esqrt_arg(detG * 4.0f * 3.14159265358979323846f * 3.14159265358979323846f)), 1e-17f);
-    o.ndc[p * 3] = xv / t; o.ndc[p * 3 + 1] = yv / t; o.ndc[p * 3 + 2] = zv;
-    o.ellipse[p * 3] = a; o.ellipse[p * 3 + 1] = b; o.ellipse[p * 3 + 2] = c;
+    const SetupRes r = splat_setup_point(pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2], nrm[p * 3], nrm[p * 3 + 1],
+                                         nrm[p * 3 + 2], h[p], V, M, S, sigma, cutoffC);
+    o.ndc[p * 3] = r.ndc[0]; o.ndc[p * 3 + 1] = r.ndc[1]; o.ndc[p * 3 + 2] = r.ndc[2];
+    o.ellipse[p * 3] = r.el[0]; o.ellipse[p * 3 + 1] = r.el[1]; o.ellipse[p * 3 + 2] = r.el[2];
     o.cutoff[p] = cutoffC;
-    o.radii[p * 2] = rx; o.radii[p * 2 + 1] = ry;
-    o.scaler[p] = sc;
+    o.radii[p * 2] = r.rad[0]; o.radii[p * 2 + 1] = r.rad[1];
+    o.scaler[p] = r.scaler;
+  }
+}
+
+// ---------------------------------------------------------------- fused filter + compaction + set-up
+// The cycle's front end works on the UNFILTERED cloud: a point's renderable views are bits of
+// mask[i] (iso_splat_view_mask), its bandwidths h[v*P+i] (iso_splat_h_fused).  The packed order of
+// the reference (view-major, points ascending: rasterizer.py:597-618) needs, for point i in view v,
+// the number of renderable points before it: chunk counts (k_mask_chunk_count) -> one scan
+// (k_mask_chunk_scan, also first_idx / num_points on the device: no host read anywhere) -> ranks
+// inside the chunk from wave ballots here.
+constexpr int kChunk = 1024;   // points per workgroup: 256 lanes x 4 consecutive points
+
+__global__ __launch_bounds__(256) void k_mask_chunk_count(const int32_t* __restrict__ mask, int64_t P, int n_views,
+                                                          int n_chunks, int32_t* __restrict__ chunk_cnt /*(8, n_chunks)*/) {
+  __shared__ int s_cnt[8];
+  if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * kChunk + threadIdx.x * 4;
+  int m[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m[k] = i0 + k < P ? mask[i0 + k] : 0;
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    if (v < n_views) {
+      int c = ((m[0] >> v) & 1) + ((m[1] >> v) & 1) + ((m[2] >> v) & 1) + ((m[3] >> v) & 1);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+      if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[v], c);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < n_views) chunk_cnt[threadIdx.x * n_chunks + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
+// one workgroup: exclusive scan of every view's chunk counts in place; first_idx / num_points (i64,
+// the layout _C.splat_points takes) and the int32 view totals
+__global__ __launch_bounds__(1024) void k_mask_chunk_scan(int32_t* __restrict__ chunk_cnt, int n_chunks, int n_views,
+                                                         int64_t* __restrict__ first, int64_t* __restrict__ num,
+                                                         int32_t* __restrict__ view_total) {
+  __shared__ int s_w[16];
+  __shared__ int s_tot[8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int v = 0; v < n_views; ++v) {
+    int carry = 0;
+    int32_t* row = chunk_cnt + (int64_t)v * n_chunks;
+    for (int c0 = 0; c0 < n_chunks; c0 += 1024) {
+      const int i = c0 + threadIdx.x;
+      const int val = i < n_chunks ? row[i] : 0;
+      int inc = val;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+      if (lane == 63) s_w[w] = inc;
+      __syncthreads();
+      int base = 0, tot = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const int sv = s_w[k]; if (k < w) base += sv; tot += sv; }
+      if (i < n_chunks) row[i] = carry + base + inc - val;
+      carry += tot;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) s_tot[v] = carry;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int v = 0; v < n_views; ++v) { first[v] = run; num[v] = s_tot[v]; view_total[v] = s_tot[v]; run += s_tot[v]; }
+    for (int v = n_views; v < 8; ++v) view_total[v] = 0;
+  }
+}
+
+struct FrontOut {
+  float* ndc; float* ellipse; float* cutoff; float* radii; float* scaler;
+  float* feat;      // (cap, C) packed features or null
+  int32_t* src;     // (cap) original point of a packed row, or null
+};
+
+__global__ __launch_bounds__(256) void k_splat_front(const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                     const float* __restrict__ feat_in, int C,
+                                                     const int32_t* __restrict__ mask, const float* __restrict__ h,
+                                                     int64_t P, const int32_t* __restrict__ chunk_off, int n_chunks,
+                                                     const int64_t* __restrict__ first, const float* __restrict__ views,
+                                                     const float* __restrict__ projs, int n_views, int S, float sigma,
+                                                     float cutoffC, int feat_from_normal, FrontOut o) {
+  __shared__ int s_w[8][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * kChunk + threadIdx.x * 4;
+  int m[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m[k] = i0 + k < P ? mask[i0 + k] : 0;
+  // rank of my first point among the chunk's renderable points, per view
+  int rank[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    rank[v] = 0;
+    if (v < n_views) {
+      const int c = ((m[0] >> v) & 1) + ((m[1] >> v) & 1) + ((m[2] >> v) & 1) + ((m[3] >> v) & 1);
+      int inc = c;
+#pragma unroll
+      for (int o2 = 1; o2 < 64; o2 <<= 1) { const int t = __shfl_up(inc, o2); if (lane >= o2) inc += t; }
+      if (lane == 63) s_w[v][w] = inc;
+      rank[v] = inc - c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < 8; ++v)
+    if (v < n_views)
+      for (int k = 0; k < w; ++k) rank[v] += s_w[v][k];
+  if ((m[0] | m[1] | m[2] | m[3]) == 0) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!m[k]) continue;
+    const int64_t i = i0 + k;
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    const float nx = nrm[i * 3], ny = nrm[i * 3 + 1], nz = nrm[i * 3 + 2];
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (o.feat) {
+      if (feat_from_normal) {                       // 0.5 (normalize(n) + 1): the cycle's shading-free features
+        float nn = sqrtf((nx * nx + ny * ny) + nz * nz);
+        nn = nn > 1e-12f ? nn : 1e-12f;
+        f[0] = 0.5f * (nx / nn + 1.0f); f[1] = 0.5f * (ny / nn + 1.0f); f[2] = 0.5f * (nz / nn + 1.0f);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < C) f[c] = feat_in[i * C + c];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      if (v < n_views && ((m[k] >> v) & 1)) {
+        const int64_t p = first[v] + chunk_off[(int64_t)v * n_chunks + blockIdx.x] + rank[v];
+        ++rank[v];
+        const SetupRes r = splat_setup_point(x, y, z, nx, ny, nz, h[(int64_t)v * P + i], views + v * 16, projs + v * 16,
+                                             S, sigma, cutoffC);
+        o.ndc[p * 3] = r.ndc[0]; o.ndc[p * 3 + 1] = r.ndc[1]; o.ndc[p * 3 + 2] = r.ndc[2];
+        o.ellipse[p * 3] = r.el[0]; o.ellipse[p * 3 + 1] = r.el[1]; o.ellipse[p * 3 + 2] = r.el[2];
+        o.cutoff[p] = cutoffC;
+        o.radii[p * 2] = r.rad[0]; o.radii[p * 2 + 1] = r.rad[1];
+        o.scaler[p] = r.scaler;
+        if (o.src) o.src[p] = (int32_t)i;
+        if (o.feat) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) if (c < C) o.feat[p * C + c] = f[c];
+        }
+      }
+    }
   }
 }
 
@@ -828,6 +985,46 @@ extern "C" int iso_splat_setup(const float* points, const float* normals, const 
   return ISO_OK;
 }
 
+extern "C" int64_t iso_splat_front_workspace_bytes(int64_t n_points) {
+  if (n_points < 0) n_points = 0;
+  return 8 * 4 * ((n_points + kChunk - 1) / kChunk + 1);
+}
+
+extern "C" int iso_splat_front(const float* points, const float* normals, const float* features, int channels,
+                               int features_from_normals, const int32_t* mask, const float* h, int64_t n_points,
+                               const float* views, const float* projs, int n_views, int image_size, float sigma,
+                               float cutoff, void* workspace, int64_t workspace_bytes, int64_t* first_idx_out,
+                               int64_t* num_pts_out, int32_t* view_total_out, float* ndc_out, float* ellipse_out,
+                               float* cutoff_out, float* radii_out, float* scaler_out, float* features_out,
+                               int32_t* src_out, void* stream) {
+  ISO_REQUIRE(n_points >= 0 && n_views >= 1 && n_views <= 8 && image_size > 0, ISO_ERR_INVALID,
+              "iso_splat_front: bad sizes (1..8 views per call)");
+  ISO_REQUIRE(channels >= 0 && channels <= 8, ISO_ERR_UNSUPPORTED, "iso_splat_front: channels must be <= 8");
+  ISO_REQUIRE(!features_from_normals || channels == 3, ISO_ERR_INVALID, "iso_splat_front: features_from_normals needs 3 channels");
+  ISO_REQUIRE(first_idx_out && num_pts_out && view_total_out && workspace, ISO_ERR_INVALID, "iso_splat_front: null pointer");
+  ISO_REQUIRE(workspace_bytes >= iso_splat_front_workspace_bytes(n_points), ISO_ERR_WORKSPACE,
+              "iso_splat_front: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_chunks = (int)((n_points + kChunk - 1) / kChunk);
+  int32_t* chunk = (int32_t*)workspace;
+  if (n_points > 0) {
+    ISO_REQUIRE(points && normals && mask && h && views && projs && ndc_out && ellipse_out && cutoff_out && radii_out &&
+                    scaler_out && (!features_out || features || features_from_normals),
+                ISO_ERR_INVALID, "iso_splat_front: null pointer");
+    hipLaunchKernelGGL(k_mask_chunk_count, dim3(n_chunks), dim3(256), 0, s, mask, n_points, n_views, n_chunks, chunk);
+  }
+  hipLaunchKernelGGL(k_mask_chunk_scan, dim3(1), dim3(1024), 0, s, chunk, n_chunks, n_views, first_idx_out, num_pts_out,
+                     view_total_out);
+  if (n_points > 0) {
+    FrontOut o{ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out, features_out, src_out};
+    hipLaunchKernelGGL(k_splat_front, dim3(n_chunks), dim3(256), 0, s, points, normals, features, channels, mask, h,
+                       n_points, chunk, n_chunks, first_idx_out, views, projs, n_views, image_size, sigma, cutoff,
+                       features_from_normals, o);
+  }
+  ISO_CHECK_LAUNCH("iso_splat_front");
+  return ISO_OK;
+}
+
 extern "C" int iso_splat_tiles_per_side(int image_size) { return (image_size + TILE - 1) / TILE; }
 
 extern "C" int iso_splat_bin_count(const float* points, const float* radii,
@@ -994,13 +1191,16 @@ __global__ __launch_bounds__(256) void k_z_absmax(const float* __restrict__ gz, 
   }
 }
 
-__global__ void k_z_scale(ZScale* zs) {
+// terms_log2 = ceil(log2(max number of slots that can list one point)) = ceil(log2(S*S)): every term is
+// < 2^(61 - terms_log2) in magnitude after scaling, so no sum of them reaches 2^61 -- the range kept for
+// the NaN / Inf poison (a point that received one stays at >= 2^61 whatever else is added).
+__global__ void k_z_scale(ZScale* zs, int terms_log2) {
   const unsigned b = zs->max_bits;
   int e = 0;
   if (b != 0u && b < 0x7f800000u) {
     int ex;
     (void)frexpf(__uint_as_float(b), &ex);      // max = f * 2^ex, f in [0.5,1)
-    e = 44 - ex;
+    e = 61 - terms_log2 - ex;
   }
   zs->exp2 = e;
 }
@@ -1014,9 +1214,11 @@ __global__ void k_z_scatter(const int32_t* __restrict__ idx, const float* __rest
       if (p < 0) break;
       const float g = gz[i * K + k];
       if (g == 0.0f) continue;
-      long long q;
-      if (g != g || fabsf(g) > 3.0e38f) q = 1ll << 61;               // poison: the point ends up NaN
-      else q = __double2ll_rn(ldexp((double)g, e));
+      if (g != g || fabsf(g) > 3.0e38f) {                            // poison: the point ends up NaN
+        atomicMax(&acc[p], 1ll << 62);
+        continue;
+      }
+      const long long q = __double2ll_rn(ldexp((double)g, e));
       atomicAdd(reinterpret_cast<unsigned long long*>(&acc[p]), (unsigned long long)q);
     }
   }
@@ -1028,7 +1230,7 @@ __global__ void k_z_finish(const long long* __restrict__ acc, const ZScale* __re
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
     const long long a = acc[p];
     float z = (float)ldexp((double)a, -e);
-    if (a >= (1ll << 60) || a <= -(1ll << 60)) z = __builtin_nanf("");
+    if (a >= (1ll << 61) || a <= -(1ll << 61)) z = __builtin_nanf("");
     grad[p * 3 + 2] = z;
   }
 }
@@ -1086,7 +1288,9 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
     (void)hipMemsetAsync(zs, 0, 16 + 8 * (size_t)total_points, s);
     int gm = iso_div_up(npix * points_per_pixel, 256 * 16); if (gm > 1024) gm = 1024; if (gm < 1) gm = 1;
     hipLaunchKernelGGL(k_z_absmax, dim3(gm), dim3(256), 0, s, grad_zbuf, npix * points_per_pixel, zs);
-    hipLaunchKernelGGL(k_z_scale, dim3(1), dim3(1), 0, s, zs);
+    int terms_log2 = 0;
+    while ((1ll << terms_log2) < (int64_t)image_size * image_size) ++terms_log2;
+    hipLaunchKernelGGL(k_z_scale, dim3(1), dim3(1), 0, s, zs, terms_log2);
     hipLaunchKernelGGL(k_z_scatter, dim3(iso_stream_grid(npix, 256)), dim3(256), 0, s, idx, grad_zbuf,
                        points_per_pixel, npix, zs, zacc);
     hipLaunchKernelGGL(k_z_finish, dim3(iso_stream_grid(total_points, 256)), dim3(256), 0, s, zacc, zs,
@@ -1096,5 +1300,127 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
                      first_idx, num_pts, n_clouds, grad_occ, blk, NB, blk2, NB2, image_size, rect_mode, radii_s,
                      heavy, heavy_count, grad_points);
   ISO_CHECK_LAUNCH("iso_splat_backward");
+  return ISO_OK;
+}
+
+// ---- the z gradient in pieces (N ranks: every rank scatters the pixels of its own tile rows; the
+// 64-bit accumulators are summed over the ranks before the finish; the scale comes from the global
+// max |grad|).  zscale: 2 ints [max |grad| bits, exponent].
+extern "C" int iso_splat_z_absmax(const float* grad_zbuf, int64_t n, int32_t* zscale, void* stream) {
+  ISO_REQUIRE(zscale && n >= 0 && (grad_zbuf || n == 0), ISO_ERR_INVALID, "iso_splat_z_absmax: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(zscale, 0, 8, s);
+  if (n > 0) {
+    int gm = iso_div_up(n, 256 * 16); if (gm > 1024) gm = 1024; if (gm < 1) gm = 1;
+    hipLaunchKernelGGL(k_z_absmax, dim3(gm), dim3(256), 0, s, grad_zbuf, n, reinterpret_cast<ZScale*>(zscale));
+  }
+  ISO_CHECK_LAUNCH("iso_splat_z_absmax");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_z_scatter(const int32_t* idx, const float* grad_zbuf, int64_t n_pixels, int points_per_pixel,
+                                   int image_size, int32_t* zscale, int64_t* acc, void* stream) {
+  ISO_REQUIRE(zscale && acc && n_pixels >= 0 && points_per_pixel >= 1 && image_size > 0 && ((idx && grad_zbuf) || n_pixels == 0),
+              ISO_ERR_INVALID, "iso_splat_z_scatter: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int terms_log2 = 0;
+  while ((1ll << terms_log2) < (int64_t)image_size * image_size) ++terms_log2;
+  hipLaunchKernelGGL(k_z_scale, dim3(1), dim3(1), 0, s, reinterpret_cast<ZScale*>(zscale), terms_log2);
+  if (n_pixels > 0)
+    hipLaunchKernelGGL(k_z_scatter, dim3(iso_stream_grid(n_pixels, 256)), dim3(256), 0, s, idx, grad_zbuf, points_per_pixel,
+                       n_pixels, reinterpret_cast<const ZScale*>(zscale), reinterpret_cast<long long*>(acc));
+  ISO_CHECK_LAUNCH("iso_splat_z_scatter");
+  return ISO_OK;
+}
+
+namespace {
+__global__ void k_z_finish_rows(const long long* __restrict__ acc, const ZScale* __restrict__ zs, int64_t row0, int64_t n,
+                                float* __restrict__ grad) {
+  const int e = zs->exp2;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+    const long long a = acc[row0 + j];
+    float z = (float)ldexp((double)a, -e);
+    if (a >= (1ll << 61) || a <= -(1ll << 61)) z = __builtin_nanf("");
+    grad[(row0 + j) * 3 + 2] = z;
+  }
+}
+
+// packed global rows (view-major, then rank, then the rank's own order) from the all-gathered per-rank
+// blocks: block s = 12 arrays of `cap` rows (ndc 3, ellipse 3, radii 2, scaler 1, features 3) as written
+// by iso_splat_front into one buffer; counts (world, 8) = the ranks' num_points per view.
+__global__ __launch_bounds__(256) void k_repack_records(const float* __restrict__ gathered, int64_t cap, int world,
+                                                        int n_views, const int32_t* __restrict__ counts, float cutoffC,
+                                                        float* __restrict__ ndc, float* __restrict__ ellipse,
+                                                        float* __restrict__ cutoff, float* __restrict__ radii,
+                                                        float* __restrict__ scaler, float* __restrict__ feat) {
+  const int s = blockIdx.y, v = blockIdx.z;
+  int64_t g0 = 0, l0 = 0;                       // first global row of (v, s); first local row of view v in block s
+  for (int vv = 0; vv < n_views; ++vv)
+    for (int ss = 0; ss < world; ++ss) {
+      const int c = counts[ss * 8 + vv];
+      if (vv < v || (vv == v && ss < s)) g0 += c;
+      if (ss == s && vv < v) l0 += c;
+    }
+  const int n = counts[s * 8 + v];
+  const float* blk = gathered + (int64_t)s * 12 * cap;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t l = l0 + j, g = g0 + j;
+    if (l >= cap) break;                         // the sender's buffer overflowed (flagged by the host side)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ndc[g * 3 + c] = blk[l * 3 + c];
+      ellipse[g * 3 + c] = blk[3 * cap + l * 3 + c];
+      feat[g * 3 + c] = blk[9 * cap + l * 3 + c];
+    }
+    radii[g * 2] = blk[6 * cap + l * 2]; radii[g * 2 + 1] = blk[6 * cap + l * 2 + 1];
+    scaler[g] = blk[8 * cap + l];
+    cutoff[g] = cutoffC;
+  }
+}
+
+// first_idx / num_points of the global packed layout and of this rank's own rows in it
+__global__ void k_repack_offsets(const int32_t* __restrict__ counts, int world, int n_views, int rank,
+                                 int64_t* __restrict__ first_g, int64_t* __restrict__ num_g,
+                                 int64_t* __restrict__ first_own, int64_t* __restrict__ num_own) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int64_t run = 0;
+  for (int v = 0; v < n_views; ++v) {
+    first_g[v] = run;
+    for (int s = 0; s < world; ++s) {
+      if (s == rank) { first_own[v] = run; num_own[v] = counts[s * 8 + v]; }
+      run += counts[s * 8 + v];
+    }
+    num_g[v] = run - first_g[v];
+  }
+}
+}  // namespace
+
+extern "C" int iso_splat_z_finish(const int64_t* acc, const int32_t* zscale, int64_t row0, int64_t n_rows,
+                                  float* grad_points, void* stream) {
+  ISO_REQUIRE(acc && zscale && grad_points && row0 >= 0 && n_rows >= 0, ISO_ERR_INVALID, "iso_splat_z_finish: bad arguments");
+  if (n_rows > 0)
+    hipLaunchKernelGGL(k_z_finish_rows, dim3(iso_stream_grid(n_rows, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(acc), reinterpret_cast<const ZScale*>(zscale), row0, n_rows,
+                       grad_points);
+  ISO_CHECK_LAUNCH("iso_splat_z_finish");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_repack(const float* gathered, int64_t capacity, int world, int rank, int n_views,
+                                const int32_t* counts, float cutoff, int64_t max_rows, float* ndc_out,
+                                float* ellipse_out, float* cutoff_out, float* radii_out, float* scaler_out,
+                                float* features_out, int64_t* first_idx_out, int64_t* num_pts_out,
+                                int64_t* own_first_out, int64_t* own_num_out, void* stream) {
+  ISO_REQUIRE(gathered && counts && world >= 1 && rank >= 0 && rank < world && n_views >= 1 && n_views <= 8 &&
+                  capacity >= 0 && ndc_out && ellipse_out && cutoff_out && radii_out && scaler_out && features_out &&
+                  first_idx_out && num_pts_out && own_first_out && own_num_out,
+              ISO_ERR_INVALID, "iso_splat_repack: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_repack_offsets, dim3(1), dim3(64), 0, s, counts, world, n_views, rank, first_idx_out, num_pts_out,
+                     own_first_out, own_num_out);
+  int gx = iso_div_up(max_rows > 0 ? max_rows : 1, 256); if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(k_repack_records, dim3(gx, world, n_views), dim3(256), 0, s, gathered, capacity, world, n_views, counts,
+                     cutoff, ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out, features_out);
+  ISO_CHECK_LAUNCH("iso_splat_repack");
   return ISO_OK;
 }

@@ -1,36 +1,46 @@
 """The iso-point cycle on one or several MI355X (one process per GPU, torch.distributed:
-backend "nccl" = RCCL over xGMI; "gloo" works too and is what the CPU/1-GPU tests use).
+backend "nccl" = RCCL over xGMI; "gloo" works too and is what the CPU / one-GPU tests use).
 
-The reference has no distributed layer; this is new design:
+The reference has no distributed layer; this is the design SURVEY 8(e) / the north star
+ask for.  The cloud is sharded by SPACE: the ranks hold consecutive x-slabs (balanced by point count;
+`slab_order`), i.e. contiguous ranges of the brick-sorted order of csrc/bricks.hip, and the global
+point order is rank-major, so every index the single-GPU cycle produces keeps its meaning.
 
-  stage                         partition                         exchange
-  ----------------------------  --------------------------------  ---------------------------------
-  Newton projection (T=10, 3)   points: contiguous slice / rank   none
-  FRNN tree + repulsion         queries / moves: own slice;       all-gather of positions + normals
-                                grid built over the whole cloud   (24 B/pt) -> neighbour indices are
-                                                                  GLOBAL and bit-identical to 1 GPU
-  splat filter / compaction     replicated (0.3 ms)               (uses the gathered cloud)
-  K=7 FRNN for h                queries: slice of every view      all-reduce(sum) of h (4 B/pt-view)
-  per-point EWA set-up          replicated (bit-identical)        none
-  tile binning + raster         pixels: band of 16-px tile rows   none (all splats are local)
-  compositing, loss gradient    own band                          all-reduce(sum) of occ_grad bands
-  visible set                   own band                          all-reduce(max) of the flags
-  backward xy (point-major)     points: slice of every view       none
-  backward z (pixel-major)      own band                          all-reduce(sum) of z-gradients
+  stage                          partition                        exchange (per cycle)
+  -----------------------------  -------------------------------  -------------------------------------------
+  Newton projection (T=10, T=3)  own points                       none
+  FRNN tree + repulsion          own points; neighbours = own     all-gather of 8-float bounding boxes, then ONE
+   (fused, csrc/bricks.hip)      bricks + imported halo cells     all-gather of the halo cells (points + normals +
+                                                                  ids of the points within one fine cell of
+                                                                  another slab: 32 B each)
+  renderable mask, K=7           own points; halo as above        boxes + per-view counts (64 B), halo cells
+   bandwidth h (fused)                                            (points + view masks)
+  filter / compaction / EWA      own points -> own packed rows    none
+   set-up (fused front end)
+  tile binning, raster,          tiles: a band of 16-px tile      all-gather of the ranks' packed rows (48 B per
+   compositing, loss             rows per rank                    visible point-view: the inputs of every tile)
+  backward xy (point-major)      own rows                         all-reduce(sum) of the occ_grad bands (4 B/pixel),
+                                                                  all-reduce(max) of the visible flags (1 B/row)
+  backward z (pixel-major,       own band -> own rows             all-reduce(max) of the scale (8 B), all-reduce(sum)
+   fixed point)                                                   of the 64-bit accumulators
 
-Every collective moves O(points) or O(pixels) bytes once per cycle (about 70 MB at 1M points /
-512^2 x 4 views); nothing is exchanged inside a kernel.  With world == 1 every exchange is a no-op
-and the class is exactly the single-GPU cycle bench.py times.
+Nothing is replicated except the tile binning's pass over the gathered rows (each rank keeps the rows
+that reach its band) and the median radius of the backward.  No collective sits inside a kernel, none
+needs a size from the host: buffers have calibrated capacities and device-side counts (`calibrate`,
+`check`).  With world == 1 every exchange disappears and the class is the single-GPU cycle bench.py
+times.  The cycle is written as a generator that yields its exchanges, so the same code runs under a
+process group (`step`) and in lock-step inside one process (`run_lockstep`: tests, and the per-rank
+compute share of tools/rank_share_bench.py).
 """
 import math
 
 import torch
 
 from . import _lib
-from . import frnn
-from .levelset_sampling import UniformProjection, cloud_diag, full_lengths, with_host_lengths
+from . import bricks
+from .levelset_sampling import UniformProjection, full_lengths
 from .rasterizer import (PointFragments, PointsRasterizationSettings, SurfaceSplatting, _C, _f32c,
-                         _visible_and_radius, gather_with_neg_idx, median_radius)
+                         _visible_and_radius, median_radius)
 
 
 # ----------------------------------------------------------------------------- pure helpers
@@ -45,6 +55,15 @@ def all_shard_bounds(n, world):
     return [shard_bounds(n, world, r) for r in range(world)]
 
 
+def slab_order(points, world):
+    """Permutation that puts a (P,3) cloud into x-slab order (stable sort by x): rank r of `world`
+    then holds rows shard_bounds(P, world, r) of the permuted cloud.  Identity for world == 1."""
+    P = points.shape[0]
+    if world == 1:
+        return torch.arange(P, device=points.device)
+    return torch.sort(points[:, 0], stable=True).indices
+
+
 class Comm(object):
     """Thin wrapper over a torch.distributed process group (None = single process)."""
 
@@ -55,262 +74,352 @@ class Comm(object):
         self.group = group
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
+        self.bytes_log = []          # (kind, bytes contributed by this rank) of the last cycle
 
-    def all_gather_rows(self, x_local, n_total):
-        """Concatenate per-rank row blocks (shard_bounds order) into the full (n_total, ...) tensor."""
-        if self.world == 1:
-            return x_local
-        bounds = all_shard_bounds(n_total, self.world)
-        mx = max(hi - lo for lo, hi in bounds)
-        tail = tuple(x_local.shape[1:])
-        buf = x_local.new_zeros((mx,) + tail)
-        buf[: x_local.shape[0]] = x_local
-        out = x_local.new_empty((self.world * mx,) + tail)
-        self.dist.all_gather_into_tensor(out, buf.contiguous(), group=self.group)
-        if all(hi - lo == mx for lo, hi in bounds):
+    def execute(self, req):
+        kind, x = req[0], req[1]
+        self.bytes_log.append((kind, x.numel() * x.element_size()))
+        if kind == "all_gather":
+            out = x.new_empty((self.world,) + tuple(x.shape))
+            self.dist.all_gather_into_tensor(out.view(-1), x.contiguous().view(-1), group=self.group)
             return out
-        return torch.cat([out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(bounds)], dim=0)
-
-    def all_reduce_(self, x, op="sum"):
-        if self.world == 1:
-            return x
-        ops = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN}
-        self.dist.all_reduce(x, op=ops[op], group=self.group)
+        ops = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX}
+        self.dist.all_reduce(x, op=ops[req[2]], group=self.group)
         return x
+
+    # host-side agreement (set-up / calibration only)
+    def max_int(self, v, device):
+        if self.world == 1:
+            return int(v)
+        t = torch.tensor([int(v)], dtype=torch.int64, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+
+class _Single(object):
+    world, rank = 1, 0
+    bytes_log = []
+
+    def max_int(self, v, device):
+        return int(v)
 
 
 # ----------------------------------------------------------------------------- the cycle
 class IsoCycle(object):
     """project(T=10) -> resample(sample_iters=1) -> splat forward -> compositing -> backward
-    (SURVEY 8(d) 'cycle'), on `comm.world` GPUs.  `points0` is the WHOLE initial cloud (1,P,3) on
-    this rank's device (the same on every rank); each rank works on its slice."""
+    (SURVEY 8(d) 'cycle') on `world` GPUs.  `points0` (1,P,3) is the WHOLE initial cloud in the order
+    the job works in (for world > 1: x-slab order, see `slab_order`), identical on every rank; rank r
+    keeps rows shard_bounds(P, world, r)."""
 
-    def __init__(self, model, points0, views, projs, raster_settings=None, knn_k=8, comm=None,
-                 target=None):
-        self.comm = comm or Comm(enabled=False)
+    def __init__(self, model, points0, views, projs, raster_settings=None, knn_k=8, comm=None, target=None,
+                 world=None, rank=None):
+        self.comm = comm or _Single()
+        self.world = self.comm.world if world is None else int(world)
+        self.rank = self.comm.rank if rank is None else int(rank)
         self.model = model
+        self.dev = points0.device
         self.P = points0.shape[1]
-        self.lo, self.hi = shard_bounds(self.P, self.comm.world, self.comm.rank)
+        self.lo, self.hi = shard_bounds(self.P, self.world, self.rank)
+        self.n_own = self.hi - self.lo
         self.pts0_local = points0[:, self.lo:self.hi].contiguous()
         self.num_local = full_lengths(self.pts0_local)
+        self.knn_k = knn_k
         self.proj = UniformProjection(proj_max_iters=10, proj_tolerance=5e-5, knn_k=knn_k, sample_iters=1)
         self.rs = raster_settings or PointsRasterizationSettings(image_size=512, points_per_pixel=8)
         self.splat = SurfaceSplatting(raster_settings=self.rs)
         self.views, self.projs = _f32c(views), _f32c(projs)
+        self.N = self.views.shape[0]
         self.target = target
         self.project_hook = None      # bench.py installs timing events here
+        # capacities (rows / records); `calibrate` shrinks them to what the workload needs
+        w = self.world
+        self.halo_cap = 0 if w == 1 else max(4096, self.n_own)            # worst case: every own point is exported
+        self.import_cap = 0 if w == 1 else max(4096, 2 * self.n_own)
+        self.rec_cap = max(self.N * self.n_own, 1)
+        self.pair_cap = max(1 << 16, 6 * self.N * self.P // w)
+        self._alloc()
+        self._ovf = []
+
+    def _alloc(self):
+        dev, w = self.dev, self.world
+        self.grid = bricks.BrickGrid(self.n_own, dev, import_max=self.import_cap)
+        if w > 1:
+            self.exp_buf = torch.zeros((2 * (self.halo_cap + 1) * 4,), dtype=torch.float32, device=dev)
+            self.imp0 = torch.empty((self.import_cap, 4), dtype=torch.float32, device=dev)
+            self.imp1 = torch.empty((self.import_cap, 4), dtype=torch.float32, device=dev)
+            self.imp_count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.wire = torch.empty((12 * self.rec_cap,), dtype=torch.float32, device=dev)
 
     # -- stage 1/2: projection + resample -------------------------------------------------
     def _project(self, pts_local, T):
+        fn = lambda: self.proj._project_points(self.model, pts_local, self.num_local, proj_max_iters=T)
         if self.project_hook is not None:
-            return self.project_hook(lambda: self.proj._project_points(self.model, pts_local, self.num_local,
-                                                                       proj_max_iters=T), T)
-        return self.proj._project_points(self.model, pts_local, self.num_local, proj_max_iters=T)
+            return self.project_hook(fn, T)
+        return fn()
+
+    def _halo_build(self, pts, nrm, payload, box, boxes, radius, knn_k, cell_scale):
+        """N ranks: common grid from the reduced box, halo export -> all-gather -> import, build."""
+        p, lib_call, g = _lib.ptr, _lib.call, self.grid
+        gbox = torch.cat([boxes[:, 0:4].min(dim=0).values, boxes[:, 4:8].max(dim=0).values]).contiguous()
+        lib_call("iso_bricks_params", p(gbox), self.P, self.n_own, self.lo, float(radius), int(knn_k), float(cell_scale),
+                 p(g.ws), g.n_max, _lib.stream())
+        lib_call("iso_halo_export", p(g.ws), p(pts), p(nrm), p(payload), self.n_own, p(boxes), self.world, self.rank,
+                 p(self.exp_buf), self.halo_cap, _lib.stream())
+        gathered = yield ("all_gather", self.exp_buf)
+        lib_call("iso_halo_import", p(g.ws), g.n_max, p(gathered), p(boxes), self.world, self.rank, self.halo_cap,
+                 p(self.imp0), p(self.imp1), p(self.imp_count), self.import_cap, _lib.stream())
+        g.build(pts, nrm, payload=payload, params_done=True, id_base=self.lo, n_total=self.P,
+                imports=(self.imp0, self.imp1, self.imp_count))
+
+    def _resample(self, pts, nrm):
+        """FRNN K+1 query + tangent-plane repulsion of the own points (levelset_sampling.py:254-284)."""
+        box = bricks.points_bbox(pts)
+        cs = bricks.RESAMPLE_CELL * self.knn_k
+        if self.world == 1:
+            self.grid.build(pts, nrm, bbox=box, knn_k=self.knn_k, cell_scale=cs)
+        else:
+            boxes = yield ("all_gather", box)
+            yield from self._halo_build(pts, nrm, None, box, boxes, -1.0, self.knn_k, cs)
+        moved, _, _ = bricks.resample_fused(self.grid, self.knn_k + 1)
+        return moved
 
     def project_resample(self):
-        c, proj = self.comm, self.proj
+        """Generator: stages 1 and 2 -> ProjectionResult of the own points."""
         r0 = self._project(self.pts0_local, 10)
-        pts_all = c.all_gather_rows(r0.points[0], self.P).view(1, self.P, 3)
-        nrm_all = c.all_gather_rows(r0.normals[0], self.P).view(1, self.P, 3)
-        num_all = full_lengths(pts_all)
-        diag_all = cloud_diag(pts_all)                                  # one bounding-box pass for both uses
-        diag = diag_all[0]                                              # levelset_sampling.py:254-256
-        inv_sigma = (num_all.float() / diag).reshape(1).contiguous()
-        if c.world == 1:
-            proj._create_tree(pts_all, refresh_tree=True, num_points_per_cloud=num_all)
-            idx = proj._knn_idx
+        moved = yield from self._resample(r0.points[0].contiguous(), r0.normals[0].contiguous())
+        return self._project(moved.view(1, -1, 3), 3)
+
+    # -- stage 3: splat front end + forward ------------------------------------------------------
+    def _front(self, pts, nrm):
+        ss, N, w = self.splat, self.N, self.world
+        mask, cnt = bricks.view_mask(pts, nrm, self.views, ss.znear, ss.zfar, self.rs.backface_culling)
+        box = bricks.points_bbox(pts)
+        counts = None
+        if w == 1:
+            self.grid.build(pts, nrm, payload=mask, bbox=box, radius=float(ss.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
+            view_total = cnt
         else:
-            radius = (torch.sqrt(diag_all / num_all.float()) * proj.knn_k).contiguous()              # :129-131
-            grid = frnn.build_grid(pts_all, num_all, radius)
-            own = pts_all[:, self.lo:self.hi].contiguous()
-            _, idxs, _, _ = frnn.frnn_grid_points(own, pts_all, self.num_local, num_all, K=proj.knn_k + 1,
-                                                  r=radius, grid=grid)
-            idx = idxs[..., 1:]
-        moved = proj.repulsion_step(pts_all, nrm_all, idx, inv_sigma, first_point=self.lo)
-        r1 = self._project(moved, 3)
-        self.knn_idx = idx
-        return r1
-
-    # -- stage 3: splat forward ---------------------------------------------------------------
-    def splat_forward(self, pts_all, nrm_all, features_all=None):
-        """pts_all/nrm_all (P,3): the whole (gathered) cloud.  Returns fragments for this rank's
-        band of tile rows (other pixels -1 / 0) and the filtered per-view data."""
-        c, ss, rs = self.comm, self.splat, self.rs
-        dev = pts_all.device
-        S, K, N = int(rs.image_size), int(rs.points_per_pixel), self.views.shape[0]
-        P = pts_all.shape[0]
-        flags, off, lens = ss.filter_renderable(pts_all, nrm_all, self.views)
-        tot = sum(lens)
-        fl = [sum(lens[:i]) for i in range(N)]
-        num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
-        first = with_host_lengths(torch.tensor(fl, dtype=torch.int64, device=dev), fl)
-        pts_f = ss.compact(pts_all, flags, off, P, tot)
-        nrm_f = ss.compact(nrm_all, flags, off, P, tot)
-        feat_f = ss.compact(features_all, flags, off, P, tot) if features_all is not None else None
-        if c.world == 1:
-            ndc, info = ss.per_point_info(pts_f, nrm_f, first, num, self.views, self.projs)
-        else:
-            h = self._h_share(pts_f, lens, fl, num, tot)
-            c.all_reduce_(h, "sum")
-            ndc, info = self._setup_with_h(pts_f, nrm_f, h, first, num)
-        T = _lib.load().iso_splat_tiles_per_side(S)
-        band = shard_bounds(T, c.world, c.rank)
-        self.band = band
-        idx, zbuf, qv, occ = _C.splat_points(ndc, info["ellipse_params"], info["cutoff_threshold"],
-                                             info["radii"], first, num, rs.depth_merging_threshold, S, K,
-                                             0, 0, tile_rows=band if c.world > 1 else None)
-        frags = PointFragments(idx, zbuf, qv, gather_with_neg_idx(info["scaler"], idx), occ)
-        filt = {"points": pts_f, "normals": nrm_f, "features": feat_f, "ndc": ndc, "num_points": num,
-                "first_idx": first, **info}
-        return frags, filt
-
-    def _h_share(self, pts_f, lens, fl, num, tot):
-        """This rank's part of h (rasterizer.py:367-386: K=7 self query per view cloud), zero
-        elsewhere -- the caller sum-reduces.  With at least as many ranks as views (and a multiple
-        of them) a view belongs to world/N ranks: each builds ONLY that view's grid and queries its
-        share of that view's rows.  Otherwise every rank builds all N grids and queries rows
-        [qlo, qhi) of each (padded) view cloud."""
-        c, ss = self.comm, self.splat
-        dev = pts_f.device
-        N = len(lens)
-        h = torch.zeros((tot,), dtype=torch.float32, device=dev)
-        if N > 0 and c.world >= N and c.world % N == 0:
-            per_view = c.world // N
-            v, part = c.rank // per_view, c.rank % per_view
-            lv = lens[v]
-            qlo, qhi = shard_bounds(lv, per_view, part)
-            if qhi > qlo:
-                cloud = pts_f[fl[v]:fl[v] + lv].view(1, lv, 3)
-                num_v = with_host_lengths(torch.tensor([lv], dtype=torch.int64, device=dev), [lv])
-                r7 = torch.full((1,), float(ss.frnn_radius), dtype=torch.float32, device=dev)
-                grid = frnn.build_grid(cloud, num_v, r7)
-                qnum = with_host_lengths(torch.tensor([qhi - qlo], dtype=torch.int64, device=dev), [qhi - qlo])
-                dists, _, _, _ = frnn.frnn_grid_points(cloud[:, qlo:qhi].contiguous(), cloud, qnum, num_v, K=7,
-                                                       r=r7, grid=grid)
-                qfirst = torch.tensor([fl[v] + qlo], dtype=torch.int64, device=dev)
-                _lib.call("iso_splat_vrk_h", _lib.ptr(dists), _lib.ptr(qfirst), _lib.ptr(qnum), _lib.ptr(num_v),
-                          _lib.ptr(h), 1, dists.shape[1], _lib.stream())
-            return h
-        mx = max(lens) if lens else 0
-        padded = torch.zeros((N, max(mx, 1), 3), dtype=torch.float32, device=dev)
-        for i in range(N):
-            padded[i, :lens[i]] = pts_f[fl[i]:fl[i] + lens[i]]
-        r7 = torch.full((N,), float(ss.frnn_radius), dtype=torch.float32, device=dev)
-        grid = frnn.build_grid(padded, num, r7)
-        qlo, qhi = shard_bounds(mx, c.world, c.rank)
-        qlens = [min(max(l - qlo, 0), qhi - qlo) for l in lens]
-        if qhi > qlo:
-            qnum = with_host_lengths(torch.tensor(qlens, dtype=torch.int64, device=dev), qlens)
-            dists, _, _, _ = frnn.frnn_grid_points(padded[:, qlo:qhi].contiguous(), padded, qnum, num, K=7,
-                                                   r=r7, grid=grid)
-            qfirst = torch.tensor([f + qlo for f in fl], dtype=torch.int64, device=dev)
-            _lib.call("iso_splat_vrk_h", _lib.ptr(dists), _lib.ptr(qfirst), _lib.ptr(qnum), _lib.ptr(num),
-                      _lib.ptr(h), N, dists.shape[1], _lib.stream())
-        return h
-
-    def _setup_with_h(self, pts_f, nrm_f, h, first, num):
-        rs = self.rs
-        dev = pts_f.device
-        tot = pts_f.shape[0]
-        N = self.views.shape[0]
-        lens = num._iso_host
-        ndc = torch.empty((tot, 3), dtype=torch.float32, device=dev)
-        ellipse = torch.empty((tot, 3), dtype=torch.float32, device=dev)
-        cutoff = torch.empty((tot,), dtype=torch.float32, device=dev)
-        radii = torch.empty((tot, 2), dtype=torch.float32, device=dev)
-        scaler = torch.empty((tot,), dtype=torch.float32, device=dev)
+            msg = torch.cat([box, cnt.view(torch.float32)])
+            got = yield ("all_gather", msg)
+            boxes = got[:, :8].contiguous()
+            counts = got[:, 8:].contiguous().view(torch.int32)                     # (world, 8)
+            view_total = counts.sum(dim=0, dtype=torch.int32)
+            yield from self._halo_build(pts, nrm, mask, box, boxes, float(ss.frnn_radius), 0, bricks.H_CELL_SCALE)
+        h = bricks.splat_h_fused(self.grid, mask, view_total, N)
+        fr = ss.front_setup(pts, nrm, self.views, self.projs, mask, h, features_from_normals=True, out=self.wire,
+                            capacity=self.rec_cap)
+        if w == 1:
+            fr["own_first"], fr["own_num"], fr["max_pts"], fr["rows"] = fr["first_idx"], fr["num_points"], self.P, self.rec_cap
+            return fr
+        gathered = yield ("all_gather", self.wire)
+        rows = N * self.P
+        dev = self.dev
+        out = {k: torch.empty((rows, c) if c > 1 else (rows,), dtype=torch.float32, device=dev)
+               for k, c in (("ndc", 3), ("ellipse_params", 3), ("cutoff_threshold", 1), ("radii", 2), ("scaler", 1),
+                            ("features", 3))}
+        fi = torch.empty((4, N), dtype=torch.int64, device=dev)
         p = _lib.ptr
-        _lib.call("iso_splat_setup", p(pts_f), p(nrm_f), p(h), p(first), p(num), p(self.views), p(self.projs),
-                  N, max(lens) if lens else 0, int(rs.image_size), float(rs.antialiasing_sigma),
-                  float(rs.cutoff_threshold), p(ndc), p(ellipse), p(cutoff), p(radii), p(scaler), _lib.stream())
-        return ndc, {"radii": radii, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "scaler": scaler}
+        _lib.call("iso_splat_repack", p(gathered), self.rec_cap, w, self.rank, N, p(counts), float(self.rs.cutoff_threshold),
+                  rows, p(out["ndc"]), p(out["ellipse_params"]), p(out["cutoff_threshold"]), p(out["radii"]),
+                  p(out["scaler"]), p(out["features"]), p(fi[0]), p(fi[1]), p(fi[2]), p(fi[3]), _lib.stream())
+        out.update({"first_idx": fi[0], "num_points": fi[1], "own_first": fi[2], "own_num": fi[3], "src": fr["src"],
+                    "mask": mask, "h": h, "max_pts": self.P, "rows": rows, "own_counts": fr["view_total"]})
+        return out
+
+    def splat_forward(self, fr):
+        rs = self.rs
+        S, K = int(rs.image_size), int(rs.points_per_pixel)
+        T = _lib.load().iso_splat_tiles_per_side(S)
+        self.band = shard_bounds(T, self.world, self.rank)
+        self._ovf = []
+        idx, zbuf, qv, occ = _C.splat_points(fr["ndc"], fr["ellipse_params"], fr["cutoff_threshold"], fr["radii"],
+                                             fr["first_idx"], fr["num_points"], rs.depth_merging_threshold, S, K, 0, 0,
+                                             tile_rows=self.band if self.world > 1 else None, max_pts=fr["max_pts"],
+                                             pair_capacity=self.pair_cap, overflow_out=self._ovf)
+        return PointFragments(idx, zbuf, qv, None, occ)
 
     def band_rows(self):
         """Output-image pixel rows [y0, y1) of this rank's tile-row band (the image is flipped)."""
         S = int(self.rs.image_size)
+        if self.world == 1:
+            return 0, S
         b0, b1 = self.band
         return max(S - 16 * b1, 0), S - 16 * b0
 
     # -- stage 4: compositing + loss gradient + backward ------------------------------------------
-    def composite_band(self, frags, filt):
+    def composite_band(self, frags, fr):
         """(N,S,S,C+1) image, own band filled (renderer.py:53-78)."""
         idx, qv, occ = frags.idx, frags.qvalue, frags.occupancy
         N, S, _, K = idx.shape
-        feat = filt["features"]
+        feat = fr["features"]
         C = feat.shape[1]
-        y0, y1 = self.band_rows() if self.comm.world > 1 else (0, S)
-        img = torch.zeros((N, S, S, C + 1), dtype=torch.float32, device=idx.device)
+        y0, y1 = self.band_rows()
         p = _lib.ptr
+        if self.world == 1:
+            img = torch.empty((N, S, S, C + 1), dtype=torch.float32, device=idx.device)
+            _lib.call("iso_splat_composite", p(idx), p(qv), p(occ), p(fr["scaler"]), p(feat), N * S * S, K, C, 1, 1e-4,
+                      None, p(img), _lib.stream())
+            return img
+        img = torch.zeros((N, S, S, C + 1), dtype=torch.float32, device=idx.device)
         for n in range(N):
             if y1 > y0:
-                _lib.call("iso_splat_composite", p(idx[n, y0:y1]), p(qv[n, y0:y1]), p(occ[n, y0:y1]),
-                          p(filt["scaler"]), p(feat), (y1 - y0) * S, K, C, 1, 1e-4, None, p(img[n, y0:y1]),
-                          _lib.stream())
+                _lib.call("iso_splat_composite", p(idx[n, y0:y1]), p(qv[n, y0:y1]), p(occ[n, y0:y1]), p(fr["scaler"]),
+                          p(feat), (y1 - y0) * S, K, C, 1, 1e-4, None, p(img[n, y0:y1]), _lib.stream())
         return img
 
-    def backward(self, frags, filt, occ_grad_band, zbuf_grad_band):
-        """occ_grad / zbuf_grad are valid on this rank's band (zero elsewhere).  Returns
-        (grad (tot,3): xy rows of this rank's point slices + z of all points, visible flags)."""
-        c = self.comm
+    def backward(self, frags, fr, occ_grad_band, zbuf_grad_band):
+        """occ_grad / zbuf_grad are valid on this rank's band (zero elsewhere).  Returns grad (rows,3):
+        d loss / d (NDC x, y, z) of this rank's OWN packed rows fr['own_first'][v] .. + fr['own_num'][v]
+        (all rows for world == 1); fr['src'] maps own rows to own points."""
         idx = frags.idx
         N, S, _, K = idx.shape
-        dev = idx.device
-        first, num = filt["first_idx"], filt["num_points"]
-        lens, fl = num._iso_host, first._iso_host
-        tot = filt["ndc"].shape[0]
-        y0, y1 = self.band_rows() if c.world > 1 else (0, S)
-        occ_grad = c.all_reduce_(occ_grad_band.contiguous(), "sum")
-        if c.world == 1:
-            vis, rs_ = _visible_and_radius(idx, filt["radii"], first, num, float(self.rs.radii_backward_scaler))
-            grad = _C._backward(filt["ndc"], filt["radii"], occ_grad, first, num, visible=vis, rs=rs_, idx=idx,
-                                grad_zbuf=zbuf_grad_band)
-            return grad, vis
-        # visible flags from the own band, max-reduced; median radius replicated
-        vis = torch.zeros((tot,), dtype=torch.uint8, device=dev)
-        p = _lib.ptr
+        first, num = fr["first_idx"], fr["num_points"]
+        scal = float(self.rs.radii_backward_scaler)
+        if self.world == 1:
+            vis, rs_ = _visible_and_radius(idx, fr["radii"], first, num, scal, max_pts=fr["max_pts"])
+            return _C._backward(fr["ndc"], fr["radii"], occ_grad_band, first, num, visible=vis, rs=rs_, idx=idx,
+                                grad_zbuf=zbuf_grad_band, max_pts=fr["max_pts"])
+        dev, p, rows = idx.device, _lib.ptr, fr["rows"]
+        y0, y1 = self.band_rows()
+        occ_grad = yield ("all_reduce", occ_grad_band.contiguous(), "sum")
+        vis = torch.zeros((rows,), dtype=torch.uint8, device=dev)
+        zs = torch.zeros((2,), dtype=torch.int32, device=dev)
+        zmax = torch.zeros((2,), dtype=torch.int32, device=dev)
         for n in range(N):
             if y1 > y0:
                 _lib.call("iso_splat_mark_visible", p(idx[n, y0:y1]), (y1 - y0) * S, K, p(vis), _lib.stream())
-        vis_i = vis.to(torch.int32)
-        c.all_reduce_(vis_i, "max")
-        vis = vis_i.to(torch.uint8)
-        rs_ = median_radius(vis, filt["radii"], first, num, float(self.rs.radii_backward_scaler))
-        # xy: point-major over this rank's slice of every view
-        sub = [shard_bounds(l, c.world, c.rank) for l in lens]
-        sfirst = [f + lo for f, (lo, hi) in zip(fl, sub)]
-        snum = [hi - lo for lo, hi in sub]
-        sf = with_host_lengths(torch.tensor(sfirst, dtype=torch.int64, device=dev), sfirst)
-        sn = with_host_lengths(torch.tensor(snum, dtype=torch.int64, device=dev), snum)
-        grad = _C._backward(filt["ndc"], filt["radii"], occ_grad, sf, sn, visible=vis, rs=rs_)
-        # z: pixel-major scatter on the own band, sum-reduced
-        gz = torch.zeros((tot, 1), dtype=torch.float32, device=dev)
+                _lib.call("iso_splat_z_absmax", p(zbuf_grad_band[n, y0:y1]), (y1 - y0) * S * K, p(zs), _lib.stream())
+                zmax = torch.maximum(zmax, zs)
+        vis = yield ("all_reduce", vis, "max")
+        zmax = yield ("all_reduce", zmax, "max")
+        rs_ = median_radius(vis, fr["radii"], first, num, scal, max_pts=fr["max_pts"])
+        grad = _C._backward(fr["ndc"], fr["radii"], occ_grad, fr["own_first"], fr["own_num"], visible=vis, rs=rs_,
+                            max_pts=self.n_own)
+        acc = torch.zeros((rows,), dtype=torch.int64, device=dev)
         for n in range(N):
             if y1 > y0:
-                _C._backward_zbuf(idx[n:n + 1, y0:y1], zbuf_grad_band[n:n + 1, y0:y1], gz)
-        c.all_reduce_(gz, "sum")
-        grad[:, 2] = gz[:, 0]
-        return grad, vis
+                _lib.call("iso_splat_z_scatter", p(idx[n, y0:y1]), p(zbuf_grad_band[n, y0:y1]), (y1 - y0) * S, K, S,
+                          p(zmax), p(acc), _lib.stream())
+        acc = yield ("all_reduce", acc, "sum")
+        if y1 <= y0:      # a rank without tile rows still has to know the exponent
+            _lib.call("iso_splat_z_scatter", None, None, 0, K, S, p(zmax), p(acc), _lib.stream())
+        _lib.call("iso_splat_z_finish", p(acc), p(zmax), 0, rows, p(grad), _lib.stream())
+        return grad
 
     # -- the whole cycle -----------------------------------------------------------------------
-    def step(self):
-        c = self.comm
-        r1 = self.project_resample()
-        pts_all = c.all_gather_rows(r1.points[0], self.P)
-        nrm_all = c.all_gather_rows(r1.normals[0], self.P)
-        feats = 0.5 * (torch.nn.functional.normalize(nrm_all, dim=-1) + 1)
-        frags, filt = self.splat_forward(pts_all, nrm_all, feats)
-        img = self.composite_band(frags, filt)
+    def cycle(self):
+        """Generator over the exchanges of one cycle; returns (projection result of the own points,
+        image with the own band filled, gradient of the packed rows, fragments, front-end dict)."""
+        r1 = yield from self.project_resample()
+        fr = yield from self._front(r1.points[0].contiguous(), r1.normals[0].contiguous())
+        frags = self.splat_forward(fr)
+        img = self.composite_band(frags, fr)
         # loss of SURVEY 8(d) cfg 3: mean((alpha - target)^2) [+ 1e-2 mean(rgb^2): no grad to the op]
         alpha = img[..., 3]
-        N, S = alpha.shape[0], alpha.shape[1]
-        y0, y1 = self.band_rows() if c.world > 1 else (0, S)
-        occ_grad = torch.zeros_like(alpha)
+        y0, y1 = self.band_rows()
         tgt = self.target if self.target is not None else torch.zeros_like(alpha)
-        occ_grad[:, y0:y1] = 2.0 * (alpha[:, y0:y1] - tgt[:, y0:y1]) / alpha.numel()
-        zbuf_grad = torch.zeros_like(frags.zbuf)
-        zbuf_grad[:, y0:y1, :, 0] = 1e-3 / alpha.numel()
-        grad, vis = self.backward(frags, filt, occ_grad, zbuf_grad)
-        return r1, img, grad, frags, filt
+        if self.world == 1:
+            occ_grad = 2.0 * (alpha - tgt) / alpha.numel()
+            zbuf_grad = torch.zeros_like(frags.zbuf)
+            zbuf_grad[..., 0] = 1e-3 / alpha.numel()
+        else:
+            occ_grad = torch.zeros_like(alpha)
+            occ_grad[:, y0:y1] = 2.0 * (alpha[:, y0:y1] - tgt[:, y0:y1]) / alpha.numel()
+            zbuf_grad = torch.zeros_like(frags.zbuf)
+            zbuf_grad[:, y0:y1, :, 0] = 1e-3 / alpha.numel()
+        grad = yield from self.backward(frags, fr, occ_grad, zbuf_grad)
+        return r1, img, grad, frags, fr
+
+    def run(self, g):
+        """Drive a generator of this class (cycle, project_resample, ...) with the process group."""
+        try:
+            req = next(g)
+            while True:
+                req = g.send(self.comm.execute(req))
+        except StopIteration as e:
+            return e.value
+
+    def step(self):
+        self.comm.bytes_log = []
+        return self.run(self.cycle())
+
+    # -- capacities ------------------------------------------------------------------------------------
+    def usage(self, fr=None):
+        """Host read of the device-side counts of the last cycle (set-up / tests only)."""
+        hdr = self.grid.header()
+        c = self.grid.ws[256:320].cpu().view(torch.int32).tolist()
+        u = {"grid": hdr, "halo_export_overflow": c[4], "halo_import_overflow": c[5],
+             "pair_overflow": int(self._ovf[0].item()) if self._ovf else 0}
+        if self.world > 1:
+            u["halo_exported"] = int(self.exp_buf[:1].view(torch.int32).item())
+            u["halo_imported"] = int(self.imp_count.item())
+        if fr is not None:
+            u["own_rows"] = int(fr["own_num"].sum().item())
+        return u
+
+    def check(self, fr=None):
+        u = self.usage(fr)
+        bad = [k for k in ("halo_export_overflow", "halo_import_overflow", "pair_overflow") if u[k]]
+        if self.world > 1 and (u["halo_exported"] > self.halo_cap or u["halo_imported"] > self.import_cap):
+            bad.append("halo capacity")
+        if fr is not None and self.world > 1 and u["own_rows"] > self.rec_cap:
+            bad.append("row capacity")
+        if bad:
+            raise RuntimeError("IsoCycle: buffer overflow (%s): %s -- raise the capacities / calibrate()" % (bad, u))
+        return u
+
+    def calibrate(self, margin=1.5):
+        """One synchronised cycle, then shrink the exchange buffers to `margin` x what it used (agreed
+        over the ranks).  Untimed set-up; the capacities stay fixed afterwards and `check` reports
+        an overflow."""
+        out = self.step()
+        u = self.check(out[4])
+        if self.world > 1:
+            c = self.comm
+            self.halo_cap = max(1024, int(margin * c.max_int(u["halo_exported"], self.dev)))
+            self.import_cap = max(1024, int(margin * c.max_int(u["halo_imported"], self.dev)))
+            self.rec_cap = max(1024, int(min(margin, 1.25) * c.max_int(u["own_rows"], self.dev)))
+            self._alloc()
+        return u
+
+
+def run_lockstep(cycles, timer=None):
+    """Run one cycle of every rank of a job inside ONE process (all ranks on one device): the generators
+    advance in lock-step and the exchanges are done by hand.  Returns the list of the ranks' results.
+    `timer(rank)` (optional) is a context manager entered around every compute segment of a rank --
+    tools/rank_share_bench.py sums the device time per rank with it."""
+    import contextlib
+    gens = [c.cycle() for c in cycles]
+    tm = timer or (lambda r: contextlib.nullcontext())
+    reqs, results = [None] * len(gens), [None] * len(gens)
+    live = list(range(len(gens)))
+    send = [None] * len(gens)
+    first = True
+    while live:
+        for r in list(live):
+            try:
+                with tm(r):
+                    reqs[r] = next(gens[r]) if first else gens[r].send(send[r])
+            except StopIteration as e:
+                results[r] = e.value
+                live.remove(r)
+        first = False
+        if not live:
+            break
+        assert len(live) == len(gens), "ranks left the cycle at different exchanges"
+        kind = reqs[0][0]
+        assert all(q[0] == kind for q in reqs)
+        if kind == "all_gather":
+            g = torch.stack([q[1] for q in reqs])
+            send = [g for _ in gens]
+        else:
+            st = torch.stack([q[1] for q in reqs])
+            red = st.sum(dim=0) if reqs[0][2] == "sum" else st.max(dim=0).values
+            send = []
+            for q in reqs:
+                q[1].copy_(red)
+                send.append(q[1])
+    return results
 
 
 def sphere_silhouette(S, n_views, dist, fov_deg, device):

@@ -136,6 +136,7 @@ class UniformProjection(LevelSetProjection):
         self.sample_iters = sample_iters
         self.resampling_clip = resampling_clip  # stored, unused -- as in the reference (:108)
         self._packed_cache = None
+        self.materialize_knn = False   # resample(): also write the neighbour lists the fused kernel selects
 
     # -- tree ------------------------------------------------------------------------
     def _create_tree(self, points_padded, refresh_tree=True, num_points_per_cloud=None):
@@ -347,16 +348,37 @@ class UniformProjection(LevelSetProjection):
         if batch_size != 1:
             raise NotImplementedError("resample: one cloud per call (the reference's broadcast of "
                                       "inv_sigma_spatial is only valid for batch size 1, :256,:274)")
-        diag = cloud_diag(points_init.reshape(1, -1, 3))[0]                   # :254-255
-        inv_sigma = (num_points.float() / diag).reshape(1).contiguous()      # device scalar (:256)
         points = points_init
         projection_result = None
         idx = None
+        inv_sigma = None
+        P = points_init.shape[1]
+        fused = (points_init.is_cuda and self.knn_k + 1 <= 13 and host_lengths(num_points)[0] == P
+                 and points_init.dtype == torch.float32)
         for sample_iter in range(sample_iters):
-            if sample_iter % 2 == 0:
-                self._create_tree(points, refresh_tree=True, num_points_per_cloud=num_points)
-                idx = self._knn_idx
-            points = self.repulsion_step(points, normals_init, idx, inv_sigma)
+            if sample_iter == 0 and fused:
+                # tree + repulsion in one kernel on the brick grid (csrc/bricks.hip); the neighbour lists are
+                # only materialised when a later iteration re-uses them (:262-266) or the caller asks for them
+                from . import bricks
+                grid = bricks.BrickGrid(P, points.device)
+                grid.build(points[0].contiguous(), normals_init[0].contiguous(), knn_k=self.knn_k)
+                keep = sample_iters > 1 or self.materialize_knn
+                moved, idx_f, d2_f = bricks.resample_fused(grid, self.knn_k + 1, want_idx=keep)
+                inv_sigma = grid.ws[48:52].view(torch.float32)                      # P / diag of points_init (:254-256)
+                idx = idx_f.view(1, P, self.knn_k) if keep else None
+                self._knn_idx = idx
+                self._knn_dists = d2_f.view(1, P, self.knn_k) if keep else None
+                self._knn_nn = None
+                self.knn_gather = self._knn_gather = frnn.frnn_gather
+                points = moved.view(1, P, 3)
+            else:
+                if inv_sigma is None:
+                    diag = cloud_diag(points_init.reshape(1, -1, 3))[0]               # :254-255
+                    inv_sigma = (num_points.float() / diag).reshape(1).contiguous()  # device scalar (:256)
+                if sample_iter % 2 == 0:
+                    self._create_tree(points, refresh_tree=True, num_points_per_cloud=num_points)
+                    idx = self._knn_idx
+                points = self.repulsion_step(points, normals_init, idx, inv_sigma)
             projection_result = self._project_points(model, points, num_points, proj_max_iters=3,
                                                      **forward_kwargs)
         return projection_result

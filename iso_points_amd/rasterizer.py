@@ -95,8 +95,12 @@ class _CNamespace(object):
     @staticmethod
     def splat_points(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
                      num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel,
-                     bin_size=0, max_points_per_bin=0, tile_rows=None, out=None):
+                     bin_size=0, max_points_per_bin=0, tile_rows=None, out=None, max_pts=None,
+                     pair_capacity=None, overflow_out=None):
         """-> (idx i32 (N,S,S,K), zbuf, qvalue f32 (N,S,S,K), occupancy f32 (N,S,S)).
+        max_pts (upper bound of the points of a cloud) + pair_capacity (upper bound of the point-tile
+        pairs): with both given nothing is read back to the host; an overflow of the pair list sets
+        the int32 flag appended to `overflow_out` (checked by the caller when convenient).
         bin_size / max_points_per_bin are accepted and ignored: binning is internal (16x16 tiles,
         exact-size pair list), so the reference's num_bins<22 / max_points_per_bin limits do not
         exist here.  tile_rows=(begin, end) (extension, used by the sharded path) rasterises
@@ -135,7 +139,7 @@ class _CNamespace(object):
         if N == 0 or S == 0:
             return idx, zbuf, qv, occ
         ntiles = N * T * T
-        maxp = _max_pts(num)
+        maxp = int(max_pts) if max_pts is not None else _max_pts(num)
         p, s = _lib.ptr, _lib.stream()
         tile_cnt = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)
         _lib.call("iso_splat_bin_count", p(pts), p(ra), p(first), p(num), N, maxp, S, band[0], band[1],
@@ -144,9 +148,14 @@ class _CNamespace(object):
         ws_b = lib.iso_prefix_sum_workspace_bytes(ntiles + 1, 1)
         ws = torch.empty((ws_b,), dtype=torch.uint8, device=dev)
         _lib.call("iso_prefix_sum", p(tile_cnt), p(tile_off), ntiles + 1, 1, ntiles + 1, p(ws), ws_b, s)
-        total = int(tile_off[ntiles].item())          # the one host read of the forward pass
+        if pair_capacity is None:
+            total = int(tile_off[ntiles].item())      # the one host read of the forward pass
+        else:
+            total = int(pair_capacity)
         pairs = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
         cursor = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)   # [ntiles] = overflow flag
+        if overflow_out is not None:
+            overflow_out.append(cursor[ntiles:])
         _lib.call("iso_splat_forward", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
                   float(depth_merging_thres), S, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
                   _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), s)
@@ -161,7 +170,7 @@ class _CNamespace(object):
 
     @staticmethod
     def _backward(points, radii, grad_occ, first, num, visible=None, rs=None, rect_mode=0, radii_s=10.0,
-                  idx=None, grad_zbuf=None):
+                  idx=None, grad_zbuf=None, max_pts=None):
         dev = points.device
         P = points.shape[0]
         N, S = grad_occ.shape[0], grad_occ.shape[1]
@@ -180,7 +189,8 @@ class _CNamespace(object):
         K = idx.shape[-1] if idx is not None else 1
         p = _lib.ptr
         _lib.call("iso_splat_backward", p(pts), p(ra), p(visible) if visible is not None else None,
-                  p(_f32c(rs)) if rs is not None else None, p(first), p(num_c), N, _max_pts(num_c), p(go),
+                  p(_f32c(rs)) if rs is not None else None, p(first), p(num_c), N,
+                  int(max_pts) if max_pts is not None else _max_pts(num_c), p(go),
                   p(idx.contiguous()) if idx is not None else None,
                   p(_f32c(grad_zbuf)) if grad_zbuf is not None else None, S, K, int(rect_mode),
                   float(radii_s), P, p(ws), ws.numel(), p(grad), _lib.stream())
@@ -229,7 +239,7 @@ _C = _CNamespace()
 
 
 # ----------------------------------------------------------------------------- autograd op
-def _visible_and_radius(idx, radii, first_idx, num_points, radii_s):
+def _visible_and_radius(idx, radii, first_idx, num_points, radii_s, max_pts=None):
     """rasterizer.py:850-856,884: visible set + per-cloud r = median(visible radii) * radii_s,
     computed on the device (sort + device-side index, no host sync)."""
     P = radii.shape[0]
@@ -238,10 +248,10 @@ def _visible_and_radius(idx, radii, first_idx, num_points, radii_s):
     npix = idx.numel() // idx.shape[-1]
     _lib.call("iso_splat_mark_visible", _lib.ptr(idx.contiguous()), npix, idx.shape[-1], _lib.ptr(vis),
               _lib.stream())
-    return vis, median_radius(vis, radii, first_idx, num_points, radii_s)
+    return vis, median_radius(vis, radii, first_idx, num_points, radii_s, max_pts=max_pts)
 
 
-def median_radius(vis, radii, first_idx, num_points, radii_s):
+def median_radius(vis, radii, first_idx, num_points, radii_s, max_pts=None):
     """(N,) device tensor r_n = median(visible radii of cloud n) * radii_s (iso_splat_median_radius)."""
     dev = radii.device
     N = num_points.shape[0]
@@ -251,7 +261,8 @@ def median_radius(vis, radii, first_idx, num_points, radii_s):
     out = torch.empty((N,), dtype=torch.float32, device=dev)
     p = _lib.ptr
     _lib.call("iso_splat_median_radius", p(_f32c(radii)), p(vis), p(_i64c(first_idx)), p(_i64c(num_points)), N,
-              _max_pts(num_points), float(radii_s), p(ws), ws_b, p(out), _lib.stream())
+              int(max_pts) if max_pts is not None else _max_pts(num_points), float(radii_s), p(ws), ws_b, p(out),
+              _lib.stream())
     return out
 
 
@@ -380,35 +391,98 @@ class SurfaceSplatting(object):
                   float(rs.cutoff_threshold), p(ndc), p(ellipse), p(cutoff), p(radii), p(scaler), s)
         return ndc, {"radii": radii, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "scaler": scaler}
 
+    # -- fused front end (section E of the C ABI): no filtered copies, no host read ---------------------
+    def front(self, points, normals, views, projs, features=None, features_from_normals=False, grid=None,
+              out=None, capacity=None):
+        """mask -> brick grid -> h (all views in one pass) -> compaction + per-point set-up of ONE cloud
+        seen by N <= 8 cameras.  Returns a dict of capacity-sized packed arrays (rows beyond the
+        device-side total are unspecified), first_idx / num_points int64 (N,) and view_total int32 (8,)
+        on the device, mask (P,) int32, src (rows -> original point).  `out`: a (12, capacity) f32
+        buffer to write ndc / ellipse / radii / scaler / features into (the multi-GPU wire layout)."""
+        from . import bricks
+        rs = self.raster_settings
+        if rs.Vrk_invariant or not rs.Vrk_isotropic:
+            raise NotImplementedError("only the default isotropic Vrk is built (SURVEY 2.1 #3)")
+        P, N = points.shape[0], views.shape[0]
+        if N > 8:
+            raise NotImplementedError("front: at most 8 views per call")
+        dev = points.device
+        mask, cnt = bricks.view_mask(points, normals, views, self.znear, self.zfar, rs.backface_culling)
+        if grid is None:
+            grid = bricks.BrickGrid(P, dev)
+        grid.build(points, normals, payload=mask, radius=float(self.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
+        h = bricks.splat_h_fused(grid, mask, cnt, N)
+        return self.front_setup(points, normals, views, projs, mask, h, features, features_from_normals, out, capacity)
+
+    def front_setup(self, points, normals, views, projs, mask, h, features=None, features_from_normals=False,
+                    out=None, capacity=None):
+        rs = self.raster_settings
+        P, N = points.shape[0], views.shape[0]
+        dev = points.device
+        cap = int(capacity) if capacity is not None else max(N * P, 1)
+        C = 3 if features_from_normals else (features.shape[1] if features is not None else 0)
+        if out is None:
+            out = torch.empty((12 * cap,), dtype=torch.float32, device=dev)
+        flat = out.view(-1)
+        assert flat.numel() >= 12 * cap
+        ndc = flat[0:3 * cap].view(cap, 3)
+        ellipse = flat[3 * cap:6 * cap].view(cap, 3)
+        radii = flat[6 * cap:8 * cap].view(cap, 2)
+        scaler = flat[8 * cap:9 * cap]
+        if C == 3:
+            feat = flat[9 * cap:12 * cap].view(cap, 3)
+        else:
+            feat = torch.empty((cap, C), dtype=torch.float32, device=dev) if C else None
+        cutoff = torch.empty((cap,), dtype=torch.float32, device=dev)
+        src = torch.empty((cap,), dtype=torch.int32, device=dev)
+        first = torch.empty((N,), dtype=torch.int64, device=dev)
+        num = torch.empty((N,), dtype=torch.int64, device=dev)
+        view_total = torch.empty((8,), dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        ws_b = lib.iso_splat_front_workspace_bytes(P)
+        ws = torch.empty((ws_b,), dtype=torch.uint8, device=dev)
+        p = _lib.ptr
+        _lib.call("iso_splat_front", p(points), p(normals), p(_f32c(features)) if (features is not None and not features_from_normals) else None,
+                  C, int(bool(features_from_normals)), p(mask), p(h), P, p(_f32c(views)), p(_f32c(projs)), N,
+                  int(rs.image_size), float(rs.antialiasing_sigma), float(rs.cutoff_threshold), p(ws), ws_b, p(first),
+                  p(num), p(view_total), p(ndc), p(ellipse), p(cutoff), p(radii), p(scaler),
+                  p(feat) if feat is not None else None, p(src), _lib.stream())
+        return {"ndc": ndc, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "radii": radii, "scaler": scaler,
+                "features": feat, "src": src, "first_idx": first, "num_points": num, "view_total": view_total,
+                "mask": mask, "h": h, "wire": out, "capacity": cap}
+
     def forward(self, points, normals, cameras=None, features=None):
         """points/normals (P,3) one cloud seen by N cameras (the reference extends the cloud to the
         number of cameras, :597-598).  Returns (PointFragments, filtered dict)."""
         views, projs = cameras or self.cameras
         rs = self.raster_settings
-        pts, nrm = _f32c(points), _f32c(normals)
-        P, N = pts.shape[0], views.shape[0]
-        dev = pts.device
-        views_c = _f32c(views)
-        flags, off, lens = self.filter_renderable(pts, nrm, views_c)
-        tot = sum(lens)
-        num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
-        fl = [sum(lens[:i]) for i in range(N)]
-        first = with_host_lengths(torch.tensor(fl, dtype=torch.int64, device=dev), fl)
-        S, K = int(rs.image_size), int(rs.points_per_pixel)
-        if tot == 0:
-            idx = torch.full((N, S, S, K), -1, dtype=torch.int32, device=dev)
-            neg = torch.full((N, S, S, K), -1.0, dtype=torch.float32, device=dev)
-            occ = torch.zeros((N, S, S), dtype=torch.float32, device=dev)
-            return PointFragments(idx, neg, neg.clone(), neg.clone(), occ), {"num_points": num, "first_idx": first}
-        pts_f = self.compact(pts, flags, off, P, tot)
-        nrm_f = self.compact(nrm, flags, off, P, tot)
-        feat_f = self.compact(features, flags, off, P, tot) if features is not None else None
-        with torch.no_grad():
-            ndc, info = self.per_point_info(pts_f, nrm_f, first, num, views_c, projs)
         if points.requires_grad:
             raise NotImplementedError("gradient w.r.t. world points goes through the camera transform, "
                                       "which is the caller's (pytorch3d's) job: rasterise NDC points that "
                                       "require grad with rasterize_elliptical_points")
+        pts, nrm = _f32c(points), _f32c(normals)
+        P, N = pts.shape[0], views.shape[0]
+        dev = pts.device
+        S, K = int(rs.image_size), int(rs.points_per_pixel)
+        with torch.no_grad():
+            fr = self.front(pts, nrm, _f32c(views), _f32c(projs), features=features)
+        lens = [int(x) for x in fr["num_points"].tolist()]          # the API returns exact-size tensors: one host read
+        tot = sum(lens)
+        fl = [sum(lens[:i]) for i in range(N)]
+        num = with_host_lengths(fr["num_points"], lens)
+        first = with_host_lengths(fr["first_idx"], fl)
+        flags = ((fr["mask"][None] >> torch.arange(N, device=dev)[:, None]) & 1).to(torch.int32)
+        if tot == 0:
+            idx = torch.full((N, S, S, K), -1, dtype=torch.int32, device=dev)
+            neg = torch.full((N, S, S, K), -1.0, dtype=torch.float32, device=dev)
+            occ = torch.zeros((N, S, S), dtype=torch.float32, device=dev)
+            return PointFragments(idx, neg, neg.clone(), neg.clone(), occ), {"num_points": num, "first_idx": first,
+                                                                             "flags": flags}
+        info = {k: fr[k][:tot] for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler")}
+        ndc = fr["ndc"][:tot]
+        src = fr["src"][:tot].long()
+        self._Vrk_h = fr["h"].view(-1)[(torch.arange(N, device=dev).repeat_interleave(torch.tensor(lens, device=dev))
+                                        * P + src)]
         idx, zbuf, qv, occ = rasterize_elliptical_points(
             PackedClouds(ndc, first, num), info["ellipse_params"], info["cutoff_threshold"], info["radii"],
             depth_merging_threshold=rs.depth_merging_threshold, image_size=S, points_per_pixel=K,
@@ -418,8 +492,9 @@ class SurfaceSplatting(object):
         frags = PointFragments(idx, zbuf, qv, frag_scaler, occ)
         vis = torch.zeros((tot,), dtype=torch.uint8, device=dev)
         _lib.call("iso_splat_mark_visible", _lib.ptr(idx), N * S * S, K, _lib.ptr(vis), _lib.stream())
-        filtered = {"points": pts_f, "normals": nrm_f, "features": feat_f, "ndc": ndc, "num_points": num,
-                    "first_idx": first, "flags": flags[:-1].view(N, P), "visibility": vis.bool(), **info}
+        filtered = {"points": pts[src], "normals": nrm[src],
+                    "features": fr["features"][:tot] if fr["features"] is not None else None, "ndc": ndc,
+                    "num_points": num, "first_idx": first, "flags": flags, "visibility": vis.bool(), "src": src, **info}
         return frags, filtered
 
 

@@ -1,5 +1,7 @@
-"""Multi-process (gloo, world_size 2/3, CPU) tests of the sharding helpers the N>1 path is
-built from (iso_points_amd/dist.py): shard bounds, ragged all-gather in shard order, reductions."""
+"""Multi-process (gloo, world_size 2/3, CPU) tests of what the N>1 path is built from
+(iso_points_amd/dist.py): shard bounds, the x-slab order, the exchange protocol of `Comm.execute`
+(the requests the cycle generator yields) and the in-process lock-step driver, which must give the
+same answers as the process group."""
 import os
 import socket
 
@@ -16,35 +18,63 @@ def _free_port():
     return port
 
 
+def _toy_cycle(rank, world, n):
+    """A generator with the exchange pattern of IsoCycle.cycle: gather of boxes, gather of a padded
+    record buffer with a count in word 0, max / sum reductions of disjoint segments."""
+    box = torch.tensor([float(rank), 0, 0, 0, float(rank + 1), 0, 0, 0])
+    boxes = yield ("all_gather", box)
+    cap = 5
+    buf = torch.zeros(cap + 1)
+    cnt = 1 + rank % cap
+    buf[0] = cnt
+    buf[1:1 + cnt] = torch.arange(cnt, dtype=torch.float32) + 10 * rank
+    got = yield ("all_gather", buf)
+    vis = torch.zeros(n, dtype=torch.uint8)
+    vis[rank::world] = 1
+    vis = yield ("all_reduce", vis, "max")
+    acc = torch.zeros(n, dtype=torch.int64)
+    acc[rank::world] = rank + 1
+    acc = yield ("all_reduce", acc, "sum")
+    return boxes, got, vis, acc
+
+
+def _expect(world, n):
+    boxes = torch.stack([torch.tensor([float(r), 0, 0, 0, float(r + 1), 0, 0, 0]) for r in range(world)])
+    vis = torch.ones(n, dtype=torch.uint8)
+    acc = torch.tensor([(i % world) + 1 for i in range(n)], dtype=torch.int64)
+    return boxes, vis, acc
+
+
 def _worker(rank, world, port, n_total, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from iso_points_amd.dist import Comm, shard_bounds
+        from iso_points_amd.dist import Comm
         c = Comm()
         assert c.world == world and c.rank == rank
-        full = torch.arange(n_total * 3, dtype=torch.float32).view(n_total, 3)
-        lo, hi = shard_bounds(n_total, world, rank)
-        got = c.all_gather_rows(full[lo:hi].clone(), n_total)
-        ok = torch.equal(got, full)
-        # sum-reduce of disjoint segments == concatenation (how h / occ_grad bands are merged)
-        buf = torch.zeros(n_total)
-        buf[lo:hi] = full[lo:hi, 0]
-        c.all_reduce_(buf, "sum")
-        ok = ok and torch.equal(buf, full[:, 0])
-        flags = torch.zeros(n_total, dtype=torch.int32)
-        flags[rank::world] = 1
-        c.all_reduce_(flags, "max")
-        ok = ok and bool((flags == 1).all())
+        g = _toy_cycle(rank, world, n_total)
+        try:
+            req = next(g)
+            while True:
+                req = g.send(c.execute(req))
+        except StopIteration as e:
+            boxes, got, vis, acc = e.value
+        eb, ev, ea = _expect(world, n_total)
+        ok = torch.equal(boxes, eb) and torch.equal(vis, ev) and torch.equal(acc, ea)
+        for r in range(world):
+            cnt = int(got[r, 0])
+            ok = ok and cnt == 1 + r % 5 and torch.equal(got[r, 1:1 + cnt], torch.arange(cnt, dtype=torch.float32) + 10 * r)
+        ok = ok and [k for k, _ in c.bytes_log] == ["all_gather", "all_gather", "all_reduce", "all_reduce"]
+        ok = ok and c.max_int(rank * 7, torch.device("cpu")) == (world - 1) * 7
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,n_total", [(2, 10), (2, 7), (3, 8)])
-def test_comm_helpers_gloo(world, n_total):
+def test_exchange_protocol_gloo(world, n_total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -58,30 +88,50 @@ def test_comm_helpers_gloo(world, n_total):
     assert all(res.values())
 
 
-def test_shard_bounds_cover_range():
+@pytest.mark.parametrize("world,n_total", [(2, 10), (3, 8), (8, 33)])
+def test_lockstep_driver_matches_the_protocol(world, n_total):
+    """run_lockstep's hand-made exchanges = what the process group returns (same toy cycle)."""
+    from iso_points_amd.dist import run_lockstep
+
+    class Toy(object):
+        def __init__(self, r):
+            self.r = r
+
+        def cycle(self):
+            return _toy_cycle(self.r, world, n_total)
+
+    res = run_lockstep([Toy(r) for r in range(world)])
+    eb, ev, ea = _expect(world, n_total)
+    for r, (boxes, got, vis, acc) in enumerate(res):
+        assert torch.equal(boxes, eb) and torch.equal(vis, ev) and torch.equal(acc, ea)
+        for s in range(world):
+            assert int(got[s, 0]) == 1 + s % 5
+
+
+def test_shard_bounds_cover_everything():
     from iso_points_amd.dist import all_shard_bounds, shard_bounds
-    for n in (0, 1, 7, 32, 1000001):
+    for n in (0, 1, 7, 100, 1000003):
         for w in (1, 2, 3, 8):
             b = all_shard_bounds(n, w)
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
-            assert b[w - 1] == shard_bounds(n, w, w - 1)
+            assert shard_bounds(n, w, w - 1) == b[-1]
 
 
-def test_ray_bounds_host_logic():
-    """ray_tracing.sphere_entry_exit (torch glue of RayTracing, no kernel) == the oracle's restatement of
-    intersection_with_unit_sphere, hits and tangent-plane misses, cameras outside and inside."""
-    import torch
-    from oracle import iso_oracle as O
-    from iso_points_amd.ray_tracing import sphere_entry_exit
+def test_slab_order_is_a_stable_x_sort():
+    from iso_points_amd.dist import shard_bounds, slab_order
     g = torch.Generator().manual_seed(0)
-    for cam in ([[0.0, 0.3, 2.5]], [[0.2, -0.1, 0.4]], [[0.0, 0.0, -3.0], [1.5, 1.5, 0.0]]):
-        c = torch.tensor(cam)
-        d = torch.nn.functional.normalize((torch.rand(c.shape[0], 500, 3, generator=g) - 0.5) * 2.5 - c[:, None], dim=-1)
-        for radius in (1.0, 0.7):
-            e0, e1, hit = sphere_entry_exit(c, d, radius)
-            r0, r1, rh = O.sphere_entry_exit(c, d, radius)
-            assert torch.equal(hit, rh) and 0 < int(hit.sum()) < hit.numel() or c.norm(dim=-1).min() < radius
-            assert torch.allclose(e0, r0, rtol=0, atol=2e-6) and torch.allclose(e1, r1, rtol=0, atol=2e-6)
+    p = torch.randn(1000, 3, generator=g)
+    p[100:120, 0] = p[5, 0]                      # ties keep their original order
+    assert torch.equal(slab_order(p, 1), torch.arange(1000))
+    perm = slab_order(p, 4)
+    xs = p[perm, 0]
+    assert (xs[1:] >= xs[:-1]).all() and sorted(perm.tolist()) == list(range(1000))
+    tie = perm[(xs == p[5, 0])]
+    assert (tie[1:] > tie[:-1]).all()
+    # rank r's slab lies left of rank r+1's
+    for r in range(3):
+        lo, hi = shard_bounds(1000, 4, r)
+        assert xs[hi - 1] <= xs[hi]

@@ -1,140 +1,156 @@
-"""The sharded iso-point cycle (iso_points_amd/dist.py) with 2 ranks == the single-GPU cycle.
-Both ranks share the one GPU of the test box and talk over gloo (RCCL refuses two ranks on one
-device); the collectives, shard bookkeeping and every kernel are the ones the N>1 bench runs."""
+"""The sharded iso-point cycle (iso_points_amd/dist.py) against the single-GPU one.
+
+world ranks in lock-step inside one process (run_lockstep: the same generator code the process group
+drives): every result of the N-rank job must be BIT-identical to the single-GPU cycle on the same
+(x-slab ordered) cloud -- projected points, per-pixel index lists, z-buffers, images and the gradients
+of every packed row (z included: fixed-point accumulation).  Plus one real 2-process run over gloo."""
 import os
-import socket
+import subprocess
+import sys
 
 import pytest
 import torch
-import torch.multiprocessing as mp
+
+from util import sphere_cloud
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
-def _setup(dev, P, S, n_views=3):
+def _scene(dev, P, S, N, seed=3):
     from iso_points_amd.cameras import look_at_view, perspective
     from iso_points_amd.dist import sphere_silhouette
     from iso_points_amd.rasterizer import PointsRasterizationSettings
-    from iso_points_amd.sdf_models import Siren
-    g = torch.Generator().manual_seed(0)
-    pts = torch.nn.functional.normalize(torch.randn(1, P, 3, generator=g), dim=-1)
-    pts = (pts + 0.05 * (torch.rand(1, P, 3, generator=g) - 0.5)).to(dev)
-    views = torch.stack([look_at_view(5.0, 20.0, 120.0 * i) for i in range(n_views)]).to(dev)
+    pts = sphere_cloud(P, seed=seed).to(dev)
+    views = torch.stack([look_at_view(3.0, 20.0, 360.0 / N * i) for i in range(N)]).to(dev)
     projs = views @ perspective(30.0).to(dev)
-    rs = PointsRasterizationSettings(image_size=S, points_per_pixel=6)
-    target = sphere_silhouette(S, n_views, 5.0, 30.0, dev)
-    return pts, views, projs, rs, target
+    rs = PointsRasterizationSettings(image_size=S, points_per_pixel=8, cutoff_threshold=1.0, depth_merging_threshold=0.05,
+                                     radii_backward_scaler=10, backface_culling=True, Vrk_isotropic=True)
+    return pts, views, projs, rs, sphere_silhouette(S, N, 3.0, 30.0, dev)
 
 
-def _run(model_kind, dev, comm, P, S, n_views=3):
-    from iso_points_amd.dist import IsoCycle
-    from iso_points_amd.sdf_models import SphereSDF, Siren
-    pts, views, projs, rs, target = _setup(dev, P, S, n_views)
-    if model_kind == "sphere":
-        model = SphereSDF().to(dev)
-    else:
-        torch.manual_seed(0)
-        model = Siren(hidden_size=128, n_layers=2).to(dev)     # random weights: fixed iteration counts
-    cyc = IsoCycle(model, pts, views, projs, raster_settings=rs, comm=comm, target=target)
-    return cyc, cyc.step()
-
-
-def _worker(rank, world, port, model_kind, P, S, outdir, n_views=3):
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from iso_points_amd.dist import Comm
-        dev = torch.device("cuda:0")
-        comm = Comm()
-        cyc, (r1, img, grad, frags, filt) = _run(model_kind, dev, comm, P, S, n_views)
-        pts_all = comm.all_gather_rows(r1.points[0], P)
-        # merge the bands / slices so that every rank holds the full result
-        idx = frags.idx.clone(); comm.all_reduce_(idx, "max")           # -1 outside the own band
-        zb = frags.zbuf.clone(); comm.all_reduce_(zb, "max")
-        im = img.clone(); comm.all_reduce_(im, "sum")                    # 0 outside the own band
-        gxy = grad[:, :2].clone().contiguous(); comm.all_reduce_(gxy, "sum")   # 0 outside the own slices
-        torch.cuda.synchronize()
-        if rank == 0:
-            torch.save({"pts": pts_all.cpu(), "idx": idx.cpu(), "zbuf": zb.cpu(), "img": im.cpu(),
-                        "gxy": gxy.cpu(), "gz": grad[:, 2].cpu(), "knn": None}, os.path.join(outdir, "sharded.pt"))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("model_kind,n_views,world", [("sphere", 3, 2), ("siren", 3, 2), ("sphere", 2, 2),
-                                                      ("sphere", 2, 4)])
-def test_sharded_cycle_equals_single_gpu(dev, tmp_path, model_kind, n_views, world):
-    """3 views on 2 ranks: every rank queries a row range of every view; 2 views on 2 ranks: a view
-    belongs to one rank; 2 views on 4 ranks: to two ranks (what the 8-GPU x 4-view bench runs)."""
-    from iso_points_amd.dist import Comm
-    P, S = 30001, 80            # odd P: uneven shards; S not a multiple of 16*world
-    cyc, (r1, img, grad, frags, filt) = _run(model_kind, dev, Comm(enabled=False), P, S, n_views)
-    ref = {"pts": r1.points[0].cpu(), "idx": frags.idx.cpu(), "zbuf": frags.zbuf.cpu(), "img": img.cpu(),
-           "gxy": grad[:, :2].cpu(), "gz": grad[:, 2].cpu()}
-    ctx = mp.get_context("spawn")
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, model_kind, P, S, str(tmp_path), n_views))
-             for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(600)
-        assert p.exitcode == 0
-    got = torch.load(os.path.join(str(tmp_path), "sharded.pt"))
-    assert torch.equal(got["pts"], ref["pts"])          # projection + FRNN + repulsion: bit-identical
-    assert torch.equal(got["idx"], ref["idx"])          # per-pixel splat lists: bit-identical
-    assert torch.equal(got["zbuf"], ref["zbuf"])
-    assert torch.equal(got["img"], ref["img"])
-    assert torch.equal(got["gxy"], ref["gxy"])          # point-major xy gradient: bit-identical
-    # z gradient: pixel-major atomic scatter on the sharded path vs point-major sum on one GPU
-    scale = ref["gz"].abs().max().clamp_min(1e-30)
-    assert ((got["gz"] - ref["gz"]).abs().max() / scale) < 1e-5
-    assert ref["gz"].abs().sum() > 0 and ref["gxy"].abs().sum() > 0
-
-
-class _RankOf(object):
-    """stand-in for Comm: rank `rank` of `world`, no process group (only .world / .rank are read)"""
-
-    def __init__(self, world, rank):
-        self.world, self.rank = world, rank
-
-
-@pytest.mark.parametrize("world,n_views", [(4, 2), (8, 4), (4, 4), (3, 4), (6, 4), (2, 1)])
-def test_h_shares_sum_to_the_whole(dev, world, n_views):
-    """IsoCycle._h_share over all ranks (what the sum all-reduce adds up) == the all-rows result,
-    for view-owned (world a multiple of the views) and row-range (otherwise) splits."""
-    from iso_points_amd.dist import IsoCycle
-    from iso_points_amd.levelset_sampling import with_host_lengths
+def _models(dev, kind):
     from iso_points_amd.sdf_models import SphereSDF
-    pts, views, projs, rs, target = _setup(dev, 20011, 64, n_views)
-    cyc = IsoCycle(SphereSDF().to(dev), pts, views, projs, raster_settings=rs, target=target)
-    p_all = torch.nn.functional.normalize(pts[0], dim=-1)
-    flags, off, lens = cyc.splat.filter_renderable(p_all, p_all, cyc.views)
-    tot = sum(lens)
-    fl = [sum(lens[:i]) for i in range(n_views)]
-    num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
-    pts_f = cyc.splat.compact(p_all, flags, off, p_all.shape[0], tot)
-    cyc.comm = _RankOf(n_views + 1, 0) if n_views > 1 else _RankOf(3, 0)     # a row-range split ...
-    ref = torch.zeros(tot, device=dev)
-    for r in range(cyc.comm.world):                                          # ... summed = the whole
-        cyc.comm.rank = r
-        ref += cyc._h_share(pts_f, lens, fl, num, tot)
-    assert (ref > 0).all()
-    total = torch.zeros(tot, device=dev)
-    filled = torch.zeros(tot, device=dev)
-    for r in range(world):
-        cyc.comm = _RankOf(world, r)
-        h = cyc._h_share(pts_f, lens, fl, num, tot)
-        total += h
-        filled += (h != 0).float()
-    assert torch.equal(total, ref) and (filled == 1).all()                   # every row written by one rank
+    if kind == "sphere":
+        return SphereSDF().to(dev)
+    from oracle import iso_oracle as O
+    from util import fitted_siren
+    return fitted_siren(O, 128, 2, seed=0, fit=100).to(dev)
+
+
+@pytest.mark.parametrize("world,P,S,N,kind", [(2, 20000, 64, 2, "sphere"), (4, 60000, 128, 4, "sphere"),
+                                              (8, 200000, 256, 4, "sphere"), (3, 30000, 96, 3, "siren"),
+                                              (8, 9000, 64, 1, "sphere")])
+def test_lockstep_ranks_equal_single_gpu(dev, world, P, S, N, kind):
+    from iso_points_amd.dist import IsoCycle, run_lockstep, shard_bounds, slab_order
+    pts, views, projs, rs, target = _scene(dev, P, S, N)
+    model = _models(dev, kind)
+    pts = pts[:, slab_order(pts[0], world)].contiguous()
+    one = IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target)
+    r1, img, grad, frags, fr = one.step()
+    one.check(fr)
+    tot = int(fr["num_points"].sum().item())
+    ranks = [IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, world=world, rank=r)
+             for r in range(world)]
+    res = run_lockstep(ranks)
+    for r, (c, out) in enumerate(zip(ranks, res)):
+        u = c.check(out[4])
+        assert u["halo_exported"] > 0 and u["grid"]["overflow_bricks"] == 0
+    for r, (c, (q1, qimg, qgrad, qfrags, qfr)) in enumerate(zip(ranks, res)):
+        lo, hi = shard_bounds(P, world, r)
+        assert torch.equal(q1.points[0], r1.points[0, lo:hi]), "rank %d: resampled points differ" % r
+        assert torch.equal(q1.normals[0], r1.normals[0, lo:hi]) and torch.equal(q1.mask[0], r1.mask[0, lo:hi])
+        # the global packed layout every rank rebuilt = the single-GPU one
+        assert torch.equal(qfr["first_idx"], fr["first_idx"]) and torch.equal(qfr["num_points"], fr["num_points"])
+        for k in ("ndc", "ellipse_params", "radii", "scaler", "features"):
+            assert torch.equal(qfr[k][:tot], fr[k][:tot]), "rank %d: packed %s differs" % (r, k)
+        y0, y1 = c.band_rows()
+        if y1 > y0:
+            assert torch.equal(qfrags.idx[:, y0:y1], frags.idx[:, y0:y1]), "rank %d: index lists differ" % r
+            assert torch.equal(qfrags.zbuf[:, y0:y1], frags.zbuf[:, y0:y1])
+            assert torch.equal(qfrags.qvalue[:, y0:y1], frags.qvalue[:, y0:y1])
+            assert torch.equal(qfrags.occupancy[:, y0:y1], frags.occupancy[:, y0:y1])
+            assert torch.equal(qimg[:, y0:y1], img[:, y0:y1]), "rank %d: image band differs" % r
+        for v in range(N):
+            a, n = int(qfr["own_first"][v]), int(qfr["own_num"][v])
+            assert torch.equal(qgrad[a:a + n], grad[a:a + n]), "rank %d view %d: row gradients differ" % (r, v)
+    # the own rows of all ranks tile the packed layout
+    cover = torch.zeros(tot, dtype=torch.int32)
+    for (_, _, _, _, qfr) in res:
+        for v in range(N):
+            a, n = int(qfr["own_first"][v]), int(qfr["own_num"][v])
+            cover[a:a + n] += 1
+    assert (cover == 1).all()
+
+
+def test_calibrated_capacities(dev):
+    """calibrate() shrinks the exchange buffers; the cycle afterwards is unchanged and check() passes."""
+    from iso_points_amd.dist import IsoCycle, run_lockstep
+    from iso_points_amd.dist import slab_order
+    world, P = 4, 40000
+    pts, views, projs, rs, target = _scene(dev, P, 64, 2)
+    model = _models(dev, "sphere")
+    pts = pts[:, slab_order(pts[0], world)].contiguous()
+    ranks = [IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, world=world, rank=r)
+             for r in range(world)]
+    base = run_lockstep(ranks)
+    use = [c.check(o[4]) for c, o in zip(ranks, base)]
+    for c in ranks:      # what calibrate() does, without a process group
+        c.halo_cap = max(1024, int(1.5 * max(u["halo_exported"] for u in use)))
+        c.import_cap = max(1024, int(1.5 * max(u["halo_imported"] for u in use)))
+        c.rec_cap = max(1024, int(1.25 * max(u["own_rows"] for u in use)))
+        c._alloc()
+    again = run_lockstep(ranks)
+    for c, a, b in zip(ranks, base, again):
+        c.check(b[4])
+        assert torch.equal(a[0].points, b[0].points) and torch.equal(a[2], b[2]) and torch.equal(a[3].idx, b[3].idx)
+    # a capacity that is too small is reported, not silently dropped
+    for c in ranks:
+        c.halo_cap = 16
+        c._alloc()
+    out = run_lockstep(ranks)
+    with pytest.raises(RuntimeError):
+        for c, o in zip(ranks, out):
+            c.check(o[4])
+
+
+_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch.distributed as dist
+dist.init_process_group(backend="gloo")
+from test_dist_gpu import _scene, _models
+from iso_points_amd.dist import Comm, IsoCycle, slab_order
+dev = torch.device("cuda:0")
+world, rank = dist.get_world_size(), dist.get_rank()
+pts, views, projs, rs, target = _scene(dev, 30000, 96, 2)
+model = _models(dev, "sphere")
+pts = pts[:, slab_order(pts[0], world)].contiguous()
+c = IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, comm=Comm())
+c.calibrate()
+r1, img, grad, frags, fr = c.step()
+c.check(fr)
+one = IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target)
+s1, simg, sgrad, sfrags, sfr = one.step()
+y0, y1 = c.band_rows()
+ok = torch.equal(r1.points[0], s1.points[0, c.lo:c.hi]) and torch.equal(frags.idx[:, y0:y1], sfrags.idx[:, y0:y1]) \
+    and torch.equal(img[:, y0:y1], simg[:, y0:y1])
+for v in range(2):
+    a, n = int(fr["own_first"][v]), int(fr["own_num"][v])
+    ok = ok and torch.equal(grad[a:a + n], sgrad[a:a + n])
+print("RANK", rank, "OK" if ok else "MISMATCH", c.comm.bytes_log)
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+"""
+
+
+def test_two_processes_over_gloo(dev, tmp_path):
+    """The same cycle under a real process group (2 processes sharing the test GPU, gloo)."""
+    w = tmp_path / "worker.py"
+    w.write_text(_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531", str(w), ROOT],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("OK") == 2

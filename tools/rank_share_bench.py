@@ -1,112 +1,113 @@
-"""What ONE rank of an N-GPU run of the bench cycle computes, timed on one GPU: the collectives
-are replaced by copies from a cached single-GPU run (all_gather_rows) or skipped (all_reduce), so
-the figure is rank 0's compute + launch time per step without any wire time -- the ceiling of the
-strong-scaling curve the driver measures, and a per-stage view of what does not shrink with N.
-usage: python tools/rank_share_bench.py [--model sphere|siren]"""
-import argparse, json, os, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import bench
-from iso_points_amd.dist import Comm, shard_bounds
+"""What ONE rank of an N-GPU run of the bench cycle computes, measured on one GPU: the N ranks run in
+lock-step inside this process (iso_points_amd.dist.run_lockstep: the same generator code a process group
+drives; exchanges are device copies), HIP events bracket every compute segment of every rank, and the
+slowest rank's sum is the per-step compute time of the job = the ceiling of the strong-scaling curve
+before any wire time.  Also logs the bytes every rank contributes to each collective.
+
+usage: python tools/rank_share_bench.py [sphere|siren] [P] [steps]"""
+import contextlib
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B
+from iso_points_amd.dist import IsoCycle, run_lockstep, slab_order, sphere_silhouette
+from iso_points_amd.rasterizer import PointsRasterizationSettings
 from iso_points_amd.sdf_models import SphereSDF
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--model", default="siren")
-ap.add_argument("--steps", type=int, default=10)
-ap.add_argument("--world", type=int, default=0, help="only this N (for kernel traces); default 1,2,4,8")
-args = ap.parse_args()
-dev = torch.device("cuda:0")
 
+class Timer(object):
+    def __init__(self, world):
+        self.ev = [[] for _ in range(world)]
 
-class ShareOfN(Comm):
-    """rank 0 of `world`; gathers are filled from the tensors a single-GPU run produced."""
+    @contextlib.contextmanager
+    def __call__(self, r):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        yield
+        b.record()
+        self.ev[r].append((a, b))
 
-    def __init__(self, world, full):
-        super().__init__(enabled=False)
-        self.world, self.rank, self.full, self.k = world, 0, full, 0
-
-    def all_gather_rows(self, x_local, n_total):
-        if self.world == 1:
-            return x_local
-        ref = self.full[self.k % len(self.full)]
-        self.k += 1
-        out = ref.clone()
-        lo, hi = shard_bounds(n_total, self.world, 0)
-        out[lo:hi] = x_local
-        return out
-
-    def all_reduce_(self, x, op="sum"):
-        return x
-
-
-if args.model == "siren":
-    model = bench.fitted_siren(dev)             # the bench's own network
-else:
-    model = SphereSDF().to(dev)
-
-
-def stage_times(cyc, comm, steps):
-    """per-stage HIP-event times of IsoCycle.step: the four stage methods wrapped with events."""
-    c = cyc.cyc
-    names = ["project_resample", "splat_forward", "composite_band", "backward"]
-    log = []
-
-    def wrap(name):
-        fn = getattr(c, name)
-
-        def timed(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn(*a, **k)
-            e1.record()
-            log.append((name, e0, e1))
-            return r
-        setattr(c, name, timed)
-        return fn
-    saved = {n: wrap(n) for n in names}
-    tot = 0.0
-    for _ in range(steps):
-        comm.k = 0
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); c.step(); e1.record()
+    def per_rank_ms(self):
         torch.cuda.synchronize()
-        tot += e0.elapsed_time(e1) / steps
-    for n, fn in saved.items():
-        setattr(c, n, fn)
-    acc = dict.fromkeys(names, 0.0)
-    for n, a, b_ in log:
-        acc[n] += a.elapsed_time(b_) / steps
-    acc["glue (gathers, features, loss gradient)"] = tot - sum(acc.values())
-    return acc
+        return [sum(a.elapsed_time(b) for a, b in evs) for evs in self.ev]
 
 
-# the single-GPU run whose intermediate clouds stand in for the other ranks' rows
-one = bench.Cycle(dev, model, Comm(enabled=False))
-r0 = one.cyc._project(one.cyc.pts0_local, 10)
-r1 = one.cyc.project_resample()
-full = [r0.points[0].clone(), r0.normals[0].clone(), r1.points[0].clone(), r1.normals[0].clone()]
-res = {}
-for world in ((args.world,) if args.world else (1, 2, 4, 8)):
-    comm = ShareOfN(world, full)
-    cyc = bench.Cycle(dev, model, comm)
-    for _ in range(2):
-        comm.k = 0; cyc.step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        comm.k = 0; cyc.step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / args.steps * 1e3
-    comm.k = 0
-    try:
-        st = stage_times(cyc, comm, 5)
-    except Exception as e:                      # the stage split follows IsoCycle.step; keep the total if it drifts
-        st = {"error": repr(e)}
-    res[world] = {"ms_per_step_rank0": ms, "ceiling_speedup": None, "stages_ms": st}
-    print(world, "ms/step %.3f" % ms, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}, flush=True)
-if 1 in res:
-    for w in res:
-        res[w]["ceiling_speedup"] = res[1]["ms_per_step_rank0"] / res[w]["ms_per_step_rank0"]
-    print({w: round(res[w]["ceiling_speedup"], 2) for w in res})
-os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "rank_share_%s.json" % args.model), "w"), indent=1)
+class LogComm(object):
+    """records the requests one rank yields (bytes per collective)"""
+    def __init__(self):
+        self.log = []
+
+
+def main():
+    kind = sys.argv[1] if len(sys.argv) > 1 else "sphere"
+    P = int(sys.argv[2]) if len(sys.argv) > 2 else B.P_TOTAL
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    dev = torch.device("cuda:0")
+    model = SphereSDF().to(dev) if kind == "sphere" else B.fitted_siren(dev)
+    views, projs = B.cameras(dev)
+    rs = PointsRasterizationSettings(image_size=B.IMAGE, points_per_pixel=B.KPIX, cutoff_threshold=1.0,
+                                     depth_merging_threshold=0.05, radii_backward_scaler=10, backface_culling=True,
+                                     Vrk_isotropic=True, bin_size=None)
+    target = sphere_silhouette(B.IMAGE, B.VIEWS, 3.0, 30.0, dev)
+    base = B.sphere_cloud(P, seed=0, device=dev)
+    out = {"sdf": kind, "points": P, "steps": steps, "worlds": {}}
+    t1 = None
+    for world in (1, 2, 4, 8):
+        pts = base[:, slab_order(base[0], world)].contiguous()
+        ranks = [IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, world=world, rank=r)
+                 for r in range(world)]
+        res = run_lockstep(ranks)
+        use = [c.check(o[4]) for c, o in zip(ranks, res)]
+        if world > 1:           # = IsoCycle.calibrate() without a process group
+            for c in ranks:
+                c.halo_cap = max(1024, int(1.5 * max(u["halo_exported"] for u in use)))
+                c.import_cap = max(1024, int(1.5 * max(u["halo_imported"] for u in use)))
+                c.rec_cap = max(1024, int(1.25 * max(u["own_rows"] for u in use)))
+                c._alloc()
+        del res
+        for _ in range(2):
+            run_lockstep(ranks)
+        tm = Timer(world)
+        for _ in range(steps):
+            res = run_lockstep(ranks, timer=tm)
+        ms = [t / steps for t in tm.per_rank_ms()]
+        use = [c.check(o[4]) for c, o in zip(ranks, res)]
+        # bytes each rank contributes per collective: replay rank 0's generator requests
+        log = []
+        if world > 1:
+            gens = [c.cycle() for c in ranks]
+            reqs = [next(g) for g in gens]
+            while True:
+                log.append((reqs[0][0] + ("" if reqs[0][0] == "all_gather" else ":" + reqs[0][2]),
+                            reqs[0][1].numel() * reqs[0][1].element_size()))
+                if reqs[0][0] == "all_gather":
+                    send = [torch.stack([q[1] for q in reqs])] * world
+                else:
+                    st = torch.stack([q[1] for q in reqs])
+                    red = st.sum(0) if reqs[0][2] == "sum" else st.max(0).values
+                    send = [red] * world
+                try:
+                    reqs = [g.send(s) for g, s in zip(gens, send)]
+                except StopIteration:
+                    break
+        if world == 1:
+            t1 = max(ms)
+        out["worlds"][str(world)] = {
+            "per_rank_ms": [round(x, 3) for x in ms], "slowest_rank_ms": round(max(ms), 3),
+            "compute_ceiling_x": round(t1 / max(ms), 2),
+            "collectives_bytes_per_rank": log, "bytes_per_rank_total": sum(b for _, b in log),
+            "halo_exported_max": max((u.get("halo_exported", 0) for u in use), default=0),
+            "halo_imported_max": max((u.get("halo_imported", 0) for u in use), default=0),
+            "own_rows_max": max(u["own_rows"] for u in use)}
+        print(world, out["worlds"][str(world)]["slowest_rank_ms"], out["worlds"][str(world)]["compute_ceiling_x"], file=sys.stderr)
+        del ranks, res
+        torch.cuda.empty_cache()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
