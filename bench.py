@@ -93,19 +93,28 @@ class Cycle(object):
                             target=sphere_silhouette(IMAGE, VIEWS, 3.0, 30.0, device))
         if comm.world > 1:
             self.cyc.calibrate()                                     # untimed: sizes of the exchange buffers
-        self.cyc.project_hook = self._timed_project
+        self.cyc.marks = True
+        self.cyc.use_graphs = os.environ.get("ISO_BENCH_GRAPHS", "1") != "0"
+        comm.on_mark = self._on_mark
         self.ev = []
         self.timed = False
+        self._open = None
+        self._count_hook = None
 
-    def _timed_project(self, fn, T):
+    def _on_mark(self, name, T):
+        """HIP events on the launch stream around the two Newton projections of a cycle."""
+        if self._count_hook is not None:
+            if name == "project_end":
+                self._count_hook(T)
+            return
         if not self.timed:
-            return fn()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        r = fn()
-        b.record()
-        self.ev.append((a, b, T))
-        return r
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        if name == "project_begin":
+            self._open = e
+        else:
+            self.ev.append((self._open, e, T))
 
     def step(self):
         return self.cyc.step()
@@ -118,7 +127,7 @@ class Cycle(object):
 
     def active_counts(self):
         """Point-evaluations of one cycle on this rank, from the kernel's own device-side
-        active-list counters (one extra untimed pass of the two projections)."""
+        active-list counters (one extra untimed, eager pass of the two projections)."""
         from iso_points_amd import _lib
         lib = _lib.load()
         cyc = self.cyc
@@ -126,15 +135,13 @@ class Cycle(object):
         off = lib.iso_project_siren_workspace_bytes(n, HIDDEN, LAYERS) - 64 * 4 - 64
         counts = []
 
-        def hook(fn, T):
-            r = fn()
+        def hook(T):
             torch.cuda.synchronize()
             c = cyc.proj._packed_cache._ws[off:off + 64 * 4].view(torch.int32).tolist()
             counts.append([n] + c[1:T + 1])
-            return r
-        cyc.project_hook = hook
+        self._count_hook = hook
         cyc.run(cyc.project_resample())
-        cyc.project_hook = self._timed_project
+        self._count_hook = None
         return counts
 
 

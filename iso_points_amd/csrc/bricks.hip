@@ -1017,7 +1017,7 @@ extern "C" int iso_halo_export(void* workspace, const float* points, const float
                   capacity < (1ll << 30) && (points || n_own == 0),
               ISO_ERR_INVALID, "iso_halo_export: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(export_buf, 0, 16, s);
+  iso_zero_words(export_buf, 4, s);
   if (n_own > 0)
     hipLaunchKernelGGL(k_halo_export, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, normals, payload, n_own,
                        (const BrickHdr*)workspace, rank_boxes, world, rank, (float4*)export_buf, (int)capacity);
@@ -1033,7 +1033,7 @@ extern "C" int iso_halo_import(void* workspace, int64_t n_max, const float* gath
               ISO_ERR_INVALID, "iso_halo_import: bad arguments");
   const BrickWs w = bricks_carve(workspace, n_max);
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(import_count, 0, 4, s);
+  iso_zero_words(import_count, 1, s);
   if (capacity > 0 && world > 1)
     hipLaunchKernelGGL(k_halo_import, dim3(iso_stream_grid(capacity, 256) > 64 ? 64 : iso_stream_grid(capacity, 256), world),
                        dim3(256), 0, s, (const float4*)gathered, world, rank, (int)capacity, w.hdr, rank_boxes,
@@ -1076,7 +1076,7 @@ extern "C" int iso_splat_view_mask(const float* points, const float* normals, co
   ISO_REQUIRE(views && mask_out && view_count_out && (points || n == 0) && (normals || !backface_culling),
               ISO_ERR_INVALID, "iso_splat_view_mask: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(view_count_out, 0, 8 * sizeof(int32_t), s);
+  iso_zero_words(view_count_out, 8, s);
   if (n > 0)
     hipLaunchKernelGGL(k_view_mask, dim3(iso_stream_grid(n, 256 * 4)), dim3(256), 0, s, points, normals, views, n_views,
                        n, znear, zfar, backface_culling, mask_out, view_count_out);

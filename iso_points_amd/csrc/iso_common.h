@@ -53,3 +53,15 @@ __device__ __forceinline__ float iso_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+
+// Zero a few words with a kernel instead of hipMemsetAsync: memset nodes of a few bytes captured into a
+// HIP graph were observed to leave garbage on replay (ROCm 7.2), a kernel node is exact.
+static __global__ void iso_k_zero_words(uint32_t* p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline void iso_zero_words(void* p, int64_t n_words, hipStream_t s) {
+  int64_t g = (n_words + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(iso_k_zero_words, dim3((int)g), dim3(256), 0, s, (uint32_t*)p, n_words);
+}

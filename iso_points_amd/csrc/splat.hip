@@ -1275,7 +1275,7 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
                      dim3(256), 0, s, blk, NB, NB2, n_clouds, blk2);
   int32_t* heavy_count = (int32_t*)((uint8_t*)workspace + bwd_maps_bytes(n_clouds, image_size));
   int32_t* heavy = heavy_count + 16;
-  (void)hipMemsetAsync(heavy_count, 0, 64, s);
+  iso_zero_words(heavy_count, 16, s);
   int gx = iso_div_up(max_pts, 256); if (gx > 8192) gx = 8192;
   // xy part point-major (z written as 0), then the z part pixel-major in fixed point
   hipLaunchKernelGGL(k_splat_backward, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, visible,
@@ -1285,7 +1285,7 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
     ZScale* zs = reinterpret_cast<ZScale*>((char*)(heavy_count) + 64 + (4 * total_points + 15) / 16 * 16);
     long long* zacc = reinterpret_cast<long long*>((char*)zs + 16);
     const int64_t npix = (int64_t)n_clouds * image_size * image_size;
-    (void)hipMemsetAsync(zs, 0, 16 + 8 * (size_t)total_points, s);
+    iso_zero_words(zs, 4 + 2 * total_points, s);
     int gm = iso_div_up(npix * points_per_pixel, 256 * 16); if (gm > 1024) gm = 1024; if (gm < 1) gm = 1;
     hipLaunchKernelGGL(k_z_absmax, dim3(gm), dim3(256), 0, s, grad_zbuf, npix * points_per_pixel, zs);
     int terms_log2 = 0;
@@ -1309,7 +1309,7 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
 extern "C" int iso_splat_z_absmax(const float* grad_zbuf, int64_t n, int32_t* zscale, void* stream) {
   ISO_REQUIRE(zscale && n >= 0 && (grad_zbuf || n == 0), ISO_ERR_INVALID, "iso_splat_z_absmax: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(zscale, 0, 8, s);
+  iso_zero_words(zscale, 2, s);
   if (n > 0) {
     int gm = iso_div_up(n, 256 * 16); if (gm > 1024) gm = 1024; if (gm < 1) gm = 1;
     hipLaunchKernelGGL(k_z_absmax, dim3(gm), dim3(256), 0, s, grad_zbuf, n, reinterpret_cast<ZScale*>(zscale));

@@ -76,11 +76,19 @@ class Comm(object):
         self.rank = dist.get_rank(group) if self.on else 0
         self.bytes_log = []          # (kind, bytes contributed by this rank) of the last cycle
 
+        self.on_mark = None          # callback(name, arg) for the ("mark", name, arg) requests (bench timing)
+
     def execute(self, req):
+        """One request of the cycle generator: ("all_gather", x[, out]) -> (world, *x.shape) tensor,
+        ("all_reduce", x, "sum"|"max") -> x reduced in place, ("mark", name, arg) -> None."""
         kind, x = req[0], req[1]
+        if kind == "mark":
+            if self.on_mark is not None:
+                self.on_mark(x, req[2])
+            return None
         self.bytes_log.append((kind, x.numel() * x.element_size()))
         if kind == "all_gather":
-            out = x.new_empty((self.world,) + tuple(x.shape))
+            out = req[2] if len(req) > 2 and req[2] is not None else x.new_empty((self.world,) + tuple(x.shape))
             self.dist.all_gather_into_tensor(out.view(-1), x.contiguous().view(-1), group=self.group)
             return out
         ops = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX}
@@ -99,6 +107,13 @@ class Comm(object):
 class _Single(object):
     world, rank = 1, 0
     bytes_log = []
+    on_mark = None
+
+    def execute(self, req):
+        assert req[0] == "mark", "a single rank has nothing to exchange"
+        if self.on_mark is not None:
+            self.on_mark(req[1], req[2])
+        return None
 
     def max_int(self, v, device):
         return int(v)
@@ -130,7 +145,10 @@ class IsoCycle(object):
         self.views, self.projs = _f32c(views), _f32c(projs)
         self.N = self.views.shape[0]
         self.target = target
-        self.project_hook = None      # bench.py installs timing events here
+        self.marks = False            # yield ("mark", ...) requests around the projections (bench.py timing)
+        self.use_graphs = False       # replay the segments between two exchanges as HIP graphs
+        self._segs = None
+        self._pool = None
         # capacities (rows / records); `calibrate` shrinks them to what the workload needs
         w = self.world
         self.halo_cap = 0 if w == 1 else max(4096, self.n_own)            # worst case: every own point is exported
@@ -142,6 +160,7 @@ class IsoCycle(object):
 
     def _alloc(self):
         dev, w = self.dev, self.world
+        self._segs = None             # captured graphs hold the old buffers
         self.grid = bricks.BrickGrid(self.n_own, dev, import_max=self.import_cap)
         if w > 1:
             self.exp_buf = torch.zeros((2 * (self.halo_cap + 1) * 4,), dtype=torch.float32, device=dev)
@@ -152,10 +171,14 @@ class IsoCycle(object):
 
     # -- stage 1/2: projection + resample -------------------------------------------------
     def _project(self, pts_local, T):
-        fn = lambda: self.proj._project_points(self.model, pts_local, self.num_local, proj_max_iters=T)
-        if self.project_hook is not None:
-            return self.project_hook(fn, T)
-        return fn()
+        """Newton projection of the own points, bracketed by marks (bench.py times the SDF kernel
+        between them; in graph mode they are segment boundaries)."""
+        if self.marks:
+            yield ("mark", "project_begin", T)
+        r = self.proj._project_points(self.model, pts_local, self.num_local, proj_max_iters=T)
+        if self.marks:
+            yield ("mark", "project_end", T)
+        return r
 
     def _halo_build(self, pts, nrm, payload, box, boxes, radius, knn_k, cell_scale):
         """N ranks: common grid from the reduced box, halo export -> all-gather -> import, build."""
@@ -185,9 +208,10 @@ class IsoCycle(object):
 
     def project_resample(self):
         """Generator: stages 1 and 2 -> ProjectionResult of the own points."""
-        r0 = self._project(self.pts0_local, 10)
+        r0 = yield from self._project(self.pts0_local, 10)
         moved = yield from self._resample(r0.points[0].contiguous(), r0.normals[0].contiguous())
-        return self._project(moved.view(1, -1, 3), 3)
+        r1 = yield from self._project(moved.view(1, -1, 3), 3)
+        return r1
 
     # -- stage 3: splat front end + forward ------------------------------------------------------
     def _front(self, pts, nrm):
@@ -312,8 +336,14 @@ class IsoCycle(object):
         image with the own band filled, gradient of the packed rows, fragments, front-end dict)."""
         r1 = yield from self.project_resample()
         fr = yield from self._front(r1.points[0].contiguous(), r1.normals[0].contiguous())
+        if self.marks:
+            yield ("mark", "front_end", 0)
         frags = self.splat_forward(fr)
+        if self.marks:
+            yield ("mark", "raster_end", 0)
         img = self.composite_band(frags, fr)
+        if self.marks:
+            yield ("mark", "composite_end", 0)
         # loss of SURVEY 8(d) cfg 3: mean((alpha - target)^2) [+ 1e-2 mean(rgb^2): no grad to the op]
         alpha = img[..., 3]
         y0, y1 = self.band_rows()
@@ -339,9 +369,59 @@ class IsoCycle(object):
         except StopIteration as e:
             return e.value
 
+    def generator(self):
+        return self.graph_cycle() if self.use_graphs else self.cycle()
+
     def step(self):
         self.comm.bytes_log = []
-        return self.run(self.cycle())
+        if self.use_graphs and self._segs is None:
+            self.run(self.cycle())            # eager warm-up (lazy kernel attributes, allocator)
+            self.run(self.graph_cycle())      # capture: nothing executes yet
+        return self.run(self.generator())
+
+    def graph_cycle(self):
+        """The cycle with every segment between two requests captured once as a HIP graph and replayed
+        afterwards: one graph launch instead of tens of kernel launches and allocator calls per
+        segment (the per-step host time is what bounds a rank once its share of the work is small).
+        Same request protocol as `cycle`; the first pass only captures -- its results are undefined."""
+        if self._segs is None:
+            segs = []
+            self._pool = torch.cuda.graph_pool_handle()
+            cap_stream = torch.cuda.Stream(device=self.dev)
+            g = self.cycle()
+            incoming, first, final = None, True, None
+            while True:
+                graph = torch.cuda.CUDAGraph()
+                done = False
+                req = None
+                try:
+                    with torch.cuda.graph(graph, pool=self._pool, stream=cap_stream):
+                        req = next(g) if first else g.send(incoming)
+                except StopIteration as e:
+                    final, done = e.value, True
+                first = False
+                if done:
+                    segs.append((graph, None, None))
+                    break
+                incoming = yield req
+                segs.append((graph, req, incoming))
+            self._segs, self._final = segs, final
+            return final
+        import os
+        dbg = os.environ.get("ISO_GRAPH_DEBUG")
+        for k, (graph, req, static) in enumerate(self._segs):
+            graph.replay()
+            if dbg:
+                torch.cuda.synchronize()
+                print("rank %d segment %d (%s) replayed" % (self.rank, k, req[0] if req else "end"), flush=True)
+            if req is None:
+                return self._final
+            if req[0] == "all_gather":
+                got = yield (req[0], req[1], static)
+                if got is not static:
+                    static.copy_(got)
+            else:
+                yield req
 
     # -- capacities ------------------------------------------------------------------------------------
     def usage(self, fr=None):
@@ -389,7 +469,7 @@ def run_lockstep(cycles, timer=None):
     `timer(rank)` (optional) is a context manager entered around every compute segment of a rank --
     tools/rank_share_bench.py sums the device time per rank with it."""
     import contextlib
-    gens = [c.cycle() for c in cycles]
+    gens = [c.generator() if hasattr(c, "generator") else c.cycle() for c in cycles]
     tm = timer or (lambda r: contextlib.nullcontext())
     reqs, results = [None] * len(gens), [None] * len(gens)
     live = list(range(len(gens)))
@@ -409,9 +489,17 @@ def run_lockstep(cycles, timer=None):
         assert len(live) == len(gens), "ranks left the cycle at different exchanges"
         kind = reqs[0][0]
         assert all(q[0] == kind for q in reqs)
-        if kind == "all_gather":
+        if kind == "mark":
+            send = [None for _ in gens]
+        elif kind == "all_gather":
             g = torch.stack([q[1] for q in reqs])
-            send = [g for _ in gens]
+            send = []
+            for q in reqs:
+                if len(q) > 2 and q[2] is not None:
+                    q[2].copy_(g)
+                    send.append(q[2])
+                else:
+                    send.append(g.clone() if len(reqs) > 1 and getattr(cycles[0], "use_graphs", False) else g)
         else:
             st = torch.stack([q[1] for q in reqs])
             red = st.sum(dim=0) if reqs[0][2] == "sum" else st.max(dim=0).values

@@ -136,7 +136,8 @@ class UniformProjection(LevelSetProjection):
         self.sample_iters = sample_iters
         self.resampling_clip = resampling_clip  # stored, unused -- as in the reference (:108)
         self._packed_cache = None
-        self.materialize_knn = False   # resample(): also write the neighbour lists the fused kernel selects
+        self.materialize_knn = True    # resample(): also write the neighbour lists the fused kernel selects
+                                       # (_knn_idx / _knn_dists, as the reference's _create_tree leaves them)
 
     # -- tree ------------------------------------------------------------------------
     def _create_tree(self, points_padded, refresh_tree=True, num_points_per_cloud=None):

@@ -83,6 +83,33 @@ def test_lockstep_ranks_equal_single_gpu(dev, world, P, S, N, kind):
     assert (cover == 1).all()
 
 
+@pytest.mark.parametrize("world", [1, 4])
+def test_graph_replay_equals_eager(dev, world):
+    """use_graphs: the segments between two exchanges replayed as HIP graphs give the eager results,
+    step after step (nothing in the cycle depends on a host read)."""
+    from iso_points_amd.dist import IsoCycle, run_lockstep, slab_order
+    P, S, N = 50000, 128, 2
+    pts, views, projs, rs, target = _scene(dev, P, S, N)
+    model = _models(dev, "sphere")
+    pts = pts[:, slab_order(pts[0], world)].contiguous()
+    mk = lambda: [IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, world=world, rank=r)
+                  for r in range(world)]
+    eager = run_lockstep(mk())
+    ranks = mk()
+    for c in ranks:
+        c.use_graphs = True
+        c.marks = True
+    run_lockstep([type("E", (), {"generator": c.cycle, "use_graphs": False})() for c in ranks])   # eager warm-up
+    run_lockstep(ranks)                                                                        # capture
+    for _ in range(3):
+        got = run_lockstep(ranks)                                                              # replays
+        for a, b in zip(eager, got):
+            assert torch.equal(a[0].points, b[0].points) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+            assert torch.equal(a[3].idx, b[3].idx) and torch.equal(a[3].zbuf, b[3].zbuf)
+    for c, o in zip(ranks, got):
+        c.check(o[4])
+
+
 def test_calibrated_capacities(dev):
     """calibrate() shrinks the exchange buffers; the cycle afterwards is unchanged and check() passes."""
     from iso_points_amd.dist import IsoCycle, run_lockstep

@@ -27,9 +27,11 @@ class Timer(object):
     def __call__(self, r):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        yield
-        b.record()
-        self.ev[r].append((a, b))
+        try:
+            yield
+        finally:
+            b.record()
+            self.ev[r].append((a, b))
 
     def per_rank_ms(self):
         torch.cuda.synchronize()
@@ -46,6 +48,7 @@ def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "sphere"
     P = int(sys.argv[2]) if len(sys.argv) > 2 else B.P_TOTAL
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    graphs = len(sys.argv) > 4 and sys.argv[4] == "graphs"
     dev = torch.device("cuda:0")
     model = SphereSDF().to(dev) if kind == "sphere" else B.fitted_siren(dev)
     views, projs = B.cameras(dev)
@@ -54,9 +57,9 @@ def main():
                                      Vrk_isotropic=True, bin_size=None)
     target = sphere_silhouette(B.IMAGE, B.VIEWS, 3.0, 30.0, dev)
     base = B.sphere_cloud(P, seed=0, device=dev)
-    out = {"sdf": kind, "points": P, "steps": steps, "worlds": {}}
+    out = {"sdf": kind, "points": P, "steps": steps, "graphs": graphs, "worlds": {}}
     t1 = None
-    for world in (1, 2, 4, 8):
+    for world in [int(w) for w in os.environ.get("ISO_WORLDS", "1,2,4,8").split(",")]:
         pts = base[:, slab_order(base[0], world)].contiguous()
         ranks = [IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, world=world, rank=r)
                  for r in range(world)]
@@ -69,7 +72,11 @@ def main():
                 c.rec_cap = max(1024, int(1.25 * max(u["own_rows"] for u in use)))
                 c._alloc()
         del res
-        for _ in range(2):
+        run_lockstep(ranks)
+        if graphs:
+            for c in ranks:
+                c.use_graphs = True
+        for _ in range(3):
             run_lockstep(ranks)
         tm = Timer(world)
         for _ in range(steps):
@@ -79,6 +86,8 @@ def main():
         # bytes each rank contributes per collective: replay rank 0's generator requests
         log = []
         if world > 1:
+            for c in ranks:
+                c.use_graphs = False
             gens = [c.cycle() for c in ranks]
             reqs = [next(g) for g in gens]
             while True:
@@ -94,15 +103,16 @@ def main():
                     reqs = [g.send(s) for g, s in zip(gens, send)]
                 except StopIteration:
                     break
-        if world == 1:
-            t1 = max(ms)
+        if t1 is None:
+            t1 = max(ms) * world if world > 1 else max(ms)
         out["worlds"][str(world)] = {
             "per_rank_ms": [round(x, 3) for x in ms], "slowest_rank_ms": round(max(ms), 3),
             "compute_ceiling_x": round(t1 / max(ms), 2),
             "collectives_bytes_per_rank": log, "bytes_per_rank_total": sum(b for _, b in log),
             "halo_exported_max": max((u.get("halo_exported", 0) for u in use), default=0),
             "halo_imported_max": max((u.get("halo_imported", 0) for u in use), default=0),
-            "own_rows_max": max(u["own_rows"] for u in use)}
+            "own_rows_max": max(u["own_rows"] for u in use),
+            "grid_per_rank": [{k: u["grid"][k] for k in ("occupied", "tail", "overflow_bricks", "tail_h", "n")} for u in use]}
         print(world, out["worlds"][str(world)]["slowest_rank_ms"], out["worlds"][str(world)]["compute_ceiling_x"], file=sys.stderr)
         del ranks, res
         torch.cuda.empty_cache()
