@@ -395,6 +395,9 @@ int iso_splat_setup(const float* points, const float* normals, const float* h,
  * Outputs as the reference: idx i32, zbuf/qvalue f32 (N,S,S,K), occ f32 (N,S,S),
  * image flipped in both axes (+X left, +Y up).  *overflow_flag != 0 afterwards
  * means pair_capacity was too small (result incomplete).
+ * workspace (optional, NULL = none): iso_splat_forward_workspace_bytes(tiles of the band, K); with it
+ * the tiles that hold many times the mean number of candidates (silhouettes) are rasterised in slices
+ * by several workgroups and merged -- same result, the longest work item is a slice.
  * [tile_row_begin, tile_row_end) restricts both calls to a band of tile rows (in NDC pixel
  * order, i.e. before the flip): a rank of a sharded run rasterises only its band and leaves
  * the other pixels of the output tensors untouched; pass 0, T for the whole image.          */
@@ -409,7 +412,8 @@ int iso_splat_forward(const float* points, const float* ellipse, const float* cu
                       int32_t* tile_cursor, const int32_t* tile_off,
                       int32_t* pairs, int64_t pair_capacity, int32_t* overflow_flag,
                       int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out,
-                      void* stream);
+                      void* workspace, int64_t workspace_bytes, void* stream);
+int64_t iso_splat_forward_workspace_bytes(int64_t n_tiles, int points_per_pixel);
 
 /* renderer.py:53-78: w = exp(-0.5 q) * scaler[idx] (0 where idx < 0);
  * image[..., c] = sum_k w f / max(sum_k w, eps) (norm_weighted) or sum_k w f;

@@ -486,7 +486,8 @@ template <int KMAX>
 __global__ __launch_bounds__(256) void k_raster(
     const float* __restrict__ pts, const float* __restrict__ ellipse,
     const float* __restrict__ cutoff, const float* __restrict__ radii,
-    const int32_t* __restrict__ tile_order, const int32_t* __restrict__ tile_off,
+    const int32_t* __restrict__ tile_order, const int4* __restrict__ items, const int32_t* __restrict__ item_count,
+    float* __restrict__ scratch, const int32_t* __restrict__ tile_off,
     const int32_t* __restrict__ pairs, int64_t capacity, int S, int T,
     int K, float depth_thres, int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out,
     float* __restrict__ occ_out) {
@@ -499,7 +500,17 @@ __global__ __launch_bounds__(256) void k_raster(
   __shared__ int s_cntw[4][4];       // [source wave][target wave]
   // workgroups take the tiles of the band heaviest first (k_tile_order): a tile on the sphere's
   // silhouette holds 8x the mean number of candidates and would otherwise finish long after the rest
-  const int tile = tile_order[blockIdx.x];
+  // a work item = a tile, or -- for the tiles that hold many times the mean number of candidates (a
+  // silhouette) -- one slice of its candidate list; the K-best lists of the slices are merged afterwards
+  // (k_raster_merge), so the longest item is a slice, not the heaviest tile
+  int tile, slice = 0, nslices = 1, slot = 0;
+  if (items) {
+    if ((int)blockIdx.x >= *item_count) return;
+    const int4 it = items[blockIdx.x];
+    tile = it.x; slice = it.y; nslices = it.z; slot = it.w;
+  } else {
+    tile = tile_order[blockIdx.x];
+  }
   const int tx = tile % T, ty = (tile / T) % T, n = tile / (T * T);
   const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
   const int xi = tx * TILE + lx, yi = ty * TILE + ly;  // NDC pixel index
@@ -521,7 +532,13 @@ __global__ __launch_bounds__(256) void k_raster(
   const int64_t off = tile_off[tile];
   int cnt = tile_off[tile + 1] - tile_off[tile];
   if (off + cnt > capacity) cnt = off < capacity ? (int)(capacity - off) : 0;  // overflow guard
-  for (int c0 = 0; c0 < cnt; c0 += 256) {
+  int c_begin = 0;
+  if (nslices > 1) {                       // slice s of ns: chunk-aligned share of the list
+    const int chunks = (cnt + 255) / 256;
+    c_begin = (int)((int64_t)chunks * slice / nslices) * 256;
+    cnt = min(cnt, (int)((int64_t)chunks * (slice + 1) / nslices) * 256);
+  }
+  for (int c0 = c_begin; c0 < cnt; c0 += 256) {
     const int m = min(256, cnt - c0);
     __syncthreads();
     bool hit_band[4] = {false, false, false, false};
@@ -578,6 +595,16 @@ __global__ __launch_bounds__(256) void k_raster(
       }
     }
   }
+  if (nslices > 1) {                       // partial result: the raw K-best of this slice, [z | q | id][k][pixel]
+    float* sc = scratch + (int64_t)slot * 3 * KMAX * 256;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      sc[j * 256 + threadIdx.x] = best.z[j];
+      sc[(KMAX + j) * 256 + threadIdx.x] = best.q[j];
+      sc[(2 * KMAX + j) * 256 + threadIdx.x] = __int_as_float(best.id[j]);
+    }
+    return;
+  }
   if (!inside) return;
   // output pixel is flipped in both axes (+X left, +Y up; rasterize_points.cu:577-580)
   const int yo = S - 1 - yi, xo = S - 1 - xi;
@@ -619,6 +646,113 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
   for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
     const int tile = tile_of(i);
     order[atomicAdd(&base[bucket_of(tile)], 1)] = tile;
+  }
+}
+
+// Work items of a band (see k_raster): tiles with more than kSplitMin candidates are cut into slices of
+// about kSlice candidates as long as the scratch slots last; slices first, then the whole tiles heaviest
+// first.  heavy[h] = (tile, first scratch slot, slices).  counters: [0] items, [1] heavy tiles.
+constexpr int kSplitMin = 1536, kSlice = 1024;
+__global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__ tile_off, int T, int ty_begin,
+                                                     int ty_rows, int n_clouds, int max_slots,
+                                                     int4* __restrict__ items, int4* __restrict__ heavy,
+                                                     int32_t* __restrict__ counters) {
+  __shared__ int hist[64], base[64];
+  __shared__ int s_slots, s_heavy, s_slice;
+  const int tiles = n_clouds * T * ty_rows;
+  auto tile_of = [&](int i) { return ((i / (T * ty_rows)) * T + ty_begin + (i / T) % ty_rows) * T + i % T; };
+  auto count_of = [&](int tile) { return tile_off[tile + 1] - tile_off[tile]; };
+  // slice size: kSlice, doubled until the slices of all heavy tiles fit the scratch slots
+  if (threadIdx.x == 0) s_slice = kSlice;
+  __syncthreads();
+  for (int round = 0; round < 16; ++round) {
+    if (threadIdx.x == 0) s_slots = 0;
+    __syncthreads();
+    const int sl = s_slice;
+    int mine = 0;
+    for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
+      const int c = count_of(tile_of(i));
+      if (c > kSplitMin && c > sl) mine += (c + sl - 1) / sl;
+    }
+    if (mine) atomicAdd(&s_slots, mine);
+    __syncthreads();
+    const bool fits = s_slots <= max_slots;
+    __syncthreads();
+    if (fits) break;
+    if (threadIdx.x == 0) s_slice = sl * 2;
+    __syncthreads();
+  }
+  const int sl = s_slice;
+  auto slices_of = [&](int c) { return (c > kSplitMin && c > sl && max_slots > 0) ? (c + sl - 1) / sl : 1; };
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { s_slots = 0; s_heavy = 0; }
+  __syncthreads();
+  auto bucket_of = [&](int c) { return min(c >> 6, 63); };
+  for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
+    const int tile = tile_of(i), c = count_of(tile), ns = slices_of(c);
+    if (ns > 1) {
+      const int b0 = atomicAdd(&s_slots, ns);
+      heavy[atomicAdd(&s_heavy, 1)] = make_int4(tile, b0, ns, 0);
+      for (int k = 0; k < ns; ++k) items[b0 + k] = make_int4(tile, k, ns, b0 + k);
+    } else {
+      atomicAdd(&hist[bucket_of(c)], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = s_slots;
+    for (int b = 63; b >= 0; --b) { base[b] = run; run += hist[b]; }
+    counters[0] = run;
+    counters[1] = s_heavy;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
+    const int tile = tile_of(i), c = count_of(tile);
+    if (slices_of(c) == 1) items[atomicAdd(&base[bucket_of(c)], 1)] = make_int4(tile, 0, 1, 0);
+  }
+}
+
+// K-best of a heavy tile's pixels from the K-best lists of its slices (same (z, idx) order: the result
+// does not depend on how the list was cut), then the depth-merging cut and the outputs of k_raster.
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ heavy, const int32_t* __restrict__ counters,
+                                                      const float* __restrict__ scratch, int S, int T, int K,
+                                                      float depth_thres, int32_t* __restrict__ idx_out,
+                                                      float* __restrict__ zbuf_out, float* __restrict__ q_out,
+                                                      float* __restrict__ occ_out) {
+  const int nh = counters[1];
+  for (int hI = blockIdx.x; hI < nh; hI += gridDim.x) {
+    const int4 hv = heavy[hI];
+    const int tile = hv.x;
+    const int tx = tile % T, ty = (tile / T) % T, n = tile / (T * T);
+    const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
+    const int xi = tx * TILE + lx, yi = ty * TILE + ly;
+    PixK<KMAX> best;
+    best.init();
+    for (int sI = 0; sI < hv.z; ++sI) {
+      const float* sc = scratch + (int64_t)(hv.y + sI) * 3 * KMAX * 256;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        const float z = sc[j * 256 + threadIdx.x];
+        if (j < K && z < FLT_MAX)
+          best.push(z, __float_as_int(sc[(2 * KMAX + j) * 256 + threadIdx.x]), sc[(KMAX + j) * 256 + threadIdx.x], K);
+      }
+    }
+    if (xi >= S || yi >= S) continue;
+    const int yo = S - 1 - yi, xo = S - 1 - xi;
+    const int64_t pix = ((int64_t)n * S + yo) * S + xo;
+    const float z0 = best.z[0];
+    const bool hit = z0 < FLT_MAX;
+    occ_out[pix] = hit ? 1.0f : 0.0f;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < K) {
+        const bool ok = best.z[j] < FLT_MAX && !((best.z[j] - z0) > depth_thres);
+        idx_out[pix * K + j] = ok ? best.id[j] : -1;
+        zbuf_out[pix * K + j] = ok ? best.z[j] : -1.0f;
+        q_out[pix * K + j] = ok ? best.q[j] : -1.0f;
+      }
+    }
   }
 }
 
@@ -1044,6 +1178,15 @@ extern "C" int iso_splat_bin_count(const float* points, const float* radii,
   return ISO_OK;
 }
 
+extern "C" int64_t iso_splat_forward_workspace_bytes(int64_t n_tiles, int points_per_pixel) {
+  const int K = points_per_pixel;
+  const int KM = K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 16 ? 16 : 32));
+  if (n_tiles < 0) n_tiles = 0;
+  int64_t slots = n_tiles / 2 + 256;               // room to cut every other tile once; k_tile_items adapts the slice size
+  if (slots > 8192) slots = 8192;
+  return 64 + 32 * n_tiles + slots * (16 + (int64_t)3 * KM * 256 * 4);
+}
+
 extern "C" int iso_splat_forward(const float* points, const float* ellipse, const float* cutoff,
                                  const float* radii, const int64_t* first_idx,
                                  const int64_t* num_pts, int n_clouds, int64_t max_pts,
@@ -1051,7 +1194,8 @@ extern "C" int iso_splat_forward(const float* points, const float* ellipse, cons
                                  int tile_row_begin, int tile_row_end, int32_t* tile_cursor,
                                  const int32_t* tile_off, int32_t* pairs,
                                  int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
-                                 float* zbuf_out, float* qvalue_out, float* occ_out, void* stream) {
+                                 float* zbuf_out, float* qvalue_out, float* occ_out, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
   ISO_REQUIRE(points_per_pixel >= 1 && points_per_pixel <= 32, ISO_ERR_UNSUPPORTED,
               "iso_splat_forward: points_per_pixel must be in [1,32], got %d", points_per_pixel);
   ISO_REQUIRE(n_clouds >= 0 && max_pts >= 0 && image_size > 0, ISO_ERR_INVALID, "iso_splat_forward: bad sizes");
@@ -1072,18 +1216,41 @@ extern "C" int iso_splat_forward(const float* points, const float* ellipse, cons
   const int ty_rows = tile_row_end - tile_row_begin;
   const int tiles = n_clouds * T * ty_rows;
   const int K = points_per_pixel;
-  // the fill cursors are dead now: their array takes the heaviest-first tile order
-  hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tile_off, T, tile_row_begin, ty_rows, n_clouds,
-                     tile_cursor);
-#define ISO_LAUNCH_R(KM)                                                                        \
-  hipLaunchKernelGGL(k_raster<KM>, dim3(tiles), dim3(256), 0, s, points, ellipse, cutoff, radii, \
-                     tile_cursor, tile_off, pairs, pair_capacity, image_size, T,                 \
-                     K, depth_merging_thres,                                                     \
-                     idx_out, zbuf_out, qvalue_out, occ_out)
-  if (K <= 4) ISO_LAUNCH_R(4);
-  else if (K <= 8) ISO_LAUNCH_R(8);
-  else if (K <= 16) ISO_LAUNCH_R(16);
-  else ISO_LAUNCH_R(32);
+  const int KM = K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 16 ? 16 : 32));
+  // workspace (optional): work items with the heavy tiles cut into slices
+  //   [counters 64 B][items int4 (tiles + slots)][heavy int4 (tiles)][scratch slots * 3 * KM * 256 floats]
+  int max_slots = 0;
+  int4* items = nullptr; int4* heavy = nullptr; int32_t* counters = nullptr; float* scratch = nullptr;
+  if (workspace && tiles > 0) {
+    const int64_t per_slot = 16 + (int64_t)3 * KM * 256 * 4;
+    const int64_t fixed = 64 + (int64_t)32 * tiles;
+    int64_t slots = workspace_bytes > fixed ? (workspace_bytes - fixed) / per_slot : 0;
+    if (slots > 65536) slots = 65536;
+    max_slots = (int)slots;
+    counters = (int32_t*)workspace;
+    items = (int4*)((char*)workspace + 64);
+    heavy = items + tiles + max_slots;
+    scratch = (float*)(heavy + tiles);
+  }
+  if (items) {
+    hipLaunchKernelGGL(k_tile_items, dim3(1), dim3(1024), 0, s, tile_off, T, tile_row_begin, ty_rows, n_clouds, max_slots,
+                       items, heavy, counters);
+  } else {
+    // the fill cursors are dead now: their array takes the heaviest-first tile order
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tile_off, T, tile_row_begin, ty_rows, n_clouds,
+                       tile_cursor);
+  }
+#define ISO_LAUNCH_R(KM_)                                                                            \
+  hipLaunchKernelGGL(k_raster<KM_>, dim3(tiles + max_slots), dim3(256), 0, s, points, ellipse, cutoff, radii, \
+                     tile_cursor, items, counters, scratch, tile_off, pairs, pair_capacity, image_size, T,    \
+                     K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out);                 \
+  if (items)                                                                                          \
+    hipLaunchKernelGGL(k_raster_merge<KM_>, dim3(tiles < 1024 ? tiles : 1024), dim3(256), 0, s, heavy, counters, scratch, \
+                       image_size, T, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out)
+  if (K <= 4) { ISO_LAUNCH_R(4); }
+  else if (K <= 8) { ISO_LAUNCH_R(8); }
+  else if (K <= 16) { ISO_LAUNCH_R(16); }
+  else { ISO_LAUNCH_R(32); }
 #undef ISO_LAUNCH_R
   ISO_CHECK_LAUNCH("iso_splat_forward");
   return ISO_OK;
@@ -1361,20 +1528,20 @@ __global__ __launch_bounds__(256) void k_repack_records(const float* __restrict_
       if (vv < v || (vv == v && ss < s)) g0 += c;
       if (ss == s && vv < v) l0 += c;
     }
-  const int n = counts[s * 8 + v];
+  int64_t n = counts[s * 8 + v];
+  if (l0 + n > cap) n = cap > l0 ? cap - l0 : 0;      // the sender's buffer overflowed (flagged by the host side)
   const float* blk = gathered + (int64_t)s * 12 * cap;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t l = l0 + j, g = g0 + j;
-    if (l >= cap) break;                         // the sender's buffer overflowed (flagged by the host side)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      ndc[g * 3 + c] = blk[l * 3 + c];
-      ellipse[g * 3 + c] = blk[3 * cap + l * 3 + c];
-      feat[g * 3 + c] = blk[9 * cap + l * 3 + c];
-    }
-    radii[g * 2] = blk[6 * cap + l * 2]; radii[g * 2 + 1] = blk[6 * cap + l * 2 + 1];
-    scaler[g] = blk[8 * cap + l];
-    cutoff[g] = cutoffC;
+  // every field of the (view, rank) block is one contiguous run in both layouts: flat, coalesced copies
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = t0; j < 3 * n; j += step) {
+    ndc[g0 * 3 + j] = blk[l0 * 3 + j];
+    ellipse[g0 * 3 + j] = blk[3 * cap + l0 * 3 + j];
+    feat[g0 * 3 + j] = blk[9 * cap + l0 * 3 + j];
+  }
+  for (int64_t j = t0; j < 2 * n; j += step) radii[g0 * 2 + j] = blk[6 * cap + l0 * 2 + j];
+  for (int64_t j = t0; j < n; j += step) {
+    scaler[g0 + j] = blk[8 * cap + l0 + j];
+    cutoff[g0 + j] = cutoffC;
   }
 }
 
@@ -1418,7 +1585,7 @@ extern "C" int iso_splat_repack(const float* gathered, int64_t capacity, int wor
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_repack_offsets, dim3(1), dim3(64), 0, s, counts, world, n_views, rank, first_idx_out, num_pts_out,
                      own_first_out, own_num_out);
-  int gx = iso_div_up(max_rows > 0 ? max_rows : 1, 256); if (gx > 1024) gx = 1024;
+  int gx = iso_div_up(max_rows > 0 ? 3 * max_rows / (world * n_views) + 1 : 1, 256); if (gx > 256) gx = 256;
   hipLaunchKernelGGL(k_repack_records, dim3(gx, world, n_views), dim3(256), 0, s, gathered, capacity, world, n_views, counts,
                      cutoff, ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out, features_out);
   ISO_CHECK_LAUNCH("iso_splat_repack");

@@ -334,6 +334,8 @@ class IsoCycle(object):
     def cycle(self):
         """Generator over the exchanges of one cycle; returns (projection result of the own points,
         image with the own band filled, gradient of the packed rows, fragments, front-end dict)."""
+        # the SDF weights are packed once per cycle (they change once per optimiser step), not per projection
+        self.proj.reuse_packed, self.proj._packed_cache = True, None
         r1 = yield from self.project_resample()
         fr = yield from self._front(r1.points[0].contiguous(), r1.normals[0].contiguous())
         if self.marks:

@@ -36,16 +36,18 @@ def eps_denom(denom, eps=1e-17):
 
 
 def with_host_lengths(num_points, host):
-    """Attach the host copy of a lengths tensor so later stages need no .tolist() sync."""
+    """Attach the host copy of a lengths tensor so later stages need no .tolist() sync (dropped as
+    soon as the tensor is modified in place: the copy is keyed on the tensor's version)."""
     num_points._iso_host = [int(x) for x in host]
+    num_points._iso_host_version = num_points._version
     return num_points
 
 
 def host_lengths(num_points):
     h = getattr(num_points, "_iso_host", None)
-    if h is None:
+    if h is None or getattr(num_points, "_iso_host_version", None) != num_points._version:
         h = [int(x) for x in num_points.tolist()]  # host sync, as the reference (:308)
-        num_points._iso_host = h
+        with_host_lengths(num_points, h)
     return h
 
 
@@ -136,6 +138,9 @@ class UniformProjection(LevelSetProjection):
         self.sample_iters = sample_iters
         self.resampling_clip = resampling_clip  # stored, unused -- as in the reference (:108)
         self._packed_cache = None
+        self._packed_for = None
+        self.reuse_packed = False      # keep the packed weight image of the last call (the caller clears
+                                       # _packed_cache whenever the weights may have changed)
         self.materialize_knn = True    # resample(): also write the neighbour lists the fused kernel selects
                                        # (_knn_idx / _knn_dists, as the reference's _create_tree leaves them)
 
@@ -197,13 +202,18 @@ class UniformProjection(LevelSetProjection):
         mask = torch.zeros((n,), dtype=torch.uint8, device=dev)
         p = _lib.ptr
         if getattr(model, "iso_analytic", None) == "sphere" and not forward_kwargs:
-            c = [float(x) for x in model.center.tolist()] if not hasattr(model, "_iso_center") else model._iso_center
-            model._iso_center = c
+            cached = getattr(model, "_iso_center", None)     # host copy of the centre, re-read when the buffer changes
+            if cached is None or cached[0] != (model.center._version, model.center.data_ptr()):
+                cached = ((model.center._version, model.center.data_ptr()), [float(x) for x in model.center.tolist()])
+                model._iso_center = cached
+            c = cached[1]
             _lib.call("iso_project_sphere", p(pts), p(out), p(normals), p(mask), n, c[0], c[1], c[2],
                       float(model.radius), int(proj_max_iters), float(proj_tolerance), _lib.stream())
             return out, normals, mask.bool()
         if siren_spec(model) is not None and not forward_kwargs:
-            ps = PackedSiren(model, dev)
+            ps = self._packed_cache if (self.reuse_packed and isinstance(self._packed_cache, PackedSiren)
+                                        and self._packed_for is model) else PackedSiren(model, dev)
+            self._packed_for = model
             ws = ps.workspace(n)
             _lib.call("iso_project_siren", p(pts), p(out), p(normals), p(mask), n, p(ps.packed),
                       ps.hidden, ps.n_hidden, ps.omega_first, ps.omega_hidden, int(proj_max_iters),
@@ -211,7 +221,9 @@ class UniformProjection(LevelSetProjection):
             self._packed_cache = ps  # keep the workspace alive until the stream has used it
             return out, normals, mask.bool()
         if idr_spec(model) is not None and not forward_kwargs:
-            pk = PackedIdr(model, dev)
+            pk = self._packed_cache if (self.reuse_packed and isinstance(self._packed_cache, PackedIdr)
+                                        and self._packed_for is model) else PackedIdr(model, dev)
+            self._packed_for = model
             ws = pk.workspace(n)
             _lib.call("iso_project_idr", p(pts), p(out), p(normals), p(mask), n, p(pk.packed), pk.hidden,
                       pk.n_layers, pk.skip, pk.n_freq, 100.0, int(proj_max_iters), float(proj_tolerance),

@@ -96,7 +96,7 @@ class _CNamespace(object):
     def splat_points(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
                      num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel,
                      bin_size=0, max_points_per_bin=0, tile_rows=None, out=None, max_pts=None,
-                     pair_capacity=None, overflow_out=None):
+                     pair_capacity=None, overflow_out=None, split_heavy_tiles=True):
         """-> (idx i32 (N,S,S,K), zbuf, qvalue f32 (N,S,S,K), occupancy f32 (N,S,S)).
         max_pts (upper bound of the points of a cloud) + pair_capacity (upper bound of the point-tile
         pairs): with both given nothing is read back to the host; an overflow of the pair list sets
@@ -119,8 +119,8 @@ class _CNamespace(object):
         N = num_points_per_cloud.shape[0]
         pts, el, cu, ra = _f32c(points), _f32c(ellipse_params), _f32c(cutoff_thres), _f32c(radii)
         first, num = _i64c(cloud_to_packed_first_idx), _i64c(num_points_per_cloud)
-        if hasattr(num_points_per_cloud, "_iso_host"):
-            num._iso_host = num_points_per_cloud._iso_host
+        if hasattr(num_points_per_cloud, "_iso_host") and num is not num_points_per_cloud:
+            with_host_lengths(num, host_lengths(num_points_per_cloud))
         lib = _lib.load()
         T = lib.iso_splat_tiles_per_side(S) if S > 0 else 0
         band = (0, T) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
@@ -156,9 +156,11 @@ class _CNamespace(object):
         cursor = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)   # [ntiles] = overflow flag
         if overflow_out is not None:
             overflow_out.append(cursor[ntiles:])
+        rws_b = lib.iso_splat_forward_workspace_bytes(N * T * (band[1] - band[0]), K) if split_heavy_tiles else 0
+        rws = torch.empty((rws_b,), dtype=torch.uint8, device=dev) if rws_b else None
         _lib.call("iso_splat_forward", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
                   float(depth_merging_thres), S, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
-                  _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), s)
+                  _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), p(rws), rws_b, s)
         return idx, zbuf, qv, occ
 
     @staticmethod
@@ -181,8 +183,8 @@ class _CNamespace(object):
             return grad
         pts, ra, go = _f32c(points), _f32c(radii), _f32c(grad_occ)
         first, num_c = _i64c(first), _i64c(num)
-        if hasattr(num, "_iso_host"):
-            num_c._iso_host = num._iso_host
+        if hasattr(num, "_iso_host") and num_c is not num:
+            with_host_lengths(num_c, host_lengths(num))
         lib = _lib.load()
         ws_b = lib.iso_splat_backward_workspace_bytes(N, S, P)
         ws = torch.empty((max(ws_b, 1),), dtype=torch.uint8, device=dev)

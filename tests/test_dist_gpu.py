@@ -92,14 +92,13 @@ def test_graph_replay_equals_eager(dev, world):
     pts, views, projs, rs, target = _scene(dev, P, S, N)
     model = _models(dev, "sphere")
     pts = pts[:, slab_order(pts[0], world)].contiguous()
-    mk = lambda: [IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, world=world, rank=r)
-                  for r in range(world)]
-    eager = run_lockstep(mk())
-    ranks = mk()
+    ranks = [IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, world=world, rank=r)
+             for r in range(world)]
+    eager = run_lockstep(ranks)                                                                # also the warm-up
+    eager = [(a[0], a[1].clone(), a[2].clone(), a[3]) for a in eager]
     for c in ranks:
         c.use_graphs = True
         c.marks = True
-    run_lockstep([type("E", (), {"generator": c.cycle, "use_graphs": False})() for c in ranks])   # eager warm-up
     run_lockstep(ranks)                                                                        # capture
     for _ in range(3):
         got = run_lockstep(ranks)                                                              # replays

@@ -294,6 +294,31 @@ def test_full_size_properties(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("P,S,K", [(150000, 64, 8), (400000, 128, 5), (60000, 32, 20)])
+def test_heavy_tiles_in_slices_equal_whole_tiles(dev, P, S, K):
+    """Tiles with thousands of candidates are rasterised in slices by several workgroups and merged:
+    bit-identical to one workgroup per tile (the K-best rule is an order on (z, idx))."""
+    from iso_points_amd.rasterizer import _C
+    SO = _SO()
+    g = torch.Generator().manual_seed(P)
+    pts = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    view = SO.look_at_view(3.0, 20.0, 30.0)
+    M44 = view @ SO.perspective(30.0)
+    keep = SO.filter_renderable(pts, pts, view)
+    pf = pts[keep]
+    h = torch.full((pf.shape[0],), 2e-4)
+    info = SO.per_point_info(pf, pf, h, M44, S)
+    ndc = SO.transform_to_ndc(pf, view, M44)
+    first, num = torch.tensor([0]), torch.tensor([pf.shape[0]])
+    args = [t.to(dev) for t in (ndc, info["ellipse_params"], info["cutoff_threshold"], info["radii"], first, num)]
+    a = _C.splat_points(*args, 0.05, S, K, split_heavy_tiles=True)
+    b = _C.splat_points(*args, 0.05, S, K, split_heavy_tiles=False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert (a[0] >= 0).float().mean() > 0.3
+
+
+@pytest.mark.gpu
 def test_median_radius_matches_torch_median():
     """rasterizer.py:884: r_n = torch.median(radii[visible of cloud n]) * scaler -- the radix select
     must return the same element bit for bit (lower median, duplicates, empty visible set)."""
