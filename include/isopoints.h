@@ -414,6 +414,19 @@ int iso_splat_forward(const float* points, const float* ellipse, const float* cu
                       int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out,
                       void* workspace, int64_t workspace_bytes, void* stream);
 int64_t iso_splat_forward_workspace_bytes(int64_t n_tiles, int points_per_pixel);
+/* iso_splat_forward and iso_splat_composite (below) in one pass: image_out (N,S,S,channels+1) is
+ * composited from the pixels' K-best lists while they are in registers -- same arithmetic and order,
+ * the (N,S,S,K) lists are written as before (the backward needs them) but not read again.       */
+int iso_splat_render(const float* points, const float* ellipse, const float* cutoff,
+                     const float* radii, const int64_t* first_idx, const int64_t* num_pts,
+                     int n_clouds, int64_t max_pts, float depth_merging_thres, int image_size,
+                     int points_per_pixel, int tile_row_begin, int tile_row_end,
+                     int32_t* tile_cursor, const int32_t* tile_off,
+                     int32_t* pairs, int64_t pair_capacity, int32_t* overflow_flag,
+                     int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out,
+                     void* workspace, int64_t workspace_bytes, const float* scaler,
+                     const float* features, int channels, int norm_weighted, float eps,
+                     float* image_out, void* stream);
 
 /* renderer.py:53-78: w = exp(-0.5 q) * scaler[idx] (0 where idx < 0);
  * image[..., c] = sum_k w f / max(sum_k w, eps) (norm_weighted) or sum_k w f;
@@ -440,6 +453,15 @@ int iso_splat_composite(const int32_t* idx, const float* qvalue, const float* oc
  * rect_mode = 1 switches the xy support to the slow reference kernel's rectangle
  * |d| <= radii * radii_s (_C._splat_points_occ_backward, rasterize_points.cu:673-760);
  * search_radius is then unused.                                                  */
+/* Backward of iso_splat_composite (renderer.py:53-78 composites through pytorch3d's differentiable
+ * compositors): grad_image (n_pixels, channels + 1) -> grad_features (P, channels) and grad_scaler (P)
+ * ACCUMULATED into the caller's zero-initialised buffers (float atomics), grad_qvalue (n_pixels, K)
+ * and grad_occ (n_pixels) written; any output pointer may be NULL.                               */
+int iso_splat_composite_backward(const int32_t* idx, const float* qvalue, const float* scaler,
+                                 const float* features, const float* grad_image, int64_t n_pixels,
+                                 int points_per_pixel, int channels, int norm_weighted, float eps,
+                                 float* grad_features, float* grad_qvalue, float* grad_scaler,
+                                 float* grad_occ, void* stream);
 int iso_splat_mark_visible(const int32_t* idx, int64_t n_pixels, int points_per_pixel,
                            uint8_t* visible, void* stream);
 /* search_radius_out[n] = lower-median(radii of the visible points of cloud n, both columns

@@ -482,6 +482,43 @@ struct Cand {  // one LDS record per candidate (SoA in LDS)
   int id;
 };
 
+// optional epilogue of the raster kernels: the compositing of k_composite for the pixel just finished
+// (same arithmetic, same order; saves re-reading the K-deep lists)
+struct CompositeArgs {
+  const float* scaler;   // null: no compositing
+  const float* feat;
+  float* img;            // (N,S,S,C+1)
+  int C, norm;
+  float eps;
+};
+
+template <int KMAX>
+__device__ __forceinline__ void composite_pixel(const PixK<KMAX>& best, int K, float z0, float depth_thres, bool hit,
+                                                const CompositeArgs& ca, int64_t pix) {
+  float sw = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    if (j < K) {
+      const bool ok = best.z[j] < FLT_MAX && !((best.z[j] - z0) > depth_thres);
+      if (ok) {
+        const int p = best.id[j];
+        const float w = expf(-0.5f * best.q[j]) * ca.scaler[p];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < ca.C) acc[c] += w * ca.feat[(int64_t)p * ca.C + c];
+        sw += w;
+      }
+    }
+  }
+  float d = 1.0f;
+  if (ca.norm) d = sw > ca.eps ? sw : ca.eps;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) if (c < ca.C) ca.img[pix * (ca.C + 1) + c] = ca.norm ? acc[c] / d : acc[c];
+  ca.img[pix * (ca.C + 1) + ca.C] = hit ? 1.0f : 0.0f;
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(256) void k_raster(
     const float* __restrict__ pts, const float* __restrict__ ellipse,
@@ -490,7 +527,7 @@ __global__ __launch_bounds__(256) void k_raster(
     float* __restrict__ scratch, const int32_t* __restrict__ tile_off,
     const int32_t* __restrict__ pairs, int64_t capacity, int S, int T,
     int K, float depth_thres, int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out,
-    float* __restrict__ occ_out) {
+    float* __restrict__ occ_out, CompositeArgs ca) {
   __shared__ float s_px[256], s_py[256], s_pz[256], s_a[256], s_b[256], s_c[256], s_rx[256],
       s_ry[256], s_cut[256];
   __shared__ int s_id[256];
@@ -621,6 +658,7 @@ __global__ __launch_bounds__(256) void k_raster(
       q_out[pix * K + j] = ok ? best.q[j] : -1.0f;
     }
   }
+  if (ca.scaler) composite_pixel<KMAX>(best, K, z0, depth_thres, hit, ca, pix);
 }
 
 // Tiles of the band [ty_begin, ty_begin+ty_rows) of every cloud, heaviest first (64 buckets of the
@@ -719,7 +757,7 @@ __global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ h
                                                       const float* __restrict__ scratch, int S, int T, int K,
                                                       float depth_thres, int32_t* __restrict__ idx_out,
                                                       float* __restrict__ zbuf_out, float* __restrict__ q_out,
-                                                      float* __restrict__ occ_out) {
+                                                      float* __restrict__ occ_out, CompositeArgs ca) {
   const int nh = counters[1];
   for (int hI = blockIdx.x; hI < nh; hI += gridDim.x) {
     const int4 hv = heavy[hI];
@@ -753,6 +791,7 @@ __global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ h
         q_out[pix * K + j] = ok ? best.q[j] : -1.0f;
       }
     }
+    if (ca.scaler) composite_pixel<KMAX>(best, K, z0, depth_thres, hit, ca, pix);
   }
 }
 
@@ -783,6 +822,62 @@ __global__ void k_composite(const int32_t* __restrict__ idx, const float* __rest
     if (norm) d = sw > eps ? sw : eps;
     for (int c = 0; c < C; ++c) out[i * (C + 1) + c] = norm ? acc[c] / d : acc[c];
     out[i * (C + 1) + C] = occ[i];
+  }
+}
+
+// Backward of k_composite (SurfaceSplattingRenderer.forward, renderer.py:53-78, is differentiable with
+// respect to the features and the fragment weights through pytorch3d's compositor):
+//   w_k = exp(-q_k / 2) s_k,  A_c = sum_k w_k f_c[p_k],  d = max(sum w, eps),  out_c = A_c / d (norm) or A_c
+//   dL/df_c[p_k] += g_c w_k / d
+//   dL/dw_k       = sum_c g_c (f_c[p_k] - [sum w > eps] out_c) / d            (norm; d = 1 and no second term otherwise)
+//   dL/dq_k = -w_k / 2 dL/dw_k ,  dL/ds[p_k] += exp(-q_k / 2) dL/dw_k ,  dL/docc = g_alpha
+// Feature and scaler gradients are scattered with float atomics (as pytorch3d's compositor does).
+__global__ void k_composite_backward(const int32_t* __restrict__ idx, const float* __restrict__ qv,
+                                     const float* __restrict__ scaler, const float* __restrict__ feat,
+                                     const float* __restrict__ grad_img, int K, int C, int norm, float eps, int64_t npix,
+                                     float* __restrict__ grad_feat, float* __restrict__ grad_q,
+                                     float* __restrict__ grad_scaler, float* __restrict__ grad_occ) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+    float g[8], acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { g[c] = c < C ? grad_img[i * (C + 1) + c] : 0.f; acc[c] = 0.f; }
+    if (grad_occ) grad_occ[i] = grad_img[i * (C + 1) + C];
+    float sw = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int p = idx[i * K + k];
+      if (p >= 0) {
+        const float w = expf(-0.5f * qv[i * K + k]) * scaler[p];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < C) acc[c] += w * feat[(int64_t)p * C + c];
+        sw += w;
+      }
+    }
+    const float d = norm ? (sw > eps ? sw : eps) : 1.0f;
+    const bool through = norm && sw > eps;
+    float go = 0.f;                               // sum_c g_c out_c
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < C) go += g[c] * (acc[c] / d);
+    for (int k = 0; k < K; ++k) {
+      const int p = idx[i * K + k];
+      float gq = 0.f;
+      if (p >= 0) {
+        const float e = expf(-0.5f * qv[i * K + k]);
+        const float sc = scaler[p];
+        const float w = e * sc;
+        float gw = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < C) {
+            const float f = feat[(int64_t)p * C + c];
+            gw += g[c] * f;
+            if (grad_feat && g[c] != 0.f) atomicAdd(&grad_feat[(int64_t)p * C + c], g[c] * w / d);
+          }
+        gw = (gw - (through ? go : 0.f)) / d;
+        gq = -0.5f * w * gw;
+        if (grad_scaler && gw != 0.f) atomicAdd(&grad_scaler[p], e * gw);
+      }
+      if (grad_q) grad_q[i * K + k] = gq;
+    }
   }
 }
 
@@ -1187,7 +1282,7 @@ extern "C" int64_t iso_splat_forward_workspace_bytes(int64_t n_tiles, int points
   return 64 + 32 * n_tiles + slots * (16 + (int64_t)3 * KM * 256 * 4);
 }
 
-extern "C" int iso_splat_forward(const float* points, const float* ellipse, const float* cutoff,
+static int splat_forward_impl(CompositeArgs ca, const float* points, const float* ellipse, const float* cutoff,
                                  const float* radii, const int64_t* first_idx,
                                  const int64_t* num_pts, int n_clouds, int64_t max_pts,
                                  float depth_merging_thres, int image_size, int points_per_pixel,
@@ -1243,10 +1338,10 @@ extern "C" int iso_splat_forward(const float* points, const float* ellipse, cons
 #define ISO_LAUNCH_R(KM_)                                                                            \
   hipLaunchKernelGGL(k_raster<KM_>, dim3(tiles + max_slots), dim3(256), 0, s, points, ellipse, cutoff, radii, \
                      tile_cursor, items, counters, scratch, tile_off, pairs, pair_capacity, image_size, T,    \
-                     K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out);                 \
+                     K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);             \
   if (items)                                                                                          \
     hipLaunchKernelGGL(k_raster_merge<KM_>, dim3(tiles < 1024 ? tiles : 1024), dim3(256), 0, s, heavy, counters, scratch, \
-                       image_size, T, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out)
+                       image_size, T, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca)
   if (K <= 4) { ISO_LAUNCH_R(4); }
   else if (K <= 8) { ISO_LAUNCH_R(8); }
   else if (K <= 16) { ISO_LAUNCH_R(16); }
@@ -1254,6 +1349,43 @@ extern "C" int iso_splat_forward(const float* points, const float* ellipse, cons
 #undef ISO_LAUNCH_R
   ISO_CHECK_LAUNCH("iso_splat_forward");
   return ISO_OK;
+}
+
+extern "C" int iso_splat_forward(const float* points, const float* ellipse, const float* cutoff,
+                                 const float* radii, const int64_t* first_idx,
+                                 const int64_t* num_pts, int n_clouds, int64_t max_pts,
+                                 float depth_merging_thres, int image_size, int points_per_pixel,
+                                 int tile_row_begin, int tile_row_end, int32_t* tile_cursor,
+                                 const int32_t* tile_off, int32_t* pairs,
+                                 int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
+                                 float* zbuf_out, float* qvalue_out, float* occ_out, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  CompositeArgs ca{nullptr, nullptr, nullptr, 0, 0, 0.f};
+  return splat_forward_impl(ca, points, ellipse, cutoff, radii, first_idx, num_pts, n_clouds, max_pts, depth_merging_thres,
+                            image_size, points_per_pixel, tile_row_begin, tile_row_end, tile_cursor, tile_off, pairs,
+                            pair_capacity, overflow_flag, idx_out, zbuf_out, qvalue_out, occ_out, workspace,
+                            workspace_bytes, stream);
+}
+
+// iso_splat_forward + iso_splat_composite in one pass: the pixels' images are composited from the K-best
+// lists while they are still in registers (same arithmetic and order as iso_splat_composite).
+extern "C" int iso_splat_render(const float* points, const float* ellipse, const float* cutoff,
+                                const float* radii, const int64_t* first_idx,
+                                const int64_t* num_pts, int n_clouds, int64_t max_pts,
+                                float depth_merging_thres, int image_size, int points_per_pixel,
+                                int tile_row_begin, int tile_row_end, int32_t* tile_cursor,
+                                const int32_t* tile_off, int32_t* pairs,
+                                int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
+                                float* zbuf_out, float* qvalue_out, float* occ_out, void* workspace,
+                                int64_t workspace_bytes, const float* scaler, const float* features, int channels,
+                                int norm_weighted, float eps, float* image_out, void* stream) {
+  ISO_REQUIRE(channels >= 0 && channels <= 8, ISO_ERR_UNSUPPORTED, "iso_splat_render: channels must be <= 8");
+  ISO_REQUIRE(scaler && image_out && (features || channels == 0), ISO_ERR_INVALID, "iso_splat_render: null pointer");
+  CompositeArgs ca{scaler, features, image_out, channels, norm_weighted, eps};
+  return splat_forward_impl(ca, points, ellipse, cutoff, radii, first_idx, num_pts, n_clouds, max_pts, depth_merging_thres,
+                            image_size, points_per_pixel, tile_row_begin, tile_row_end, tile_cursor, tile_off, pairs,
+                            pair_capacity, overflow_flag, idx_out, zbuf_out, qvalue_out, occ_out, workspace,
+                            workspace_bytes, stream);
 }
 
 extern "C" int iso_splat_composite(const int32_t* idx, const float* qvalue, const float* occ,
@@ -1269,6 +1401,23 @@ extern "C" int iso_splat_composite(const int32_t* idx, const float* qvalue, cons
                      (hipStream_t)stream, idx, qvalue, occ, scaler, features, points_per_pixel,
                      channels, norm_weighted, eps, n_pixels, frag_scaler_out, image_out);
   ISO_CHECK_LAUNCH("iso_splat_composite");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_composite_backward(const int32_t* idx, const float* qvalue, const float* scaler,
+                                            const float* features, const float* grad_image, int64_t n_pixels,
+                                            int points_per_pixel, int channels, int norm_weighted, float eps,
+                                            float* grad_features, float* grad_qvalue, float* grad_scaler,
+                                            float* grad_occ, void* stream) {
+  ISO_REQUIRE(channels >= 0 && channels <= 8, ISO_ERR_UNSUPPORTED, "iso_splat_composite_backward: channels must be <= 8");
+  ISO_REQUIRE(n_pixels >= 0 && points_per_pixel >= 1, ISO_ERR_INVALID, "iso_splat_composite_backward: bad sizes");
+  if (n_pixels == 0) return ISO_OK;
+  ISO_REQUIRE(idx && qvalue && scaler && grad_image && (features || channels == 0), ISO_ERR_INVALID,
+              "iso_splat_composite_backward: null pointer");
+  hipLaunchKernelGGL(k_composite_backward, dim3(iso_stream_grid(n_pixels, 256)), dim3(256), 0, (hipStream_t)stream, idx,
+                     qvalue, scaler, features, grad_image, points_per_pixel, channels, norm_weighted, eps, n_pixels,
+                     grad_features, grad_qvalue, grad_scaler, grad_occ);
+  ISO_CHECK_LAUNCH("iso_splat_composite_backward");
   return ISO_OK;
 }
 

@@ -251,16 +251,19 @@ class IsoCycle(object):
         return out
 
     def splat_forward(self, fr):
+        """Tile binning + raster of this rank's band of tile rows, the image composited in the same
+        kernel (renderer.py:53-78).  Returns (fragments, image with the own band filled)."""
         rs = self.rs
         S, K = int(rs.image_size), int(rs.points_per_pixel)
         T = _lib.load().iso_splat_tiles_per_side(S)
         self.band = shard_bounds(T, self.world, self.rank)
         self._ovf = []
-        idx, zbuf, qv, occ = _C.splat_points(fr["ndc"], fr["ellipse_params"], fr["cutoff_threshold"], fr["radii"],
-                                             fr["first_idx"], fr["num_points"], rs.depth_merging_threshold, S, K, 0, 0,
-                                             tile_rows=self.band if self.world > 1 else None, max_pts=fr["max_pts"],
-                                             pair_capacity=self.pair_cap, overflow_out=self._ovf)
-        return PointFragments(idx, zbuf, qv, None, occ)
+        idx, zbuf, qv, occ, img = _C.splat_points(
+            fr["ndc"], fr["ellipse_params"], fr["cutoff_threshold"], fr["radii"], fr["first_idx"], fr["num_points"],
+            rs.depth_merging_threshold, S, K, 0, 0, tile_rows=self.band if self.world > 1 else None,
+            max_pts=fr["max_pts"], pair_capacity=self.pair_cap, overflow_out=self._ovf,
+            composite_with=(fr["scaler"], fr["features"], True, 1e-4))
+        return PointFragments(idx, zbuf, qv, None, occ), img
 
     def band_rows(self):
         """Output-image pixel rows [y0, y1) of this rank's tile-row band (the image is flipped)."""
@@ -340,12 +343,9 @@ class IsoCycle(object):
         fr = yield from self._front(r1.points[0].contiguous(), r1.normals[0].contiguous())
         if self.marks:
             yield ("mark", "front_end", 0)
-        frags = self.splat_forward(fr)
+        frags, img = self.splat_forward(fr)
         if self.marks:
             yield ("mark", "raster_end", 0)
-        img = self.composite_band(frags, fr)
-        if self.marks:
-            yield ("mark", "composite_end", 0)
         # loss of SURVEY 8(d) cfg 3: mean((alpha - target)^2) [+ 1e-2 mean(rgb^2): no grad to the op]
         alpha = img[..., 3]
         y0, y1 = self.band_rows()

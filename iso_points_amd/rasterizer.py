@@ -96,11 +96,14 @@ class _CNamespace(object):
     def splat_points(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
                      num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel,
                      bin_size=0, max_points_per_bin=0, tile_rows=None, out=None, max_pts=None,
-                     pair_capacity=None, overflow_out=None, split_heavy_tiles=True):
+                     pair_capacity=None, overflow_out=None, split_heavy_tiles=True, composite_with=None,
+                     image_out=None):
         """-> (idx i32 (N,S,S,K), zbuf, qvalue f32 (N,S,S,K), occupancy f32 (N,S,S)).
         max_pts (upper bound of the points of a cloud) + pair_capacity (upper bound of the point-tile
         pairs): with both given nothing is read back to the host; an overflow of the pair list sets
         the int32 flag appended to `overflow_out` (checked by the caller when convenient).
+        composite_with=(scaler (P,), features (P,C), norm_weighted, eps): also composite the image in the
+        raster kernel (= composite(); iso_splat_render) into image_out (N,S,S,C+1): a 5th return value.
         bin_size / max_points_per_bin are accepted and ignored: binning is internal (16x16 tiles,
         exact-size pair list), so the reference's num_bins<22 / max_points_per_bin limits do not
         exist here.  tile_rows=(begin, end) (extension, used by the sharded path) rasterises
@@ -158,6 +161,17 @@ class _CNamespace(object):
             overflow_out.append(cursor[ntiles:])
         rws_b = lib.iso_splat_forward_workspace_bytes(N * T * (band[1] - band[0]), K) if split_heavy_tiles else 0
         rws = torch.empty((rws_b,), dtype=torch.uint8, device=dev) if rws_b else None
+        if composite_with is not None:
+            sc_, ft_, norm_, eps_ = composite_with
+            C = ft_.shape[1]
+            img = image_out if image_out is not None else (
+                torch.empty((N, S, S, C + 1), dtype=torch.float32, device=dev) if band == (0, T)
+                else torch.zeros((N, S, S, C + 1), dtype=torch.float32, device=dev))
+            _lib.call("iso_splat_render", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
+                      float(depth_merging_thres), S, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
+                      _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), p(rws), rws_b,
+                      p(_f32c(sc_)), p(_f32c(ft_)), C, int(bool(norm_)), float(eps_), p(img), s)
+            return idx, zbuf, qv, occ, img
         _lib.call("iso_splat_forward", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
                   float(depth_merging_thres), S, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
                   _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), p(rws), rws_b, s)
@@ -506,15 +520,42 @@ def gather_with_neg_idx(values, idx):
     return torch.where(idx >= 0, g, torch.zeros_like(g))
 
 
+class _Composite(autograd.Function):
+    """iso_splat_composite with its backward: gradients to the per-point features and scaler, the
+    fragments' qvalue and occupancy (idx carries none)."""
+
+    @staticmethod
+    def forward(ctx, idx, qvalue, occupancy, scaler, features, norm_weighted, eps):
+        N, S, S2, K = idx.shape
+        C = features.shape[1]
+        out = torch.empty((N, S, S2, C + 1), dtype=torch.float32, device=idx.device)
+        idx_c, qv, occ, sc, ft = idx.contiguous(), _f32c(qvalue), _f32c(occupancy), _f32c(scaler), _f32c(features)
+        _lib.call("iso_splat_composite", _lib.ptr(idx_c), _lib.ptr(qv), _lib.ptr(occ), _lib.ptr(sc), _lib.ptr(ft),
+                  N * S * S2, K, C, int(bool(norm_weighted)), float(eps), None, _lib.ptr(out), _lib.stream())
+        ctx.save_for_backward(idx_c, qv, sc, ft)
+        ctx.cfg = (int(bool(norm_weighted)), float(eps))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_img):
+        idx, qv, sc, ft = ctx.saved_tensors
+        N, S, S2, K = idx.shape
+        C = ft.shape[1]
+        need = ctx.needs_input_grad
+        g = _f32c(grad_img)
+        gq = torch.empty_like(qv) if need[1] else None
+        gocc = torch.empty((N, S, S2), dtype=torch.float32, device=idx.device) if need[2] else None
+        gsc = torch.zeros_like(sc) if need[3] else None
+        gft = torch.zeros_like(ft) if need[4] else None
+        p = _lib.ptr
+        _lib.call("iso_splat_composite_backward", p(idx), p(qv), p(sc), p(ft), p(g), N * S * S2, K, C, ctx.cfg[0],
+                  ctx.cfg[1], p(gft), p(gq), p(gsc), p(gocc), _lib.stream())
+        return None, gq, gocc, gsc, gft, None, None
+
+
 def composite(fragments, scaler, features, norm_weighted=True, eps=1e-4):
     """SurfaceSplattingRenderer.forward (renderer.py:53-78): per-pixel weights exp(-q/2)*scaler,
     (norm-)weighted sum of per-point features, occupancy appended as alpha -> (N,S,S,C+1).
-    `scaler` is the per-point EWA normaliser (P,), features (P,C) packed."""
-    idx, qv, occ = fragments.idx, fragments.qvalue, fragments.occupancy
-    N, S, _, K = idx.shape
-    C = features.shape[1]
-    out = torch.empty((N, S, S, C + 1), dtype=torch.float32, device=idx.device)
-    _lib.call("iso_splat_composite", _lib.ptr(idx.contiguous()), _lib.ptr(_f32c(qv)), _lib.ptr(_f32c(occ)),
-              _lib.ptr(_f32c(scaler)), _lib.ptr(_f32c(features)), N * S * S, K, C, int(bool(norm_weighted)),
-              float(eps), None, _lib.ptr(out), _lib.stream())
-    return out
+    `scaler` is the per-point EWA normaliser (P,), features (P,C) packed.  Differentiable with respect
+    to features, scaler, fragments.qvalue and fragments.occupancy like the reference's compositor."""
+    return _Composite.apply(fragments.idx, fragments.qvalue, fragments.occupancy, scaler, features, norm_weighted, eps)

@@ -183,6 +183,35 @@ def test_composite(dev):
         assert rel_err(got, ref) < 1e-5
 
 
+@pytest.mark.parametrize("norm", [True, False])
+def test_composite_backward_vs_autograd_of_the_oracle(dev, norm):
+    """renderer.py:53-78 composites through differentiable pytorch3d compositors: gradients of the image
+    with respect to features, scaler (fragment weights), qvalue and occupancy against torch autograd
+    through the oracle's restatement (float64)."""
+    SO = _SO()
+    from iso_points_amd.rasterizer import PointFragments, composite
+    S, K = 40, 6
+    sc = sphere_scene(2500, n_views=2, S=S, seed=56)
+    idx, zb, qv, occ = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"],
+                                        sc["num"], 0.05, S, K)
+    g = torch.Generator().manual_seed(1)
+    gimg = torch.randn(2, S, S, 4, generator=g)
+    feat = (0.5 * (sc["normals"] + 1)).double().requires_grad_(True)
+    scal = sc["scaler"].double().requires_grad_(True)
+    qd = qv.double().requires_grad_(True)
+    od = occ.double().requires_grad_(True)
+    fr = SO.PointFragments(idx, zb.double(), qd, SO.gather_scaler(scal, idx), od)
+    SO.composite(fr, feat, norm_weighted=norm, eps=1e-4).backward(gimg.double())
+    f2 = feat.detach().float().to(dev).requires_grad_(True)
+    s2 = scal.detach().float().to(dev).requires_grad_(True)
+    q2 = qv.to(dev).requires_grad_(True)
+    o2 = occ.to(dev).requires_grad_(True)
+    out = composite(PointFragments(idx.to(dev), zb.to(dev), q2, None, o2), s2, f2, norm_weighted=norm)
+    out.backward(gimg.to(dev))
+    assert rel_err(f2.grad, feat.grad) < 1e-5 and rel_err(s2.grad, scal.grad) < 1e-5
+    assert rel_err(q2.grad, qd.grad) < 1e-5 and torch.equal(o2.grad.cpu(), gimg[..., 3])
+
+
 def _grads(S, seed, sparse=True):
     g = torch.Generator().manual_seed(seed)
     go = torch.randn(2, S, S, generator=g)
@@ -316,6 +345,15 @@ def test_heavy_tiles_in_slices_equal_whole_tiles(dev, P, S, K):
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert (a[0] >= 0).float().mean() > 0.3
+    # raster + compositing in one kernel (iso_splat_render) = the two stand-alone calls, bit for bit
+    from iso_points_amd.rasterizer import PointFragments, composite
+    feat = (0.5 * (pf + 1)).to(dev)
+    scal = info["scaler"].to(dev)
+    for norm in (True, False):
+        r = _C.splat_points(*args, 0.05, S, K, composite_with=(scal, feat, norm, 1e-4))
+        for x, y in zip(r[:4], a):
+            assert torch.equal(x, y)
+        assert torch.equal(r[4], composite(PointFragments(a[0], a[1], a[2], None, a[3]), scal, feat, norm_weighted=norm))
 
 
 @pytest.mark.gpu
