@@ -107,7 +107,7 @@ class Cycle(object):
             if name == "project_end":
                 self._count_hook(T)
             return
-        if not self.timed:
+        if not self.timed or name not in ("project_begin", "project_end"):
             return
         e = torch.cuda.Event(enable_timing=True)
         e.record()

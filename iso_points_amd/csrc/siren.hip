@@ -336,6 +336,13 @@ extern "C" int64_t iso_project_siren_workspace_bytes(int64_t n, int hidden, int 
   return stash_floats_any(hidden, n_hidden) * 4 + 2 * n * 4 + 64 * 4 + 64;
 }
 
+constexpr int64_t kSmallListMax = 8192;     // 256 tiles of 32 points: one round of the persistent grid
+static bool siren_small_tiles_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ISO_SIREN_SMALL_TILES"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 // The iteration driver shared by the Newton projection and sphere tracing: launch `it` evaluates
 // the list launch it-1 left (device-side counts, no host read), the last one does not move.
 static int run_iterations(SirenArgs a, int hidden, int64_t n, int max_iters, void* workspace,
@@ -352,7 +359,15 @@ static int run_iterations(SirenArgs a, int hidden, int64_t n, int max_iters, voi
     a.idx_out = (it & 1) ? idxB : idxA;
     a.count_out = counts + it + 1;
     a.do_move = (it < max_iters) ? 1 : 0;
+    // from the third launch on (the list has usually shrunk) both tile shapes are issued; the device-side
+    // count decides which one works (per-point results do not depend on the shape)
+    const bool both = it >= 2 && hidden == 256 && !a.fwd_only && use_x3(hidden, a.L) && siren_small_tiles_enabled();
+    a.small_tiles = 0; a.cnt_lo = both ? kSmallListMax : -1; a.cnt_hi = INT64_MAX;
     ISO_REQUIRE(run_step(a, hidden, n, s) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size %d", who, hidden);
+    if (both) {
+      a.small_tiles = 1; a.cnt_lo = -1; a.cnt_hi = kSmallListMax;
+      ISO_REQUIRE(run_step(a, hidden, n, s) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size %d", who, hidden);
+    }
   }
   return ISO_OK;
 }

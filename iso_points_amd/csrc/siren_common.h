@@ -24,6 +24,11 @@ struct SirenArgs {
   const float* dirs = nullptr;
   float alpha = 1.f, bound = 0.f, tol_valid = 0.f;
   int fwd_only = 0;          // 1: the gradient is not needed (evaluation of the value / tracing)
+  // a launch only works when cnt_lo < (device-side) count <= cnt_hi: the late Newton iterations are issued
+  // twice, as the 96-point-tile kernel for long lists and as the 32-point-tile kernel for short ones
+  // (a short list costs one tile time per launch whatever its length: 54 us against 25 us)
+  int64_t cnt_lo = -1, cnt_hi = INT64_MAX;
+  int small_tiles = 0;
 };
 
 // ---- packed weight buffer, f32 section (siren.hip) ---------------------------------------

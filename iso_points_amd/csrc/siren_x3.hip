@@ -111,7 +111,8 @@ __global__ void k_siren_wscale(const float* __restrict__ raw, float* __restrict_
   const int64_t HH = (int64_t)H * H;
   const float* Wl = raw + (int64_t)H * 4 + (int64_t)l * (HH + H);
   float m = 0.f;
-  for (int64_t i = threadIdx.x; i < HH; i += 256) {
+#pragma unroll 16
+  for (int64_t i = threadIdx.x; i < HH; i += 256) {        // (16 loads in flight: the loop is a latency chain otherwise)
     const float a = fabsf(Wl[i]);
     m = (a == a && a > m) ? a : m;
   }
@@ -138,6 +139,7 @@ __global__ void k_siren_wscale(const float* __restrict__ raw, float* __restrict_
   float cs = 0.f;
   for (int f = threadIdx.x; f < H; f += 256) {
     float t = 0.f;
+#pragma unroll 16
     for (int k = 0; k < H; ++k) t += fabsf(Wl[(int64_t)k * H + f]);
     cs = fmaxf(cs, t);
   }
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   x3_prefetch_a<TW, NTO, FP>(A, fwd_img(0), 0, lane);
 
   const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
+  if (count <= a.cnt_lo || count > a.cnt_hi) return;       // the other tile shape serves this list (uniform)
   const int64_t n_tiles = (count + P - 1) / P;
 #ifdef X3_DBG_TIMES
   long long* dbg = reinterpret_cast<long long*>(a.stash + (int64_t)gridDim.x * S::kStashPerWg(L)) - NW * 128;
@@ -733,6 +736,7 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
 }
 
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
+  if (a.small_tiles && H == 256 && !a.fwd_only) return launch_x3<256, X3_NW, 1, X3_MINB256, false>(a, n_upper, s);
   if (a.fwd_only) {
     if (H == 256) return launch_x3<256, X3_NW, X3_NB256, X3_MINB256, true>(a, n_upper, s);
     if (H == 128) return launch_x3<128, 4, 3, X3_MINB128, true>(a, n_upper, s);

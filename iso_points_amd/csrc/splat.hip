@@ -687,10 +687,10 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
   }
 }
 
-// Work items of a band (see k_raster): tiles with more than kSplitMin candidates are cut into slices of
-// about kSlice candidates as long as the scratch slots last; slices first, then the whole tiles heaviest
+// Work items of a band (see k_raster): tiles with more than 1.5 slices of candidates are cut into slices
+// (<= kSlice candidates each) as long as the scratch slots last; slices first, then the whole tiles heaviest
 // first.  heavy[h] = (tile, first scratch slot, slices).  counters: [0] items, [1] heavy tiles.
-constexpr int kSplitMin = 1536, kSlice = 1024;
+constexpr int kSlice = 1024, kTargetItems = 2048;
 __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__ tile_off, int T, int ty_begin,
                                                      int ty_rows, int n_clouds, int max_slots,
                                                      int4* __restrict__ items, int4* __restrict__ heavy,
@@ -700,8 +700,20 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
   const int tiles = n_clouds * T * ty_rows;
   auto tile_of = [&](int i) { return ((i / (T * ty_rows)) * T + ty_begin + (i / T) % ty_rows) * T + i % T; };
   auto count_of = [&](int tile) { return tile_off[tile + 1] - tile_off[tile]; };
-  // slice size: kSlice, doubled until the slices of all heavy tiles fit the scratch slots
-  if (threadIdx.x == 0) s_slice = kSlice;
+  // slice size: total candidates / kTargetItems (so that a small band still yields enough work items to
+  // fill the chip), within [256, kSlice], doubled until the slices of all cut tiles fit the scratch slots
+  if (threadIdx.x == 0) s_slots = 0;
+  __syncthreads();
+  {
+    int mine = 0;
+    for (int i = threadIdx.x; i < tiles; i += blockDim.x) mine += count_of(tile_of(i));
+    if (mine) atomicAdd(&s_slots, mine);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int sl0 = (s_slots / kTargetItems + 255) / 256 * 256;
+    s_slice = sl0 < 256 ? 256 : (sl0 > kSlice ? kSlice : sl0);
+  }
   __syncthreads();
   for (int round = 0; round < 16; ++round) {
     if (threadIdx.x == 0) s_slots = 0;
@@ -710,7 +722,7 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
     int mine = 0;
     for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
       const int c = count_of(tile_of(i));
-      if (c > kSplitMin && c > sl) mine += (c + sl - 1) / sl;
+      if (2 * c > 3 * sl) mine += (c + sl - 1) / sl;
     }
     if (mine) atomicAdd(&s_slots, mine);
     __syncthreads();
@@ -721,7 +733,7 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
     __syncthreads();
   }
   const int sl = s_slice;
-  auto slices_of = [&](int c) { return (c > kSplitMin && c > sl && max_slots > 0) ? (c + sl - 1) / sl : 1; };
+  auto slices_of = [&](int c) { return (2 * c > 3 * sl && max_slots > 0) ? (c + sl - 1) / sl : 1; };
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   if (threadIdx.x == 0) { s_slots = 0; s_heavy = 0; }
   __syncthreads();
@@ -1278,6 +1290,7 @@ extern "C" int64_t iso_splat_forward_workspace_bytes(int64_t n_tiles, int points
   const int KM = K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 16 ? 16 : 32));
   if (n_tiles < 0) n_tiles = 0;
   int64_t slots = n_tiles / 2 + 256;               // room to cut every other tile once; k_tile_items adapts the slice size
+  if (slots < 2048) slots = 2048;                  // a small band is cut finer (enough work items to fill the chip)
   if (slots > 8192) slots = 8192;
   return 64 + 32 * n_tiles + slots * (16 + (int64_t)3 * KM * 256 * 4);
 }
