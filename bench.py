@@ -145,6 +145,36 @@ class Cycle(object):
         return counts
 
 
+def measured_traffic(x3):
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        return d["k_siren_step_x3" if x3 else "k_siren_step"]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def f32_mode_cycle(dev, model, comm, steps=3):
+    """The same cycle with the hidden-layer products on the f32 matrix cores (iso_siren_set_gemm_mode(0)):
+    printed beside the split-fp16 headline."""
+    from iso_points_amd import _lib
+    lib = _lib.load()
+    lib.iso_siren_set_gemm_mode(0)
+    try:
+        os.environ["ISO_BENCH_GRAPHS"] = "0"
+        cyc = Cycle(dev, model, comm)
+        cyc.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cyc.step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        lib.iso_siren_set_gemm_mode(1)
+    return {"ms_per_step": round(ms, 4), "value": round(P_TOTAL / (ms * 1e-3) / 1e6, 3), "unit": "Mpoints/s",
+            "note": "hidden-layer products on v_mfma_f32_16x16x4_f32 (k_siren_step<16>), everything else unchanged"}
+
+
 def analytic_cycle(dev, comm, args):
     """SURVEY 8(d) cfg 3a: the same cycle with the analytic sphere SDF -- the HBM-bound variant.
     Reported beside the headline (cfg 3b), not instead of it."""
@@ -168,7 +198,11 @@ def analytic_cycle(dev, comm, args):
 
 def cpu_baseline(gpu_model):
     """The oracle (CPU restatement of the reference's pure-PyTorch path + C rasteriser) timed on
-    the host cores on a bounded sample of the same workload (same fitted SIREN weights)."""
+    the host cores of this box: (1) the whole cycle on a bounded sample of the same
+    workload (same fitted SIREN weights) = `value`; (2) the point stages one by one at FULL size with
+    the analytic sphere SDF (project T=10, FRNN K+1=9, one repulsion step, project T=3) -- the FRNN of
+    1 M points by scipy's cKDTree (the oracle's exact search is a chunked brute force, O(P^2));
+    (3) the SIREN projection on 100 k points (its cost is linear in P)."""
     from oracle import iso_oracle as O
     from oracle import splat_oracle as SO
     ncores = torch.get_num_threads()
@@ -196,19 +230,60 @@ def cpu_baseline(gpu_model):
     info = SO.per_point_info(pf, nf, h, M44, S)
     ndc = SO.transform_to_ndc(pf, view, M44)
     first, numv = torch.tensor([0]), torch.tensor([pf.shape[0]])
+    ts = time.perf_counter()
     idx, zb, qv, occ = SO.splat_forward(ndc, info["ellipse_params"], info["cutoff_threshold"], info["radii"],
                                         first, numv, 0.05, S, KPIX)
+    t_fwd = time.perf_counter() - ts
     fr = SO.PointFragments(idx, zb, qv, SO.gather_scaler(info["scaler"], idx), occ)
     img = SO.composite(fr, 0.5 * (torch.nn.functional.normalize(nf, dim=-1) + 1))
     go = 2.0 * (img[..., 3] - 0.5) / img[..., 3].numel()
     gz = torch.zeros_like(zb)
+    ts = time.perf_counter()
     SO.splat_backward(ndc, info["radii"], idx, first, numv, go, gz, 10.0)
+    t_bwd = time.perf_counter() - ts
     t_all = time.perf_counter() - t0
+    stages = {"sample_cycle_s": round(t_all, 2), "sample_project_resample_s": round(t_pr, 2),
+              "sample_splat_forward_s": round(t_fwd, 2), "sample_splat_backward_s": round(t_bwd, 2),
+              "sample": "%d points, splat %dx%dx%d view" % (P, S, S, V)}
+    # (2) full-size point stages, analytic SDF
+    try:
+        import numpy as np
+        from scipy.spatial import cKDTree
+        PF = P_TOTAL
+        g = torch.Generator().manual_seed(0)
+        full = torch.nn.functional.normalize(torch.randn(1, PF, 3, generator=g), dim=-1)
+        full = full + 0.05 * (torch.rand(1, PF, 3, generator=g) - 0.5)
+        numf = torch.tensor([PF])
+        sph = O.SphereSDF()
+        ts = time.perf_counter()
+        q0 = O.project_points(sph, full, numf, proj_max_iters=10)
+        stages["full_project_T10_sphere_s"] = round(time.perf_counter() - ts, 2)
+        r = float(O.search_radius(q0.points, numf, 8))
+        ts = time.perf_counter()
+        tree = cKDTree(q0.points[0].numpy())
+        dd, ii = tree.query(q0.points[0].numpy(), k=9, distance_upper_bound=r, workers=-1)
+        stages["full_frnn_K9_ckdtree_s"] = round(time.perf_counter() - ts, 2)
+        ii = torch.from_numpy(np.where(np.isfinite(dd), ii, -1).astype(np.int64))[None, :, 1:]
+        diag = (q0.points.view(-1, 3).max(0).values - q0.points.view(-1, 3).min(0).values).norm().item()
+        ts = time.perf_counter()
+        moved = O.repulsion_step(q0.points, torch.nn.functional.normalize(q0.normals, dim=-1), ii, numf / diag)
+        stages["full_repulsion_s"] = round(time.perf_counter() - ts, 2)
+        ts = time.perf_counter()
+        O.project_points(sph, moved, numf, proj_max_iters=3)
+        stages["full_project_T3_sphere_s"] = round(time.perf_counter() - ts, 2)
+        stages["full_points"] = PF
+        # (3) SIREN projection, 100 k points
+        ts = time.perf_counter()
+        O.project_points(m, full[:, :100000], torch.tensor([100000]), proj_max_iters=10)
+        stages["siren_project_T10_100k_s"] = round(time.perf_counter() - ts, 2)
+    except Exception as e:                    # the per-stage block is informative; the baseline of record is (1)
+        stages["full_size_error"] = repr(e)
     return {"value": round(P / t_all / 1e6, 6), "unit": "Mpoints/s", "cores": ncores, "kind": "port",
             "sample": "oracle (torch-CPU restatement of the reference's PyTorch path, %d threads; C rasteriser "
                       "single-threaded) on %d points, SIREN 4x256 fitted, project T=10 + resample + splat "
                       "fwd/bwd at %dx%dx%d view: %.1f s total, %.1f s project+resample"
-                      % (ncores, P, S, S, V, t_all, t_pr)}
+                      % (ncores, P, S, S, V, t_all, t_pr),
+            "stages": stages}
 
 
 def main():
@@ -310,12 +385,13 @@ def main():
                          "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),
                          "frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                         # HBM-side bytes per launch from the PMC passes of this same command
-                         # (profiles/r01_v12_pmc_3.txt, _4.txt: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction);
-                         # bench.py cannot run rocprofv3 on itself, so this is the committed measurement
-                         "traffic": 2.047e9 if x3 else 2.47e9,
-                         "traffic_note": "bytes/launch, PMC (2*FETCH_SIZE+WRITE_SIZE) from profiles/; algorithmic point "
-                                         "I/O is %.1f MB/launch -- the rest is the w*cos stash round trip"
+                         # HBM-side bytes per launch: bench.py cannot run rocprofv3 on itself; the PMC passes of this
+                         # same command (tools/pmc_run.sh; 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) leave
+                         # their result in profiles/r02_traffic.json, read here -- null when that file is absent
+                         "traffic": measured_traffic(x3),
+                         "traffic_note": "bytes/launch of the dominant kernel, PMC (2*FETCH_SIZE+WRITE_SIZE) of this "
+                                         "command, from profiles/r02_traffic.json; algorithmic point I/O is %.1f MB/launch "
+                                         "-- the rest is the w*cos stash round trip"
                                          % (evals_per_step / max(launches_per_step, 1) * 37 / 1e6),
                          "peak_note": ("fp16 dense MFMA peak 2516.6 / 3 passes per f32 product; executed fp16 "
                                        "rate = %.1f TFLOP/s" % (ach * X3_PASSES)) if x3
@@ -328,6 +404,7 @@ def main():
         }
         if world == 1:
             out["cfg3a_analytic_sdf"] = analytic_cycle(dev, comm, args)
+            out["f32_mfma_mode"] = f32_mode_cycle(dev, model, comm)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))

@@ -522,15 +522,18 @@ int iso_bricks_build(const float* points, const float* normals, const int32_t* p
  * (world, 8) floats, every rank's local iso_points_bbox), the export buffers are all-gathered
  * (one RCCL all-gather of `export_buf`: float4[2][capacity + 1], word 0 = record count), and each
  * rank keeps what its own queries can reach (iso_halo_import) as the imported records of
- * iso_bricks_build (bbox = NULL: header already written).  Overflows are counted in the grid's
- * counters (slot 4: an exporter ran out of capacity, slot 5: the import buffer did).          */
+ * iso_bricks_build (bbox = NULL: header already written).  halo_cells: width of the exchanged band in
+ * fine cells (>= 1; the fused kernels certify their results within one cell, the tail kernels -- a query
+ * whose K-th neighbour lies farther -- check their search ball against the imported band and count the
+ * queries that left it).  The grid's counters: slot 4 an exporter ran out of capacity, slot 5 the import
+ * buffer did, slot 6 tail queries that needed more than the imported band.                       */
 int iso_bricks_params(const float* bbox, int64_t n_total, int64_t n_own, int64_t id_base, float radius,
                       int knn_k, float cell_scale, void* workspace, int64_t n_max, void* stream);
 int iso_halo_export(void* workspace, const float* points, const float* normals, const int32_t* payload,
-                    int64_t n_own, const float* rank_boxes, int world, int rank, float* export_buf,
-                    int64_t capacity, void* stream);
+                    int64_t n_own, const float* rank_boxes, int world, int rank, int halo_cells,
+                    float* export_buf, int64_t capacity, void* stream);
 int iso_halo_import(void* workspace, int64_t n_max, const float* gathered, const float* rank_boxes, int world,
-                    int rank, int64_t capacity, float* import_rec0, float* import_rec1,
+                    int rank, int halo_cells, int64_t capacity, float* import_rec0, float* import_rec1,
                     int32_t* import_count, int64_t import_capacity, void* stream);
 /* One resample move of every own point: K+1 = k_plus_one self-inclusive FRNN query (radius of
  * the build), column 0 dropped, tangent-plane repulsion with inv_sigma = n_total / diag

@@ -25,7 +25,8 @@ struct BrickHdr {                      // device resident, 32 dwords
   int nb[3]; int n_bricks;             // 16..19
   int nf[3]; int n;                    // 20..23  fine cells per axis (4 nb), points in the grid (own + imported)
   int n_own; int id_base; int g_covers_r; int n_total;  // 24..27
-  int pad1[4];                         // 28..31
+  float x_lo, x_hi;                    // 28..29  N ranks: x-range inside which this rank holds EVERY point of the cloud
+  int pad1[2];                         // 30..31
 };
 
 constexpr int BK_CAP = 1024;           // staged candidates per brick (10-bit slot field of the selection keys)
@@ -42,7 +43,8 @@ static inline int bricks_nb_cap(int64_t n_max) {
 
 struct BrickWs {      // carved out of one caller-owned workspace
   BrickHdr* hdr;
-  int32_t* counters;  // [0] list_count  [1] tail_count  [2] overflow bricks  [3] tail2_count  (16 ints)
+  int32_t* counters;  // [0] list_count  [1] tail_count  [2] overflow bricks  [3] tail2_count  [4] export overflow
+                      // [5] import overflow  [6] tail queries whose search left the imported halo  (16 ints)
   int32_t* cnt;       // [G]
   int32_t* off;       // [G]
   int32_t* slot;      // [n_max]

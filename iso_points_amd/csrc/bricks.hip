@@ -102,6 +102,7 @@ __global__ void k_bricks_params(const float* __restrict__ bbox, int64_t n_total,
   h->n_own = (int)n_own; h->id_base = (int)id_base;
   h->g_covers_r = g >= r ? 1 : 0;
   h->n_total = (int)n_total;
+  h->x_lo = -FLT_MAX; h->x_hi = FLT_MAX;
   for (int i = 0; i < 16; ++i) counters[i] = 0;
 }
 
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(64) void k_brick_resample_tail(
     }
     Repulse R;
     R.px = qx; R.py = qy; R.pz = qz; R.inv_sigma = h.inv_sigma;
-    wave_merge3<KMAX>(best, K, [&](int k, float md, int mi, int ma) {
+    const float kthf = wave_merge3<KMAX>(best, K, [&](int k, float md, int mi, int ma) {
       if (k == 0) return;                                  // column 0 is dropped (levelset_sampling.py:136-138)
       if (md < FLT_MAX) {
         const float4 c = rec0[ma];
@@ -640,7 +641,11 @@ __global__ __launch_bounds__(64) void k_brick_resample_tail(
         if (d2_out) d2_out[(int64_t)row * (K - 1) + k - 1] = md < FLT_MAX ? md : -1.0f;
       }
     });
-    if (lane == 0) R.finish(out + (int64_t)row * 3);
+    if (lane == 0) {
+      R.finish(out + (int64_t)row * 3);
+      const float need = kthf < FLT_MAX ? sqrtf(kthf) : h.r;         // how far this query had to look
+      if (qx - need < h.x_lo || qx + need >= h.x_hi) atomicAdd(const_cast<int32_t*>(&counters[6]), 1);
+    }
   }
 }
 
@@ -861,7 +866,11 @@ __global__ __launch_bounds__(64) void k_brick_h_tail(
       }
     }
     wave_merge_f7(best, m7);
-    if (lane == 0) h_out[(int64_t)v * h.n_own + row] = h_from_list(m7, small_cloud);
+    if (lane == 0) {
+      h_out[(int64_t)v * h.n_own + row] = h_from_list(m7, small_cloud);
+      const float need = m7[6] < FLT_MAX ? sqrtf(m7[6]) : h.r;
+      if (!small_cloud && (qx - need < h.x_lo || qx + need >= h.x_hi)) atomicAdd(const_cast<int32_t*>(&counters[6]), 1);
+    }
   }
 }
 
@@ -884,7 +893,7 @@ __device__ __forceinline__ void wave_append(bool take, int32_t* counter, int cap
 __global__ __launch_bounds__(256) void k_halo_export(const float* __restrict__ pts, const float* __restrict__ nrm,
                                                      const int32_t* __restrict__ payload, int64_t n_own,
                                                      const BrickHdr* __restrict__ hp, const float* __restrict__ ranges,
-                                                     int world, int rank, float4* __restrict__ out, int cap) {
+                                                     int world, int rank, int halo, float4* __restrict__ out, int cap) {
   const BrickHdr h = *hp;
   int32_t* counter = reinterpret_cast<int32_t*>(out);
   const int64_t span = (int64_t)gridDim.x * blockDim.x;
@@ -897,8 +906,8 @@ __global__ __launch_bounds__(256) void k_halo_export(const float* __restrict__ p
       const int fx = bk_fine(x, h.mn[0], h.inv_f, h.nf[0]);
       for (int k = 0; k < world; ++k) {
         if (k == rank) continue;
-        const int lo = bk_fine(ranges[k * 8], h.mn[0], h.inv_f, h.nf[0]) - 1;
-        const int hi = bk_fine(ranges[k * 8 + 4], h.mn[0], h.inv_f, h.nf[0]) + 1;
+        const int lo = bk_fine(ranges[k * 8], h.mn[0], h.inv_f, h.nf[0]) - halo;
+        const int hi = bk_fine(ranges[k * 8 + 4], h.mn[0], h.inv_f, h.nf[0]) + halo;
         take = take || (fx >= lo && fx <= hi);
       }
     }
@@ -914,18 +923,26 @@ __global__ __launch_bounds__(256) void k_halo_export(const float* __restrict__ p
 }
 
 __global__ __launch_bounds__(256) void k_halo_import(const float4* __restrict__ gathered, int world, int rank, int cap,
-                                                     const BrickHdr* __restrict__ hp, const float* __restrict__ ranges,
+                                                     int halo, BrickHdr* __restrict__ hp, const float* __restrict__ ranges,
                                                      float4* __restrict__ imp0, float4* __restrict__ imp1,
                                                      int32_t* __restrict__ imp_count, int imp_cap,
                                                      int32_t* __restrict__ counters) {
   const int src = blockIdx.y;
-  if (src == rank) return;
   const BrickHdr h = *hp;
+  const int lo = bk_fine(ranges[rank * 8], h.mn[0], h.inv_f, h.nf[0]) - halo;
+  const int hi = bk_fine(ranges[rank * 8 + 4], h.mn[0], h.inv_f, h.nf[0]) + halo;
+  if (src == rank) {
+    // everything the cloud holds in fine x-cells [lo, hi] is on this rank now: the tail kernels check their
+    // search balls against this range (a query that needs more is counted, IsoCycle.check reports it)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      hp->x_lo = lo <= 0 ? -FLT_MAX : h.mn[0] + (float)lo * h.f;
+      hp->x_hi = hi >= h.nf[0] - 1 ? FLT_MAX : h.mn[0] + (float)(hi + 1) * h.f;
+    }
+    return;
+  }
   const float4* blk = gathered + (int64_t)src * 2 * (cap + 1);
   int cnt = __float_as_int(blk[0].x);
   if (cnt > cap) { cnt = cap; if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[4], 1); }   // the exporter overflowed
-  const int lo = bk_fine(ranges[rank * 8], h.mn[0], h.inv_f, h.nf[0]) - 1;
-  const int hi = bk_fine(ranges[rank * 8 + 4], h.mn[0], h.inv_f, h.nf[0]) + 1;
   const int span = gridDim.x * blockDim.x;
   for (int j0 = blockIdx.x * blockDim.x; j0 < cnt; j0 += span) {
     const int j = j0 + threadIdx.x;
@@ -1011,8 +1028,8 @@ extern "C" int iso_bricks_params(const float* bbox, int64_t n_total, int64_t n_o
 }
 
 extern "C" int iso_halo_export(void* workspace, const float* points, const float* normals, const int32_t* payload,
-                               int64_t n_own, const float* rank_boxes, int world, int rank, float* export_buf,
-                               int64_t capacity, void* stream) {
+                               int64_t n_own, const float* rank_boxes, int world, int rank, int halo_cells,
+                               float* export_buf, int64_t capacity, void* stream) {
   ISO_REQUIRE(workspace && rank_boxes && export_buf && world >= 1 && rank >= 0 && rank < world && capacity >= 0 &&
                   capacity < (1ll << 30) && (points || n_own == 0),
               ISO_ERR_INVALID, "iso_halo_export: bad arguments");
@@ -1020,23 +1037,23 @@ extern "C" int iso_halo_export(void* workspace, const float* points, const float
   iso_zero_words(export_buf, 4, s);
   if (n_own > 0)
     hipLaunchKernelGGL(k_halo_export, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, normals, payload, n_own,
-                       (const BrickHdr*)workspace, rank_boxes, world, rank, (float4*)export_buf, (int)capacity);
+                       (const BrickHdr*)workspace, rank_boxes, world, rank, halo_cells, (float4*)export_buf, (int)capacity);
   ISO_CHECK_LAUNCH("iso_halo_export");
   return ISO_OK;
 }
 
 extern "C" int iso_halo_import(void* workspace, int64_t n_max, const float* gathered, const float* rank_boxes, int world,
-                               int rank, int64_t capacity, float* import_rec0, float* import_rec1,
+                               int rank, int halo_cells, int64_t capacity, float* import_rec0, float* import_rec1,
                                int32_t* import_count, int64_t import_capacity, void* stream) {
   ISO_REQUIRE(workspace && gathered && rank_boxes && import_rec0 && import_rec1 && import_count && world >= 1 &&
-                  rank >= 0 && rank < world && capacity >= 0 && import_capacity >= 0,
+                  rank >= 0 && rank < world && capacity >= 0 && import_capacity >= 0 && halo_cells >= 1,
               ISO_ERR_INVALID, "iso_halo_import: bad arguments");
   const BrickWs w = bricks_carve(workspace, n_max);
   hipStream_t s = (hipStream_t)stream;
   iso_zero_words(import_count, 1, s);
   if (capacity > 0 && world > 1)
     hipLaunchKernelGGL(k_halo_import, dim3(iso_stream_grid(capacity, 256) > 64 ? 64 : iso_stream_grid(capacity, 256), world),
-                       dim3(256), 0, s, (const float4*)gathered, world, rank, (int)capacity, w.hdr, rank_boxes,
+                       dim3(256), 0, s, (const float4*)gathered, world, rank, (int)capacity, halo_cells, w.hdr, rank_boxes,
                        (float4*)import_rec0, (float4*)import_rec1, import_count, (int)import_capacity, w.counters);
   ISO_CHECK_LAUNCH("iso_halo_import");
   return ISO_OK;

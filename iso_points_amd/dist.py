@@ -155,6 +155,7 @@ class IsoCycle(object):
         self.import_cap = 0 if w == 1 else max(4096, 2 * self.n_own)
         self.rec_cap = max(self.N * self.n_own, 1)
         self.pair_cap = max(1 << 16, 6 * self.N * self.P // w)
+        self.halo_cells = 2           # exchanged band, in fine cells (2 x 0.8 r covers the FRNN radius r)
         self._alloc()
         self._ovf = []
 
@@ -187,9 +188,10 @@ class IsoCycle(object):
         lib_call("iso_bricks_params", p(gbox), self.P, self.n_own, self.lo, float(radius), int(knn_k), float(cell_scale),
                  p(g.ws), g.n_max, _lib.stream())
         lib_call("iso_halo_export", p(g.ws), p(pts), p(nrm), p(payload), self.n_own, p(boxes), self.world, self.rank,
-                 p(self.exp_buf), self.halo_cap, _lib.stream())
+                 self.halo_cells, p(self.exp_buf), self.halo_cap, _lib.stream())
         gathered = yield ("all_gather", self.exp_buf)
-        lib_call("iso_halo_import", p(g.ws), g.n_max, p(gathered), p(boxes), self.world, self.rank, self.halo_cap,
+        lib_call("iso_halo_import", p(g.ws), g.n_max, p(gathered), p(boxes), self.world, self.rank, self.halo_cells,
+                 self.halo_cap,
                  p(self.imp0), p(self.imp1), p(self.imp_count), self.import_cap, _lib.stream())
         g.build(pts, nrm, payload=payload, params_done=True, id_base=self.lo, n_total=self.P,
                 imports=(self.imp0, self.imp1, self.imp_count))
@@ -430,7 +432,7 @@ class IsoCycle(object):
         """Host read of the device-side counts of the last cycle (set-up / tests only)."""
         hdr = self.grid.header()
         c = self.grid.ws[256:320].cpu().view(torch.int32).tolist()
-        u = {"grid": hdr, "halo_export_overflow": c[4], "halo_import_overflow": c[5],
+        u = {"grid": hdr, "halo_export_overflow": c[4], "halo_import_overflow": c[5], "halo_uncertified": c[6],
              "pair_overflow": int(self._ovf[0].item()) if self._ovf else 0}
         if self.world > 1:
             u["halo_exported"] = int(self.exp_buf[:1].view(torch.int32).item())
@@ -441,7 +443,7 @@ class IsoCycle(object):
 
     def check(self, fr=None):
         u = self.usage(fr)
-        bad = [k for k in ("halo_export_overflow", "halo_import_overflow", "pair_overflow") if u[k]]
+        bad = [k for k in ("halo_export_overflow", "halo_import_overflow", "halo_uncertified", "pair_overflow") if u[k]]
         if self.world > 1 and (u["halo_exported"] > self.halo_cap or u["halo_imported"] > self.import_cap):
             bad.append("halo capacity")
         if fr is not None and self.world > 1 and u["own_rows"] > self.rec_cap:
