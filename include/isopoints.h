@@ -398,17 +398,23 @@ int iso_splat_setup(const float* points, const float* normals, const float* h,
  * workspace (optional, NULL = none): iso_splat_forward_workspace_bytes(tiles of the band, K); with it
  * the tiles that hold many times the mean number of candidates (silhouettes) are rasterised in slices
  * by several workgroups and merged -- same result, the longest work item is a slice.
+ * Non-square images (beyond the reference, whose rasteriser is square-only, rasterizer.py:52): image_size
+ * = rows H, image_width = columns W (<= 0: W = H); outputs (N,H,W,K).  NDC follows pytorch3d's non-square
+ * convention: the shorter side spans [-1,1], the longer [-e,e], e = longer / shorter -- square pixels of
+ * 2 / min(H,W); the per-point set-up (iso_splat_setup / iso_splat_front) takes image_size = min(H,W).
+ * T = iso_splat_tiles_per_side(H) tile rows, iso_splat_tiles_per_side(W) tile columns.
  * [tile_row_begin, tile_row_end) restricts both calls to a band of tile rows (in NDC pixel
  * order, i.e. before the flip): a rank of a sharded run rasterises only its band and leaves
  * the other pixels of the output tensors untouched; pass 0, T for the whole image.          */
 int iso_splat_tiles_per_side(int image_size);
 int iso_splat_bin_count(const float* points, const float* radii, const int64_t* first_idx,
                         const int64_t* num_pts, int n_clouds, int64_t max_pts, int image_size,
-                        int tile_row_begin, int tile_row_end, int32_t* tile_cnt, void* stream);
+                        int image_width, int tile_row_begin, int tile_row_end, int32_t* tile_cnt,
+                        void* stream);
 int iso_splat_forward(const float* points, const float* ellipse, const float* cutoff,
                       const float* radii, const int64_t* first_idx, const int64_t* num_pts,
                       int n_clouds, int64_t max_pts, float depth_merging_thres, int image_size,
-                      int points_per_pixel, int tile_row_begin, int tile_row_end,
+                      int image_width, int points_per_pixel, int tile_row_begin, int tile_row_end,
                       int32_t* tile_cursor, const int32_t* tile_off,
                       int32_t* pairs, int64_t pair_capacity, int32_t* overflow_flag,
                       int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out,
@@ -420,7 +426,7 @@ int64_t iso_splat_forward_workspace_bytes(int64_t n_tiles, int points_per_pixel)
 int iso_splat_render(const float* points, const float* ellipse, const float* cutoff,
                      const float* radii, const int64_t* first_idx, const int64_t* num_pts,
                      int n_clouds, int64_t max_pts, float depth_merging_thres, int image_size,
-                     int points_per_pixel, int tile_row_begin, int tile_row_end,
+                     int image_width, int points_per_pixel, int tile_row_begin, int tile_row_end,
                      int32_t* tile_cursor, const int32_t* tile_off,
                      int32_t* pairs, int64_t pair_capacity, int32_t* overflow_flag,
                      int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out,
@@ -472,12 +478,13 @@ int iso_splat_median_radius(const float* radii, const uint8_t* visible, const in
                             const int64_t* num_pts, int n_clouds, int64_t max_pts, float radii_s,
                             void* workspace, int64_t workspace_bytes, float* search_radius_out,
                             void* stream);
-int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size, int64_t total_points);
+int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size, int image_width,
+                                           int64_t total_points);
 int iso_splat_backward(const float* points, const float* radii, const uint8_t* visible,
                        const float* search_radius, const int64_t* first_idx,
                        const int64_t* num_pts, int n_clouds, int64_t max_pts,
                        const float* grad_occ, const int32_t* idx, const float* grad_zbuf,
-                       int image_size, int points_per_pixel, int rect_mode, float radii_s,
+                       int image_size, int image_width, int points_per_pixel, int rect_mode, float radii_s,
                        int64_t total_points, void* workspace, int64_t workspace_bytes,
                        float* grad_points, void* stream);
 /* _C._backward_zbuf alone (rasterize_points.cu:823-846): z_grad[idx] += grad_zbuf
@@ -583,7 +590,7 @@ int iso_splat_front(const float* points, const float* normals, const float* feat
  * order independent like the single-GPU path (ZbufBackwardKernel, rasterize_points.cu:823-846).     */
 int iso_splat_z_absmax(const float* grad_zbuf, int64_t n, int32_t* zscale, void* stream);
 int iso_splat_z_scatter(const int32_t* idx, const float* grad_zbuf, int64_t n_pixels, int points_per_pixel,
-                        int image_size, int32_t* zscale, int64_t* acc, void* stream);
+                        int64_t pixels_per_view, int32_t* zscale, int64_t* acc, void* stream);
 int iso_splat_z_finish(const int64_t* acc, const int32_t* zscale, int64_t row0, int64_t n_rows,
                        float* grad_points, void* stream);
 /* N ranks: the packed per-view arrays of the WHOLE cloud (view-major, then rank, then the rank's own

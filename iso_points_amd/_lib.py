@@ -67,19 +67,19 @@ SIGNATURES = {
     "iso_splat_vrk_h": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "iso_splat_setup": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "iso_splat_tiles_per_side": (_I, [_I]),
-    "iso_splat_bin_count": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P]),
-    "iso_splat_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P,
+    "iso_splat_bin_count": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P, _P]),
+    "iso_splat_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P,
                                _L, _P]),
     "iso_splat_forward_workspace_bytes": (_L, [_L, _I]),
-    "iso_splat_render": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P,
+    "iso_splat_render": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P,
                               _L, _P, _P, _I, _I, _F, _P, _P]),
     "iso_splat_composite": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _P, _P]),
     "iso_splat_composite_backward": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
     "iso_splat_mark_visible": (_I, [_P, _L, _I, _P, _P]),
     "iso_splat_median_radius_workspace_bytes": (_L, [_I]),
     "iso_splat_median_radius": (_I, [_P, _P, _P, _P, _I, _L, _F, _P, _L, _P, _P]),
-    "iso_splat_backward_workspace_bytes": (_L, [_I, _I, _L]),
-    "iso_splat_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _I, _I, _I, _F, _L, _P, _L, _P, _P]),
+    "iso_splat_backward_workspace_bytes": (_L, [_I, _I, _I, _L]),
+    "iso_splat_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _I, _I, _I, _I, _F, _L, _P, _L, _P, _P]),
     "iso_splat_zbuf_backward": (_I, [_P, _P, _L, _I, _P, _P]),
     "iso_bricks_workspace_bytes": (_L, [_L]),
     "iso_bricks_build": (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _L, _P, _L, _F, _I, _F, _P, _L, _P]),
@@ -90,7 +90,7 @@ SIGNATURES = {
     "iso_splat_view_mask": (_I, [_P, _P, _P, _I, _L, _F, _F, _I, _P, _P, _P]),
     "iso_splat_h_fused": (_I, [_P, _L, _P, _P, _L, _P, _I, _P, _P]),
     "iso_splat_z_absmax": (_I, [_P, _L, _P, _P]),
-    "iso_splat_z_scatter": (_I, [_P, _P, _L, _I, _I, _P, _P, _P]),
+    "iso_splat_z_scatter": (_I, [_P, _P, _L, _I, _L, _P, _P, _P]),
     "iso_splat_z_finish": (_I, [_P, _P, _L, _L, _P, _P]),
     "iso_splat_repack": (_I, [_P, _L, _I, _I, _I, _P, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "iso_splat_front_workspace_bytes": (_L, [_L]),

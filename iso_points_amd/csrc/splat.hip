@@ -38,7 +38,18 @@ namespace {
 
 constexpr int TILE = 16;  // pixels per tile side; one workgroup = 16x16 lanes
 
-__device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1 + (2 * i + 1.0f) / S; }
+// Image frame: H rows x W columns of square pixels.  NDC follows pytorch3d's non-square convention: the
+// shorter side spans [-1, 1], the longer one [-e, e] with e = longer / shorter, i.e. a pixel is 2 / min(H, W)
+// wide in both axes; H == W is the reference's square image (rasterizer.py:52 supports nothing else).
+struct Frame { int W, H, Tx, Ty, m; float ex, ey; };
+static inline Frame make_frame(int H, int W) {
+  Frame F;
+  F.W = W; F.H = H; F.Tx = (W + 15) / 16; F.Ty = (H + 15) / 16; F.m = H < W ? H : W;
+  F.ex = (float)W / (float)F.m; F.ey = (float)H / (float)F.m;
+  return F;
+}
+__device__ __forceinline__ float ndc_x(int i, const Frame& F) { return -F.ex + (2 * i + 1.0f) / F.m; }
+__device__ __forceinline__ float ndc_y(int i, const Frame& F) { return -F.ey + (2 * i + 1.0f) / F.m; }
 
 __device__ __forceinline__ float esqrt_arg(float x) {  // eps_sqrt, mathHelper.py:20-25
   float a = fabsf(x);
@@ -344,25 +355,26 @@ __global__ __launch_bounds__(256) void k_splat_front(const float* __restrict__ p
 // ---------------------------------------------------------------- tile binning
 // NDC-index range of pixels whose centre can lie within [c-r, c+r] (one pixel of slack on
 // each side; the exact reference test runs in the raster kernel)
-__device__ __forceinline__ bool pixel_range(float c, float r, int S, int& lo, int& hi) {
+// (n pixels along the axis, half extent e of the axis in NDC, m = min(H, W))
+__device__ __forceinline__ bool pixel_range(float c, float r, int n, float e, int m, int& lo, int& hi) {
   if (!(r >= 0.f) || !(c == c)) return false;
-  float flo = ((c - r) + 1.0f) * 0.5f * (float)S - 0.5f;
-  float fhi = ((c + r) + 1.0f) * 0.5f * (float)S - 0.5f;
+  float flo = ((c - r) + e) * 0.5f * (float)m - 0.5f;
+  float fhi = ((c + r) + e) * 0.5f * (float)m - 0.5f;
   if (!(flo < 1e9f)) return false;
   if (!(fhi > -1e9f)) return false;
   flo = fmaxf(flo, -4.0f);
-  fhi = fminf(fhi, (float)S + 4.0f);
+  fhi = fminf(fhi, (float)n + 4.0f);
   lo = (int)ceilf(flo) - 1;
   hi = (int)floorf(fhi) + 1;
   if (lo < 0) lo = 0;
-  if (hi > S - 1) hi = S - 1;
+  if (hi > n - 1) hi = n - 1;
   return lo <= hi;
 }
 
 template <bool FILL>
 __global__ void k_bin(const float* __restrict__ pts, const float* __restrict__ radii,
-                      const int64_t* __restrict__ first, const int64_t* __restrict__ num, int S,
-                      int T /*tiles per side*/, int ty_begin, int ty_end,
+                      const int64_t* __restrict__ first, const int64_t* __restrict__ num, Frame F,
+                      int ty_begin, int ty_end,
                       int32_t* __restrict__ tile_cnt,
                       const int32_t* __restrict__ tile_off, int32_t* __restrict__ pairs,
                       int64_t capacity, int32_t* __restrict__ overflow) {
@@ -374,11 +386,11 @@ __global__ void k_bin(const float* __restrict__ pts, const float* __restrict__ r
     const float z = pts[p * 3 + 2];
     if (!(z >= 0.f)) continue;  // behind the camera (rasterize_points.cu:87-88) or NaN
     int x0, x1, y0, y1;
-    if (!pixel_range(pts[p * 3], radii[p * 2], S, x0, x1)) continue;
-    if (!pixel_range(pts[p * 3 + 1], radii[p * 2 + 1], S, y0, y1)) continue;
+    if (!pixel_range(pts[p * 3], radii[p * 2], F.W, F.ex, F.m, x0, x1)) continue;
+    if (!pixel_range(pts[p * 3 + 1], radii[p * 2 + 1], F.H, F.ey, F.m, y0, y1)) continue;
     for (int ty = max(y0 / TILE, ty_begin); ty <= min(y1 / TILE, ty_end - 1); ++ty)
       for (int tx = x0 / TILE; tx <= x1 / TILE; ++tx) {
-        const int tile = (n * T + ty) * T + tx;
+        const int tile = (n * F.Ty + ty) * F.Tx + tx;
         const int slot = atomicAdd(&tile_cnt[tile], 1);
         if (FILL) {
           const int64_t dst = (int64_t)tile_off[tile] + slot;
@@ -397,17 +409,18 @@ constexpr int kBinChunk = 8192;
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin_lds(const float* __restrict__ pts, const float* __restrict__ radii,
                                                  const int64_t* __restrict__ first, const int64_t* __restrict__ num,
-                                                 int S, int T, int ty_begin, int ty_end,
+                                                 Frame F, int ty_begin, int ty_end,
                                                  int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ tile_off,
                                                  int32_t* __restrict__ pairs, int64_t capacity,
                                                  int32_t* __restrict__ overflow) {
-  extern __shared__ int lh[];          // T*T
+  extern __shared__ int lh[];          // Tx*Ty
+  const int TT = F.Tx * F.Ty;
   const int n = blockIdx.y;
   const int64_t len = num[n], base = first[n];
   const int64_t i0 = (int64_t)blockIdx.x * kBinChunk;
   if (i0 >= len) return;
   const int64_t i1 = min(len, i0 + kBinChunk);
-  for (int t = threadIdx.x; t < T * T; t += blockDim.x) lh[t] = 0;
+  for (int t = threadIdx.x; t < TT; t += blockDim.x) lh[t] = 0;
   __syncthreads();
   auto walk = [&](auto&& visit) {
     for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
@@ -415,18 +428,18 @@ __global__ __launch_bounds__(256) void k_bin_lds(const float* __restrict__ pts, 
       const float z = pts[p * 3 + 2];
       if (!(z >= 0.f)) continue;  // behind the camera (rasterize_points.cu:87-88) or NaN
       int x0, x1, y0, y1;
-      if (!pixel_range(pts[p * 3], radii[p * 2], S, x0, x1)) continue;
-      if (!pixel_range(pts[p * 3 + 1], radii[p * 2 + 1], S, y0, y1)) continue;
+      if (!pixel_range(pts[p * 3], radii[p * 2], F.W, F.ex, F.m, x0, x1)) continue;
+      if (!pixel_range(pts[p * 3 + 1], radii[p * 2 + 1], F.H, F.ey, F.m, y0, y1)) continue;
       for (int ty = max(y0 / TILE, ty_begin); ty <= min(y1 / TILE, ty_end - 1); ++ty)
-        for (int tx = x0 / TILE; tx <= x1 / TILE; ++tx) visit(ty * T + tx, p);
+        for (int tx = x0 / TILE; tx <= x1 / TILE; ++tx) visit(ty * F.Tx + tx, p);
     }
   };
   walk([&](int t, int64_t) { atomicAdd(&lh[t], 1); });
   __syncthreads();
-  for (int t = threadIdx.x; t < T * T; t += blockDim.x) {
+  for (int t = threadIdx.x; t < TT; t += blockDim.x) {
     const int c = lh[t];
     if (c) {
-      const int b = atomicAdd(&tile_cnt[n * T * T + t], c);
+      const int b = atomicAdd(&tile_cnt[n * TT + t], c);
       if (FILL) lh[t] = b;
     }
   }
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(256) void k_bin_lds(const float* __restrict__ pts, 
   __syncthreads();
   walk([&](int t, int64_t p) {
     const int slot = atomicAdd(&lh[t], 1);
-    const int64_t dst = (int64_t)tile_off[n * T * T + t] + slot;
+    const int64_t dst = (int64_t)tile_off[n * TT + t] + slot;
     if (dst < capacity) pairs[dst] = (int32_t)p;
     else *overflow = 1;
   });
@@ -442,15 +455,15 @@ __global__ __launch_bounds__(256) void k_bin_lds(const float* __restrict__ pts, 
 
 template <bool FILL>
 void launch_bin(const float* points, const float* radii, const int64_t* first_idx, const int64_t* num_pts,
-                int n_clouds, int64_t max_pts, int S, int T, int ty0, int ty1, int32_t* tile_cnt,
+                int n_clouds, int64_t max_pts, Frame F, int ty0, int ty1, int32_t* tile_cnt,
                 const int32_t* tile_off, int32_t* pairs, int64_t capacity, int32_t* overflow, hipStream_t s) {
-  if (T * T <= 4096) {
+  if (F.Tx * F.Ty <= 4096) {
     hipLaunchKernelGGL(k_bin_lds<FILL>, dim3(iso_div_up(max_pts, kBinChunk), n_clouds), dim3(256),
-                       (size_t)T * T * sizeof(int), s, points, radii, first_idx, num_pts, S, T, ty0, ty1, tile_cnt,
+                       (size_t)F.Tx * F.Ty * sizeof(int), s, points, radii, first_idx, num_pts, F, ty0, ty1, tile_cnt,
                        tile_off, pairs, capacity, overflow);
   } else {
     int gx = iso_div_up(max_pts, 256); if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(k_bin<FILL>, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, first_idx, num_pts, S, T,
+    hipLaunchKernelGGL(k_bin<FILL>, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, first_idx, num_pts, F,
                        ty0, ty1, tile_cnt, tile_off, pairs, capacity, overflow);
   }
 }
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(256) void k_raster(
     const float* __restrict__ cutoff, const float* __restrict__ radii,
     const int32_t* __restrict__ tile_order, const int4* __restrict__ items, const int32_t* __restrict__ item_count,
     float* __restrict__ scratch, const int32_t* __restrict__ tile_off,
-    const int32_t* __restrict__ pairs, int64_t capacity, int S, int T,
+    const int32_t* __restrict__ pairs, int64_t capacity, Frame F,
     int K, float depth_thres, int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out,
     float* __restrict__ occ_out, CompositeArgs ca) {
   __shared__ float s_px[256], s_py[256], s_pz[256], s_a[256], s_b[256], s_c[256], s_rx[256],
@@ -548,19 +561,19 @@ __global__ __launch_bounds__(256) void k_raster(
   } else {
     tile = tile_order[blockIdx.x];
   }
-  const int tx = tile % T, ty = (tile / T) % T, n = tile / (T * T);
+  const int tx = tile % F.Tx, ty = (tile / F.Tx) % F.Ty, n = tile / (F.Tx * F.Ty);
   const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
   const int xi = tx * TILE + lx, yi = ty * TILE + ly;  // NDC pixel index
-  const bool inside = xi < S && yi < S;
-  const float xf = pix_to_ndc(xi, S), yf = pix_to_ndc(yi, S);
+  const bool inside = xi < F.W && yi < F.H;
+  const float xf = ndc_x(xi, F), yf = ndc_y(yi, F);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // NDC y-range of the four row bands (pix_to_ndc is increasing), widened a little so that the
   // band test is a strict superset of the exact per-pixel test below
   float band_lo[4], band_hi[4];
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    band_lo[w] = pix_to_ndc(ty * TILE + 4 * w, S) - 1.0e-6f;
-    band_hi[w] = pix_to_ndc(ty * TILE + 4 * w + 3, S) + 1.0e-6f;
+    band_lo[w] = ndc_y(ty * TILE + 4 * w, F) - 1.0e-6f;
+    band_hi[w] = ndc_y(ty * TILE + 4 * w + 3, F) + 1.0e-6f;
   }
   PixK<KMAX> best;
   best.init();
@@ -644,8 +657,8 @@ __global__ __launch_bounds__(256) void k_raster(
   }
   if (!inside) return;
   // output pixel is flipped in both axes (+X left, +Y up; rasterize_points.cu:577-580)
-  const int yo = S - 1 - yi, xo = S - 1 - xi;
-  const int64_t pix = ((int64_t)n * S + yo) * S + xo;
+  const int yo = F.H - 1 - yi, xo = F.W - 1 - xi;
+  const int64_t pix = ((int64_t)n * F.H + yo) * F.W + xo;
   const float z0 = best.z[0];
   const bool hit = z0 < FLT_MAX;
   occ_out[pix] = hit ? 1.0f : 0.0f;
@@ -663,13 +676,14 @@ __global__ __launch_bounds__(256) void k_raster(
 
 // Tiles of the band [ty_begin, ty_begin+ty_rows) of every cloud, heaviest first (64 buckets of the
 // candidate count; the order inside a bucket is arbitrary -- it only affects scheduling).
-__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_off, int T, int ty_begin,
+__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
                                                      int ty_rows, int n_clouds, int32_t* __restrict__ order) {
+  const int T = F.Tx, TY = F.Ty;
   __shared__ int hist[64], base[64];
   const int tiles = n_clouds * T * ty_rows;
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
-  auto tile_of = [&](int i) { return ((i / (T * ty_rows)) * T + ty_begin + (i / T) % ty_rows) * T + i % T; };
+  auto tile_of = [&](int i) { return ((i / (T * ty_rows)) * TY + ty_begin + (i / T) % ty_rows) * T + i % T; };
   auto bucket_of = [&](int tile) {
     const int c = tile_off[tile + 1] - tile_off[tile];
     return min(c >> 6, 63);
@@ -691,14 +705,15 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
 // (<= kSlice candidates each) as long as the scratch slots last; slices first, then the whole tiles heaviest
 // first.  heavy[h] = (tile, first scratch slot, slices).  counters: [0] items, [1] heavy tiles.
 constexpr int kSlice = 1024, kTargetItems = 2048;
-__global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__ tile_off, int T, int ty_begin,
+__global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
                                                      int ty_rows, int n_clouds, int max_slots,
                                                      int4* __restrict__ items, int4* __restrict__ heavy,
                                                      int32_t* __restrict__ counters) {
   __shared__ int hist[64], base[64];
   __shared__ int s_slots, s_heavy, s_slice;
+  const int T = F.Tx, TY = F.Ty;
   const int tiles = n_clouds * T * ty_rows;
-  auto tile_of = [&](int i) { return ((i / (T * ty_rows)) * T + ty_begin + (i / T) % ty_rows) * T + i % T; };
+  auto tile_of = [&](int i) { return ((i / (T * ty_rows)) * TY + ty_begin + (i / T) % ty_rows) * T + i % T; };
   auto count_of = [&](int tile) { return tile_off[tile + 1] - tile_off[tile]; };
   // slice size: total candidates / kTargetItems (so that a small band still yields enough work items to
   // fill the chip), within [256, kSlice], doubled until the slices of all cut tiles fit the scratch slots
@@ -766,7 +781,7 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
 // does not depend on how the list was cut), then the depth-merging cut and the outputs of k_raster.
 template <int KMAX>
 __global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ heavy, const int32_t* __restrict__ counters,
-                                                      const float* __restrict__ scratch, int S, int T, int K,
+                                                      const float* __restrict__ scratch, Frame F, int K,
                                                       float depth_thres, int32_t* __restrict__ idx_out,
                                                       float* __restrict__ zbuf_out, float* __restrict__ q_out,
                                                       float* __restrict__ occ_out, CompositeArgs ca) {
@@ -774,7 +789,7 @@ __global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ h
   for (int hI = blockIdx.x; hI < nh; hI += gridDim.x) {
     const int4 hv = heavy[hI];
     const int tile = hv.x;
-    const int tx = tile % T, ty = (tile / T) % T, n = tile / (T * T);
+    const int tx = tile % F.Tx, ty = (tile / F.Tx) % F.Ty, n = tile / (F.Tx * F.Ty);
     const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
     const int xi = tx * TILE + lx, yi = ty * TILE + ly;
     PixK<KMAX> best;
@@ -788,9 +803,9 @@ __global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ h
           best.push(z, __float_as_int(sc[(2 * KMAX + j) * 256 + threadIdx.x]), sc[(KMAX + j) * 256 + threadIdx.x], K);
       }
     }
-    if (xi >= S || yi >= S) continue;
-    const int yo = S - 1 - yi, xo = S - 1 - xi;
-    const int64_t pix = ((int64_t)n * S + yo) * S + xo;
+    if (xi >= F.W || yi >= F.H) continue;
+    const int yo = F.H - 1 - yi, xo = F.W - 1 - xi;
+    const int64_t pix = ((int64_t)n * F.H + yo) * F.W + xo;
     const float z0 = best.z[0];
     const bool hit = z0 < FLT_MAX;
     occ_out[pix] = hit ? 1.0f : 0.0f;
@@ -926,42 +941,49 @@ __global__ void k_zbuf_scatter(const int32_t* __restrict__ idx, const float* __r
 
 // coarse map of 8x8 pixel blocks that hold a non-zero occupancy gradient
 constexpr int GB = 8;
-__global__ void k_grad_blocks(const float* __restrict__ grad_occ, int S, int NB, int N,
+struct BlkGeo { int NBx, NBy, NB2x, NB2y; };
+static inline BlkGeo make_blk(int H, int W) {
+  BlkGeo g;
+  g.NBx = (W + GB - 1) / GB; g.NBy = (H + GB - 1) / GB; g.NB2x = (g.NBx + 7) / 8; g.NB2y = (g.NBy + 7) / 8;
+  return g;
+}
+
+__global__ void k_grad_blocks(const float* __restrict__ grad_occ, Frame F, BlkGeo G, int N,
                               uint8_t* __restrict__ blk) {
-  const int64_t total = (int64_t)N * NB * NB;
+  const int64_t total = (int64_t)N * G.NBx * G.NBy;
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total;
        b += (int64_t)gridDim.x * blockDim.x) {
-    const int bx = b % NB, by = (b / NB) % NB, n = b / ((int64_t)NB * NB);
+    const int bx = b % G.NBx, by = (b / G.NBx) % G.NBy, n = b / ((int64_t)G.NBx * G.NBy);
     uint8_t any = 0;
-    for (int y = by * GB; y < min(S, (by + 1) * GB) && !any; ++y)
-      for (int x = bx * GB; x < min(S, (bx + 1) * GB); ++x)
-        if (grad_occ[((int64_t)n * S + y) * S + x] != 0.0f) { any = 1; break; }
+    for (int y = by * GB; y < min(F.H, (by + 1) * GB) && !any; ++y)
+      for (int x = bx * GB; x < min(F.W, (bx + 1) * GB); ++x)
+        if (grad_occ[((int64_t)n * F.H + y) * F.W + x] != 0.0f) { any = 1; break; }
     blk[b] = any;
   }
 }
 
 // second level: 64x64-pixel super blocks (8x8 of the 8x8 blocks)
-__global__ void k_grad_superblocks(const uint8_t* __restrict__ blk, int NB, int NB2, int N,
+__global__ void k_grad_superblocks(const uint8_t* __restrict__ blk, BlkGeo G, int N,
                                    uint8_t* __restrict__ blk2) {
-  const int64_t total = (int64_t)N * NB2 * NB2;
+  const int64_t total = (int64_t)N * G.NB2x * G.NB2y;
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total;
        b += (int64_t)gridDim.x * blockDim.x) {
-    const int bx = b % NB2, by = (b / NB2) % NB2, n = b / ((int64_t)NB2 * NB2);
+    const int bx = b % G.NB2x, by = (b / G.NB2x) % G.NB2y, n = b / ((int64_t)G.NB2x * G.NB2y);
     uint8_t any = 0;
-    for (int y = by * 8; y < min(NB, (by + 1) * 8) && !any; ++y)
-      for (int x = bx * 8; x < min(NB, (bx + 1) * 8); ++x)
-        if (blk[((int64_t)n * NB + y) * NB + x]) { any = 1; break; }
+    for (int y = by * 8; y < min(G.NBy, (by + 1) * 8) && !any; ++y)
+      for (int x = bx * 8; x < min(G.NBx, (bx + 1) * 8); ++x)
+        if (blk[((int64_t)n * G.NBy + y) * G.NBx + x]) { any = 1; break; }
     blk2[b] = any;
   }
 }
 
 
 // output-pixel range [lo,hi] (after the axis flip) whose centres may lie within c +- r
-__device__ __forceinline__ bool out_range(float c, float r, int S, int& lo, int& hi) {
+__device__ __forceinline__ bool out_range(float c, float r, int n, float e, int m, int& lo, int& hi) {
   int a, b;
-  if (!pixel_range(c, r, S, a, b)) return false;
-  lo = S - 1 - b;
-  hi = S - 1 - a;
+  if (!pixel_range(c, r, n, e, m, a, b)) return false;
+  lo = n - 1 - b;
+  hi = n - 1 - a;
   return true;
 }
 
@@ -991,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_splat_backward(
     const float* __restrict__ pts, const float* __restrict__ radii,
     const uint8_t* __restrict__ visible, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num,
-    const uint8_t* __restrict__ blk2, int NB2, int S, int rect_mode, float radii_s,
+    const uint8_t* __restrict__ blk2, BlkGeo G, Frame F, int rect_mode, float radii_s,
     int32_t* __restrict__ heavy, int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
   const int n = blockIdx.y;
   const int64_t len = num[n], base = first[n];
@@ -1009,12 +1031,13 @@ __global__ __launch_bounds__(256) void k_splat_backward(
       const bool vis = (!visible || visible[p]);
       grad[p * 3] = 0.f; grad[p * 3 + 1] = 0.f; grad[p * 3 + 2] = 0.f;   // z: k_z_scatter / k_z_finish
       const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
-      if (vis && !(pz < 0.f || fabsf(py) > 1.0f || fabsf(px) > 1.0f) && sx > 0.f && sy > 0.f) {
+      // (the fast kernel skips points outside the image: rasterize_points_backward.cu:101-103; here: outside the frame)
+      if (vis && !(pz < 0.f || fabsf(py) > F.ey || fabsf(px) > F.ex) && sx > 0.f && sy > 0.f) {
         int x0, x1, y0, y1;
-        if (out_range(px, sx, S, x0, x1) && out_range(py, sy, S, y0, y1)) {
+        if (out_range(px, sx, F.W, F.ex, F.m, x0, x1) && out_range(py, sy, F.H, F.ey, F.m, y0, y1)) {
           for (int sy2 = y0 / 64; sy2 <= y1 / 64 && !is_heavy; ++sy2)
             for (int sx2 = x0 / 64; sx2 <= x1 / 64; ++sx2)
-              if (blk2[((int64_t)n * NB2 + sy2) * NB2 + sx2]) { is_heavy = true; break; }
+              if (blk2[((int64_t)n * G.NB2y + sy2) * G.NB2x + sx2]) { is_heavy = true; break; }
         }
       }
     }
@@ -1044,8 +1067,8 @@ __global__ __launch_bounds__(256) void k_splat_backward(
 __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     const float* __restrict__ pts, const float* __restrict__ radii, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num, int n_clouds,
-    const float* __restrict__ grad_occ, const uint8_t* __restrict__ blk, int NB,
-    const uint8_t* __restrict__ blk2, int NB2, int S,
+    const float* __restrict__ grad_occ, const uint8_t* __restrict__ blk,
+    const uint8_t* __restrict__ blk2, BlkGeo G, Frame F,
     int rect_mode, float radii_s, const int32_t* __restrict__ heavy,
     const int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
   const int lane = threadIdx.x & 63;
@@ -1062,22 +1085,22 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
     int x0, x1, y0, y1;
     float gx = 0.f, gy = 0.f;
-    if (out_range(px, sx, S, x0, x1) && out_range(py, sy, S, y0, y1)) {
+    if (out_range(px, sx, F.W, F.ex, F.m, x0, x1) && out_range(py, sy, F.H, F.ey, F.m, y0, y1)) {
       const int bx0 = x0 / GB, bx1 = x1 / GB, by0 = y0 / GB, by1 = y1 / GB;
       const int ly = lane >> 3, lx = lane & 7;
       // 64x64 super blocks first (one flag per 64 8x8 blocks), then the flagged 8x8 blocks inside
       for (int sby = by0 / 8; sby <= by1 / 8; ++sby)
         for (int sbx = bx0 / 8; sbx <= bx1 / 8; ++sbx) {
-          if (!blk2[((int64_t)n * NB2 + sby) * NB2 + sbx]) continue;               // wave-uniform
+          if (!blk2[((int64_t)n * G.NB2y + sby) * G.NB2x + sbx]) continue;         // wave-uniform
           for (int by = max(by0, sby * 8); by <= min(by1, sby * 8 + 7); ++by) {
             const int yo = by * GB + ly;
-            const float dy = pix_to_ndc(S - 1 - yo, S) - py;
+            const float dy = ndc_y(F.H - 1 - yo, F) - py;
             for (int bx = max(bx0, sbx * 8); bx <= min(bx1, sbx * 8 + 7); ++bx) {
-              if (!blk[((int64_t)n * NB + by) * NB + bx]) continue;                 // wave-uniform
+              if (!blk[((int64_t)n * G.NBy + by) * G.NBx + bx]) continue;           // wave-uniform
               const int xo = bx * GB + lx;
               if (yo < y0 || yo > y1 || xo < x0 || xo > x1) continue;
-              const float g = grad_occ[((int64_t)n * S + yo) * S + xo];
-              const float dx = pix_to_ndc(S - 1 - xo, S) - px;
+              const float g = grad_occ[((int64_t)n * F.H + yo) * F.W + xo];
+              const float dx = ndc_x(F.W - 1 - xo, F) - px;
               occ_term(g, dx, dy, rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
             }
           }
@@ -1270,16 +1293,16 @@ extern "C" int iso_splat_tiles_per_side(int image_size) { return (image_size + T
 
 extern "C" int iso_splat_bin_count(const float* points, const float* radii,
                                    const int64_t* first_idx, const int64_t* num_pts, int n_clouds,
-                                   int64_t max_pts, int image_size, int tile_row_begin,
+                                   int64_t max_pts, int image_size, int image_width, int tile_row_begin,
                                    int tile_row_end, int32_t* tile_cnt, void* stream) {
   ISO_REQUIRE(n_clouds >= 0 && max_pts >= 0 && image_size > 0, ISO_ERR_INVALID, "iso_splat_bin_count: bad sizes");
   if (n_clouds == 0 || max_pts == 0) return ISO_OK;
   ISO_REQUIRE(points && radii && first_idx && num_pts && tile_cnt, ISO_ERR_INVALID,
               "iso_splat_bin_count: null pointer");
-  const int T = iso_splat_tiles_per_side(image_size);
-  ISO_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= T,
+  const Frame F = make_frame(image_size, image_width > 0 ? image_width : image_size);
+  ISO_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= F.Ty,
               ISO_ERR_INVALID, "iso_splat_bin_count: bad tile row band");
-  launch_bin<false>(points, radii, first_idx, num_pts, n_clouds, max_pts, image_size, T, tile_row_begin,
+  launch_bin<false>(points, radii, first_idx, num_pts, n_clouds, max_pts, F, tile_row_begin,
                     tile_row_end, tile_cnt, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
   ISO_CHECK_LAUNCH("iso_splat_bin_count");
   return ISO_OK;
@@ -1298,7 +1321,7 @@ extern "C" int64_t iso_splat_forward_workspace_bytes(int64_t n_tiles, int points
 static int splat_forward_impl(CompositeArgs ca, const float* points, const float* ellipse, const float* cutoff,
                                  const float* radii, const int64_t* first_idx,
                                  const int64_t* num_pts, int n_clouds, int64_t max_pts,
-                                 float depth_merging_thres, int image_size, int points_per_pixel,
+                                 float depth_merging_thres, int image_size, int image_width, int points_per_pixel,
                                  int tile_row_begin, int tile_row_end, int32_t* tile_cursor,
                                  const int32_t* tile_off, int32_t* pairs,
                                  int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
@@ -1312,13 +1335,14 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
                   zbuf_out && qvalue_out && occ_out && (pairs || pair_capacity == 0),
               ISO_ERR_INVALID, "iso_splat_forward: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const int T = iso_splat_tiles_per_side(image_size);
-  ISO_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= T,
+  const Frame F = make_frame(image_size, image_width > 0 ? image_width : image_size);
+  const int T = F.Tx;
+  ISO_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= F.Ty,
               ISO_ERR_INVALID, "iso_splat_forward: bad tile row band");
   if (tile_row_begin == tile_row_end) return ISO_OK;
   if (max_pts > 0) {
     ISO_REQUIRE(points && ellipse && cutoff && radii, ISO_ERR_INVALID, "iso_splat_forward: null pointer");
-    launch_bin<true>(points, radii, first_idx, num_pts, n_clouds, max_pts, image_size, T, tile_row_begin,
+    launch_bin<true>(points, radii, first_idx, num_pts, n_clouds, max_pts, F, tile_row_begin,
                      tile_row_end, tile_cursor, tile_off, pairs, pair_capacity, overflow_flag, s);
   }
   const int ty_rows = tile_row_end - tile_row_begin;
@@ -1341,20 +1365,20 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
     scratch = (float*)(heavy + tiles);
   }
   if (items) {
-    hipLaunchKernelGGL(k_tile_items, dim3(1), dim3(1024), 0, s, tile_off, T, tile_row_begin, ty_rows, n_clouds, max_slots,
+    hipLaunchKernelGGL(k_tile_items, dim3(1), dim3(1024), 0, s, tile_off, F, tile_row_begin, ty_rows, n_clouds, max_slots,
                        items, heavy, counters);
   } else {
     // the fill cursors are dead now: their array takes the heaviest-first tile order
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tile_off, T, tile_row_begin, ty_rows, n_clouds,
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tile_off, F, tile_row_begin, ty_rows, n_clouds,
                        tile_cursor);
   }
 #define ISO_LAUNCH_R(KM_)                                                                            \
   hipLaunchKernelGGL(k_raster<KM_>, dim3(tiles + max_slots), dim3(256), 0, s, points, ellipse, cutoff, radii, \
-                     tile_cursor, items, counters, scratch, tile_off, pairs, pair_capacity, image_size, T,    \
+                     tile_cursor, items, counters, scratch, tile_off, pairs, pair_capacity, F,                \
                      K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);             \
   if (items)                                                                                          \
     hipLaunchKernelGGL(k_raster_merge<KM_>, dim3(tiles < 1024 ? tiles : 1024), dim3(256), 0, s, heavy, counters, scratch, \
-                       image_size, T, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca)
+                       F, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca)
   if (K <= 4) { ISO_LAUNCH_R(4); }
   else if (K <= 8) { ISO_LAUNCH_R(8); }
   else if (K <= 16) { ISO_LAUNCH_R(16); }
@@ -1367,7 +1391,7 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
 extern "C" int iso_splat_forward(const float* points, const float* ellipse, const float* cutoff,
                                  const float* radii, const int64_t* first_idx,
                                  const int64_t* num_pts, int n_clouds, int64_t max_pts,
-                                 float depth_merging_thres, int image_size, int points_per_pixel,
+                                 float depth_merging_thres, int image_size, int image_width, int points_per_pixel,
                                  int tile_row_begin, int tile_row_end, int32_t* tile_cursor,
                                  const int32_t* tile_off, int32_t* pairs,
                                  int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
@@ -1375,7 +1399,7 @@ extern "C" int iso_splat_forward(const float* points, const float* ellipse, cons
                                  int64_t workspace_bytes, void* stream) {
   CompositeArgs ca{nullptr, nullptr, nullptr, 0, 0, 0.f};
   return splat_forward_impl(ca, points, ellipse, cutoff, radii, first_idx, num_pts, n_clouds, max_pts, depth_merging_thres,
-                            image_size, points_per_pixel, tile_row_begin, tile_row_end, tile_cursor, tile_off, pairs,
+                            image_size, image_width, points_per_pixel, tile_row_begin, tile_row_end, tile_cursor, tile_off, pairs,
                             pair_capacity, overflow_flag, idx_out, zbuf_out, qvalue_out, occ_out, workspace,
                             workspace_bytes, stream);
 }
@@ -1385,7 +1409,7 @@ extern "C" int iso_splat_forward(const float* points, const float* ellipse, cons
 extern "C" int iso_splat_render(const float* points, const float* ellipse, const float* cutoff,
                                 const float* radii, const int64_t* first_idx,
                                 const int64_t* num_pts, int n_clouds, int64_t max_pts,
-                                float depth_merging_thres, int image_size, int points_per_pixel,
+                                float depth_merging_thres, int image_size, int image_width, int points_per_pixel,
                                 int tile_row_begin, int tile_row_end, int32_t* tile_cursor,
                                 const int32_t* tile_off, int32_t* pairs,
                                 int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
@@ -1396,7 +1420,7 @@ extern "C" int iso_splat_render(const float* points, const float* ellipse, const
   ISO_REQUIRE(scaler && image_out && (features || channels == 0), ISO_ERR_INVALID, "iso_splat_render: null pointer");
   CompositeArgs ca{scaler, features, image_out, channels, norm_weighted, eps};
   return splat_forward_impl(ca, points, ellipse, cutoff, radii, first_idx, num_pts, n_clouds, max_pts, depth_merging_thres,
-                            image_size, points_per_pixel, tile_row_begin, tile_row_end, tile_cursor, tile_off, pairs,
+                            image_size, image_width, points_per_pixel, tile_row_begin, tile_row_end, tile_cursor, tile_off, pairs,
                             pair_capacity, overflow_flag, idx_out, zbuf_out, qvalue_out, occ_out, workspace,
                             workspace_bytes, stream);
 }
@@ -1564,24 +1588,22 @@ __global__ void k_z_finish(const long long* __restrict__ acc, const ZScale* __re
   }
 }
 
-static int64_t bwd_maps_bytes(int n_clouds, int image_size) {
-  int64_t nb = (image_size + GB - 1) / GB;
-  int64_t nb2 = (nb + 7) / 8;
-  return (((int64_t)n_clouds * (nb * nb + nb2 * nb2)) + 63) / 64 * 64;   // blk, blk2
+static int64_t bwd_maps_bytes(int n_clouds, int image_size, int image_width) {
+  const BlkGeo G = make_blk(image_size, image_width > 0 ? image_width : image_size);
+  return (((int64_t)n_clouds * ((int64_t)G.NBx * G.NBy + (int64_t)G.NB2x * G.NB2y)) + 63) / 64 * 64;   // blk, blk2
 }
-
-extern "C" int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size,
+extern "C" int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size, int image_width,
                                                       int64_t total_points) {
   if (total_points < 0) total_points = 0;
   // [block maps][heavy count (64 B) + heavy list (4 B/pt)][pad 16][ZScale 16 B][z accumulators 8 B/pt]
-  return bwd_maps_bytes(n_clouds, image_size) + 64 + (4 * total_points + 15) / 16 * 16 + 16 + 8 * total_points;
+  return bwd_maps_bytes(n_clouds, image_size, image_width) + 64 + (4 * total_points + 15) / 16 * 16 + 16 + 8 * total_points;
 }
 
 extern "C" int iso_splat_backward(const float* points, const float* radii, const uint8_t* visible,
                                   const float* search_radius, const int64_t* first_idx,
                                   const int64_t* num_pts, int n_clouds, int64_t max_pts,
                                   const float* grad_occ, const int32_t* idx,
-                                  const float* grad_zbuf, int image_size, int points_per_pixel,
+                                  const float* grad_zbuf, int image_size, int image_width, int points_per_pixel,
                                   int rect_mode, float radii_s, int64_t total_points,
                                   void* workspace, int64_t workspace_bytes, float* grad_points,
                                   void* stream) {
@@ -1590,35 +1612,35 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
   ISO_REQUIRE(points && radii && (search_radius || rect_mode) && first_idx && num_pts && grad_occ &&
                   grad_points && workspace && (!grad_zbuf || idx),
               ISO_ERR_INVALID, "iso_splat_backward: null pointer");
-  ISO_REQUIRE(workspace_bytes >= iso_splat_backward_workspace_bytes(n_clouds, image_size, total_points),
+  ISO_REQUIRE(workspace_bytes >= iso_splat_backward_workspace_bytes(n_clouds, image_size, image_width, total_points),
               ISO_ERR_WORKSPACE, "iso_splat_backward: workspace too small");
-  ISO_REQUIRE(image_size <= 2048, ISO_ERR_UNSUPPORTED, "iso_splat_backward: image_size must be <= 2048");
+  const Frame F = make_frame(image_size, image_width > 0 ? image_width : image_size);
+  const BlkGeo G = make_blk(F.H, F.W);
+  ISO_REQUIRE(F.H <= 2048 && F.W <= 2048, ISO_ERR_UNSUPPORTED, "iso_splat_backward: image sides must be <= 2048");
   hipStream_t s = (hipStream_t)stream;
-  const int NB = (image_size + GB - 1) / GB;
   uint8_t* blk = (uint8_t*)workspace;
-  const int NB2 = (NB + 7) / 8;
-  uint8_t* blk2 = blk + (int64_t)n_clouds * NB * NB;
-  hipLaunchKernelGGL(k_grad_blocks, dim3(iso_stream_grid((int64_t)n_clouds * NB * NB, 256)), dim3(256),
-                     0, s, grad_occ, image_size, NB, n_clouds, blk);
-  hipLaunchKernelGGL(k_grad_superblocks, dim3(iso_stream_grid((int64_t)n_clouds * NB2 * NB2, 256)),
-                     dim3(256), 0, s, blk, NB, NB2, n_clouds, blk2);
-  int32_t* heavy_count = (int32_t*)((uint8_t*)workspace + bwd_maps_bytes(n_clouds, image_size));
+  uint8_t* blk2 = blk + (int64_t)n_clouds * G.NBx * G.NBy;
+  hipLaunchKernelGGL(k_grad_blocks, dim3(iso_stream_grid((int64_t)n_clouds * G.NBx * G.NBy, 256)), dim3(256),
+                     0, s, grad_occ, F, G, n_clouds, blk);
+  hipLaunchKernelGGL(k_grad_superblocks, dim3(iso_stream_grid((int64_t)n_clouds * G.NB2x * G.NB2y, 256)),
+                     dim3(256), 0, s, blk, G, n_clouds, blk2);
+  int32_t* heavy_count = (int32_t*)((uint8_t*)workspace + bwd_maps_bytes(n_clouds, image_size, image_width));
   int32_t* heavy = heavy_count + 16;
   iso_zero_words(heavy_count, 16, s);
   int gx = iso_div_up(max_pts, 256); if (gx > 8192) gx = 8192;
   // xy part point-major (z written as 0), then the z part pixel-major in fixed point
   hipLaunchKernelGGL(k_splat_backward, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, visible,
-                     search_radius, first_idx, num_pts, blk2, NB2, image_size, rect_mode, radii_s, heavy,
+                     search_radius, first_idx, num_pts, blk2, G, F, rect_mode, radii_s, heavy,
                      heavy_count, grad_points);
   if (grad_zbuf && total_points > 0) {
     ZScale* zs = reinterpret_cast<ZScale*>((char*)(heavy_count) + 64 + (4 * total_points + 15) / 16 * 16);
     long long* zacc = reinterpret_cast<long long*>((char*)zs + 16);
-    const int64_t npix = (int64_t)n_clouds * image_size * image_size;
+    const int64_t npix = (int64_t)n_clouds * F.H * F.W;
     iso_zero_words(zs, 4 + 2 * total_points, s);
     int gm = iso_div_up(npix * points_per_pixel, 256 * 16); if (gm > 1024) gm = 1024; if (gm < 1) gm = 1;
     hipLaunchKernelGGL(k_z_absmax, dim3(gm), dim3(256), 0, s, grad_zbuf, npix * points_per_pixel, zs);
     int terms_log2 = 0;
-    while ((1ll << terms_log2) < (int64_t)image_size * image_size) ++terms_log2;
+    while ((1ll << terms_log2) < (int64_t)F.H * F.W) ++terms_log2;
     hipLaunchKernelGGL(k_z_scale, dim3(1), dim3(1), 0, s, zs, terms_log2);
     hipLaunchKernelGGL(k_z_scatter, dim3(iso_stream_grid(npix, 256)), dim3(256), 0, s, idx, grad_zbuf,
                        points_per_pixel, npix, zs, zacc);
@@ -1626,7 +1648,7 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
                        total_points, grad_points);
   }
   hipLaunchKernelGGL(k_splat_backward_heavy, dim3(2048), dim3(256), 0, s, points, radii, search_radius,
-                     first_idx, num_pts, n_clouds, grad_occ, blk, NB, blk2, NB2, image_size, rect_mode, radii_s,
+                     first_idx, num_pts, n_clouds, grad_occ, blk, blk2, G, F, rect_mode, radii_s,
                      heavy, heavy_count, grad_points);
   ISO_CHECK_LAUNCH("iso_splat_backward");
   return ISO_OK;
@@ -1648,12 +1670,12 @@ extern "C" int iso_splat_z_absmax(const float* grad_zbuf, int64_t n, int32_t* zs
 }
 
 extern "C" int iso_splat_z_scatter(const int32_t* idx, const float* grad_zbuf, int64_t n_pixels, int points_per_pixel,
-                                   int image_size, int32_t* zscale, int64_t* acc, void* stream) {
-  ISO_REQUIRE(zscale && acc && n_pixels >= 0 && points_per_pixel >= 1 && image_size > 0 && ((idx && grad_zbuf) || n_pixels == 0),
+                                   int64_t pixels_per_view, int32_t* zscale, int64_t* acc, void* stream) {
+  ISO_REQUIRE(zscale && acc && n_pixels >= 0 && points_per_pixel >= 1 && pixels_per_view > 0 && ((idx && grad_zbuf) || n_pixels == 0),
               ISO_ERR_INVALID, "iso_splat_z_scatter: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   int terms_log2 = 0;
-  while ((1ll << terms_log2) < (int64_t)image_size * image_size) ++terms_log2;
+  while ((1ll << terms_log2) < pixels_per_view) ++terms_log2;
   hipLaunchKernelGGL(k_z_scale, dim3(1), dim3(1), 0, s, reinterpret_cast<ZScale*>(zscale), terms_log2);
   if (n_pixels > 0)
     hipLaunchKernelGGL(k_z_scatter, dim3(iso_stream_grid(n_pixels, 256)), dim3(256), 0, s, idx, grad_zbuf, points_per_pixel,

@@ -327,11 +327,11 @@ class IsoCycle(object):
         acc = torch.zeros((rows,), dtype=torch.int64, device=dev)
         for n in range(N):
             if y1 > y0:
-                _lib.call("iso_splat_z_scatter", p(idx[n, y0:y1]), p(zbuf_grad_band[n, y0:y1]), (y1 - y0) * S, K, S,
+                _lib.call("iso_splat_z_scatter", p(idx[n, y0:y1]), p(zbuf_grad_band[n, y0:y1]), (y1 - y0) * S, K, S * S,
                           p(zmax), p(acc), _lib.stream())
         acc = yield ("all_reduce", acc, "sum")
         if y1 <= y0:      # a rank without tile rows still has to know the exponent
-            _lib.call("iso_splat_z_scatter", None, None, 0, K, S, p(zmax), p(acc), _lib.stream())
+            _lib.call("iso_splat_z_scatter", None, None, 0, K, S * S, p(zmax), p(acc), _lib.stream())
         _lib.call("iso_splat_z_finish", p(acc), p(zmax), 0, rows, p(grad), _lib.stream())
         return grad
 

@@ -26,6 +26,15 @@ from .levelset_sampling import host_lengths, with_host_lengths
 kMaxPointsPerPixel = 32      # registers-resident K-best list (the reference allows 150)
 
 
+def image_hw(image_size):
+    """image_size as the reference takes it (an int: square) or pytorch3d's (H, W) pair -> (H, W).  Non-square
+    images are beyond the reference's rasteriser (rasterizer.py:52); NDC then follows pytorch3d's convention:
+    the shorter side spans [-1, 1], the longer [-e, e] with e = longer / shorter."""
+    if isinstance(image_size, (tuple, list)):
+        return int(image_size[0]), int(image_size[1])
+    return int(image_size), int(image_size)
+
+
 class PointFragments(NamedTuple):
     idx: torch.Tensor
     zbuf: torch.Tensor
@@ -110,7 +119,8 @@ class _CNamespace(object):
         only that band of 16-pixel tile rows (NDC pixel order) into `out` (or fresh -1/0 tensors)."""
         if not points.is_cuda:
             raise RuntimeError("iso_points_amd._C.splat_points: tensors must be on the GPU; there is no CPU path")
-        K, S = int(points_per_pixel), int(image_size)
+        K = int(points_per_pixel)
+        S, W = image_hw(image_size)              # S = rows (H), W = columns
         if K > kMaxPointsPerPixel or K < 1:
             raise RuntimeError("Must have 1 <= points_per_pixel <= %d" % kMaxPointsPerPixel)
         if points.ndim != 2 or points.shape[1] != 3:
@@ -125,27 +135,28 @@ class _CNamespace(object):
         if hasattr(num_points_per_cloud, "_iso_host") and num is not num_points_per_cloud:
             with_host_lengths(num, host_lengths(num_points_per_cloud))
         lib = _lib.load()
-        T = lib.iso_splat_tiles_per_side(S) if S > 0 else 0
+        T = lib.iso_splat_tiles_per_side(S) if S > 0 else 0           # tile rows
+        TW = lib.iso_splat_tiles_per_side(W) if W > 0 else 0          # tile columns
         band = (0, T) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
         if out is not None:
             idx, zbuf, qv, occ = out
         elif band == (0, T):
-            idx = torch.empty((N, S, S, K), dtype=torch.int32, device=dev)
-            zbuf = torch.empty((N, S, S, K), dtype=torch.float32, device=dev)
-            qv = torch.empty((N, S, S, K), dtype=torch.float32, device=dev)
-            occ = torch.empty((N, S, S), dtype=torch.float32, device=dev)
+            idx = torch.empty((N, S, W, K), dtype=torch.int32, device=dev)
+            zbuf = torch.empty((N, S, W, K), dtype=torch.float32, device=dev)
+            qv = torch.empty((N, S, W, K), dtype=torch.float32, device=dev)
+            occ = torch.empty((N, S, W), dtype=torch.float32, device=dev)
         else:
-            idx = torch.full((N, S, S, K), -1, dtype=torch.int32, device=dev)
-            zbuf = torch.full((N, S, S, K), -1.0, dtype=torch.float32, device=dev)
-            qv = torch.full((N, S, S, K), -1.0, dtype=torch.float32, device=dev)
-            occ = torch.zeros((N, S, S), dtype=torch.float32, device=dev)
-        if N == 0 or S == 0:
+            idx = torch.full((N, S, W, K), -1, dtype=torch.int32, device=dev)
+            zbuf = torch.full((N, S, W, K), -1.0, dtype=torch.float32, device=dev)
+            qv = torch.full((N, S, W, K), -1.0, dtype=torch.float32, device=dev)
+            occ = torch.zeros((N, S, W), dtype=torch.float32, device=dev)
+        if N == 0 or S == 0 or W == 0:
             return idx, zbuf, qv, occ
-        ntiles = N * T * T
+        ntiles = N * T * TW
         maxp = int(max_pts) if max_pts is not None else _max_pts(num)
         p, s = _lib.ptr, _lib.stream()
         tile_cnt = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)
-        _lib.call("iso_splat_bin_count", p(pts), p(ra), p(first), p(num), N, maxp, S, band[0], band[1],
+        _lib.call("iso_splat_bin_count", p(pts), p(ra), p(first), p(num), N, maxp, S, W, band[0], band[1],
                   p(tile_cnt), s)
         tile_off = torch.empty_like(tile_cnt)
         ws_b = lib.iso_prefix_sum_workspace_bytes(ntiles + 1, 1)
@@ -159,21 +170,21 @@ class _CNamespace(object):
         cursor = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)   # [ntiles] = overflow flag
         if overflow_out is not None:
             overflow_out.append(cursor[ntiles:])
-        rws_b = lib.iso_splat_forward_workspace_bytes(N * T * (band[1] - band[0]), K) if split_heavy_tiles else 0
+        rws_b = lib.iso_splat_forward_workspace_bytes(N * TW * (band[1] - band[0]), K) if split_heavy_tiles else 0
         rws = torch.empty((rws_b,), dtype=torch.uint8, device=dev) if rws_b else None
         if composite_with is not None:
             sc_, ft_, norm_, eps_ = composite_with
             C = ft_.shape[1]
             img = image_out if image_out is not None else (
-                torch.empty((N, S, S, C + 1), dtype=torch.float32, device=dev) if band == (0, T)
-                else torch.zeros((N, S, S, C + 1), dtype=torch.float32, device=dev))
+                torch.empty((N, S, W, C + 1), dtype=torch.float32, device=dev) if band == (0, T)
+                else torch.zeros((N, S, W, C + 1), dtype=torch.float32, device=dev))
             _lib.call("iso_splat_render", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
-                      float(depth_merging_thres), S, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
+                      float(depth_merging_thres), S, W, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
                       _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), p(rws), rws_b,
                       p(_f32c(sc_)), p(_f32c(ft_)), C, int(bool(norm_)), float(eps_), p(img), s)
             return idx, zbuf, qv, occ, img
         _lib.call("iso_splat_forward", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
-                  float(depth_merging_thres), S, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
+                  float(depth_merging_thres), S, W, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
                   _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), p(rws), rws_b, s)
         return idx, zbuf, qv, occ
 
@@ -189,9 +200,7 @@ class _CNamespace(object):
                   idx=None, grad_zbuf=None, max_pts=None):
         dev = points.device
         P = points.shape[0]
-        N, S = grad_occ.shape[0], grad_occ.shape[1]
-        if grad_occ.shape[1] != grad_occ.shape[2]:
-            raise RuntimeError("splat backward only supports square images")
+        N, S, W = grad_occ.shape[0], grad_occ.shape[1], grad_occ.shape[2]
         grad = torch.zeros((P, 3), dtype=torch.float32, device=dev)
         if P == 0 or N == 0:
             return grad
@@ -200,7 +209,7 @@ class _CNamespace(object):
         if hasattr(num, "_iso_host") and num_c is not num:
             with_host_lengths(num_c, host_lengths(num))
         lib = _lib.load()
-        ws_b = lib.iso_splat_backward_workspace_bytes(N, S, P)
+        ws_b = lib.iso_splat_backward_workspace_bytes(N, S, W, P)
         ws = torch.empty((max(ws_b, 1),), dtype=torch.uint8, device=dev)
         K = idx.shape[-1] if idx is not None else 1
         p = _lib.ptr
@@ -208,7 +217,7 @@ class _CNamespace(object):
                   p(_f32c(rs)) if rs is not None else None, p(first), p(num_c), N,
                   int(max_pts) if max_pts is not None else _max_pts(num_c), p(go),
                   p(idx.contiguous()) if idx is not None else None,
-                  p(_f32c(grad_zbuf)) if grad_zbuf is not None else None, S, K, int(rect_mode),
+                  p(_f32c(grad_zbuf)) if grad_zbuf is not None else None, S, W, K, int(rect_mode),
                   float(radii_s), P, p(ws), ws.numel(), p(grad), _lib.stream())
         return grad
 
@@ -403,7 +412,7 @@ class SurfaceSplatting(object):
         radii = torch.empty((tot, 2), dtype=torch.float32, device=dev)
         scaler = torch.empty((tot,), dtype=torch.float32, device=dev)
         _lib.call("iso_splat_setup", p(points_f), p(normals_f), p(h), p(first), p(num), p(_f32c(views)),
-                  p(_f32c(projs)), N, mx, int(rs.image_size), float(rs.antialiasing_sigma),
+                  p(_f32c(projs)), N, mx, min(image_hw(rs.image_size)), float(rs.antialiasing_sigma),
                   float(rs.cutoff_threshold), p(ndc), p(ellipse), p(cutoff), p(radii), p(scaler), s)
         return ndc, {"radii": radii, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "scaler": scaler}
 
@@ -460,7 +469,7 @@ class SurfaceSplatting(object):
         p = _lib.ptr
         _lib.call("iso_splat_front", p(points), p(normals), p(_f32c(features)) if (features is not None and not features_from_normals) else None,
                   C, int(bool(features_from_normals)), p(mask), p(h), P, p(_f32c(views)), p(_f32c(projs)), N,
-                  int(rs.image_size), float(rs.antialiasing_sigma), float(rs.cutoff_threshold), p(ws), ws_b, p(first),
+                  min(image_hw(rs.image_size)), float(rs.antialiasing_sigma), float(rs.cutoff_threshold), p(ws), ws_b, p(first),
                   p(num), p(view_total), p(ndc), p(ellipse), p(cutoff), p(radii), p(scaler),
                   p(feat) if feat is not None else None, p(src), _lib.stream())
         return {"ndc": ndc, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "radii": radii, "scaler": scaler,
@@ -479,7 +488,7 @@ class SurfaceSplatting(object):
         pts, nrm = _f32c(points), _f32c(normals)
         P, N = pts.shape[0], views.shape[0]
         dev = pts.device
-        S, K = int(rs.image_size), int(rs.points_per_pixel)
+        (S, W), K = image_hw(rs.image_size), int(rs.points_per_pixel)
         with torch.no_grad():
             fr = self.front(pts, nrm, _f32c(views), _f32c(projs), features=features)
         lens = [int(x) for x in fr["num_points"].tolist()]          # the API returns exact-size tensors: one host read
@@ -489,9 +498,9 @@ class SurfaceSplatting(object):
         first = with_host_lengths(fr["first_idx"], fl)
         flags = ((fr["mask"][None] >> torch.arange(N, device=dev)[:, None]) & 1).to(torch.int32)
         if tot == 0:
-            idx = torch.full((N, S, S, K), -1, dtype=torch.int32, device=dev)
-            neg = torch.full((N, S, S, K), -1.0, dtype=torch.float32, device=dev)
-            occ = torch.zeros((N, S, S), dtype=torch.float32, device=dev)
+            idx = torch.full((N, S, W, K), -1, dtype=torch.int32, device=dev)
+            neg = torch.full((N, S, W, K), -1.0, dtype=torch.float32, device=dev)
+            occ = torch.zeros((N, S, W), dtype=torch.float32, device=dev)
             return PointFragments(idx, neg, neg.clone(), neg.clone(), occ), {"num_points": num, "first_idx": first,
                                                                              "flags": flags}
         info = {k: fr[k][:tot] for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler")}
@@ -501,13 +510,13 @@ class SurfaceSplatting(object):
                                         * P + src)]
         idx, zbuf, qv, occ = rasterize_elliptical_points(
             PackedClouds(ndc, first, num), info["ellipse_params"], info["cutoff_threshold"], info["radii"],
-            depth_merging_threshold=rs.depth_merging_threshold, image_size=S, points_per_pixel=K,
+            depth_merging_threshold=rs.depth_merging_threshold, image_size=rs.image_size, points_per_pixel=K,
             bin_size=rs.bin_size, max_points_per_bin=rs.max_points_per_bin,
             radii_backward_scaler=rs.radii_backward_scaler, clip_pts_grad=rs.clip_pts_grad)
         frag_scaler = gather_with_neg_idx(info["scaler"], idx)
         frags = PointFragments(idx, zbuf, qv, frag_scaler, occ)
         vis = torch.zeros((tot,), dtype=torch.uint8, device=dev)
-        _lib.call("iso_splat_mark_visible", _lib.ptr(idx), N * S * S, K, _lib.ptr(vis), _lib.stream())
+        _lib.call("iso_splat_mark_visible", _lib.ptr(idx), N * S * W, K, _lib.ptr(vis), _lib.stream())
         filtered = {"points": pts[src], "normals": nrm[src],
                     "features": fr["features"][:tot] if fr["features"] is not None else None, "ndc": ndc,
                     "num_points": num, "first_idx": first, "flags": flags, "visibility": vis.bool(), "src": src, **info}

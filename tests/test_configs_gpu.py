@@ -4,7 +4,9 @@ of configs[4] against the oracle at reduced size.
 
   configs[3]: 4 M points, 8-layer IDR SDF (8 x 512, skip 4, 6 frequencies), points sharded by brick slab
   configs[4]: 500 k iso-points, loss-weighted insert, splat fwd+bwd at the reference's largest squares
-              (1024, 1344: rasterizer.py:52 is square-only and rasterize_points.cu:462 caps the bins)"""
+              (1024, 1344: rasterizer.py:52 is square-only and rasterize_points.cu:462 caps the bins) and at
+              1200 x 1600 (H != W: pytorch3d's non-square NDC convention, tests/test_splat_gpu.py pins it to
+              the square sub-case)"""
 import pytest
 import torch
 
@@ -108,7 +110,7 @@ def test_cfg4_insert_500k_and_large_square_splat(dev):
     cloud = torch.nn.functional.normalize(new_pts[0], dim=-1).contiguous()
     views = torch.stack([look_at_view(3.0, 20.0, 0.0)]).to(dev)
     projs = views @ perspective(30.0).to(dev)
-    for S in (1024, 1344):
+    for S in (1024, 1344, (1200, 1600)):      # the last one is configs[4]'s own frame: beyond the reference (H != W)
         rs = PointsRasterizationSettings(image_size=S, points_per_pixel=8)
         ss = SurfaceSplatting(raster_settings=rs)
         frags, filt = ss.forward(cloud, cloud, cameras=(views, projs))

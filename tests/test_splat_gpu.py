@@ -357,6 +357,63 @@ def test_heavy_tiles_in_slices_equal_whole_tiles(dev, P, S, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(96, 160), (160, 96), (100, 130)])
+def test_non_square_image_against_the_square_sub_case(dev, H, W):
+    """H != W is beyond the reference (rasterizer.py:52: square only).  Convention: pytorch3d's non-square
+    NDC (shorter side [-1,1], square pixels), so the central min(H,W)^2 crop of an H x W render IS the
+    square render of the same cameras: per-pixel lists, images and the gradients of points that only see
+    crop pixels must agree (pixel centres differ by float rounding: a few borderline hits may flip)."""
+    from iso_points_amd.rasterizer import (PointsRasterizationSettings, SurfaceSplatting, _C, _visible_and_radius,
+                                           composite)
+    SO = _SO()
+    m = min(H, W)
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    P = 40000
+    pts = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    views = torch.stack([SO.look_at_view(3.0, 20.0, 40.0), SO.look_at_view(3.5, -10.0, 200.0)]).to(dev)
+    projs = views @ SO.perspective(30.0).to(dev)
+    K = 6
+    res = {}
+    for key, size in (("rect", (H, W)), ("square", m)):
+        ss = SurfaceSplatting(raster_settings=PointsRasterizationSettings(image_size=size, points_per_pixel=K))
+        frags, filt = ss.forward(pts, pts, cameras=(views, projs))
+        img = composite(frags, filt["scaler"], 0.5 * (filt["normals"] + 1))
+        res[key] = (frags, filt, img)
+    fr, fs = res["rect"][0], res["square"][0]
+    assert fr.idx.shape == (2, H, W, K) and res["rect"][2].shape == (2, H, W, 4)
+    y0, x0 = (H - m) // 2, (W - m) // 2
+    assert (H - m) % 2 == 0 and (W - m) % 2 == 0
+    crop = lambda t: t[:, y0:y0 + m, x0:x0 + m]
+    for k in ("radii", "ellipse_params", "scaler", "ndc"):
+        assert torch.equal(res["rect"][1][k], res["square"][1][k])          # the set-up only sees min(H, W)
+    same = (crop(fr.idx) == fs.idx).all(dim=-1).float().mean().item()
+    assert same > 0.995, same
+    ok = (crop(fr.idx) == fs.idx).all(dim=-1)
+    assert torch.equal(crop(fr.zbuf)[ok], fs.zbuf[ok])
+    assert (crop(res["rect"][2])[ok] - res["square"][2][ok]).abs().max().item() < 1e-5
+    # outside the crop the longer axis keeps rendering: some hits there (the sphere overflows the square view)
+    assert (fr.idx[..., 0] >= 0).sum() > (fs.idx[..., 0] >= 0).sum()
+    # backward with a gradient that lives on the crop only
+    go_s = torch.zeros((2, m, m), device=dev)
+    go_s.copy_(torch.randn(2, m, m, generator=g).to(dev))
+    go_s[go_s.abs() < 1.2] = 0
+    go_r = torch.zeros((2, H, W), device=dev)
+    go_r[:, y0:y0 + m, x0:x0 + m] = go_s
+    grads = {}
+    for key, go, (frags, filt, _) in (("rect", go_r, res["rect"]), ("square", go_s, res["square"])):
+        zg = torch.zeros_like(frags.zbuf)
+        vis, rs_ = _visible_and_radius(fs.idx, filt["radii"], filt["first_idx"], filt["num_points"], 10.0)   # same visible set
+        grads[key] = _C._backward(filt["ndc"], filt["radii"], go, filt["first_idx"], filt["num_points"], visible=vis,
+                                  rs=rs_, idx=frags.idx, grad_zbuf=zg)
+    ndc = res["square"][1]["ndc"]
+    inside = (ndc[:, 0].abs() <= 1) & (ndc[:, 1].abs() <= 1)                   # the square kernel skips the others
+    a, b = grads["rect"][inside][:, :2], grads["square"][inside][:, :2]
+    err = (a - b).abs().amax(dim=-1) / b.abs().max()
+    # a pixel centre that moves by one ulp can enter or leave a disc / splat rectangle: rare single-term flips
+    assert (err > 1e-5).float().mean().item() < 5e-3 and err.median().item() < 1e-6
+
+
+@pytest.mark.gpu
 def test_median_radius_matches_torch_median():
     """rasterizer.py:884: r_n = torch.median(radii[visible of cloud n]) * scaler -- the radix select
     must return the same element bit for bit (lower median, duplicates, empty visible set)."""
