@@ -7,10 +7,10 @@
 //
 // f32 product from 16-bit MFMAs (mfma_split.h).  Default (X3_FWD_F16 = X3_BWD_F16 = 1): every f32
 // operand is cut into TWO fp16 numbers (11 + 11 significant bits, round-to-nearest at each cut:
-// exact to 2^-24 relative) under an exact power-of-two scale -- per layer for the weights, 2^12 for
+// <= 2^-22 relative in the worst case) under an exact power-of-two scale -- per layer for the weights, 2^12 for
 // the activations, per point for the adjoint of the reverse sweep -- and W.x is accumulated in f32
 // from three products  Wl.xh + Wh.xl + Wh.xh  (fp16 x fp16 is exact in f32; the dropped Wl.xl is
-// 2^-24 relative).  The fp16 pipe runs 16x the f32 MFMA rate, so three passes are 5.3x faster than
+// <= 2^-22 relative; see mfma_split.h for what that means against the 2^-24 of f32).  The fp16 pipe runs 16x the f32 MFMA rate, so three passes are 5.3x faster than
 // one f32 pass; measured against float64 in tests/test_projection_gpu.py next to the f32-MFMA
 // kernel.  With X3_FWD_F16 = X3_BWD_F16 = 0 the operands are cut exactly into three bf16 numbers
 // instead (no scales needed, six products, three parts per LDS entry): the form this file started

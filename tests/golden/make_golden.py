@@ -246,6 +246,9 @@ def main():
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "idr"):
         from make_golden_pp import gen_idr
         gen_idr(L)
+    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "siren_ref"):
+        from make_golden_pp import gen_siren_ref
+        gen_siren_ref(L)
     if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "trace"):
         from make_golden_trace import gen_trace
         gen_trace(L)

@@ -166,3 +166,28 @@ def gen_idr(L):
         parts += [W.reshape(-1), lin.bias.detach().reshape(-1)]
     npz("idr_small.npz", points=x, sdf=sdf, grad=grad, hidden=H, n_layers=NL, skip=SK[0], n_freq=NF,
         raw=torch.cat(parts), T=5, fixed_points=res.points, fixed_normals=res.normals)
+
+
+def gen_siren_ref(L):
+    """The reference's own Siren class (DSS/models/common.py:90-165; c_dim = 0 as test_dtu_points.py:216-227
+    builds it) evaluated through the reference's _compute_sdf_and_grad / _project_points: pins SURVEY 8(a2)
+    with the class the training scripts instantiate, not with the oracle's restatement of it."""
+    import importlib
+    import warnings
+    from make_golden import npz
+    warnings.filterwarnings("ignore")
+    C = importlib.import_module("DSS.models.common")
+    for name, H, NL, seed in (("siren_ref_128x2.npz", 128, 1, 11), ("siren_ref_256x4.npz", 256, 3, 12)):
+        torch.manual_seed(seed)
+        m = C.Siren(dim=3, hidden_size=H, n_layers=NL, c_dim=0, first_omega_0=30, hidden_omega_0=30.0)
+        g = torch.Generator().manual_seed(seed + 100)
+        x = (torch.rand(1, 1500, 3, generator=g) - 0.5) * 1.6
+        up = L.UniformProjection()
+        sdf, grad = up._compute_sdf_and_grad(x.clone(), m)
+        res = up._project_points(m, x.clone(), torch.tensor([1500]), proj_max_iters=4, proj_tolerance=1e-30)
+        parts = []
+        for layer in list(m.net):
+            lin = layer.linear if hasattr(layer, "linear") else layer
+            parts += [lin.weight.detach().reshape(-1), lin.bias.detach().reshape(-1)]
+        npz(name, points=x, sdf=sdf, grad=grad, hidden=H, n_layers=NL, raw=torch.cat(parts), T=4,
+            fixed_points=res.points, fixed_normals=res.normals)

@@ -76,3 +76,29 @@ def test_project_points_driver(dev):
         g["points"].to(dev), SphereSDF().to(dev), skip_upsampling=True)
     assert out["levelset_points"].shape == g["levelset_points"].shape
     assert_projection_close(out["levelset_points"], g["levelset_points"])
+
+
+@pytest.mark.parametrize("name", ["siren_ref_128x2.npz", "siren_ref_256x4.npz"])
+@pytest.mark.parametrize("mode", ["split16", "f32"])
+def test_fused_siren_vs_the_reference_siren_class(dev, name, mode):
+    """the fused SDF + gradient kernel and the Newton projection on the weights of the
+    reference's own Siren class (common.py:90-165) against what the reference computed with them
+    (model.forward + autograd, 4 clamped Newton moves), 1e-5 relative."""
+    from test_oracle_golden import load, siren_from_ref
+    from iso_points_amd import _lib
+    from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
+    from iso_points_amd.sdf_models import siren_sdf_and_grad
+    from util import rel_err
+    g = load(name)
+    m = siren_from_ref(g).to(dev)
+    lib = _lib.load()
+    lib.iso_siren_set_gemm_mode(1 if mode == "split16" else 0)
+    try:
+        sdf, grad = siren_sdf_and_grad(m, g["points"].to(dev))
+        assert rel_err(sdf, g["sdf"].reshape(sdf.shape)) < 1e-5 and rel_err(grad, g["grad"].reshape(grad.shape)) < 1e-5
+        x = g["points"].to(dev)
+        r = UniformProjection(proj_tolerance=1e-30)._project_points(m, x, full_lengths(x), proj_max_iters=int(g["T"]))
+        assert rel_err(r.points, g["fixed_points"]) < 1e-5
+        assert rel_err(r.normals, g["fixed_normals"]) < 1e-4
+    finally:
+        lib.iso_siren_set_gemm_mode(1)

@@ -170,6 +170,35 @@ def test_insert():
     assert rel_err(child, g["child_pts"]) < TIGHT
 
 
+def siren_from_ref(g):
+    """oracle SirenSDF carrying the weights of a golden made by the reference's own Siren class."""
+    from oracle import iso_oracle as O
+    m = O.SirenSDF(hidden_size=int(g["hidden"]), n_layers=int(g["n_layers"]))
+    raw, o = g["raw"], 0
+    with torch.no_grad():
+        for lin in m.lins:
+            n = lin.weight.numel()
+            lin.weight.copy_(raw[o:o + n].view_as(lin.weight)); o += n
+            n = lin.bias.numel()
+            lin.bias.copy_(raw[o:o + n]); o += n
+    assert o == raw.numel()
+    return m
+
+
+@pytest.mark.parametrize("name", ["siren_ref_128x2.npz", "siren_ref_256x4.npz"])
+def test_siren_restatement_vs_the_reference_class(name):
+    """the oracle's SirenSDF against the reference's own Siren (common.py:90-165, c_dim = 0)
+    evaluated through the reference's _compute_sdf_and_grad / _project_points."""
+    from oracle import iso_oracle as O
+    g = load(name)
+    m = siren_from_ref(g)
+    sdf, grad = O.compute_sdf_and_grad(g["points"], m)
+    assert rel_err(sdf, g["sdf"]) < 1e-5 and rel_err(grad, g["grad"]) < 1e-5
+    r = O.project_points(m, g["points"], torch.tensor([g["points"].shape[1]]), proj_max_iters=int(g["T"]),
+                         proj_tolerance=1e-30)
+    assert rel_err(r.points, g["fixed_points"]) < 1e-5
+
+
 def idr_from(g):
     from oracle import iso_oracle as O
     m = O.IdrSDF(hidden_size=int(g["hidden"]), n_layers=int(g["n_layers"]), skip_in=(int(g["skip"]),),
@@ -381,3 +410,24 @@ def test_denoise_normals_restatement(K):
     out = O.denoise_normals(g["points"], g["normals"], sharpness_sigma=g["sigma"], neighborhood_size=K)
     assert rel_err(out, g["out"]) < TIGHT
     assert rel_err(torch.nn.functional.normalize(g["normals"], dim=-1), g["out"]) > 0.05    # it did something
+
+
+def test_ray_sampling_restatement():
+    """ray_nearest_point / insurface_segments / lowest_sdf_on_segments against the
+    reference's own statements (combined_modeling.py:324-386, executed by tests/golden/make_golden_rays.py)."""
+    from oracle import iso_oracle as O
+    g = load("ray_sampling.npz")
+    B = g["cam_pos"].shape[0]
+    model = O.SphereSDF(radius=float(g["sdf_radius"]))
+    l0s, l1s, ps, valid_all = [], [], [], []
+    for b in range(B):
+        cam = g["cam_pos"][b]
+        ray0 = torch.nn.functional.normalize(g["samples"][b] - cam.view(1, 3), dim=-1)
+        l0, l1, valid = O.insurface_segments(cam, ray0, g["frontal%d" % b], g["occluded%d" % b])
+        valid_all.append(valid)
+        l0s.append(l0[valid]); l1s.append(l1[valid])
+        p, _ = O.lowest_sdf_on_segments(model, cam, ray0[valid], l0[valid], l1[valid], int(g["n_points_per_ray"]))
+        ps.append(p)
+    assert torch.equal(torch.stack(valid_all), g["mask_insurface"].bool())
+    assert rel_err(torch.cat(l0s), g["ray_len0"]) < 1e-6 and rel_err(torch.cat(l1s), g["ray_len1"]) < 1e-6
+    assert rel_err(torch.cat(ps), g["p_insurface"]) < 1e-6

@@ -159,3 +159,32 @@ def test_get_tensor_values_vs_oracle_large(dev):
     assert got.shape == (4, 250000) and (got.cpu() - ref).abs().max() < 2e-5
     empty = get_tensor_values(mask.to(dev).float(), torch.zeros(4, 0, 2, device=dev))
     assert empty.shape == (4, 0, 1)
+
+
+def test_ray_side_sampling_vs_the_reference_statements(dev):
+    """iso_ray_nearest_point + segment bounds + lowest-SDF candidate against the reference's own dense
+    (R,M) statements (combined_modeling.py:324-386; tests/golden/ray_sampling.npz)."""
+    from test_oracle_golden import load
+    from iso_points_amd.ray_sampling import insurface_segments, lowest_sdf_on_segments
+    from iso_points_amd.sdf_models import SphereSDF
+    g = load("ray_sampling.npz")
+    B = g["cam_pos"].shape[0]
+    model = SphereSDF(radius=float(g["sdf_radius"])).to(dev)
+    l0s, l1s, ps, valid_all = [], [], [], []
+    for b in range(B):
+        cam = g["cam_pos"][b]
+        ray0 = torch.nn.functional.normalize(g["samples"][b] - cam.view(1, 3), dim=-1).to(dev)
+        l0, l1, valid = insurface_segments(cam, ray0, g["frontal%d" % b].to(dev), g["occluded%d" % b].to(dev))
+        valid_all.append(valid.cpu())
+        l0s.append(l0[valid].cpu()); l1s.append(l1[valid].cpu())
+        ps.append(lowest_sdf_on_segments(model, cam.to(dev), ray0[valid], l0[valid], l1[valid],
+                                         n_points_per_ray=int(g["n_points_per_ray"])).cpu())
+    assert torch.equal(torch.stack(valid_all), g["mask_insurface"].bool())
+    # the point nearest to a ray is the same unless two distances agree to rounding (the dense statement
+    # subtracts two large squares); the bounds then differ by the spacing of the cloud
+    e0 = (torch.cat(l0s) - g["ray_len0"]).abs() / g["ray_len0"].abs().max()
+    e1 = (torch.cat(l1s) - g["ray_len1"]).abs() / g["ray_len1"].abs().max()
+    assert (e0 > 1e-5).float().mean() < 0.01 and (e1 > 1e-5).float().mean() < 0.01
+    ok = (e0 <= 1e-5) & (e1 <= 1e-5)
+    ep = (torch.cat(ps) - g["p_insurface"]).abs().amax(-1)
+    assert (ep[ok] > 1e-5).float().mean() < 0.02       # equal candidate values on a symmetric chord may tie
