@@ -19,7 +19,7 @@
 
 struct BrickHdr {                      // device resident, 32 dwords
   float mn[3]; float inv_f;            //  0..3   origin of the fine grid, 1 / fine cell size
-  float nbx_f, nby_f, nbz_f, total_f;  //  4..7   ISO_GRID3_PARAMS layout for iso_frnn_scan_cells ([7] = bricks + 1)
+  float nbx_f, nby_f, nbz_f, total_f;  //  4..7   ISO_GRID3_PARAMS layout for iso_frnn_scan_cells ([7] = 8 * bricks + 1)
   float f, r, r2, g2;                  //  8..11  fine cell, search radius, r^2, (0.999 f)^2
   float inv_sigma, diag, spacing, pad0;  // 12..15  P / diag (levelset_sampling.py:256), |bbox diagonal|, sqrt(diag / P)
   int nb[3]; int n_bricks;             // 16..19
@@ -45,7 +45,7 @@ struct BrickWs {      // carved out of one caller-owned workspace
   BrickHdr* hdr;
   int32_t* counters;  // [0] list_count  [1] tail_count  [2] overflow bricks  [3] tail2_count  [4] export overflow
                       // [5] import overflow  [6] tail queries whose search left the imported halo  (16 ints)
-  int32_t* cnt;       // [G]
+  int32_t* cnt;       // [G]  G = 8 * cap^3 + 1: eight counters per brick
   int32_t* off;       // [G]
   int32_t* slot;      // [n_max]
   float4* rec0;       // [n_max]

@@ -28,7 +28,7 @@ BrickWs bricks_carve(void* ws, int64_t n_max) {
   BrickWs w;
   if (n_max < 1) n_max = 1;
   w.nb_cap = bricks_nb_cap(n_max);
-  w.G = (int64_t)w.nb_cap * w.nb_cap * w.nb_cap + 1;
+  w.G = 8 * (int64_t)w.nb_cap * w.nb_cap * w.nb_cap + 1;       // 8 counters per brick (see brick_key)
   auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
   char* p = (char*)ws;
   int64_t o = 0;
@@ -91,7 +91,7 @@ __global__ void k_bricks_params(const float* __restrict__ bbox, int64_t n_total,
   const int nbr = nb[0] * nb[1] * nb[2];
   h->inv_f = inv_f;
   h->nbx_f = (float)nb[0]; h->nby_f = (float)nb[1]; h->nbz_f = (float)nb[2];
-  h->total_f = (float)(nbr + 1);
+  h->total_f = (float)(8 * nbr + 1);
   h->f = f; h->r = r; h->r2 = r * r;
   const float g = 0.999f * f;
   h->g2 = g * g;
@@ -107,7 +107,7 @@ __global__ void k_bricks_params(const float* __restrict__ bbox, int64_t n_total,
 }
 
 __global__ void k_bricks_zero(const BrickHdr* __restrict__ h, int32_t* __restrict__ cnt) {
-  const int n = h->n_bricks + 1;
+  const int n = 8 * h->n_bricks + 1;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cnt[i] = 0;
 }
 
@@ -118,13 +118,24 @@ __device__ __forceinline__ int brick_of(const BrickHdr& h, float x, float y, flo
   return ((fx >> 2) * h.nb[1] + (fy >> 2)) * h.nb[2] + (fz >> 2);
 }
 
+// Counter of a point: 8 per brick (its 2x2x2 half-brick octants).  The records of brick b are
+// [off[8 b], off[8 (b + 1)]) whatever the order inside; eight times as many counters as bricks keep the
+// same-address atomics of the counting pass short (a 1 M-point surface fills only ~8 k bricks).
+__device__ __forceinline__ int brick_key(const BrickHdr& h, float x, float y, float z) {
+  const int fx = bk_fine(x, h.mn[0], h.inv_f, h.nf[0]);
+  const int fy = bk_fine(y, h.mn[1], h.inv_f, h.nf[1]);
+  const int fz = bk_fine(z, h.mn[2], h.inv_f, h.nf[2]);
+  const int b = ((fx >> 2) * h.nb[1] + (fy >> 2)) * h.nb[2] + (fz >> 2);
+  return b * 8 + ((fx >> 1) & 1) * 4 + ((fy >> 1) & 1) * 2 + ((fz >> 1) & 1);
+}
+
 // own points (packed (n,3) f32): arrival slot inside the brick
 __global__ __launch_bounds__(256) void k_brick_count(const float* __restrict__ pts, int64_t n,
                                                      const BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
                                                      int32_t* __restrict__ slot) {
   const BrickHdr h = *hp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = brick_of(h, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
+    const int b = brick_key(h, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
     slot[i] = atomicAdd(&cnt[b], 1);
   }
 }
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(256) void k_brick_count_recs(const float4* __restri
   if (blockIdx.x == 0 && threadIdx.x == 0) hp->n = h.n_own + (int)m;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
     const float4 p = imp0[j];
-    slot[h.n_own + j] = atomicAdd(&cnt[brick_of(h, p.x, p.y, p.z)], 1);
+    slot[h.n_own + j] = atomicAdd(&cnt[brick_key(h, p.x, p.y, p.z)], 1);
   }
 }
 
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256) void k_brick_scatter(const float* __restrict__
   const BrickHdr h = *hp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
-    const int64_t dst = (int64_t)off[brick_of(h, x, y, z)] + slot[i];
+    const int64_t dst = (int64_t)off[brick_key(h, x, y, z)] + slot[i];
     rec0[dst] = make_float4(x, y, z, __int_as_float(h.id_base + (int)i));
     float4 u = make_float4(0.f, 0.f, 0.f, __int_as_float(payload ? payload[i] : 0));
     if (nrm) { u.x = nrm[i * 3]; u.y = nrm[i * 3 + 1]; u.z = nrm[i * 3 + 2]; }
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256) void k_brick_scatter_recs(const float4* __rest
   const int64_t m = h.n - h.n_own;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
     const float4 p = imp0[j];
-    const int64_t dst = (int64_t)off[brick_of(h, p.x, p.y, p.z)] + slot[h.n_own + j];
+    const int64_t dst = (int64_t)off[brick_key(h, p.x, p.y, p.z)] + slot[h.n_own + j];
     rec0[dst] = p;
     rec1[dst] = imp1[j];
   }
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256) void k_brick_list(const BrickHdr* __restrict__
   const int lane = threadIdx.x & 63;
   for (int b0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; b0 < nb; b0 += gridDim.x * blockDim.x) {
     const int b = b0 + lane;
-    const bool occ = b < nb && off[b + 1] > off[b];
+    const bool occ = b < nb && off[8 * (b + 1)] > off[8 * b];
     const unsigned long long bal = __ballot(occ);
     int base = 0;
     if (lane == 0 && bal) base = atomicAdd(&counters[0], __popcll(bal));
@@ -227,8 +238,8 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
     int i0 = 0, len = 0;
     if (x >= 0 && x < nbx && y >= 0 && y < nby) {
       const int z0 = max(g.bz - 1, 0), z1 = min(g.bz + 1, nbz - 1);
-      i0 = off[(x * nby + y) * nbz + z0];
-      len = off[(x * nby + y) * nbz + z1 + 1] - i0;
+      i0 = off[8 * ((x * nby + y) * nbz + z0)];
+      len = off[8 * ((x * nby + y) * nbz + z1 + 1)] - i0;
     }
     S.run_i0[tid] = i0;
     S.run_pre[tid + 1] = len;
@@ -371,7 +382,7 @@ __device__ __forceinline__ void walk_candidates(const BrickStage<WITH_NRM>& S, i
 // a brick whose neighbourhood does not fit LDS: its own points go to the tail kernel
 __device__ void brick_to_tail(const BrickHdr& h, const int32_t* __restrict__ off, const float4* __restrict__ rec0, int b,
                               int32_t* __restrict__ tail, int32_t* __restrict__ counters, int tail_slot, int per_query) {
-  for (int i = off[b] + threadIdx.x; i < off[b + 1]; i += BK_THREADS) {
+  for (int i = off[8 * b] + threadIdx.x; i < off[8 * (b + 1)]; i += BK_THREADS) {
     const int gid = __float_as_int(rec0[i].w);
     if (gid >= h.id_base && gid < h.id_base + h.n_own) {
       const int at = atomicAdd(&counters[tail_slot], per_query);
@@ -527,8 +538,8 @@ __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz,
         za = max(za, 0); zb = min(zb, nbz - 1);
         if (za > zb) continue;
         const int c0 = (x * nby + y) * nbz + za, c1 = (x * nby + y) * nbz + zb;
-        const int e = off[c1 + 1];
-        for (int i = off[c0] + lane; i < e; i += 64) body(i);
+        const int e = off[8 * (c1 + 1)];
+        for (int i = off[8 * c0] + lane; i < e; i += 64) body(i);
       }
     }
 }

@@ -92,26 +92,31 @@ out = ins.insert(Ref(), pts, num)
 t_ins = timeit(lambda: ins.insert(Ref(), pts, num), warm=1, rep=5)
 put("cfg5_fps_5000_of_500k", ms=t_fps)
 put("cfg5_insert_500k", ms=t_ins, children=int(out[3].sum()))
-for S in (1024, 1344):
+from iso_points_amd.rasterizer import SurfaceSplatting, _C, _visible_and_radius, composite, image_hw
+for S in (1024, 1344, (1200, 1600)):      # the last: configs[4]'s own frame (H != W is beyond the reference)
     rs = PointsRasterizationSettings(image_size=S, points_per_pixel=8, cutoff_threshold=1.0, depth_merging_threshold=0.05,
                                      radii_backward_scaler=10, backface_culling=True, Vrk_isotropic=True, bin_size=None)
     views = torch.stack([look_at_view(3.0, 20.0, 90.0 * i) for i in range(1)]).to(dev)
     projs = views @ perspective(30.0).to(dev)
-    cyc = IsoCycle(sph, pts, views, projs, raster_settings=rs, knn_k=8, target=sphere_silhouette(S, 1, 3.0, 30.0, dev))
-    nrm = pts[0].clone()
-    feats = 0.5 * (nrm + 1)
+    ss = SurfaceSplatting(raster_settings=rs)
+    cloud = pts[0].contiguous()
+    H, W = image_hw(S)
 
     def splat():
-        frags, filt = cyc.splat_forward(pts[0], nrm, feats)
-        img = cyc.composite_band(frags, filt)
+        fr = ss.front(cloud, cloud, views, projs, features_from_normals=True)
+        idx, zb, qv, occ, img = _C.splat_points(fr["ndc"], fr["ellipse_params"], fr["cutoff_threshold"], fr["radii"],
+                                                fr["first_idx"], fr["num_points"], 0.05, S, 8, max_pts=P,
+                                                pair_capacity=8 * P, composite_with=(fr["scaler"], fr["features"], True, 1e-4))
         alpha = img[..., 3]
-        occ_grad = 2.0 * (alpha - cyc.target) / alpha.numel()
-        zg = torch.zeros_like(frags.zbuf)
+        occ_grad = 2.0 * (alpha - 0.5) / alpha.numel()
+        zg = torch.zeros_like(zb)
         zg[..., 0] = 1e-3 / alpha.numel()
-        return cyc.backward(frags, filt, occ_grad, zg)
+        vis, rs_ = _visible_and_radius(idx, fr["radii"], fr["first_idx"], fr["num_points"], 10.0, max_pts=P)
+        return _C._backward(fr["ndc"], fr["radii"], occ_grad, fr["first_idx"], fr["num_points"], visible=vis, rs=rs_,
+                            idx=idx, grad_zbuf=zg, max_pts=P)
 
     splat()
     t = timeit(splat, warm=1, rep=5)
-    put("cfg5_splat_fwd_bwd_500k_%dx%d_1view" % (S, S), ms=t, Mpoints_s=P / t / 1e3)
+    put("cfg5_splat_fwd_bwd_500k_%dx%d_1view" % (H, W), ms=t, Mpoints_s=P / t / 1e3)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "configs_bench.json"), "w"), indent=1)

@@ -1,0 +1,37 @@
+"""HBM-side bytes per launch of the dominant kernels from the FETCH_SIZE / WRITE_SIZE PMC passes
+(MI355X_MICROARCH.md: both count 32-B units... the summaries hold raw counter sums; gfx950 correction:
+FETCH_SIZE under-reports wide coalesced reads by 2x).  traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 B / launches
+(rocprofv3 reports both in KiB).  usage: traffic_from_pmc.py fetch.txt write.txt out.json"""
+import json
+import re
+import sys
+
+
+def per_kernel(path, counter):
+    out = {}
+    for line in open(path):
+        if counter not in line:
+            continue
+        m = re.match(r"(.{90})\s+(\S+)\s+(\d+)\s+(\S+)\s+(\S+)", line)
+        if m and m.group(2) == counter:
+            out[m.group(1).strip()] = (int(m.group(3)), float(m.group(4)))
+    return out
+
+
+def main():
+    f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    res = {}
+    for name, key in (("k_siren_step_x3<256, 8, 3", "k_siren_step_x3"), ("k_siren_step<", "k_siren_step")):
+        ks = [k for k in f if name in k]
+        if not ks:
+            continue
+        k = ks[0]
+        n, fs = f[k]
+        ws = w.get(k, (n, 0.0))[1]
+        res[key] = {"kernel": k, "launches": n, "fetch_kib_sum": fs, "write_kib_sum": ws,
+                    "bytes_per_launch": (2 * fs + ws) * 1024.0 / max(n, 1),
+                    "note": "(2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes, per launch; FETCH_SIZE x2: gfx950 correction"}
+    json.dump(res, open(sys.argv[3], "w"), indent=1)
+
+
+main()
