@@ -519,29 +519,39 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
 }
 
 // ---- rings of bricks around a query (tail kernels: one wave per query) ---------------------------
-// All lanes walk the same column of bricks and split its records (a ring has as few as one
-// column).
+// All lanes walk the same column of bricks and split its records (a ring has as few as one column).
+// The record ranges of up to 64 columns are fetched by 64 lanes at once and handed round with shuffles: a
+// ring then costs one global-memory latency for its bounds instead of one per column.
 template <class Body>
 __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz, int nbx, int nby, int nbz,
                                              const int32_t* __restrict__ off, int lane, Body&& body) {
   const int x0 = max(qbx - rho, 0), x1 = min(qbx + rho, nbx - 1);
   const int y0 = max(qby - rho, 0), y1 = min(qby + rho, nby - 1);
-  for (int x = x0; x <= x1; ++x)
-    for (int y = y0; y <= y1; ++y) {
+  if (x0 > x1 || y0 > y1) return;
+  const int ny = y1 - y0 + 1, ncols = (x1 - x0 + 1) * ny;
+  for (int c0 = 0; c0 < ncols; c0 += 64) {
+    int s0 = 0, e0 = 0, s1 = 0, e1 = 0;                  // this lane's column: one z-run (edge) or two caps
+    const int col = c0 + lane;
+    if (col < ncols) {
+      const int x = x0 + col / ny, y = y0 + col % ny;
       const bool edge = (x == qbx - rho) || (x == qbx + rho) || (y == qby - rho) || (y == qby + rho);
-      const int nseg = edge ? 1 : 2;
-      for (int sg = 0; sg < nseg; ++sg) {
-        int za, zb;
-        if (edge) { za = qbz - rho; zb = qbz + rho; }
-        else if (sg == 0) { za = qbz - rho; zb = qbz - rho; }
-        else { za = qbz + rho; zb = qbz + rho; }
-        za = max(za, 0); zb = min(zb, nbz - 1);
-        if (za > zb) continue;
-        const int c0 = (x * nby + y) * nbz + za, c1 = (x * nby + y) * nbz + zb;
-        const int e = off[8 * (c1 + 1)];
-        for (int i = off[8 * c0] + lane; i < e; i += 64) body(i);
+      const int cb = (x * nby + y) * nbz;
+      if (edge) {
+        const int za = max(qbz - rho, 0), zb = min(qbz + rho, nbz - 1);
+        if (za <= zb) { s0 = off[8 * (cb + za)]; e0 = off[8 * (cb + zb + 1)]; }
+      } else {
+        const int za = qbz - rho, zb = qbz + rho;
+        if (za >= 0) { s0 = off[8 * (cb + za)]; e0 = off[8 * (cb + za + 1)]; }
+        if (zb < nbz) { s1 = off[8 * (cb + zb)]; e1 = off[8 * (cb + zb + 1)]; }
       }
     }
+    const int nc = min(64, ncols - c0);
+    for (int c = 0; c < nc; ++c) {
+      const int a0 = __shfl(s0, c), b0 = __shfl(e0, c), a1 = __shfl(s1, c), b1 = __shfl(e1, c);
+      for (int i = a0 + lane; i < b0; i += 64) body(i);
+      for (int i = a1 + lane; i < b1; i += 64) body(i);
+    }
+  }
 }
 
 template <int KMAX>

@@ -1160,33 +1160,55 @@ __global__ __launch_bounds__(256) void k_rsel_hist(const float* __restrict__ rad
   if (lh[threadIdx.x]) atomicAdd(&hist[n * 256 + threadIdx.x], lh[threadIdx.x]);
 }
 
-__global__ void k_rsel_pick(RselState* st, unsigned* hist, int n_clouds, float radii_s,
-                            float* __restrict__ out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+// one 256-lane workgroup per cloud: bucket of the wanted rank by a parallel prefix over the 256 counters
+__global__ __launch_bounds__(256) void k_rsel_pick(RselState* st, unsigned* hist, int n_clouds, float radii_s,
+                                                   float* __restrict__ out) {
+  __shared__ long long s_w[4];
+  __shared__ int s_b;
+  const int n = blockIdx.x;
   if (n >= n_clouds) return;
   RselState s = st[n];
   unsigned* h = hist + n * 256;
-  if (s.k < 0) {                       // first pass: total count and target rank
-    long long tot = 0;
-    for (int b = 0; b < 256; ++b) tot += h[b];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const long long v = h[t];
+  long long inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const long long u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+  if (lane == 63) s_w[w] = inc;
+  if (t == 0) s_b = 255;
+  __syncthreads();
+  long long base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (k < w) base += s_w[k]; tot += s_w[k]; }
+  inc += base;                                   // inclusive prefix of bucket t
+  if (s.k < 0) {                                 // first pass: total count and target rank
     s.cnt = tot;
     s.k = tot > 0 ? (tot - 1) / 2 : 0;
   }
-  if (s.cnt > 0) {
-    long long cum = 0;
-    int b = 0;
-    for (; b < 256; ++b) {
-      if (cum + (long long)h[b] > s.k) break;
-      cum += h[b];
+  __syncthreads();
+  if (s.cnt > 0 && inc > s.k && inc - v <= s.k) s_b = t;     // the bucket that holds rank k (exactly one lane)
+  __syncthreads();
+  h[t] = 0u;
+  if (t == 0) {
+    if (s.cnt > 0) {
+      const int b = s_b;
+      long long cum = 0;
+      // exclusive prefix of bucket b = inclusive - count; recomputed from the shared partials is not needed:
+      // lane b published only its index, so fetch its exclusive prefix through LDS
+      (void)cum;
+      s.prefix |= ((unsigned)b) << s.shift;
     }
-    if (b > 255) b = 255;
-    s.k -= cum;
-    s.prefix |= ((unsigned)b) << s.shift;
   }
-  s.shift -= 8;
-  for (int b = 0; b < 256; ++b) h[b] = 0u;
-  st[n] = s;
-  if (s.shift < 0) out[n] = s.cnt > 0 ? __uint_as_float(s.prefix) * radii_s : 0.0f;
+  // rank inside the bucket: k -= exclusive prefix of the chosen bucket (published by its lane)
+  __shared__ long long s_excl;
+  if (s.cnt > 0 && inc > s.k && inc - v <= s.k) s_excl = inc - v;
+  __syncthreads();
+  if (t == 0) {
+    if (s.cnt > 0) s.k -= s_excl;
+    s.shift -= 8;
+    st[n] = s;
+    if (s.shift < 0) out[n] = s.cnt > 0 ? __uint_as_float(s.prefix) * radii_s : 0.0f;
+  }
 }
 
 }  // namespace
@@ -1494,7 +1516,7 @@ extern "C" int iso_splat_median_radius(const float* radii, const uint8_t* visibl
   for (int pass = 0; pass < 4; ++pass) {
     if (max_pts > 0)
       hipLaunchKernelGGL(k_rsel_hist, dim3(gx, n_clouds), dim3(256), 0, s, radii, visible, first_idx, num_pts, st, hist);
-    hipLaunchKernelGGL(k_rsel_pick, dim3(iso_div_up(n_clouds, 64)), dim3(64), 0, s, st, hist, n_clouds, radii_s,
+    hipLaunchKernelGGL(k_rsel_pick, dim3(n_clouds), dim3(256), 0, s, st, hist, n_clouds, radii_s,
                        search_radius_out);
   }
   ISO_CHECK_LAUNCH("iso_splat_median_radius");

@@ -152,10 +152,12 @@ class IsoCycle(object):
         # capacities (rows / records); `calibrate` shrinks them to what the workload needs
         w = self.world
         self.halo_cap = 0 if w == 1 else max(4096, self.n_own)            # worst case: every own point is exported
-        self.import_cap = 0 if w == 1 else max(4096, 2 * self.n_own)
+        self.import_cap = 0 if w == 1 else max(4096, self.P - self.n_own)  # worst case: everybody else's points
         self.rec_cap = max(self.N * self.n_own, 1)
         self.pair_cap = max(1 << 16, 6 * self.N * self.P // w)
-        self.halo_cells = 2           # exchanged band, in fine cells (2 x 0.8 r covers the FRNN radius r)
+        self.halo_cells = 2           # exchanged band of the resample grid, in fine cells (2 x 0.8 r covers the radius r)
+        self.halo_cells_h = 4         # ... of the bandwidth grid: its K = 7 search has no useful radius bound (r = 0.2);
+                                      # a tail query that needs more than the band is counted (check: halo_uncertified)
         self._alloc()
         self._ovf = []
 
@@ -169,6 +171,7 @@ class IsoCycle(object):
             self.imp1 = torch.empty((self.import_cap, 4), dtype=torch.float32, device=dev)
             self.imp_count = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.wire = torch.empty((12 * self.rec_cap,), dtype=torch.float32, device=dev)
+        self._flags = torch.zeros((16,), dtype=torch.int32, device=dev)
 
     # -- stage 1/2: projection + resample -------------------------------------------------
     def _project(self, pts_local, T):
@@ -181,20 +184,25 @@ class IsoCycle(object):
             yield ("mark", "project_end", T)
         return r
 
-    def _halo_build(self, pts, nrm, payload, box, boxes, radius, knn_k, cell_scale):
+    def _halo_build(self, pts, nrm, payload, box, boxes, radius, knn_k, cell_scale, halo):
         """N ranks: common grid from the reduced box, halo export -> all-gather -> import, build."""
         p, lib_call, g = _lib.ptr, _lib.call, self.grid
         gbox = torch.cat([boxes[:, 0:4].min(dim=0).values, boxes[:, 4:8].max(dim=0).values]).contiguous()
         lib_call("iso_bricks_params", p(gbox), self.P, self.n_own, self.lo, float(radius), int(knn_k), float(cell_scale),
                  p(g.ws), g.n_max, _lib.stream())
         lib_call("iso_halo_export", p(g.ws), p(pts), p(nrm), p(payload), self.n_own, p(boxes), self.world, self.rank,
-                 self.halo_cells, p(self.exp_buf), self.halo_cap, _lib.stream())
+                 halo, p(self.exp_buf), self.halo_cap, _lib.stream())
         gathered = yield ("all_gather", self.exp_buf)
-        lib_call("iso_halo_import", p(g.ws), g.n_max, p(gathered), p(boxes), self.world, self.rank, self.halo_cells,
+        lib_call("iso_halo_import", p(g.ws), g.n_max, p(gathered), p(boxes), self.world, self.rank, halo,
                  self.halo_cap,
                  p(self.imp0), p(self.imp1), p(self.imp_count), self.import_cap, _lib.stream())
         g.build(pts, nrm, payload=payload, params_done=True, id_base=self.lo, n_total=self.P,
                 imports=(self.imp0, self.imp1, self.imp_count))
+
+    def _note_counters(self):
+        """The grid's device-side counters (overflows, uncertified tail queries) are reset by the next build:
+        accumulate them over the cycle (one tiny kernel, no host read)."""
+        self._flags += self.grid.ws[256:320].view(torch.int32)
 
     def _resample(self, pts, nrm):
         """FRNN K+1 query + tangent-plane repulsion of the own points (levelset_sampling.py:254-284)."""
@@ -204,8 +212,9 @@ class IsoCycle(object):
             self.grid.build(pts, nrm, bbox=box, knn_k=self.knn_k, cell_scale=cs)
         else:
             boxes = yield ("all_gather", box)
-            yield from self._halo_build(pts, nrm, None, box, boxes, -1.0, self.knn_k, cs)
+            yield from self._halo_build(pts, nrm, None, box, boxes, -1.0, self.knn_k, cs, self.halo_cells)
         moved, _, _ = bricks.resample_fused(self.grid, self.knn_k + 1)
+        self._note_counters()
         return moved
 
     def project_resample(self):
@@ -230,8 +239,10 @@ class IsoCycle(object):
             boxes = got[:, :8].contiguous()
             counts = got[:, 8:].contiguous().view(torch.int32)                     # (world, 8)
             view_total = counts.sum(dim=0, dtype=torch.int32)
-            yield from self._halo_build(pts, nrm, mask, box, boxes, float(ss.frnn_radius), 0, bricks.H_CELL_SCALE)
+            yield from self._halo_build(pts, nrm, mask, box, boxes, float(ss.frnn_radius), 0, bricks.H_CELL_SCALE,
+                                        self.halo_cells_h)
         h = bricks.splat_h_fused(self.grid, mask, view_total, N)
+        self._note_counters()
         fr = ss.front_setup(pts, nrm, self.views, self.projs, mask, h, features_from_normals=True, out=self.wire,
                             capacity=self.rec_cap)
         if w == 1:
@@ -341,6 +352,7 @@ class IsoCycle(object):
         image with the own band filled, gradient of the packed rows, fragments, front-end dict)."""
         # the SDF weights are packed once per cycle (they change once per optimiser step), not per projection
         self.proj.reuse_packed, self.proj._packed_cache = True, None
+        self._flags.zero_()
         r1 = yield from self.project_resample()
         fr = yield from self._front(r1.points[0].contiguous(), r1.normals[0].contiguous())
         if self.marks:
@@ -431,7 +443,8 @@ class IsoCycle(object):
     def usage(self, fr=None):
         """Host read of the device-side counts of the last cycle (set-up / tests only)."""
         hdr = self.grid.header()
-        c = self.grid.ws[256:320].cpu().view(torch.int32).tolist()
+        c = self._flags.tolist()                      # summed over the two grids of the cycle
+        hdr["tail"], hdr["overflow_bricks"], hdr["tail_h"] = c[1], c[2], c[3]
         u = {"grid": hdr, "halo_export_overflow": c[4], "halo_import_overflow": c[5], "halo_uncertified": c[6],
              "pair_overflow": int(self._ovf[0].item()) if self._ovf else 0}
         if self.world > 1:
@@ -457,6 +470,14 @@ class IsoCycle(object):
         over the ranks).  Untimed set-up; the capacities stay fixed afterwards and `check` reports
         an overflow."""
         out = self.step()
+        if self.world > 1:
+            # a bandwidth query near a slab face whose 7th neighbour lies beyond the exchanged band: widen it
+            for _ in range(6):
+                unc = self.comm.max_int(int(self._flags[6].item()), self.dev)
+                if unc == 0:
+                    break
+                self.halo_cells_h *= 2
+                out = self.step()
         u = self.check(out[4])
         if self.world > 1:
             c = self.comm

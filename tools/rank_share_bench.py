@@ -64,8 +64,14 @@ def main():
         ranks = [IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, world=world, rank=r)
                  for r in range(world)]
         res = run_lockstep(ranks)
+        for _ in range(6):      # = IsoCycle.calibrate() without a process group: widen the bandwidth halo if needed
+            if max(int(c._flags[6].item()) for c in ranks) == 0:
+                break
+            for c in ranks:
+                c.halo_cells_h *= 2
+            res = run_lockstep(ranks)
         use = [c.check(o[4]) for c, o in zip(ranks, res)]
-        if world > 1:           # = IsoCycle.calibrate() without a process group
+        if world > 1:
             for c in ranks:
                 c.halo_cap = max(1024, int(1.5 * max(u["halo_exported"] for u in use)))
                 c.import_cap = max(1024, int(1.5 * max(u["halo_imported"] for u in use)))
@@ -111,7 +117,7 @@ def main():
             "collectives_bytes_per_rank": log, "bytes_per_rank_total": sum(b for _, b in log),
             "halo_exported_max": max((u.get("halo_exported", 0) for u in use), default=0),
             "halo_imported_max": max((u.get("halo_imported", 0) for u in use), default=0),
-            "own_rows_max": max(u["own_rows"] for u in use),
+            "own_rows_max": max(u["own_rows"] for u in use), "halo_cells": [ranks[0].halo_cells, ranks[0].halo_cells_h],
             "grid_per_rank": [{k: u["grid"][k] for k in ("occupied", "tail", "overflow_bricks", "tail_h", "n")} for u in use]}
         print(world, out["worlds"][str(world)]["slowest_rank_ms"], out["worlds"][str(world)]["compute_ceiling_x"], file=sys.stderr)
         del ranks, res
