@@ -192,8 +192,8 @@ def analytic_cycle(dev, comm, args):
     return {"ms_per_step": round(ms, 4), "value": round(P_TOTAL / (ms * 1e-3) / 1e6, 3), "unit": "Mpoints/s",
             "roofline": {"bound": "hbm", "achieved": round(gb / (ms * 1e-3) / 1e3, 4), "peak": PEAK_HBM_TBS,
                          "unit": "TB/s", "frac": round(gb / (ms * 1e-3) / 1e3 / PEAK_HBM_TBS, 4),
-                         "note": "1.19 GB algorithmic bytes per cycle (SURVEY 8(d)); the neighbour-search and "
-                                 "raster stages are latency/L2-bound, not HBM-bound"}}
+                         "note": "1.19 GB algorithmic bytes per cycle (SURVEY 8(d)); every kernel above 0.1 ms of "
+                                 "this cycle is instruction-bound, not HBM-bound (DESIGN.md 4.1)"}}
 
 
 def cpu_baseline(gpu_model):

@@ -45,7 +45,7 @@ if has cfg3a; then
 fi
 if has ranks; then
   ( cd $REPO && timeout 1500 python tools/rank_share_bench.py siren 1000000 5 > $OUT/r02_rank_share_siren.json 2> $OUT/r02_rank_share_siren.err; tail -4 $OUT/r02_rank_share_siren.err
-    timeout 900 python tools/rank_share_bench.py sphere 1000000 5 > $OUT/r02_rank_share_sphere.json 2> $OUT/r02_rank_share_sphere.err; tail -4 $OUT/r02_rank_share_sphere.err )
+    timeout 900 python tools/rank_share_bench.py sphere 1000000 5 graphs > $OUT/r02_rank_share_sphere.json 2> $OUT/r02_rank_share_sphere.err; tail -4 $OUT/r02_rank_share_sphere.err )
   DB=$(ISO_WORLDS=8 run_prof rs8 "--stats" python tools/rank_share_bench.py siren 1000000 4)
   python $REPO/tools/rocprof_summary.py $DB $OUT/r02_rank_share_world8_kernel_stats.txt
 fi
