@@ -582,6 +582,14 @@ int iso_splat_front(const float* points, const float* normals, const float* feat
                     int64_t* num_pts_out, int32_t* view_total_out, float* ndc_out, float* ellipse_out,
                     float* cutoff_out, float* radii_out, float* scaler_out, float* features_out,
                     int32_t* src_out, void* stream);
+/* Gradient of the packed NDC rows of iso_splat_front w.r.t. the WORLD points (the part of the reference's
+ * backward that autograd runs through cameras.transform_points in SurfaceSplatting.transform,
+ * rasterizer.py:565-582,618: per-point set-up is under no_grad :608-610, so d(ndc)/d(point) is all there is).
+ * grad_ndc (rows,3) -> grad_points (n_points,3), summed over the views a point is rendered in (ascending view
+ * order, deterministic); mask / src / first_idx / num_points as written by iso_splat_view_mask / iso_splat_front. */
+int iso_splat_points_backward(const float* points, int64_t n_points, const float* views, const float* projs,
+                              int n_views, const int32_t* mask, const int32_t* src, const int64_t* first_idx,
+                              const int64_t* num_points, const float* grad_ndc, float* grad_points, void* stream);
 /* The z gradient of iso_splat_backward in pieces, for N ranks that each own a band of tile rows:
  * zscale (2 ints: bits of max |grad_zbuf|, exponent) <- iso_splat_z_absmax over the rank's pixels, MAX-
  * reduced over the ranks (word 0); iso_splat_z_scatter derives the exponent and adds the rank's pixels

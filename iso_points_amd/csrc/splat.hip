@@ -1276,6 +1276,61 @@ extern "C" int64_t iso_splat_front_workspace_bytes(int64_t n_points) {
   return 8 * 4 * ((n_points + kChunk - 1) / kChunk + 1);
 }
 
+// ---- gradient of the packed NDC rows w.r.t. the world points ---------------------------------------
+// Row (v, i) of the front end is ndc = (xv / t, yv / t, zv) with [xv, yv, ., t] = [p, 1] M_v and zv = [p, 1] V_v[:, 2]
+// (splat_setup_point; SurfaceSplatting.transform, rasterizer.py:565-582 -> cameras.transform_points), so
+//   d L / d p_j = sum_v  gx (M[j][0] - ndc_x M[j][3]) / t + gy (M[j][1] - ndc_y M[j][3]) / t + gz V[j][2].
+// Point-major: thread = point, views in ascending order (deterministic); the row of (v, i) is found by binary
+// search in the view's ascending src list.
+__global__ void k_splat_points_backward(const float* __restrict__ pts, int64_t n, const float* __restrict__ views,
+                                        const float* __restrict__ projs, int n_views, const int32_t* __restrict__ mask,
+                                        const int32_t* __restrict__ src, const int64_t* __restrict__ first,
+                                        const int64_t* __restrict__ num, const float* __restrict__ grad_ndc,
+                                        float* __restrict__ grad_pts) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    const int m = mask[i];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int v = 0; v < n_views; ++v) {
+      if (!((m >> v) & 1)) continue;
+      const int32_t* sv = src + first[v];
+      int64_t lo = 0, hi = num[v];
+      while (lo < hi) {                       // first row whose source point is >= i
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)sv[mid] < i) lo = mid + 1; else hi = mid;
+      }
+      if (lo >= num[v] || (int64_t)sv[lo] != i) continue;      // (cannot happen for a mask / src pair of one front end)
+      const int64_t row = first[v] + lo;
+      const float* M = projs + v * 16;
+      const float* V = views + v * 16;
+      const float xv = ((x * M[0] + y * M[4]) + z * M[8]) + M[12];
+      const float yv = ((x * M[1] + y * M[5]) + z * M[9]) + M[13];
+      const float t = ((x * M[3] + y * M[7]) + z * M[11]) + M[15];
+      const float it = 1.0f / iso_eps_denom(t, 1e-17f);
+      const float nx = xv * it, ny = yv * it;
+      const float g0 = grad_ndc[row * 3] * it, g1 = grad_ndc[row * 3 + 1] * it, g2 = grad_ndc[row * 3 + 2];
+      gx += (g0 * (M[0] - nx * M[3]) + g1 * (M[1] - ny * M[3])) + g2 * V[2];
+      gy += (g0 * (M[4] - nx * M[7]) + g1 * (M[5] - ny * M[7])) + g2 * V[6];
+      gz += (g0 * (M[8] - nx * M[11]) + g1 * (M[9] - ny * M[11])) + g2 * V[10];
+    }
+    grad_pts[i * 3] = gx; grad_pts[i * 3 + 1] = gy; grad_pts[i * 3 + 2] = gz;
+  }
+}
+
+extern "C" int iso_splat_points_backward(const float* points, int64_t n_points, const float* views, const float* projs,
+                                         int n_views, const int32_t* mask, const int32_t* src, const int64_t* first_idx,
+                                         const int64_t* num_points, const float* grad_ndc, float* grad_points,
+                                         void* stream) {
+  ISO_REQUIRE(n_points >= 0 && n_views >= 1 && n_views <= 8, ISO_ERR_INVALID, "iso_splat_points_backward: bad sizes (1..8 views)");
+  if (n_points == 0) return ISO_OK;
+  ISO_REQUIRE(points && views && projs && mask && src && first_idx && num_points && grad_ndc && grad_points, ISO_ERR_INVALID,
+              "iso_splat_points_backward: null pointer");
+  hipLaunchKernelGGL(k_splat_points_backward, dim3(iso_stream_grid(n_points, 256)), dim3(256), 0, (hipStream_t)stream, points,
+                     n_points, views, projs, n_views, mask, src, first_idx, num_points, grad_ndc, grad_points);
+  ISO_CHECK_LAUNCH("iso_splat_points_backward");
+  return ISO_OK;
+}
+
 extern "C" int iso_splat_front(const float* points, const float* normals, const float* features, int channels,
                                int features_from_normals, const int32_t* mask, const float* h, int64_t n_points,
                                const float* views, const float* projs, int n_views, int image_size, float sigma,

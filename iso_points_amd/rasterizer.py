@@ -481,11 +481,7 @@ class SurfaceSplatting(object):
         number of cameras, :597-598).  Returns (PointFragments, filtered dict)."""
         views, projs = cameras or self.cameras
         rs = self.raster_settings
-        if points.requires_grad:
-            raise NotImplementedError("gradient w.r.t. world points goes through the camera transform, "
-                                      "which is the caller's (pytorch3d's) job: rasterise NDC points that "
-                                      "require grad with rasterize_elliptical_points")
-        pts, nrm = _f32c(points), _f32c(normals)
+        pts, nrm = _f32c(points.detach()), _f32c(normals.detach())
         P, N = pts.shape[0], views.shape[0]
         dev = pts.device
         (S, W), K = image_hw(rs.image_size), int(rs.points_per_pixel)
@@ -505,6 +501,10 @@ class SurfaceSplatting(object):
                                                                              "flags": flags}
         info = {k: fr[k][:tot] for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler")}
         ndc = fr["ndc"][:tot]
+        if points.requires_grad:
+            # the reference's gradient reaches the world points through cameras.transform_points (:618); the set-up
+            # is under no_grad (:608-610)
+            ndc = _WorldToRows.apply(points, ndc, _f32c(views), _f32c(projs), fr["mask"], fr["src"], first, num)
         src = fr["src"][:tot].long()
         self._Vrk_h = fr["h"].view(-1)[(torch.arange(N, device=dev).repeat_interleave(torch.tensor(lens, device=dev))
                                         * P + src)]
@@ -521,6 +521,27 @@ class SurfaceSplatting(object):
                     "features": fr["features"][:tot] if fr["features"] is not None else None, "ndc": ndc,
                     "num_points": num, "first_idx": first, "flags": flags, "visibility": vis.bool(), "src": src, **info}
         return frags, filtered
+
+
+class _WorldToRows(autograd.Function):
+    """The packed NDC rows as a function of the world points: forward hands the rows of the front end through,
+    backward is iso_splat_points_backward (SurfaceSplatting.transform, rasterizer.py:565-582)."""
+
+    @staticmethod
+    def forward(ctx, points, ndc_rows, views, projs, mask, src, first, num):
+        ctx.save_for_backward(points.detach(), views, projs, mask, src, first, num)
+        return ndc_rows.clone()
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        points, views, projs, mask, src, first, num = ctx.saved_tensors
+        pts = _f32c(points)
+        g = _f32c(grad_rows)
+        out = torch.empty_like(pts)
+        p = _lib.ptr
+        _lib.call("iso_splat_points_backward", p(pts), pts.shape[0], p(views), p(projs), views.shape[0], p(mask), p(src),
+                  p(first), p(num), p(g), p(out), _lib.stream())
+        return out.to(points.dtype), None, None, None, None, None, None, None
 
 
 def gather_with_neg_idx(values, idx):
