@@ -314,6 +314,19 @@ int iso_repulse(const float* points, const float* normals, const int64_t* idx,
                 int64_t idx_row_stride, float* points_out, int64_t n,
                 int64_t first_point, int K, const float* inv_sigma, void* stream);
 
+/* UniformProjection.insert (DSS/models/levelset_sampling.py:172-233) on the device.
+ * iso_insert_fathers: father[b][i] = 1 when the nearest of the n_refs (device int32, <= 64) selected reference
+ *   points lies within the K = 1 query radius and 0 < d^2 < 4 spacing^2 (:200-206); params (device, 2 floats) =
+ *   {(4 r)^2, 4 spacing^2}.
+ * iso_insert_children: child = 2 father / 3 + neighbour / 3 over the LAST `patch` columns of knn_idx (:207-209),
+ *   cloud b written from row out_first[b], fathers in ascending order (rank_inclusive = inclusive prefix sum of
+ *   father over each cloud); neighbour index < 0 = the origin (what frnn_gather returns there).             */
+int iso_insert_fathers(const float* points, const int64_t* lengths, int n_clouds, int64_t max_points,
+                       const float* refs, const int32_t* n_refs, const float* params, uint8_t* father_out,
+                       void* stream);
+int iso_insert_children(const float* points, const int64_t* knn_idx, int n_clouds, int64_t max_points, int K,
+                        int patch, const uint8_t* father, const int64_t* rank_inclusive, const int64_t* out_first,
+                        float* children_out, void* stream);
 /* Sparsest-edge candidates of point_processing.upsample
  * (DSS/utils/point_processing.py:326-339): per point p with neighbours nn_k (knn (n,K,3)):
  * mid_k = (nn_k + 2p)/3, spars_k = min_j |mid_k - nn_j|, sparsity = max_k spars_k,

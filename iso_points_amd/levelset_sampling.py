@@ -275,57 +275,61 @@ class UniformProjection(LevelSetProjection):
 
     # -- insert / upsample ---------------------------------------------------------------
     def insert(self, ref_pcl, points, num_points, current_knn_result=None):
-        """Insert points around high-metric reference points (levelset_sampling.py:172-233).
-        ref_pcl: an object with points_packed(), features_packed() (P_ref,1 metric),
-        num_points_per_cloud() -- one cloud.  Returns (points, num_points, child_pts, child_per_batch)."""
-        import math
-        from . import frnn as _frnn
-        batch_size = points.shape[0]
-        flat = points.reshape(-1, 3)
-        diag = (flat.max(dim=0).values - flat.min(0).values).norm().item()
-        num_ref_cloud = int(ref_pcl.num_points_per_cloud().item())
-        avg_spacing = math.sqrt(diag / num_ref_cloud)
-        patch_size = 8
-        knn_k = patch_size
-        search_radius = min(avg_spacing * knn_k, 0.2)
+        """Children around the iso-points nearest to the high-metric reference points
+        (levelset_sampling.py:172-233), on the device: iso_insert_fathers / iso_insert_children
+        (csrc/insert.hip).  ref_pcl: one cloud with points_packed() (R,3) and features_packed() (R,1), the
+        per-point metric.  Returns (points + children, num_points + children, children padded, children
+        per cloud).  One host read, of the result sizes."""
+        from . import bricks
+        PATCH = 8                                                     # neighbours that mother a child (:181)
+        B, P = points.shape[0], points.shape[1]
+        dev = points.device
+        pts = points.detach().float().contiguous()
+        metric = ref_pcl.features_packed().detach().float().reshape(-1)
+        ref_xyz = ref_pcl.points_packed().detach().float()
+        R = int(ref_xyz.shape[0])
+        no_children = (points.new_zeros((B, 0, 3)), with_host_lengths(num_points.new_zeros((B,)), [0] * B))
+        if R == 0 or P == 0:
+            return points, num_points, no_children[0], no_children[1]
+        # device-side scalars: spacing of the cloud, query radius (:178-183)
+        box = bricks.points_bbox(pts.view(-1, 3))
+        spacing = torch.sqrt((box[4:7] - box[0:3]).norm() / R)
+        radius = torch.clamp(spacing * PATCH, max=0.2)
         if current_knn_result is None:
-            dists, idxs, nn, _ = _frnn.frnn_grid_points(points, points, num_points, num_points, K=knn_k + 1,
-                                                        r=search_radius, grid=None, return_nn=True)
-            cur_idx = idxs[..., 1:]
+            _, nbr, _, _ = frnn.frnn_grid_points(pts, pts, num_points, num_points, K=PATCH + 1,
+                                                 r=radius.expand(B).contiguous(), grid=None, return_nn=False)
+            nbr = nbr[..., 1:]
         else:
-            cur_idx = current_knn_result.idx
-        try:
-            metrics = ref_pcl.features_packed()
-            num_ref = metrics.shape[0]
-            threshold = min(metrics.median() * 2, metrics.max() * 0.5)
-            ref_all = ref_pcl.points_packed()
-            ref_pts = ref_all[(metrics > threshold).squeeze(-1)].view(1, -1, 3)
-            if ref_pts.shape[1] == 0 or ref_pts.shape[1] > min(50, int(num_ref / 20)):
-                top = metrics.sort(dim=0).indices[-max(min(50, int(num_ref / 20)), 1):, 0]
-                ref_pts = ref_all[top].view(1, -1, 3).expand(batch_size, -1, -1)
-            ref_b = ref_pts.expand(batch_size, -1, -1).contiguous()
-            dists_to_ref, _, _, _ = _frnn.frnn_grid_points(points, ref_b, lengths1=num_points, lengths2=None,
-                                                           K=1, return_nn=True, grid=None, r=search_radius * 4)
-            dists_to_ref = dists_to_ref.view(batch_size, -1)
-            dist_threshold = avg_spacing ** 2
-            father_pts_mask = (dists_to_ref < 4 * dist_threshold) & (dists_to_ref > 0)
-            father_pts = points[father_pts_mask]
-            mother_pts = _frnn.frnn_gather(points, cur_idx[..., -patch_size:].contiguous())
-            mother_pts = mother_pts[father_pts_mask]
-            child_pts = 2 * father_pts.unsqueeze(-2) / 3 + mother_pts / 3
-            child_per_batch = father_pts_mask.sum(-1) * mother_pts.shape[-2]
-            child_pts = child_pts.view(-1, 3)
-            lens = [int(x) for x in child_per_batch.tolist()]
-            child_pts = packed_to_padded(child_pts, lens) if sum(lens) > 0 else points.new_zeros((batch_size, 0, 3))
-            child_per_batch = with_host_lengths(child_per_batch, lens)
-        except Exception as e:  # same catch-all as the reference (:226-229)
-            import logging
-            logging.getLogger(__name__).error("Error occurred during insertion {}".format(e))
-            child_pts = points.new_zeros((batch_size, 0, 3))
-            child_per_batch = with_host_lengths(num_points.new_zeros((batch_size,)), [0] * batch_size)
-        points = torch.cat((points, child_pts), dim=1)
-        num_points = num_points + child_per_batch
-        return points, num_points, child_pts, child_per_batch
+            nbr = current_knn_result.idx
+        nbr = nbr.to(torch.int64).contiguous()
+        # the selected reference points (:186-194): those above min(2 median, max / 2) when they are between 1 and
+        # `cap` many, else the `cap` largest -- either way the n_sel largest metrics, n_sel known on the device only
+        cap = min(50, R // 20)
+        kmax = max(cap, 1)
+        bar = torch.minimum(metric.median() * 2, metric.max() * 0.5)
+        above = (metric > bar).sum()
+        n_sel = torch.where((above >= 1) & (above <= cap), above, torch.full_like(above, kmax)).to(torch.int32).view(1)
+        selected = ref_xyz[torch.topk(metric, kmax).indices].contiguous()
+        limits = torch.stack([(radius * 4) ** 2, 4 * spacing * spacing]).float().contiguous()
+        father = torch.empty((B, P), dtype=torch.uint8, device=dev)
+        lens_dev = num_points.to(torch.int64).contiguous()
+        cp = _lib.ptr
+        _lib.call("iso_insert_fathers", cp(pts), cp(lens_dev), B, P, cp(selected), cp(n_sel), cp(limits), cp(father),
+                  _lib.stream())
+        rank = father.to(torch.int64).cumsum(dim=1).contiguous()
+        per_cloud = rank[:, -1] * PATCH
+        first = (per_cloud.cumsum(0) - per_cloud).contiguous()
+        sizes = [int(v) for v in per_cloud.tolist()]                  # the result shapes: the one host read
+        total = sum(sizes)
+        if total == 0:
+            return points, num_points, no_children[0], no_children[1]
+        packed = torch.empty((total, 3), dtype=torch.float32, device=dev)
+        _lib.call("iso_insert_children", cp(pts), cp(nbr), B, P, nbr.shape[-1], PATCH, cp(father), cp(rank), cp(first),
+                  cp(packed), _lib.stream())
+        children = packed_to_padded(packed, sizes)
+        grown = torch.cat((points, children.to(points.dtype)), dim=1)
+        per_cloud = with_host_lengths(per_cloud, sizes)
+        return grown, num_points + per_cloud, children, per_cloud
 
     def upsample(self, points, n_points, model, num_points=None, **forward_kwargs):
         """levelset_sampling.py:235-237."""
