@@ -146,23 +146,17 @@ class UniformProjection(LevelSetProjection):
 
     # -- tree ------------------------------------------------------------------------
     def _create_tree(self, points_padded, refresh_tree=True, num_points_per_cloud=None):
-        """levelset_sampling.py:110-140: r = sqrt(diag/P)*knn_k, K = knn_k+1 self-inclusive
-        query, column 0 dropped.  Results are cached on self like the reference."""
-        if not refresh_tree and getattr(self, "_knn_idx", None) is not None:
-            return self._knn_idx
-        assert points_padded.ndim == 3
-        if num_points_per_cloud is None:
-            num_points_per_cloud = full_lengths(points_padded)
-        diag = cloud_diag(points_padded)            # (max - min).norm over the padded tensor (:129-130)
-        search_radius = torch.sqrt(diag / num_points_per_cloud.float()) * self.knn_k
-        dists, idxs, nn, grid = frnn.frnn_grid_points(
-            points_padded, points_padded, num_points_per_cloud, num_points_per_cloud,
-            K=self.knn_k + 1, r=search_radius, grid=None, return_nn=True)
-        self._knn_gather = frnn.frnn_gather
-        self._knn_idx = idxs[..., 1:]
-        self._knn_dists = dists[..., 1:]
-        self._knn_nn = nn[..., 1:, :]
-        self.knn_gather = frnn.frnn_gather
+        """Neighbour lists of the cloud within r = knn_k * sqrt(bbox diagonal / P) (levelset_sampling.py:110-140):
+        a self-inclusive K = knn_k + 1 query whose first column (the point itself) is dropped.  Cached on self
+        under the reference's attribute names."""
+        if refresh_tree or getattr(self, "_knn_idx", None) is None:
+            assert points_padded.ndim == 3
+            lengths = full_lengths(points_padded) if num_points_per_cloud is None else num_points_per_cloud
+            radius = self.knn_k * torch.sqrt(cloud_diag(points_padded) / lengths.float())
+            d2, ids, xyz, _ = frnn.frnn_grid_points(points_padded, points_padded, lengths, lengths, K=self.knn_k + 1,
+                                                    r=radius, grid=None, return_nn=True)
+            self._knn_idx, self._knn_dists, self._knn_nn = ids[..., 1:], d2[..., 1:], xyz[..., 1:, :]
+            self._knn_gather = self.knn_gather = frnn.frnn_gather
         return self._knn_idx
 
     # -- SDF evaluation ----------------------------------------------------------------
@@ -405,45 +399,36 @@ class UniformProjection(LevelSetProjection):
                        skip_resampling: bool = False, skip_upsampling: bool = False, ref_pcl=None,
                        proj_max_iters: Optional[int] = None, sample_iters: Optional[int] = None,
                        **forward_kwargs):
-        """levelset_sampling.py:353-439."""
-        points_init, num_points = convert_pointclouds_to_tensor(point_clouds)
-        num_points_init = num_points
-        proj_max_iters = proj_max_iters or self.proj_max_iters
-        sample_iters = sample_iters or self.sample_iters
+        """The whole extraction (levelset_sampling.py:353-439) as a chain of stages over one ProjectionResult:
+        project -> [keep converged, resample] -> [keep converged, grow (insert around ref_pcl, or upsample back
+        to the input count), project what is new].  Returns the reference's dict."""
+        cloud, lengths = convert_pointclouds_to_tensor(point_clouds)
+        wanted = lengths                                              # upsample() refills to the input count
+
+        def converged(res):
+            kept = _filter_projection_result(res)
+            return kept, kept.mask.sum(dim=-1)
+
         with torch.no_grad():
-            points_projected, normals_projected, valid_projection = self._project_points(
-                model, points_init, num_points, proj_max_iters=proj_max_iters, **forward_kwargs)
-            if not valid_projection.any():
-                return {"levelset_points": points_projected, "mask": valid_projection}
+            res = self._project_points(model, cloud, lengths, proj_max_iters=proj_max_iters or self.proj_max_iters,
+                                       **forward_kwargs)
+            if not res.mask.any():
+                return {"levelset_points": res.points, "mask": res.mask}
             if not skip_resampling:
-                points_projected, normals_projected, valid_projection = _filter_projection_result(
-                    ProjectionResult(points_projected, normals_projected, valid_projection))
-                num_points = valid_projection.sum(dim=-1)
-                points_projected, normals_projected, valid_projection = self.resample(
-                    model, points_projected, normals_projected, num_points, sample_iters=sample_iters,
-                    **forward_kwargs)
-                num_points = valid_projection.sum(dim=-1)
-            if not skip_upsampling and ref_pcl is not None:                       # :411-424
-                points_projected, normals_projected, valid_projection = _filter_projection_result(
-                    ProjectionResult(points_projected, normals_projected, valid_projection))
-                num_points = valid_projection.sum(dim=-1)
-                _, _, new_points, num_new_points = self.insert(ref_pcl, points_projected, num_points)
-                if new_points.shape[1] > 0:
-                    npj, nnj, nvj = self._project_points(model, new_points, num_new_points, proj_max_iters=10,
-                                                         **forward_kwargs)
-                    points_projected = torch.cat([points_projected, npj], dim=1)
-                    normals_projected = torch.cat([normals_projected, nnj], dim=1)
-                    valid_projection = torch.cat([valid_projection, nvj], dim=1)
-            elif not skip_upsampling:                                             # :426-434
-                points_projected, normals_projected, valid_projection = _filter_projection_result(
-                    ProjectionResult(points_projected, normals_projected, valid_projection))
-                num_points = valid_projection.sum(dim=-1)
-                points_projected, num_points = self.upsample(points_projected, num_points_init, model,
-                                                             num_points, **forward_kwargs)
-                points_projected, normals_projected, valid_projection = self._project_points(
-                    model, points_projected, num_points, proj_max_iters=10, **forward_kwargs)
-            return {"levelset_points": points_projected, "levelset_normals": normals_projected,
-                    "mask": valid_projection}
+                res, lengths = converged(res)
+                res = self.resample(model, res.points, res.normals, lengths,
+                                    sample_iters=sample_iters or self.sample_iters, **forward_kwargs)
+            if not skip_upsampling:
+                res, lengths = converged(res)
+                if ref_pcl is not None:                               # :411-424: children of the flagged regions
+                    _, _, fresh, n_fresh = self.insert(ref_pcl, res.points, lengths)
+                    if fresh.shape[1] > 0:
+                        more = self._project_points(model, fresh, n_fresh, proj_max_iters=10, **forward_kwargs)
+                        res = ProjectionResult(*(torch.cat(pair, dim=1) for pair in zip(res, more)))
+                else:                                                 # :426-434: back to the input count
+                    dense, lengths = self.upsample(res.points, wanted, model, lengths, **forward_kwargs)
+                    res = self._project_points(model, dense, lengths, proj_max_iters=10, **forward_kwargs)
+            return {"levelset_points": res.points, "levelset_normals": res.normals, "mask": res.mask}
 
 
 class EdgeAwareProjection(UniformProjection):
@@ -488,21 +473,16 @@ class EdgeAwareProjection(UniformProjection):
         if points.shape[0] != 1:
             raise NotImplementedError("EdgeAwareProjection: one cloud per call (the reference's "
                                       "num_points / 2.0 broadcast is only valid for batch size 1, :515)")
-        normals = F.normalize(normals, dim=-1)
-        knn_normals = self.knn_gather(normals, self._knn_idx, num_points)
-        self.sharpness_sigma = kwargs.get("sharpness_sigma", self.sharpness_sigma)
-        weights_n = ((1 - torch.sum(knn_normals * normals[:, :, None, :], dim=-1)) / self.sharpness_sigma) ** 2
-        weights_n = torch.exp(-weights_n)
-        inv_sigma_spatial = num_points / 2.0
-        spatial_dist = 16 / inv_sigma_spatial
-        deltap = self._knn_nn - points[:, :, None, :]
-        deltap = torch.sum(deltap * deltap, dim=-1)
-        weights_p = torch.exp(-deltap * inv_sigma_spatial)
-        weights_p = torch.where(deltap > spatial_dist, torch.zeros_like(weights_p), weights_p)
-        weights = weights_p * weights_n
-        normals_denoised = torch.sum(knn_normals * weights[:, :, :, None], dim=-2) / \
-            eps_denom(torch.sum(weights, dim=-1, keepdim=True))
-        return F.normalize(normals_denoised, dim=-1), weights_p, weights_n
+        unit = F.normalize(normals, dim=-1)
+        nbr_n = self.knn_gather(unit, self._knn_idx, num_points)                       # (1,P,K,3)
+        sigma = self.sharpness_sigma = kwargs.get("sharpness_sigma", self.sharpness_sigma)
+        bandwidth = num_points / 2.0                                                   # 1 / sigma_p^2 = P / 2 (:515)
+        d2 = (self._knn_nn - points[:, :, None, :]).square().sum(dim=-1)
+        w_space = torch.exp(-d2 * bandwidth).masked_fill(d2 > 16 / bandwidth, 0.0)
+        w_angle = torch.exp(-(((1 - (nbr_n * unit[:, :, None, :]).sum(dim=-1)) / sigma) ** 2))
+        w = w_space * w_angle
+        mean = (nbr_n * w[..., None]).sum(dim=-2) / eps_denom(w.sum(dim=-1, keepdim=True))
+        return F.normalize(mean, dim=-1), w_space, w_angle
 
     def upsample(self, points, n_points, model, num_points=None, **forward_kwargs):
         """:528-661.  points (1,P,3) on the level set; returns (points (1,P',3), num_points (1,))
@@ -691,15 +671,12 @@ class SampleNetwork(nn.Module):
     def forward(self, network, levelset_points, return_eval=False):
         if not levelset_points.is_cuda:
             raise RuntimeError("iso_points_amd: points must be on the GPU; there is no CPU path")
-        levelset_points = levelset_points.detach()
-        levelset_points_Dx = _value_gradient(network, levelset_points)
-        network_eval = network.forward(levelset_points).sdf
-        sum_square_grad = torch.sum(levelset_points_Dx ** 2, dim=-1, keepdim=True)
-        sampled_points = levelset_points - (network_eval - network_eval.detach()).view(
-            levelset_points.shape[:-1] + (1,)) * (levelset_points_Dx / eps_denom(sum_square_grad, 1e-17))
-        if return_eval:
-            return sampled_points, network_eval
-        return sampled_points
+        p = levelset_points.detach()
+        grad = _value_gradient(network, p)                            # D_xF at theta_0, no graph
+        value = network.forward(p).sdf                                # F(p; theta): the only term with a graph
+        newton_dir = grad / eps_denom((grad * grad).sum(dim=-1, keepdim=True), 1e-17)
+        moved = p - (value - value.detach()).view(p.shape[:-1] + (1,)) * newton_dir
+        return (moved, value) if return_eval else moved
 
 
 class DirectionalSamplingNetwork(SampleNetwork):
@@ -709,17 +686,14 @@ class DirectionalSamplingNetwork(SampleNetwork):
     def forward(self, network, iso_points, ray, cam_pos, c=None, return_eval=False):
         if not iso_points.is_cuda:
             raise RuntimeError("iso_points_amd: points must be on the GPU; there is no CPU path")
-        iso_points = iso_points.detach()
-        iso_points_Dx = _value_gradient(network, iso_points)
-        surface_dists = (iso_points - cam_pos).norm(dim=-1, keepdim=True)
-        network_eval = network.forward(iso_points).sdf
-        ray = F.normalize(ray, dim=-1, p=2)
-        surface_points_dot = torch.sum(iso_points_Dx * ray.detach(), dim=-1, keepdim=True)
-        surface_dists_theta = surface_dists - (network_eval - network_eval.detach()) / eps_denom(surface_points_dot, 1e-10)
-        surface_points_theta_c_v = cam_pos + surface_dists_theta * ray
-        if return_eval:
-            return surface_points_theta_c_v, network_eval
-        return surface_points_theta_c_v
+        p = iso_points.detach()
+        grad = _value_gradient(network, p)
+        value = network.forward(p).sdf
+        view_dir = F.normalize(ray, dim=-1, p=2)
+        depth = (p - cam_pos).norm(dim=-1, keepdim=True)
+        slope = (grad * view_dir.detach()).sum(dim=-1, keepdim=True)  # D_xF . v
+        moved = cam_pos + (depth - (value - value.detach()) / eps_denom(slope, 1e-10)) * view_dir
+        return (moved, value) if return_eval else moved
 
 
 class _KwModel(object):

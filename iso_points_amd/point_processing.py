@@ -166,39 +166,33 @@ def wlop(points, num_points=None, ratio=0.5, neighborhood_size=16, iters=3, repu
         noise = torch.randn(X.shape, generator=generator, device="cpu").to(dev) if generator is not None \
             else torch.randn_like(X)
         X = X + noise * (h * 0.1).view(-1, 1, 1)
-    tsi = theta_sigma_inv.view(-1, 1, 1)
+    falloff = theta_sigma_inv.view(-1, 1, 1)
 
-    def theta(r2):
-        return torch.exp(-r2 * tsi)
+    def weight(r2, ids):                       # theta(r) = exp(-16 r^2 / h^2), zero for a missing neighbour
+        return torch.exp(-r2 * falloff).masked_fill(ids < 0, 0.0)
 
     K = neighborhood_size
-    dists, idxs, _, grid = frnn.frnn_grid_points(P, P, num_P, num_P, K=K + 1, r=search_radius)
-    idx_pp = idxs[..., 1:]
-    deltapp = torch.norm(P.unsqueeze(-2) - frnn.frnn_gather(P, idx_pp.contiguous()), dim=-1)
-    theta_pp = theta(deltapp ** 2)
-    theta_pp[idx_pp < 0] = 0
-    density_P = torch.sum(theta_pp, dim=-1) + 1
+    _, ids_pp, _, grid = frnn.frnn_grid_points(P, P, num_P, num_P, K=K + 1, r=search_radius)
+    ids_pp = ids_pp[..., 1:].contiguous()
+    gap_pp = torch.norm(P.unsqueeze(-2) - frnn.frnn_gather(P, ids_pp), dim=-1)
+    dens_P = weight(gap_pp ** 2, ids_pp).sum(dim=-1) + 1                    # local density of the input cloud (:66-70)
     for _ in range(iters):
-        _, idx_xp, _, grid = frnn.frnn_grid_points(X, P, num_X, num_P, K=K, r=search_radius, grid=grid)
-        _, idx_xx, _, _ = frnn.frnn_grid_points(X, X, num_X, num_X, K=K + 1, r=search_radius)
-        idx_xx = idx_xx[..., 1:].contiguous()
-        nn_XtoP = frnn.frnn_gather(P, idx_xp)
-        epsilon = X.unsqueeze(-2) - nn_XtoP
-        delta = X.unsqueeze(-2) - frnn.frnn_gather(X, idx_xx)
-        deltaxx2 = (delta ** 2).sum(dim=-1)
-        deltaxp2 = (epsilon ** 2).sum(dim=-1)
-        alpha = theta(deltaxp2) / eps_denom(epsilon.norm(dim=-1))
-        beta = theta(deltaxx2) * torch.ones_like(deltaxx2) / eps_denom(delta.norm(dim=-1))
-        density_X = torch.sum(theta(deltaxx2), dim=-1) + 1
-        new_alpha = alpha / frnn.frnn_gather(density_P.unsqueeze(-1), idx_xp).squeeze(-1)
-        new_alpha[idx_xp < 0] = 0
-        new_beta = density_X.unsqueeze(-1) * beta
-        new_beta[idx_xx < 0] = 0
-        term_data = torch.sum(new_alpha[..., None] * nn_XtoP, dim=-2) / \
-            eps_denom(torch.sum(new_alpha, dim=-1, keepdim=True))
-        term_repul = repulsion_mu * torch.sum(new_beta[..., None] * delta, dim=-2) / \
-            eps_denom(torch.sum(new_beta, dim=-1, keepdim=True))
-        X = term_data + term_repul
+        _, ids_xp, _, grid = frnn.frnn_grid_points(X, P, num_X, num_P, K=K, r=search_radius, grid=grid)
+        _, ids_xx, _, _ = frnn.frnn_grid_points(X, X, num_X, num_X, K=K + 1, r=search_radius)
+        ids_xx = ids_xx[..., 1:].contiguous()
+        anchor = frnn.frnn_gather(P, ids_xp)                                 # input points near each sample
+        to_anchor = X.unsqueeze(-2) - anchor
+        to_peer = X.unsqueeze(-2) - frnn.frnn_gather(X, ids_xx)
+        r2_anchor, r2_peer = (to_anchor ** 2).sum(dim=-1), (to_peer ** 2).sum(dim=-1)
+        dens_X = torch.exp(-r2_peer * falloff).sum(dim=-1) + 1
+        # attraction to the input, each anchor discounted by its density; repulsion among the samples (:84-118)
+        pull = weight(r2_anchor, ids_xp) / eps_denom(to_anchor.norm(dim=-1)) / \
+            frnn.frnn_gather(dens_P.unsqueeze(-1), ids_xp).squeeze(-1)
+        pull = pull.masked_fill(ids_xp < 0, 0.0)
+        push = dens_X.unsqueeze(-1) * (torch.exp(-r2_peer * falloff) / eps_denom(to_peer.norm(dim=-1)))
+        push = push.masked_fill(ids_xx < 0, 0.0)
+        X = (pull[..., None] * anchor).sum(dim=-2) / eps_denom(pull.sum(dim=-1, keepdim=True)) + \
+            repulsion_mu * (push[..., None] * to_peer).sum(dim=-2) / eps_denom(push.sum(dim=-1, keepdim=True))
     return X, num_X
 
 
@@ -225,24 +219,18 @@ def denoise_normals(points, normals, sharpness_sigma=30, knn_result=None, neighb
     if points.shape[0] != 1:
         raise NotImplementedError("denoise_normals: one cloud per call (math.sqrt(diag / P) at :249 "
                                   "needs a single-element tensor)")
-    normals = torch.nn.functional.normalize(normals, dim=-1)
+    unit = torch.nn.functional.normalize(normals, dim=-1)
     if knn_result is None:
-        diag = (points.max(dim=-2)[0] - points.min(dim=-2)[0]).norm(dim=-1)
-        avg_spacing = math.sqrt(diag / points.shape[1])
-        search_radius = min(4 * avg_spacing * neighborhood_size, 0.2)
-        dists, idxs, _, _ = frnn.frnn_grid_points(points, points, num_points, num_points,
-                                                  K=neighborhood_size + 1, r=search_radius, grid=None, return_nn=True)
-        knn_result = _KNN(dists=dists[..., 1:], idx=idxs[..., 1:], knn=None)
-    knn = knn_result.knn if knn_result.knn is not None else frnn.frnn_gather(points, knn_result.idx, num_points)
-    knn_normals = frnn.frnn_gather(normals, knn_result.idx, num_points)
-    weights_n = torch.exp(-((1 - torch.sum(knn_normals * normals[:, :, None, :], dim=-1)) / sharpness_sigma) ** 2)
-    inv_sigma_spatial = num_points / 2.0
-    spatial_dist = 16 / inv_sigma_spatial
-    deltap = knn - points[:, :, None, :]
-    deltap = torch.sum(deltap * deltap, dim=-1)
-    weights_p = torch.exp(-deltap * inv_sigma_spatial)
-    weights_p = torch.where(deltap > spatial_dist, torch.zeros_like(weights_p), weights_p)
-    weights = weights_p * weights_n
-    normals_denoised = torch.sum(knn_normals * weights[:, :, :, None], dim=-2) / \
-        eps_denom(torch.sum(weights, dim=-1, keepdim=True))
-    return torch.nn.functional.normalize(normals_denoised, dim=-1).view_as(normals)
+        extent = (points.amax(dim=-2) - points.amin(dim=-2)).norm(dim=-1)
+        radius = min(4 * neighborhood_size * math.sqrt(extent / points.shape[1]), 0.2)
+        d2, ids, _, _ = frnn.frnn_grid_points(points, points, num_points, num_points, K=neighborhood_size + 1, r=radius,
+                                              grid=None, return_nn=True)
+        knn_result = _KNN(dists=d2[..., 1:], idx=ids[..., 1:], knn=None)
+    nbr_p = knn_result.knn if knn_result.knn is not None else frnn.frnn_gather(points, knn_result.idx, num_points)
+    nbr_n = frnn.frnn_gather(unit, knn_result.idx, num_points)
+    bandwidth = num_points / 2.0                                      # 1 / sigma_p^2 = P / 2
+    gap2 = (nbr_p - points[:, :, None, :]).square().sum(dim=-1)
+    w = torch.exp(-gap2 * bandwidth).masked_fill(gap2 > 16 / bandwidth, 0.0) * \
+        torch.exp(-(((1 - (nbr_n * unit[:, :, None, :]).sum(dim=-1)) / sharpness_sigma) ** 2))
+    mean = (nbr_n * w[..., None]).sum(dim=-2) / eps_denom(w.sum(dim=-1, keepdim=True))
+    return torch.nn.functional.normalize(mean, dim=-1).view_as(normals)
