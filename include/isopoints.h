@@ -402,7 +402,7 @@ int iso_splat_setup(const float* points, const float* normals, const float* h,
  *           allocate `pairs` (i32, >= total), zero tile_cursor (n_clouds*T*T i32) and
  *           overflow_flag; tile_off needs n_clouds*T*T + 1 entries (the last = total);
  *   iso_splat_forward   : fill + raster (tile_cursor holds the fill cursors first and is then
- *                         overwritten with the heaviest-first tile order the raster walks).  Per pixel the points_per_pixel (<= 32)
+ *                         overwritten with the heaviest-first tile order the raster walks).  Per pixel the points_per_pixel (<= 150; above 32 a slow kernel that keeps the lists in the outputs)
  *                         smallest (z, idx) hits, entries with z - z0 >
  *                         depth_merging_thres reset to -1, occupancy = any hit.
  * Outputs as the reference: idx i32, zbuf/qvalue f32 (N,S,S,K), occ f32 (N,S,S),

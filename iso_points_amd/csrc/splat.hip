@@ -674,6 +674,95 @@ __global__ __launch_bounds__(256) void k_raster(
   if (ca.scaler) composite_pixel<KMAX>(best, K, z0, depth_thres, hit, ca, pix);
 }
 
+// points_per_pixel above 32 (the reference allows 150, rasterization_utils.cuh:18): the K-best list of a pixel does
+// not fit its thread's registers, so it lives where it ends up anyway -- in the pixel's rows of the output arrays --
+// and a hit is inserted by shifting the tail in global memory.  Same candidate walk, same (z, id) order, same
+// outputs as k_raster; built for completeness, not for speed (a list this deep is a debugging setting).
+__global__ __launch_bounds__(256) void k_raster_deep(
+    const float* __restrict__ pts, const float* __restrict__ ellipse, const float* __restrict__ cutoff,
+    const float* __restrict__ radii, const int32_t* __restrict__ tile_order, const int32_t* __restrict__ tile_off,
+    const int32_t* __restrict__ pairs, int64_t capacity, Frame F, int K, float depth_thres,
+    int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out, float* __restrict__ occ_out,
+    CompositeArgs ca) {
+  __shared__ float s_px[256], s_py[256], s_pz[256], s_a[256], s_b[256], s_c[256], s_rx[256], s_ry[256], s_cut[256];
+  __shared__ int s_id[256];
+  const int tile = tile_order[blockIdx.x];
+  const int tx = tile % F.Tx, ty = (tile / F.Tx) % F.Ty, n = tile / (F.Tx * F.Ty);
+  const int lx = threadIdx.x % TILE, ly = threadIdx.x / TILE;
+  const int xi = tx * TILE + lx, yi = ty * TILE + ly;
+  const bool inside = xi < F.W && yi < F.H;
+  const float xf = ndc_x(xi, F), yf = ndc_y(yi, F);
+  const int yo = F.H - 1 - yi, xo = F.W - 1 - xi;
+  const int64_t pix = ((int64_t)n * F.H + yo) * F.W + xo;
+  int32_t* const li = idx_out + pix * K;      // the pixel's lists (only touched when inside)
+  float* const lz = zbuf_out + pix * K;
+  float* const lq = q_out + pix * K;
+  int have = 0;
+  float wz = FLT_MAX;                         // worst entry of a full list
+  int wi = 0x7fffffff;
+  const int64_t off = tile_off[tile];
+  int cnt = tile_off[tile + 1] - tile_off[tile];
+  if (off + cnt > capacity) cnt = off < capacity ? (int)(capacity - off) : 0;
+  for (int c0 = 0; c0 < cnt; c0 += 256) {
+    const int m = min(256, cnt - c0);
+    __syncthreads();
+    if ((int)threadIdx.x < m) {
+      const int p = pairs[off + c0 + threadIdx.x];
+      s_px[threadIdx.x] = pts[(int64_t)p * 3]; s_py[threadIdx.x] = pts[(int64_t)p * 3 + 1]; s_pz[threadIdx.x] = pts[(int64_t)p * 3 + 2];
+      s_a[threadIdx.x] = ellipse[(int64_t)p * 3]; s_b[threadIdx.x] = ellipse[(int64_t)p * 3 + 1]; s_c[threadIdx.x] = ellipse[(int64_t)p * 3 + 2];
+      s_rx[threadIdx.x] = radii[(int64_t)p * 2]; s_ry[threadIdx.x] = radii[(int64_t)p * 2 + 1];
+      s_cut[threadIdx.x] = cutoff[p]; s_id[threadIdx.x] = p;
+    }
+    __syncthreads();
+    if (!inside) continue;
+    for (int k = 0; k < m; ++k) {
+      const float dx = xf - s_px[k], dy = yf - s_py[k];
+      if (fabsf(dx) > s_rx[k] || fabsf(dy) > s_ry[k]) continue;                  // rasterize_points.cu:92
+      const float q = s_a[k] * dx * dx + s_b[k] * dx * dy + s_c[k] * dy * dy;      // :94
+      if (q > s_cut[k]) continue;                                                // :96
+      const float pz = s_pz[k];
+      const int id = s_id[k];
+      if (have == K && !(pz < wz || (pz == wz && id < wi))) continue;
+      int j = have < K ? have : K - 1;        // the slot that opens (the worst entry drops out of a full list)
+      while (j > 0) {
+        const float zj = lz[j - 1];
+        const int ij = li[j - 1];
+        if (!(pz < zj || (pz == zj && id < ij))) break;
+        lz[j] = zj; li[j] = ij; lq[j] = lq[j - 1];
+        --j;
+      }
+      lz[j] = pz; li[j] = id; lq[j] = q;
+      if (have < K) ++have;
+      if (have == K) { wz = lz[K - 1]; wi = li[K - 1]; }
+    }
+  }
+  if (!inside) return;
+  const bool hit = have > 0;
+  const float z0 = hit ? lz[0] : FLT_MAX;
+  occ_out[pix] = hit ? 1.0f : 0.0f;
+  float sw = 0.f, acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  for (int j = 0; j < K; ++j) {
+    const bool ok = j < have && !((lz[j] - z0) > depth_thres);
+    if (ok && ca.scaler) {
+      const int p = li[j];
+      const float w = expf(-0.5f * lq[j]) * ca.scaler[p];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < ca.C) acc[c] += w * ca.feat[(int64_t)p * ca.C + c];
+      sw += w;
+    }
+    if (!ok) { li[j] = -1; lz[j] = -1.0f; lq[j] = -1.0f; }
+  }
+  if (ca.scaler) {
+    float d = 1.0f;
+    if (ca.norm) d = sw > ca.eps ? sw : ca.eps;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < ca.C) ca.img[pix * (ca.C + 1) + c] = ca.norm ? acc[c] / d : acc[c];
+    ca.img[pix * (ca.C + 1) + ca.C] = hit ? 1.0f : 0.0f;
+  }
+}
+
 // Tiles of the band [ty_begin, ty_begin+ty_rows) of every cloud, heaviest first (64 buckets of the
 // candidate count; the order inside a bucket is arbitrary -- it only affects scheduling).
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
@@ -1404,8 +1493,8 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
                                  int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
                                  float* zbuf_out, float* qvalue_out, float* occ_out, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
-  ISO_REQUIRE(points_per_pixel >= 1 && points_per_pixel <= 32, ISO_ERR_UNSUPPORTED,
-              "iso_splat_forward: points_per_pixel must be in [1,32], got %d", points_per_pixel);
+  ISO_REQUIRE(points_per_pixel >= 1 && points_per_pixel <= 150, ISO_ERR_UNSUPPORTED,
+              "iso_splat_forward: points_per_pixel must be in [1,150] (rasterization_utils.cuh:18), got %d", points_per_pixel);
   ISO_REQUIRE(n_clouds >= 0 && max_pts >= 0 && image_size > 0, ISO_ERR_INVALID, "iso_splat_forward: bad sizes");
   if (n_clouds == 0) return ISO_OK;
   ISO_REQUIRE(first_idx && num_pts && tile_cursor && tile_off && overflow_flag && idx_out &&
@@ -1425,6 +1514,13 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
   const int ty_rows = tile_row_end - tile_row_begin;
   const int tiles = n_clouds * T * ty_rows;
   const int K = points_per_pixel;
+  if (K > 32) {                               // lists too deep for registers: one workgroup per tile, lists in the outputs
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tile_off, F, tile_row_begin, ty_rows, n_clouds, tile_cursor);
+    hipLaunchKernelGGL(k_raster_deep, dim3(tiles), dim3(256), 0, s, points, ellipse, cutoff, radii, tile_cursor, tile_off, pairs,
+                       pair_capacity, F, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);
+    ISO_CHECK_LAUNCH("iso_splat_forward");
+    return ISO_OK;
+  }
   const int KM = K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 16 ? 16 : 32));
   // workspace (optional): work items with the heavy tiles cut into slices
   //   [counters 64 B][items int4 (tiles + slots)][heavy int4 (tiles)][scratch slots * 3 * KM * 256 floats]

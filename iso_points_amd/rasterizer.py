@@ -23,7 +23,7 @@ from . import _lib
 from . import frnn
 from .levelset_sampling import host_lengths, with_host_lengths
 
-kMaxPointsPerPixel = 32      # registers-resident K-best list (the reference allows 150)
+kMaxPointsPerPixel = 150     # as the reference (rasterization_utils.cuh:18); lists deeper than 32 take the slow kernel
 
 
 def image_hw(image_size):

@@ -29,7 +29,7 @@ def _assert_fwd_equal(got, ref):
         assert torch.equal(g.cpu(), r), "%s differs (%d entries)" % (nm, (g.cpu() != r).sum().item())
 
 
-@pytest.mark.parametrize("S,K", [(64, 8), (48, 5), (50, 1), (33, 16), (16, 3)])
+@pytest.mark.parametrize("S,K", [(64, 8), (48, 5), (50, 1), (33, 16), (16, 3), (40, 48), (24, 150)])
 def test_forward_scene_bit_exact(dev, S, K):
     SO = _SO()
     sc = sphere_scene(4000, n_views=2, S=S, seed=S + K)
@@ -51,7 +51,7 @@ def test_forward_large_image_bit_exact(dev):
     assert ref[3].sum() > 50
 
 
-@pytest.mark.parametrize("K,pad", [(8, 1.0), (4, 0.7), (32, 1.3)])
+@pytest.mark.parametrize("K,pad", [(8, 1.0), (4, 0.7), (32, 1.3), (33, 1.0), (100, 1.3)])
 def test_forward_random_splats_bit_exact(dev, K, pad):
     """Unstructured input: points behind the camera, off screen, z ties, radii smaller/larger than
     the true ellipse bbox (the `||` reject rule matters when pad < 1)."""
@@ -323,7 +323,7 @@ def test_full_size_properties(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,S,K", [(150000, 64, 8), (400000, 128, 5), (60000, 32, 20)])
+@pytest.mark.parametrize("P,S,K", [(150000, 64, 8), (400000, 128, 5), (60000, 32, 20), (40000, 32, 40)])
 def test_heavy_tiles_in_slices_equal_whole_tiles(dev, P, S, K):
     """Tiles with thousands of candidates are rasterised in slices by several workgroups and merged:
     bit-identical to one workgroup per tile (the K-best rule is an order on (z, idx))."""
