@@ -23,7 +23,7 @@
 #include "iso_newton.h"
 #include "mfma_split.h"
 
-static_assert(X3_FWD_F16 && X3_BWD_F16, "idr_x16.hip is written for the two-part fp16 layout");
+static_assert(kAP == 2, "idr_x16.hip is written for the two-part fp16 layout");
 
 namespace {
 

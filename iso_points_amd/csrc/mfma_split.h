@@ -1,5 +1,5 @@
 // Split-operand MFMA building blocks shared by the fused-MLP step kernels (siren_x3.hip, idr_x16.hip):
-// operand cuts (three-way bf16, two-way fp16 under a power-of-two scale), the weight-fragment pipeline
+// operand cut (two-way fp16 under a power-of-two scale), the weight-fragment pipeline
 // and the layer GEMM.  Feature order of all per-feature data: x3_feat() in siren_common.h.
 #pragma once
 #include "siren_common.h"
@@ -8,46 +8,32 @@
 namespace {
 
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// Forward products on split fp16 instead of split bf16 (X3_FWD_F16, default on): an f32 number cut
-// into TWO fp16 numbers (11 + 11 significant bits, round-to-nearest at each cut: unit roundoff 2^-11
-// each) is represented to 2^-22 relative in the worst case, and W.x is formed from THREE partial
-// products (W_h x_l + W_l x_h + W_h x_h; the dropped W_l x_l is <= 2^-22 relative) instead of six: half
-// the MFMAs of a forward layer.  Worst-case bounds, that is: two bits above the f32 unit roundoff 2^-24;
-// the errors are not correlated over the 256 terms of a dot product, and against float64 the kernel's
-// gradient error is the same as torch's f32 autograd (0.89e-6 vs 0.81e-6 mean, 4.9e-6 vs 4.6e-6 max:
-// tests/test_projection_gpu.py::test_siren_grad_accuracy_vs_float64, the evidence this rests on).  fp16 has a 5-bit exponent, so both operands are brought into range by
-// exact power-of-two scales: activations (|sin| <= 1) by 2^12 (the low part then stays a normal
-// number down to contributions of 2^-26), the weights of layer l by 2^s_l with
-// max|2^s_l W| in [512, 1024); the bias enters the accumulator scaled by 2^(s_l + 12) and the
-// scale is taken out again, exactly, in the multiplication by omega that follows.  The reverse
-// sweep keeps the three-way bf16 cut: adjoint values have no a-priori range.
-#ifndef X3_FWD_F16
-#define X3_FWD_F16 1
-#endif
-// The reverse sweep on split fp16 as well (X3_BWD_F16, needs X3_FWD_F16): the adjoint has no
-// a-priori range, so every POINT carries its own power-of-two scale.  max_f |a_l[f][p]| is exchanged
-// between the waves through LDS (it rides on the barrier that already ends the stage), and the
-// scale of the next adjoint is taken from the rigorous bound
+// f32 products from fp16 MFMAs: an f32 number cut into TWO fp16 numbers (11 + 11 significant bits, round-to-nearest
+// at each cut: unit roundoff 2^-11 each) is represented to 2^-22 relative in the worst case, and W.x is formed from
+// THREE partial products (W_h x_l + W_l x_h + W_h x_h; the dropped W_l x_l is <= 2^-22 relative).  Worst-case bounds,
+// that is: two bits above the f32 unit roundoff 2^-24; the errors are not correlated over the 256 terms of a dot
+// product, and against float64 the kernel's gradient error is the same as torch's f32 autograd (0.89e-6 vs 0.81e-6
+// mean, 4.9e-6 vs 4.6e-6 max: tests/test_projection_gpu.py::test_siren_grad_accuracy_vs_float64, the evidence this
+// rests on).  fp16 has a 5-bit exponent, so both operands are brought into range by exact power-of-two scales:
+// activations (|sin| <= 1) by 2^12 (the low part then stays a normal number down to contributions of 2^-26), the
+// weights of layer l by 2^s_l with max|2^s_l W| in [512, 1024); the bias enters the accumulator scaled by
+// 2^(s_l + 12) and the scale is taken out again, exactly, in the multiplication by omega that follows.
+// The adjoint of the reverse sweep has no a-priori range, so every POINT carries its own power-of-two scale.
+// max_f |a_l[f][p]| is exchanged between the waves through LDS (it rides on the barrier that already ends the
+// stage), and the scale of the next adjoint is taken from the rigorous bound
 //   |a_{l-1}[f][p]| <= omega * (max_f sum_k |W_l[k][f]|) * max_k |a_l[k][p]|
-// (column sums prepared at pack time), scaled to below 2^14: no overflow whatever the weights, and
-// since every element keeps 22 significant bits of its own, the ~20x slack of the bound only
-// moves the subnormal floor (elements below 2^-13 of the largest one) -- contributions at the f32
-// rounding level of the dot product.
-#ifndef X3_BWD_F16
-#define X3_BWD_F16 1
-#endif
-static_assert(!X3_BWD_F16 || X3_FWD_F16, "the split-fp16 reverse sweep shares the fp16 activation layout");
-// parts per (K-step, point tile) entry of the activation buffer in LDS: two when no stage uses the
-// three-way bf16 cut (a third less LDS: room for four point tiles per workgroup)
-constexpr int kAP = (X3_FWD_F16 && X3_BWD_F16) ? 2 : 3;
+// (column sums prepared at pack time), scaled to below 2^14: no overflow whatever the weights, and since every
+// element keeps 22 significant bits of its own, the ~20x slack of the bound only moves the subnormal floor
+// (elements below 2^-13 of the largest one) -- contributions at the f32 rounding level of the dot product.
+// (An exact three-way bf16 cut with six products was the first form of these kernels: tools/experiments/, history.)
+// parts per (K-step, point tile) entry of the activation buffer in LDS
+constexpr int kAP = 2;
 
 // 2^E with bound * 2^E in [2^13, 2^14) (1 for a zero / non-finite bound)
 __device__ __forceinline__ float x3_scale_for(float bound) {
@@ -60,42 +46,8 @@ __device__ __forceinline__ float x3_scale_for(float bound) {
 }
 constexpr float kActScale = 4096.0f;             // 2^12
 
-// exact three-way cut of two floats; element 0 in the low half of each word
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid,
-                                           unsigned& lo) {
-  const bf16x2 h = __builtin_convertvector((f32x2){x0, x1}, bf16x2);
-  const f32x2 hf = __builtin_convertvector(h, f32x2);
-  const float r0 = x0 - hf.x, r1 = x1 - hf.y;
-  const bf16x2 m = __builtin_convertvector((f32x2){r0, r1}, bf16x2);
-  const f32x2 mf = __builtin_convertvector(m, f32x2);
-  const bf16x2 l = __builtin_convertvector((f32x2){r0 - mf.x, r1 - mf.y}, bf16x2);
-  hi = __builtin_bit_cast(unsigned, h);
-  mid = __builtin_bit_cast(unsigned, m);
-  lo = __builtin_bit_cast(unsigned, l);
-}
-
-// step-major over the four pairs, for the same reason as iso_sincos_core2x4 (mlp_common.h):
-// per pair exactly split_pair
-__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
-  f32x2 x[4], f[4];
-  bf16x2 h[4], m[4], l[4];
-  ISO_X4(x[p] = ((f32x2){v[2 * p], v[2 * p + 1]}));
-  ISO_X4(h[p] = __builtin_convertvector(x[p], bf16x2));
-  ISO_X4(f[p] = __builtin_convertvector(h[p], f32x2));
-  ISO_X4(x[p] = x[p] - f[p]);
-  ISO_X4(m[p] = __builtin_convertvector(x[p], bf16x2));
-  ISO_X4(f[p] = __builtin_convertvector(m[p], f32x2));
-  ISO_X4(x[p] = x[p] - f[p]);
-  ISO_X4(l[p] = __builtin_convertvector(x[p], bf16x2));
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    hi[d] = __builtin_bit_cast(unsigned, h[d]);
-    mid[d] = __builtin_bit_cast(unsigned, m[d]);
-    lo[d] = __builtin_bit_cast(unsigned, l[d]);
-  }
-}
-
-// two-way fp16 cut of scale * v (step-major as split8); scale is a power of two
+// two-way fp16 cut of scale * v, step-major over the four pairs (a packed op whose result feeds the next
+// instruction costs a wait state, mlp_common.h); scale is a power of two
 __device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, float scale = kActScale) {
   f32x2 x[4], f[4];
   f16x2 h[4], l[4];
@@ -133,7 +85,7 @@ constexpr int kAD = X3_KAD;
 
 // imgw is WAVE-UNIFORM (no lane term): the loads take the scalar-base + 32-bit lane-offset form,
 // so no 64-bit per-lane address registers are needed.
-// PARTS = 3: split-bf16 image, 2: split-fp16 image (imgw then points TW*w*PARTS*64 into it)
+// PARTS = 2: the split-fp16 image (imgw points TW*w*PARTS*64 into it)
 // IP: `const u32x4*`, or the same with an explicit global address space (siren_pp.hip)
 typedef const __attribute__((address_space(1))) u32x4* gimg_t;
 template <class IP> struct x3_byte_ptr { typedef const char* type; };
@@ -173,10 +125,9 @@ __device__ __forceinline__ void x3_keep_alive(const u32x4 (&X)[N][3]) {
     for (int c = 0; c < PARTS; ++c) asm volatile("" ::"v"(X[i][c]));
 }
 
-// PARTS / NEXT_PARTS: operand format of this stage / of the stage whose first fragments are
-// requested at the end (3 = split bf16, six products; 2 = split fp16, three products).
+// PARTS / NEXT_PARTS: operand parts of this stage / of the stage whose first fragments are requested at the end (2).
 // bias_scale multiplies the bias (the accumulator scale of a split-fp16 stage; 1 otherwise).
-template <int TW, int NB, int NTO, int KS, int INIT, bool IL, int PARTS = 3, int NEXT_PARTS = 3, class IP = const u32x4*>
+template <int TW, int NB, int NTO, int KS, int INIT, bool IL, int PARTS = 2, int NEXT_PARTS = 2, class IP = const u32x4*>
 __device__ __forceinline__ void gemm_x3(IP imgw, const float* __restrict__ bias_h,
                                         const u32x4* actl, f32x16 (&acc)[TW][NB], int w, int s0,
                                         u32x4 (&A)[4][TW][3], IP next_imgw, int next_s,
@@ -226,36 +177,22 @@ __device__ __forceinline__ void gemm_x3(IP imgw, const float* __restrict__ bias_
 #pragma unroll
       for (int n = 0; n < NB; ++n)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc[t][n][c] += __builtin_bit_cast(f32x4, Ar[t][c]).x * __builtin_bit_cast(f32x4, Br[n][c]).y;
+        for (int c = 0; c < 2; ++c) acc[t][n][c] += __builtin_bit_cast(f32x4, Ar[t][c]).x * __builtin_bit_cast(f32x4, Br[n][c]).y;
     return;
 #endif
-    if constexpr (PARTS == 2) {
-      // W_l x_h + W_h x_l + W_h x_h
-      constexpr int QA[3] = {1, 0, 0};
-      constexpr int QB[3] = {0, 1, 0};
+    static_assert(PARTS == 2, "two fp16 parts per operand");
+    // W_l x_h + W_h x_l + W_h x_h
+    constexpr int QA[3] = {1, 0, 0};
+    constexpr int QB[3] = {0, 1, 0};
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-          for (int n = 0; n < NB; ++n)
-            acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ar[t][QA[q]]),
-                                                               __builtin_bit_cast(f16x8, Br[n][QB[q]]),
-                                                               acc[t][n], 0, 0, 0);
-      return;
-    }
-    // smallest terms first; consecutive MFMAs go to different accumulators
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int t = 0; t < TW; ++t)
 #pragma unroll
         for (int n = 0; n < NB; ++n)
-          acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ar[t][PA[q]]),
-                                                              __builtin_bit_cast(bf16x8, Br[n][PB[q]]),
-                                                              acc[t][n], 0, 0, 0);
+          acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ar[t][QA[q]]),
+                                                             __builtin_bit_cast(f16x8, Br[n][QB[q]]),
+                                                             acc[t][n], 0, 0, 0);
   };
   ldB(B[0], s0);
 #ifndef X3_GEMM_PRIO
@@ -296,7 +233,7 @@ __device__ __forceinline__ void gemm_x3(IP imgw, const float* __restrict__ bias_
 #endif
 #if X3_IL_VM
 #pragma unroll
-      for (int g = 0; g < TW * (PARTS > NEXT_PARTS ? PARTS : NEXT_PARTS) && g < TW * NB * (PARTS == 2 ? 3 : 6) - NB * PARTS; ++g) {
+      for (int g = 0; g < TW * (PARTS > NEXT_PARTS ? PARTS : NEXT_PARTS) && g < TW * NB * 3 - NB * PARTS; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }

@@ -272,7 +272,7 @@ bool siren_shape_ok(int H, int L) {
   return (H == 64 || H == 128 || H == 256) && L >= 0 && L <= 8;
 }
 
-// 0 = f32 MFMA kernel (this file), 1 = split-bf16 MFMA kernel (siren_x3.hip) where it applies.
+// 0 = f32 MFMA kernel (this file), 1 = split-fp16 MFMA kernel (siren_x3.hip) where it applies.
 // Default 1; the environment variable ISO_SIREN_GEMM=f32 selects 0 at load time.
 int g_gemm_mode = -1;
 int gemm_mode() {
@@ -309,7 +309,7 @@ extern "C" int64_t iso_siren_packed_floats(int hidden, int n_hidden) {
 }
 
 extern "C" int iso_siren_set_gemm_mode(int mode) {
-  ISO_REQUIRE(mode == 0 || mode == 1, ISO_ERR_INVALID, "iso_siren_set_gemm_mode: mode must be 0 (f32) or 1 (3xbf16)");
+  ISO_REQUIRE(mode == 0 || mode == 1, ISO_ERR_INVALID, "iso_siren_set_gemm_mode: mode must be 0 (f32 MFMA) or 1 (split fp16)");
   g_gemm_mode = mode;
   return ISO_OK;
 }

@@ -1,5 +1,5 @@
 // Shared between siren.hip (f32-MFMA step kernel, packing, C ABI) and siren_x3.hip (the
-// split-bf16 MFMA step kernel): argument block and the layout of the packed weight buffer.
+// split-fp16 MFMA step kernel): argument block and the layout of the packed weight buffer.
 #pragma once
 #include "iso_common.h"
 
@@ -40,16 +40,13 @@ __host__ __device__ inline int64_t off_hidden(int H, int l) {
   return 5 * (int64_t)H + 4 + (int64_t)l * ((int64_t)H + 2 * (int64_t)H * H);
 }
 
-// ---- packed weight buffer, split-bf16 section (siren_x3.hip), appended to the f32 section ----
+// ---- packed weight buffer, K-order section (siren_x3.hip), appended to the f32 section ----
 // All per-feature vectors are in "K-order": position ko = (s*2 + h)*8 + e  <->  feature
 //   f = x3_feat(s, 8h+e),  s = K-step of 16 features, h = lane half, e = element of the lane's
-// 16-B B-operand entry.  With the D layout of v_mfma_f32_32x32x16_bf16 (lane (h,j), register
+// 16-B B-operand entry.  With the D layout of v_mfma_f32_32x32x16_f16 (lane (h,j), register
 // r of output tile T is row 8(r/4)+4h+(r%4)) registers 8p..8p+7 of tile T are exactly the
 // lane's entry for K-step s = 2T+p, so activations never change lanes between layers.
-//   [W0k 4*H][WLk H][ per hidden layer: bias_k H | FWx3 3*H*H/2 | BWx3 3*H*H/2 ]   (float units)
-// FWx3/BWx3: uint4 index ((s*NTO + To)*3 + part)*64 + lane, 8 bf16 each (part 0/1/2 = high /
-// middle / low third of the f32 mantissa), lane = 32h'+row:  W[32To+row][x3_feat(s,8h'+e)]
-// (BWx3: the transpose).
+//   [W0k 4*H][WLk H][ per hidden layer: bias_k H ]   (float units)
 __host__ __device__ inline int x3_feat(int s, int kappa) {
   return 32 * (s >> 1) + 16 * (s & 1) + 8 * ((kappa & 7) >> 2) + 4 * (kappa >> 3) + (kappa & 3);
 }
@@ -57,15 +54,15 @@ __host__ __device__ inline int64_t x3_base(int H, int L) { return off_hidden(H, 
 __host__ __device__ inline int64_t x3_off_w0(int H, int L) { return x3_base(H, L); }
 __host__ __device__ inline int64_t x3_off_wl(int H, int L) { return x3_base(H, L) + 4 * (int64_t)H; }
 __host__ __device__ inline int64_t x3_off_layer(int H, int L, int l) {
-  return x3_base(H, L) + 5 * (int64_t)H + (int64_t)l * ((int64_t)H + 3 * (int64_t)H * H);
+  return x3_base(H, L) + 5 * (int64_t)H + (int64_t)l * (int64_t)H;
 }
-// ---- images in split fp16 (siren_x3.hip), appended to the split-bf16 section --------------------
+// ---- images in split fp16 (siren_x3.hip), appended to the K-order section --------------------
 //   [24 floats: 0..7  2^s_l, the power-of-two scale of hidden layer l
 //               8..15 c_l = max over input features f of sum_k |W_l[k][f]|  (growth bound of the adjoint)
 //               16    max |W_head| ]
 //   [ per hidden layer: FW16 H*H ][ per hidden layer: BW16 H*H ]                       (float units)
 // FW16 / BW16: uint4 index ((s*NTO + To)*2 + part)*64 + lane, 8 fp16 each (part 0/1 = high / low
-// 11+11 bits of 2^s_l * W resp. its transpose), same (s, To, lane, element) map as FWx3 / BWx3.
+// 11+11 bits of 2^s_l * W resp. its transpose), lane = 32h'+row:  W[32To+row][x3_feat(s,8h'+e)].
 constexpr int kX16Header = 24;
 __host__ __device__ inline int64_t x16_base(int H, int L) { return x3_off_layer(H, L, L); }
 __host__ __device__ inline int64_t x16_off_layer(int H, int L, int l) { return x16_base(H, L) + kX16Header + (int64_t)l * H * H; }

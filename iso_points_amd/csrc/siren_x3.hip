@@ -5,16 +5,15 @@
 // autograd.grad in UniformProjection._compute_sdf_and_grad, levelset_sampling.py:142-170, iterated
 // by _project_points :313-342); this file only changes how the H x H products are formed.
 //
-// f32 product from 16-bit MFMAs (mfma_split.h).  Default (X3_FWD_F16 = X3_BWD_F16 = 1): every f32
+// f32 product from 16-bit MFMAs (mfma_split.h): every f32
 // operand is cut into TWO fp16 numbers (11 + 11 significant bits, round-to-nearest at each cut:
 // <= 2^-22 relative in the worst case) under an exact power-of-two scale -- per layer for the weights, 2^12 for
 // the activations, per point for the adjoint of the reverse sweep -- and W.x is accumulated in f32
 // from three products  Wl.xh + Wh.xl + Wh.xh  (fp16 x fp16 is exact in f32; the dropped Wl.xl is
 // <= 2^-22 relative; see mfma_split.h for what that means against the 2^-24 of f32).  The fp16 pipe runs 16x the f32 MFMA rate, so three passes are 5.3x faster than
 // one f32 pass; measured against float64 in tests/test_projection_gpu.py next to the f32-MFMA
-// kernel.  With X3_FWD_F16 = X3_BWD_F16 = 0 the operands are cut exactly into three bf16 numbers
-// instead (no scales needed, six products, three parts per LDS entry): the form this file started
-// with (hence the x3 in the names).
+// kernel.  (The file started with an exact three-way bf16 cut, six products -- hence the x3 in the names; that
+// form and the overlap experiments built on it are in tools/experiments/ and in the history.)
 //
 // Work decomposition (differs from siren.hip: weights are NOT staged through LDS)
 //   * one workgroup = P = 32*NB points (NB = 3), NW = 8 waves (two per SIMD; NW = 4 also builds).
@@ -57,11 +56,10 @@ __device__ __forceinline__ void x3_sin_wcos8(float w_in, float w, const float (&
 
 // ---- packing -------------------------------------------------------------------------------
 // raw layout: W0[H*3] b0[H] {Wi[H*H] bi[H]}*L WL[H] bL[1]
-// with_images = 0: only the K-order vectors (W0k, WLk, biases); the split-bf16 images are left alone
-__global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict__ packed, int H, int L, int with_images) {
+// the K-order vectors: W0k, WLk, the biases of the hidden layers
+__global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict__ packed, int H, int L) {
   const int64_t base = x3_base(H, L), total = x16_base(H, L);
   const int64_t HH = (int64_t)H * H;
-  const int NTO = H / 32;
   const float* b0 = raw + (int64_t)H * 3;
   const float* WL = raw + (int64_t)H * 4 + (int64_t)L * (HH + H);
   for (int64_t o = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total;
@@ -74,32 +72,10 @@ __global__ void k_siren_pack_x3(const float* __restrict__ raw, float* __restrict
     } else if (rel < 5 * (int64_t)H) {
       packed[o] = WL[feat_of(rel - 4 * (int64_t)H)];
     } else {
-      const int64_t per = H + 3 * HH;
-      const int64_t r2 = rel - 5 * (int64_t)H;
-      const int l = (int)(r2 / per);
-      int64_t q = r2 % per;
+      const int64_t r2 = rel - 5 * (int64_t)H;          // bias of hidden layer l, K-order
+      const int l = (int)(r2 / H);
       const float* Wl = raw + (int64_t)H * 4 + (int64_t)l * (HH + H);
-      if (q < H) {
-        packed[o] = Wl[HH + feat_of(q)];
-      } else if (with_images) {
-        q -= H;
-        const bool bwd = q >= 3 * HH / 2;
-        if (bwd) q -= 3 * HH / 2;
-        const int d = (int)(q & 3), lane = (int)((q >> 2) & 63);
-        const int64_t blk = q >> 8;                 // (s*NTO + To)*3 + part
-        const int part = (int)(blk % 3);
-        const int To = (int)((blk / 3) % NTO), s = (int)(blk / (3 * NTO));
-        const int fo = 32 * To + (lane & 31);
-        float v[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int fi = x3_feat(s, 8 * (lane >> 5) + 2 * d + u);
-          v[u] = bwd ? Wl[(int64_t)fi * H + fo] : Wl[(int64_t)fo * H + fi];
-        }
-        unsigned a, b, c;
-        split_pair(v[0], v[1], a, b, c);
-        reinterpret_cast<unsigned*>(packed)[o] = part == 0 ? a : (part == 1 ? b : c);
-      }
+      packed[o] = Wl[HH + feat_of(r2 % H)];
     }
   }
 }
@@ -235,19 +211,6 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   const int lane = tid & 63, h = lane >> 5, j = lane & 31;
   u32x4* own = act + (size_t)(SL * w) * NB * kAP * 64 + lane;    // this wave's K-steps (+lane)
   u32x4* park = own + (size_t)(kAP - 2) * NG * 64;               // last NG*2 KiB of the region
-  // Two teams (NW == 8): waves 0..NW/2-1 own the lower half of the features (K-steps 0..NS/2-1 of
-  // the next layer), the others the upper half, one wave of each team per SIMD.  Team 1 runs the
-  // same sequence of stages ONE STAGE BEHIND team 0 (it takes one extra barrier first, team 0
-  // one extra at the end), and a layer is cut into three stages
-  //     [GEMM over K-half a]  [GEMM over K-half b]  [sin/cos + split + store]
-  // so that while one wave of a SIMD is in its VALU stage its partner is in a GEMM stage: the
-  // matrix pipe and the VALU run concurrently.  Hazards: a team overwrites its K-half of the
-  // activation buffer in stage i+2 after the halves were read in stages i (own team) and i+1
-  // (other team); its new values are first read in stage i+3 / i+4.  One barrier per stage.
-#ifndef X3_SKEW
-#define X3_SKEW 0
-#endif
-  constexpr bool SKEW = (NW == 8) && X3_SKEW;
   // Operand loads pinned behind the MFMAs (gemm_x3): used for the 8-wave shape only.  The 4-wave,
   // two-workgroups-per-CU build of H = 128 loses run-to-run repeatability as soon as the loads may
   // be scheduled between the MFMAs (tools/siren_stress.py: every repeat differs; the same source
@@ -258,8 +221,6 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 #else
   constexpr bool IL = (NW == 8);
 #endif
-  constexpr int KH = NS / 2;
-  const int team = SKEW ? (w >= NW / 2) : 0;
   const int L = a.L;
   const float* X = a.packed + x3_base(H, L);
   // wave-uniform bases (SGPRs) + small per-lane offsets: no 64-bit per-lane pointers are kept live
@@ -270,30 +231,12 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   f32x4* stash = reinterpret_cast<f32x4*>(a.stash) +
                  ((int64_t)blockIdx.x * NW + w) * (int64_t)(L + 1) * NG * 128;   // + lane
 
-  // weight images of this wave: forward / transposed image of hidden layer l
-  auto fw_img = [&](int l) {
-    return reinterpret_cast<const u32x4*>(a.packed + x3_off_layer(H, L, l) + H) + (TW * w * 3) * 64;
-  };
-  auto bw_img = [&](int l) {
-    return reinterpret_cast<const u32x4*>(a.packed + x3_off_layer(H, L, l) + H + 3 * (H * H / 2)) + (TW * w * 3) * 64;
-  };
-  constexpr int FP = X3_FWD_F16 ? 2 : 3;      // operand parts of the forward stages
-  // forward image of hidden layer l in the forward format
-  auto fwd_img = [&](int l) {
-    if constexpr (X3_FWD_F16)
-      return reinterpret_cast<const u32x4*>(a.packed + x16_off_layer(H, L, l)) + (TW * w * 2) * 64;
-    else
-      return fw_img(l);
-  };
+  // weight images of this wave: forward / transposed image of hidden layer l (two fp16 parts)
+  constexpr int FP = 2, BP = 2;
+  auto fwd_img = [&](int l) { return reinterpret_cast<const u32x4*>(a.packed + x16_off_layer(H, L, l)) + (TW * w * 2) * 64; };
+  auto rev_img = [&](int l) { return reinterpret_cast<const u32x4*>(a.packed + x16_off_bw(H, L, l)) + (TW * w * 2) * 64; };
   // accumulator scale of forward layer l: 2^12 (activations) * 2^s_l (weights)
-  auto fwd_scale = [&](int l) { return X3_FWD_F16 ? kActScale * a.packed[x16_base(H, L) + l] : 1.0f; };
-  constexpr int BP = X3_BWD_F16 ? 2 : 3;      // operand parts of the reverse stages
-  auto rev_img = [&](int l) {
-    if constexpr (X3_BWD_F16)
-      return reinterpret_cast<const u32x4*>(a.packed + x16_off_bw(H, L, l)) + (TW * w * 2) * 64;
-    else
-      return bw_img(l);
-  };
+  auto fwd_scale = [&](int l) { return kActScale * a.packed[x16_base(H, L) + l]; };
   // per-point maxima of the adjoint, exchanged between the waves: [2][P][NW] floats in the (otherwise
   // idle until the final reduction) `red` region
   float* redm = reinterpret_cast<float*>(red);
@@ -334,8 +277,6 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       }
     }
     X3_STAMP();
-    if (SKEW && team == 1) __syncthreads();
-    X3_STAMP();
     // ---- layer 0 (3 -> H) on the VALU: this wave's H/NW features of all P points ------------
     for (int sl = 0; sl < SL; ++sl) {
       f32x4 wv[8];
@@ -348,14 +289,10 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         for (int e = 0; e < 8; ++e) zz[e] = ((wv[e].x * px[n] + wv[e].y * py[n]) + wv[e].z * pz[n]) + wv[e].w;
         x3_sin_wcos8(a.w0, a.w0, zz, hv, sv);
         const int k = sl * NB + n;
-        if constexpr (X3_FWD_F16) {
+        {
           u32x4 p0, p1;
           split8_f16(hv, p0, p1);
           own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
-        } else {
-          u32x4 p0, p1, p2;
-          split8(hv, p0, p1, p2);
-          own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1; own[(k * kAP + 2) * 64] = p2;
         }
 #ifndef X3_DBG_NOSTASH
         if constexpr (!FWD) {
@@ -379,15 +316,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       const u32x4* img = fwd_img(l);
       const float zscale = fwd_scale(l);             // the accumulators hold zscale * (W h + b)
       const float w_in = a.wh / zscale;              // exact: zscale is a power of two
-      static_assert(!SKEW || !X3_FWD_F16, "the two-team experiment is written for the split-bf16 forward");
-      if constexpr (SKEW) {
-        const u32x4* nxt = l + 1 < L ? fw_img(l + 1) : (FWD ? fw_img(0) : bw_img(L - 1));
-        gemm_x3<TW, NB, NTO, KH, kBias, IL>(img, lay, act + lane, acc, w, 0, A, img, KH, lane);
-        X3_STAMP();
-        __syncthreads();
-        X3_STAMP();
-        gemm_x3<TW, NB, NTO, KH, kAccumulate, IL>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0, lane);
-      } else if (l + 1 < L || FWD) {
+      if (l + 1 < L || FWD) {
         // the next stage is a forward one again (layer l+1, or layer 0 of the next tile)
         gemm_x3<TW, NB, NTO, NS, kBias, IL, FP, FP>(img, lay, act + lane, acc, w, 0, A,
                                                     l + 1 < L ? fwd_img(l + 1) : fwd_img(0), 0, lane, zscale);
@@ -402,7 +331,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       f32x4* st_l = stash + (int64_t)(l + 1) * NG * 128;
       // one 8-value group: sin / w cos, head or stash, split, store as the next layer's B entry
       // scale of the adjoint seed (uniform): |W_head[f] * w cos| <= max|W_head| * w
-      const float seed_scale = X3_BWD_F16 ? x3_scale_for(a.packed[x16_base(H, L) + 16] * a.wh * 1.01f) : 1.0f;
+      const float seed_scale = x3_scale_for(a.packed[x16_base(H, L) + 16] * a.wh * 1.01f);
       if (top) {
 #pragma unroll
         for (int n = 0; n < NB; ++n) { amax[n] = 0.f; bscale[n] = seed_scale; }
@@ -420,16 +349,14 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
           if constexpr (FWD) return;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { hv[e] = wl0[e] * sv[e]; hv[4 + e] = wl1[e] * sv[4 + e]; }
-          if constexpr (X3_BWD_F16) {
-            float m = amax[n];
+          float m = amax[n];
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(hv[e]), __builtin_fabsf(hv[e + 1])));
-            amax[n] = m;
-            u32x4 p0, p1;
-            split8_f16(hv, p0, p1, seed_scale);
-            own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
-            return;
-          }
+          for (int e = 0; e < 8; e += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(hv[e]), __builtin_fabsf(hv[e + 1])));
+          amax[n] = m;
+          u32x4 p0, p1;
+          split8_f16(hv, p0, p1, seed_scale);
+          own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
+          return;
         } else {
 #ifndef X3_DBG_NOSTASH
           if constexpr (!FWD) {
@@ -438,15 +365,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
           }
 #endif
         }
-        if (X3_FWD_F16 && !top) {               // input of the next forward layer
-          u32x4 p0, p1;
-          split8_f16(hv, p0, p1);
-          own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
-        } else {                                // seed of the reverse sweep
-          u32x4 p0, p1, p2;
-          split8(hv, p0, p1, p2);
-          own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1; own[(k * kAP + 2) * 64] = p2;
-        }
+        u32x4 p0, p1;                           // input of the next forward layer
+        split8_f16(hv, p0, p1);
+        own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
       };
 #ifndef X3_DIRECT_ACT
 #define X3_DIRECT_ACT 1
@@ -501,7 +422,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
           }
         }
       }
-      if constexpr (X3_BWD_F16 && !FWD) { if (top) put_amax(0); }
+      if constexpr (!FWD) { if (top) put_amax(0); }
       X3_STAMP();
       __syncthreads();                      // the next layer's inputs are complete
       X3_STAMP();
@@ -527,25 +448,16 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       };
       // max_k |a_l[k][p]| of this lane's points (written before the barrier that ended the last stage)
       float Mp[NB];
-      if constexpr (X3_BWD_F16) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          float m = 0.f;
+      for (int n = 0; n < NB; ++n) {
+        float m = 0.f;
 #pragma unroll
-          for (int ww = 0; ww < NW; ++ww) m = __builtin_fmaxf(m, redm[(mbuf * P + 32 * n + j) * NW + ww]);
-          Mp[n] = m;
-        }
+        for (int ww = 0; ww < NW; ++ww) m = __builtin_fmaxf(m, redm[(mbuf * P + 32 * n + j) * NW + ww]);
+        Mp[n] = m;
       }
       // w cos(w z) of the layer below: requested before the GEMM when the registers allow it
       if constexpr (NG <= 6 && X3_EARLY_STASH) ld_stash();
-      if constexpr (SKEW) {
-        const u32x4* nxt = l > 0 ? bw_img(l - 1) : fw_img(0);
-        gemm_x3<TW, NB, NTO, KH, kZero, IL>(img, nullptr, act + lane, acc, w, 0, A, img, KH, lane);
-        X3_STAMP();
-        __syncthreads();
-        X3_STAMP();
-        gemm_x3<TW, NB, NTO, KH, kAccumulate, IL>(img, nullptr, act + lane, acc, w, KH, A, nxt, 0, lane);
-      } else if (l > 0) {
+      if (l > 0) {
         gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, BP>(img, nullptr, act + lane, acc, w, 0, A, rev_img(l - 1), 0, lane);
       } else {
         gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, FP>(img, nullptr, act + lane, acc, w, 0, A, fwd_img(0), 0, lane);
@@ -557,15 +469,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       // split-fp16 reverse: the accumulators hold 2^s_l * bscale[p] * (W_l^T a_l); the scale comes out
       // exactly, the next adjoint gets the scale its bound allows
       float inv[NB], nscale[NB];
-#pragma unroll
-      for (int n = 0; n < NB; ++n) { inv[n] = 1.0f; nscale[n] = 1.0f; }
-      if constexpr (X3_BWD_F16) {
+      {
         const float iw = 1.0f / a.packed[x16_base(H, L) + l];
         const float grow = a.packed[x16_base(H, L) + 8 + l] * a.wh * 1.01f;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
           inv[n] = iw / bscale[n];
-          if (l > 0) nscale[n] = x3_scale_for(Mp[n] * grow);
+          nscale[n] = l > 0 ? x3_scale_for(Mp[n] * grow) : 1.0f;
           amax[n] = 0.f;
         }
       }
@@ -584,23 +494,16 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
             float av[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              if constexpr (X3_BWD_F16) av[e] = (acc[t][n][8 * p + e] * inv[n]) * sv[k][e >> 2][e & 3];
-              else av[e] = acc[t][n][8 * p + e] * sv[k][e >> 2][e & 3];
+              av[e] = (acc[t][n][8 * p + e] * inv[n]) * sv[k][e >> 2][e & 3];
             }
             if (l > 0) {
-              if constexpr (X3_BWD_F16) {
-                float m = amax[n];
+              float m = amax[n];
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(av[e]), __builtin_fabsf(av[e + 1])));
-                amax[n] = m;
-                u32x4 p0, p1;
-                split8_f16(av, p0, p1, nscale[n]);
-                own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
-              } else {
-                u32x4 p0, p1, p2;
-                split8(av, p0, p1, p2);
-                own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1; own[(k * kAP + 2) * 64] = p2;
-              }
+              for (int e = 0; e < 8; e += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(av[e]), __builtin_fabsf(av[e + 1])));
+              amax[n] = m;
+              u32x4 p0, p1;
+              split8_f16(av, p0, p1, nscale[n]);
+              own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
@@ -611,20 +514,16 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
             }
           }
         }
-      if constexpr (X3_BWD_F16) {
-        if (l > 0) {
+      if (l > 0) {
 #pragma unroll
-          for (int n = 0; n < NB; ++n) bscale[n] = nscale[n];
-          put_amax(mbuf ^ 1);
-          mbuf ^= 1;
-        }
+        for (int n = 0; n < NB; ++n) bscale[n] = nscale[n];
+        put_amax(mbuf ^ 1);
+        mbuf ^= 1;
       }
       X3_STAMP();
       __syncthreads();
       X3_STAMP();
     }
-    if (SKEW && team == 0) __syncthreads();
-    X3_STAMP();
     // ---- reduce head + gradient over the lane halves and the waves -----------------------------
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
@@ -726,9 +625,7 @@ int64_t siren_x3_stash_floats(int H, int L) {
 
 void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s) {
   const int64_t words = x16_base(H, L) - x3_base(H, L);
-  // the three-way bf16 images are only read by the -DX3_FWD_F16=0 / -DX3_BWD_F16=0 builds
-  hipLaunchKernelGGL(k_siren_pack_x3, dim3(iso_stream_grid(words, 256)), dim3(256), 0, s, raw, packed, H, L,
-                     (X3_FWD_F16 && X3_BWD_F16) ? 0 : 1);
+  hipLaunchKernelGGL(k_siren_pack_x3, dim3(iso_stream_grid(words, 256)), dim3(256), 0, s, raw, packed, H, L);
   if (L > 0) {
     hipLaunchKernelGGL(k_siren_wscale, dim3(L), dim3(256), 0, s, raw, packed, H, L);
     hipLaunchKernelGGL(k_siren_pack_f16, dim3(iso_stream_grid(2 * (int64_t)L * H * H, 256)), dim3(256), 0, s, raw, packed, H, L);

@@ -41,9 +41,8 @@ def test_size_helpers_need_no_gpu():
     lib = _lib.load()
     H, L = 256, 3
     assert lib.iso_siren_raw_floats(H, L) == H * 3 + H + L * (H * H + H) + H + 1
-    # f32-MFMA images + the pre-split bf16 images (3 parts x 2 B = 1.5 floats per weight, both directions)
-    assert lib.iso_siren_packed_floats(H, L) == (5 * H + 4 + L * (H + 2 * H * H)) + (5 * H + L * (H + 3 * H * H)) + \
-        (24 + 2 * L * H * H)     # f32 images + split-bf16 images + split-fp16 images (header, forward, transposed)
+    # f32-MFMA images + K-order vectors + split-fp16 images (header, forward, transposed)
+    assert lib.iso_siren_packed_floats(H, L) == (5 * H + 4 + L * (H + 2 * H * H)) + (5 * H + L * H) + (24 + 2 * L * H * H)
     assert lib.iso_prefix_sum_workspace_bytes(1, 1) >= 4
     assert lib.iso_project_siren_workspace_bytes(1000, H, L) > 0
 
