@@ -532,7 +532,18 @@ __device__ __forceinline__ void composite_pixel(const PixK<KMAX>& best, int K, f
   ca.img[pix * (ca.C + 1) + ca.C] = hit ? 1.0f : 0.0f;
 }
 
-template <int KMAX>
+// CP ("candidate parallel"): how the hits of a chunk of 256 candidates reach the pixels.
+//   false: every pixel thread walks the candidates that reach its wave's four rows and tests each one (the first
+//          form: the K-best insertion, ~50 instructions, runs for the whole wave whenever ANY of its lanes is hit --
+//          with splats a few pixels wide that is nearly every candidate, for a handful of lanes each time);
+//   true:  thread t walks the few pixels of candidate t's bounding box inside the tile, tests them exactly as the
+//          pixel thread would (same expressions on the same operands) and appends t to the hit list of every pixel
+//          it covers (LDS counters); the pixel threads then insert only their own hits.  The K-best rule is a total
+//          order on (z, id), so the arrival order in the lists does not matter.  Candidates whose box covers more
+//          than kWideArea pixels, and pixels whose list overflows, take the first form.
+constexpr int kHitList = 40, kWideArea = 48;
+
+template <int KMAX, bool CP>
 __global__ __launch_bounds__(256) void k_raster(
     const float* __restrict__ pts, const float* __restrict__ ellipse,
     const float* __restrict__ cutoff, const float* __restrict__ radii,
@@ -541,13 +552,15 @@ __global__ __launch_bounds__(256) void k_raster(
     const int32_t* __restrict__ pairs, int64_t capacity, Frame F,
     int K, float depth_thres, int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out,
     float* __restrict__ occ_out, CompositeArgs ca) {
-  __shared__ float s_px[256], s_py[256], s_pz[256], s_a[256], s_b[256], s_c[256], s_rx[256],
-      s_ry[256], s_cut[256];
-  __shared__ int s_id[256];
+  constexpr int NSOA = CP ? 1 : 256;
+  __shared__ float s_px[NSOA], s_py[NSOA], s_pz[NSOA], s_a[NSOA], s_b[NSOA], s_c[NSOA], s_rx[NSOA], s_ry[NSOA], s_cut[NSOA];
+  __shared__ int s_id[NSOA];
   // per-wave candidate lists: wave w owns pixel rows 4w..4w+3 of the tile and only walks the
   // candidates whose y-extent reaches those rows (splats are a few pixels wide: ~40 % of them)
-  __shared__ short s_list[4][256];
+  __shared__ short s_list[4][NSOA];
   __shared__ int s_cntw[4][4];       // [source wave][target wave]
+  __shared__ int s_hits[CP ? 256 : 1];                      // CP: hits of the chunk per pixel
+  __shared__ unsigned char s_hit[CP ? 256 : 1][CP ? kHitList : 1];
   // workgroups take the tiles of the band heaviest first (k_tile_order): a tile on the sphere's
   // silhouette holds 8x the mean number of candidates and would otherwise finish long after the rest
   // a work item = a tile, or -- for the tiles that hold many times the mean number of candidates (a
@@ -588,59 +601,143 @@ __global__ __launch_bounds__(256) void k_raster(
     c_begin = (int)((int64_t)chunks * slice / nslices) * 256;
     cnt = min(cnt, (int)((int64_t)chunks * (slice + 1) / nslices) * 256);
   }
-  for (int c0 = c_begin; c0 < cnt; c0 += 256) {
-    const int m = min(256, cnt - c0);
-    __syncthreads();
-    bool hit_band[4] = {false, false, false, false};
-    if ((int)threadIdx.x < m) {
-      const int p = pairs[off + c0 + threadIdx.x];
-      const float py = pts[(int64_t)p * 3 + 1], ry = radii[(int64_t)p * 2 + 1];
-      s_px[threadIdx.x] = pts[(int64_t)p * 3];
-      s_py[threadIdx.x] = py;
-      s_pz[threadIdx.x] = pts[(int64_t)p * 3 + 2];
-      s_a[threadIdx.x] = ellipse[(int64_t)p * 3];
-      s_b[threadIdx.x] = ellipse[(int64_t)p * 3 + 1];
-      s_c[threadIdx.x] = ellipse[(int64_t)p * 3 + 2];
-      s_rx[threadIdx.x] = radii[(int64_t)p * 2];
-      s_ry[threadIdx.x] = ry;
-      s_cut[threadIdx.x] = cutoff[p];
-      s_id[threadIdx.x] = p;
-      const float ylo = py - ry * 1.000001f - 1.0e-6f, yhi = py + ry * 1.000001f + 1.0e-6f;
+  if constexpr (CP) {
+    // records of a chunk: {x, y, z, id} {a, b, c, cutoff} {rx, ry}; two buffers, the next chunk's records are
+    // requested (into registers) while this one is worked on, two barriers per chunk
+    __shared__ float4 s_rec[2][256][3];
+    __shared__ short s_wide[2][256];
+    __shared__ int s_nw[2];
+    float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0;
+    auto fetch = [&](int c0) {
+      if (c0 + (int)threadIdx.x < cnt) {
+        const int p = pairs[off + c0 + threadIdx.x];
+        r0 = make_float4(pts[(int64_t)p * 3], pts[(int64_t)p * 3 + 1], pts[(int64_t)p * 3 + 2], __int_as_float(p));
+        r1 = make_float4(ellipse[(int64_t)p * 3], ellipse[(int64_t)p * 3 + 1], ellipse[(int64_t)p * 3 + 2], cutoff[p]);
+        r2 = make_float4(radii[(int64_t)p * 2], radii[(int64_t)p * 2 + 1], 0.f, 0.f);
+      }
+    };
+    int par = 0;
+    auto test_push = [&](int k, bool exact_hit) {
+      const float4 c0v = s_rec[par][k][0], c1v = s_rec[par][k][1];
+      const float dx = xf - c0v.x, dy = yf - c0v.y;
+      if (!exact_hit) {
+        const float4 c2v = s_rec[par][k][2];
+        if (fabsf(dx) > c2v.x || fabsf(dy) > c2v.y) return;                        // rasterize_points.cu:92
+      }
+      const float q = c1v.x * dx * dx + c1v.y * dx * dy + c1v.z * dy * dy;        // :94
+      if (!exact_hit && q > c1v.w) return;                                        // :96
+      const float pz = c0v.z;
+      const int id = __float_as_int(c0v.w);
+      if (pz < wz || (pz == wz && id < wi)) {
+        best.push(pz, id, q, K);
 #pragma unroll
-      for (int w = 0; w < 4; ++w) hit_band[w] = !(yhi < band_lo[w]) && !(ylo > band_hi[w]);   // NaN -> kept
-    }
-    int rank[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const unsigned long long bal = __ballot(hit_band[w]);
-      rank[w] = __popcll(bal & ((1ull << lane) - 1ull));
-      if (lane == 0) s_cntw[wave][w] = __popcll(bal);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (hit_band[w]) {
-        int base = 0;
-#pragma unroll
-        for (int sw = 0; sw < 4; ++sw) base += (sw < wave) ? s_cntw[sw][w] : 0;
-        s_list[w][base + rank[w]] = (short)threadIdx.x;
+        for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wz = best.z[j]; wi = best.id[j]; }
+      }
+    };
+    s_hits[threadIdx.x] = 0;
+    if (threadIdx.x < 2) s_nw[threadIdx.x] = 0;
+    fetch(c_begin);
+    for (int c0 = c_begin; c0 < cnt; c0 += 256, par ^= 1) {
+      const int m = min(256, cnt - c0);
+      if ((int)threadIdx.x < m) { s_rec[par][threadIdx.x][0] = r0; s_rec[par][threadIdx.x][1] = r1; s_rec[par][threadIdx.x][2] = r2; }
+      __syncthreads();                                    // records visible; the hit counters are zero
+      fetch(c0 + 256);
+      if ((int)threadIdx.x < m) {
+        const int k = threadIdx.x;
+        const float4 c0v = s_rec[par][k][0], c1v = s_rec[par][k][1], c2v = s_rec[par][k][2];
+        int x0, x1, y0, y1;
+        const bool any = pixel_range(c0v.x, c2v.x, F.W, F.ex, F.m, x0, x1) && pixel_range(c0v.y, c2v.y, F.H, F.ey, F.m, y0, y1);
+        x0 = max(x0, tx * TILE); x1 = min(x1, tx * TILE + TILE - 1);
+        y0 = max(y0, ty * TILE); y1 = min(y1, ty * TILE + TILE - 1);
+        if (any && x0 <= x1 && y0 <= y1) {
+          if ((x1 - x0 + 1) * (y1 - y0 + 1) > kWideArea) {
+            s_wide[par][atomicAdd(&s_nw[par], 1)] = (short)k;
+          } else {
+            for (int y = y0; y <= y1; ++y) {
+              const float dy = ndc_y(y, F) - c0v.y;
+              if (fabsf(dy) > c2v.y) continue;
+              for (int x = x0; x <= x1; ++x) {
+                const float dx = ndc_x(x, F) - c0v.x;
+                if (fabsf(dx) > c2v.x) continue;
+                const float q = c1v.x * dx * dx + c1v.y * dx * dy + c1v.z * dy * dy;
+                if (q > c1v.w) continue;
+                const int pl = (y - ty * TILE) * TILE + (x - tx * TILE);
+                const int slot = atomicAdd(&s_hits[pl], 1);
+                if (slot < kHitList) s_hit[pl][slot] = (unsigned char)k;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();                                    // hit lists complete
+      const int nh = s_hits[threadIdx.x];
+      s_hits[threadIdx.x] = 0;
+      if (threadIdx.x == 0) s_nw[par ^ 1] = 0;
+      if (inside) {
+        if (nh <= kHitList) {
+          for (int i = 0; i < nh; ++i) test_push(s_hit[threadIdx.x][i], true);
+          const int nw = s_nw[par];
+          for (int i = 0; i < nw; ++i) test_push(s_wide[par][i], false);
+        } else {
+          for (int k = 0; k < m; ++k) test_push(k, false);        // an overfull list: every candidate, tested here
+        }
       }
     }
-    const int mine = s_cntw[0][wave] + s_cntw[1][wave] + s_cntw[2][wave] + s_cntw[3][wave];
-    __syncthreads();
-    if (inside) {
-      for (int i = 0; i < mine; ++i) {
-        const int k = s_list[wave][i];
-        const float dx = xf - s_px[k], dy = yf - s_py[k];
-        if (fabsf(dx) > s_rx[k] || fabsf(dy) > s_ry[k]) continue;  // rasterize_points.cu:92
-        const float q = s_a[k] * dx * dx + s_b[k] * dx * dy + s_c[k] * dy * dy;  // :94
-        if (q > s_cut[k]) continue;                                              // :96
-        const float pz = s_pz[k];
-        const int id = s_id[k];
-        if (pz < wz || (pz == wz && id < wi)) {
-          best.push(pz, id, q, K);
-#pragma unroll
-          for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wz = best.z[j]; wi = best.id[j]; }
+  } else {
+  for (int c0 = c_begin; c0 < cnt; c0 += 256) {
+      const int m = min(256, cnt - c0);
+      __syncthreads();
+      bool hit_band[4] = {false, false, false, false};
+      if ((int)threadIdx.x < m) {
+        const int p = pairs[off + c0 + threadIdx.x];
+        const float py = pts[(int64_t)p * 3 + 1], ry = radii[(int64_t)p * 2 + 1];
+        s_px[threadIdx.x] = pts[(int64_t)p * 3];
+        s_py[threadIdx.x] = py;
+        s_pz[threadIdx.x] = pts[(int64_t)p * 3 + 2];
+        s_a[threadIdx.x] = ellipse[(int64_t)p * 3];
+        s_b[threadIdx.x] = ellipse[(int64_t)p * 3 + 1];
+        s_c[threadIdx.x] = ellipse[(int64_t)p * 3 + 2];
+        s_rx[threadIdx.x] = radii[(int64_t)p * 2];
+        s_ry[threadIdx.x] = ry;
+        s_cut[threadIdx.x] = cutoff[p];
+        s_id[threadIdx.x] = p;
+        const float ylo = py - ry * 1.000001f - 1.0e-6f, yhi = py + ry * 1.000001f + 1.0e-6f;
+  #pragma unroll
+        for (int w = 0; w < 4; ++w) hit_band[w] = !(yhi < band_lo[w]) && !(ylo > band_hi[w]);   // NaN -> kept
+      }
+      int rank[4];
+  #pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const unsigned long long bal = __ballot(hit_band[w]);
+        rank[w] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cntw[wave][w] = __popcll(bal);
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (hit_band[w]) {
+          int base = 0;
+  #pragma unroll
+          for (int sw = 0; sw < 4; ++sw) base += (sw < wave) ? s_cntw[sw][w] : 0;
+          s_list[w][base + rank[w]] = (short)threadIdx.x;
+        }
+      }
+      const int mine = s_cntw[0][wave] + s_cntw[1][wave] + s_cntw[2][wave] + s_cntw[3][wave];
+      __syncthreads();
+      if (inside) {
+        for (int i = 0; i < mine; ++i) {
+          const int k = s_list[wave][i];
+          const float dx = xf - s_px[k], dy = yf - s_py[k];
+          if (fabsf(dx) > s_rx[k] || fabsf(dy) > s_ry[k]) continue;  // rasterize_points.cu:92
+          const float q = s_a[k] * dx * dx + s_b[k] * dx * dy + s_c[k] * dy * dy;  // :94
+          if (q > s_cut[k]) continue;                                              // :96
+          const float pz = s_pz[k];
+          const int id = s_id[k];
+          if (pz < wz || (pz == wz && id < wi)) {
+            best.push(pz, id, q, K);
+  #pragma unroll
+            for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wz = best.z[j]; wi = best.id[j]; }
+          }
         }
       }
     }
@@ -1484,6 +1581,13 @@ extern "C" int64_t iso_splat_forward_workspace_bytes(int64_t n_tiles, int points
   return 64 + 32 * n_tiles + slots * (16 + (int64_t)3 * KM * 256 * 4);
 }
 
+// ISO_RASTER_CP=0 in the environment selects the first form of the hit distribution (k_raster)
+static bool raster_cp() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ISO_RASTER_CP"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 static int splat_forward_impl(CompositeArgs ca, const float* points, const float* ellipse, const float* cutoff,
                                  const float* radii, const int64_t* first_idx,
                                  const int64_t* num_pts, int n_clouds, int64_t max_pts,
@@ -1546,9 +1650,14 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
                        tile_cursor);
   }
 #define ISO_LAUNCH_R(KM_)                                                                            \
-  hipLaunchKernelGGL(k_raster<KM_>, dim3(tiles + max_slots), dim3(256), 0, s, points, ellipse, cutoff, radii, \
-                     tile_cursor, items, counters, scratch, tile_off, pairs, pair_capacity, F,                \
-                     K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);             \
+  if (raster_cp())                                                                                   \
+    hipLaunchKernelGGL((k_raster<KM_, true>), dim3(tiles + max_slots), dim3(256), 0, s, points, ellipse, cutoff, radii, \
+                       tile_cursor, items, counters, scratch, tile_off, pairs, pair_capacity, F,                \
+                       K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);             \
+  else                                                                                               \
+    hipLaunchKernelGGL((k_raster<KM_, false>), dim3(tiles + max_slots), dim3(256), 0, s, points, ellipse, cutoff, radii, \
+                       tile_cursor, items, counters, scratch, tile_off, pairs, pair_capacity, F,                \
+                       K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);             \
   if (items)                                                                                          \
     hipLaunchKernelGGL(k_raster_merge<KM_>, dim3(tiles < 1024 ? tiles : 1024), dim3(256), 0, s, heavy, counters, scratch, \
                        F, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca)
