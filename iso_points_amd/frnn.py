@@ -24,6 +24,10 @@ MAX_RES = 256                      # ISO_GRID_MAX_RES
 def grid_max_res(p2):
     """Cells per axis the dense grid may use: 128 is plenty below ~250 k points, a 1 M-point
     surface wants 256 (4x fewer candidates per query); the arrays are (max_res+1)^3 ints."""
+    if p2 <= 2048:
+        return 16                     # 4 913 cells: small clouds (ray batches, tests) do not pay for a 2 M-cell table
+    if p2 <= 32768:
+        return 48
     if p2 <= 262144:
         return 128
     return 192 if p2 <= 655360 else MAX_RES

@@ -99,6 +99,14 @@ def get_tensor_values(tensor, p, grid_sample=True, mode="bilinear", with_mask=Fa
     B, C, H, W = tensor.shape
     if not grid_sample:
         assert H == W                                               # :358
+    if grid_sample and (tensor.requires_grad or p.requires_grad):
+        # a caller that differentiates through the lookup gets the reference's own differentiable op (on the GPU)
+        out = torch.nn.functional.grid_sample(tensor, p.unsqueeze(1), mode=mode, padding_mode="reflection",
+                                              align_corners=False).squeeze(2).permute(0, 2, 1)
+        keep = torch.isfinite(out) if with_mask else None
+        if squeeze_channel_dim:
+            out, keep = out.squeeze(-1), (keep.squeeze(-1) if with_mask else None)
+        return (out, keep) if with_mask else out
     img = tensor.detach().float().contiguous()
     pts = p.detach().float().contiguous()
     assert pts.shape[0] == B and pts.shape[-1] == 2 and pts.dim() == 3
