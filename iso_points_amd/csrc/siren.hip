@@ -336,11 +336,22 @@ extern "C" int64_t iso_project_siren_workspace_bytes(int64_t n, int hidden, int 
   return stash_floats_any(hidden, n_hidden) * 4 + 2 * n * 4 + 64 * 4 + 64;
 }
 
-constexpr int64_t kSmallListMax = 8192;     // 256 tiles of 32 points: one round of the persistent grid
 static bool siren_small_tiles_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("ISO_SIREN_SMALL_TILES"); v = (e && e[0] == '0') ? 0 : 1; }
   return v == 1;
+}
+
+// One evaluation of a list whose length only the device knows: for the H = 256 gradient kernels the list is cut at
+// siren_split_point into a 96-point-tile launch and a 32-point-tile launch (per-point results do not depend on the
+// tile shape); everything else is one launch.
+static int run_step_split(SirenArgs a, int hidden, int64_t n, hipStream_t s) {
+  const bool split = hidden == 256 && !a.fwd_only && use_x3(hidden, a.L) && siren_small_tiles_enabled();
+  a.small_tiles = 0; a.split = split ? 1 : 0;
+  int rc = run_step(a, hidden, n, s);
+  if (rc != 0 || !split) return rc;
+  a.small_tiles = 1; a.split = 2;
+  return run_step(a, hidden, n, s);
 }
 
 // The iteration driver shared by the Newton projection and sphere tracing: launch `it` evaluates
@@ -359,15 +370,7 @@ static int run_iterations(SirenArgs a, int hidden, int64_t n, int max_iters, voi
     a.idx_out = (it & 1) ? idxB : idxA;
     a.count_out = counts + it + 1;
     a.do_move = (it < max_iters) ? 1 : 0;
-    // from the third launch on (the list has usually shrunk) both tile shapes are issued; the device-side
-    // count decides which one works (per-point results do not depend on the shape)
-    const bool both = it >= 2 && hidden == 256 && !a.fwd_only && use_x3(hidden, a.L) && siren_small_tiles_enabled();
-    a.small_tiles = 0; a.cnt_lo = both ? kSmallListMax : -1; a.cnt_hi = INT64_MAX;
-    ISO_REQUIRE(run_step(a, hidden, n, s) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size %d", who, hidden);
-    if (both) {
-      a.small_tiles = 1; a.cnt_lo = -1; a.cnt_hi = kSmallListMax;
-      ISO_REQUIRE(run_step(a, hidden, n, s) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size %d", who, hidden);
-    }
+    ISO_REQUIRE(run_step_split(a, hidden, n, s) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size %d", who, hidden);
   }
   return ISO_OK;
 }
@@ -454,7 +457,7 @@ extern "C" int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_
   a.packed = packed; a.stash = (float*)workspace; a.n = n; a.L = n_hidden;
   a.w0 = omega_first; a.wh = omega_hidden; a.tol = 0.f; a.do_move = 0; a.eval_only = 1;
   a.fwd_only = grad_out ? 0 : 1;       // value only: forward sweep only where the kernel has one
-  ISO_REQUIRE(run_step(a, hidden, n, (hipStream_t)stream) == 0, ISO_ERR_UNSUPPORTED,
+  ISO_REQUIRE(run_step_split(a, hidden, n, (hipStream_t)stream) == 0, ISO_ERR_UNSUPPORTED,
               "iso_siren_sdf_grad: unsupported hidden size %d", hidden);
   ISO_CHECK_LAUNCH("iso_siren_sdf_grad");
   return ISO_OK;

@@ -29,7 +29,21 @@ struct SirenArgs {
   // (a short list costs one tile time per launch whatever its length: 54 us against 25 us)
   int64_t cnt_lo = -1, cnt_hi = INT64_MAX;
   int small_tiles = 0;
+  // split != 0 (H = 256 step kernels): the list is served by TWO launches, 96-point tiles for the slots
+  // [0, siren_split_point(count)) (split = 1) and 32-point tiles for the rest (split = 2), so that the last, partly
+  // filled round of the persistent grid costs a 32-point tile time instead of a 96-point one
+  int split = 0;
 };
+
+// Slots served by the 96-point-tile launch of a split list.  A round of the persistent grid is 256 tiles: 24 576
+// points in 71 us (96-point tiles) or 8 192 points in 25 us (32-point tiles); the remainder after the full rounds goes
+// to the small tiles when it fits two of their rounds, else it gets one more round of the large ones.
+__host__ __device__ inline int64_t siren_split_point(int64_t count) {
+  const int64_t big = 256 * 96, small = 256 * 32;
+  const int64_t full = count / big * big, rem = count - full;
+  if (rem == 0) return count;
+  return (rem + small - 1) / small <= 2 ? full : count;
+}
 
 // ---- packed weight buffer, f32 section (siren.hip) ---------------------------------------
 // [W0img 4*H][WLimg H][bL,pad 4][ per hidden layer: bias H | FW H*H | BW H*H ]

@@ -252,9 +252,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   u32x4 A[4][TW][3];                     // weight-fragment pipeline, carried across stages
   x3_prefetch_a<TW, NTO, FP>(A, fwd_img(0), 0, lane);
 
-  const int64_t count = a.count_in ? (int64_t)(*a.count_in) : a.n;
-  if (count <= a.cnt_lo || count > a.cnt_hi) return;       // the other tile shape serves this list (uniform)
-  const int64_t n_tiles = (count + P - 1) / P;
+  const int64_t total = a.count_in ? (int64_t)(*a.count_in) : a.n;
+  if (total <= a.cnt_lo || total > a.cnt_hi) return;       // the other tile shape serves this list (uniform)
+  // this launch's share of the list: slots [slot0, count)  (SirenArgs::split)
+  const int64_t cut = a.split ? siren_split_point(total) : total;
+  const int64_t slot0 = a.split == 2 ? cut : 0;
+  const int64_t count = a.split == 1 ? cut : total;
+  const int64_t n_tiles = (count - slot0 + P - 1) / P;
 #ifdef X3_DBG_TIMES
   long long* dbg = reinterpret_cast<long long*>(a.stash + (int64_t)gridDim.x * S::kStashPerWg(L)) - NW * 128;
 #endif
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     asm volatile("" : "+v"(j_e));
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-      const int64_t slot = tile * P + 32 * n + j_e;
+      const int64_t slot = slot0 + tile * P + 32 * n + j_e;
       px[n] = py[n] = pz[n] = 0.f;
       if (slot < count) {
         const int64_t idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     int tid_e = tid, lane_e = lane;
     asm volatile("" : "+v"(tid_e), "+v"(lane_e));
     {
-      const int64_t slot = tile * P + tid_e;
+      const int64_t slot = slot0 + tile * P + tid_e;
       if (tid_e < P && slot < count) {
         f32x4 r = red[tid_e];
 #pragma unroll
