@@ -1983,7 +1983,7 @@ __global__ void k_z_finish_rows(const long long* __restrict__ acc, const ZScale*
 // by iso_splat_front into one buffer; counts (world, 8) = the ranks' num_points per view.
 __global__ __launch_bounds__(256) void k_repack_records(const float* __restrict__ gathered, int64_t cap, int world,
                                                         int n_views, const int32_t* __restrict__ counts, float cutoffC,
-                                                        float* __restrict__ ndc, float* __restrict__ ellipse,
+                                                        int64_t max_rows, float* __restrict__ ndc, float* __restrict__ ellipse,
                                                         float* __restrict__ cutoff, float* __restrict__ radii,
                                                         float* __restrict__ scaler, float* __restrict__ feat) {
   const int s = blockIdx.y, v = blockIdx.z;
@@ -1996,6 +1996,7 @@ __global__ __launch_bounds__(256) void k_repack_records(const float* __restrict_
     }
   int64_t n = counts[s * 8 + v];
   if (l0 + n > cap) n = cap > l0 ? cap - l0 : 0;      // the sender's buffer overflowed (flagged by the host side)
+  if (g0 + n > max_rows) n = max_rows > g0 ? max_rows - g0 : 0;   // ... and so the packed arrays would
   const float* blk = gathered + (int64_t)s * 12 * cap;
   // every field of the (view, rank) block is one contiguous run in both layouts: flat, coalesced copies
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
@@ -2012,18 +2013,19 @@ __global__ __launch_bounds__(256) void k_repack_records(const float* __restrict_
 }
 
 // first_idx / num_points of the global packed layout and of this rank's own rows in it
-__global__ void k_repack_offsets(const int32_t* __restrict__ counts, int world, int n_views, int rank,
+__global__ void k_repack_offsets(const int32_t* __restrict__ counts, int world, int n_views, int rank, int64_t max_rows,
                                  int64_t* __restrict__ first_g, int64_t* __restrict__ num_g,
                                  int64_t* __restrict__ first_own, int64_t* __restrict__ num_own) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int64_t run = 0;
   for (int v = 0; v < n_views; ++v) {
-    first_g[v] = run;
+    first_g[v] = run < max_rows ? run : max_rows;
     for (int s = 0; s < world; ++s) {
-      if (s == rank) { first_own[v] = run; num_own[v] = counts[s * 8 + v]; }
-      run += counts[s * 8 + v];
+      const int64_t c = counts[s * 8 + v];
+      if (s == rank) { first_own[v] = run < max_rows ? run : max_rows; num_own[v] = run + c <= max_rows ? c : (max_rows > run ? max_rows - run : 0); }
+      run += c;
     }
-    num_g[v] = run - first_g[v];
+    num_g[v] = (run < max_rows ? run : max_rows) - first_g[v];      // rows beyond max_rows do not exist (overflow: flagged)
   }
 }
 }  // namespace
@@ -2049,11 +2051,11 @@ extern "C" int iso_splat_repack(const float* gathered, int64_t capacity, int wor
                   first_idx_out && num_pts_out && own_first_out && own_num_out,
               ISO_ERR_INVALID, "iso_splat_repack: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_repack_offsets, dim3(1), dim3(64), 0, s, counts, world, n_views, rank, first_idx_out, num_pts_out,
-                     own_first_out, own_num_out);
+  hipLaunchKernelGGL(k_repack_offsets, dim3(1), dim3(64), 0, s, counts, world, n_views, rank, max_rows, first_idx_out,
+                     num_pts_out, own_first_out, own_num_out);
   int gx = iso_div_up(max_rows > 0 ? 3 * max_rows / (world * n_views) + 1 : 1, 256); if (gx > 256) gx = 256;
   hipLaunchKernelGGL(k_repack_records, dim3(gx, world, n_views), dim3(256), 0, s, gathered, capacity, world, n_views, counts,
-                     cutoff, ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out, features_out);
+                     cutoff, max_rows, ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out, features_out);
   ISO_CHECK_LAUNCH("iso_splat_repack");
   return ISO_OK;
 }

@@ -249,7 +249,7 @@ class IsoCycle(object):
             fr["own_first"], fr["own_num"], fr["max_pts"], fr["rows"] = fr["first_idx"], fr["num_points"], self.P, self.rec_cap
             return fr
         gathered = yield ("all_gather", self.wire)
-        rows = N * self.P
+        rows = min(N * self.P, w * self.rec_cap)              # every rank sends at most rec_cap rows
         dev = self.dev
         out = {k: torch.empty((rows, c) if c > 1 else (rows,), dtype=torch.float32, device=dev)
                for k, c in (("ndc", 3), ("ellipse_params", 3), ("cutoff_threshold", 1), ("radii", 2), ("scaler", 1),

@@ -129,7 +129,8 @@ def test_calibrated_capacities(dev):
     again = run_lockstep(ranks)
     for c, a, b in zip(ranks, base, again):
         c.check(b[4])
-        assert torch.equal(a[0].points, b[0].points) and torch.equal(a[2], b[2]) and torch.equal(a[3].idx, b[3].idx)
+        m = min(a[2].shape[0], b[2].shape[0])            # the packed arrays are sized by the record capacity
+        assert torch.equal(a[0].points, b[0].points) and torch.equal(a[2][:m], b[2][:m]) and torch.equal(a[3].idx, b[3].idx)
     # a capacity that is too small is reported, not silently dropped
     for c in ranks:
         c.halo_cap = 16
