@@ -151,9 +151,10 @@ class IsoCycle(object):
         self._pool = None
         # capacities (rows / records); `calibrate` shrinks them to what the workload needs
         w = self.world
-        self.halo_cap = 0 if w == 1 else max(4096, self.n_own)            # worst case: every own point is exported
-        self.import_cap = 0 if w == 1 else max(4096, self.P - self.n_own)  # worst case: everybody else's points
-        self.rec_cap = max(self.N * self.n_own, 1)
+        own_max = (self.P + w - 1) // w                                   # the same on every rank (buffers are gathered)
+        self.halo_cap = 0 if w == 1 else max(4096, own_max)               # worst case: every own point is exported
+        self.import_cap = 0 if w == 1 else max(4096, self.P - self.P // w)  # worst case: everybody else's points
+        self.rec_cap = max(self.N * own_max, 1)
         self.pair_cap = max(1 << 16, 6 * self.N * self.P // w)
         self.halo_cells = 2           # exchanged band of the resample grid, in fine cells (2 x 0.8 r covers the radius r)
         self.halo_cells_h = 4         # ... of the bandwidth grid: its K = 7 search has no useful radius bound (r = 0.2);

@@ -40,7 +40,7 @@ def _models(dev, kind):
 
 @pytest.mark.parametrize("world,P,S,N,kind", [(2, 20000, 64, 2, "sphere"), (4, 60000, 128, 4, "sphere"),
                                               (8, 200000, 256, 4, "sphere"), (3, 30000, 96, 3, "siren"),
-                                              (8, 9000, 64, 1, "sphere")])
+                                              (8, 9000, 64, 1, "sphere"), (3, 20011, 64, 2, "sphere")])
 def test_lockstep_ranks_equal_single_gpu(dev, world, P, S, N, kind):
     from iso_points_amd.dist import IsoCycle, run_lockstep, shard_bounds, slab_order
     pts, views, projs, rs, target = _scene(dev, P, S, N)
@@ -62,6 +62,9 @@ def test_lockstep_ranks_equal_single_gpu(dev, world, P, S, N, kind):
         assert torch.equal(q1.normals[0], r1.normals[0, lo:hi]) and torch.equal(q1.mask[0], r1.mask[0, lo:hi])
         # the global packed layout every rank rebuilt = the single-GPU one
         assert torch.equal(qfr["first_idx"], fr["first_idx"]) and torch.equal(qfr["num_points"], fr["num_points"])
+        seen = ((fr["mask"][None, lo:hi] >> torch.arange(N, device=dev)[:, None]) & 1).bool()      # h exists where the point is rendered
+        assert torch.equal(qfr["mask"], fr["mask"][lo:hi]) and torch.equal(qfr["h"][seen], fr["h"][:, lo:hi][seen]), \
+            "rank %d: bandwidths differ" % r
         for k in ("ndc", "ellipse_params", "radii", "scaler", "features"):
             assert torch.equal(qfr[k][:tot], fr[k][:tot]), "rank %d: packed %s differs" % (r, k)
         y0, y1 = c.band_rows()
