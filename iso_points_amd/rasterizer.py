@@ -476,10 +476,28 @@ class SurfaceSplatting(object):
                 "features": feat, "src": src, "first_idx": first, "num_points": num, "view_total": view_total,
                 "mask": mask, "h": h, "wire": out, "capacity": cap}
 
-    def forward(self, points, normals, cameras=None, features=None):
+    @staticmethod
+    def _camera_matrices(cameras):
+        """(views, projs) from a tuple of (N,4,4) tensors or from a pytorch3d-style camera object
+        (get_world_to_view_transform() / get_full_projection_transform(), each with get_matrix(): the two
+        matrices the reference reads, rasterizer.py:139,189,463-464)."""
+        if isinstance(cameras, (tuple, list)):
+            return cameras
+        return (cameras.get_world_to_view_transform().get_matrix(), cameras.get_full_projection_transform().get_matrix())
+
+    def forward(self, points, normals=None, cameras=None, features=None):
         """points/normals (P,3) one cloud seen by N cameras (the reference extends the cloud to the
-        number of cameras, :597-598).  Returns (PointFragments, filtered dict)."""
-        views, projs = cameras or self.cameras
+        number of cameras, :597-598), or a Pointclouds-like container of ONE cloud (points_packed(),
+        normals_packed(), optionally features_packed()).  cameras: (views, projs) or a pytorch3d-style
+        camera object.  Returns (PointFragments, filtered dict)."""
+        if hasattr(points, "points_packed"):
+            cloud = points
+            if len(cloud) != 1:
+                raise NotImplementedError("SurfaceSplatting.forward: one cloud per call (it is extended to the cameras)")
+            points, normals = cloud.points_packed(), cloud.normals_packed()
+            if features is None and hasattr(cloud, "features_packed"):
+                features = cloud.features_packed()
+        views, projs = self._camera_matrices(cameras if cameras is not None else self.cameras)
         rs = self.raster_settings
         pts, nrm = _f32c(points.detach()), _f32c(normals.detach())
         P, N = pts.shape[0], views.shape[0]

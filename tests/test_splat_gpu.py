@@ -483,3 +483,34 @@ def test_gradient_reaches_the_world_points(dev):
     unseen = torch.ones(P, dtype=torch.bool, device=dev)
     unseen[src] = False
     assert (x.grad[unseen] == 0).all()
+
+
+@pytest.mark.gpu
+def test_forward_accepts_the_reference_containers(dev):
+    """SurfaceSplatting.forward(point_clouds, cameras=...) with a Pointclouds-like cloud and a pytorch3d-style camera
+    object (rasterizer.py:584-600) = the tensor form."""
+    from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    SO = _SO()
+    P, S = 3000, 48
+    pts = torch.nn.functional.normalize(torch.randn(P, 3, generator=torch.Generator().manual_seed(2)), dim=-1).to(dev)
+    views = torch.stack([SO.look_at_view(3.0, 10.0, 70.0 * i) for i in range(2)]).to(dev)
+    projs = views @ SO.perspective(30.0).to(dev)
+
+    class _T(object):
+        def __init__(s, m): s.m = m
+        def get_matrix(s): return s.m
+
+    class Cams(object):
+        def get_world_to_view_transform(s): return _T(views)
+        def get_full_projection_transform(s): return _T(projs)
+
+    class Cloud(object):
+        def __len__(s): return 1
+        def points_packed(s): return pts
+        def normals_packed(s): return pts
+
+    ss = SurfaceSplatting(cameras=Cams(), raster_settings=PointsRasterizationSettings(image_size=S, points_per_pixel=4))
+    a, _ = ss.forward(Cloud())
+    b, _ = ss.forward(pts, pts, cameras=(views, projs))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
