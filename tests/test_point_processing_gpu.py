@@ -197,3 +197,34 @@ def test_denoise_normals_golden(dev, K):
     assert out.shape == g["out"].shape and rel_err(out, g["out"]) < 1e-5
     with pytest.raises(NotImplementedError):
         denoise_normals(torch.cat([g["points"], g["points"]]).to(dev), torch.cat([g["normals"], g["normals"]]).to(dev))
+
+
+def test_insert_batch_of_ragged_clouds(dev):
+    """insert() on a batch: cloud 0 = the golden cloud, cloud 1 = its first 700 points (padded): cloud 0's children are
+    the golden's, each cloud's children follow from its own valid points only (levelset_sampling.py:172-233)."""
+    from iso_points_amd.levelset_sampling import UniformProjection, with_host_lengths
+    g = load("insert.npz")
+
+    class Ref(object):
+        def __init__(s):
+            s.p, s.f = g["ref_points"].to(dev), g["ref_metrics"].to(dev)
+        def points_packed(s): return s.p
+        def features_packed(s): return s.f
+        def num_points_per_cloud(s): return torch.tensor([s.p.shape[0]], device=dev)
+        def __len__(s): return 1
+
+    one = g["points"].to(dev)                                      # (1,P,3)
+    P = one.shape[1]
+    two = torch.cat([one, one.clone()], dim=0)
+    two[1, 700:] = 0
+    lens = with_host_lengths(torch.tensor([P, 700], dtype=torch.int64, device=dev), [P, 700])
+    proj = UniformProjection(knn_k=8)
+    grown, n_after, child, cpb = proj.insert(Ref(), two, lens)
+    assert int(cpb[0]) == int(g["child_per_batch"][0]) and rel_err(child[0, :int(cpb[0])], g["child_pts"][0]) < 1e-6
+    # cloud 1 alone (same bounding box: the padding rows are zeros inside it)
+    solo = two[1:2].clone()
+    _, _, child1, cpb1 = proj.insert(Ref(), torch.cat([solo, solo]), with_host_lengths(
+        torch.tensor([700, 700], dtype=torch.int64, device=dev), [700, 700]))
+    assert int(cpb[1]) == int(cpb1[0]) == int(cpb1[1]) and int(cpb[1]) % 8 == 0
+    assert torch.equal(child1[0], child1[1])
+    assert grown.shape[1] == P + child.shape[1] and n_after.tolist() == [P + int(cpb[0]), 700 + int(cpb[1])]
