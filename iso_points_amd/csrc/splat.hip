@@ -405,7 +405,7 @@ __global__ void k_bin(const float* __restrict__ pts, const float* __restrict__ r
 // a workgroup walks kBinChunk consecutive points, counts them per tile in LDS, reserves one range per
 // touched tile with a single global atomic and (FILL) hands out the slots from LDS.  The hot tiles on
 // a silhouette otherwise take thousands of same-address global atomics.
-constexpr int kBinChunk = 8192;
+constexpr int kBinChunk = 2048;      // rows per workgroup: 8 per thread -- with 8192 a 512^2 x 4 job was 245 workgroups of 32 sequential rows per thread, latency bound
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin_lds(const float* __restrict__ pts, const float* __restrict__ radii,
                                                  const int64_t* __restrict__ first, const int64_t* __restrict__ num,

@@ -3,6 +3,9 @@ usage: python tools/cycle_only.py [steps]"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from iso_points_amd import _lib
+if os.environ.get("ISO_DEV_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["ISO_DEV_LIB"])
 import bench
 from iso_points_amd.dist import Comm
 from iso_points_amd.sdf_models import SphereSDF
