@@ -312,43 +312,72 @@ __global__ __launch_bounds__(256) void k_splat_front(const float* __restrict__ p
   for (int v = 0; v < 8; ++v)
     if (v < n_views)
       for (int k = 0; k < w; ++k) rank[v] += s_w[v][k];
-  if ((m[0] | m[1] | m[2] | m[3]) == 0) return;
+  // The rows of a chunk in one view are contiguous in the packed arrays: they are staged in LDS view by view and
+  // written out as full lines (a lane storing its own 12-byte rows touches every 128-byte line three times: 350 MB
+  // of partial writes for 168 MB of records at 1 M points x 4 views).
+  __shared__ float s_ndc[kChunk * 3], s_el[kChunk * 3], s_rad[kChunk * 2], s_sc[kChunk], s_ft[kChunk * 3];
+  __shared__ int s_src[kChunk];
+  const bool any = (m[0] | m[1] | m[2] | m[3]) != 0;
+  float x[4], y[4], z[4], nx[4], ny[4], nz[4], f[4][3];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    x[k] = y[k] = z[k] = nx[k] = ny[k] = nz[k] = 0.f;
+    f[k][0] = f[k][1] = f[k][2] = 0.f;
     if (!m[k]) continue;
     const int64_t i = i0 + k;
-    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
-    const float nx = nrm[i * 3], ny = nrm[i * 3 + 1], nz = nrm[i * 3 + 2];
-    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (o.feat) {
-      if (feat_from_normal) {                       // 0.5 (normalize(n) + 1): the cycle's shading-free features
-        float nn = sqrtf((nx * nx + ny * ny) + nz * nz);
-        nn = nn > 1e-12f ? nn : 1e-12f;
-        f[0] = 0.5f * (nx / nn + 1.0f); f[1] = 0.5f * (ny / nn + 1.0f); f[2] = 0.5f * (nz / nn + 1.0f);
-      } else {
+    x[k] = pts[i * 3]; y[k] = pts[i * 3 + 1]; z[k] = pts[i * 3 + 2];
+    nx[k] = nrm[i * 3]; ny[k] = nrm[i * 3 + 1]; nz[k] = nrm[i * 3 + 2];
+    if (o.feat && feat_from_normal) {               // 0.5 (normalize(n) + 1): the cycle's shading-free features
+      float nn = sqrtf((nx[k] * nx[k] + ny[k] * ny[k]) + nz[k] * nz[k]);
+      nn = nn > 1e-12f ? nn : 1e-12f;
+      f[k][0] = 0.5f * (nx[k] / nn + 1.0f); f[k][1] = 0.5f * (ny[k] / nn + 1.0f); f[k][2] = 0.5f * (nz[k] / nn + 1.0f);
+    } else if (o.feat && C <= 3) {
+      for (int c = 0; c < C; ++c) f[k][c] = feat_in[i * C + c];
+    }
+  }
+  const bool stage_feat = o.feat && C <= 3;         // wider feature rows are written directly
+  const int Cs = C;
+  for (int v = 0; v < n_views; ++v) {
+    const int cnt = s_w[v][0] + s_w[v][1] + s_w[v][2] + s_w[v][3];
+    if (cnt == 0) continue;                                                      // workgroup-uniform
+    const int64_t p0 = first[v] + chunk_off[(int64_t)v * n_chunks + blockIdx.x];
+    int lr = 0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) if (c < C) f[c] = feat_in[i * C + c];
+    for (int q = 0; q < 8; ++q) if (q == v) lr = rank[q];
+    if (any) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!((m[k] >> v) & 1)) continue;
+        const int64_t i = i0 + k;
+        const SetupRes r = splat_setup_point(x[k], y[k], z[k], nx[k], ny[k], nz[k], h[(int64_t)v * P + i], views + v * 16,
+                                             projs + v * 16, S, sigma, cutoffC);
+        s_ndc[lr * 3] = r.ndc[0]; s_ndc[lr * 3 + 1] = r.ndc[1]; s_ndc[lr * 3 + 2] = r.ndc[2];
+        s_el[lr * 3] = r.el[0]; s_el[lr * 3 + 1] = r.el[1]; s_el[lr * 3 + 2] = r.el[2];
+        s_rad[lr * 2] = r.rad[0]; s_rad[lr * 2 + 1] = r.rad[1];
+        s_sc[lr] = r.scaler;
+        s_src[lr] = (int32_t)i;
+        if (stage_feat)
+          for (int c = 0; c < Cs; ++c) s_ft[lr * Cs + c] = f[k][c];
+        else if (o.feat)
+          for (int c = 0; c < C; ++c)
+            o.feat[(p0 + lr) * C + c] = feat_from_normal ? (c < 3 ? f[k][c] : 0.f) : feat_in[i * C + c];
+        ++lr;
       }
     }
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      if (v < n_views && ((m[k] >> v) & 1)) {
-        const int64_t p = first[v] + chunk_off[(int64_t)v * n_chunks + blockIdx.x] + rank[v];
-        ++rank[v];
-        const SetupRes r = splat_setup_point(x, y, z, nx, ny, nz, h[(int64_t)v * P + i], views + v * 16, projs + v * 16,
-                                             S, sigma, cutoffC);
-        o.ndc[p * 3] = r.ndc[0]; o.ndc[p * 3 + 1] = r.ndc[1]; o.ndc[p * 3 + 2] = r.ndc[2];
-        o.ellipse[p * 3] = r.el[0]; o.ellipse[p * 3 + 1] = r.el[1]; o.ellipse[p * 3 + 2] = r.el[2];
-        o.cutoff[p] = cutoffC;
-        o.radii[p * 2] = r.rad[0]; o.radii[p * 2 + 1] = r.rad[1];
-        o.scaler[p] = r.scaler;
-        if (o.src) o.src[p] = (int32_t)i;
-        if (o.feat) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) if (c < C) o.feat[p * C + c] = f[c];
-        }
-      }
+    __syncthreads();
+    for (int j = threadIdx.x; j < cnt * 3; j += 256) {
+      o.ndc[p0 * 3 + j] = s_ndc[j];
+      o.ellipse[p0 * 3 + j] = s_el[j];
     }
+    for (int j = threadIdx.x; j < cnt * 2; j += 256) o.radii[p0 * 2 + j] = s_rad[j];
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+      o.cutoff[p0 + j] = cutoffC;
+      o.scaler[p0 + j] = s_sc[j];
+      if (o.src) o.src[p0 + j] = s_src[j];
+    }
+    if (stage_feat)
+      for (int j = threadIdx.x; j < cnt * Cs; j += 256) o.feat[p0 * Cs + j] = s_ft[j];
+    __syncthreads();
   }
 }
 
@@ -645,7 +674,7 @@ __global__ __launch_bounds__(256) void k_raster(
       if ((int)threadIdx.x < m) {
         const int k = threadIdx.x;
         const float4 c0v = s_rec[par][k][0], c1v = s_rec[par][k][1], c2v = s_rec[par][k][2];
-        int x0, x1, y0, y1;
+        int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
         const bool any = pixel_range(c0v.x, c2v.x, F.W, F.ex, F.m, x0, x1) && pixel_range(c0v.y, c2v.y, F.H, F.ey, F.m, y0, y1);
         x0 = max(x0, tx * TILE); x1 = min(x1, tx * TILE + TILE - 1);
         y0 = max(y0, ty * TILE); y1 = min(y1, ty * TILE + TILE - 1);
@@ -1247,9 +1276,11 @@ __global__ __launch_bounds__(256) void k_splat_backward(
   }
 }
 
-// Pass 2, one WAVE per heavy point: the 8x8 blocks of the support that hold a gradient are
-// visited band by band, one pixel per lane; lane-private partial sums are combined by a
-// fixed butterfly -> bit-stable (no atomics), independent of how many waves run.
+// Pass 2, one WAVE per heavy point.  The lanes fetch the flags of the 8x8 blocks of the support together (one
+// ballot per 64 blocks), the flagged blocks are then visited four at a time, one pixel per lane, so that the
+// gradient loads of a round are in flight together (the block-by-block walk was a chain of dependent loads,
+// ~30 L2 latencies per point); lane-private partial sums in ascending block order are combined by a fixed
+// butterfly -> bit-stable (no atomics), independent of how many waves run.
 __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     const float* __restrict__ pts, const float* __restrict__ radii, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num, int n_clouds,
@@ -1258,9 +1289,10 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     int rect_mode, float radii_s, const int32_t* __restrict__ heavy,
     const int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int count = *heavy_count;
+  const int ly = lane >> 3, lx = lane & 7;
   for (int w = wave; w < count; w += nwaves) {
     const int64_t p = heavy[w];
     int n = 0;
@@ -1272,25 +1304,43 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     int x0, x1, y0, y1;
     float gx = 0.f, gy = 0.f;
     if (out_range(px, sx, F.W, F.ex, F.m, x0, x1) && out_range(py, sy, F.H, F.ey, F.m, y0, y1)) {
-      const int bx0 = x0 / GB, bx1 = x1 / GB, by0 = y0 / GB, by1 = y1 / GB;
-      const int ly = lane >> 3, lx = lane & 7;
-      // 64x64 super blocks first (one flag per 64 8x8 blocks), then the flagged 8x8 blocks inside
-      for (int sby = by0 / 8; sby <= by1 / 8; ++sby)
-        for (int sbx = bx0 / 8; sbx <= bx1 / 8; ++sbx) {
-          if (!blk2[((int64_t)n * G.NB2y + sby) * G.NB2x + sbx]) continue;         // wave-uniform
-          for (int by = max(by0, sby * 8); by <= min(by1, sby * 8 + 7); ++by) {
-            const int yo = by * GB + ly;
-            const float dy = ndc_y(F.H - 1 - yo, F) - py;
-            for (int bx = max(bx0, sbx * 8); bx <= min(bx1, sbx * 8 + 7); ++bx) {
-              if (!blk[((int64_t)n * G.NBy + by) * G.NBx + bx]) continue;           // wave-uniform
-              const int xo = bx * GB + lx;
-              if (yo < y0 || yo > y1 || xo < x0 || xo > x1) continue;
-              const float g = grad_occ[((int64_t)n * F.H + yo) * F.W + xo];
-              const float dx = ndc_x(F.W - 1 - xo, F) - px;
-              occ_term(g, dx, dy, rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
+      const int bx0 = x0 / GB, by0 = y0 / GB;
+      const int nbx = x1 / GB - bx0 + 1, nb = nbx * (y1 / GB - by0 + 1);
+      const float* __restrict__ gimg = grad_occ + (int64_t)n * F.H * F.W;
+      const uint8_t* __restrict__ flags = blk + (int64_t)n * G.NBy * G.NBx;
+      for (int c0 = 0; c0 < nb; c0 += 64) {
+        // lane c: block (bx0 + c % nbx, by0 + c / nbx) of the support, packed as by * 256 + bx (sides <= 2048)
+        const int c = c0 + lane;
+        int mine = 0;
+        bool flagged = false;
+        if (c < nb) {
+          const int by = by0 + c / nbx, bx = bx0 + c % nbx;
+          mine = by * 256 + bx;
+          flagged = flags[by * G.NBx + bx] != 0;
+        }
+        unsigned long long todo = __ballot(flagged);
+        while (todo) {
+          float g[4], dx[4], dy[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            g[u] = 0.f; dx[u] = 0.f; dy[u] = 0.f;
+            if (todo) {                                                   // wave-uniform
+              const int src = __ffsll((long long)todo) - 1;
+              todo &= todo - 1;
+              const int b = __builtin_amdgcn_readlane(mine, src);
+              const int yo = (b >> 8) * GB + ly, xo = (b & 255) * GB + lx;
+              if (yo >= y0 && yo <= y1 && xo >= x0 && xo <= x1) {
+                g[u] = gimg[(int64_t)yo * F.W + xo];
+                dx[u] = ndc_x(F.W - 1 - xo, F) - px;
+                dy[u] = ndc_y(F.H - 1 - yo, F) - py;
+              }
             }
           }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            occ_term(g[u], dx[u], dy[u], rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
         }
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
