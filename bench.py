@@ -89,7 +89,10 @@ class Cycle(object):
         views, projs = cameras(device)
         from iso_points_amd.dist import slab_order
         pts0 = sphere_cloud(P_TOTAL, seed=0, device=device)          # identical on every rank
-        pts0 = pts0[:, slab_order(pts0[0], comm.world)].contiguous()  # N ranks: the job's point order is x-slab major
+        # the job's point order: x-slab major, z-order curve inside a slab (one sort at set-up; ISO_BENCH_ORDER=x
+        # keeps the generator's order inside a slab, for A/B measurements)
+        local = None if os.environ.get("ISO_BENCH_ORDER", "cell") == "x" else "cell"
+        pts0 = pts0[:, slab_order(pts0[0], comm.world, local=local)].contiguous()
         self.cyc = IsoCycle(model, pts0, views, projs, raster_settings=rs, knn_k=8, comm=comm,
                             target=sphere_silhouette(IMAGE, VIEWS, 3.0, 30.0, device))
         if comm.world > 1:

@@ -129,14 +129,54 @@ __device__ __forceinline__ int brick_key(const BrickHdr& h, float x, float y, fl
   return b * 8 + ((fx >> 1) & 1) * 4 + ((fy >> 1) & 1) * 2 + ((fz >> 1) & 1);
 }
 
-// own points (packed (n,3) f32): arrival slot inside the brick
+// own points (packed (n,3) f32): arrival slot inside the brick.  A workgroup first counts its 1024 points per
+// brick in an LDS hash table and then reserves each brick's range with ONE returning global atomic (a point
+// order with any spatial coherence -- the cycle's clouds are x-slab sorted -- puts several of a round's points in
+// the same brick; one returning atomic per point was the whole cost of this kernel).  All points of a workgroup
+// use the same one of the brick's eight counters (which one is free: the records of a brick are the union of its
+// eight ranges), so that workgroups still spread over eight addresses per brick.  slot = rank | counter << 28;
+// a point that finds no table entry within kCntProbe probes takes its rank from global memory directly.
+constexpr int kCntTab = 2048, kCntProbe = 16;
+
 __global__ __launch_bounds__(256) void k_brick_count(const float* __restrict__ pts, int64_t n,
                                                      const BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
                                                      int32_t* __restrict__ slot) {
+  __shared__ int t_key[kCntTab], t_cnt[kCntTab];
   const BrickHdr h = *hp;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = brick_key(h, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
-    slot[i] = atomicAdd(&cnt[b], 1);
+  const int oct = blockIdx.x & 7;
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < n; base += (int64_t)gridDim.x * 1024) {
+    for (int j = threadIdx.x; j < kCntTab; j += 256) { t_key[j] = -1; t_cnt[j] = 0; }
+    __syncthreads();
+    int e[4], rk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = base + k * 256 + threadIdx.x;
+      e[k] = -1; rk[k] = 0;
+      if (i < n) {
+        const int key = 8 * brick_of(h, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]) + oct;
+        unsigned at = ((unsigned)key * 2654435761u) >> 21;          // 11 bits
+        bool found = false;
+        for (int t = 0; t < kCntProbe && !found; ++t) {
+          const int prev = atomicCAS(&t_key[at], -1, key);
+          if (prev == -1 || prev == key) found = true;
+          else at = (at + 1) & (kCntTab - 1);
+        }
+        if (found) { e[k] = (int)at; rk[k] = atomicAdd(&t_cnt[at], 1); }
+        else rk[k] = atomicAdd(&cnt[key], 1);
+      }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < kCntTab; j += 256) {
+      const int c = t_cnt[j];
+      if (c > 0) t_cnt[j] = atomicAdd(&cnt[t_key[j]], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = base + k * 256 + threadIdx.x;
+      if (i < n) slot[i] = ((e[k] >= 0 ? t_cnt[e[k]] : 0) + rk[k]) | (oct << 28);
+    }
+    __syncthreads();
   }
 }
 
@@ -162,7 +202,8 @@ __global__ __launch_bounds__(256) void k_brick_scatter(const float* __restrict__
   const BrickHdr h = *hp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
-    const int64_t dst = (int64_t)off[brick_key(h, x, y, z)] + slot[i];
+    const int sl = slot[i];                                           // rank | counter << 28 (k_brick_count)
+    const int64_t dst = (int64_t)off[8 * brick_of(h, x, y, z) + ((unsigned)sl >> 28)] + (sl & 0x0fffffff);
     rec0[dst] = make_float4(x, y, z, __int_as_float(h.id_base + (int)i));
     float4 u = make_float4(0.f, 0.f, 0.f, __int_as_float(payload ? payload[i] : 0));
     if (nrm) { u.x = nrm[i * 3]; u.y = nrm[i * 3 + 1]; u.z = nrm[i * 3 + 2]; }
@@ -1017,7 +1058,7 @@ extern "C" int iso_bricks_build(const float* points, const float* normals, const
                        cell_scale, w.nb_cap, w.hdr, w.counters);
   hipLaunchKernelGGL(k_bricks_zero, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, s, w.hdr, w.cnt);
   if (n_own > 0)
-    hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, n_own, w.hdr, w.cnt,
+    hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 1024)), dim3(256), 0, s, points, n_own, w.hdr, w.cnt,
                        w.slot);
   if (import_max > 0)
     hipLaunchKernelGGL(k_brick_count_recs, dim3(iso_stream_grid(import_max, 256)), dim3(256), 0, s,

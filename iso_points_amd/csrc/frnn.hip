@@ -56,15 +56,31 @@ __global__ __launch_bounds__(BLOCK) void k_bbox(const float* __restrict__ pts,
   if (len <= 0) return;
   const float* p = pts + (int64_t)n * p_stride * 3;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  // flat float index so consecutive lanes read consecutive dwords
+  // flat float index so consecutive lanes read consecutive dwords; the launcher makes the grid stride a
+  // multiple of 3 floats, so a thread stays on one coordinate axis and keeps four loads in flight
   const int64_t nfl = len * 3;
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < nfl;
-       i += (int64_t)gridDim.x * BLOCK) {
-    const float v = p[i];
-    const int a = (int)(i % 3);
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  const int64_t i_first = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (stride % 3 == 0) {
+    float lo = FLT_MAX, hi = -FLT_MAX;
+    int64_t i = i_first;
+    for (; i + 3 * stride < nfl; i += 4 * stride) {
+      const float v0 = p[i], v1 = p[i + stride], v2 = p[i + 2 * stride], v3 = p[i + 3 * stride];
+      lo = fminf(fminf(lo, v0), fminf(v1, fminf(v2, v3)));
+      hi = fmaxf(fmaxf(hi, v0), fmaxf(v1, fmaxf(v2, v3)));
+    }
+    for (; i < nfl; i += stride) { const float v = p[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+    const int a = (int)(i_first % 3);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if (a == c) { mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v); }
+    for (int c = 0; c < 3; ++c) if (a == c) { mn[c] = lo; mx[c] = hi; }
+  } else {
+    for (int64_t i = i_first; i < nfl; i += stride) {
+      const float v = p[i];
+      const int a = (int)(i % 3);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (a == c) { mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v); }
+      }
     }
   }
 #pragma unroll
@@ -733,6 +749,14 @@ __global__ void k_gather(const float* __restrict__ x,
 }  // namespace
 
 // ---------------------------------------------------------------------------
+// workgroups of k_bbox: four loads per thread and round, a stride of a multiple of 3 floats
+static int bbox_grid(int64_t p_stride) {
+  int gx = iso_div_up(p_stride * 3, 256 * 4);
+  if (gx > 255) gx = 255;              // six same-address atomics per workgroup: more workgroups cost more than they read
+  if (gx >= 3) gx -= gx % 3;
+  return gx < 1 ? 1 : gx;
+}
+
 extern "C" int iso_frnn_make_grid_density(const float* points, const int64_t* lengths,
                                           const float* radius, int n_clouds, int64_t p_stride,
                                           int max_res, float points_per_cell, float* grid_params,
@@ -749,8 +773,7 @@ extern "C" int iso_frnn_make_grid_density(const float* points, const int64_t* le
   unsigned* keys = reinterpret_cast<unsigned*>(grid_params);
   hipLaunchKernelGGL(k_bbox_init, dim3(iso_div_up(n_clouds * 8, 256)), dim3(256), 0, s, keys, n_clouds);
   if (p_stride > 0) {
-    int gx = iso_div_up(p_stride * 3, 256 * 16);
-    if (gx > 256) gx = 256;
+    int gx = bbox_grid(p_stride);
     hipLaunchKernelGGL(k_bbox<256>, dim3(gx, n_clouds), dim3(256), 0, s, points, lengths, p_stride, keys);
   }
   hipLaunchKernelGGL(k_grid_finalize, dim3(iso_div_up(n_clouds, 64)), dim3(64), 0, s,
@@ -776,8 +799,7 @@ extern "C" int iso_points_bbox(const float* points, const int64_t* lengths, int 
   unsigned* keys = reinterpret_cast<unsigned*>(minmax);
   hipLaunchKernelGGL(k_bbox_init, dim3(iso_div_up(n_clouds * 8, 256)), dim3(256), 0, s, keys, n_clouds);
   if (p_stride > 0) {
-    int gx = iso_div_up(p_stride * 3, 256 * 16);
-    if (gx > 256) gx = 256;
+    int gx = bbox_grid(p_stride);
     hipLaunchKernelGGL(k_bbox<256>, dim3(gx, n_clouds), dim3(256), 0, s, points, lengths, p_stride, keys);
   }
   hipLaunchKernelGGL(k_bbox_decode, dim3(iso_div_up(n_clouds, 64)), dim3(64), 0, s, keys, lengths,

@@ -517,6 +517,32 @@ struct PixK {
       }
     }
   }
+  // The same insertion for the (z, id) part only (the caller recomputes q for the K survivors at the end).
+  // Compares are half-rate instructions here and the swap chain above spends three per level plus six
+  // selects; this form takes one `<` and one `==` per level (the id compare only when some lane of the wave
+  // meets an equal depth), the depths move with one v_med3_f32 per level and the ids with two selects.
+  __device__ __forceinline__ void push_zi(float cz, int ci, int K) {
+    bool lt[KMAX], eq[KMAX];
+    bool tie = false;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      lt[j] = j < K && cz < z[j];
+      eq[j] = j < K && cz == z[j];
+      tie = tie || eq[j];
+    }
+    if (__any(tie)) {
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) lt[j] = lt[j] || (eq[j] && ci < id[j]);
+    }
+#pragma unroll
+    for (int j = KMAX - 1; j >= 1; --j) {
+      id[j] = lt[j - 1] ? id[j - 1] : (lt[j] ? ci : id[j]);
+      if (K == KMAX) z[j] = __builtin_amdgcn_fmed3f(z[j - 1], cz, z[j]);     // sorted list: the middle one
+      else z[j] = lt[j - 1] ? z[j - 1] : (lt[j] ? cz : z[j]);
+    }
+    id[0] = lt[0] ? ci : id[0];
+    z[0] = lt[0] ? cz : z[0];
+  }
 };
 
 struct Cand {  // one LDS record per candidate (SoA in LDS)
@@ -653,14 +679,19 @@ __global__ __launch_bounds__(256) void k_raster(
         const float4 c2v = s_rec[par][k][2];
         if (fabsf(dx) > c2v.x || fabsf(dy) > c2v.y) return;                        // rasterize_points.cu:92
       }
-      const float q = c1v.x * dx * dx + c1v.y * dx * dy + c1v.z * dy * dy;        // :94
-      if (!exact_hit && q > c1v.w) return;                                        // :96
+      if (!exact_hit) {
+        const float q = c1v.x * dx * dx + c1v.y * dx * dy + c1v.z * dy * dy;      // :94
+        if (q > c1v.w) return;                                                    // :96
+      }
       const float pz = c0v.z;
       const int id = __float_as_int(c0v.w);
       if (pz < wz || (pz == wz && id < wi)) {
-        best.push(pz, id, q, K);
+        best.push_zi(pz, id, K);
+        if (K == KMAX) { wz = best.z[KMAX - 1]; wi = best.id[KMAX - 1]; }
+        else {
 #pragma unroll
-        for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wz = best.z[j]; wi = best.id[j]; }
+          for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wz = best.z[j]; wi = best.id[j]; }
+        }
       }
     };
     s_hits[threadIdx.x] = 0;
@@ -709,6 +740,18 @@ __global__ __launch_bounds__(256) void k_raster(
           for (int i = 0; i < nw; ++i) test_push(s_wide[par][i], false);
         } else {
           for (int k = 0; k < m; ++k) test_push(k, false);        // an overfull list: every candidate, tested here
+        }
+      }
+    }
+    // q of the K survivors (:94; the same expression on the same operands as the hit test): their records are
+    // re-read once per tile instead of carrying q through every insertion
+    if (inside) {
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        if (j < K && best.z[j] < FLT_MAX) {
+          const int64_t p = best.id[j];
+          const float dx = xf - pts[p * 3], dy = yf - pts[p * 3 + 1];
+          best.q[j] = ellipse[p * 3] * dx * dx + ellipse[p * 3 + 1] * dx * dy + ellipse[p * 3 + 2] * dy * dy;
         }
       }
     }
@@ -1233,44 +1276,57 @@ __global__ __launch_bounds__(256) void k_splat_backward(
   const int n = blockIdx.y;
   const int64_t len = num[n], base = first[n];
   const float r = rect_mode ? 0.f : rs[n];
-  const int lane = threadIdx.x & 63;
-  const int64_t span = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < len; i0 += span) {
-    const int64_t i = i0 + threadIdx.x;
-    bool is_heavy = false;
-    int64_t p = -1;
-    if (i < len) {
-      p = base + i;
-      const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
-      const float rx = radii[p * 2], ry = radii[p * 2 + 1];
-      const bool vis = (!visible || visible[p]);
-      grad[p * 3] = 0.f; grad[p * 3 + 1] = 0.f; grad[p * 3 + 2] = 0.f;   // z: k_z_scatter / k_z_finish
-      const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
-      // (the fast kernel skips points outside the image: rasterize_points_backward.cu:101-103; here: outside the frame)
-      if (vis && !(pz < 0.f || fabsf(py) > F.ey || fabsf(px) > F.ex) && sx > 0.f && sy > 0.f) {
-        int x0, x1, y0, y1;
-        if (out_range(px, sx, F.W, F.ex, F.m, x0, x1) && out_range(py, sy, F.H, F.ey, F.m, y0, y1)) {
-          for (int sy2 = y0 / 64; sy2 <= y1 / 64 && !is_heavy; ++sy2)
-            for (int sx2 = x0 / 64; sx2 <= x1 / 64; ++sx2)
-              if (blk2[((int64_t)n * G.NB2y + sy2) * G.NB2x + sx2]) { is_heavy = true; break; }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // 1024 points per round and workgroup: the heavy list is appended to with ONE returning atomic per round
+  // (one per 256 points made ~8 k same-address atomics the critical path of the kernel)
+  __shared__ int s_wcnt[4][4], s_base;
+  const int64_t span = (int64_t)gridDim.x * 1024;
+  for (int64_t i0 = (int64_t)blockIdx.x * 1024; i0 < len; i0 += span) {
+    bool is_heavy[4];
+    int64_t pp[4];
+    unsigned long long bal[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * 256 + threadIdx.x;
+      is_heavy[k] = false;
+      pp[k] = -1;
+      if (i < len) {
+        const int64_t p = base + i;
+        pp[k] = p;
+        const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
+        const float rx = radii[p * 2], ry = radii[p * 2 + 1];
+        const bool vis = (!visible || visible[p]);
+        grad[p * 3] = 0.f; grad[p * 3 + 1] = 0.f; grad[p * 3 + 2] = 0.f;   // z: k_z_scatter / k_z_finish
+        const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
+        // (the fast kernel skips points outside the image: rasterize_points_backward.cu:101-103; here: outside the frame)
+        if (vis && !(pz < 0.f || fabsf(py) > F.ey || fabsf(px) > F.ex) && sx > 0.f && sy > 0.f) {
+          int x0, x1, y0, y1;
+          if (out_range(px, sx, F.W, F.ex, F.m, x0, x1) && out_range(py, sy, F.H, F.ey, F.m, y0, y1)) {
+            for (int sy2 = y0 / 64; sy2 <= y1 / 64 && !is_heavy[k]; ++sy2)
+              for (int sx2 = x0 / 64; sx2 <= x1 / 64; ++sx2)
+                if (blk2[((int64_t)n * G.NB2y + sy2) * G.NB2x + sx2]) { is_heavy[k] = true; break; }
+          }
         }
       }
+      bal[k] = __ballot(is_heavy[k]);
+      if (lane == 0) s_wcnt[k][wv] = __popcll(bal[k]);
     }
-    // one global atomic per workgroup: wave counts -> LDS -> base
-    __shared__ int s_wcnt[4], s_base;
-    const unsigned long long bal = __ballot(is_heavy);
-    const int wv = threadIdx.x >> 6;
-    if (lane == 0) s_wcnt[wv] = __popcll(bal);
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+      int tot = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tot += s_wcnt[q >> 2][q & 3];
       s_base = tot ? atomicAdd(heavy_count, tot) : 0;
     }
     __syncthreads();
-    if (is_heavy) {
-      int b0 = s_base;
-      for (int q = 0; q < wv; ++q) b0 += s_wcnt[q];
-      heavy[b0 + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)p;
+    int b0 = s_base;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q == wv && is_heavy[k]) heavy[b0 + __popcll(bal[k] & ((1ull << lane) - 1ull))] = (int32_t)pp[k];
+        b0 += s_wcnt[k][q];
+      }
     }
     __syncthreads();
   }
@@ -1959,7 +2015,7 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
   int32_t* heavy_count = (int32_t*)((uint8_t*)workspace + bwd_maps_bytes(n_clouds, image_size, image_width));
   int32_t* heavy = heavy_count + 16;
   iso_zero_words(heavy_count, 16, s);
-  int gx = iso_div_up(max_pts, 256); if (gx > 8192) gx = 8192;
+  int gx = iso_div_up(max_pts, 1024); if (gx > 8192) gx = 8192;
   // xy part point-major (z written as 0), then the z part pixel-major in fixed point
   hipLaunchKernelGGL(k_splat_backward, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, visible,
                      search_radius, first_idx, num_pts, blk2, G, F, rect_mode, radii_s, heavy,

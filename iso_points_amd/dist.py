@@ -55,13 +55,41 @@ def all_shard_bounds(n, world):
     return [shard_bounds(n, world, r) for r in range(world)]
 
 
-def slab_order(points, world):
-    """Permutation that puts a (P,3) cloud into x-slab order (stable sort by x): rank r of `world`
-    then holds rows shard_bounds(P, world, r) of the permuted cloud.  Identity for world == 1."""
+def _cell_key(points, bits=10):
+    """30-bit Morton key of a (P,3) cloud on a 2^bits grid over its bounding box (z-order curve: consecutive
+    keys are neighbouring cells)."""
+    mn = points.min(0).values
+    ext = (points.max(0).values - mn).clamp_min(1e-20)
+    q = ((points - mn) / ext * float(2 ** bits - 1)).to(torch.int64).clamp_(0, 2 ** bits - 1)
+
+    def spread(v):                                   # 10 bits -> every third bit of 30
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    return (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
+
+
+def slab_order(points, world, local="cell"):
+    """Permutation that puts a (P,3) cloud into the order the job works in: x-slab major (stable sort by x; rank r
+    of `world` then holds rows shard_bounds(P, world, r) of the permuted cloud) and, inside a slab, along the
+    z-order curve of a 1024^3 grid (`local="cell"`: consecutive rows are neighbours in space, so the atomics of the
+    grid build, the gathers of the raster and the per-point stores of the fused kernels stay within a few cache
+    lines; `local=None`: rows of a slab stay in x order).  One sort at set-up, not on the per-cycle path; every
+    result of the cycle is per point, so the order only permutes them."""
     P = points.shape[0]
-    if world == 1:
+    if world == 1 and local is None:
         return torch.arange(P, device=points.device)
-    return torch.sort(points[:, 0], stable=True).indices
+    by_x = torch.sort(points[:, 0], stable=True).indices
+    if local is None:
+        return by_x
+    slab = torch.empty(P, dtype=torch.int64, device=points.device)
+    for r in range(world):
+        lo, hi = shard_bounds(P, world, r)
+        slab[by_x[lo:hi]] = r
+    key = (slab << 30) | _cell_key(points)
+    return torch.sort(key, stable=True).indices
 
 
 class Comm(object):
