@@ -125,8 +125,8 @@ def test_slab_order_is_a_stable_x_sort():
     g = torch.Generator().manual_seed(0)
     p = torch.randn(1000, 3, generator=g)
     p[100:120, 0] = p[5, 0]                      # ties keep their original order
-    assert torch.equal(slab_order(p, 1), torch.arange(1000))
-    perm = slab_order(p, 4)
+    assert torch.equal(slab_order(p, 1, local=None), torch.arange(1000))
+    perm = slab_order(p, 4, local=None)
     xs = p[perm, 0]
     assert (xs[1:] >= xs[:-1]).all() and sorted(perm.tolist()) == list(range(1000))
     tie = perm[(xs == p[5, 0])]
@@ -135,3 +135,22 @@ def test_slab_order_is_a_stable_x_sort():
     for r in range(3):
         lo, hi = shard_bounds(1000, 4, r)
         assert xs[hi - 1] <= xs[hi]
+
+
+def test_slab_order_cell_order_keeps_the_slabs_and_is_local():
+    """Default order: the same x-slabs (same point sets per rank as the plain x sort), rows of a slab along the
+    z-order curve -- consecutive rows are near each other."""
+    from iso_points_amd.dist import shard_bounds, slab_order
+    g = torch.Generator().manual_seed(1)
+    p = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g), dim=-1)
+    for world in (1, 3, 4):
+        by_x = slab_order(p, world, local=None)
+        perm = slab_order(p, world)
+        assert sorted(perm.tolist()) == list(range(20000))
+        for r in range(world):
+            lo, hi = shard_bounds(20000, world, r)
+            assert set(perm[lo:hi].tolist()) == set(by_x[lo:hi].tolist())
+        q = p[perm]
+        step = (q[1:] - q[:-1]).norm(dim=-1).median()
+        assert step < 0.1 * (p[1:] - p[:-1]).norm(dim=-1).median()
+    assert torch.equal(slab_order(p, 2), slab_order(p.clone(), 2))        # deterministic
