@@ -265,7 +265,9 @@ struct BrickGeo { int bx, by, bz, ox, oy, oz; };
 // the first (BK_RAW in flight: the staging is a chain of global-memory latencies otherwise).
 constexpr int BK_RAW = 8;
 
-template <bool WITH_NRM>
+// VS (bandwidth kernel only): bit stride of the view mask in the staged record -- 1: as stored; 8: view v at bit
+// 8 v (up to four views), so that masked records add up to four 8-bit per-view counters in one register.
+template <bool WITH_NRM, int VS = 1>
 __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int32_t* __restrict__ off,
                            const float4* __restrict__ rec0, const float4* __restrict__ rec1, int b, BrickGeo& g) {
   const int tid = threadIdx.x;
@@ -311,7 +313,9 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
     } else {
       const int gid = __float_as_int(p.w);
       const bool own = gid >= h.id_base && gid < h.id_base + h.n_own;
-      const int m = (__float_as_int(u.w) & 0xff) | (own ? 0 : (int)0x80000000);
+      int m = __float_as_int(u.w) & 0xff;
+      if (VS == 8) m = (m & 1) | ((m & 2) << 7) | ((m & 4) << 14) | ((m & 8) << 21);
+      m |= own ? 0 : (int)0x80000000;
       S.rec0[pos] = make_float4(p.x, p.y, p.z, __int_as_float(m));
       S.gid[pos] = gid;
     }
@@ -781,7 +785,8 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_h(
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
     const int b = list[li];
     BrickGeo g;
-    const int C = stage_brick<false>(S, h, off, rec0, rec1, b, g);
+    constexpr int VS = NV <= 4 ? 8 : 1;                 // staged view masks: one byte per view when they fit a word
+    const int C = stage_brick<false, VS>(S, h, off, rec0, rec1, b, g);
     if (C < 0) { brick_to_tail(h, off, rec0, b, tail, counters, 3, 8); continue; }
     const int nq = S.qpre[16];
     for (int t0 = 0; t0 < nq; t0 += BK_THREADS) {
@@ -802,18 +807,30 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_h(
       int cnt[NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) cnt[v] = 0;
-      if (qmask)
+      if (VS == 8 && C <= 255) {                                     // (workgroup-uniform) byte counters cannot overflow
+        unsigned acc = 0;
+        if (qmask)
+          walk_candidates(S, lx, ly, lz, [&](const float4& c0, int, const float4& c1, int, bool two) {
+            const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
+            const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
+            const unsigned ma = da <= t2 ? (__float_as_uint(c0.w) & 0x01010101u) : 0u;
+            const unsigned mb = (two && db <= t2) ? (__float_as_uint(c1.w) & 0x01010101u) : 0u;
+            acc += ma + mb;
+          });
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cnt[v] = (int)((acc >> (8 * (v & 3))) & 0xffu);
+      } else if (qmask)
         walk_candidates(S, lx, ly, lz, [&](const float4& c0, int, const float4& c1, int, bool two) {
           const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
           const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
           const int ma = da <= t2 ? __float_as_int(c0.w) : 0;
           const int mb = (two && db <= t2) ? __float_as_int(c1.w) : 0;
 #pragma unroll
-          for (int v = 0; v < NV; ++v) cnt[v] += ((ma >> v) & 1) + ((mb >> v) & 1);
+          for (int v = 0; v < NV; ++v) cnt[v] += ((ma >> (VS * v)) & 1) + ((mb >> (VS * v)) & 1);
         });
       bool open_ = false;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) open_ = open_ || (((qmask >> v) & 1) && !small_cloud[v] && cnt[v] < 7);
+      for (int v = 0; v < NV; ++v) open_ = open_ || (((qmask >> (VS * v)) & 1) && !small_cloud[v] && cnt[v] < 7);
       // pass 2 (only the lanes with an open view; rare away from the terminator of a dense cloud):
       // the 7 smallest d2 per view
       float d[NV][7];
@@ -830,8 +847,8 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_h(
           const int ma = __float_as_int(c0.w), mb = __float_as_int(c1.w);
 #pragma unroll
           for (int v = 0; v < NV; ++v) {
-            const float ka = (ma >> v) & 1 ? da : FLT_MAX;
-            const float kb = (mb >> v) & 1 ? db : FLT_MAX;
+            const float ka = (ma >> (VS * v)) & 1 ? da : FLT_MAX;
+            const float kb = (mb >> (VS * v)) & 1 ? db : FLT_MAX;
 #pragma unroll
             for (int j = 6; j >= 1; --j) d[v][j] = __builtin_amdgcn_fmed3f(d[v][j - 1], ka, d[v][j]);
             d[v][0] = fminf(d[v][0], ka);
@@ -843,7 +860,7 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_h(
       if (qmask) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          if (v < n_views && ((qmask >> v) & 1)) {
+          if (v < n_views && ((qmask >> (VS * v)) & 1)) {
             float hv;
             bool cert = true;
             if (small_cloud[v]) hv = fminf(fmaxf(0.5f * 1e-3f, 5e-5f), 0.01f);
