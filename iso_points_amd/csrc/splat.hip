@@ -596,7 +596,7 @@ __device__ __forceinline__ void composite_pixel(const PixK<KMAX>& best, int K, f
 //          it covers (LDS counters); the pixel threads then insert only their own hits.  The K-best rule is a total
 //          order on (z, id), so the arrival order in the lists does not matter.  Candidates whose box covers more
 //          than kWideArea pixels, and pixels whose list overflows, take the first form.
-constexpr int kHitList = 40, kWideArea = 48;
+constexpr int kHitList = 40, kWideArea = 48;   // (32 / 24 / 16-entry lists: 316 / 333 / 429 us against 302)
 
 template <int KMAX, bool CP>
 __global__ __launch_bounds__(256) void k_raster(
@@ -657,9 +657,13 @@ __global__ __launch_bounds__(256) void k_raster(
     cnt = min(cnt, (int)((int64_t)chunks * (slice + 1) / nslices) * 256);
   }
   if constexpr (CP) {
-    // records of a chunk: {x, y, z, id} {a, b, c, cutoff} {rx, ry}; two buffers, the next chunk's records are
-    // requested (into registers) while this one is worked on, two barriers per chunk
-    __shared__ float4 s_rec[2][256][3];
+    // records of a chunk: {x, y, z, id} {a, b, c, cutoff} {rx, ry}; the next chunk's records are requested (into
+    // registers) while this one is worked on
+    // ONE record buffer (a third barrier per chunk): 22.5 KB of LDS instead of 37 put seven workgroups on a CU
+    // instead of four -- 387 -> 302 us; the kernel is bound by what the resident waves can overlap
+    constexpr int NB = 1;
+    __shared__ float4 s_r0[NB][256], s_r1[NB][256];
+    __shared__ float2 s_r2[NB][256];
     __shared__ short s_wide[2][256];
     __shared__ int s_nw[2];
     float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0;
@@ -673,10 +677,10 @@ __global__ __launch_bounds__(256) void k_raster(
     };
     int par = 0;
     auto test_push = [&](int k, bool exact_hit) {
-      const float4 c0v = s_rec[par][k][0], c1v = s_rec[par][k][1];
+      const float4 c0v = s_r0[par % NB][k], c1v = s_r1[par % NB][k];
       const float dx = xf - c0v.x, dy = yf - c0v.y;
       if (!exact_hit) {
-        const float4 c2v = s_rec[par][k][2];
+        const float2 c2v = s_r2[par % NB][k];
         if (fabsf(dx) > c2v.x || fabsf(dy) > c2v.y) return;                        // rasterize_points.cu:92
       }
       if (!exact_hit) {
@@ -699,12 +703,13 @@ __global__ __launch_bounds__(256) void k_raster(
     fetch(c_begin);
     for (int c0 = c_begin; c0 < cnt; c0 += 256, par ^= 1) {
       const int m = min(256, cnt - c0);
-      if ((int)threadIdx.x < m) { s_rec[par][threadIdx.x][0] = r0; s_rec[par][threadIdx.x][1] = r1; s_rec[par][threadIdx.x][2] = r2; }
+      if ((int)threadIdx.x < m) { s_r0[par % NB][threadIdx.x] = r0; s_r1[par % NB][threadIdx.x] = r1; s_r2[par % NB][threadIdx.x] = make_float2(r2.x, r2.y); }
       __syncthreads();                                    // records visible; the hit counters are zero
       fetch(c0 + 256);
       if ((int)threadIdx.x < m) {
         const int k = threadIdx.x;
-        const float4 c0v = s_rec[par][k][0], c1v = s_rec[par][k][1], c2v = s_rec[par][k][2];
+        const float4 c0v = s_r0[par % NB][k], c1v = s_r1[par % NB][k];
+        const float2 c2v = s_r2[par % NB][k];
         int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
         const bool any = pixel_range(c0v.x, c2v.x, F.W, F.ex, F.m, x0, x1) && pixel_range(c0v.y, c2v.y, F.H, F.ey, F.m, y0, y1);
         x0 = max(x0, tx * TILE); x1 = min(x1, tx * TILE + TILE - 1);
@@ -742,6 +747,7 @@ __global__ __launch_bounds__(256) void k_raster(
           for (int k = 0; k < m; ++k) test_push(k, false);        // an overfull list: every candidate, tested here
         }
       }
+      if (NB == 1) __syncthreads();                       // one record buffer: all reads done before the next chunk lands
     }
     // q of the K survivors (:94; the same expression on the same operands as the hit test): their records are
     // re-read once per tile instead of carrying q through every insertion
