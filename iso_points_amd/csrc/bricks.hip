@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void k_brick_list(const BrickHdr* __restrict__
 template <bool WITH_NRM>
 struct BrickStage {
   float4 rec0[BK_CAP];
-  float4 rec1[WITH_NRM ? BK_CAP : 1];
+  int src[WITH_NRM ? BK_CAP : 1];     // WITH_NRM: position of the staged record in the brick-sorted arrays (its rec1 is read
+                                      // from there by the few that need it: staging it cost 16 KB of LDS = three workgroups per CU)
   int gid[WITH_NRM ? 1 : BK_CAP];
   int cstart[220];   // [217] used: local fine cell -> first staged slot
   int ccur[216];
@@ -306,14 +307,14 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
     const int lz = bk_fine(p.z, h.mn[2], h.inv_f, h.nf[2]) - g.oz;
     return ((unsigned)lx < 6u && (unsigned)ly < 6u && (unsigned)lz < 6u) ? (lx * 6 + ly) * 6 + lz : -1;
   };
-  auto store = [&](int pos, const float4& p, const float4& u) {
+  auto store = [&](int pos, const float4& p, int at, float uw) {
     if (WITH_NRM) {
       S.rec0[pos] = p;
-      S.rec1[pos] = u;
+      S.src[pos] = at;
     } else {
       const int gid = __float_as_int(p.w);
       const bool own = gid >= h.id_base && gid < h.id_base + h.n_own;
-      int m = __float_as_int(u.w) & 0xff;
+      int m = __float_as_int(uw) & 0xff;
       if (VS == 8) m = (m & 1) | ((m & 2) << 7) | ((m & 4) << 14) | ((m & 8) << 21);
       m |= own ? 0 : (int)0x80000000;
       S.rec0[pos] = make_float4(p.x, p.y, p.z, __int_as_float(m));
@@ -354,15 +355,14 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
     scan_cells();
     __syncthreads();
     if (S.cstart[216] > BK_CAP) return -1;
+    const float* __restrict__ rec1w = reinterpret_cast<const float*>(rec1) + 3;     // the payload word of a second record
+    float uw[BK_RAW];
 #pragma unroll
-    for (int h2 = 0; h2 < BK_RAW; h2 += 4) {         // the second records of the accepted candidates, four in flight
-      float4 u[4];
+    for (int k = 0; k < BK_RAW; ++k)                 // (bandwidth kernel) the payload words of the accepted candidates, all in flight
+      uw[k] = (!WITH_NRM && cell[k] >= 0) ? rec1w[4 * (int64_t)idx[k]] : 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) u[k] = cell[h2 + k] >= 0 ? rec1[idx[h2 + k]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (cell[h2 + k] >= 0) store(atomicAdd(&S.ccur[cell[h2 + k]], 1), p[h2 + k], u[k]);
-    }
+    for (int k = 0; k < BK_RAW; ++k)
+      if (cell[k] >= 0) store(atomicAdd(&S.ccur[cell[k]], 1), p[k], idx[k], uw[k]);
   } else {                                           // very dense neighbourhood: two passes over global memory
     for (int j = tid; j < total_raw; j += BK_THREADS) {
       const int c = cell_of(rec0[index_of(j)]);
@@ -376,7 +376,7 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
       const int i = index_of(j);
       const float4 p = rec0[i];
       const int c = cell_of(p);
-      if (c >= 0) store(atomicAdd(&S.ccur[c], 1), p, rec1[i]);
+      if (c >= 0) store(atomicAdd(&S.ccur[c], 1), p, i, WITH_NRM ? 0.f : rec1[i].w);
     }
   }
   if (tid < 16) {                                    // the brick's own 4x4x4 fine cells: 16 contiguous z-runs
@@ -542,12 +542,23 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
       if (!(cert_list && cert_geo)) { tail[atomicAdd(&counters[1], 1)] = row; continue; }
       Repulse R;
       R.px = q.x; R.py = q.y; R.pz = q.z; R.inv_sigma = h.inv_sigma;
+      // the normals of the K - 1 neighbours come from the brick-sorted array (four requests in flight)
 #pragma unroll
-      for (int j = 1; j < M; ++j) {
-        if (j < K && d[j] < FLT_MAX) {
-          const float4 c = S.rec0[ps[j]];
-          const float4 u = S.rec1[ps[j]];
-          R.add(c.x, c.y, c.z, u.x, u.y, u.z);
+      for (int j0 = 1; j0 < M; j0 += 4) {
+        float4 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = j0 + k;
+          u[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j < M && j < K && d[j < M ? j : 0] < FLT_MAX) u[k] = rec1[S.src[ps[j < M ? j : 0]]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = j0 + k;
+          if (j < M && j < K && d[j < M ? j : 0] < FLT_MAX) {
+            const float4 c = S.rec0[ps[j < M ? j : 0]];
+            R.add(c.x, c.y, c.z, u[k].x, u[k].y, u[k].z);
+          }
         }
       }
       R.finish(out + (int64_t)row * 3);
@@ -767,8 +778,9 @@ __device__ __forceinline__ float h_from_list(const float* d /*7 ascending, FLT_M
   return fminf(fmaxf(0.5f * m, 5e-5f), 0.01f);
 }
 
+// (five waves per SIMD: 277 -> 257 us; the resample kernel above is bound by its instruction count and gains nothing)
 template <int NV>
-__global__ __launch_bounds__(BK_THREADS, 4) void k_brick_h(
+__global__ __launch_bounds__(BK_THREADS, NV <= 4 ? 5 : 4) void k_brick_h(
     const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off, const int32_t* __restrict__ list,
     const float4* __restrict__ rec0, const float4* __restrict__ rec1, const int32_t* __restrict__ view_total,
     int n_views, float* __restrict__ h_out /*(n_views, n_own)*/, int32_t* __restrict__ tail,
