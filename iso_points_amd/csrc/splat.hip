@@ -599,7 +599,7 @@ __device__ __forceinline__ void composite_pixel(const PixK<KMAX>& best, int K, f
 constexpr int kHitList = 40, kWideArea = 48;   // (32 / 24 / 16-entry lists: 316 / 333 / 429 us against 302)
 
 template <int KMAX, bool CP>
-__global__ __launch_bounds__(256) void k_raster(
+__global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
     const float* __restrict__ pts, const float* __restrict__ ellipse,
     const float* __restrict__ cutoff, const float* __restrict__ radii,
     const int32_t* __restrict__ tile_order, const int4* __restrict__ items, const int32_t* __restrict__ item_count,
