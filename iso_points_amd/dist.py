@@ -440,7 +440,9 @@ class IsoCycle(object):
                 done = False
                 req = None
                 try:
-                    with torch.cuda.graph(graph, pool=self._pool, stream=cap_stream):
+                    # thread-local capture mode: the process group's watchdog thread polls its events while a
+                    # segment is being captured; in the default (global) mode that would invalidate the capture
+                    with torch.cuda.graph(graph, pool=self._pool, stream=cap_stream, capture_error_mode="thread_local"):
                         req = next(g) if first else g.send(incoming)
                 except StopIteration as e:
                     final, done = e.value, True
