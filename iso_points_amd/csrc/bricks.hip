@@ -28,7 +28,7 @@ BrickWs bricks_carve(void* ws, int64_t n_max) {
   BrickWs w;
   if (n_max < 1) n_max = 1;
   w.nb_cap = bricks_nb_cap(n_max);
-  w.G = 8 * (int64_t)w.nb_cap * w.nb_cap * w.nb_cap + 1;       // 8 counters per brick (see brick_key)
+  w.G = BK_CPB * (int64_t)w.nb_cap * w.nb_cap * w.nb_cap + 1;   // BK_CPB counters per brick (bricks.h)
   auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
   char* p = (char*)ws;
   int64_t o = 0;
@@ -91,7 +91,7 @@ __global__ void k_bricks_params(const float* __restrict__ bbox, int64_t n_total,
   const int nbr = nb[0] * nb[1] * nb[2];
   h->inv_f = inv_f;
   h->nbx_f = (float)nb[0]; h->nby_f = (float)nb[1]; h->nbz_f = (float)nb[2];
-  h->total_f = (float)(8 * nbr + 1);
+  h->total_f = (float)(BK_CPB * nbr + 1);
   h->f = f; h->r = r; h->r2 = r * r;
   const float g = 0.999f * f;
   h->g2 = g * g;
@@ -107,7 +107,7 @@ __global__ void k_bricks_params(const float* __restrict__ bbox, int64_t n_total,
 }
 
 __global__ void k_bricks_zero(const BrickHdr* __restrict__ h, int32_t* __restrict__ cnt) {
-  const int n = 8 * h->n_bricks + 1;
+  const int n = BK_CPB * h->n_bricks + 1;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cnt[i] = 0;
 }
 
@@ -118,80 +118,78 @@ __device__ __forceinline__ int brick_of(const BrickHdr& h, float x, float y, flo
   return ((fx >> 2) * h.nb[1] + (fy >> 2)) * h.nb[2] + (fz >> 2);
 }
 
-// Counter of a point: 8 per brick (its 2x2x2 half-brick octants).  The records of brick b are
-// [off[8 b], off[8 (b + 1)]) whatever the order inside; eight times as many counters as bricks keep the
-// same-address atomics of the counting pass short (a 1 M-point surface fills only ~8 k bricks).
-__device__ __forceinline__ int brick_key(const BrickHdr& h, float x, float y, float z) {
-  const int fx = bk_fine(x, h.mn[0], h.inv_f, h.nf[0]);
-  const int fy = bk_fine(y, h.mn[1], h.inv_f, h.nf[1]);
-  const int fz = bk_fine(z, h.mn[2], h.inv_f, h.nf[2]);
-  const int b = ((fx >> 2) * h.nb[1] + (fy >> 2)) * h.nb[2] + (fz >> 2);
-  return b * 8 + ((fx >> 1) & 1) * 4 + ((fy >> 1) & 1) * 2 + ((fz >> 1) & 1);
-}
-
-// own points (packed (n,3) f32): arrival slot inside the brick.  A workgroup first counts its 1024 points per
-// brick in an LDS hash table and then reserves each brick's range with ONE returning global atomic (a point
-// order with any spatial coherence -- the cycle's clouds are x-slab sorted -- puts several of a round's points in
-// the same brick; one returning atomic per point was the whole cost of this kernel).  All points of a workgroup
-// use the same one of the brick's eight counters (which one is free: the records of a brick are the union of its
-// eight ranges), so that workgroups still spread over eight addresses per brick.  slot = rank | counter << 28;
-// a point that finds no table entry within kCntProbe probes takes its rank from global memory directly.
+// Arrival slot of a record inside its brick (own points: packed (n,3) f32; imported halo records: float4).  The records
+// of brick b are [off[BK_CPB b], off[BK_CPB (b + 1)]) whatever the order inside.  A workgroup first counts its 1024
+// records per brick in an LDS hash table and then reserves each brick's range with ONE returning global atomic (a
+// record order with any spatial coherence -- the cycle's clouds run along a z-order curve -- puts many of a round's
+// records in the same brick; one returning atomic per record was the whole cost of this pass).  All records of a
+// workgroup use the same one of the brick's BK_CPB counters; slot = rank | counter << 28; a record that finds no table
+// entry within kCntProbe probes takes its rank from global memory directly.
 constexpr int kCntTab = 2048, kCntProbe = 16;
+
+// one round of 1024 records of a workgroup: pos(i, x, y, z) fetches record i, its slot goes to slot_out[i]
+template <class Pos>
+__device__ __forceinline__ void brick_count_round(const BrickHdr& h, int64_t base, int64_t n, int32_t* __restrict__ cnt,
+                                                  int32_t* __restrict__ slot_out, int* t_key, int* t_cnt, Pos&& pos) {
+  const int oct = blockIdx.x & (BK_CPB - 1);
+  for (int j = threadIdx.x; j < kCntTab; j += 256) { t_key[j] = -1; t_cnt[j] = 0; }
+  __syncthreads();
+  int e[4], rk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    e[k] = -1; rk[k] = 0;
+    if (i < n) {
+      float x, y, z;
+      pos(i, x, y, z);
+      const int key = BK_CPB * brick_of(h, x, y, z) + oct;
+      unsigned at = ((unsigned)key * 2654435761u) >> 21;          // 11 bits
+      bool found = false;
+      for (int t = 0; t < kCntProbe && !found; ++t) {
+        const int prev = atomicCAS(&t_key[at], -1, key);
+        if (prev == -1 || prev == key) found = true;
+        else at = (at + 1) & (kCntTab - 1);
+      }
+      if (found) { e[k] = (int)at; rk[k] = atomicAdd(&t_cnt[at], 1); }
+      else rk[k] = atomicAdd(&cnt[key], 1);
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < kCntTab; j += 256) {
+    const int c = t_cnt[j];
+    if (c > 0) t_cnt[j] = atomicAdd(&cnt[t_key[j]], c);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    if (i < n) slot_out[i] = ((e[k] >= 0 ? t_cnt[e[k]] : 0) + rk[k]) | (oct << 28);
+  }
+  __syncthreads();
+}
 
 __global__ __launch_bounds__(256) void k_brick_count(const float* __restrict__ pts, int64_t n,
                                                      const BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
                                                      int32_t* __restrict__ slot) {
   __shared__ int t_key[kCntTab], t_cnt[kCntTab];
   const BrickHdr h = *hp;
-  const int oct = blockIdx.x & 7;
-  for (int64_t base = (int64_t)blockIdx.x * 1024; base < n; base += (int64_t)gridDim.x * 1024) {
-    for (int j = threadIdx.x; j < kCntTab; j += 256) { t_key[j] = -1; t_cnt[j] = 0; }
-    __syncthreads();
-    int e[4], rk[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int64_t i = base + k * 256 + threadIdx.x;
-      e[k] = -1; rk[k] = 0;
-      if (i < n) {
-        const int key = 8 * brick_of(h, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]) + oct;
-        unsigned at = ((unsigned)key * 2654435761u) >> 21;          // 11 bits
-        bool found = false;
-        for (int t = 0; t < kCntProbe && !found; ++t) {
-          const int prev = atomicCAS(&t_key[at], -1, key);
-          if (prev == -1 || prev == key) found = true;
-          else at = (at + 1) & (kCntTab - 1);
-        }
-        if (found) { e[k] = (int)at; rk[k] = atomicAdd(&t_cnt[at], 1); }
-        else rk[k] = atomicAdd(&cnt[key], 1);
-      }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < kCntTab; j += 256) {
-      const int c = t_cnt[j];
-      if (c > 0) t_cnt[j] = atomicAdd(&cnt[t_key[j]], c);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int64_t i = base + k * 256 + threadIdx.x;
-      if (i < n) slot[i] = ((e[k] >= 0 ? t_cnt[e[k]] : 0) + rk[k]) | (oct << 28);
-    }
-    __syncthreads();
-  }
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < n; base += (int64_t)gridDim.x * 1024)
+    brick_count_round(h, base, n, cnt, slot, t_key, t_cnt,
+                      [&](int64_t i, float& x, float& y, float& z) { x = pts[i * 3]; y = pts[i * 3 + 1]; z = pts[i * 3 + 2]; });
 }
 
-// imported halo records (count on the device)
+// imported halo records (count on the device); same aggregation
 __global__ __launch_bounds__(256) void k_brick_count_recs(const float4* __restrict__ imp0, const int32_t* __restrict__ imp_count,
                                                           int64_t imp_max, BrickHdr* __restrict__ hp,
                                                           int32_t* __restrict__ cnt, int32_t* __restrict__ slot) {
+  __shared__ int t_key[kCntTab], t_cnt[kCntTab];
   const BrickHdr h = *hp;
   int64_t m = *imp_count;
   if (m > imp_max) m = imp_max;
   if (blockIdx.x == 0 && threadIdx.x == 0) hp->n = h.n_own + (int)m;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
-    const float4 p = imp0[j];
-    slot[h.n_own + j] = atomicAdd(&cnt[brick_key(h, p.x, p.y, p.z)], 1);
-  }
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < m; base += (int64_t)gridDim.x * 1024)
+    brick_count_round(h, base, m, cnt, slot + h.n_own, t_key, t_cnt,
+                      [&](int64_t j, float& x, float& y, float& z) { const float4 p = imp0[j]; x = p.x; y = p.y; z = p.z; });
 }
 
 __global__ __launch_bounds__(256) void k_brick_scatter(const float* __restrict__ pts, const float* __restrict__ nrm,
@@ -203,7 +201,7 @@ __global__ __launch_bounds__(256) void k_brick_scatter(const float* __restrict__
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
     const int sl = slot[i];                                           // rank | counter << 28 (k_brick_count)
-    const int64_t dst = (int64_t)off[8 * brick_of(h, x, y, z) + ((unsigned)sl >> 28)] + (sl & 0x0fffffff);
+    const int64_t dst = (int64_t)off[BK_CPB * brick_of(h, x, y, z) + ((unsigned)sl >> 28)] + (sl & 0x0fffffff);
     rec0[dst] = make_float4(x, y, z, __int_as_float(h.id_base + (int)i));
     float4 u = make_float4(0.f, 0.f, 0.f, __int_as_float(payload ? payload[i] : 0));
     if (nrm) { u.x = nrm[i * 3]; u.y = nrm[i * 3 + 1]; u.z = nrm[i * 3 + 2]; }
@@ -219,25 +217,48 @@ __global__ __launch_bounds__(256) void k_brick_scatter_recs(const float4* __rest
   const int64_t m = h.n - h.n_own;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
     const float4 p = imp0[j];
-    const int64_t dst = (int64_t)off[brick_key(h, p.x, p.y, p.z)] + slot[h.n_own + j];
+    const int sl = slot[h.n_own + j];
+    const int64_t dst = (int64_t)off[BK_CPB * brick_of(h, p.x, p.y, p.z) + ((unsigned)sl >> 28)] + (sl & 0x0fffffff);
     rec0[dst] = p;
     rec1[dst] = imp1[j];
   }
 }
 
-// occupied bricks (the order only affects scheduling)
+// occupied bricks (the order only affects scheduling); 1024 bricks per workgroup and round, ONE returning atomic
+// for them (one per wave made ~2 k same-address atomics the kernel's whole duration)
 __global__ __launch_bounds__(256) void k_brick_list(const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off,
                                                     int32_t* __restrict__ list, int32_t* __restrict__ counters) {
+  __shared__ int s_cnt[4][4], s_base;
   const int nb = hp->n_bricks;
-  const int lane = threadIdx.x & 63;
-  for (int b0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; b0 < nb; b0 += gridDim.x * blockDim.x) {
-    const int b = b0 + lane;
-    const bool occ = b < nb && off[8 * (b + 1)] > off[8 * b];
-    const unsigned long long bal = __ballot(occ);
-    int base = 0;
-    if (lane == 0 && bal) base = atomicAdd(&counters[0], __popcll(bal));
-    base = __shfl(base, 0);
-    if (occ) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = b;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int b0 = blockIdx.x * 1024; b0 < nb; b0 += gridDim.x * 1024) {
+    bool occ[4];
+    unsigned long long bal[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int b = b0 + k * 256 + threadIdx.x;
+      occ[k] = b < nb && off[BK_CPB * (b + 1)] > off[BK_CPB * b];
+      bal[k] = __ballot(occ[k]);
+      if (lane == 0) s_cnt[k][wv] = __popcll(bal[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tot += s_cnt[q >> 2][q & 3];
+      s_base = tot ? atomicAdd(&counters[0], tot) : 0;
+    }
+    __syncthreads();
+    int at = s_base;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q == wv && occ[k]) list[at + __popcll(bal[k] & ((1ull << lane) - 1ull))] = b0 + k * 256 + threadIdx.x;
+        at += s_cnt[k][q];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -282,8 +303,8 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
     int i0 = 0, len = 0;
     if (x >= 0 && x < nbx && y >= 0 && y < nby) {
       const int z0 = max(g.bz - 1, 0), z1 = min(g.bz + 1, nbz - 1);
-      i0 = off[8 * ((x * nby + y) * nbz + z0)];
-      len = off[8 * ((x * nby + y) * nbz + z1 + 1)] - i0;
+      i0 = off[BK_CPB * ((x * nby + y) * nbz + z0)];
+      len = off[BK_CPB * ((x * nby + y) * nbz + z1 + 1)] - i0;
     }
     S.run_i0[tid] = i0;
     S.run_pre[tid + 1] = len;
@@ -427,7 +448,7 @@ __device__ __forceinline__ void walk_candidates(const BrickStage<WITH_NRM>& S, i
 // a brick whose neighbourhood does not fit LDS: its own points go to the tail kernel
 __device__ void brick_to_tail(const BrickHdr& h, const int32_t* __restrict__ off, const float4* __restrict__ rec0, int b,
                               int32_t* __restrict__ tail, int32_t* __restrict__ counters, int tail_slot, int per_query) {
-  for (int i = off[8 * b] + threadIdx.x; i < off[8 * (b + 1)]; i += BK_THREADS) {
+  for (int i = off[BK_CPB * b] + threadIdx.x; i < off[BK_CPB * (b + 1)]; i += BK_THREADS) {
     const int gid = __float_as_int(rec0[i].w);
     if (gid >= h.id_base && gid < h.id_base + h.n_own) {
       const int at = atomicAdd(&counters[tail_slot], per_query);
@@ -594,11 +615,11 @@ __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz,
       const int cb = (x * nby + y) * nbz;
       if (edge) {
         const int za = max(qbz - rho, 0), zb = min(qbz + rho, nbz - 1);
-        if (za <= zb) { s0 = off[8 * (cb + za)]; e0 = off[8 * (cb + zb + 1)]; }
+        if (za <= zb) { s0 = off[BK_CPB * (cb + za)]; e0 = off[BK_CPB * (cb + zb + 1)]; }
       } else {
         const int za = qbz - rho, zb = qbz + rho;
-        if (za >= 0) { s0 = off[8 * (cb + za)]; e0 = off[8 * (cb + za + 1)]; }
-        if (zb < nbz) { s1 = off[8 * (cb + zb)]; e1 = off[8 * (cb + zb + 1)]; }
+        if (za >= 0) { s0 = off[BK_CPB * (cb + za)]; e0 = off[BK_CPB * (cb + za + 1)]; }
+        if (zb < nbz) { s1 = off[BK_CPB * (cb + zb)]; e1 = off[BK_CPB * (cb + zb + 1)]; }
       }
     }
     const int nc = min(64, ncols - c0);
@@ -986,29 +1007,36 @@ __global__ __launch_bounds__(256) void k_halo_export(const float* __restrict__ p
                                                      const BrickHdr* __restrict__ hp, const float* __restrict__ ranges,
                                                      int world, int rank, int halo, float4* __restrict__ out, int cap) {
   const BrickHdr h = *hp;
+  __shared__ int s_app[17];
   int32_t* counter = reinterpret_cast<int32_t*>(out);
-  const int64_t span = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n_own; i0 += span) {
-    const int64_t i = i0 + threadIdx.x;
-    bool take = false;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (i < n_own) {
-      x = pts[i * 3]; y = pts[i * 3 + 1]; z = pts[i * 3 + 2];
-      const int fx = bk_fine(x, h.mn[0], h.inv_f, h.nf[0]);
-      for (int k = 0; k < world; ++k) {
-        if (k == rank) continue;
-        const int lo = bk_fine(ranges[k * 8], h.mn[0], h.inv_f, h.nf[0]) - halo;
-        const int hi = bk_fine(ranges[k * 8 + 4], h.mn[0], h.inv_f, h.nf[0]) + halo;
-        take = take || (fx >= lo && fx <= hi);
+  const int64_t span = (int64_t)gridDim.x * 1024;
+  for (int64_t i0 = (int64_t)blockIdx.x * 1024; i0 < n_own; i0 += span) {
+    bool take[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t i = i0 + q * 256 + threadIdx.x;
+      take[q] = false;
+      if (i < n_own) {
+        const int fx = bk_fine(pts[i * 3], h.mn[0], h.inv_f, h.nf[0]);
+        for (int k = 0; k < world; ++k) {
+          if (k == rank) continue;
+          const int lo = bk_fine(ranges[k * 8], h.mn[0], h.inv_f, h.nf[0]) - halo;
+          const int hi = bk_fine(ranges[k * 8 + 4], h.mn[0], h.inv_f, h.nf[0]) + halo;
+          take[q] = take[q] || (fx >= lo && fx <= hi);
+        }
       }
     }
-    int slot;
-    wave_append(take, counter, cap, slot);
-    if (slot >= 0) {
-      out[1 + slot] = make_float4(x, y, z, __int_as_float(h.id_base + (int)i));
-      float4 u = make_float4(0.f, 0.f, 0.f, __int_as_float(payload ? payload[i] : 0));
-      if (nrm) { u.x = nrm[i * 3]; u.y = nrm[i * 3 + 1]; u.z = nrm[i * 3 + 2]; }
-      out[(int64_t)cap + 1 + 1 + slot] = u;
+    int slot[4];
+    iso_block_append4(take, counter, s_app, slot);      // (the count may pass cap: the importer clamps and reports it)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (slot[q] >= 0 && slot[q] < cap) {
+        const int64_t i = i0 + q * 256 + threadIdx.x;
+        out[1 + slot[q]] = make_float4(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], __int_as_float(h.id_base + (int)i));
+        float4 u = make_float4(0.f, 0.f, 0.f, __int_as_float(payload ? payload[i] : 0));
+        if (nrm) { u.x = nrm[i * 3]; u.y = nrm[i * 3 + 1]; u.z = nrm[i * 3 + 2]; }
+        out[(int64_t)cap + 1 + 1 + slot[q]] = u;
+      }
     }
   }
 }
@@ -1034,24 +1062,28 @@ __global__ __launch_bounds__(256) void k_halo_import(const float4* __restrict__ 
   const float4* blk = gathered + (int64_t)src * 2 * (cap + 1);
   int cnt = __float_as_int(blk[0].x);
   if (cnt > cap) { cnt = cap; if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[4], 1); }   // the exporter overflowed
-  const int span = gridDim.x * blockDim.x;
-  for (int j0 = blockIdx.x * blockDim.x; j0 < cnt; j0 += span) {
-    const int j = j0 + threadIdx.x;
-    bool take = false;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < cnt) {
-      p = blk[1 + j];
-      const int fx = bk_fine(p.x, h.mn[0], h.inv_f, h.nf[0]);
-      take = fx >= lo && fx <= hi;
+  __shared__ int s_app[17];
+  const int span = gridDim.x * 1024;
+  for (int j0 = blockIdx.x * 1024; j0 < cnt; j0 += span) {
+    bool take[4];
+    float4 p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = j0 + q * 256 + threadIdx.x;
+      take[q] = false;
+      p[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < cnt) {
+        p[q] = blk[1 + j];
+        const int fx = bk_fine(p[q].x, h.mn[0], h.inv_f, h.nf[0]);
+        take[q] = fx >= lo && fx <= hi;
+      }
     }
-    const int lane = threadIdx.x & 63;
-    const unsigned long long bal = __ballot(take);
-    int base = 0;
-    if (lane == 0 && bal) base = atomicAdd(imp_count, __popcll(bal));
-    base = __shfl(base, 0);
-    if (take) {
-      const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-      if (slot < imp_cap) { imp0[slot] = p; imp1[slot] = blk[(int64_t)cap + 1 + 1 + j]; }
+    int slot[4];
+    iso_block_append4(take, imp_count, s_app, slot);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (slot[q] < 0) continue;
+      if (slot[q] < imp_cap) { imp0[slot[q]] = p[q]; imp1[slot[q]] = blk[(int64_t)cap + 1 + 1 + j0 + q * 256 + threadIdx.x]; }
       else atomicAdd(&counters[5], 1);                                                                // import overflow
     }
   }
@@ -1090,7 +1122,7 @@ extern "C" int iso_bricks_build(const float* points, const float* normals, const
     hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 1024)), dim3(256), 0, s, points, n_own, w.hdr, w.cnt,
                        w.slot);
   if (import_max > 0)
-    hipLaunchKernelGGL(k_brick_count_recs, dim3(iso_stream_grid(import_max, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_brick_count_recs, dim3(iso_stream_grid(import_max, 1024)), dim3(256), 0, s,
                        (const float4*)import_rec0, import_count, import_max, w.hdr, w.cnt, w.slot);
   int rc = iso_frnn_scan_cells(w.cnt, w.off, reinterpret_cast<const float*>(w.hdr), 1, w.G, 3, w.scan_ws,
                                w.scan_ws_bytes, stream);
@@ -1101,7 +1133,7 @@ extern "C" int iso_bricks_build(const float* points, const float* normals, const
   if (import_max > 0)
     hipLaunchKernelGGL(k_brick_scatter_recs, dim3(iso_stream_grid(import_max, 256)), dim3(256), 0, s,
                        (const float4*)import_rec0, (const float4*)import_rec1, w.hdr, w.off, w.slot, w.rec0, w.rec1);
-  hipLaunchKernelGGL(k_brick_list, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, s, w.hdr, w.off, w.list, w.counters);
+  hipLaunchKernelGGL(k_brick_list, dim3(iso_stream_grid(w.G, 1024)), dim3(256), 0, s, w.hdr, w.off, w.list, w.counters);
   ISO_CHECK_LAUNCH("iso_bricks_build");
   return ISO_OK;
 }
@@ -1127,7 +1159,7 @@ extern "C" int iso_halo_export(void* workspace, const float* points, const float
   hipStream_t s = (hipStream_t)stream;
   iso_zero_words(export_buf, 4, s);
   if (n_own > 0)
-    hipLaunchKernelGGL(k_halo_export, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, normals, payload, n_own,
+    hipLaunchKernelGGL(k_halo_export, dim3(iso_stream_grid(n_own, 1024)), dim3(256), 0, s, points, normals, payload, n_own,
                        (const BrickHdr*)workspace, rank_boxes, world, rank, halo_cells, (float4*)export_buf, (int)capacity);
   ISO_CHECK_LAUNCH("iso_halo_export");
   return ISO_OK;

@@ -48,6 +48,40 @@ __device__ __forceinline__ float iso_eps_denom(float x, float eps) {
   return s * (a < eps ? eps : a);
 }
 
+// Append the flagged ones of 4 items per thread (256-thread workgroup, all threads call) to a list whose length is
+// *counter: ONE returning atomic per call.  Same-address returning atomics retire a few ns apart whatever issues
+// them, so one per wave makes the atomics the whole duration of a compaction kernel at a few thousand waves.
+// slot[k] = position of item k (item k of thread t is element base + k * 256 + t of the round), -1 if not taken.
+// smem: 17 ints of LDS, free again after the call returns on every thread's next barrier.
+__device__ __forceinline__ void iso_block_append4(const bool (&take)[4], int32_t* counter, int* smem, int (&slot)[4]) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned long long bal[4];
+  __syncthreads();                                  // the previous round's readers of smem are done
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bal[k] = __ballot(take[k]);
+    if (lane == 0) smem[k * 4 + wv] = __popcll(bal[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += smem[q];
+    smem[16] = tot ? atomicAdd(counter, tot) : 0;
+  }
+  __syncthreads();
+  int at = smem[16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    slot[k] = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q == wv && take[k]) slot[k] = at + __popcll(bal[k] & ((1ull << lane) - 1ull));
+      at += smem[k * 4 + q];
+    }
+  }
+}
+
 __device__ __forceinline__ float iso_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
