@@ -980,12 +980,29 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
   auto tile_of = [&](int i) { return ((i / (T * ty_rows)) * TY + ty_begin + (i / T) % ty_rows) * T + i % T; };
   auto count_of = [&](int tile) { return tile_off[tile + 1] - tile_off[tile]; };
   // slice size: total candidates / kTargetItems (so that a small band still yields enough work items to
-  // fill the chip), within [256, kSlice], doubled until the slices of all cut tiles fit the scratch slots
+  // fill the chip), within [256, kSlice], doubled until the slices of all cut tiles fit the scratch slots.
+  // A thread's first four tiles (all of them up to 4096 tiles) are read once and kept in registers: every
+  // pass below would otherwise start with the same global-memory latency.
+  int cc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = threadIdx.x + k * (int)blockDim.x;
+    cc[k] = i < tiles ? count_of(tile_of(i)) : 0;
+  }
+  // visit(f): f(i, tile, count) for every tile of this thread
+  auto visit = [&](auto&& f) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + k * (int)blockDim.x;
+      if (i < tiles) f(i, tile_of(i), cc[k]);
+    }
+    for (int i = threadIdx.x + 4 * (int)blockDim.x; i < tiles; i += blockDim.x) f(i, tile_of(i), count_of(tile_of(i)));
+  };
   if (threadIdx.x == 0) s_slots = 0;
   __syncthreads();
   {
     int mine = 0;
-    for (int i = threadIdx.x; i < tiles; i += blockDim.x) mine += count_of(tile_of(i));
+    visit([&](int, int, int c) { mine += c; });
     if (mine) atomicAdd(&s_slots, mine);
   }
   __syncthreads();
@@ -999,10 +1016,7 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
     __syncthreads();
     const int sl = s_slice;
     int mine = 0;
-    for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
-      const int c = count_of(tile_of(i));
-      if (2 * c > 3 * sl) mine += (c + sl - 1) / sl;
-    }
+    visit([&](int, int, int c) { if (2 * c > 3 * sl) mine += (c + sl - 1) / sl; });
     if (mine) atomicAdd(&s_slots, mine);
     __syncthreads();
     const bool fits = s_slots <= max_slots;
@@ -1017,8 +1031,8 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
   if (threadIdx.x == 0) { s_slots = 0; s_heavy = 0; }
   __syncthreads();
   auto bucket_of = [&](int c) { return min(c >> 6, 63); };
-  for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
-    const int tile = tile_of(i), c = count_of(tile), ns = slices_of(c);
+  visit([&](int, int tile, int c) {
+    const int ns = slices_of(c);
     if (ns > 1) {
       const int b0 = atomicAdd(&s_slots, ns);
       heavy[atomicAdd(&s_heavy, 1)] = make_int4(tile, b0, ns, 0);
@@ -1026,7 +1040,7 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
     } else {
       atomicAdd(&hist[bucket_of(c)], 1);
     }
-  }
+  });
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = s_slots;
@@ -1035,10 +1049,9 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
     counters[1] = s_heavy;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
-    const int tile = tile_of(i), c = count_of(tile);
+  visit([&](int, int tile, int c) {
     if (slices_of(c) == 1) items[atomicAdd(&base[bucket_of(c)], 1)] = make_int4(tile, 0, 1, 0);
-  }
+  });
 }
 
 // K-best of a heavy tile's pixels from the K-best lists of its slices (same (z, idx) order: the result
@@ -1212,32 +1225,49 @@ static inline BlkGeo make_blk(int H, int W) {
   return g;
 }
 
+// eight lanes per block, one pixel row each (a thread per block walked its 64 pixels as a chain of loads)
 __global__ void k_grad_blocks(const float* __restrict__ grad_occ, Frame F, BlkGeo G, int N,
                               uint8_t* __restrict__ blk) {
   const int64_t total = (int64_t)N * G.NBx * G.NBy;
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total;
-       b += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t span = (int64_t)gridDim.x * blockDim.x / 8;
+  const int row = threadIdx.x & 7;
+  for (int64_t b0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 8;; b0 += span) {
+    if (b0 - (threadIdx.x & 63) / 8 >= total) break;                   // wave-uniform exit: the shuffles below need all lanes
+    const bool live = b0 < total;
+    const int64_t b = live ? b0 : 0;
     const int bx = b % G.NBx, by = (b / G.NBx) % G.NBy, n = b / ((int64_t)G.NBx * G.NBy);
-    uint8_t any = 0;
-    for (int y = by * GB; y < min(F.H, (by + 1) * GB) && !any; ++y)
+    const int y = by * GB + row;
+    int any = 0;
+    if (live && y < F.H)
       for (int x = bx * GB; x < min(F.W, (bx + 1) * GB); ++x)
-        if (grad_occ[((int64_t)n * F.H + y) * F.W + x] != 0.0f) { any = 1; break; }
-    blk[b] = any;
+        any |= grad_occ[((int64_t)n * F.H + y) * F.W + x] != 0.0f;
+    any |= __shfl_xor(any, 1);
+    any |= __shfl_xor(any, 2);
+    any |= __shfl_xor(any, 4);
+    if (live && row == 0) blk[b] = (uint8_t)any;
   }
 }
 
-// second level: 64x64-pixel super blocks (8x8 of the 8x8 blocks)
+// second level: 64x64-pixel super blocks (8x8 of the 8x8 blocks); eight lanes per super block, one row of blocks each
 __global__ void k_grad_superblocks(const uint8_t* __restrict__ blk, BlkGeo G, int N,
                                    uint8_t* __restrict__ blk2) {
   const int64_t total = (int64_t)N * G.NB2x * G.NB2y;
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total;
-       b += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t span = (int64_t)gridDim.x * blockDim.x / 8;
+  const int row = threadIdx.x & 7;
+  for (int64_t b0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 8;; b0 += span) {
+    if (b0 - (threadIdx.x & 63) / 8 >= total) break;
+    const bool live = b0 < total;
+    const int64_t b = live ? b0 : 0;
     const int bx = b % G.NB2x, by = (b / G.NB2x) % G.NB2y, n = b / ((int64_t)G.NB2x * G.NB2y);
-    uint8_t any = 0;
-    for (int y = by * 8; y < min(G.NBy, (by + 1) * 8) && !any; ++y)
+    const int y = by * 8 + row;
+    int any = 0;
+    if (live && y < G.NBy)
       for (int x = bx * 8; x < min(G.NBx, (bx + 1) * 8); ++x)
-        if (blk[((int64_t)n * G.NBy + y) * G.NBx + x]) { any = 1; break; }
-    blk2[b] = any;
+        any |= blk[((int64_t)n * G.NBy + y) * G.NBx + x] != 0;
+    any |= __shfl_xor(any, 1);
+    any |= __shfl_xor(any, 2);
+    any |= __shfl_xor(any, 4);
+    if (live && row == 0) blk2[b] = (uint8_t)any;
   }
 }
 
@@ -2014,9 +2044,9 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
   hipStream_t s = (hipStream_t)stream;
   uint8_t* blk = (uint8_t*)workspace;
   uint8_t* blk2 = blk + (int64_t)n_clouds * G.NBx * G.NBy;
-  hipLaunchKernelGGL(k_grad_blocks, dim3(iso_stream_grid((int64_t)n_clouds * G.NBx * G.NBy, 256)), dim3(256),
+  hipLaunchKernelGGL(k_grad_blocks, dim3(iso_stream_grid((int64_t)n_clouds * G.NBx * G.NBy * 8, 256)), dim3(256),
                      0, s, grad_occ, F, G, n_clouds, blk);
-  hipLaunchKernelGGL(k_grad_superblocks, dim3(iso_stream_grid((int64_t)n_clouds * G.NB2x * G.NB2y, 256)),
+  hipLaunchKernelGGL(k_grad_superblocks, dim3(iso_stream_grid((int64_t)n_clouds * G.NB2x * G.NB2y * 8, 256)),
                      dim3(256), 0, s, blk, G, n_clouds, blk2);
   int32_t* heavy_count = (int32_t*)((uint8_t*)workspace + bwd_maps_bytes(n_clouds, image_size, image_width));
   int32_t* heavy = heavy_count + 16;
