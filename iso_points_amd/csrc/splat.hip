@@ -1190,6 +1190,18 @@ __global__ void k_composite_backward(const int32_t* __restrict__ idx, const floa
 // (rasterizer.py:850-856)
 __global__ void k_mark_visible(const int32_t* __restrict__ idx, int K, int64_t npix,
                                uint8_t* __restrict__ visible) {
+  if ((K & 3) == 0 && ((uintptr_t)idx & 15) == 0) {                    // four list entries per 16-byte load
+    const int4* __restrict__ idx4 = reinterpret_cast<const int4*>(idx);
+    const int64_t nq = npix * (K / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+      const int4 p = idx4[i];
+      if (p.x >= 0) visible[p.x] = 1;
+      if (p.y >= 0) visible[p.y] = 1;
+      if (p.z >= 0) visible[p.z] = 1;
+      if (p.w >= 0) visible[p.w] = 1;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
        i += (int64_t)gridDim.x * blockDim.x) {
     if (idx[i * K] < 0) continue;
@@ -1982,21 +1994,39 @@ __global__ void k_z_scale(ZScale* zs, int terms_log2) {
   zs->exp2 = e;
 }
 
+__device__ __forceinline__ void z_scatter_one(int p, float g, int e, long long* __restrict__ acc) {
+  if (g == 0.0f) return;
+  if (g != g || fabsf(g) > 3.0e38f) {                                // poison: the point ends up NaN
+    atomicMax(&acc[p], 1ll << 62);
+    return;
+  }
+  const long long q = __double2ll_rn(ldexp((double)g, e));
+  atomicAdd(reinterpret_cast<unsigned long long*>(&acc[p]), (unsigned long long)q);
+}
+
 __global__ void k_z_scatter(const int32_t* __restrict__ idx, const float* __restrict__ gz, int K, int64_t npix,
                             const ZScale* __restrict__ zs, long long* __restrict__ acc) {
   const int e = zs->exp2;
+  if ((K & 3) == 0 && (((uintptr_t)idx | (uintptr_t)gz) & 15) == 0) {   // a pixel's lists as 16-byte loads
+    const int4* __restrict__ idx4 = reinterpret_cast<const int4*>(idx);
+    const float4* __restrict__ gz4 = reinterpret_cast<const float4*>(gz);
+    const int64_t nq = npix * (K / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+      const int4 p = idx4[i];
+      if (p.x < 0) continue;                                         // -1 padding is a suffix of a pixel's list
+      const float4 g = gz4[i];
+      z_scatter_one(p.x, g.x, e, acc);
+      if (p.y >= 0) z_scatter_one(p.y, g.y, e, acc);
+      if (p.z >= 0) z_scatter_one(p.z, g.z, e, acc);
+      if (p.w >= 0) z_scatter_one(p.w, g.w, e, acc);
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
     for (int k = 0; k < K; ++k) {
       const int p = idx[i * K + k];
       if (p < 0) break;
-      const float g = gz[i * K + k];
-      if (g == 0.0f) continue;
-      if (g != g || fabsf(g) > 3.0e38f) {                            // poison: the point ends up NaN
-        atomicMax(&acc[p], 1ll << 62);
-        continue;
-      }
-      const long long q = __double2ll_rn(ldexp((double)g, e));
-      atomicAdd(reinterpret_cast<unsigned long long*>(&acc[p]), (unsigned long long)q);
+      z_scatter_one(p, gz[i * K + k], e, acc);
     }
   }
 }
