@@ -596,12 +596,18 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
 }
 
 // ---- rings of bricks around a query (tail kernels: one wave per query) ---------------------------
-// All lanes walk the same column of bricks and split its records (a ring has as few as one column).
-// The record ranges of up to 64 columns are fetched by 64 lanes at once and handed round with shuffles: a
-// ring then costs one global-memory latency for its bounds instead of one per column.
-template <class Body>
+// The record ranges of up to 64 columns of bricks are fetched by 64 lanes at once (a ring then costs one
+// global-memory latency for its bounds instead of one per column); the records of those columns are one index
+// space split over the lanes.  bound() (wave-uniform, asked once per 64 columns) is the squared distance beyond
+// which a record cannot matter any more -- the radius, or the K-th distance found so far: bricks whose box lies
+// farther than that from the query are dropped before their records are read (a stray point of the SIREN level
+// set 0.15 off the surface would otherwise scan the whole shell of bricks that reaches the surface anywhere).
+struct WalkGeo { float qx, qy, qz, mnx, mny, mnz, B; };
+
+template <class Fetch, class Body, class Bound>
 __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz, int nbx, int nby, int nbz,
-                                             const int32_t* __restrict__ off, int lane, Body&& body) {
+                                             const int32_t* __restrict__ off, int lane, const WalkGeo& G,
+                                             Fetch&& fetch, Body&& body, Bound&& bound) {
   const int x0 = max(qbx - rho, 0), x1 = min(qbx + rho, nbx - 1);
   const int y0 = max(qby - rho, 0), y1 = min(qby + rho, nby - 1);
   if (x0 > x1 || y0 > y1) return;
@@ -609,24 +615,57 @@ __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz,
   for (int c0 = 0; c0 < ncols; c0 += 64) {
     int s0 = 0, e0 = 0, s1 = 0, e1 = 0;                  // this lane's column: one z-run (edge) or two caps
     const int col = c0 + lane;
+    const float far2 = bound();
+    // squared distance from the query to bricks [b0, b1] of one axis, shortened by a margin that covers the
+    // rounding of the brick assignment (so that "farther than far2" is never claimed wrongly)
+    auto gap = [&](float q, float mn, int b0, int b1) {
+      const float lo = mn + (float)b0 * G.B, hi = mn + (float)(b1 + 1) * G.B;
+      return fmaxf(0.f, fmaxf(lo - q, q - hi) - 1e-3f * G.B);
+    };
     if (col < ncols) {
       const int x = x0 + col / ny, y = y0 + col % ny;
       const bool edge = (x == qbx - rho) || (x == qbx + rho) || (y == qby - rho) || (y == qby + rho);
       const int cb = (x * nby + y) * nbz;
+      const float gx = gap(G.qx, G.mnx, x, x), gy = gap(G.qy, G.mny, y, y);
+      const float gxy2 = gx * gx + gy * gy;
+      auto beyond = [&](int za, int zb) { const float gz = gap(G.qz, G.mnz, za, zb); return gxy2 + gz * gz > far2; };
       if (edge) {
         const int za = max(qbz - rho, 0), zb = min(qbz + rho, nbz - 1);
-        if (za <= zb) { s0 = off[BK_CPB * (cb + za)]; e0 = off[BK_CPB * (cb + zb + 1)]; }
+        if (za <= zb && !beyond(za, zb)) { s0 = off[BK_CPB * (cb + za)]; e0 = off[BK_CPB * (cb + zb + 1)]; }
       } else {
         const int za = qbz - rho, zb = qbz + rho;
-        if (za >= 0) { s0 = off[BK_CPB * (cb + za)]; e0 = off[BK_CPB * (cb + za + 1)]; }
-        if (zb < nbz) { s1 = off[BK_CPB * (cb + zb)]; e1 = off[BK_CPB * (cb + zb + 1)]; }
+        if (za >= 0 && !beyond(za, za)) { s0 = off[BK_CPB * (cb + za)]; e0 = off[BK_CPB * (cb + za + 1)]; }
+        if (zb < nbz && !beyond(zb, zb)) { s1 = off[BK_CPB * (cb + zb)]; e1 = off[BK_CPB * (cb + zb + 1)]; }
       }
     }
-    const int nc = min(64, ncols - c0);
-    for (int c = 0; c < nc; ++c) {
-      const int a0 = __shfl(s0, c), b0 = __shfl(e0, c), a1 = __shfl(s1, c), b1 = __shfl(e1, c);
-      for (int i = a0 + lane; i < b0; i += 64) body(i);
-      for (int i = a1 + lane; i < b1; i += 64) body(i);
+    // a lane finds the column of its item in the prefix sums of the column lengths
+    const int len0 = e0 - s0, len = len0 + (e1 - s1);
+    int inc = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    const int ex = inc - len, total = __shfl(inc, 63);
+    for (int j0 = 0; j0 < total; j0 += 256) {                // four items per lane and trip: their loads overlap
+      int at[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * 64 + lane;
+        int c = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {         // the last column whose prefix is <= j holds item j
+          const int cand = c + step;
+          const int v = __shfl(ex, cand & 63);
+          if (cand < 64 && v <= j) c = cand;
+        }
+        const int cs0 = __shfl(s0, c), cl0 = __shfl(len0, c), cs1 = __shfl(s1, c), cex = __shfl(ex, c);
+        const int r = j - cex;
+        at[u] = j < total ? (r < cl0 ? cs0 + r : cs1 + (r - cl0)) : -1;
+      }
+      decltype(fetch(0)) rec[4];                             // loads first (no control flow in between), then the work
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rec[u] = fetch(at[u] >= 0 ? at[u] : 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (at[u] >= 0) body(at[u], rec[u]);
     }
   }
 }
@@ -699,9 +738,18 @@ __global__ __launch_bounds__(64) void k_brick_resample_tail(
     float wd = FLT_MAX;
     int wi = 0x7fffffff;
     int found = 0;
+    const WalkGeo geo = {qx, qy, qz, h.mn[0], h.mn[1], h.mn[2], B};
+    float kth_seen = FLT_MAX;                               // K-th distance of the wave at the last ring end
+    // a lane that holds K records within wd proves that the K-th distance of the query is <= wd
+    auto far2 = [&]() {
+      float m = wd;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+      return fminf(h.r2, fminf(m, kth_seen));
+    };
     for (int rho = 0; rho <= rho_max; ++rho) {
-      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, [&](int i) {
-        const float4 c = rec0[i];
+      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, [&](int i) { return rec0[i]; },
+                   [&](int i, const float4& c) {
         const float d2 = bk_d2(qx, qy, qz, c.x, c.y, c.z);
         if (d2 < h.r2) {
           if (found < KMAX) ++found;
@@ -712,7 +760,7 @@ __global__ __launch_bounds__(64) void k_brick_resample_tail(
             for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wd = best.d[j]; wi = best.id[j]; }
           }
         }
-      });
+      }, far2);
       if (rho >= 1) {
         const float gg = (float)rho * B * 0.999f;
         if (gg >= h.r) break;
@@ -721,6 +769,7 @@ __global__ __launch_bounds__(64) void k_brick_resample_tail(
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
         if (tot >= K) {
           const float kth = wave_merge3<KMAX>(best, K, [](int, float, int, int) {});
+          kth_seen = fminf(kth_seen, kth);
           if (kth < FLT_MAX && kth <= gg * gg) break;
         }
       }
@@ -963,17 +1012,27 @@ __global__ __launch_bounds__(64) void k_brick_h_tail(
     TopF<7> best;
     best.init();
     float m7[7];
+    const WalkGeo geo = {qx, qy, qz, h.mn[0], h.mn[1], h.mn[2], B};
+    float kth_seen = FLT_MAX;
+    auto far2 = [&]() {                                     // a lane's own 7th distance bounds the query's
+      float m = best.d[6];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+      return fminf(h.r2, fminf(m, kth_seen));
+    };
     for (int rho = 0; rho <= rho_max; ++rho) {
-      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, [&](int i) {
-        const float4 c = rec0[i];
-        if (!((__float_as_int(rec1[i].w) >> v) & 1)) return;
+      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo,
+                   [&](int i) { float4 c = rec0[i]; c.w = rec1[i].w; return c; },        // position + view mask
+                   [&](int, const float4& c) {
+        if (!((__float_as_int(c.w) >> v) & 1)) return;
         const float d2 = bk_d2(qx, qy, qz, c.x, c.y, c.z);
         if (d2 < h.r2) best.push(d2);
-      });
+      }, far2);
       if (rho >= 1) {
         const float gg = (float)rho * B * 0.999f;
         if (gg >= h.r) break;
         wave_merge_f7(best, m7);
+        kth_seen = fminf(kth_seen, m7[6]);
         if (m7[6] < FLT_MAX && m7[6] <= gg * gg) break;
       }
     }
