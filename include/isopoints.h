@@ -614,6 +614,15 @@ int iso_splat_z_scatter(const int32_t* idx, const float* grad_zbuf, int64_t n_pi
                         int64_t pixels_per_view, int32_t* zscale, int64_t* acc, void* stream);
 int iso_splat_z_finish(const int64_t* acc, const int32_t* zscale, int64_t row0, int64_t n_rows,
                        float* grad_points, void* stream);
+/* The same for the band of EVERY view in one call each (a rank's band = rows [y0, y1) of all n_views images of the
+ * (N,H,W,K) arrays; idx / grad_zbuf point at the band's first pixel of view 0, view_pixels = H * W, band_pixels =
+ * (y1 - y0) * W): iso_splat_band_marks = iso_splat_mark_visible + iso_splat_z_absmax (zscale zeroed first) over
+ * the n_views slices, iso_splat_band_z_scatter = iso_splat_z_scatter over them (pixels_per_view = view_pixels).
+ * Two launches per call instead of two per view -- a rank's share of a cycle is a chain of small kernels.   */
+int iso_splat_band_marks(const int32_t* idx, const float* grad_zbuf, int n_views, int64_t view_pixels,
+                         int64_t band_pixels, int points_per_pixel, uint8_t* visible, int32_t* zscale, void* stream);
+int iso_splat_band_z_scatter(const int32_t* idx, const float* grad_zbuf, int n_views, int64_t view_pixels,
+                             int64_t band_pixels, int points_per_pixel, int32_t* zscale, int64_t* acc, void* stream);
 /* N ranks: the packed per-view arrays of the WHOLE cloud (view-major, then rank, then the rank's own
  * order = the single-GPU order when the ranks hold consecutive ranges of the cloud) from the
  * all-gathered per-rank outputs of iso_splat_front.  gathered: world blocks of 12 * capacity floats

@@ -92,6 +92,8 @@ SIGNATURES = {
     "iso_splat_z_absmax": (_I, [_P, _L, _P, _P]),
     "iso_splat_z_scatter": (_I, [_P, _P, _L, _I, _L, _P, _P, _P]),
     "iso_splat_z_finish": (_I, [_P, _P, _L, _L, _P, _P]),
+    "iso_splat_band_marks": (_I, [_P, _P, _I, _L, _L, _I, _P, _P, _P]),
+    "iso_splat_band_z_scatter": (_I, [_P, _P, _I, _L, _L, _I, _P, _P, _P]),
     "iso_splat_repack": (_I, [_P, _L, _I, _I, _I, _P, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "iso_insert_fathers": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P]),
     "iso_insert_children": (_I, [_P, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P]),

@@ -1188,8 +1188,9 @@ __global__ void k_composite_backward(const int32_t* __restrict__ idx, const floa
 // ---------------------------------------------------------------- backward
 // visible[p] = 1 for every point listed in a pixel whose first slot is filled
 // (rasterizer.py:850-856)
-__global__ void k_mark_visible(const int32_t* __restrict__ idx, int K, int64_t npix,
-                               uint8_t* __restrict__ visible) {
+__global__ void k_mark_visible(const int32_t* __restrict__ idx0, int K, int64_t npix,
+                               uint8_t* __restrict__ visible, int64_t view_stride = 0) {
+  const int32_t* __restrict__ idx = idx0 + (int64_t)blockIdx.y * view_stride * K;   // (N views of a band: grid.y)
   if ((K & 3) == 0 && ((uintptr_t)idx & 15) == 0) {                    // four list entries per 16-byte load
     const int4* __restrict__ idx4 = reinterpret_cast<const int4*>(idx);
     const int64_t nq = npix * (K / 4);
@@ -1958,7 +1959,9 @@ extern "C" int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbu
 // the exactly rounded sum (error <= 2^-44 max|grad| per term), bit-stable from run to run.
 struct ZScale { unsigned max_bits; int exp2; };
 
-__global__ __launch_bounds__(256) void k_z_absmax(const float* __restrict__ gz, int64_t n, ZScale* __restrict__ zs) {
+__global__ __launch_bounds__(256) void k_z_absmax(const float* __restrict__ gz0, int64_t n, ZScale* __restrict__ zs,
+                                                  int64_t view_stride = 0) {
+  const float* __restrict__ gz = gz0 + (int64_t)blockIdx.y * view_stride;
   __shared__ unsigned sm[4];
   unsigned m = 0u;
   const int64_t n4 = n / 4;
@@ -2004,8 +2007,10 @@ __device__ __forceinline__ void z_scatter_one(int p, float g, int e, long long* 
   atomicAdd(reinterpret_cast<unsigned long long*>(&acc[p]), (unsigned long long)q);
 }
 
-__global__ void k_z_scatter(const int32_t* __restrict__ idx, const float* __restrict__ gz, int K, int64_t npix,
-                            const ZScale* __restrict__ zs, long long* __restrict__ acc) {
+__global__ void k_z_scatter(const int32_t* __restrict__ idx0, const float* __restrict__ gz0, int K, int64_t npix,
+                            const ZScale* __restrict__ zs, long long* __restrict__ acc, int64_t view_stride = 0) {
+  const int32_t* __restrict__ idx = idx0 + (int64_t)blockIdx.y * view_stride * K;
+  const float* __restrict__ gz = gz0 + (int64_t)blockIdx.y * view_stride * K;
   const int e = zs->exp2;
   if ((K & 3) == 0 && (((uintptr_t)idx | (uintptr_t)gz) & 15) == 0) {   // a pixel's lists as 16-byte loads
     const int4* __restrict__ idx4 = reinterpret_cast<const int4*>(idx);
@@ -2135,6 +2140,48 @@ extern "C" int iso_splat_z_scatter(const int32_t* idx, const float* grad_zbuf, i
     hipLaunchKernelGGL(k_z_scatter, dim3(iso_stream_grid(n_pixels, 256)), dim3(256), 0, s, idx, grad_zbuf, points_per_pixel,
                        n_pixels, reinterpret_cast<const ZScale*>(zscale), reinterpret_cast<long long*>(acc));
   ISO_CHECK_LAUNCH("iso_splat_z_scatter");
+  return ISO_OK;
+}
+
+// The three band calls of a cycle for all views at once (grid.y = view): the same kernels on
+// idx / grad_zbuf + v * view_pixels * K for v < n_views (the band's rows of every view of an (N,H,W,K) array).
+extern "C" int iso_splat_band_marks(const int32_t* idx, const float* grad_zbuf, int n_views, int64_t view_pixels,
+                                    int64_t band_pixels, int points_per_pixel, uint8_t* visible, int32_t* zscale,
+                                    void* stream) {
+  ISO_REQUIRE(zscale && n_views >= 0 && view_pixels >= band_pixels && band_pixels >= 0 && points_per_pixel >= 1,
+              ISO_ERR_INVALID, "iso_splat_band_marks: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  iso_zero_words(zscale, 2, s);
+  if (band_pixels == 0 || n_views == 0) return ISO_OK;
+  ISO_REQUIRE(idx && grad_zbuf && visible, ISO_ERR_INVALID, "iso_splat_band_marks: null pointer");
+  ISO_REQUIRE((((uintptr_t)grad_zbuf) & 15) == 0 && ((view_pixels * points_per_pixel) & 3) == 0 &&
+                  ((band_pixels * points_per_pixel) & 3) == 0,
+              ISO_ERR_UNSUPPORTED, "iso_splat_band_marks: grad_zbuf slices must be 16-byte aligned");
+  hipLaunchKernelGGL(k_mark_visible, dim3(iso_stream_grid(band_pixels, 256), n_views), dim3(256), 0, s, idx,
+                     points_per_pixel, band_pixels, visible, view_pixels);
+  const int64_t n = band_pixels * points_per_pixel;
+  int gm = iso_div_up(n, 256 * 16); if (gm > 1024) gm = 1024; if (gm < 1) gm = 1;
+  hipLaunchKernelGGL(k_z_absmax, dim3(gm, n_views), dim3(256), 0, s, grad_zbuf, n, reinterpret_cast<ZScale*>(zscale),
+                     view_pixels * points_per_pixel);
+  ISO_CHECK_LAUNCH("iso_splat_band_marks");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_band_z_scatter(const int32_t* idx, const float* grad_zbuf, int n_views, int64_t view_pixels,
+                                        int64_t band_pixels, int points_per_pixel, int32_t* zscale, int64_t* acc,
+                                        void* stream) {
+  ISO_REQUIRE(zscale && acc && n_views >= 0 && view_pixels > 0 && band_pixels >= 0 && points_per_pixel >= 1 &&
+                  ((idx && grad_zbuf) || band_pixels == 0),
+              ISO_ERR_INVALID, "iso_splat_band_z_scatter: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int terms_log2 = 0;
+  while ((1ll << terms_log2) < view_pixels) ++terms_log2;
+  hipLaunchKernelGGL(k_z_scale, dim3(1), dim3(1), 0, s, reinterpret_cast<ZScale*>(zscale), terms_log2);
+  if (band_pixels > 0 && n_views > 0)
+    hipLaunchKernelGGL(k_z_scatter, dim3(iso_stream_grid(band_pixels, 256), n_views), dim3(256), 0, s, idx, grad_zbuf,
+                       points_per_pixel, band_pixels, reinterpret_cast<const ZScale*>(zscale),
+                       reinterpret_cast<long long*>(acc), view_pixels);
+  ISO_CHECK_LAUNCH("iso_splat_band_z_scatter");
   return ISO_OK;
 }
 

@@ -352,26 +352,21 @@ class IsoCycle(object):
         y0, y1 = self.band_rows()
         occ_grad = yield ("all_reduce", occ_grad_band.contiguous(), "sum")
         vis = torch.zeros((rows,), dtype=torch.uint8, device=dev)
-        zs = torch.zeros((2,), dtype=torch.int32, device=dev)
         zmax = torch.zeros((2,), dtype=torch.int32, device=dev)
-        for n in range(N):
-            if y1 > y0:
-                _lib.call("iso_splat_mark_visible", p(idx[n, y0:y1]), (y1 - y0) * S, K, p(vis), _lib.stream())
-                _lib.call("iso_splat_z_absmax", p(zbuf_grad_band[n, y0:y1]), (y1 - y0) * S * K, p(zs), _lib.stream())
-                zmax = torch.maximum(zmax, zs)
+        H, W = idx.shape[1], idx.shape[2]
+        band = (y1 - y0) * W                         # the band of every view in one call (grid.y = view)
+        _lib.call("iso_splat_band_marks", p(idx[0, y0:y1]) if band else None, p(zbuf_grad_band[0, y0:y1]) if band else None,
+                  N, H * W, band, K, p(vis), p(zmax), _lib.stream())
         vis = yield ("all_reduce", vis, "max")
         zmax = yield ("all_reduce", zmax, "max")
         rs_ = median_radius(vis, fr["radii"], first, num, scal, max_pts=fr["max_pts"])
         grad = _C._backward(fr["ndc"], fr["radii"], occ_grad, fr["own_first"], fr["own_num"], visible=vis, rs=rs_,
                             max_pts=self.n_own)
         acc = torch.zeros((rows,), dtype=torch.int64, device=dev)
-        for n in range(N):
-            if y1 > y0:
-                _lib.call("iso_splat_z_scatter", p(idx[n, y0:y1]), p(zbuf_grad_band[n, y0:y1]), (y1 - y0) * S, K, S * S,
-                          p(zmax), p(acc), _lib.stream())
+        # (a rank without tile rows still derives the exponent: the call then only runs the scale kernel)
+        _lib.call("iso_splat_band_z_scatter", p(idx[0, y0:y1]) if band else None,
+                  p(zbuf_grad_band[0, y0:y1]) if band else None, N, H * W, band, K, p(zmax), p(acc), _lib.stream())
         acc = yield ("all_reduce", acc, "sum")
-        if y1 <= y0:      # a rank without tile rows still has to know the exponent
-            _lib.call("iso_splat_z_scatter", None, None, 0, K, S * S, p(zmax), p(acc), _lib.stream())
         _lib.call("iso_splat_z_finish", p(acc), p(zmax), 0, rows, p(grad), _lib.stream())
         return grad
 
