@@ -547,7 +547,9 @@ int iso_bricks_build(const float* points, const float* normals, const int32_t* p
  * whose K-th neighbour lies farther -- check their search ball against the imported band and count the
  * queries that left it).  The grid's counters: slot 4 an exporter ran out of capacity, slot 5 the import
  * buffer did, slot 6 tail queries that needed more than the imported band.                       */
-int iso_bricks_params(const float* bbox, int64_t n_total, int64_t n_own, int64_t id_base, float radius,
+/* boxes: n_boxes rows of 8 floats (iso_points_bbox layout: every rank's local box as all-gathered); the header is
+ * written for their union.                                                                          */
+int iso_bricks_params(const float* boxes, int n_boxes, int64_t n_total, int64_t n_own, int64_t id_base, float radius,
                       int knn_k, float cell_scale, void* workspace, int64_t n_max, void* stream);
 int iso_halo_export(void* workspace, const float* points, const float* normals, const int32_t* payload,
                     int64_t n_own, const float* rank_boxes, int world, int rank, int halo_cells,

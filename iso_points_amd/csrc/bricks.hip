@@ -61,12 +61,16 @@ __device__ __forceinline__ int wave_incl_scan_i(int v) {
 
 // ---- header ------------------------------------------------------------------------------------
 // bbox: [min xyz, 0, max xyz, 0] (iso_points_bbox layout; for N ranks the caller reduces it first)
-__global__ void k_bricks_params(const float* __restrict__ bbox, int64_t n_total, int64_t n_own, int64_t id_base,
+__global__ void k_bricks_params(const float* __restrict__ bbox, int n_boxes, int64_t n_total, int64_t n_own, int64_t id_base,
                                 float radius, int knn_k, float cell_scale, int nb_cap, BrickHdr* __restrict__ h,
                                 int32_t* __restrict__ counters) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float mn[3], ext[3];
-  for (int a = 0; a < 3; ++a) { mn[a] = bbox[a]; ext[a] = bbox[4 + a] - bbox[a]; if (!(ext[a] >= 0.f)) ext[a] = 0.f; }
+  for (int a = 0; a < 3; ++a) {                     // the union of the n_boxes boxes (N ranks: every rank's local box)
+    float lo = bbox[a], hi = bbox[4 + a];
+    for (int k = 1; k < n_boxes; ++k) { lo = fminf(lo, bbox[k * 8 + a]); hi = fmaxf(hi, bbox[k * 8 + 4 + a]); }
+    mn[a] = lo; ext[a] = hi - lo; if (!(ext[a] >= 0.f)) ext[a] = 0.f;
+  }
   const float diag = sqrtf((ext[0] * ext[0] + ext[1] * ext[1]) + ext[2] * ext[2]);
   const float np = (float)(n_total > 0 ? n_total : 1);
   const float spacing = sqrtf(diag / np);
@@ -1174,7 +1178,7 @@ extern "C" int iso_bricks_build(const float* points, const float* normals, const
               (long long)workspace_bytes, (long long)w.bytes);
   hipStream_t s = (hipStream_t)stream;
   if (bbox)        // NULL: the header was written by iso_bricks_params (N ranks: between it and here the halo exchange)
-    hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, s, bbox, n_total, n_own, id_base, radius, knn_k,
+    hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, s, bbox, 1, n_total, n_own, id_base, radius, knn_k,
                        cell_scale, w.nb_cap, w.hdr, w.counters);
   hipLaunchKernelGGL(k_bricks_zero, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, s, w.hdr, w.cnt);
   if (n_own > 0)
@@ -1197,14 +1201,15 @@ extern "C" int iso_bricks_build(const float* points, const float* normals, const
   return ISO_OK;
 }
 
-extern "C" int iso_bricks_params(const float* bbox, int64_t n_total, int64_t n_own, int64_t id_base, float radius,
-                                 int knn_k, float cell_scale, void* workspace, int64_t n_max, void* stream) {
-  ISO_REQUIRE(bbox && workspace && n_max >= n_own && n_own >= 0 && n_total >= 0, ISO_ERR_INVALID, "iso_bricks_params: bad arguments");
+extern "C" int iso_bricks_params(const float* boxes, int n_boxes, int64_t n_total, int64_t n_own, int64_t id_base,
+                                 float radius, int knn_k, float cell_scale, void* workspace, int64_t n_max, void* stream) {
+  ISO_REQUIRE(boxes && n_boxes >= 1 && workspace && n_max >= n_own && n_own >= 0 && n_total >= 0, ISO_ERR_INVALID,
+              "iso_bricks_params: bad arguments");
   ISO_REQUIRE(cell_scale > 0.f && (radius > 0.f || knn_k > 0), ISO_ERR_INVALID,
               "iso_bricks_params: cell_scale and radius / knn_k must be positive");
   const BrickWs w = bricks_carve(workspace, n_max);
-  hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, (hipStream_t)stream, bbox, n_total, n_own, id_base, radius,
-                     knn_k, cell_scale, w.nb_cap, w.hdr, w.counters);
+  hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, (hipStream_t)stream, boxes, n_boxes, n_total, n_own, id_base,
+                     radius, knn_k, cell_scale, w.nb_cap, w.hdr, w.counters);
   ISO_CHECK_LAUNCH("iso_bricks_params");
   return ISO_OK;
 }

@@ -216,9 +216,8 @@ class IsoCycle(object):
     def _halo_build(self, pts, nrm, payload, box, boxes, radius, knn_k, cell_scale, halo):
         """N ranks: common grid from the reduced box, halo export -> all-gather -> import, build."""
         p, lib_call, g = _lib.ptr, _lib.call, self.grid
-        gbox = torch.cat([boxes[:, 0:4].min(dim=0).values, boxes[:, 4:8].max(dim=0).values]).contiguous()
-        lib_call("iso_bricks_params", p(gbox), self.P, self.n_own, self.lo, float(radius), int(knn_k), float(cell_scale),
-                 p(g.ws), g.n_max, _lib.stream())
+        lib_call("iso_bricks_params", p(boxes), self.world, self.P, self.n_own, self.lo, float(radius), int(knn_k),
+                 float(cell_scale), p(g.ws), g.n_max, _lib.stream())      # header for the union of the ranks' boxes
         lib_call("iso_halo_export", p(g.ws), p(pts), p(nrm), p(payload), self.n_own, p(boxes), self.world, self.rank,
                  halo, p(self.exp_buf), self.halo_cap, _lib.stream())
         gathered = yield ("all_gather", self.exp_buf)
