@@ -1072,12 +1072,24 @@ __global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ h
     PixK<KMAX> best;
     best.init();
     for (int sI = 0; sI < hv.z; ++sI) {
+      // a slice's list is requested whole before any of it is used (the id / q loads sat behind the depth test);
+      // the first slice's list IS the K-best so far
       const float* sc = scratch + (int64_t)(hv.y + sI) * 3 * KMAX * 256;
+      float zz[KMAX], qq[KMAX];
+      int ii[KMAX];
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) {
-        const float z = sc[j * 256 + threadIdx.x];
-        if (j < K && z < FLT_MAX)
-          best.push(z, __float_as_int(sc[(2 * KMAX + j) * 256 + threadIdx.x]), sc[(KMAX + j) * 256 + threadIdx.x], K);
+        zz[j] = sc[j * 256 + threadIdx.x];
+        qq[j] = sc[(KMAX + j) * 256 + threadIdx.x];
+        ii[j] = __float_as_int(sc[(2 * KMAX + j) * 256 + threadIdx.x]);
+      }
+      if (sI == 0) {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) { best.z[j] = zz[j]; best.q[j] = qq[j]; best.id[j] = ii[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+          if (j < K && zz[j] < FLT_MAX) best.push(zz[j], ii[j], qq[j], K);
       }
     }
     if (xi >= F.W || yi >= F.H) continue;
