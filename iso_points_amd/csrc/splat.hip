@@ -596,7 +596,9 @@ __device__ __forceinline__ void composite_pixel(const PixK<KMAX>& best, int K, f
 //          it covers (LDS counters); the pixel threads then insert only their own hits.  The K-best rule is a total
 //          order on (z, id), so the arrival order in the lists does not matter.  Candidates whose box covers more
 //          than kWideArea pixels, and pixels whose list overflows, take the first form.
-constexpr int kHitList = 40, kWideArea = 48;   // (32 / 24 / 16-entry lists: 316 / 333 / 429 us against 302)
+// (32 / 24 / 16-entry lists: 316 / 333 / 429 us against 302; wide boxes from 24 / 48 / 96 / 192 pixels: 367 / 302 / 294 /
+// 298 us, and 124 / 98 / 75 / 74 us for a rank's band at N = 8, where the items with many grazing splats set the time)
+constexpr int kHitList = 40, kWideArea = 96;
 
 template <int KMAX, bool CP>
 __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(

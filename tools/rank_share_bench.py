@@ -13,6 +13,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from iso_points_amd import _lib as _L
+if os.environ.get("ISO_DEV_LIB"):
+    _L.LIB_PATH = os.path.abspath(os.environ["ISO_DEV_LIB"])
 import bench as B
 from iso_points_amd.dist import IsoCycle, run_lockstep, slab_order, sphere_silhouette
 from iso_points_amd.rasterizer import PointsRasterizationSettings
