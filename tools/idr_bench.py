@@ -2,6 +2,9 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from tools_common import timeit
+from iso_points_amd import _lib as _L
+if os.environ.get("ISO_DEV_LIB"):
+    _L.LIB_PATH = os.path.abspath(os.environ["ISO_DEV_LIB"])
 from oracle import iso_oracle as O   # model definition only (weights); compute is the HIP path
 from iso_points_amd.sdf_models import idr_sdf_and_grad, PackedIdr
 from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
