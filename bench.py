@@ -150,11 +150,33 @@ class Cycle(object):
 
 
 def measured_traffic(x3):
+    """HBM-side bytes per launch of the dominant kernel.  bench.py cannot run rocprofv3 on itself: the figure comes
+    from the PMC passes of THIS command in an earlier builder run (tools/pmc_run.sh -> tools/traffic_from_pmc.py ->
+    profiles/rNN_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction).  Returns (bytes, source)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            return d["k_siren_step_x3" if x3 else "k_siren_step"]["bytes_per_launch"], "profiles/" + os.path.basename(f)
+        except Exception:
+            continue
+    return None, None
+
+
+def checked(cyc, comm, dev):
+    """One more, untimed cycle whose device-side overflow flags (pair list, packed rows, halo export / import,
+    uncertified halo queries) are read back: a truncated raster or neighbour list must not produce a number.
+    Raises on every rank if any rank overflowed; returns the usage dict."""
+    out = cyc.cyc.step()
+    err, u = None, None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        return d["k_siren_step_x3" if x3 else "k_siren_step"]["bytes_per_launch"]
-    except Exception:
-        return None
+        u = cyc.cyc.check(out[4])
+    except RuntimeError as e:
+        err = str(e)
+    bad = comm.max_int(1 if err else 0, dev)
+    if bad:
+        raise RuntimeError("bench.py: capacity overflow inside the timed cycle -- the figure would be invalid: %s" % err)
+    return u
 
 
 def f32_mode_cycle(dev, model, comm, steps=3):
@@ -163,6 +185,7 @@ def f32_mode_cycle(dev, model, comm, steps=3):
     from iso_points_amd import _lib
     lib = _lib.load()
     lib.iso_siren_set_gemm_mode(0)
+    old_graphs = os.environ.get("ISO_BENCH_GRAPHS")
     try:
         os.environ["ISO_BENCH_GRAPHS"] = "0"
         cyc = Cycle(dev, model, comm)
@@ -173,10 +196,40 @@ def f32_mode_cycle(dev, model, comm, steps=3):
             cyc.step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
+        checked(cyc, comm, dev)
     finally:
         lib.iso_siren_set_gemm_mode(1)
+        if old_graphs is None:
+            os.environ.pop("ISO_BENCH_GRAPHS", None)
+        else:
+            os.environ["ISO_BENCH_GRAPHS"] = old_graphs
     return {"ms_per_step": round(ms, 4), "value": round(P_TOTAL / (ms * 1e-3) / 1e6, 3), "unit": "Mpoints/s",
             "note": "hidden-layer products on v_mfma_f32_16x16x4_f32 (k_siren_step<16>), everything else unchanged"}
+
+
+def generator_order_cycle(dev, model, comm, steps=3):
+    """The headline cycle on the cloud in the order the generator emitted it (no x-slab / z-order sort at set-up):
+    what a caller pays who hands over an unordered cloud and does not re-sort."""
+    old = os.environ.get("ISO_BENCH_ORDER")
+    os.environ["ISO_BENCH_ORDER"] = "x"
+    try:
+        cyc = Cycle(dev, model, comm)
+        for _ in range(2):
+            cyc.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cyc.step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        checked(cyc, comm, dev)
+    finally:
+        if old is None:
+            os.environ.pop("ISO_BENCH_ORDER", None)
+        else:
+            os.environ["ISO_BENCH_ORDER"] = old
+    return {"ms_per_step": round(ms, 4), "value": round(P_TOTAL / (ms * 1e-3) / 1e6, 3), "unit": "Mpoints/s",
+            "note": "same cycle, input cloud in generator (random) order"}
 
 
 def analytic_cycle(dev, comm, args):
@@ -192,6 +245,7 @@ def analytic_cycle(dev, comm, args):
         cyc.step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
+    checked(cyc, comm, dev)
     gb = 1.19                                            # algorithmic bytes of one cfg-3a cycle
     return {"ms_per_step": round(ms, 4), "value": round(P_TOTAL / (ms * 1e-3) / 1e6, 3), "unit": "Mpoints/s",
             "roofline": {"bound": "hbm", "achieved": round(gb / (ms * 1e-3) / 1e3, 4), "peak": PEAK_HBM_TBS,
@@ -290,6 +344,40 @@ def cpu_baseline(gpu_model):
             "stages": stages}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly the way the driver would
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    ...`), pass their output through and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:                          # a free port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def dry_run(args, world, rank):
+    """ISO_BENCH_DRYRUN=1 (CPU test of the launch path, tests/test_dist_cpu.py): the ranks only rendezvous over gloo,
+    run the timing protocol's barrier / max-over-ranks on an empty step and rank 0 prints a line marked as such."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "max_over_ranks": t.item()}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,9 +389,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus %d needs torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
-        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))       # started bare: become the launcher of our own ranks
+    if os.environ.get("ISO_BENCH_DRYRUN"):
+        return dry_run(args, world, rank)
     if os.environ.get("ISO_BENCH_ONE_DEVICE"):     # test hook: all ranks on cuda:0 (with ISO_BENCH_BACKEND=gloo)
         local = 0
     torch.cuda.set_device(local)
@@ -350,8 +439,16 @@ def main():
     elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
 
+    usage = checked(cyc, comm, dev)                      # untimed; raises if any capacity overflowed on any rank
     siren_ms, siren_launches = cyc.siren_stats()
     counts = cyc.active_counts()
+    # ~2 s of back-to-back cycles outside the timed region, so that an external utilisation sampler (the driver's
+    # rocm-smi samples) sees the GPU at work: the timed region itself lasts a fraction of a second
+    t_busy = time.perf_counter()
+    while time.perf_counter() - t_busy < float(os.environ.get("ISO_BENCH_BUSY_S", "2.0")):
+        for _ in range(8):
+            cyc.step()
+        torch.cuda.synchronize()
     evals_per_step = sum(sum(c) for c in counts)          # this rank's share
     flop_per_step = evals_per_step * FLOP_PER_EVAL
     launches_per_step = siren_launches / max(args.steps, 1)
@@ -363,6 +460,7 @@ def main():
     # for the split-operand kernel an algorithmic flop costs 3 fp16 MFMA flops, so the ceiling is the
     # fp16 dense peak / 3 = 839 TFLOP/s (executed fp16 flops = 3 x achieved, reported alongside).
     peak = PEAK_BF16_MFMA_TFLOPS / X3_PASSES if x3 else PEAK_F32_MFMA_TFLOPS
+    traffic_bytes, traffic_src = measured_traffic(x3)
     if rank == 0:
         out = {
             "metric": "Mpoints/s full iso-point cycle (project+resample+splat), 1M pts",
@@ -373,13 +471,16 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",            # 1 M points in total for every N (BASELINE.json: the same cycle at 1 and 8 GPUs)
             "vs_baseline": None,
-            "dtype": "f32 (hidden-layer products from split operands on the fp16 matrix cores, f32 accumulate: every "
-                     "f32 operand = 2 fp16 parts under an exact power-of-two scale, 3 MFMA passes)" if x3 else "f32",
+            "dtype": "f32-class (split-fp16 operands, 2^-22: hidden-layer products from two fp16 parts per f32 operand "
+                     "under exact power-of-two scales, 3 fp16-MFMA passes, f32 accumulate; everything else f32)" if x3 else "f32",
             "data": "synthetic",
+            "overflow": None,                # checked(): pair / row / halo capacities of the timed cycle held on every rank
             "config": {"workload": "configs[2]: 1M points project(T=10)+resample(FRNN K=9, repulsion, T=3) + EWA "
                                    "splat fwd/bwd 512x512x4 views, K=8",
                        "sdf": "SIREN 3->256x4->1 (omega 30), fitted to the unit sphere (300 Adam steps, seed 0)",
                        "points": P_TOTAL,
+                       "point_order": "x-slab major, z-order curve inside a slab: one sort of the input cloud at set-up, "
+                                      "untimed (dist.slab_order); `generator_order` below is the same cycle without it",
                        "parallelism": "1 rank" if world == 1 else
                        "x-slabs of the cloud (per-point stages; halo cells all-gathered) and tile-row bands "
                        "(per-pixel stages; packed rows all-gathered) x%d ranks, RCCL" % world},
@@ -389,13 +490,13 @@ def main():
                          "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),
                          "frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                         # HBM-side bytes per launch: bench.py cannot run rocprofv3 on itself; the PMC passes of this
-                         # same command (tools/pmc_run.sh; 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) leave
-                         # their result in profiles/r02_traffic.json, read here -- null when that file is absent
-                         "traffic": measured_traffic(x3),
-                         "traffic_note": "bytes/launch of the dominant kernel, PMC (2*FETCH_SIZE+WRITE_SIZE) of this "
-                                         "command, from profiles/r02_traffic.json; algorithmic point I/O is %.1f MB/launch "
-                                         "-- the rest is the w*cos stash round trip"
+                         # HBM-side bytes per launch, NOT measured in this run (bench.py cannot profile itself): PMC
+                         # passes of this same command in the builder's last profiled run (see measured_traffic)
+                         "traffic": traffic_bytes,
+                         "traffic_source": traffic_src,
+                         "traffic_note": "bytes/launch of the dominant kernel from the PMC passes (2*FETCH_SIZE+WRITE_SIZE) of "
+                                         "an earlier run of this command, file named in traffic_source -- not this run; "
+                                         "algorithmic point I/O is %.1f MB/launch, the rest is the w*cos stash round trip"
                                          % (evals_per_step / max(launches_per_step, 1) * 37 / 1e6),
                          "peak_note": ("fp16 dense MFMA peak 2516.6 / 3 passes per f32 product; executed fp16 "
                                        "rate = %.1f TFLOP/s" % (ach * X3_PASSES)) if x3
@@ -414,6 +515,7 @@ def main():
         if world == 1:
             out["cfg3a_analytic_sdf"] = analytic_cycle(dev, comm, args)
             out["f32_mfma_mode"] = f32_mode_cycle(dev, model, comm)
+            out["generator_order"] = generator_order_cycle(dev, model, comm)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))

@@ -154,3 +154,22 @@ def test_slab_order_cell_order_keeps_the_slabs_and_is_local():
         step = (q[1:] - q[:-1]).norm(dim=-1).median()
         assert step < 0.1 * (p[1:] - p[:-1]).norm(dim=-1).median()
     assert torch.equal(slab_order(p, 2), slab_order(p.clone(), 2))        # deterministic
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started WITHOUT torch.distributed.run (the driver's recorded command form for one
+    GPU, extended to N): bench.py re-executes itself under the launcher, one process per rank, and rank 0 prints one
+    line.  ISO_BENCH_DRYRUN keeps the ranks to rendezvous + the timing protocol's collectives (gloo; no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ISO_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["steps"] == 3 and d["max_over_ranks"] == 2.0

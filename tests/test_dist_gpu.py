@@ -186,16 +186,20 @@ def test_two_processes_over_gloo(dev, tmp_path):
     assert out.stdout.count("OK") == 2
 
 
-def test_bench_line_of_two_ranks(dev):
+@pytest.mark.parametrize("launcher", [True, False], ids=["torchrun", "bare"])
+def test_bench_line_of_two_ranks(dev, launcher):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per process;
     both ranks on the test GPU and gloo instead of RCCL through the bench's own test hook): the cycle runs with
     calibrated buffers, graph replay and the timing protocol, and rank 0 prints the contract's line."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ISO_BENCH_ONE_DEVICE="1", ISO_BENCH_BACKEND="gloo")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    cmd = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    if launcher:
+        cmd = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29533"] + cmd
+    else:
+        env.pop("WORLD_SIZE", None)           # bare `python bench.py --gpus 2`: bench.py starts its own ranks
+    out = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
