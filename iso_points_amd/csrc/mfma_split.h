@@ -127,12 +127,19 @@ __device__ __forceinline__ void x3_keep_alive(const u32x4 (&X)[N][3]) {
 
 // PARTS / NEXT_PARTS: operand parts of this stage / of the stage whose first fragments are requested at the end (2).
 // bias_scale multiplies the bias (the accumulator scale of a split-fp16 stage; 1 otherwise).
-template <int TW, int NB, int NTO, int KS, int INIT, bool IL, int PARTS = 2, int NEXT_PARTS = 2, class IP = const u32x4*>
+struct x3_no_hook { __device__ __forceinline__ void operator()() const {} };
+
+// `hook` runs once, in front of the first request for the NEXT stage's fragments (K-step KS - kAD): memory requests
+// return in order per wave, so a request for data that is far away (the derivative stash) belongs behind the last
+// fragment this stage still waits for and in front of those nobody needs before the next stage.
+template <int TW, int NB, int NTO, int KS, int INIT, bool IL, int PARTS = 2, int NEXT_PARTS = 2, class IP = const u32x4*,
+          class Hook = x3_no_hook>
 __device__ __forceinline__ void gemm_x3(IP imgw, const float* __restrict__ bias_h,
                                         const u32x4* actl, f32x16 (&acc)[TW][NB], int w, int s0,
                                         u32x4 (&A)[4][TW][3], IP next_imgw, int next_s,
                                         unsigned lane, float bias_scale = 1.0f,
-                                        const float* bias_scale_n = nullptr) {   // per point tile, on top of bias_scale
+                                        const float* bias_scale_n = nullptr,     // per point tile, on top of bias_scale
+                                        Hook&& hook = Hook()) {
   static_assert(KS % 4 == 0, "K-steps are processed in groups of four");
   if constexpr (INIT != kAccumulate) {
 #pragma unroll
@@ -208,7 +215,10 @@ __device__ __forceinline__ void gemm_x3(IP imgw, const float* __restrict__ bias_
       const int k = i + jj;                       // K-step of this stage being multiplied
       // set (jj+3)%4 was consumed one K-step ago: refill it with K-step k+3 (or the next stage's)
       if (k + kAD < KS) x3_load_a<TW, NTO, PARTS>(A[(jj + kAD) & 3], imgw, s0 + k + kAD, lane);
-      else x3_load_a<TW, NTO, NEXT_PARTS>(A[(jj + kAD) & 3], next_imgw, next_s + (k + kAD - KS), lane);
+      else {
+        if (k + kAD == KS) hook();
+        x3_load_a<TW, NTO, NEXT_PARTS>(A[(jj + kAD) & 3], next_imgw, next_s + (k + kAD - KS), lane);
+      }
       if (k + 1 < KS) ldB(B[(jj + 1) & 1], s0 + k + 1);
 #ifndef X3_INTERLEAVE_LOADS
 #define X3_INTERLEAVE_LOADS 1

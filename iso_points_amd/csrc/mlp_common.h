@@ -204,6 +204,42 @@ __device__ __forceinline__ void iso_sin_wcos8(float w_in, float w, const float (
   }
 }
 
+// c = w*cos(w_in*z) alone, bit for bit the c of iso_sin_wcos8 (same reduction, same instructions): the reverse sweep
+// of the SIREN step recomputes layer 0's derivative from the point instead of reading it back from a stash.
+__device__ __forceinline__ void iso_wcos8(float w_in, float w, const float (&z)[8], float (&c)[8]) {
+#if ISO_SINCOS_HW
+  const iso_f32x2 w2 = {w, w}, wi2 = {w_in, w_in};
+  iso_f32x2 x[4], c2[4];
+  ISO_X4(x[p] = ((iso_f32x2){z[2 * p], z[2 * p + 1]}) * wi2);
+  {
+    const iso_f32x2 hi = {0.159154936671257019043f, 0.159154936671257019043f};
+    const iso_f32x2 lo = {6.4206383167e-9f, 6.4206383167e-9f};
+    iso_f32x2 t[4], n[4], f[4];
+    ISO_X4(t[p] = x[p] * hi);
+    ISO_X4(n[p] = ((iso_f32x2){rintf(t[p].x), rintf(t[p].y)}));
+    ISO_X4(f[p] = __builtin_elementwise_fma(x[p], hi, -n[p]));
+    ISO_X4(f[p] = __builtin_elementwise_fma(x[p], lo, f[p]));
+    ISO_X4(c2[p] = ((iso_f32x2){__builtin_amdgcn_cosf(f[p].x), __builtin_amdgcn_cosf(f[p].y)}));
+  }
+  ISO_X4(c2[p] = c2[p] * w2);
+  float amax = 0.f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    c[2 * p] = c2[p].x; c[2 * p + 1] = c2[p].y;
+    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[p].x), __builtin_fabsf(x[p].y)));
+  }
+#ifndef ISO_WCOS_NOFIX
+  if (__builtin_expect(__any(!(amax < 1.0e4f)), 0)) {
+    float s[8];
+    iso_sin_wcos8(w_in, w, z, s, c);          // the large-argument path: rare, take the full routine
+  }
+#endif
+#else
+  float s[8];
+  iso_sin_wcos8(w_in, w, z, s, c);
+#endif
+}
+
 template <int NT, bool HAS_BIAS>
 __device__ __forceinline__ void gemm_pass(const float* __restrict__ img,
                                           const float* __restrict__ bias,

@@ -170,6 +170,12 @@ __global__ void k_siren_pack_f16(const float* __restrict__ raw, float* __restric
 }
 
 // ---- the step kernel -------------------------------------------------------------------------
+#ifndef X3_LDS_STASH
+#define X3_LDS_STASH 1
+#endif
+#ifndef X3_LDS_SLOT
+#define X3_LDS_SLOT 0      // which stash slot keeps its first LG groups in LDS (0: the longest-lived one)
+#endif
 template <int H, int NW, int NB>
 struct X3Shape {
   static constexpr int NS = H / 16;        // K-steps of a hidden layer
@@ -179,8 +185,17 @@ struct X3Shape {
   static constexpr int NG = SL * NB;       // 8-value groups per lane
   static constexpr int P = 32 * NB;        // points per workgroup
   static constexpr size_t kActBytes = (size_t)NS * NB * kAP * 1024;
-  static constexpr size_t kLds = kActBytes + (size_t)NW * P * 16;
-  static constexpr int64_t kStashPerWg(int L) { return (int64_t)NW * (L + 1) * NG * 512; }  // floats
+  static constexpr size_t kRedBytes = (size_t)NW * P * 16;
+  static constexpr size_t kPtsBytes = (size_t)P * 16;                 // the tile's points, for the reverse sweep's layer 0
+  // LDS-resident part of the derivative stash: the first LG of the NG groups per lane of stash slot 0 (written by
+  // hidden layer 0, read back last of all by reverse stage 1 -- the longest-lived slot) stay in the CU; 2 KiB per
+  // group and wave, as many groups as the 160 KiB of a gfx950 CU leave room for
+  static constexpr int kLdsGroupsFit = (int)((163840 - (kActBytes + kRedBytes + kPtsBytes)) / ((size_t)NW * 2048));
+  static constexpr int LG = X3_LDS_STASH ? (kLdsGroupsFit < NG ? kLdsGroupsFit : NG) : 0;
+  static constexpr size_t kLds = kActBytes + kRedBytes + kPtsBytes + (size_t)NW * LG * 2048;
+  // slot l of the global stash = w cos(w z) of hidden layer l's output (layer 0's is recomputed, the top layer's is
+  // consumed on the spot): L - 1 slots in use, one kept for L = 1
+  static constexpr int64_t kStashPerWg(int L) { return (int64_t)NW * (L > 1 ? L : 1) * NG * 512; }  // floats
   static_assert(NTO % NW == 0 && TW >= 1, "features must split evenly over the waves");
 };
 
@@ -204,6 +219,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* act = reinterpret_cast<u32x4*>(smem_raw);
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw + S::kActBytes);   // [NW][P] {f,gx,gy,gz}
+  f32x4* ptl = reinterpret_cast<f32x4*>(smem_raw + S::kActBytes + S::kRedBytes);                  // [P] {x,y,z,-}
+  constexpr int LG = S::LG;
   const int tid = threadIdx.x;
   // the wave index is wave-uniform: say so, and everything derived from it (weight-image and
   // stash bases) lives in SGPRs; loads then use the scalar-base + lane-offset form
@@ -229,7 +246,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   const int h8 = h * 8;
   const float bL = a.packed[off_bl(H)];
   f32x4* stash = reinterpret_cast<f32x4*>(a.stash) +
-                 ((int64_t)blockIdx.x * NW + w) * (int64_t)(L + 1) * NG * 128;   // + lane
+                 ((int64_t)blockIdx.x * NW + w) * (int64_t)(L > 1 ? L : 1) * NG * 128;   // + lane
+  f32x4* lst = reinterpret_cast<f32x4*>(smem_raw + S::kActBytes + S::kRedBytes + S::kPtsBytes) + w * (LG * 128) + lane;
 
   // weight images of this wave: forward / transposed image of hidden layer l (two fp16 parts)
   constexpr int FP = 2, BP = 2;
@@ -279,6 +297,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         const int64_t idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
         px[n] = a.pts[idx * 3]; py[n] = a.pts[idx * 3 + 1]; pz[n] = a.pts[idx * 3 + 2];
       }
+      if constexpr (!FWD) {                // kept for the reverse sweep's layer 0 (visible after the barrier below)
+        if (w == 0 && h == 0) ptl[32 * n + j_e] = (f32x4){px[n], py[n], pz[n], 0.f};
+      }
     }
     X3_STAMP();
     // ---- layer 0 (3 -> H) on the VALU: this wave's H/NW features of all P points ------------
@@ -298,12 +319,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
           split8_f16(hv, p0, p1);
           own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
         }
-#ifndef X3_DBG_NOSTASH
-        if constexpr (!FWD) {
-          stash[(k * 2 + 0) * 64 + lane] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
-          stash[(k * 2 + 1) * 64 + lane] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
-        }
-#endif
+        // w cos(w z0) is NOT stashed: z0 = W0 x + b0 is three FMAs to form again in the reverse sweep
+        (void)sv;
       }
     }
     X3_STAMP();
@@ -332,7 +349,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       __syncthreads();                      // both teams have read this team's K-half
       X3_STAMP();
       const bool top = (l == L - 1);
-      f32x4* st_l = stash + (int64_t)(l + 1) * NG * 128;
+      f32x4* st_l = stash + (int64_t)l * NG * 128;
+      const bool lds_slot = (l == X3_LDS_SLOT);        // the first LG groups of this slot stay in LDS
       // one 8-value group: sin / w cos, head or stash, split, store as the next layer's B entry
       // scale of the adjoint seed (uniform): |W_head[f] * w cos| <= max|W_head| * w
       const float seed_scale = x3_scale_for(a.packed[x16_base(H, L) + 16] * a.wh * 1.01f);
@@ -364,8 +382,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         } else {
 #ifndef X3_DBG_NOSTASH
           if constexpr (!FWD) {
-            st_l[(k * 2 + 0) * 64 + lane] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
-            st_l[(k * 2 + 1) * 64 + lane] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+            if (k < LG && lds_slot) {
+              lst[(k * 2 + 0) * 64] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+              lst[(k * 2 + 1) * 64] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+            } else {
+              st_l[(k * 2 + 0) * 64 + lane] = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+              st_l[(k * 2 + 1) * 64 + lane] = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+            }
           }
 #endif
         }
@@ -436,22 +459,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 #pragma unroll
     for (int n = 0; n < NB; ++n) gx[n] = gy[n] = gz[n] = 0.f;
     int mbuf = 0;                             // exchange buffer that holds max |a_l| of the adjoint in LDS
-    for (int l = FWD ? -1 : L - 1; l >= 0; --l) {
-      const u32x4* img = rev_img(l);
-      const f32x4* st_l = stash + (int64_t)l * NG * 128;
-      f32x4 sv[NG][2];
-      auto ld_stash = [&]() {
-#pragma unroll
-        for (int k = 0; k < NG; ++k) {
-#ifdef X3_DBG_NOSTASH
-          sv[k][0] = sv[k][1] = (f32x4){1.f, 1.f, 1.f, (float)l};
-#else
-          sv[k][0] = st_l[(k * 2) * 64 + lane]; sv[k][1] = st_l[(k * 2 + 1) * 64 + lane];
-#endif
-        }
-      };
-      // max_k |a_l[k][p]| of this lane's points (written before the barrier that ended the last stage)
-      float Mp[NB];
+    // max_k |a_l[k][p]| of this lane's points (written before the barrier that ended the last stage)
+    auto get_amax = [&](float (&Mp)[NB]) {
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
         float m = 0.f;
@@ -459,12 +468,36 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
         for (int ww = 0; ww < NW; ++ww) m = __builtin_fmaxf(m, redm[(mbuf * P + 32 * n + j) * NW + ww]);
         Mp[n] = m;
       }
+    };
+    // stages l = L-1 .. 1: a_{l-1} = (W_l^T a_l) * w cos(w z_{l-1}), the derivative from the stash
+    for (int l = FWD ? 0 : L - 1; l >= 1; --l) {
+      const u32x4* img = rev_img(l);
+      const f32x4* st_l = stash + (int64_t)(l - 1) * NG * 128;      // reverse stage l reads slot l - 1
+      f32x4 sv[NG][2];
+      auto ld_stash = [&]() {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+#ifdef X3_DBG_NOSTASH
+          sv[k][0] = sv[k][1] = (f32x4){1.f, 1.f, 1.f, (float)l};
+#else
+          if (k < LG && l == X3_LDS_SLOT + 1) {
+            sv[k][0] = lst[(k * 2) * 64]; sv[k][1] = lst[(k * 2 + 1) * 64];
+          } else {
+            sv[k][0] = st_l[(k * 2) * 64 + lane]; sv[k][1] = st_l[(k * 2 + 1) * 64 + lane];
+          }
+#endif
+        }
+      };
+      float Mp[NB];
+      get_amax(Mp);
       // w cos(w z) of the layer below: requested before the GEMM when the registers allow it
-      if constexpr (NG <= 6 && X3_EARLY_STASH) ld_stash();
-      if (l > 0) {
-        gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, BP>(img, nullptr, act + lane, acc, w, 0, A, rev_img(l - 1), 0, lane);
+      // X3_EARLY_STASH 1: before the GEMM; 2: inside it, behind the stage's last own fragment request (gemm_x3's hook)
+      if constexpr (NG <= 6 && X3_EARLY_STASH == 1) ld_stash();
+      if constexpr (NG <= 6 && X3_EARLY_STASH == 2) {
+        gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, BP>(img, nullptr, act + lane, acc, w, 0, A, rev_img(l - 1), 0, lane, 1.0f,
+                                                    nullptr, ld_stash);
       } else {
-        gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, FP>(img, nullptr, act + lane, acc, w, 0, A, fwd_img(0), 0, lane);
+        gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, BP>(img, nullptr, act + lane, acc, w, 0, A, rev_img(l - 1), 0, lane);
       }
       if constexpr (NG > 6 || !X3_EARLY_STASH) ld_stash();
       X3_STAMP();
@@ -479,7 +512,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
           inv[n] = iw / bscale[n];
-          nscale[n] = l > 0 ? x3_scale_for(Mp[n] * grow) : 1.0f;
+          nscale[n] = x3_scale_for(Mp[n] * grow);
           amax[n] = 0.f;
         }
       }
@@ -487,43 +520,73 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       for (int t = 0; t < TW; ++t)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          f32x4 wv[8];
-          if (l == 0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) wv[e] = W0u[(2 * t + p) * 16 + h8 + e];
-          }
 #pragma unroll
           for (int n = 0; n < NB; ++n) {
             const int k = (2 * t + p) * NB + n;
             float av[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              av[e] = (acc[t][n][8 * p + e] * inv[n]) * sv[k][e >> 2][e & 3];
-            }
-            if (l > 0) {
-              float m = amax[n];
+            for (int e = 0; e < 8; ++e) av[e] = (acc[t][n][8 * p + e] * inv[n]) * sv[k][e >> 2][e & 3];
+            float m = amax[n];
 #pragma unroll
-              for (int e = 0; e < 8; e += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(av[e]), __builtin_fabsf(av[e + 1])));
-              amax[n] = m;
-              u32x4 p0, p1;
-              split8_f16(av, p0, p1, nscale[n]);
-              own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                gx[n] += wv[e].x * av[e];
-                gy[n] += wv[e].y * av[e];
-                gz[n] += wv[e].z * av[e];
-              }
-            }
+            for (int e = 0; e < 8; e += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(av[e]), __builtin_fabsf(av[e + 1])));
+            amax[n] = m;
+            u32x4 p0, p1;
+            split8_f16(av, p0, p1, nscale[n]);
+            own[(k * kAP + 0) * 64] = p0; own[(k * kAP + 1) * 64] = p1;
           }
         }
-      if (l > 0) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n) bscale[n] = nscale[n];
-        put_amax(mbuf ^ 1);
-        mbuf ^= 1;
+      for (int n = 0; n < NB; ++n) bscale[n] = nscale[n];
+      put_amax(mbuf ^ 1);
+      mbuf ^= 1;
+      X3_STAMP();
+      __syncthreads();
+      X3_STAMP();
+    }
+    // stage 0: d sdf / d x = W_0^T [ (W_1^T a_1) * w0 cos(w0 z_0) ] -- z_0 = W_0 x + b_0 is formed again from the point
+    // (three FMAs; the same expression on the same operands as in the forward sweep) instead of being stashed
+    if constexpr (!FWD) {
+      gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, FP>(rev_img(0), nullptr, act + lane, acc, w, 0, A, fwd_img(0), 0, lane);
+      X3_STAMP();
+      __syncthreads();
+      X3_STAMP();
+      float inv[NB];
+      {
+        const float iw = 1.0f / a.packed[x16_base(H, L)];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) inv[n] = iw / bscale[n];
       }
+      f32x4 q[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) q[n] = ptl[32 * n + j];
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          f32x4 wv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wv[e] = W0u[(2 * t + p) * 16 + h8 + e];
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            float zz[8], cv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zz[e] = ((wv[e].x * q[n].x + wv[e].y * q[n].y) + wv[e].z * q[n].z) + wv[e].w;
+#ifdef X3_DBG_NOSTASH
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cv[e] = zz[e];
+#else
+            iso_wcos8(a.w0, a.w0, zz, cv);
+#endif
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float av = (acc[t][n][8 * p + e] * inv[n]) * cv[e];
+              gx[n] += wv[e].x * av;
+              gy[n] += wv[e].y * av;
+              gz[n] += wv[e].z * av;
+            }
+            __builtin_amdgcn_sched_barrier(0);     // one group at a time: bounds register pressure
+          }
+        }
       X3_STAMP();
       __syncthreads();
       X3_STAMP();
