@@ -237,6 +237,8 @@ def analytic_cycle(dev, comm, args):
     Reported beside the headline (cfg 3b), not instead of it."""
     from iso_points_amd.sdf_models import SphereSDF
     cyc = Cycle(dev, SphereSDF().to(dev), comm)
+    cyc.cyc.marks = False         # the marks only bracket the SDF kernel for the headline's roofline figure; each one is a
+                                  # graph-segment boundary (~9 us of idle GPU), and this cycle has no SDF kernel to bracket
     for _ in range(max(args.warmup, 1)):
         cyc.step()
     torch.cuda.synchronize()

@@ -531,6 +531,19 @@ int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbuf, int64_t 
  *    carried to the kernels (the view mask for iso_splat_h_fused), or NULL.
  * ---------------------------------------------------------------------- */
 int64_t iso_bricks_workspace_bytes(int64_t n_max);
+/* Once per workspace, before its first build: zeroes the brick counters and the counter block.  Every build leaves
+ * the brick counters zeroed again (the offsets pass clears what it has read), so no build starts with a clearing
+ * pass.  The counter block (64 ints at byte 256 of the workspace): [0..15] counters of the current grid (slots as
+ * documented below), [16..31] "sticky" sums of the counters of all earlier grids on this workspace -- a header write
+ * adds what it resets -- so that a caller can check the overflow / certification counters of a whole cycle of several
+ * grids with one read afterwards.                                                                    */
+int iso_bricks_workspace_init(void* workspace, int64_t n_max, void* stream);
+/* iso_bricks_build for ONE rank that holds the whole cloud (n_total = n, id_base = 0, no imports): the bounding box
+ * is taken by the build itself -- no iso_points_bbox pass, no 8-float round trip (six launches per grid instead of
+ * twelve).  Same grid, same results as iso_points_bbox + iso_bricks_build.                          */
+int iso_bricks_build_whole(const float* points, const float* normals, const int32_t* payload, int64_t n,
+                           float radius, int knn_k, float cell_scale, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 int iso_bricks_build(const float* points, const float* normals, const int32_t* payload,
                      int64_t n_own, int64_t id_base, const float* import_rec0,
                      const float* import_rec1, const int32_t* import_count, int64_t import_max,

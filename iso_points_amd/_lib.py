@@ -82,6 +82,8 @@ SIGNATURES = {
     "iso_splat_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _I, _I, _I, _I, _F, _L, _P, _L, _P, _P]),
     "iso_splat_zbuf_backward": (_I, [_P, _P, _L, _I, _P, _P]),
     "iso_bricks_workspace_bytes": (_L, [_L]),
+    "iso_bricks_workspace_init": (_I, [_P, _L, _P]),
+    "iso_bricks_build_whole": (_I, [_P, _P, _P, _L, _F, _I, _F, _P, _L, _P]),
     "iso_bricks_build": (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _L, _P, _L, _F, _I, _F, _P, _L, _P]),
     "iso_bricks_params": (_I, [_P, _I, _L, _L, _L, _F, _I, _F, _P, _L, _P]),
     "iso_halo_export": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _P, _L, _P]),

@@ -34,20 +34,29 @@ class BrickGrid(object):
         self.ws_bytes = lib.iso_bricks_workspace_bytes(self.n_max)
         self.ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=device)
         assert self.ws.data_ptr() % 256 == 0
+        _lib.call("iso_bricks_workspace_init", _lib.ptr(self.ws), self.n_max, _lib.stream())
         self.points = None
+        self._seen = [0] * 16          # counter sums already reported by counters_since_last()
 
     def build(self, points, normals=None, payload=None, bbox=None, n_total=None, radius=-1.0, knn_k=8,
               cell_scale=None, id_base=0, imports=None, params_done=False):
         """points (n_own,3) f32 contiguous; imports = (rec0 (m,4), rec1 (m,4), count int32 (1,)) or None.
         params_done: the header was already written by iso_bricks_params (N ranks)."""
         assert points.shape == (self.n_own, 3) and points.dtype == torch.float32 and points.is_contiguous()
+        if cell_scale is None:
+            cell_scale = RESAMPLE_CELL * knn_k
+        p = _lib.ptr
+        whole = (not params_done and bbox is None and imports is None and self.import_max == 0 and int(id_base) == 0
+                 and (n_total is None or int(n_total) == self.n_own))
+        if whole:                 # one rank, the whole cloud: the build takes the bounding box itself
+            _lib.call("iso_bricks_build_whole", p(points), p(normals), p(payload), self.n_own, float(radius), int(knn_k),
+                      float(cell_scale), p(self.ws), self.ws_bytes, _lib.stream())
+            self.points = points
+            return self
         if params_done:
             bbox, radius, knn_k, cell_scale = None, 1.0, 1, 1.0
         elif bbox is None:
             bbox = points_bbox(points)
-        if cell_scale is None:
-            cell_scale = RESAMPLE_CELL * knn_k
-        p = _lib.ptr
         imp0 = imp1 = impc = None
         if imports is not None and self.import_max > 0:
             imp0, imp1, impc = imports
@@ -61,6 +70,15 @@ class BrickGrid(object):
         return self
 
     # -- diagnostics (host sync) -------------------------------------------------------------------
+    def counters_since_last(self):
+        """The grid's 16 device-side counters summed over every grid built on this workspace since the previous call
+        (current grid + the sticky sums the header writes keep, minus what was reported before)."""
+        c = self.ws[256:384].cpu().view(torch.int32).tolist()
+        tot = [c[i] + c[16 + i] for i in range(16)]
+        out = [tot[i] - self._seen[i] for i in range(16)]
+        self._seen = tot
+        return out
+
     def header(self):
         raw = self.ws[:128].cpu()
         f = raw.view(torch.float32).tolist()

@@ -61,15 +61,30 @@ __device__ __forceinline__ int wave_incl_scan_i(int v) {
 
 // ---- header ------------------------------------------------------------------------------------
 // bbox: [min xyz, 0, max xyz, 0] (iso_points_bbox layout; for N ranks the caller reduces it first)
-__global__ void k_bricks_params(const float* __restrict__ bbox, int n_boxes, int64_t n_total, int64_t n_own, int64_t id_base,
-                                float radius, int knn_k, float cell_scale, int nb_cap, BrickHdr* __restrict__ h,
-                                int32_t* __restrict__ counters) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Counter block of the workspace (64 ints): [0..15] the grid's counters (BrickWs::counters; reset by every header
+// write), [16..31] their sums over all earlier grids on this workspace ("sticky": a header write adds the counters it
+// is about to reset, so that overflows / uncertified queries of a whole cycle -- several grids -- can be read once,
+// afterwards, without an accumulation pass per grid), [32..37] bounding-box accumulators of iso_bricks_build_whole
+// (order-preserving keys, min as max of the complement: all-zero = empty), [38] the init mark.
+constexpr int kStickyAt = 16, kBoxAt = 32, kMagicAt = 38;
+constexpr int kBrickMagic = 0x1b71c5;
+
+__device__ __forceinline__ unsigned bk_f2key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float bk_key2f(unsigned k) {
+  const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// header for the box [mn, mn + ext] (one thread)
+__device__ void bricks_write_header(const float* mn_in, const float* mx_in, int64_t n_total, int64_t n_own, int64_t id_base,
+                                    float radius, int knn_k, float cell_scale, int nb_cap, BrickHdr* __restrict__ h,
+                                    int32_t* __restrict__ counters) {
   float mn[3], ext[3];
-  for (int a = 0; a < 3; ++a) {                     // the union of the n_boxes boxes (N ranks: every rank's local box)
-    float lo = bbox[a], hi = bbox[4 + a];
-    for (int k = 1; k < n_boxes; ++k) { lo = fminf(lo, bbox[k * 8 + a]); hi = fmaxf(hi, bbox[k * 8 + 4 + a]); }
-    mn[a] = lo; ext[a] = hi - lo; if (!(ext[a] >= 0.f)) ext[a] = 0.f;
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = mn_in[a]; ext[a] = mx_in[a] - mn_in[a]; if (!(ext[a] >= 0.f)) ext[a] = 0.f;
   }
   const float diag = sqrtf((ext[0] * ext[0] + ext[1] * ext[1]) + ext[2] * ext[2]);
   const float np = (float)(n_total > 0 ? n_total : 1);
@@ -107,12 +122,91 @@ __global__ void k_bricks_params(const float* __restrict__ bbox, int n_boxes, int
   h->g_covers_r = g >= r ? 1 : 0;
   h->n_total = (int)n_total;
   h->x_lo = -FLT_MAX; h->x_hi = FLT_MAX;
-  for (int i = 0; i < 16; ++i) counters[i] = 0;
+  for (int i = 0; i < 16; ++i) { counters[kStickyAt + i] += counters[i]; counters[i] = 0; }
 }
 
-__global__ void k_bricks_zero(const BrickHdr* __restrict__ h, int32_t* __restrict__ cnt) {
-  const int n = BK_CPB * h->n_bricks + 1;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cnt[i] = 0;
+// ---- header ------------------------------------------------------------------------------------
+// bbox: [min xyz, 0, max xyz, 0] (iso_points_bbox layout; for N ranks the caller reduces it first)
+__global__ void k_bricks_params(const float* __restrict__ bbox, int n_boxes, int64_t n_total, int64_t n_own, int64_t id_base,
+                                float radius, int knn_k, float cell_scale, int nb_cap, BrickHdr* __restrict__ h,
+                                int32_t* __restrict__ counters) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; ++a) {                     // the union of the n_boxes boxes (N ranks: every rank's local box)
+    float lo = bbox[a], hi = bbox[4 + a];
+    for (int k = 1; k < n_boxes; ++k) { lo = fminf(lo, bbox[k * 8 + a]); hi = fmaxf(hi, bbox[k * 8 + 4 + a]); }
+    mn[a] = lo; mx[a] = hi;
+  }
+  bricks_write_header(mn, mx, n_total, n_own, id_base, radius, knn_k, cell_scale, nb_cap, h, counters);
+}
+
+// the cloud's own box (iso_bricks_build_whole): accumulated by k_brick_bbox into the counter block, decoded here,
+// accumulators back to "empty"
+__global__ void k_bricks_params_self(int64_t n_total, int64_t n_own, int64_t id_base, float radius, int knn_k,
+                                     float cell_scale, int nb_cap, BrickHdr* __restrict__ h, int32_t* __restrict__ counters) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned* acc = reinterpret_cast<unsigned*>(counters) + kBoxAt;
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = acc[a] ? bk_key2f(~acc[a]) : 0.f;
+    mx[a] = acc[3 + a] ? bk_key2f(acc[3 + a]) : 0.f;
+    acc[a] = 0u; acc[3 + a] = 0u;
+  }
+  bricks_write_header(mn, mx, n_total, n_own, id_base, radius, knn_k, cell_scale, nb_cap, h, counters);
+}
+
+// bounding box of a packed (n,3) cloud into the counter block: flat float index (consecutive lanes read consecutive
+// dwords; the grid stride is a multiple of 3 floats, so a thread stays on one axis and keeps four loads in flight),
+// registers -> wave shuffles -> LDS -> six atomics per workgroup
+__global__ __launch_bounds__(256) void k_brick_bbox(const float* __restrict__ p, int64_t n, int32_t* __restrict__ counters) {
+  __shared__ float s_mn[4][3], s_mx[4][3];
+  const int64_t nfl = n * 3;
+  const int64_t stride = (int64_t)gridDim.x * 256;            // a multiple of 3 (launcher)
+  const int64_t i_first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  int64_t i = i_first;
+  for (; i + 3 * stride < nfl; i += 4 * stride) {
+    const float v0 = p[i], v1 = p[i + stride], v2 = p[i + 2 * stride], v3 = p[i + 3 * stride];
+    lo = fminf(fminf(lo, v0), fminf(v1, fminf(v2, v3)));
+    hi = fmaxf(fmaxf(hi, v0), fmaxf(v1, fmaxf(v2, v3)));
+  }
+  for (; i < nfl; i += stride) { const float v = p[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  const int ax = (int)(i_first % 3);
+  float mn[3], mx[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { mn[c] = ax == c ? lo : FLT_MAX; mx[c] = ax == c ? hi : -FLT_MAX; }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+    }
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { s_mn[w][a] = mn[a]; s_mx[w][a] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    float l = s_mn[0][a], u = s_mx[0][a];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { l = fminf(l, s_mn[k][a]); u = fmaxf(u, s_mx[k][a]); }
+    unsigned* acc = reinterpret_cast<unsigned*>(counters) + kBoxAt;
+    if (l <= u) {                                             // (a workgroup without a value on this axis: nothing)
+      atomicMax(&acc[a], ~bk_f2key(l));
+      atomicMax(&acc[3 + a], bk_f2key(u));
+    }
+  }
+}
+
+// zero the whole table once (iso_bricks_workspace_init); afterwards the offsets pass leaves it zeroed
+__global__ void k_bricks_init(int32_t* __restrict__ counters, int32_t* __restrict__ cnt, int64_t G) {
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = i0; i < G; i += (int64_t)gridDim.x * blockDim.x) cnt[i] = 0;
+  if (i0 < 64) counters[i0] = i0 == kMagicAt ? kBrickMagic : 0;
 }
 
 __device__ __forceinline__ int brick_of(const BrickHdr& h, float x, float y, float z) {
@@ -228,41 +322,77 @@ __global__ __launch_bounds__(256) void k_brick_scatter_recs(const float4* __rest
   }
 }
 
-// occupied bricks (the order only affects scheduling); 1024 bricks per workgroup and round, ONE returning atomic
-// for them (one per wave made ~2 k same-address atomics the kernel's whole duration)
-__global__ __launch_bounds__(256) void k_brick_list(const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off,
-                                                    int32_t* __restrict__ list, int32_t* __restrict__ counters) {
-  __shared__ int s_cnt[4][4], s_base;
+// ---- offsets of the bricks: exclusive scan of the counters in two launches ---------------------------
+// (the general 3-phase scan of frnn.hip, specialised: a table of <= ~2000 chunks needs no middle pass -- every
+// block of the second pass adds up the totals of the chunks before it -- and the second pass also does what two
+// more launches did: it leaves the counters ZEROED for the next build and appends the occupied bricks to the work
+// list, one returning atomic per 2048 bricks; the order of the list only affects scheduling.)
+constexpr int BS_ITEMS = 8, BS_CHUNK = 256 * BS_ITEMS;
+static_assert(BK_CPB == 1, "the offsets pass lists brick i when counter i is non-zero");
+
+__device__ __forceinline__ int block_excl_scan_256(int v, int& total, int* lds /*>= 4*/) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int inc = wave_incl_scan_i(v);
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int t = lds[i]; if (i < w) base += t; tot += t; }
+  total = tot;
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_brick_sums(const BrickHdr* __restrict__ hp, const int32_t* __restrict__ cnt,
+                                                    int32_t* __restrict__ sums) {
+  __shared__ int lds[4];
+  const int len = BK_CPB * hp->n_bricks + 1;
+  const int c0 = blockIdx.x * BS_CHUNK;
+  if (c0 >= len) return;
+  int v = 0;
+#pragma unroll
+  for (int k = 0; k < BS_ITEMS; ++k) {
+    const int i = c0 + threadIdx.x * BS_ITEMS + k;
+    if (i < len) v += cnt[i];
+  }
+  int tot;
+  block_excl_scan_256(v, tot, lds);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_brick_offsets(const BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
+                                                       int32_t* __restrict__ off, const int32_t* __restrict__ sums,
+                                                       int32_t* __restrict__ list, int32_t* __restrict__ counters) {
+  __shared__ int lds[4], s_base;
   const int nb = hp->n_bricks;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int b0 = blockIdx.x * 1024; b0 < nb; b0 += gridDim.x * 1024) {
-    bool occ[4];
-    unsigned long long bal[4];
+  const int len = BK_CPB * nb + 1;
+  const int c0 = blockIdx.x * BS_CHUNK;
+  if (c0 >= len) return;
+  int before = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) before += sums[i];
+  int base;
+  block_excl_scan_256(before, base, lds);                       // base = total of the chunks before this one
+  int vals[BS_ITEMS], v = 0, occ = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int b = b0 + k * 256 + threadIdx.x;
-      occ[k] = b < nb && off[BK_CPB * (b + 1)] > off[BK_CPB * b];
-      bal[k] = __ballot(occ[k]);
-      if (lane == 0) s_cnt[k][wv] = __popcll(bal[k]);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tot = 0;
+  for (int k = 0; k < BS_ITEMS; ++k) {
+    const int i = c0 + threadIdx.x * BS_ITEMS + k;
+    vals[k] = 0;
+    if (i < len) { vals[k] = cnt[i]; cnt[i] = 0; }
+    v += vals[k];
+    occ += (vals[k] > 0 && i < nb) ? 1 : 0;
+  }
+  int tot, occ_tot;
+  int ex = base + block_excl_scan_256(v, tot, lds);
+  int at = block_excl_scan_256(occ, occ_tot, lds);
+  if (threadIdx.x == 0) s_base = occ_tot ? atomicAdd(&counters[0], occ_tot) : 0;
+  __syncthreads();
+  at += s_base;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) tot += s_cnt[q >> 2][q & 3];
-      s_base = tot ? atomicAdd(&counters[0], tot) : 0;
-    }
-    __syncthreads();
-    int at = s_base;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q == wv && occ[k]) list[at + __popcll(bal[k] & ((1ull << lane) - 1ull))] = b0 + k * 256 + threadIdx.x;
-        at += s_cnt[k][q];
-      }
-    }
-    __syncthreads();
+  for (int k = 0; k < BS_ITEMS; ++k) {
+    const int i = c0 + threadIdx.x * BS_ITEMS + k;
+    if (i < len) off[i] = ex;
+    ex += vals[k];
+    if (vals[k] > 0 && i < nb) list[at++] = i;
   }
 }
 
@@ -1159,6 +1289,39 @@ extern "C" int64_t iso_bricks_workspace_bytes(int64_t n_max) {
   return bricks_carve(nullptr, n_max).bytes;
 }
 
+extern "C" int iso_bricks_workspace_init(void* workspace, int64_t n_max, void* stream) {
+  ISO_REQUIRE(workspace && n_max >= 0, ISO_ERR_INVALID, "iso_bricks_workspace_init: bad arguments");
+  ISO_REQUIRE(((uintptr_t)workspace & 255) == 0, ISO_ERR_INVALID, "iso_bricks_workspace_init: workspace must be 256-B aligned");
+  const BrickWs w = bricks_carve(workspace, n_max);
+  hipLaunchKernelGGL(k_bricks_init, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, (hipStream_t)stream, w.counters, w.cnt, w.G);
+  ISO_CHECK_LAUNCH("iso_bricks_workspace_init");
+  return ISO_OK;
+}
+
+// count -> offsets (+ work list, counters left zeroed) -> scatter, on a header that is already written
+static int bricks_fill(const BrickWs& w, const float* points, const float* normals, const int32_t* payload, int64_t n_own,
+                       const float* import_rec0, const float* import_rec1, const int32_t* import_count,
+                       int64_t import_max, hipStream_t s) {
+  if (n_own > 0)
+    hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 1024)), dim3(256), 0, s, points, n_own, w.hdr, w.cnt,
+                       w.slot);
+  if (import_max > 0)
+    hipLaunchKernelGGL(k_brick_count_recs, dim3(iso_stream_grid(import_max, 1024)), dim3(256), 0, s,
+                       (const float4*)import_rec0, import_count, import_max, w.hdr, w.cnt, w.slot);
+  const int chunks = (int)((w.G + BS_CHUNK - 1) / BS_CHUNK);
+  ISO_REQUIRE(w.scan_ws_bytes >= (int64_t)chunks * 4, ISO_ERR_WORKSPACE, "iso_bricks_build: scan workspace too small");
+  hipLaunchKernelGGL(k_brick_sums, dim3(chunks), dim3(256), 0, s, w.hdr, w.cnt, (int32_t*)w.scan_ws);
+  hipLaunchKernelGGL(k_brick_offsets, dim3(chunks), dim3(256), 0, s, w.hdr, w.cnt, w.off, (const int32_t*)w.scan_ws, w.list,
+                     w.counters);
+  if (n_own > 0)
+    hipLaunchKernelGGL(k_brick_scatter, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, normals, payload,
+                       n_own, w.hdr, w.off, w.slot, w.rec0, w.rec1);
+  if (import_max > 0)
+    hipLaunchKernelGGL(k_brick_scatter_recs, dim3(iso_stream_grid(import_max, 256)), dim3(256), 0, s,
+                       (const float4*)import_rec0, (const float4*)import_rec1, w.hdr, w.off, w.slot, w.rec0, w.rec1);
+  return ISO_OK;
+}
+
 extern "C" int iso_bricks_build(const float* points, const float* normals, const int32_t* payload,
                                 int64_t n_own, int64_t id_base, const float* import_rec0,
                                 const float* import_rec1, const int32_t* import_count, int64_t import_max,
@@ -1180,24 +1343,35 @@ extern "C" int iso_bricks_build(const float* points, const float* normals, const
   if (bbox)        // NULL: the header was written by iso_bricks_params (N ranks: between it and here the halo exchange)
     hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, s, bbox, 1, n_total, n_own, id_base, radius, knn_k,
                        cell_scale, w.nb_cap, w.hdr, w.counters);
-  hipLaunchKernelGGL(k_bricks_zero, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, s, w.hdr, w.cnt);
-  if (n_own > 0)
-    hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 1024)), dim3(256), 0, s, points, n_own, w.hdr, w.cnt,
-                       w.slot);
-  if (import_max > 0)
-    hipLaunchKernelGGL(k_brick_count_recs, dim3(iso_stream_grid(import_max, 1024)), dim3(256), 0, s,
-                       (const float4*)import_rec0, import_count, import_max, w.hdr, w.cnt, w.slot);
-  int rc = iso_frnn_scan_cells(w.cnt, w.off, reinterpret_cast<const float*>(w.hdr), 1, w.G, 3, w.scan_ws,
-                               w.scan_ws_bytes, stream);
+  int rc = bricks_fill(w, points, normals, payload, n_own, import_rec0, import_rec1, import_count, import_max, s);
   if (rc != ISO_OK) return rc;
-  if (n_own > 0)
-    hipLaunchKernelGGL(k_brick_scatter, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, normals, payload,
-                       n_own, w.hdr, w.off, w.slot, w.rec0, w.rec1);
-  if (import_max > 0)
-    hipLaunchKernelGGL(k_brick_scatter_recs, dim3(iso_stream_grid(import_max, 256)), dim3(256), 0, s,
-                       (const float4*)import_rec0, (const float4*)import_rec1, w.hdr, w.off, w.slot, w.rec0, w.rec1);
-  hipLaunchKernelGGL(k_brick_list, dim3(iso_stream_grid(w.G, 1024)), dim3(256), 0, s, w.hdr, w.off, w.list, w.counters);
   ISO_CHECK_LAUNCH("iso_bricks_build");
+  return ISO_OK;
+}
+
+extern "C" int iso_bricks_build_whole(const float* points, const float* normals, const int32_t* payload, int64_t n,
+                                      float radius, int knn_k, float cell_scale, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
+  ISO_REQUIRE(n >= 0 && workspace && (points || n == 0), ISO_ERR_INVALID, "iso_bricks_build_whole: bad arguments");
+  ISO_REQUIRE(cell_scale > 0.f && (radius > 0.f || knn_k > 0), ISO_ERR_INVALID,
+              "iso_bricks_build_whole: cell_scale and radius / knn_k must be positive");
+  ISO_REQUIRE(((uintptr_t)workspace & 255) == 0, ISO_ERR_INVALID, "iso_bricks_build_whole: workspace must be 256-B aligned");
+  ISO_REQUIRE(n < (1ll << 28), ISO_ERR_UNSUPPORTED, "iso_bricks_build_whole: ids must stay below 2^28");
+  const BrickWs w = bricks_carve(workspace, n);
+  ISO_REQUIRE(workspace_bytes >= w.bytes, ISO_ERR_WORKSPACE, "iso_bricks_build_whole: workspace too small (%lld < %lld)",
+              (long long)workspace_bytes, (long long)w.bytes);
+  hipStream_t s = (hipStream_t)stream;
+  if (n > 0) {
+    int gx = iso_div_up(n * 3, 256 * 4);       // four loads per thread and round; a stride of a multiple of 3 floats;
+    if (gx > 255) gx = 255;                    // six same-address atomics per workgroup: more workgroups cost more than they read
+    if (gx >= 3) gx -= gx % 3; else gx = 3;
+    hipLaunchKernelGGL(k_brick_bbox, dim3(gx), dim3(256), 0, s, points, n, w.counters);
+  }
+  hipLaunchKernelGGL(k_bricks_params_self, dim3(1), dim3(64), 0, s, n, n, (int64_t)0, radius, knn_k, cell_scale, w.nb_cap,
+                     w.hdr, w.counters);
+  int rc = bricks_fill(w, points, normals, payload, n, nullptr, nullptr, nullptr, 0, s);
+  if (rc != ISO_OK) return rc;
+  ISO_CHECK_LAUNCH("iso_bricks_build_whole");
   return ISO_OK;
 }
 

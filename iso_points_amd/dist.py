@@ -200,7 +200,6 @@ class IsoCycle(object):
             self.imp1 = torch.empty((self.import_cap, 4), dtype=torch.float32, device=dev)
             self.imp_count = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.wire = torch.empty((12 * self.rec_cap,), dtype=torch.float32, device=dev)
-        self._flags = torch.zeros((16,), dtype=torch.int32, device=dev)
 
     # -- stage 1/2: projection + resample -------------------------------------------------
     def _project(self, pts_local, T):
@@ -227,22 +226,16 @@ class IsoCycle(object):
         g.build(pts, nrm, payload=payload, params_done=True, id_base=self.lo, n_total=self.P,
                 imports=(self.imp0, self.imp1, self.imp_count))
 
-    def _note_counters(self):
-        """The grid's device-side counters (overflows, uncertified tail queries) are reset by the next build:
-        accumulate them over the cycle (one tiny kernel, no host read)."""
-        self._flags += self.grid.ws[256:320].view(torch.int32)
-
     def _resample(self, pts, nrm):
         """FRNN K+1 query + tangent-plane repulsion of the own points (levelset_sampling.py:254-284)."""
-        box = bricks.points_bbox(pts)
         cs = bricks.RESAMPLE_CELL * self.knn_k
         if self.world == 1:
-            self.grid.build(pts, nrm, bbox=box, knn_k=self.knn_k, cell_scale=cs)
+            self.grid.build(pts, nrm, knn_k=self.knn_k, cell_scale=cs)
         else:
+            box = bricks.points_bbox(pts)
             boxes = yield ("all_gather", box)
             yield from self._halo_build(pts, nrm, None, box, boxes, -1.0, self.knn_k, cs, self.halo_cells)
         moved, _, _ = bricks.resample_fused(self.grid, self.knn_k + 1)
-        self._note_counters()
         return moved
 
     def project_resample(self):
@@ -256,12 +249,12 @@ class IsoCycle(object):
     def _front(self, pts, nrm):
         ss, N, w = self.splat, self.N, self.world
         mask, cnt = bricks.view_mask(pts, nrm, self.views, ss.znear, ss.zfar, self.rs.backface_culling)
-        box = bricks.points_bbox(pts)
         counts = None
         if w == 1:
-            self.grid.build(pts, nrm, payload=mask, bbox=box, radius=float(ss.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
+            self.grid.build(pts, nrm, payload=mask, radius=float(ss.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
             view_total = cnt
         else:
+            box = bricks.points_bbox(pts)
             msg = torch.cat([box, cnt.view(torch.float32)])
             got = yield ("all_gather", msg)
             boxes = got[:, :8].contiguous()
@@ -270,7 +263,6 @@ class IsoCycle(object):
             yield from self._halo_build(pts, nrm, mask, box, boxes, float(ss.frnn_radius), 0, bricks.H_CELL_SCALE,
                                         self.halo_cells_h)
         h = bricks.splat_h_fused(self.grid, mask, view_total, N)
-        self._note_counters()
         fr = ss.front_setup(pts, nrm, self.views, self.projs, mask, h, features_from_normals=True, out=self.wire,
                             capacity=self.rec_cap)
         if w == 1:
@@ -375,7 +367,6 @@ class IsoCycle(object):
         image with the own band filled, gradient of the packed rows, fragments, front-end dict)."""
         # the SDF weights are packed once per cycle (they change once per optimiser step), not per projection
         self.proj.reuse_packed, self.proj._packed_cache = True, None
-        self._flags.zero_()
         r1 = yield from self.project_resample()
         fr = yield from self._front(r1.points[0].contiguous(), r1.normals[0].contiguous())
         if self.marks:
@@ -386,18 +377,31 @@ class IsoCycle(object):
         # loss of SURVEY 8(d) cfg 3: mean((alpha - target)^2) [+ 1e-2 mean(rgb^2): no grad to the op]
         alpha = img[..., 3]
         y0, y1 = self.band_rows()
-        tgt = self.target if self.target is not None else torch.zeros_like(alpha)
+        # d loss / d alpha = c (alpha - target), c = 2 / #pixels, as ONE pass over the image: c alpha + (-c target);
+        # the constant tensors (-c target, the zbuf gradient, both zero outside the rank's band) are made once
+        cgrad = self._loss_constants(alpha, frags.zbuf, y0, y1)
         if self.world == 1:
-            occ_grad = 2.0 * (alpha - tgt) / alpha.numel()
-            zbuf_grad = torch.zeros_like(frags.zbuf)
-            zbuf_grad[..., 0] = 1e-3 / alpha.numel()
+            occ_grad = torch.add(cgrad[0], alpha, alpha=cgrad[2])
         else:
             occ_grad = torch.zeros_like(alpha)
-            occ_grad[:, y0:y1] = 2.0 * (alpha[:, y0:y1] - tgt[:, y0:y1]) / alpha.numel()
-            zbuf_grad = torch.zeros_like(frags.zbuf)
-            zbuf_grad[:, y0:y1, :, 0] = 1e-3 / alpha.numel()
+            torch.add(cgrad[0][:, y0:y1], alpha[:, y0:y1], alpha=cgrad[2], out=occ_grad[:, y0:y1])
+        zbuf_grad = cgrad[1]
         grad = yield from self.backward(frags, fr, occ_grad, zbuf_grad)
         return r1, img, grad, frags, fr
+
+    def _loss_constants(self, alpha, zbuf, y0, y1):
+        """(-c target, zbuf gradient, c) of the cycle's loss, c = 2 / #pixels; the zbuf gradient is 1e-3 / #pixels
+        on the front-most slot of the rank's band rows and 0 elsewhere.  Built on first use (the eager warm-up pass),
+        constant afterwards."""
+        key = (tuple(alpha.shape), tuple(zbuf.shape), y0, y1)
+        if getattr(self, "_loss_key", None) != key:
+            c = 2.0 / alpha.numel()
+            tgt = self.target if self.target is not None else torch.zeros_like(alpha)
+            zg = torch.zeros_like(zbuf)
+            zg[:, y0:y1, :, 0] = 1e-3 / alpha.numel()
+            self._loss_c = ((-c) * tgt).contiguous(), zg, c
+            self._loss_key = key
+        return self._loss_c
 
     def run(self, g):
         """Drive a generator of this class (cycle, project_resample, ...) with the process group."""
@@ -468,7 +472,7 @@ class IsoCycle(object):
     def usage(self, fr=None):
         """Host read of the device-side counts of the last cycle (set-up / tests only)."""
         hdr = self.grid.header()
-        c = self._flags.tolist()                      # summed over the two grids of the cycle
+        c = self.grid.counters_since_last()           # summed over every grid built since the last call (all cycles)
         hdr["tail"], hdr["overflow_bricks"], hdr["tail_h"] = c[1], c[2], c[3]
         u = {"grid": hdr, "halo_export_overflow": c[4], "halo_import_overflow": c[5], "halo_uncertified": c[6],
              "pair_overflow": int(self._ovf[0].item()) if self._ovf else 0}
@@ -479,8 +483,8 @@ class IsoCycle(object):
             u["own_rows"] = int(fr["own_num"].sum().item())
         return u
 
-    def check(self, fr=None):
-        u = self.usage(fr)
+    def check(self, fr=None, usage=None):
+        u = usage if usage is not None else self.usage(fr)
         bad = [k for k in ("halo_export_overflow", "halo_import_overflow", "halo_uncertified", "pair_overflow") if u[k]]
         if self.world > 1 and (u["halo_exported"] > self.halo_cap or u["halo_imported"] > self.import_cap):
             bad.append("halo capacity")
@@ -494,16 +498,19 @@ class IsoCycle(object):
         """One synchronised cycle, then shrink the exchange buffers to `margin` x what it used (agreed
         over the ranks).  Untimed set-up; the capacities stay fixed afterwards and `check` reports
         an overflow."""
+        self.grid.counters_since_last()              # forget what earlier cycles counted
         out = self.step()
+        u = self.usage(out[4])
         if self.world > 1:
             # a bandwidth query near a slab face whose 7th neighbour lies beyond the exchanged band: widen it
             for _ in range(6):
-                unc = self.comm.max_int(int(self._flags[6].item()), self.dev)
-                if unc == 0:
+                if self.comm.max_int(u["halo_uncertified"], self.dev) == 0:
                     break
                 self.halo_cells_h *= 2
+                self._segs = None                     # captured segments have the old band width baked in
                 out = self.step()
-        u = self.check(out[4])
+                u = self.usage(out[4])
+        u = self.check(out[4], usage=u)
         if self.world > 1:
             c = self.comm
             self.halo_cap = max(1024, int(margin * c.max_int(u["halo_exported"], self.dev)))

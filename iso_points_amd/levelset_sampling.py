@@ -192,8 +192,11 @@ class UniformProjection(LevelSetProjection):
         n = pts.shape[0]
         dev = pts.device
         out = torch.empty_like(pts)
-        normals = torch.zeros_like(pts)
-        mask = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        # every point is evaluated at least once and the fused kernels write normals and mask for each point they
+        # evaluate (csrc/iso_newton.h: iso_step_finish; k_project_sphere): no zero fill; the mask is written as 0 / 1
+        # bytes straight into a bool tensor (no uint8 -> bool conversion pass)
+        normals = torch.empty_like(pts)
+        mask = torch.empty((n,), dtype=torch.bool, device=dev)
         p = _lib.ptr
         if getattr(model, "iso_analytic", None) == "sphere" and not forward_kwargs:
             cached = getattr(model, "_iso_center", None)     # host copy of the centre, re-read when the buffer changes
@@ -203,7 +206,7 @@ class UniformProjection(LevelSetProjection):
             c = cached[1]
             _lib.call("iso_project_sphere", p(pts), p(out), p(normals), p(mask), n, c[0], c[1], c[2],
                       float(model.radius), int(proj_max_iters), float(proj_tolerance), _lib.stream())
-            return out, normals, mask.bool()
+            return out, normals, mask
         if siren_spec(model) is not None and not forward_kwargs:
             ps = self._packed_cache if (self.reuse_packed and isinstance(self._packed_cache, PackedSiren)
                                         and self._packed_for is model) else PackedSiren(model, dev)
@@ -213,7 +216,7 @@ class UniformProjection(LevelSetProjection):
                       ps.hidden, ps.n_hidden, ps.omega_first, ps.omega_hidden, int(proj_max_iters),
                       float(proj_tolerance), p(ws), ws.numel(), _lib.stream())
             self._packed_cache = ps  # keep the workspace alive until the stream has used it
-            return out, normals, mask.bool()
+            return out, normals, mask
         if idr_spec(model) is not None and not forward_kwargs:
             pk = self._packed_cache if (self.reuse_packed and isinstance(self._packed_cache, PackedIdr)
                                         and self._packed_for is model) else PackedIdr(model, dev)
@@ -223,7 +226,7 @@ class UniformProjection(LevelSetProjection):
                       pk.n_layers, pk.skip, pk.n_freq, 100.0, int(proj_max_iters), float(proj_tolerance),
                       p(ws), ws.numel(), _lib.stream())
             self._packed_cache = pk
-            return out, normals, mask.bool()
+            return out, normals, mask
         return self._project_packed_generic(model, pts, proj_max_iters, proj_tolerance, **forward_kwargs)
 
     def _project_packed_generic(self, model, pts, proj_max_iters, proj_tolerance, **forward_kwargs):

@@ -12,6 +12,7 @@ from iso_points_amd.sdf_models import SphereSDF
 dev = torch.device("cuda:0")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 cyc = bench.Cycle(dev, SphereSDF().to(dev), Comm(enabled=False))
+cyc.cyc.marks = False          # as bench.analytic_cycle: no SDF kernel to bracket
 for _ in range(2):
     cyc.step()
 torch.cuda.synchronize()

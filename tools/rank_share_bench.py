@@ -67,13 +67,15 @@ def main():
         ranks = [IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, world=world, rank=r)
                  for r in range(world)]
         res = run_lockstep(ranks)
+        use = [c.usage(o[4]) for c, o in zip(ranks, res)]
         for _ in range(6):      # = IsoCycle.calibrate() without a process group: widen the bandwidth halo if needed
-            if max(int(c._flags[6].item()) for c in ranks) == 0:
+            if max(u["halo_uncertified"] for u in use) == 0:
                 break
             for c in ranks:
                 c.halo_cells_h *= 2
             res = run_lockstep(ranks)
-        use = [c.check(o[4]) for c, o in zip(ranks, res)]
+            use = [c.usage(o[4]) for c, o in zip(ranks, res)]
+        use = [c.check(o[4], usage=u) for c, o, u in zip(ranks, res, use)]
         if world > 1:
             for c in ranks:
                 c.halo_cap = max(1024, int(1.5 * max(u["halo_exported"] for u in use)))
