@@ -424,6 +424,11 @@ int iso_splat_bin_count(const float* points, const float* radii, const int64_t* 
                         const int64_t* num_pts, int n_clouds, int64_t max_pts, int image_size,
                         int image_width, int tile_row_begin, int tile_row_end, int32_t* tile_cnt,
                         void* stream);
+/* Offsets of the tile lists from the counts of iso_splat_bin_count in ONE launch: tile_off = exclusive scan of
+ * tile_cnt[0..n) (n = views x tiles + 1; same result as iso_prefix_sum), tile_cursor[0..n) = 0 (the fill cursors and,
+ * in the last word, the overflow flag iso_splat_forward expects cleared), and tile_cnt is cleared as it is read, so
+ * a caller that keeps the counter array never clears it again.                                        */
+int iso_splat_tile_offsets(int32_t* tile_cnt, int32_t* tile_off, int32_t* tile_cursor, int64_t n, void* stream);
 int iso_splat_forward(const float* points, const float* ellipse, const float* cutoff,
                       const float* radii, const int64_t* first_idx, const int64_t* num_pts,
                       int n_clouds, int64_t max_pts, float depth_merging_thres, int image_size,
@@ -485,7 +490,9 @@ int iso_splat_mark_visible(const int32_t* idx, int64_t n_pixels, int points_per_
                            uint8_t* visible, void* stream);
 /* search_radius_out[n] = lower-median(radii of the visible points of cloud n, both columns
  * flattened) * radii_s  (rasterizer.py:884, torch.median semantics), 0 for a cloud without
- * visible points.  Exact: 4-pass 8-bit radix select on the f32 bit patterns.                */
+ * visible points.  Exact: radix select on the f32 bit patterns, three histogram passes (11 + 11 + 10 bits) and
+ * a final pass.  The workspace holds the histograms: it must be ZERO on entry and is left zero on exit, so a
+ * caller that keeps one workspace clears it once (hipMemset) and never again.                        */
 int64_t iso_splat_median_radius_workspace_bytes(int n_clouds);
 int iso_splat_median_radius(const float* radii, const uint8_t* visible, const int64_t* first_idx,
                             const int64_t* num_pts, int n_clouds, int64_t max_pts, float radii_s,

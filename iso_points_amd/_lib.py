@@ -68,6 +68,7 @@ SIGNATURES = {
     "iso_splat_setup": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "iso_splat_tiles_per_side": (_I, [_I]),
     "iso_splat_bin_count": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P, _P]),
+    "iso_splat_tile_offsets": (_I, [_P, _P, _P, _L, _P]),
     "iso_splat_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P,
                                _L, _P]),
     "iso_splat_forward_workspace_bytes": (_L, [_L, _I]),

@@ -1252,51 +1252,43 @@ static inline BlkGeo make_blk(int H, int W) {
   return g;
 }
 
-// eight lanes per block, one pixel row each (a thread per block walked its 64 pixels as a chain of loads)
-__global__ void k_grad_blocks(const float* __restrict__ grad_occ, Frame F, BlkGeo G, int N,
-                              uint8_t* __restrict__ blk) {
-  const int64_t total = (int64_t)N * G.NBx * G.NBy;
-  const int64_t span = (int64_t)gridDim.x * blockDim.x / 8;
-  const int row = threadIdx.x & 7;
-  for (int64_t b0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 8;; b0 += span) {
-    if (b0 - (threadIdx.x & 63) / 8 >= total) break;                   // wave-uniform exit: the shuffles below need all lanes
-    const bool live = b0 < total;
-    const int64_t b = live ? b0 : 0;
-    const int bx = b % G.NBx, by = (b / G.NBx) % G.NBy, n = b / ((int64_t)G.NBx * G.NBy);
-    const int y = by * GB + row;
+// Both levels in one launch: one WAVE per 64x64-pixel super block, lane = one of its 8x8 blocks (lane % 8 = block
+// column); a lane reads the 8 rows of its block as 2 x 16 bytes each when the row is aligned, the super block's
+// flag is the ballot of the block flags.  Workgroup 0 also clears the few words the later passes count into
+// (heavy-point list length, z scale): no clearing launches.
+__global__ __launch_bounds__(256) void k_grad_maps(const float* __restrict__ grad_occ, Frame F, BlkGeo G, int N,
+                                                   uint8_t* __restrict__ blk, uint8_t* __restrict__ blk2,
+                                                   int32_t* __restrict__ clear_a, int n_clear_a,
+                                                   int32_t* __restrict__ clear_b, int n_clear_b) {
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < n_clear_a) clear_a[threadIdx.x] = 0;
+    if (clear_b && (int)threadIdx.x < n_clear_b) clear_b[threadIdx.x] = 0;
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t total = (int64_t)N * G.NB2x * G.NB2y;
+  for (int64_t sb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); sb < total; sb += (int64_t)gridDim.x * 4) {
+    const int sx = sb % G.NB2x, sy = (sb / G.NB2x) % G.NB2y, n = sb / ((int64_t)G.NB2x * G.NB2y);
+    const int bx = sx * 8 + (lane & 7), by = sy * 8 + (lane >> 3);
     int any = 0;
-    if (live && y < F.H)
-      for (int x = bx * GB; x < min(F.W, (bx + 1) * GB); ++x)
-        any |= grad_occ[((int64_t)n * F.H + y) * F.W + x] != 0.0f;
-    any |= __shfl_xor(any, 1);
-    any |= __shfl_xor(any, 2);
-    any |= __shfl_xor(any, 4);
-    if (live && row == 0) blk[b] = (uint8_t)any;
+    if (bx < G.NBx && by < G.NBy) {
+      const int x0 = bx * GB, x1 = min(F.W, x0 + GB);
+      for (int y = by * GB; y < min(F.H, (by + 1) * GB); ++y) {
+        const float* row = grad_occ + ((int64_t)n * F.H + y) * F.W;
+        if (x1 - x0 == GB && (((uintptr_t)(row + x0)) & 15) == 0) {
+          const float4 a = *reinterpret_cast<const float4*>(row + x0), c = *reinterpret_cast<const float4*>(row + x0 + 4);
+          any |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f) | (c.x != 0.f) | (c.y != 0.f) | (c.z != 0.f) |
+                 (c.w != 0.f);
+        } else {
+          for (int x = x0; x < x1; ++x) any |= row[x] != 0.0f;
+        }
+      }
+      blk[((int64_t)n * G.NBy + by) * G.NBx + bx] = (uint8_t)any;
+    }
+    const unsigned long long bal = __ballot(any != 0);
+    if (lane == 0) blk2[sb] = bal ? 1 : 0;
   }
 }
 
-// second level: 64x64-pixel super blocks (8x8 of the 8x8 blocks); eight lanes per super block, one row of blocks each
-__global__ void k_grad_superblocks(const uint8_t* __restrict__ blk, BlkGeo G, int N,
-                                   uint8_t* __restrict__ blk2) {
-  const int64_t total = (int64_t)N * G.NB2x * G.NB2y;
-  const int64_t span = (int64_t)gridDim.x * blockDim.x / 8;
-  const int row = threadIdx.x & 7;
-  for (int64_t b0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 8;; b0 += span) {
-    if (b0 - (threadIdx.x & 63) / 8 >= total) break;
-    const bool live = b0 < total;
-    const int64_t b = live ? b0 : 0;
-    const int bx = b % G.NB2x, by = (b / G.NB2x) % G.NB2y, n = b / ((int64_t)G.NB2x * G.NB2y);
-    const int y = by * 8 + row;
-    int any = 0;
-    if (live && y < G.NBy)
-      for (int x = bx * 8; x < min(G.NBx, (bx + 1) * 8); ++x)
-        any |= blk[((int64_t)n * G.NBy + y) * G.NBx + x] != 0;
-    any |= __shfl_xor(any, 1);
-    any |= __shfl_xor(any, 2);
-    any |= __shfl_xor(any, 4);
-    if (live && row == 0) blk2[b] = (uint8_t)any;
-  }
-}
 
 
 // output-pixel range [lo,hi] (after the axis flip) whose centres may lie within c +- r
@@ -1335,7 +1327,8 @@ __global__ __launch_bounds__(256) void k_splat_backward(
     const uint8_t* __restrict__ visible, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num,
     const uint8_t* __restrict__ blk2, BlkGeo G, Frame F, int rect_mode, float radii_s,
-    int32_t* __restrict__ heavy, int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
+    int32_t* __restrict__ heavy, int32_t* __restrict__ heavy_count, float* __restrict__ grad,
+    long long* __restrict__ zacc /* fixed-point z accumulators, cleared here row by row (NULL: none) */) {
   const int n = blockIdx.y;
   const int64_t len = num[n], base = first[n];
   const float r = rect_mode ? 0.f : rs[n];
@@ -1360,6 +1353,7 @@ __global__ __launch_bounds__(256) void k_splat_backward(
         const float rx = radii[p * 2], ry = radii[p * 2 + 1];
         const bool vis = (!visible || visible[p]);
         grad[p * 3] = 0.f; grad[p * 3 + 1] = 0.f; grad[p * 3 + 2] = 0.f;   // z: k_z_scatter / k_z_finish
+        if (zacc) zacc[p] = 0;
         const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
         // (the fast kernel skips points outside the image: rasterize_points_backward.cu:101-103; here: outside the frame)
         if (vis && !(pz < 0.f || fabsf(py) > F.ey || fabsf(px) > F.ex) && sx > 0.f && sy > 0.f) {
@@ -1473,97 +1467,96 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
 // ---------------------------------------------------------------- median radius (radix select)
 // r_n = lower-median(radii of the visible points of cloud n, both columns) * radii_s
 // (rasterizer.py:884; torch.median of the flattened (n,2) tensor).  Radii are >= 0, so their
-// f32 bit patterns order like unsigned integers: four 8-bit histogram passes pin the k-th key.
-struct RselState {      // one per cloud
-  unsigned prefix;      // bits decided so far
-  int shift;            // next digit = (key >> shift) & 255 ; starts at 24
-  long long k;          // rank still to find inside the current prefix bucket
-  long long cnt;        // number of values (2 * visible points)
-};
+// f32 bit patterns order like unsigned integers: three histogram passes over digits of 11 + 11 + 10 bits pin
+// the k-th key.  Four launches: every pass resolves the digits decided so far from the earlier histograms itself
+// (a 2048-bin prefix per workgroup -- cheaper than a launch in between), the last launch resolves all three,
+// writes the result and leaves the histograms zeroed, which is the state the workspace must be in on entry.
+constexpr int kRselBins = 2048;
+constexpr int kRselShift[3] = {21, 10, 0};
+constexpr int kRselBits[3] = {11, 11, 10};
 
-__global__ void k_rsel_init(RselState* st, unsigned* hist, int n_clouds) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_clouds) { st[i].prefix = 0u; st[i].shift = 24; st[i].k = -1; st[i].cnt = 0; }
-  if (i < n_clouds * 256) hist[i] = 0u;
+// Workgroup-wide (256 lanes): prefix and remaining rank after the first `passes` digits of cloud-local histograms
+// h[3][kRselBins].  Returns false when the cloud has no visible value.  All lanes get the same result.
+__device__ bool rsel_resolve(const unsigned* __restrict__ h, int passes, unsigned& prefix, long long& k, long long& cnt,
+                             long long* s_w /*[4]*/, long long* s_pub /*[2]*/) {
+  prefix = 0u; k = 0; cnt = 0;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (int q = 0; q < passes; ++q) {
+    const unsigned* hq = h + q * kRselBins;
+    long long v[8], sum = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = hq[t * 8 + e]; sum += v[e]; }
+    long long inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const long long u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    long long base = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { if (j < w) base += s_w[j]; tot += s_w[j]; }
+    if (q == 0) { cnt = tot; k = tot > 0 ? (tot - 1) / 2 : 0; }
+    if (cnt == 0) { __syncthreads(); return false; }
+    long long ex = base + inc - sum;                    // values in the bins before this lane's eight
+    if (k >= ex && k < ex + sum) {                      // exactly one lane holds rank k
+      int bsel = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { if (k >= ex + v[e] && e < 7 && bsel == e) { ex += v[e]; bsel = e + 1; } }
+      s_pub[0] = t * 8 + bsel; s_pub[1] = ex;
+    }
+    __syncthreads();
+    prefix |= ((unsigned)s_pub[0]) << kRselShift[q];
+    k -= s_pub[1];
+    __syncthreads();
+  }
+  return true;
 }
 
+template <int PASS>
 __global__ __launch_bounds__(256) void k_rsel_hist(const float* __restrict__ radii,
                                                    const uint8_t* __restrict__ visible,
                                                    const int64_t* __restrict__ first,
                                                    const int64_t* __restrict__ num,
-                                                   const RselState* __restrict__ st,
-                                                   unsigned* __restrict__ hist) {
-  __shared__ unsigned lh[256];
+                                                   unsigned* __restrict__ hist /*[n][3][kRselBins]*/) {
+  __shared__ unsigned lh[kRselBins];
+  __shared__ long long s_w[4], s_pub[2];
   const int n = blockIdx.y;
-  lh[threadIdx.x] = 0u;
+  unsigned prefix = 0u;
+  long long k, cnt;
+  if (PASS > 0 && !rsel_resolve(hist + (int64_t)n * 3 * kRselBins, PASS, prefix, k, cnt, s_w, s_pub)) return;
+  for (int j = threadIdx.x; j < kRselBins; j += 256) lh[j] = 0u;
   __syncthreads();
-  const unsigned prefix = st[n].prefix;
-  const int shift = st[n].shift;
-  const unsigned hi_mask = shift >= 24 ? 0u : (0xffffffffu << (shift + 8));
+  constexpr int shift = kRselShift[PASS];
+  constexpr unsigned dmask = (1u << kRselBits[PASS]) - 1u;
+  const unsigned hi_mask = PASS == 0 ? 0u : (0xffffffffu << (shift + kRselBits[PASS]));
   const int64_t len = num[n], base = first[n];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = base + i;
     if (!visible[p]) continue;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const unsigned key = __float_as_uint(radii[p * 2 + c]);
-      if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&lh[(key >> shift) & 255u], 1u);
-    }
+    const float2 r2 = *reinterpret_cast<const float2*>(radii + p * 2);
+    const unsigned k0 = __float_as_uint(r2.x), k1 = __float_as_uint(r2.y);
+    if ((k0 & hi_mask) == prefix) atomicAdd(&lh[(k0 >> shift) & dmask], 1u);
+    if ((k1 & hi_mask) == prefix) atomicAdd(&lh[(k1 >> shift) & dmask], 1u);
   }
   __syncthreads();
-  if (lh[threadIdx.x]) atomicAdd(&hist[n * 256 + threadIdx.x], lh[threadIdx.x]);
+  unsigned* hp = hist + ((int64_t)n * 3 + PASS) * kRselBins;
+  for (int j = threadIdx.x; j < kRselBins; j += 256)
+    if (lh[j]) atomicAdd(&hp[j], lh[j]);
 }
 
-// one 256-lane workgroup per cloud: bucket of the wanted rank by a parallel prefix over the 256 counters
-__global__ __launch_bounds__(256) void k_rsel_pick(RselState* st, unsigned* hist, int n_clouds, float radii_s,
-                                                   float* __restrict__ out) {
-  __shared__ long long s_w[4];
-  __shared__ int s_b;
+// one 256-lane workgroup per cloud: all three digits, the result, and the histograms back to zero
+__global__ __launch_bounds__(256) void k_rsel_final(unsigned* __restrict__ hist, int n_clouds, float radii_s,
+                                                    float* __restrict__ out) {
+  __shared__ long long s_w[4], s_pub[2];
   const int n = blockIdx.x;
   if (n >= n_clouds) return;
-  RselState s = st[n];
-  unsigned* h = hist + n * 256;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const long long v = h[t];
-  long long inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const long long u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-  if (lane == 63) s_w[w] = inc;
-  if (t == 0) s_b = 255;
+  unsigned* h = hist + (int64_t)n * 3 * kRselBins;
+  unsigned prefix;
+  long long k, cnt;
+  const bool any = rsel_resolve(h, 3, prefix, k, cnt, s_w, s_pub);
+  if (threadIdx.x == 0) out[n] = any ? __uint_as_float(prefix) * radii_s : 0.0f;
   __syncthreads();
-  long long base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { if (k < w) base += s_w[k]; tot += s_w[k]; }
-  inc += base;                                   // inclusive prefix of bucket t
-  if (s.k < 0) {                                 // first pass: total count and target rank
-    s.cnt = tot;
-    s.k = tot > 0 ? (tot - 1) / 2 : 0;
-  }
-  __syncthreads();
-  if (s.cnt > 0 && inc > s.k && inc - v <= s.k) s_b = t;     // the bucket that holds rank k (exactly one lane)
-  __syncthreads();
-  h[t] = 0u;
-  if (t == 0) {
-    if (s.cnt > 0) {
-      const int b = s_b;
-      long long cum = 0;
-      // exclusive prefix of bucket b = inclusive - count; recomputed from the shared partials is not needed:
-      // lane b published only its index, so fetch its exclusive prefix through LDS
-      (void)cum;
-      s.prefix |= ((unsigned)b) << s.shift;
-    }
-  }
-  // rank inside the bucket: k -= exclusive prefix of the chosen bucket (published by its lane)
-  __shared__ long long s_excl;
-  if (s.cnt > 0 && inc > s.k && inc - v <= s.k) s_excl = inc - v;
-  __syncthreads();
-  if (t == 0) {
-    if (s.cnt > 0) s.k -= s_excl;
-    s.shift -= 8;
-    st[n] = s;
-    if (s.shift < 0) out[n] = s.cnt > 0 ? __uint_as_float(s.prefix) * radii_s : 0.0f;
-  }
+  for (int j = threadIdx.x; j < 3 * kRselBins; j += 256) h[j] = 0u;
 }
 
 }  // namespace
@@ -1737,6 +1730,52 @@ extern "C" int iso_splat_bin_count(const float* points, const float* radii,
   launch_bin<false>(points, radii, first_idx, num_pts, n_clouds, max_pts, F, tile_row_begin,
                     tile_row_end, tile_cnt, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
   ISO_CHECK_LAUNCH("iso_splat_bin_count");
+  return ISO_OK;
+}
+
+namespace {
+// exclusive scan of the n tile counters by ONE workgroup (n = views x tiles + 1: a few thousand entries -- three
+// launches of a general multi-block scan for them were three launch latencies); the counters are cleared as they
+// are read (the next binning pass finds them zero) and the fill cursors start at zero
+__global__ __launch_bounds__(1024) void k_tile_offsets(int32_t* __restrict__ cnt, int32_t* __restrict__ off,
+                                                       int32_t* __restrict__ cursor, int64_t n) {
+  __shared__ int s_w[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int carry = 0;
+  for (int64_t c0 = 0; c0 < n; c0 += 4096) {
+    const int64_t i0 = c0 + (int64_t)threadIdx.x * 4;
+    int v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = 0;
+      if (i0 + k < n) { v[k] = cnt[i0 + k]; cnt[i0 + k] = 0; cursor[i0 + k] = 0; }
+      sum += v[k];
+    }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int sv = s_w[k]; if (k < w) base += sv; tot += sv; }
+    int ex = carry + base + inc - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < n) off[i0 + k] = ex;
+      ex += v[k];
+    }
+    carry += tot;
+    __syncthreads();
+  }
+}
+}  // namespace
+
+extern "C" int iso_splat_tile_offsets(int32_t* tile_cnt, int32_t* tile_off, int32_t* tile_cursor, int64_t n, void* stream) {
+  ISO_REQUIRE(n >= 0 && (n == 0 || (tile_cnt && tile_off && tile_cursor)), ISO_ERR_INVALID, "iso_splat_tile_offsets: bad arguments");
+  if (n == 0) return ISO_OK;
+  hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, (hipStream_t)stream, tile_cnt, tile_off, tile_cursor, n);
+  ISO_CHECK_LAUNCH("iso_splat_tile_offsets");
   return ISO_OK;
 }
 
@@ -1922,7 +1961,7 @@ extern "C" int iso_splat_mark_visible(const int32_t* idx, int64_t n_pixels, int 
 
 extern "C" int64_t iso_splat_median_radius_workspace_bytes(int n_clouds) {
   if (n_clouds < 0) n_clouds = 0;
-  return (int64_t)n_clouds * (256 * 4 + (int64_t)sizeof(RselState)) + 64;
+  return (int64_t)n_clouds * 3 * kRselBins * 4 + 64;
 }
 
 extern "C" int iso_splat_median_radius(const float* radii, const uint8_t* visible,
@@ -1936,18 +1975,17 @@ extern "C" int iso_splat_median_radius(const float* radii, const uint8_t* visibl
               ISO_ERR_INVALID, "iso_splat_median_radius: null pointer");
   ISO_REQUIRE(workspace_bytes >= iso_splat_median_radius_workspace_bytes(n_clouds), ISO_ERR_WORKSPACE,
               "iso_splat_median_radius: workspace too small");
+  ISO_REQUIRE(((uintptr_t)radii & 7) == 0, ISO_ERR_INVALID, "iso_splat_median_radius: radii must be 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  unsigned* hist = (unsigned*)workspace;
-  RselState* st = (RselState*)(hist + (int64_t)n_clouds * 256);
-  hipLaunchKernelGGL(k_rsel_init, dim3(iso_div_up((int64_t)n_clouds * 256, 256)), dim3(256), 0, s, st, hist, n_clouds);
+  unsigned* hist = (unsigned*)workspace;      // zero on entry (contract), zero again on exit (k_rsel_final)
   int gx = iso_div_up(max_pts > 0 ? max_pts : 1, 256 * 8);
   if (gx > 512) gx = 512;
-  for (int pass = 0; pass < 4; ++pass) {
-    if (max_pts > 0)
-      hipLaunchKernelGGL(k_rsel_hist, dim3(gx, n_clouds), dim3(256), 0, s, radii, visible, first_idx, num_pts, st, hist);
-    hipLaunchKernelGGL(k_rsel_pick, dim3(n_clouds), dim3(256), 0, s, st, hist, n_clouds, radii_s,
-                       search_radius_out);
+  if (max_pts > 0) {
+    hipLaunchKernelGGL(k_rsel_hist<0>, dim3(gx, n_clouds), dim3(256), 0, s, radii, visible, first_idx, num_pts, hist);
+    hipLaunchKernelGGL(k_rsel_hist<1>, dim3(gx, n_clouds), dim3(256), 0, s, radii, visible, first_idx, num_pts, hist);
+    hipLaunchKernelGGL(k_rsel_hist<2>, dim3(gx, n_clouds), dim3(256), 0, s, radii, visible, first_idx, num_pts, hist);
   }
+  hipLaunchKernelGGL(k_rsel_final, dim3(n_clouds), dim3(256), 0, s, hist, n_clouds, radii_s, search_radius_out);
   ISO_CHECK_LAUNCH("iso_splat_median_radius");
   return ISO_OK;
 }
@@ -2000,16 +2038,16 @@ __global__ __launch_bounds__(256) void k_z_absmax(const float* __restrict__ gz0,
 // terms_log2 = ceil(log2(max number of slots that can list one point)) = ceil(log2(S*S)): every term is
 // < 2^(61 - terms_log2) in magnitude after scaling, so no sum of them reaches 2^61 -- the range kept for
 // the NaN / Inf poison (a point that received one stays at >= 2^61 whatever else is added).
-__global__ void k_z_scale(ZScale* zs, int terms_log2) {
-  const unsigned b = zs->max_bits;
+__device__ __forceinline__ int z_exponent(unsigned max_bits, int terms_log2) {
   int e = 0;
-  if (b != 0u && b < 0x7f800000u) {
+  if (max_bits != 0u && max_bits < 0x7f800000u) {
     int ex;
-    (void)frexpf(__uint_as_float(b), &ex);      // max = f * 2^ex, f in [0.5,1)
+    (void)frexpf(__uint_as_float(max_bits), &ex);      // max = f * 2^ex, f in [0.5,1)
     e = 61 - terms_log2 - ex;
   }
-  zs->exp2 = e;
+  return e;
 }
+__global__ void k_z_scale(ZScale* zs, int terms_log2) { zs->exp2 = z_exponent(zs->max_bits, terms_log2); }
 
 __device__ __forceinline__ void z_scatter_one(int p, float g, int e, long long* __restrict__ acc) {
   if (g == 0.0f) return;
@@ -2021,11 +2059,13 @@ __device__ __forceinline__ void z_scatter_one(int p, float g, int e, long long* 
   atomicAdd(reinterpret_cast<unsigned long long*>(&acc[p]), (unsigned long long)q);
 }
 
+// terms_log2 >= 0: the exponent is derived here from zs->max_bits (no k_z_scale launch in between); < 0: zs->exp2
 __global__ void k_z_scatter(const int32_t* __restrict__ idx0, const float* __restrict__ gz0, int K, int64_t npix,
-                            const ZScale* __restrict__ zs, long long* __restrict__ acc, int64_t view_stride = 0) {
+                            const ZScale* __restrict__ zs, long long* __restrict__ acc, int64_t view_stride = 0,
+                            int terms_log2 = -1) {
   const int32_t* __restrict__ idx = idx0 + (int64_t)blockIdx.y * view_stride * K;
   const float* __restrict__ gz = gz0 + (int64_t)blockIdx.y * view_stride * K;
-  const int e = zs->exp2;
+  const int e = terms_log2 >= 0 ? z_exponent(zs->max_bits, terms_log2) : zs->exp2;
   if ((K & 3) == 0 && (((uintptr_t)idx | (uintptr_t)gz) & 15) == 0) {   // a pixel's lists as 16-byte loads
     const int4* __restrict__ idx4 = reinterpret_cast<const int4*>(idx);
     const float4* __restrict__ gz4 = reinterpret_cast<const float4*>(gz);
@@ -2051,9 +2091,25 @@ __global__ void k_z_scatter(const int32_t* __restrict__ idx0, const float* __res
 }
 
 __global__ void k_z_finish(const long long* __restrict__ acc, const ZScale* __restrict__ zs, int64_t n,
-                           float* __restrict__ grad) {
-  const int e = zs->exp2;
+                           float* __restrict__ grad, int terms_log2 = -1) {
+  const int e = terms_log2 >= 0 ? z_exponent(zs->max_bits, terms_log2) : zs->exp2;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    const long long a = acc[p];
+    float z = (float)ldexp((double)a, -e);
+    if (a >= (1ll << 61) || a <= -(1ll << 61)) z = __builtin_nanf("");
+    grad[p * 3 + 2] = z;
+  }
+}
+
+// the same over the rows of the clouds only (grid.y = cloud): rows of the packed arrays that belong to no cloud keep
+// what the caller put there, as in the xy pass
+__global__ void k_z_finish_clouds(const long long* __restrict__ acc, const ZScale* __restrict__ zs,
+                                  const int64_t* __restrict__ first, const int64_t* __restrict__ num,
+                                  float* __restrict__ grad, int terms_log2) {
+  const int e = z_exponent(zs->max_bits, terms_log2);
+  const int64_t len = num[blockIdx.y], base = first[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = base + i;
     const long long a = acc[p];
     float z = (float)ldexp((double)a, -e);
     if (a >= (1ll << 61) || a <= -(1ll << 61)) z = __builtin_nanf("");
@@ -2093,32 +2149,33 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
   hipStream_t s = (hipStream_t)stream;
   uint8_t* blk = (uint8_t*)workspace;
   uint8_t* blk2 = blk + (int64_t)n_clouds * G.NBx * G.NBy;
-  hipLaunchKernelGGL(k_grad_blocks, dim3(iso_stream_grid((int64_t)n_clouds * G.NBx * G.NBy * 8, 256)), dim3(256),
-                     0, s, grad_occ, F, G, n_clouds, blk);
-  hipLaunchKernelGGL(k_grad_superblocks, dim3(iso_stream_grid((int64_t)n_clouds * G.NB2x * G.NB2y * 8, 256)),
-                     dim3(256), 0, s, blk, G, n_clouds, blk2);
   int32_t* heavy_count = (int32_t*)((uint8_t*)workspace + bwd_maps_bytes(n_clouds, image_size, image_width));
   int32_t* heavy = heavy_count + 16;
-  iso_zero_words(heavy_count, 16, s);
+  const bool with_z = grad_zbuf && total_points > 0;
+  ZScale* zs = reinterpret_cast<ZScale*>((char*)(heavy_count) + 64 + (4 * total_points + 15) / 16 * 16);
+  long long* zacc = reinterpret_cast<long long*>((char*)zs + 16);
+  // block maps of the image gradient (both levels, one launch); it also clears the heavy-list length and the z scale
+  {
+    int gmaps = iso_div_up((int64_t)n_clouds * G.NB2x * G.NB2y, 4);
+    hipLaunchKernelGGL(k_grad_maps, dim3(gmaps < 1 ? 1 : gmaps), dim3(256), 0, s, grad_occ, F, G, n_clouds, blk, blk2,
+                       heavy_count, 16, with_z ? reinterpret_cast<int32_t*>(zs) : nullptr, 4);
+  }
   int gx = iso_div_up(max_pts, 1024); if (gx > 8192) gx = 8192;
-  // xy part point-major (z written as 0), then the z part pixel-major in fixed point
+  // xy part point-major (z written as 0, the z accumulators of the rows cleared), then the z part pixel-major in fixed point
   hipLaunchKernelGGL(k_splat_backward, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, visible,
                      search_radius, first_idx, num_pts, blk2, G, F, rect_mode, radii_s, heavy,
-                     heavy_count, grad_points);
-  if (grad_zbuf && total_points > 0) {
-    ZScale* zs = reinterpret_cast<ZScale*>((char*)(heavy_count) + 64 + (4 * total_points + 15) / 16 * 16);
-    long long* zacc = reinterpret_cast<long long*>((char*)zs + 16);
+                     heavy_count, grad_points, with_z ? zacc : nullptr);
+  if (with_z) {
     const int64_t npix = (int64_t)n_clouds * F.H * F.W;
-    iso_zero_words(zs, 4 + 2 * total_points, s);
     int gm = iso_div_up(npix * points_per_pixel, 256 * 16); if (gm > 1024) gm = 1024; if (gm < 1) gm = 1;
     hipLaunchKernelGGL(k_z_absmax, dim3(gm), dim3(256), 0, s, grad_zbuf, npix * points_per_pixel, zs);
     int terms_log2 = 0;
     while ((1ll << terms_log2) < (int64_t)F.H * F.W) ++terms_log2;
-    hipLaunchKernelGGL(k_z_scale, dim3(1), dim3(1), 0, s, zs, terms_log2);
+    // the exponent is derived from the maximum inside the two kernels that need it (no scale launch in between)
     hipLaunchKernelGGL(k_z_scatter, dim3(iso_stream_grid(npix, 256)), dim3(256), 0, s, idx, grad_zbuf,
-                       points_per_pixel, npix, zs, zacc);
-    hipLaunchKernelGGL(k_z_finish, dim3(iso_stream_grid(total_points, 256)), dim3(256), 0, s, zacc, zs,
-                       total_points, grad_points);
+                       points_per_pixel, npix, zs, zacc, (int64_t)0, terms_log2);
+    hipLaunchKernelGGL(k_z_finish_clouds, dim3(iso_stream_grid(max_pts, 256), n_clouds), dim3(256), 0, s, zacc, zs,
+                       first_idx, num_pts, grad_points, terms_log2);
   }
   hipLaunchKernelGGL(k_splat_backward_heavy, dim3(2048), dim3(256), 0, s, points, radii, search_radius,
                      first_idx, num_pts, n_clouds, grad_occ, blk, blk2, G, F, rect_mode, radii_s,

@@ -338,7 +338,7 @@ class IsoCycle(object):
         if self.world == 1:
             vis, rs_ = _visible_and_radius(idx, fr["radii"], first, num, scal, max_pts=fr["max_pts"])
             return _C._backward(fr["ndc"], fr["radii"], occ_grad_band, first, num, visible=vis, rs=rs_, idx=idx,
-                                grad_zbuf=zbuf_grad_band, max_pts=fr["max_pts"])
+                                grad_zbuf=zbuf_grad_band, max_pts=fr["max_pts"], rows_covered=True)
         dev, p, rows = idx.device, _lib.ptr, fr["rows"]
         y0, y1 = self.band_rows()
         occ_grad = yield ("all_reduce", occ_grad_band.contiguous(), "sum")

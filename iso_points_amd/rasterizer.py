@@ -155,19 +155,22 @@ class _CNamespace(object):
         ntiles = N * T * TW
         maxp = int(max_pts) if max_pts is not None else _max_pts(num)
         p, s = _lib.ptr, _lib.stream()
-        tile_cnt = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)
-        _lib.call("iso_splat_bin_count", p(pts), p(ra), p(first), p(num), N, maxp, S, W, band[0], band[1],
-                  p(tile_cnt), s)
-        tile_off = torch.empty_like(tile_cnt)
-        ws_b = lib.iso_prefix_sum_workspace_bytes(ntiles + 1, 1)
-        ws = torch.empty((ws_b,), dtype=torch.uint8, device=dev)
-        _lib.call("iso_prefix_sum", p(tile_cnt), p(tile_off), ntiles + 1, 1, ntiles + 1, p(ws), ws_b, s)
+        # counts -> offsets + cleared cursors in one launch; the counter array is cleared by the pass that reads it
+        tile_cnt = _zeroed_workspace("tile_cnt", dev, 4 * (ntiles + 1)).view(torch.int32)
+        tile_off = torch.empty((ntiles + 1,), dtype=torch.int32, device=dev)
+        cursor = torch.empty((ntiles + 1,), dtype=torch.int32, device=dev)   # [ntiles] = overflow flag
+        try:
+            _lib.call("iso_splat_bin_count", p(pts), p(ra), p(first), p(num), N, maxp, S, W, band[0], band[1],
+                      p(tile_cnt), s)
+            _lib.call("iso_splat_tile_offsets", p(tile_cnt), p(tile_off), p(cursor), ntiles + 1, s)
+        except Exception:
+            _ZEROED.pop(("tile_cnt", dev.index, 4 * (ntiles + 1)), None)     # it may hold counts: never reuse it
+            raise
         if pair_capacity is None:
             total = int(tile_off[ntiles].item())      # the one host read of the forward pass
         else:
             total = int(pair_capacity)
         pairs = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
-        cursor = torch.zeros((ntiles + 1,), dtype=torch.int32, device=dev)   # [ntiles] = overflow flag
         if overflow_out is not None:
             overflow_out.append(cursor[ntiles:])
         rws_b = lib.iso_splat_forward_workspace_bytes(N * TW * (band[1] - band[0]), K) if split_heavy_tiles else 0
@@ -197,11 +200,13 @@ class _CNamespace(object):
 
     @staticmethod
     def _backward(points, radii, grad_occ, first, num, visible=None, rs=None, rect_mode=0, radii_s=10.0,
-                  idx=None, grad_zbuf=None, max_pts=None):
+                  idx=None, grad_zbuf=None, max_pts=None, rows_covered=False):
+        """rows_covered: every row a caller will read lies in some cloud's [first, first + num) -- the kernels write
+        all three components of every such row, so the result needs no zero fill (rows outside: unspecified)."""
         dev = points.device
         P = points.shape[0]
         N, S, W = grad_occ.shape[0], grad_occ.shape[1], grad_occ.shape[2]
-        grad = torch.zeros((P, 3), dtype=torch.float32, device=dev)
+        grad = (torch.empty if rows_covered else torch.zeros)((P, 3), dtype=torch.float32, device=dev)
         if P == 0 or N == 0:
             return grad
         pts, ra, go = _f32c(points), _f32c(radii), _f32c(grad_occ)
@@ -276,18 +281,37 @@ def _visible_and_radius(idx, radii, first_idx, num_points, radii_s, max_pts=None
     return vis, median_radius(vis, radii, first_idx, num_points, radii_s, max_pts=max_pts)
 
 
+_ZEROED = {}
+
+
+def _zeroed_workspace(tag, dev, nbytes):
+    """A workspace for the entry points whose contract is "zero on entry, left zero on exit" (they clear what they
+    have read instead of starting with a clearing pass): cleared once, when it is first made, and kept per device
+    (a buffer made in eager mode keeps its address under graph capture and replay).  Calls that share one must be
+    ordered -- one stream, or streams the caller synchronises -- as torch's own cached workspaces require."""
+    key = (tag, dev.index, int(nbytes))
+    ws = _ZEROED.get(key)
+    if ws is None:
+        ws = torch.zeros((int(nbytes),), dtype=torch.uint8, device=dev)
+        _ZEROED[key] = ws
+    return ws
+
+
 def median_radius(vis, radii, first_idx, num_points, radii_s, max_pts=None):
     """(N,) device tensor r_n = median(visible radii of cloud n) * radii_s (iso_splat_median_radius)."""
     dev = radii.device
     N = num_points.shape[0]
-    lib = _lib.load()
-    ws_b = lib.iso_splat_median_radius_workspace_bytes(N)
-    ws = torch.empty((ws_b,), dtype=torch.uint8, device=dev)
+    ws = _zeroed_workspace("median_radius", dev, _lib.load().iso_splat_median_radius_workspace_bytes(N))
+    ws_b = ws.numel()
     out = torch.empty((N,), dtype=torch.float32, device=dev)
     p = _lib.ptr
-    _lib.call("iso_splat_median_radius", p(_f32c(radii)), p(vis), p(_i64c(first_idx)), p(_i64c(num_points)), N,
-              int(max_pts) if max_pts is not None else _max_pts(num_points), float(radii_s), p(ws), ws_b, p(out),
-              _lib.stream())
+    try:
+        _lib.call("iso_splat_median_radius", p(_f32c(radii)), p(vis), p(_i64c(first_idx)), p(_i64c(num_points)), N,
+                  int(max_pts) if max_pts is not None else _max_pts(num_points), float(radii_s), p(ws), ws_b, p(out),
+                  _lib.stream())
+    except Exception:
+        _ZEROED.pop(("median_radius", dev.index, ws_b), None)       # the histograms may be dirty: never reuse them
+        raise
     return out
 
 
