@@ -454,7 +454,7 @@ class SurfaceSplatting(object):
             raise NotImplementedError("only the default isotropic Vrk is built (SURVEY 2.1 #3)")
         P, N = points.shape[0], views.shape[0]
         if N > 8:
-            raise NotImplementedError("front: at most 8 views per call")
+            raise NotImplementedError("front: at most 8 views per pass (SurfaceSplatting.forward runs it in chunks)")
         dev = points.device
         mask, cnt = bricks.view_mask(points, normals, views, self.znear, self.zfar, rs.backface_culling)
         if grid is None:
@@ -509,47 +509,112 @@ class SurfaceSplatting(object):
             return cameras
         return (cameras.get_world_to_view_transform().get_matrix(), cameras.get_full_projection_transform().get_matrix())
 
+    @staticmethod
+    def _clouds_of(points, normals, features):
+        """[(points (P,3), normals (P,3), features (P,C) or None)] of a tensor triple or a Pointclouds-like container
+        (points_list() / normals_list() / features_list() when it has them, else the packed accessors with
+        cloud_to_packed_first_idx() / num_points_per_cloud(); a container of one cloud needs only *_packed())."""
+        if not hasattr(points, "points_packed"):
+            return [(points, normals, features)]
+        cloud = points
+        B = len(cloud)
+        feats = None
+        if features is not None:
+            feats = [features] if B == 1 else None
+        if B == 1:
+            f = feats[0] if feats else (cloud.features_packed() if hasattr(cloud, "features_packed") else None)
+            return [(cloud.points_packed(), cloud.normals_packed(), f)]
+        if hasattr(cloud, "points_list"):
+            pl, nl = cloud.points_list(), cloud.normals_list()
+            fl = cloud.features_list() if hasattr(cloud, "features_list") else None
+            return [(pl[b], nl[b], fl[b] if fl else None) for b in range(B)]
+        first = [int(x) for x in cloud.cloud_to_packed_first_idx().tolist()]
+        num = [int(x) for x in cloud.num_points_per_cloud().tolist()]
+        pp, nn = cloud.points_packed(), cloud.normals_packed()
+        ff = cloud.features_packed() if hasattr(cloud, "features_packed") else None
+        return [(pp[f0:f0 + n], nn[f0:f0 + n], ff[f0:f0 + n] if ff is not None else None) for f0, n in zip(first, num)]
+
     def forward(self, points, normals=None, cameras=None, features=None):
-        """points/normals (P,3) one cloud seen by N cameras (the reference extends the cloud to the
-        number of cameras, :597-598), or a Pointclouds-like container of ONE cloud (points_packed(),
-        normals_packed(), optionally features_packed()).  cameras: (views, projs) or a pytorch3d-style
-        camera object.  Returns (PointFragments, filtered dict)."""
-        if hasattr(points, "points_packed"):
-            cloud = points
-            if len(cloud) != 1:
-                raise NotImplementedError("SurfaceSplatting.forward: one cloud per call (it is extended to the cameras)")
-            points, normals = cloud.points_packed(), cloud.normals_packed()
-            if features is None and hasattr(cloud, "features_packed"):
-                features = cloud.features_packed()
+        """SurfaceSplatting.forward (rasterizer.py:584-661).  points / normals: (P,3) tensors of ONE cloud, or a
+        Pointclouds-like container of B clouds.  cameras: (views, projs) or a pytorch3d-style camera object, N of them.
+        As in the reference one cloud is extended to the N cameras (:597-598, :229-241); B > 1 clouds need B cameras,
+        cloud b is seen by camera b.  Any N (the fused front end takes 8 views per pass: it is run in chunks) and any
+        feature width.  Returns (PointFragments, filtered dict): the packed rows are view-major / cloud-major in
+        ascending point order -- the reference's packed layout."""
+        clouds = self._clouds_of(points, normals, features)
         views, projs = self._camera_matrices(cameras if cameras is not None else self.cameras)
+        views, projs = _f32c(views), _f32c(projs)
         rs = self.raster_settings
-        pts, nrm = _f32c(points.detach()), _f32c(normals.detach())
-        P, N = pts.shape[0], views.shape[0]
-        dev = pts.device
+        N, B = views.shape[0], len(clouds)
+        if B != 1 and B != N:
+            raise ValueError("SurfaceSplatting.forward: %d clouds need %d cameras (or one cloud for any number), got %d"
+                             % (B, B, N))
+        dev = views.device
         (S, W), K = image_hw(rs.image_size), int(rs.points_per_pixel)
-        with torch.no_grad():
-            fr = self.front(pts, nrm, _f32c(views), _f32c(projs), features=features)
-        lens = [int(x) for x in fr["num_points"].tolist()]          # the API returns exact-size tensors: one host read
+        # jobs: one cloud + a run of at most 8 cameras each (iso_splat_front's pass width)
+        jobs = []
+        if B == 1:
+            for v0 in range(0, N, 8):
+                jobs.append((clouds[0], v0, min(v0 + 8, N)))
+        else:
+            jobs = [(clouds[b], b, b + 1) for b in range(B)]
+        parts = []
+        for (pp, nn, ff), v0, v1 in jobs:
+            pts, nrm = _f32c(pp.detach()), _f32c(nn.detach())
+            wide = ff is not None and ff.shape[1] > 8        # wider than the front end packs: gathered afterwards
+            with torch.no_grad():
+                fr = self.front(pts, nrm, views[v0:v1], projs[v0:v1], features=None if wide else ff)
+            parts.append((fr, pts, nrm, pp, ff if wide else None))
+        # exact-size results: ONE host read of every job's row counts
+        counts = torch.cat([fr["num_points"] for fr, _, _, _, _ in parts]).tolist()
+        lens = [int(x) for x in counts]
         tot = sum(lens)
         fl = [sum(lens[:i]) for i in range(N)]
-        num = with_host_lengths(fr["num_points"], lens)
-        first = with_host_lengths(fr["first_idx"], fl)
-        flags = ((fr["mask"][None] >> torch.arange(N, device=dev)[:, None]) & 1).to(torch.int32)
+        num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
+        first = with_host_lengths(torch.tensor(fl, dtype=torch.int64, device=dev), fl)
+        flags_jobs = [((fr["mask"][None] >> torch.arange(v1 - v0, device=dev)[:, None]) & 1).to(torch.int32)
+                      for (fr, _, _, _, _), (_, v0, v1) in zip(parts, jobs)]
+        flags = torch.cat(flags_jobs, dim=0) if B == 1 else flags_jobs
         if tot == 0:
             idx = torch.full((N, S, W, K), -1, dtype=torch.int32, device=dev)
             neg = torch.full((N, S, W, K), -1.0, dtype=torch.float32, device=dev)
             occ = torch.zeros((N, S, W), dtype=torch.float32, device=dev)
             return PointFragments(idx, neg, neg.clone(), neg.clone(), occ), {"num_points": num, "first_idx": first,
                                                                              "flags": flags}
-        info = {k: fr[k][:tot] for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler")}
-        ndc = fr["ndc"][:tot]
-        if points.requires_grad:
-            # the reference's gradient reaches the world points through cameras.transform_points (:618); the set-up
-            # is under no_grad (:608-610)
-            ndc = _WorldToRows.apply(points, ndc, _f32c(views), _f32c(projs), fr["mask"], fr["src"], first, num)
-        src = fr["src"][:tot].long()
-        self._Vrk_h = fr["h"].view(-1)[(torch.arange(N, device=dev).repeat_interleave(torch.tensor(lens, device=dev))
-                                        * P + src)]
+        cols = {k: [] for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler", "ndc", "src", "features",
+                                "points", "normals", "h")}
+        v_at = 0
+        for (fr, pts, nrm, pp, wide_ff), (_, v0, v1) in zip(parts, jobs):
+            nv = v1 - v0
+            jl = lens[v_at:v_at + nv]
+            jt = sum(jl)
+            for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler"):
+                cols[k].append(fr[k][:jt])
+            ndc = fr["ndc"][:jt]
+            if pp.requires_grad:
+                # the reference's gradient reaches the world points through cameras.transform_points (:618); the
+                # set-up is under no_grad (:608-610)
+                jf = [sum(jl[:i]) for i in range(nv)]
+                ndc = _WorldToRows.apply(pp, ndc, views[v0:v1], projs[v0:v1], fr["mask"], fr["src"],
+                                         torch.tensor(jf, dtype=torch.int64, device=dev),
+                                         torch.tensor(jl, dtype=torch.int64, device=dev))
+            cols["ndc"].append(ndc)
+            src = fr["src"][:jt].long()
+            cols["src"].append(src)
+            cols["points"].append(pts[src])
+            cols["normals"].append(nrm[src])
+            if wide_ff is not None:
+                cols["features"].append(_f32c(wide_ff)[src])
+            elif fr["features"] is not None:
+                cols["features"].append(fr["features"][:jt])
+            P_j = pts.shape[0]
+            cols["h"].append(fr["h"].view(-1)[(torch.arange(nv, device=dev).repeat_interleave(torch.tensor(jl, device=dev))
+                                               * P_j + src)])
+            v_at += nv
+        cat = {k: (torch.cat(v, dim=0) if len(v) > 1 else v[0]) if v else None for k, v in cols.items()}
+        info = {k: cat[k] for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler")}
+        ndc = cat["ndc"]
+        self._Vrk_h = cat["h"]
         idx, zbuf, qv, occ = rasterize_elliptical_points(
             PackedClouds(ndc, first, num), info["ellipse_params"], info["cutoff_threshold"], info["radii"],
             depth_merging_threshold=rs.depth_merging_threshold, image_size=rs.image_size, points_per_pixel=K,
@@ -559,9 +624,9 @@ class SurfaceSplatting(object):
         frags = PointFragments(idx, zbuf, qv, frag_scaler, occ)
         vis = torch.zeros((tot,), dtype=torch.uint8, device=dev)
         _lib.call("iso_splat_mark_visible", _lib.ptr(idx), N * S * W, K, _lib.ptr(vis), _lib.stream())
-        filtered = {"points": pts[src], "normals": nrm[src],
-                    "features": fr["features"][:tot] if fr["features"] is not None else None, "ndc": ndc,
-                    "num_points": num, "first_idx": first, "flags": flags, "visibility": vis.bool(), "src": src, **info}
+        filtered = {"points": cat["points"], "normals": cat["normals"], "features": cat["features"], "ndc": ndc,
+                    "num_points": num, "first_idx": first, "flags": flags, "visibility": vis.bool(), "src": cat["src"],
+                    **info}
         return frags, filtered
 
 

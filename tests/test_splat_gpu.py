@@ -514,3 +514,83 @@ def test_forward_accepts_the_reference_containers(dev):
     b, _ = ss.forward(pts, pts, cameras=(views, projs))
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_forward_twelve_views_wide_features(dev):
+    """One cloud seen by 12 cameras with 16-channel features (the fused front end takes 8 views and packs up to 8
+    channels per pass: forward runs it in chunks and gathers wide features afterwards): view v of the 12-view call
+    equals the single-camera call with camera v, row for row and pixel for pixel, and the whole call agrees with the
+    oracle chain like test_surface_splatting_end_to_end."""
+    SO = _SO()
+    from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    S, K, NV, C = 48, 6, 12, 16
+    sc = sphere_scene(5000, n_views=NV, S=S, seed=9)
+    projs = torch.stack([v @ sc["proj"] for v in sc["views"]])
+    pts, nrm = sc["world_points"].to(dev), sc["world_normals"].to(dev)
+    feat = torch.randn(pts.shape[0], C, generator=torch.Generator().manual_seed(3)).to(dev)
+    ss = SurfaceSplatting(raster_settings=PointsRasterizationSettings(image_size=S, points_per_pixel=K))
+    frags, filt = ss.forward(pts, nrm, cameras=(sc["views"].to(dev), projs.to(dev)), features=feat)
+    assert frags.idx.shape == (NV, S, S, K) and filt["features"].shape == (int(sc["num"].sum()), C)
+    assert torch.equal(filt["flags"].bool().cpu(), sc["keep"]) and filt["num_points"].tolist() == sc["num"].tolist()
+    assert torch.equal(filt["points"].cpu(), sc["points"])
+    assert torch.equal(filt["features"], feat[filt["src"]])
+    first = filt["first_idx"].tolist()
+    for v in (0, 7, 8, 11):                                   # both chunks, their first and last views
+        one, f1 = ss.forward(pts, nrm, cameras=(sc["views"][v:v + 1].to(dev), projs[v:v + 1].to(dev)), features=feat)
+        n = int(f1["num_points"][0])
+        assert n == int(sc["num"][v])
+        for k in ("ndc", "radii", "ellipse_params", "scaler", "features"):
+            assert torch.equal(filt[k][first[v]:first[v] + n], f1[k]), k
+        i1 = one.idx[0]
+        shifted = torch.where(i1 >= 0, i1 + first[v], i1)
+        assert torch.equal(frags.idx[v], shifted) and torch.equal(frags.zbuf[v], one.zbuf[0])
+        assert torch.equal(frags.qvalue[v], one.qvalue[0]) and torch.equal(frags.occupancy[v], one.occupancy[0])
+    ref = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"], sc["num"], 0.05, S, K)
+    assert (frags.idx.cpu() == ref[0]).float().mean().item() > 0.999
+    assert (frags.occupancy.cpu() == ref[3]).float().mean() > 0.999
+
+
+@pytest.mark.gpu
+def test_forward_batch_of_clouds(dev):
+    """A Pointclouds-like container of three clouds of different sizes with three cameras (cloud b <-> camera b, the
+    reference's batch form, rasterizer.py:229-241): the packed result is the concatenation of the three single-cloud
+    calls, and each of those is checked against the oracle chain."""
+    SO = _SO()
+    from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    S, K = 40, 5
+    scs = [sphere_scene(P, n_views=3, S=S, seed=20 + i, radius=1.0 - 0.1 * i) for i, P in enumerate((4000, 2500, 3300))]
+    views = torch.stack([scs[b]["views"][b] for b in range(3)])
+    projs = torch.stack([views[b] @ scs[b]["proj"] for b in range(3)])
+    pl = [sc["world_points"].to(dev) for sc in scs]
+    nl = [sc["world_normals"].to(dev) for sc in scs]
+
+    class Clouds(object):
+        def __len__(s): return 3
+        def points_packed(s): return torch.cat(pl)
+        def normals_packed(s): return torch.cat(nl)
+        def cloud_to_packed_first_idx(s): return torch.tensor([0, pl[0].shape[0], pl[0].shape[0] + pl[1].shape[0]], device=dev)
+        def num_points_per_cloud(s): return torch.tensor([q.shape[0] for q in pl], device=dev)
+
+    ss = SurfaceSplatting(raster_settings=PointsRasterizationSettings(image_size=S, points_per_pixel=K))
+    frags, filt = ss.forward(Clouds(), cameras=(views.to(dev), projs.to(dev)))
+    assert frags.idx.shape == (3, S, S, K) and isinstance(filt["flags"], list) and len(filt["flags"]) == 3
+    first = filt["first_idx"].tolist()
+    for b in range(3):
+        one, f1 = ss.forward(pl[b], nl[b], cameras=(views[b:b + 1].to(dev), projs[b:b + 1].to(dev)))
+        n = int(f1["num_points"][0])
+        assert int(filt["num_points"][b]) == n == int(scs[b]["num"][b])
+        for k in ("ndc", "radii", "ellipse_params", "scaler", "points", "normals"):
+            assert torch.equal(filt[k][first[b]:first[b] + n], f1[k]), k
+        i1 = one.idx[0]
+        assert torch.equal(frags.idx[b], torch.where(i1 >= 0, i1 + first[b], i1))
+        assert torch.equal(frags.zbuf[b], one.zbuf[0]) and torch.equal(frags.occupancy[b], one.occupancy[0])
+        # the single-cloud call against the oracle chain of that (cloud, camera) pair
+        sc = scs[b]
+        sl = slice(int(sc["first"][b]), int(sc["first"][b]) + n)
+        ref = SO.splat_forward(sc["ndc"][sl], sc["ellipse"][sl], sc["cutoff"][sl], sc["radii"][sl],
+                               torch.tensor([0]), torch.tensor([n]), 0.05, S, K)
+        assert torch.equal(f1["points"].cpu(), sc["points"][sl])
+        assert (one.idx.cpu() == ref[0]).float().mean().item() > 0.999
+    with pytest.raises(ValueError):
+        ss.forward(Clouds(), cameras=(views[:2].to(dev), projs[:2].to(dev)))
