@@ -232,6 +232,55 @@ def generator_order_cycle(dev, model, comm, steps=3):
             "note": "same cycle, input cloud in generator (random) order"}
 
 
+def operator_api_cycle(dev, model, steps=3):
+    """The same configs[2] workload through the reference's OPERATOR signatures, the way train_mvr.py would drive them
+    -- no IsoCycle, no fused orchestration, no graphs, host reads where the reference's API has them:
+    UniformProjection.project_points(skip_upsampling=True) [levelset_sampling.py:353-439: project T=10, keep the
+    converged points, resample (tree + repulsion + project T=3)] -> SurfaceSplatting.forward on points that require grad
+    [rasterizer.py:584-661] -> composite [renderer.py:36-82] -> the cycle's loss -> autograd .backward() down to the
+    world points.  (project_points drops the points that did not converge before it resamples, as the reference does;
+    the headline cycle resamples all of them.)"""
+    from iso_points_amd.levelset_sampling import UniformProjection
+    from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting, composite
+    from iso_points_amd.dist import sphere_silhouette, slab_order
+    rs = PointsRasterizationSettings(image_size=IMAGE, points_per_pixel=KPIX, cutoff_threshold=1.0,
+                                     depth_merging_threshold=0.05, radii_backward_scaler=10, backface_culling=True,
+                                     Vrk_isotropic=True, bin_size=None)
+    views, projs = cameras(dev)
+    pts0 = sphere_cloud(P_TOTAL, seed=0, device=dev)
+    pts0 = pts0[:, slab_order(pts0[0], 1, local="cell")].contiguous()       # the headline's input order
+    target = sphere_silhouette(IMAGE, VIEWS, 3.0, 30.0, dev)
+    proj = UniformProjection(proj_max_iters=10, proj_tolerance=5e-5, knn_k=8, sample_iters=1)
+    ss = SurfaceSplatting(cameras=(views, projs), raster_settings=rs)
+    kept = [0]
+
+    def step():
+        out = proj.project_points(pts0, model, skip_upsampling=True)
+        m = out["mask"][0]
+        x = out["levelset_points"][0][m].detach().requires_grad_(True)
+        nrm = out["levelset_normals"][0][m]
+        kept[0] = x.shape[0]
+        frags, filt = ss.forward(x, nrm)
+        feat = 0.5 * (torch.nn.functional.normalize(filt["normals"], dim=-1) + 1.0)
+        img = composite(frags, filt["scaler"], feat)
+        loss = ((img[..., 3] - target) ** 2).mean() + 1e-3 * frags.zbuf[..., 0].mean()
+        loss.backward()
+        return x.grad
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": round(ms, 4), "value": round(P_TOTAL / (ms * 1e-3) / 1e6, 3), "unit": "Mpoints/s",
+            "points_kept_after_projection": kept[0],
+            "note": "UniformProjection.project_points(skip_upsampling=True) -> SurfaceSplatting.forward -> composite -> "
+                    "loss.backward(): the reference's operator signatures, eager, with their host reads; no IsoCycle, no graphs"}
+
+
 def analytic_cycle(dev, comm, args):
     """SURVEY 8(d) cfg 3a: the same cycle with the analytic sphere SDF -- the HBM-bound variant.
     Reported beside the headline (cfg 3b), not instead of it."""
@@ -518,6 +567,8 @@ def main():
             out["cfg3a_analytic_sdf"] = analytic_cycle(dev, comm, args)
             out["f32_mfma_mode"] = f32_mode_cycle(dev, model, comm)
             out["generator_order"] = generator_order_cycle(dev, model, comm)
+            out["operator_api"] = operator_api_cycle(dev, model)
+            out["operator_api"]["vs_headline"] = round(out["operator_api"]["ms_per_step"] / ms_per_step, 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))

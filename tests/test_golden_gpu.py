@@ -44,12 +44,11 @@ def test_siren_eval_and_fixed_count_projection(dev):
     x = g["points"].to(dev)
     r0 = UniformProjection(proj_tolerance=1e-30)._project_points(m, x, full_lengths(x), proj_max_iters=10)
     assert rel_err(r0.points, g["fixed_points"]) < 1e-5
-    # gradients: two float32 evaluations of a 4-layer omega=30 SIREN differ by a few 1e-5
-    # (test_projection_gpu.py::test_siren_grad_accuracy_vs_float64 shows both sit at that
-    # distance from the float64 value)
-    assert rel_err(r0.normals, g["fixed_normals"]) < 5e-5
-    # ... and in this test itself: against the float64 iteration the fused kernel is no further away than the
-    # reference's own float32 result (the golden) is, quantile by quantile
+    # gradients after ten moves: the yardstick is a float64 iteration of the same network.  The reference's OWN float32
+    # result (the golden) is up to 1.4e-5 away from it (measured: tools/diag/tolerance_probe.py), so "1e-5 against the
+    # golden" cannot be asked of anybody; what is asked: within 1e-5 of the float64 truth on EVERY point (measured
+    # 3.8e-6), no further from it than 1.5 x the reference's own float32 error quantile by quantile (measured ratios
+    # 0.28-1.02 split16, 0.28-1.23 f32 MFMA), and within 1e-5 + the golden's own error of the golden
     import copy
     from oracle import iso_oracle as O
     r64 = O.project_points(copy.deepcopy(m).cpu().double(), g["points"].double(), torch.tensor([g["points"].shape[1]]),
@@ -57,9 +56,11 @@ def test_siren_eval_and_fixed_count_projection(dev):
     scale = r64.normals.abs().max()
     e_ref = ((g["fixed_normals"].double() - r64.normals).abs().amax(-1) / scale).view(-1)
     e_our = ((r0.normals.cpu().double() - r64.normals).abs().amax(-1) / scale).view(-1)
+    assert e_our.max() < 1e-5, e_our.max().item()
+    assert rel_err(r0.normals, g["fixed_normals"]) < 1e-5 + e_ref.max().item()
     for q in (0.5, 0.9, 0.99, 1.0):
-        assert torch.quantile(e_our, q) <= 3 * torch.quantile(e_ref, q) + 2e-7, (q, torch.quantile(e_our, q).item(),
-                                                                                torch.quantile(e_ref, q).item())
+        assert torch.quantile(e_our, q) <= 1.5 * torch.quantile(e_ref, q) + 2e-7, (q, torch.quantile(e_our, q).item(),
+                                                                                  torch.quantile(e_ref, q).item())
     r = UniformProjection()._project_points(m, x, full_lengths(x), proj_max_iters=10)
     assert_projection_close(r.points, g["out_points"])
 
@@ -123,9 +124,11 @@ def test_fused_siren_vs_the_reference_siren_class(dev, name, mode):
         scale = r64.points.abs().max()
         e_ref = ((g["fixed_points"].double() - r64.points).abs().amax(-1) / scale).view(-1)
         e_our = ((r.points.cpu().double() - r64.points).abs().amax(-1) / scale).view(-1)
+        # measured ratios (tools/diag/tolerance_probe.py): split16 1.01-1.22, f32 MFMA 0.36-1.46
         for q in (0.5, 0.9, 0.99, 1.0):
-            assert torch.quantile(e_our, q) <= 3 * torch.quantile(e_ref, q) + 2e-7, (q, torch.quantile(e_our, q), torch.quantile(e_ref, q))
+            assert torch.quantile(e_our, q) <= 1.5 * torch.quantile(e_ref, q) + 2e-7, (q, torch.quantile(e_our, q), torch.quantile(e_ref, q))
         e_g = ((r.points.cpu() - g["fixed_points"]).abs().amax(-1) / g["fixed_points"].abs().max()).view(-1)
-        assert (e_g > 1e-5).float().mean() < 0.02 and e_g.median() < 1e-6
+        # against the golden itself: the chaotic points (both float32 runs far from float64) are 0.07 % / 0.40 % of the cloud
+        assert (e_g > 1e-5).float().mean() < 0.006 and e_g.median() < 1e-6
     finally:
         lib.iso_siren_set_gemm_mode(1)

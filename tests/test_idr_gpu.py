@@ -45,7 +45,7 @@ def test_idr_golden(dev):
         e_ref = ((gold.double() - truth).abs().amax(-1) / scale).view(-1)
         e_our = ((ours.cpu().double() - truth).abs().amax(-1) / scale).view(-1)
         for q in (0.5, 0.9, 0.99, 1.0):
-            assert torch.quantile(e_our, q) <= 3 * torch.quantile(e_ref, q) + 2e-7, (name, q, torch.quantile(e_our, q).item(),
+            assert torch.quantile(e_our, q) <= 1.5 * torch.quantile(e_ref, q) + 2e-7, (name, q, torch.quantile(e_our, q).item(),
                                                                                     torch.quantile(e_ref, q).item())
 
 
@@ -69,7 +69,7 @@ def test_idr_shapes_vs_oracle_and_float64(dev, H, NL, skip, NF):
     s_ref = (sdf32.double() - sdf64).abs().max().item()
     s_hip = (sdf.cpu().double() - sdf64).abs().max().item()
     print("H=%d L=%d: grad err vs f64: torch-f32 %.3g hip %.3g; sdf %.3g / %.3g" % (H, NL, e_ref, e_hip, s_ref, s_hip))
-    assert e_hip <= 3 * e_ref + 2e-6 and s_hip <= 3 * s_ref + 2e-7
+    assert e_hip <= 1.5 * e_ref + 2e-6 and s_hip <= 1.5 * s_ref + 2e-7
     assert rel_err(sdf, sdf32) < 1e-5 and rel_err(grad, grad32) < 2e-5
 
 
@@ -164,5 +164,7 @@ def test_idr_split16_operand_ranges(dev, H, NL, skip, NF, w_scale, head_scale, i
     s_ref = (sdf32.double() - sdf64).abs().max().item()
     s_hip = (sdf.cpu().double() - sdf64).abs().max().item()
     print("H=%d ws=%g hs=%g: grad err/max vs f64: torch-f32 %.3g hip %.3g; sdf %.3g / %.3g" % (H, w_scale, head_scale, e_ref, e_hip, s_ref, s_hip))
+    # (operand-range stress test: a max-over-points statistic of two float32 paths on networks scaled to the limits of
+    # the split-fp16 scales; the parity tests proper use 1.5 x)
     assert e_hip <= 3.0 * e_ref + 2e-6
     assert s_hip <= 3.0 * s_ref + 1e-6 * max(sdf64.abs().max().item(), 1e-30)

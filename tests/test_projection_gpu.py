@@ -167,6 +167,8 @@ def test_split16_operand_ranges(dev, hidden, n_layers, w_scale, head_scale, in_s
     e_ref = (grad32.double() - grad64).abs().max().item() / gs
     for mode in (1, 0):
         e = (out[mode][1].cpu().double() - grad64).abs().max().item() / gs
+        # (operand-range stress test: scales pushed to their limits; a max-over-points statistic of two float32 paths.
+        # The parity tests proper hold the kernels to 1.5 x the reference's own error, quantile by quantile.)
         assert e <= 3.0 * e_ref + 2e-6, (mode, e, e_ref)
     s_ref = (sdf32.double() - sdf64).abs().max().item()
     for mode in (1, 0):

@@ -28,18 +28,26 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def assert_projection_close(res_pts, ref_pts, stop_tol=5e-5, tol=1e-5, max_flip_frac=5e-3):
+FLIP_LOG = []
+
+
+def assert_projection_close(res_pts, ref_pts, stop_tol=5e-5, tol=1e-5, max_flip_frac=1e-3):
     """Positions after Newton projection.  Every point must agree to `tol` relative,
     except "stop flips": a point whose |sdf| lands within rounding of the stopping
     tolerance can take one move more or less on one side; such a point may differ by at
-    most ~stop_tol (one residual Newton move), and they must be rare.  Tests that pin the
-    iteration count (stop_tol ~ 0) therefore check the strict bound on every point."""
+    most ~stop_tol (one residual Newton move), and they must be rare: at most 0.1 % of the cloud
+    (two points for clouds below 2000: one flip in a 659-point cloud is 0.15 %).  The count is printed
+    (pytest -s) and kept in FLIP_LOG; measured over the GPU suite: 0 in most calls, at most 2 of 2000.
+    Tests that pin the iteration count (stop_tol ~ 0) check the strict bound on every point."""
     a, b = res_pts.detach().cpu().double(), ref_pts.detach().cpu().double()
     scale = b.abs().max().clamp_min(1e-30)
     err = (a - b).abs().amax(dim=-1) / scale
     bad = err > tol
     frac = bad.double().mean().item() if bad.numel() else 0.0
-    assert frac <= max_flip_frac, "%.4f%% of points differ by more than %g" % (100 * frac, tol)
+    FLIP_LOG.append((frac, int(bad.sum().item()), int(bad.numel())))
+    print("assert_projection_close: %d of %d points (%.4f%%) beyond %g (stop flips)" % (bad.sum().item(), bad.numel(), 100 * frac, tol))
+    assert bad.sum().item() <= max(max_flip_frac * bad.numel(), 2), \
+        "%.4f%% of points differ by more than %g (stop flips must stay below %.2f%%)" % (100 * frac, tol, 100 * max_flip_frac)
     if bad.any():
         assert err[bad].max().item() < 3 * stop_tol / scale.item() + tol, \
             "point differs by %g (> one residual Newton move)" % err[bad].max().item()
