@@ -657,6 +657,56 @@ int iso_splat_repack(const float* gathered, int64_t capacity, int world, int ran
                      float* features_out, int64_t* first_idx_out, int64_t* num_pts_out,
                      int64_t* own_first_out, int64_t* own_num_out, void* stream);
 
+/* ----------------------------------------------------------------------
+ * F. N ranks, splat stage: the fragment-side exchange (csrc/band.hip; SURVEY 8(e) -- the reference has no
+ *    distributed layer; the cell order it shards by is that of DSS/csrc/rasterize_points_backward.cu:119).
+ *
+ *    Every rank runs the front end on its own points and rasterises a BAND of 16-pixel tile rows of every view
+ *    (the balanced split of the tile rows over the ranks).  A packed row is needed by exactly the bands its
+ *    bounding box touches (the binning pass's test), so it is sent to those ranks only, in ONE all-to-all with equal
+ *    splits: `send` = world segments of iso_splat_band_segment_floats(cap_pair) floats, each a 16-int header
+ *    ([0..7] records per view, [8] records wanted) and cap_pair records of 13 floats (ndc 3, ellipse 3, radii 2,
+ *    scaler 1, features 3, the row's GLOBAL id: its position in the single-GPU packed layout).  Rows keep their
+ *    order inside a segment.  iso_splat_band_import lays the received segments out view-major and, inside a view, by
+ *    source rank: ascending global id, so the (z, id) tie rule of the rasteriser picks what the single-GPU run picks;
+ *    iso_splat_band_remap turns the band's per-pixel local row ids into the global ones (= the single-GPU lists).
+ *    Backward: the band's per-record results (64-bit fixed-point z sum, visible flag) go back into the slots the
+ *    records came in (iso_splat_band_return: world segments of cap_pair x 2 int64), the reverse all-to-all returns
+ *    them, iso_splat_band_merge adds them to the owner's rows (integer adds: order-independent).
+ *    flags (int32[1], caller-cleared): bit 0 a send segment overflowed cap_pair, bit 1 the local arrays did.
+ *    counts: (world, 8) int32 rows per view of every rank (all-gathered view totals of iso_splat_front).        */
+int64_t iso_splat_band_segment_floats(int64_t cap_pair);
+int64_t iso_splat_band_export_workspace_bytes(int64_t max_rows_per_view, int n_views, int world);
+int iso_splat_band_export(const float* ndc, const float* ellipse, const float* radii, const float* scaler,
+                          const float* features, const int64_t* first_idx, const int64_t* num_points,
+                          int n_views, int64_t max_rows_per_view, const int32_t* counts, int world, int rank,
+                          int image_size, int image_width, int64_t cap_pair, float* send, int32_t* sent_row,
+                          int64_t* acc_own, uint8_t* vis_own, int64_t* gid_first, int64_t* first_global,
+                          int64_t* num_global, int32_t* flags, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+int iso_splat_band_import(const float* recv, int world, int n_views, int64_t cap_pair, int64_t cap_local,
+                          float cutoff, float* ndc, float* ellipse, float* cutoff_out, float* radii,
+                          float* scaler, float* features, int32_t* gid, int32_t* origin, int64_t* acc_local,
+                          uint8_t* vis_local, int64_t* first_local, int64_t* num_local, int32_t* place,
+                          int32_t* flags, void* stream);
+int iso_splat_band_remap(const int32_t* idx_local, const int32_t* gid, int n_views, int64_t view_pixels,
+                         int64_t band_pixel0, int64_t band_pixels, int points_per_pixel, int32_t* idx_global,
+                         void* stream);
+int iso_splat_band_return(const int64_t* acc_local, const uint8_t* vis_local, const int32_t* origin,
+                          const int64_t* first_local, const int64_t* num_local, int n_views, int64_t cap_local,
+                          int64_t* ret, void* stream);
+int iso_splat_band_merge(const int64_t* back, const int32_t* sent_row, int world, int n_views,
+                         int64_t max_rows_per_view, int64_t cap_pair, int64_t* acc_own, uint8_t* vis_own,
+                         const void* workspace, void* stream);
+/* iso_splat_median_radius in pieces: pass 0, 1, 2 count the caller's rows into the pass's histograms (the slice
+ * workspace + pass * iso_splat_median_pass_words(n_clouds) words of that many words), N ranks sum that slice over
+ * the ranks before the next piece; iso_splat_median_final resolves and leaves the workspace zeroed.            */
+int64_t iso_splat_median_pass_words(int n_clouds);
+int iso_splat_median_pass(int pass, const float* radii, const uint8_t* visible, const int64_t* first_idx,
+                          const int64_t* num_pts, int n_clouds, int64_t max_pts, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+int iso_splat_median_final(void* workspace, int n_clouds, float radii_s, float* search_radius_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

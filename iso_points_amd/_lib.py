@@ -98,6 +98,17 @@ SIGNATURES = {
     "iso_splat_band_marks": (_I, [_P, _P, _I, _L, _L, _I, _P, _P, _P]),
     "iso_splat_band_z_scatter": (_I, [_P, _P, _I, _L, _L, _I, _P, _P, _P]),
     "iso_splat_repack": (_I, [_P, _L, _I, _I, _I, _P, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "iso_splat_band_segment_floats": (_L, [_L]),
+    "iso_splat_band_export_workspace_bytes": (_L, [_L, _I, _I]),
+    "iso_splat_band_export": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _P, _I, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P,
+                                   _P, _L, _P]),
+    "iso_splat_band_import": (_I, [_P, _I, _I, _L, _L, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "iso_splat_band_remap": (_I, [_P, _P, _I, _L, _L, _L, _I, _P, _P]),
+    "iso_splat_band_return": (_I, [_P, _P, _P, _P, _P, _I, _L, _P, _P]),
+    "iso_splat_band_merge": (_I, [_P, _P, _I, _I, _L, _L, _P, _P, _P, _P]),
+    "iso_splat_median_pass_words": (_L, [_I]),
+    "iso_splat_median_pass": (_I, [_I, _P, _P, _P, _P, _I, _L, _P, _L, _P]),
+    "iso_splat_median_final": (_I, [_P, _I, _F, _P, _P]),
     "iso_insert_fathers": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P]),
     "iso_insert_children": (_I, [_P, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P]),
     "iso_splat_points_backward": (_I, [_P, _L, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -31,25 +31,11 @@
 // gradients are bit-stable (the reference's gpuAtomicAdd order is not).
 #include <float.h>
 #include "iso_common.h"
+#include "splat_frame.h"
 
 #pragma clang fp contract(off)
 
 namespace {
-
-constexpr int TILE = 16;  // pixels per tile side; one workgroup = 16x16 lanes
-
-// Image frame: H rows x W columns of square pixels.  NDC follows pytorch3d's non-square convention: the
-// shorter side spans [-1, 1], the longer one [-e, e] with e = longer / shorter, i.e. a pixel is 2 / min(H, W)
-// wide in both axes; H == W is the reference's square image (rasterizer.py:52 supports nothing else).
-struct Frame { int W, H, Tx, Ty, m; float ex, ey; };
-static inline Frame make_frame(int H, int W) {
-  Frame F;
-  F.W = W; F.H = H; F.Tx = (W + 15) / 16; F.Ty = (H + 15) / 16; F.m = H < W ? H : W;
-  F.ex = (float)W / (float)F.m; F.ey = (float)H / (float)F.m;
-  return F;
-}
-__device__ __forceinline__ float ndc_x(int i, const Frame& F) { return -F.ex + (2 * i + 1.0f) / F.m; }
-__device__ __forceinline__ float ndc_y(int i, const Frame& F) { return -F.ey + (2 * i + 1.0f) / F.m; }
 
 __device__ __forceinline__ float esqrt_arg(float x) {  // eps_sqrt, mathHelper.py:20-25
   float a = fabsf(x);
@@ -379,25 +365,6 @@ __global__ __launch_bounds__(256) void k_splat_front(const float* __restrict__ p
       for (int j = threadIdx.x; j < cnt * Cs; j += 256) o.feat[p0 * Cs + j] = s_ft[j];
     __syncthreads();
   }
-}
-
-// ---------------------------------------------------------------- tile binning
-// NDC-index range of pixels whose centre can lie within [c-r, c+r] (one pixel of slack on
-// each side; the exact reference test runs in the raster kernel)
-// (n pixels along the axis, half extent e of the axis in NDC, m = min(H, W))
-__device__ __forceinline__ bool pixel_range(float c, float r, int n, float e, int m, int& lo, int& hi) {
-  if (!(r >= 0.f) || !(c == c)) return false;
-  float flo = ((c - r) + e) * 0.5f * (float)m - 0.5f;
-  float fhi = ((c + r) + e) * 0.5f * (float)m - 0.5f;
-  if (!(flo < 1e9f)) return false;
-  if (!(fhi > -1e9f)) return false;
-  flo = fmaxf(flo, -4.0f);
-  fhi = fminf(fhi, (float)n + 4.0f);
-  lo = (int)ceilf(flo) - 1;
-  hi = (int)floorf(fhi) + 1;
-  if (lo < 0) lo = 0;
-  if (hi > n - 1) hi = n - 1;
-  return lo <= hi;
 }
 
 template <bool FILL>
@@ -1477,12 +1444,14 @@ constexpr int kRselBits[3] = {11, 11, 10};
 
 // Workgroup-wide (256 lanes): prefix and remaining rank after the first `passes` digits of cloud-local histograms
 // h[3][kRselBins].  Returns false when the cloud has no visible value.  All lanes get the same result.
-__device__ bool rsel_resolve(const unsigned* __restrict__ h, int passes, unsigned& prefix, long long& k, long long& cnt,
-                             long long* s_w /*[4]*/, long long* s_pub /*[2]*/) {
+// (pass-major layout hist[3][n_clouds][kRselBins]: one pass's histograms are contiguous -- the N-rank path sums
+// exactly that slice over the ranks between two passes)
+__device__ bool rsel_resolve(const unsigned* __restrict__ hist, int n, int n_clouds, int passes, unsigned& prefix,
+                             long long& k, long long& cnt, long long* s_w /*[4]*/, long long* s_pub /*[2]*/) {
   prefix = 0u; k = 0; cnt = 0;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   for (int q = 0; q < passes; ++q) {
-    const unsigned* hq = h + q * kRselBins;
+    const unsigned* hq = hist + ((int64_t)q * n_clouds + n) * kRselBins;
     long long v[8], sum = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { v[e] = hq[t * 8 + e]; sum += v[e]; }
@@ -1516,13 +1485,13 @@ __global__ __launch_bounds__(256) void k_rsel_hist(const float* __restrict__ rad
                                                    const uint8_t* __restrict__ visible,
                                                    const int64_t* __restrict__ first,
                                                    const int64_t* __restrict__ num,
-                                                   unsigned* __restrict__ hist /*[n][3][kRselBins]*/) {
+                                                   unsigned* __restrict__ hist /*[3][n_clouds][kRselBins]*/) {
   __shared__ unsigned lh[kRselBins];
   __shared__ long long s_w[4], s_pub[2];
-  const int n = blockIdx.y;
+  const int n = blockIdx.y, n_clouds = gridDim.y;
   unsigned prefix = 0u;
   long long k, cnt;
-  if (PASS > 0 && !rsel_resolve(hist + (int64_t)n * 3 * kRselBins, PASS, prefix, k, cnt, s_w, s_pub)) return;
+  if (PASS > 0 && !rsel_resolve(hist, n, n_clouds, PASS, prefix, k, cnt, s_w, s_pub)) return;
   for (int j = threadIdx.x; j < kRselBins; j += 256) lh[j] = 0u;
   __syncthreads();
   constexpr int shift = kRselShift[PASS];
@@ -1539,7 +1508,7 @@ __global__ __launch_bounds__(256) void k_rsel_hist(const float* __restrict__ rad
     if ((k1 & hi_mask) == prefix) atomicAdd(&lh[(k1 >> shift) & dmask], 1u);
   }
   __syncthreads();
-  unsigned* hp = hist + ((int64_t)n * 3 + PASS) * kRselBins;
+  unsigned* hp = hist + ((int64_t)PASS * n_clouds + n) * kRselBins;
   for (int j = threadIdx.x; j < kRselBins; j += 256)
     if (lh[j]) atomicAdd(&hp[j], lh[j]);
 }
@@ -1550,13 +1519,13 @@ __global__ __launch_bounds__(256) void k_rsel_final(unsigned* __restrict__ hist,
   __shared__ long long s_w[4], s_pub[2];
   const int n = blockIdx.x;
   if (n >= n_clouds) return;
-  unsigned* h = hist + (int64_t)n * 3 * kRselBins;
   unsigned prefix;
   long long k, cnt;
-  const bool any = rsel_resolve(h, 3, prefix, k, cnt, s_w, s_pub);
+  const bool any = rsel_resolve(hist, n, n_clouds, 3, prefix, k, cnt, s_w, s_pub);
   if (threadIdx.x == 0) out[n] = any ? __uint_as_float(prefix) * radii_s : 0.0f;
   __syncthreads();
-  for (int j = threadIdx.x; j < 3 * kRselBins; j += 256) h[j] = 0u;
+  for (int q = 0; q < 3; ++q)
+    for (int j = threadIdx.x; j < kRselBins; j += 256) hist[((int64_t)q * n_clouds + n) * kRselBins + j] = 0u;
 }
 
 }  // namespace
@@ -1987,6 +1956,40 @@ extern "C" int iso_splat_median_radius(const float* radii, const uint8_t* visibl
   }
   hipLaunchKernelGGL(k_rsel_final, dim3(n_clouds), dim3(256), 0, s, hist, n_clouds, radii_s, search_radius_out);
   ISO_CHECK_LAUNCH("iso_splat_median_radius");
+  return ISO_OK;
+}
+
+// The same select in pieces (N ranks: every rank counts its OWN visible rows; the pass's histograms -- the slice
+// workspace + pass * n_clouds * 2048 words, n_clouds * 2048 words long -- are summed over the ranks before the next
+// piece runs).  pass = 0, 1, 2, then iso_splat_median_final.  Same workspace contract (zero on entry / on exit).
+extern "C" int64_t iso_splat_median_pass_words(int n_clouds) { return (int64_t)(n_clouds < 0 ? 0 : n_clouds) * kRselBins; }
+
+extern "C" int iso_splat_median_pass(int pass, const float* radii, const uint8_t* visible, const int64_t* first_idx,
+                                     const int64_t* num_pts, int n_clouds, int64_t max_pts, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  ISO_REQUIRE(pass >= 0 && pass <= 2 && n_clouds >= 0 && max_pts >= 0, ISO_ERR_INVALID, "iso_splat_median_pass: bad arguments");
+  if (n_clouds == 0 || max_pts == 0) return ISO_OK;
+  ISO_REQUIRE(radii && visible && first_idx && num_pts && workspace, ISO_ERR_INVALID, "iso_splat_median_pass: null pointer");
+  ISO_REQUIRE(workspace_bytes >= iso_splat_median_radius_workspace_bytes(n_clouds), ISO_ERR_WORKSPACE,
+              "iso_splat_median_pass: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned* hist = (unsigned*)workspace;
+  int gx = iso_div_up(max_pts, 256 * 8);
+  if (gx > 512) gx = 512;
+  if (pass == 0) hipLaunchKernelGGL(k_rsel_hist<0>, dim3(gx, n_clouds), dim3(256), 0, s, radii, visible, first_idx, num_pts, hist);
+  else if (pass == 1) hipLaunchKernelGGL(k_rsel_hist<1>, dim3(gx, n_clouds), dim3(256), 0, s, radii, visible, first_idx, num_pts, hist);
+  else hipLaunchKernelGGL(k_rsel_hist<2>, dim3(gx, n_clouds), dim3(256), 0, s, radii, visible, first_idx, num_pts, hist);
+  ISO_CHECK_LAUNCH("iso_splat_median_pass");
+  return ISO_OK;
+}
+
+extern "C" int iso_splat_median_final(void* workspace, int n_clouds, float radii_s, float* search_radius_out, void* stream) {
+  ISO_REQUIRE(n_clouds >= 0 && (n_clouds == 0 || (workspace && search_radius_out)), ISO_ERR_INVALID,
+              "iso_splat_median_final: bad arguments");
+  if (n_clouds == 0) return ISO_OK;
+  hipLaunchKernelGGL(k_rsel_final, dim3(n_clouds), dim3(256), 0, (hipStream_t)stream, (unsigned*)workspace, n_clouds, radii_s,
+                     search_radius_out);
+  ISO_CHECK_LAUNCH("iso_splat_median_final");
   return ISO_OK;
 }
 

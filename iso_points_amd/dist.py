@@ -17,15 +17,17 @@ point order is rank-major, so every index the single-GPU cycle produces keeps it
    bandwidth h (fused)                                            (points + view masks)
   filter / compaction / EWA      own points -> own packed rows    none
    set-up (fused front end)
-  tile binning, raster,          tiles: a band of 16-px tile      all-gather of the ranks' packed rows (48 B per
-   compositing, loss             rows per rank                    visible point-view: the inputs of every tile)
-  backward xy (point-major)      own rows                         all-reduce(sum) of the occ_grad bands (4 B/pixel),
-                                                                  all-reduce(max) of the visible flags (1 B/row)
-  backward z (pixel-major,       own band -> own rows             all-reduce(max) of the scale (8 B), all-reduce(sum)
-   fixed point)                                                   of the 64-bit accumulators
+  tile binning, raster,          tiles: a band of 16-px tile      ONE all-to-all of the packed rows, each row only
+   compositing, loss             rows per rank                    to the band(s) its box touches (52 B per record,
+                                                                  csrc/band.hip); the band works on local row ids
+  backward z (pixel-major,       own band -> per-record sums      all-reduce(max) of the scale (8 B); the reverse
+   fixed point) + visible flags                                   all-to-all returns 16 B per record to its owner
+  median radius                  own visible rows                 3 all-reduce(sum) of one pass's histograms (8 KB
+                                                                  per view) of the radix select
+  backward xy (point-major)      own rows                         all-reduce(sum) of the occ_grad bands (4 B/pixel)
 
-Nothing is replicated except the tile binning's pass over the gathered rows (each rank keeps the rows
-that reach its band) and the median radius of the backward.  No collective sits inside a kernel, none
+Nothing is replicated: binning, raster, compositing and the z scatter see a band's rows only, everything per
+point stays with the point's owner.  No collective sits inside a kernel, none
 needs a size from the host: buffers have calibrated capacities and device-side counts (`calibrate`,
 `check`).  With world == 1 every exchange disappears and the class is the single-GPU cycle bench.py
 times.  The cycle is written as a generator that yields its exchanges, so the same code runs under a
@@ -108,6 +110,7 @@ class Comm(object):
 
     def execute(self, req):
         """One request of the cycle generator: ("all_gather", x[, out]) -> (world, *x.shape) tensor,
+        ("all_to_all", x (world, ...)[, out]) -> (world, ...) tensor (equal splits: segment d of x goes to rank d),
         ("all_reduce", x, "sum"|"max") -> x reduced in place, ("mark", name, arg) -> None."""
         kind, x = req[0], req[1]
         if kind == "mark":
@@ -118,6 +121,17 @@ class Comm(object):
         if kind == "all_gather":
             out = req[2] if len(req) > 2 and req[2] is not None else x.new_empty((self.world,) + tuple(x.shape))
             self.dist.all_gather_into_tensor(out.view(-1), x.contiguous().view(-1), group=self.group)
+            return out
+        if kind == "all_to_all":          # x: (world, ...) segment d goes to rank d; out[s] = what rank s sent here
+            out = req[2] if len(req) > 2 and req[2] is not None else torch.empty_like(x)
+            if x.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                # gloo moves host memory only (the CPU / one-GPU test configurations; RCCL takes the device buffers)
+                hx = x.contiguous().view(-1).cpu()
+                ho = torch.empty_like(hx)
+                self.dist.all_to_all_single(ho, hx, group=self.group)
+                out.view(-1).copy_(ho)
+            else:
+                self.dist.all_to_all_single(out.view(-1), x.contiguous().view(-1), group=self.group)
             return out
         ops = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX}
         self.dist.all_reduce(x, op=ops[req[2]], group=self.group)
@@ -184,6 +198,8 @@ class IsoCycle(object):
         self.import_cap = 0 if w == 1 else max(4096, self.P - self.P // w)  # worst case: everybody else's points
         self.rec_cap = max(self.N * own_max, 1)
         self.pair_cap = max(1 << 16, 6 * self.N * self.P // w)
+        self.seg_cap = 0 if w == 1 else self.rec_cap          # records per ordered pair of ranks in the band exchange
+                                                              # (worst case: every own row needed by one band)
         self.halo_cells = 2           # exchanged band of the resample grid, in fine cells (2 x 0.8 r covers the radius r)
         self.halo_cells_h = 4         # ... of the bandwidth grid: its K = 7 search has no useful radius bound (r = 0.2);
                                       # a tail query that needs more than the band is counted (check: halo_uncertified)
@@ -200,6 +216,41 @@ class IsoCycle(object):
             self.imp1 = torch.empty((self.import_cap, 4), dtype=torch.float32, device=dev)
             self.imp_count = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.wire = torch.empty((12 * self.rec_cap,), dtype=torch.float32, device=dev)
+        if w > 1:
+            lib, N = _lib.load(), self.N
+            i64 = dict(dtype=torch.int64, device=dev)
+            f32 = dict(dtype=torch.float32, device=dev)
+            self.seg_floats = lib.iso_splat_band_segment_floats(self.seg_cap)
+            self.send = torch.zeros((w, self.seg_floats), **f32)
+            self.recv = torch.zeros((w, self.seg_floats), **f32)
+            self.sent_row = torch.zeros((w * self.seg_cap,), dtype=torch.int32, device=dev)
+            self.acc_own = torch.zeros((self.rec_cap,), **i64)
+            self.vis_own = torch.zeros((self.rec_cap,), dtype=torch.uint8, device=dev)
+            self.lay = torch.zeros((3, 8), **i64)                         # gid_first, first_global, num_global
+            self.band_flags = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.exp_ws = torch.zeros((lib.iso_splat_band_export_workspace_bytes(self.n_own, N, w),), dtype=torch.uint8,
+                                      device=dev)
+            self.cap_local = max(1, min(w * self.seg_cap, N * self.P))
+            cl = self.cap_local
+            self.loc = {"ndc": torch.zeros((cl, 3), **f32), "ellipse_params": torch.zeros((cl, 3), **f32),
+                        "cutoff_threshold": torch.zeros((cl,), **f32), "radii": torch.zeros((cl, 2), **f32),
+                        "scaler": torch.zeros((cl,), **f32), "features": torch.zeros((cl, 3), **f32)}
+            self.gid = torch.zeros((cl,), dtype=torch.int32, device=dev)
+            self.origin = torch.zeros((cl,), dtype=torch.int32, device=dev)
+            self.acc_l = torch.zeros((cl,), **i64)
+            self.vis_l = torch.zeros((cl,), dtype=torch.uint8, device=dev)
+            self.lay_l = torch.zeros((2, 8), **i64)                       # first_local, num_local
+            self.place = torch.zeros((3 * w * N,), dtype=torch.int32, device=dev)
+            self.ret = torch.zeros((w, self.seg_cap, 2), **i64)
+            self.back = torch.zeros((w, self.seg_cap, 2), **i64)
+            # the fragment arrays of the band: full-size (N,H,W,K) as the API has them, allocated and filled ONCE -- a
+            # cycle only rewrites the band's rows, the rest stays at the "no fragment" values
+            (S, W), K = self._image_hw(), int(self.rs.points_per_pixel)
+            self.frag = (torch.full((N, S, W, K), -1, dtype=torch.int32, device=dev), torch.full((N, S, W, K), -1.0, **f32),
+                         torch.full((N, S, W, K), -1.0, **f32), torch.zeros((N, S, W), **f32))
+            self.idx_g = torch.full((N, S, W, K), -1, dtype=torch.int32, device=dev)
+            self.img_out = torch.zeros((N, S, W, 4), **f32)
+            self.med_ws = torch.zeros((lib.iso_splat_median_radius_workspace_bytes(N),), dtype=torch.uint8, device=dev)
 
     # -- stage 1/2: projection + resample -------------------------------------------------
     def _project(self, pts_local, T):
@@ -268,65 +319,68 @@ class IsoCycle(object):
         if w == 1:
             fr["own_first"], fr["own_num"], fr["max_pts"], fr["rows"] = fr["first_idx"], fr["num_points"], self.P, self.rec_cap
             return fr
-        gathered = yield ("all_gather", self.wire)
-        rows = min(N * self.P, w * self.rec_cap)              # every rank sends at most rec_cap rows
-        dev = self.dev
-        out = {k: torch.empty((rows, c) if c > 1 else (rows,), dtype=torch.float32, device=dev)
-               for k, c in (("ndc", 3), ("ellipse_params", 3), ("cutoff_threshold", 1), ("radii", 2), ("scaler", 1),
-                            ("features", 3))}
-        fi = torch.empty((4, N), dtype=torch.int64, device=dev)
-        p = _lib.ptr
-        _lib.call("iso_splat_repack", p(gathered), self.rec_cap, w, self.rank, N, p(counts), float(self.rs.cutoff_threshold),
-                  rows, p(out["ndc"]), p(out["ellipse_params"]), p(out["cutoff_threshold"]), p(out["radii"]),
-                  p(out["scaler"]), p(out["features"]), p(fi[0]), p(fi[1]), p(fi[2]), p(fi[3]), _lib.stream())
-        out.update({"first_idx": fi[0], "num_points": fi[1], "own_first": fi[2], "own_num": fi[3], "src": fr["src"],
-                    "mask": mask, "h": h, "max_pts": self.P, "rows": rows, "own_counts": fr["view_total"]})
+        # the band exchange (csrc/band.hip): every own row goes to the ranks whose band of tile rows it touches
+        p, lib_call = _lib.ptr, _lib.call
+        S, W = self._image_hw()
+        lib_call("iso_splat_band_export", p(fr["ndc"]), p(fr["ellipse_params"]), p(fr["radii"]), p(fr["scaler"]),
+                 p(fr["features"]), p(fr["first_idx"]), p(fr["num_points"]), N, self.n_own, p(counts), w, self.rank, S, W,
+                 self.seg_cap, p(self.send), p(self.sent_row), p(self.acc_own), p(self.vis_own), p(self.lay[0]),
+                 p(self.lay[1]), p(self.lay[2]), p(self.band_flags), p(self.exp_ws), self.exp_ws.numel(), _lib.stream())
+        recv = yield ("all_to_all", self.send, self.recv)
+        L = self.loc
+        lib_call("iso_splat_band_import", p(recv), w, N, self.seg_cap, self.cap_local, float(self.rs.cutoff_threshold),
+                 p(L["ndc"]), p(L["ellipse_params"]), p(L["cutoff_threshold"]), p(L["radii"]), p(L["scaler"]),
+                 p(L["features"]), p(self.gid), p(self.origin), p(self.acc_l), p(self.vis_l), p(self.lay_l[0]),
+                 p(self.lay_l[1]), p(self.place), p(self.band_flags), _lib.stream())
+        out = dict(L)
+        out.update({"first_idx": self.lay_l[0, :N], "num_points": self.lay_l[1, :N],          # the band's local rows
+                    "own": fr,                                                                 # this rank's own rows
+                    "own_first": self.lay[0, :N], "own_num": fr["num_points"],                 # ... inside the global layout
+                    "local_first": fr["first_idx"],                                            # ... inside its own arrays
+                    "first_global": self.lay[1, :N], "num_global": self.lay[2, :N],
+                    "src": fr["src"], "mask": mask, "h": h, "max_pts": self.cap_local, "rows": self.cap_local,
+                    "own_counts": fr["view_total"], "counts": counts})
         return out
+
+    def _image_hw(self):
+        from .rasterizer import image_hw
+        return image_hw(self.rs.image_size)
 
     def splat_forward(self, fr):
         """Tile binning + raster of this rank's band of tile rows, the image composited in the same
-        kernel (renderer.py:53-78).  Returns (fragments, image with the own band filled)."""
+        kernel (renderer.py:53-78).  Returns (fragments, image with the own band filled).  N ranks: the inputs are
+        the rows the band received (local ids); fragments.idx carries the GLOBAL row ids (= the single-GPU lists),
+        the local lists stay in self._idx_l for the backward pass."""
         rs = self.rs
-        S, K = int(rs.image_size), int(rs.points_per_pixel)
-        T = _lib.load().iso_splat_tiles_per_side(S)
+        S, K = rs.image_size, int(rs.points_per_pixel)
+        H, W = self._image_hw()
+        T = _lib.load().iso_splat_tiles_per_side(H)
         self.band = shard_bounds(T, self.world, self.rank)
         self._ovf = []
+        many = self.world > 1
         idx, zbuf, qv, occ, img = _C.splat_points(
             fr["ndc"], fr["ellipse_params"], fr["cutoff_threshold"], fr["radii"], fr["first_idx"], fr["num_points"],
-            rs.depth_merging_threshold, S, K, 0, 0, tile_rows=self.band if self.world > 1 else None,
+            rs.depth_merging_threshold, S, K, 0, 0, tile_rows=self.band if many else None,
+            out=self.frag if many else None, image_out=self.img_out if many else None,
             max_pts=fr["max_pts"], pair_capacity=self.pair_cap, overflow_out=self._ovf,
             composite_with=(fr["scaler"], fr["features"], True, 1e-4))
-        return PointFragments(idx, zbuf, qv, None, occ), img
+        if not many:
+            return PointFragments(idx, zbuf, qv, None, occ), img
+        self._idx_l = idx
+        y0, y1 = self.band_rows()
+        _lib.call("iso_splat_band_remap", _lib.ptr(idx), _lib.ptr(self.gid), self.N, H * W, y0 * W, (y1 - y0) * W, K,
+                  _lib.ptr(self.idx_g), _lib.stream())
+        return PointFragments(self.idx_g, zbuf, qv, None, occ), img
 
     def band_rows(self):
         """Output-image pixel rows [y0, y1) of this rank's tile-row band (the image is flipped)."""
-        S = int(self.rs.image_size)
+        S = self._image_hw()[0]
         if self.world == 1:
             return 0, S
         b0, b1 = self.band
         return max(S - 16 * b1, 0), S - 16 * b0
 
     # -- stage 4: compositing + loss gradient + backward ------------------------------------------
-    def composite_band(self, frags, fr):
-        """(N,S,S,C+1) image, own band filled (renderer.py:53-78)."""
-        idx, qv, occ = frags.idx, frags.qvalue, frags.occupancy
-        N, S, _, K = idx.shape
-        feat = fr["features"]
-        C = feat.shape[1]
-        y0, y1 = self.band_rows()
-        p = _lib.ptr
-        if self.world == 1:
-            img = torch.empty((N, S, S, C + 1), dtype=torch.float32, device=idx.device)
-            _lib.call("iso_splat_composite", p(idx), p(qv), p(occ), p(fr["scaler"]), p(feat), N * S * S, K, C, 1, 1e-4,
-                      None, p(img), _lib.stream())
-            return img
-        img = torch.zeros((N, S, S, C + 1), dtype=torch.float32, device=idx.device)
-        for n in range(N):
-            if y1 > y0:
-                _lib.call("iso_splat_composite", p(idx[n, y0:y1]), p(qv[n, y0:y1]), p(occ[n, y0:y1]), p(fr["scaler"]),
-                          p(feat), (y1 - y0) * S, K, C, 1, 1e-4, None, p(img[n, y0:y1]), _lib.stream())
-        return img
-
     def backward(self, frags, fr, occ_grad_band, zbuf_grad_band):
         """occ_grad / zbuf_grad are valid on this rank's band (zero elsewhere).  Returns grad (rows,3):
         d loss / d (NDC x, y, z) of this rank's OWN packed rows fr['own_first'][v] .. + fr['own_num'][v]
@@ -339,26 +393,42 @@ class IsoCycle(object):
             vis, rs_ = _visible_and_radius(idx, fr["radii"], first, num, scal, max_pts=fr["max_pts"])
             return _C._backward(fr["ndc"], fr["radii"], occ_grad_band, first, num, visible=vis, rs=rs_, idx=idx,
                                 grad_zbuf=zbuf_grad_band, max_pts=fr["max_pts"], rows_covered=True)
-        dev, p, rows = idx.device, _lib.ptr, fr["rows"]
+        dev, p = idx.device, _lib.ptr
         y0, y1 = self.band_rows()
+        own = fr["own"]
         occ_grad = yield ("all_reduce", occ_grad_band.contiguous(), "sum")
-        vis = torch.zeros((rows,), dtype=torch.uint8, device=dev)
+        idx_l = self._idx_l                          # the band's lists in local row ids
         zmax = torch.zeros((2,), dtype=torch.int32, device=dev)
         H, W = idx.shape[1], idx.shape[2]
         band = (y1 - y0) * W                         # the band of every view in one call (grid.y = view)
-        _lib.call("iso_splat_band_marks", p(idx[0, y0:y1]) if band else None, p(zbuf_grad_band[0, y0:y1]) if band else None,
-                  N, H * W, band, K, p(vis), p(zmax), _lib.stream())
-        vis = yield ("all_reduce", vis, "max")
+        _lib.call("iso_splat_band_marks", p(idx_l[0, y0:y1]) if band else None, p(zbuf_grad_band[0, y0:y1]) if band else None,
+                  N, H * W, band, K, p(self.vis_l), p(zmax), _lib.stream())
         zmax = yield ("all_reduce", zmax, "max")
-        rs_ = median_radius(vis, fr["radii"], first, num, scal, max_pts=fr["max_pts"])
-        grad = _C._backward(fr["ndc"], fr["radii"], occ_grad, fr["own_first"], fr["own_num"], visible=vis, rs=rs_,
-                            max_pts=self.n_own)
-        acc = torch.zeros((rows,), dtype=torch.int64, device=dev)
         # (a rank without tile rows still derives the exponent: the call then only runs the scale kernel)
-        _lib.call("iso_splat_band_z_scatter", p(idx[0, y0:y1]) if band else None,
-                  p(zbuf_grad_band[0, y0:y1]) if band else None, N, H * W, band, K, p(zmax), p(acc), _lib.stream())
-        acc = yield ("all_reduce", acc, "sum")
-        _lib.call("iso_splat_z_finish", p(acc), p(zmax), 0, rows, p(grad), _lib.stream())
+        _lib.call("iso_splat_band_z_scatter", p(idx_l[0, y0:y1]) if band else None,
+                  p(zbuf_grad_band[0, y0:y1]) if band else None, N, H * W, band, K, p(zmax), p(self.acc_l), _lib.stream())
+        # what the band found, back to the owners of the records: fixed-point z sums and visible flags
+        _lib.call("iso_splat_band_return", p(self.acc_l), p(self.vis_l), p(self.origin), p(fr["first_idx"]),
+                  p(fr["num_points"]), N, self.cap_local, p(self.ret), _lib.stream())
+        back = yield ("all_to_all", self.ret, self.back)
+        _lib.call("iso_splat_band_merge", p(back), p(self.sent_row), self.world, N, self.n_own, self.seg_cap,
+                  p(self.acc_own), p(self.vis_own), p(self.exp_ws), _lib.stream())
+        # r = median radius of the visible rows of the WHOLE cloud: every rank counts its own rows, the histograms of a
+        # pass are summed over the ranks before the next pass resolves them (3 x 8 KB per view)
+        lib = _lib.load()
+        mws = self.med_ws                            # zero on entry, left zero by the final pass (this cycle's own: ranks
+        words = lib.iso_splat_median_pass_words(N)   # that share a process in run_lockstep must not share histograms)
+        hist = mws[:12 * words].view(torch.int32)
+        first_own, num_own = own["first_idx"], own["num_points"]
+        for ps in range(3):
+            _lib.call("iso_splat_median_pass", ps, p(own["radii"]), p(self.vis_own), p(first_own), p(num_own), N, self.n_own,
+                      p(mws), mws.numel(), _lib.stream())
+            yield ("all_reduce", hist[ps * words:(ps + 1) * words], "sum")
+        rs_ = torch.empty((N,), dtype=torch.float32, device=dev)
+        _lib.call("iso_splat_median_final", p(mws), N, scal, p(rs_), _lib.stream())
+        grad = _C._backward(own["ndc"], own["radii"], occ_grad, first_own, num_own, visible=self.vis_own, rs=rs_,
+                            max_pts=self.n_own, rows_covered=True)
+        _lib.call("iso_splat_z_finish", p(self.acc_own), p(zmax), 0, grad.shape[0], p(grad), _lib.stream())
         return grad
 
     # -- the whole cycle -----------------------------------------------------------------------
@@ -461,7 +531,7 @@ class IsoCycle(object):
                 print("rank %d segment %d (%s) replayed" % (self.rank, k, req[0] if req else "end"), flush=True)
             if req is None:
                 return self._final
-            if req[0] == "all_gather":
+            if req[0] in ("all_gather", "all_to_all"):
                 got = yield (req[0], req[1], static)
                 if got is not static:
                     static.copy_(got)
@@ -479,13 +549,17 @@ class IsoCycle(object):
         if self.world > 1:
             u["halo_exported"] = int(self.exp_buf[:1].view(torch.int32).item())
             u["halo_imported"] = int(self.imp_count.item())
+            u["band_overflow"] = int(self.band_flags.item())          # bit 0: a send segment, bit 1: the local arrays
+            u["segment_records"] = int(self.send[:, 8].contiguous().view(torch.int32).max().item())   # largest segment wanted
+            u["band_rows"] = int((self.lay_l[0, self.N - 1] + self.lay_l[1, self.N - 1]).item())       # rows this band received
         if fr is not None:
             u["own_rows"] = int(fr["own_num"].sum().item())
         return u
 
     def check(self, fr=None, usage=None):
         u = usage if usage is not None else self.usage(fr)
-        bad = [k for k in ("halo_export_overflow", "halo_import_overflow", "halo_uncertified", "pair_overflow") if u[k]]
+        bad = [k for k in ("halo_export_overflow", "halo_import_overflow", "halo_uncertified", "pair_overflow", "band_overflow")
+               if u.get(k)]
         if self.world > 1 and (u["halo_exported"] > self.halo_cap or u["halo_imported"] > self.import_cap):
             bad.append("halo capacity")
         if fr is not None and self.world > 1 and u["own_rows"] > self.rec_cap:
@@ -516,6 +590,7 @@ class IsoCycle(object):
             self.halo_cap = max(1024, int(margin * c.max_int(u["halo_exported"], self.dev)))
             self.import_cap = max(1024, int(margin * c.max_int(u["halo_imported"], self.dev)))
             self.rec_cap = max(1024, int(min(margin, 1.25) * c.max_int(u["own_rows"], self.dev)))
+            self.seg_cap = max(1024, int(min(margin, 1.25) * c.max_int(u["segment_records"], self.dev)))
             self._alloc()
         return u
 
@@ -557,6 +632,14 @@ def run_lockstep(cycles, timer=None):
                     send.append(q[2])
                 else:
                     send.append(g.clone() if len(reqs) > 1 and getattr(cycles[0], "use_graphs", False) else g)
+        elif kind == "all_to_all":
+            send = []
+            for r, q in enumerate(reqs):
+                got = torch.stack([reqs[s_][1][r] for s_ in range(len(reqs))])
+                if len(q) > 2 and q[2] is not None:
+                    q[2].copy_(got)
+                    got = q[2]
+                send.append(got)
         else:
             st = torch.stack([q[1] for q in reqs])
             red = st.sum(dim=0) if reqs[0][2] == "sum" else st.max(dim=0).values

@@ -127,6 +127,23 @@ class LevelSetProjection(object):
         raise NotImplementedError
 
 
+_GENERIC_WARNED = set()
+
+
+def _warn_generic_route(model, has_kwargs):
+    """Once per model class: this network has no fused SDF kernel (SIREN 3 -> H <= 256 x <= 8 sine layers -> 1 and
+    IDR-style 128 / 256 / 512 do), so the projection runs the reference's torch loop (model.forward + autograd per
+    iteration).  Loud on purpose: it is 10-100x slower and it is not the path the benchmarks measure."""
+    key = (type(model).__name__, has_kwargs)
+    if key in _GENERIC_WARNED:
+        return
+    _GENERIC_WARNED.add(key)
+    import warnings
+    warnings.warn("iso_points_amd: no fused SDF kernel for %s%s -- UniformProjection falls back to the generic torch "
+                  "autograd loop (levelset_sampling.py:306-341), far slower than the fused path"
+                  % (type(model).__name__, " called with forward kwargs" if has_kwargs else ""), RuntimeWarning, stacklevel=3)
+
+
 class UniformProjection(LevelSetProjection):
     """Same constructor as the reference (levelset_sampling.py:92-108)."""
 
@@ -227,6 +244,7 @@ class UniformProjection(LevelSetProjection):
                       p(ws), ws.numel(), _lib.stream())
             self._packed_cache = pk
             return out, normals, mask
+        _warn_generic_route(model, bool(forward_kwargs))
         return self._project_packed_generic(model, pts, proj_max_iters, proj_tolerance, **forward_kwargs)
 
     def _project_packed_generic(self, model, pts, proj_max_iters, proj_tolerance, **forward_kwargs):
@@ -277,6 +295,15 @@ class UniformProjection(LevelSetProjection):
         (csrc/insert.hip).  ref_pcl: one cloud with points_packed() (R,3) and features_packed() (R,1), the
         per-point metric.  Returns (points + children, num_points + children, children padded, children
         per cloud).  One host read, of the result sizes."""
+        B = points.shape[0]
+        try:
+            return self._insert(ref_pcl, points, num_points, current_knn_result)
+        except Exception as e:                                        # :226-229: any failure -> no children, logged
+            import logging
+            logging.getLogger(__name__).error("Error occurred during insertion %s", e)
+            return points, num_points, points.new_zeros((B, 0, 3)), with_host_lengths(num_points.new_zeros((B,)), [0] * B)
+
+    def _insert(self, ref_pcl, points, num_points, current_knn_result=None):
         from . import bricks
         PATCH = 8                                                     # neighbours that mother a child (:181)
         B, P = points.shape[0], points.shape[1]
@@ -306,7 +333,8 @@ class UniformProjection(LevelSetProjection):
         bar = torch.minimum(metric.median() * 2, metric.max() * 0.5)
         above = (metric > bar).sum()
         n_sel = torch.where((above >= 1) & (above <= cap), above, torch.full_like(above, kmax)).to(torch.int32).view(1)
-        selected = ref_xyz[torch.topk(metric, kmax).indices].contiguous()
+        # the kmax largest, ties at the cut resolved like the reference's ascending sort()[-kmax:] (:193-194)
+        selected = ref_xyz[torch.sort(metric, stable=True).indices[-kmax:].flip(0)].contiguous()
         limits = torch.stack([(radius * 4) ** 2, 4 * spacing * spacing]).float().contiguous()
         father = torch.empty((B, P), dtype=torch.uint8, device=dev)
         lens_dev = num_points.to(torch.int64).contiguous()

@@ -103,7 +103,7 @@ def siren_spec(model):
     H = lins[0].out_features
     if lins[0].in_features != 3 or lins[-1].out_features != 1 or lins[-1].in_features != H:
         return None
-    if H not in (64, 128, 256) or len(lins) - 2 > 8:
+    if H < 1 or H > 256 or len(lins) - 2 > 8:       # widths other than 64 / 128 / 256 are zero-padded up (PackedSiren)
         return None
     for lin in lins[1:-1]:
         if lin.in_features != H or lin.out_features != H:
@@ -123,12 +123,26 @@ class PackedSiren(object):
         if spec is None:
             raise ValueError("model is not a SIREN the fused kernel supports")
         lins, self.omega_first, self.omega_hidden = spec
-        self.hidden = lins[0].out_features
+        self.model_hidden = lins[0].out_features
+        # the fused kernels exist for H = 64 / 128 / 256: any other width runs as the next one up with ZERO rows and
+        # columns added -- a padded unit has z = 0, sin(0) = 0 and feeds zero columns, so value and gradient are those
+        # of the unpadded network (zeros add exactly nothing to a sum)
+        self.hidden = H = next(h for h in (64, 128, 256) if h >= self.model_hidden)
         self.n_hidden = len(lins) - 2
         parts = []
-        for lin in lins:
-            parts += [lin.weight.detach().reshape(-1), lin.bias.detach().reshape(-1)]
-        raw = torch.cat(parts).to(device=device, dtype=torch.float32).contiguous()
+        for i, lin in enumerate(lins):
+            w = lin.weight.detach().to(device=device, dtype=torch.float32)
+            b = lin.bias.detach().to(device=device, dtype=torch.float32)
+            rows = H if i < len(lins) - 1 else w.shape[0]
+            cols = H if i > 0 else w.shape[1]
+            if (rows, cols) != tuple(w.shape):
+                wp = w.new_zeros((rows, cols))
+                wp[:w.shape[0], :w.shape[1]] = w
+                bp = b.new_zeros((rows,))
+                bp[:b.shape[0]] = b
+                w, b = wp, bp
+            parts += [w.reshape(-1), b.reshape(-1)]
+        raw = torch.cat(parts).contiguous()
         lib = _lib.load()
         assert raw.numel() == lib.iso_siren_raw_floats(self.hidden, self.n_hidden)
         self.packed = torch.empty((lib.iso_siren_packed_floats(self.hidden, self.n_hidden),),

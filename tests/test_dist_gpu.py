@@ -60,13 +60,25 @@ def test_lockstep_ranks_equal_single_gpu(dev, world, P, S, N, kind):
         lo, hi = shard_bounds(P, world, r)
         assert torch.equal(q1.points[0], r1.points[0, lo:hi]), "rank %d: resampled points differ" % r
         assert torch.equal(q1.normals[0], r1.normals[0, lo:hi]) and torch.equal(q1.mask[0], r1.mask[0, lo:hi])
-        # the global packed layout every rank rebuilt = the single-GPU one
-        assert torch.equal(qfr["first_idx"], fr["first_idx"]) and torch.equal(qfr["num_points"], fr["num_points"])
+        # the global packed layout every rank derives from the all-gathered counts = the single-GPU one
+        assert torch.equal(qfr["first_global"], fr["first_idx"]) and torch.equal(qfr["num_global"], fr["num_points"])
         seen = ((fr["mask"][None, lo:hi] >> torch.arange(N, device=dev)[:, None]) & 1).bool()      # h exists where the point is rendered
         assert torch.equal(qfr["mask"], fr["mask"][lo:hi]) and torch.equal(qfr["h"][seen], fr["h"][:, lo:hi][seen]), \
             "rank %d: bandwidths differ" % r
-        for k in ("ndc", "ellipse_params", "radii", "scaler", "features"):
-            assert torch.equal(qfr[k][:tot], fr[k][:tot]), "rank %d: packed %s differs" % (r, k)
+        # the rank's own packed rows = its slice of every view of the single-GPU arrays
+        for v in range(N):
+            a, n, lf = int(qfr["own_first"][v]), int(qfr["own_num"][v]), int(qfr["local_first"][v])
+            for k in ("ndc", "ellipse_params", "radii", "scaler", "features"):
+                assert torch.equal(qfr["own"][k][lf:lf + n], fr[k][a:a + n]), "rank %d view %d: packed %s differs" % (r, v, k)
+        # the rows the band received: ascending global ids inside every view, each one the single-GPU row of that id
+        nl = [int(x) for x in qfr["num_points"].tolist()]
+        fl = [int(x) for x in qfr["first_idx"].tolist()]
+        for v in range(N):
+            g = c.gid[fl[v]:fl[v] + nl[v]].long()
+            assert (g[1:] > g[:-1]).all() and (nl[v] == 0 or (g[0] >= int(fr["first_idx"][v]) and
+                                                               g[-1] < int(fr["first_idx"][v] + fr["num_points"][v])))
+            for k in ("ndc", "ellipse_params", "radii", "scaler", "features"):
+                assert torch.equal(qfr[k][fl[v]:fl[v] + nl[v]], fr[k][g]), "rank %d view %d: received %s differs" % (r, v, k)
         y0, y1 = c.band_rows()
         if y1 > y0:
             assert torch.equal(qfrags.idx[:, y0:y1], frags.idx[:, y0:y1]), "rank %d: index lists differ" % r
@@ -75,8 +87,8 @@ def test_lockstep_ranks_equal_single_gpu(dev, world, P, S, N, kind):
             assert torch.equal(qfrags.occupancy[:, y0:y1], frags.occupancy[:, y0:y1])
             assert torch.equal(qimg[:, y0:y1], img[:, y0:y1]), "rank %d: image band differs" % r
         for v in range(N):
-            a, n = int(qfr["own_first"][v]), int(qfr["own_num"][v])
-            assert torch.equal(qgrad[a:a + n], grad[a:a + n]), "rank %d view %d: row gradients differ" % (r, v)
+            a, n, lf = int(qfr["own_first"][v]), int(qfr["own_num"][v]), int(qfr["local_first"][v])
+            assert torch.equal(qgrad[lf:lf + n], grad[a:a + n]), "rank %d view %d: row gradients differ" % (r, v)
     # the own rows of all ranks tile the packed layout
     cover = torch.zeros(tot, dtype=torch.int32)
     for (_, _, _, _, qfr) in res:
@@ -98,7 +110,9 @@ def test_graph_replay_equals_eager(dev, world):
     ranks = [IsoCycle(model, pts, views, projs, raster_settings=rs, knn_k=8, target=target, world=world, rank=r)
              for r in range(world)]
     eager = run_lockstep(ranks)                                                                # also the warm-up
-    eager = [(a[0], a[1].clone(), a[2].clone(), a[3]) for a in eager]
+    from iso_points_amd.rasterizer import PointFragments
+    eager = [(a[0], a[1].clone(), a[2].clone(),                      # (N ranks: the arrays are the cycle's persistent buffers)
+              PointFragments(a[3].idx.clone(), a[3].zbuf.clone(), a[3].qvalue, None, a[3].occupancy)) for a in eager]
     for c in ranks:
         c.use_graphs = True
         c.marks = True
@@ -109,7 +123,7 @@ def test_graph_replay_equals_eager(dev, world):
             assert torch.equal(a[0].points, b[0].points) and torch.equal(a[1], b[1])
             # the row gradients over the rows that exist (the packed arrays have capacity size; rows beyond the
             # device-side totals are unspecified)
-            for f0, n0 in zip(b[4]["own_first"].tolist(), b[4]["own_num"].tolist()):
+            for f0, n0 in zip(b[4].get("local_first", b[4]["own_first"]).tolist(), b[4]["own_num"].tolist()):
                 assert torch.equal(a[2][f0:f0 + n0], b[2][f0:f0 + n0])
             assert torch.equal(a[3].idx, b[3].idx) and torch.equal(a[3].zbuf, b[3].zbuf)
     for c, o in zip(ranks, got):
@@ -132,18 +146,30 @@ def test_calibrated_capacities(dev):
         c.halo_cap = max(1024, int(1.5 * max(u["halo_exported"] for u in use)))
         c.import_cap = max(1024, int(1.5 * max(u["halo_imported"] for u in use)))
         c.rec_cap = max(1024, int(1.25 * max(u["own_rows"] for u in use)))
+        c.seg_cap = max(1024, int(1.25 * max(u["segment_records"] for u in use)))
         c._alloc()
     again = run_lockstep(ranks)
     for c, a, b in zip(ranks, base, again):
-        c.check(b[4])
-        m = min(a[2].shape[0], b[2].shape[0])            # the packed arrays are sized by the record capacity
-        assert torch.equal(a[0].points, b[0].points) and torch.equal(a[2][:m], b[2][:m]) and torch.equal(a[3].idx, b[3].idx)
+        u = c.check(b[4])
+        assert u["segment_records"] <= c.seg_cap and u["band_rows"] <= c.cap_local
+        assert torch.equal(a[0].points, b[0].points) and torch.equal(a[3].idx, b[3].idx)
+        for f0, n0 in zip(b[4]["local_first"].tolist(), b[4]["own_num"].tolist()):      # the rows that exist
+            assert torch.equal(a[2][f0:f0 + n0], b[2][f0:f0 + n0])
     # a capacity that is too small is reported, not silently dropped
     for c in ranks:
         c.halo_cap = 16
         c._alloc()
     out = run_lockstep(ranks)
     with pytest.raises(RuntimeError):
+        for c, o in zip(ranks, out):
+            c.check(o[4])
+    # ... and so is a band segment that is too small
+    for c in ranks:
+        c.halo_cap = max(1024, int(1.5 * max(u["halo_exported"] for u in use)))
+        c.seg_cap = 64
+        c._alloc()
+    out = run_lockstep(ranks)
+    with pytest.raises(RuntimeError, match="band_overflow"):
         for c, o in zip(ranks, out):
             c.check(o[4])
 
@@ -170,8 +196,8 @@ y0, y1 = c.band_rows()
 ok = torch.equal(r1.points[0], s1.points[0, c.lo:c.hi]) and torch.equal(frags.idx[:, y0:y1], sfrags.idx[:, y0:y1]) \
     and torch.equal(img[:, y0:y1], simg[:, y0:y1])
 for v in range(2):
-    a, n = int(fr["own_first"][v]), int(fr["own_num"][v])
-    ok = ok and torch.equal(grad[a:a + n], sgrad[a:a + n])
+    a, n, lf = int(fr["own_first"][v]), int(fr["own_num"][v]), int(fr["local_first"][v])
+    ok = ok and torch.equal(grad[lf:lf + n], sgrad[a:a + n])
 print("RANK", rank, "OK" if ok else "MISMATCH", c.comm.bytes_log)
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)

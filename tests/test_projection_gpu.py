@@ -76,9 +76,11 @@ def _siren(hidden, n_layers, seed=0, fit=0):
     return fitted_siren(_oracle(), hidden, n_layers, seed=seed, fit=fit)
 
 
-@pytest.mark.parametrize("hidden,n_layers", [(256, 3), (64, 1), (128, 2), (256, 0), (256, 1), (128, 4)])
+@pytest.mark.parametrize("hidden,n_layers", [(256, 3), (64, 1), (128, 2), (256, 0), (256, 1), (128, 4), (96, 2), (200, 3),
+                                              (32, 1)])
 def test_siren_sdf_and_grad(dev, hidden, n_layers, gemm_mode):
-    """Fused MFMA SDF+grad vs torch autograd (levelset_sampling.py:142-170)."""
+    """Fused MFMA SDF+grad vs torch autograd (levelset_sampling.py:142-170); widths other than 64 / 128 / 256 run
+    zero-padded to the next fused width (PackedSiren) -- same function, same gradient."""
     O = _oracle()
     from iso_points_amd.sdf_models import siren_sdf_and_grad
     m = _siren(hidden, n_layers, seed=1)
@@ -246,7 +248,10 @@ def test_generic_model_route(dev):
     pts = cube_cloud(2000, seed=7)
     ref = O.project_points(Torus(), pts, torch.tensor([2000]), proj_max_iters=10)
     g = pts.to(dev)
-    res = UniformProjection()._project_points(Torus(), g, full_lengths(g), proj_max_iters=10)
+    from iso_points_amd import levelset_sampling as LS
+    LS._GENERIC_WARNED.clear()
+    with pytest.warns(RuntimeWarning, match="no fused SDF kernel"):       # the slow route announces itself
+        res = UniformProjection()._project_points(Torus(), g, full_lengths(g), proj_max_iters=10)
     _check_projection(res, ref, Torus())
 
 
