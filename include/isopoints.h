@@ -617,6 +617,21 @@ int iso_splat_front(const float* points, const float* normals, const float* feat
                     int64_t* num_pts_out, int32_t* view_total_out, float* ndc_out, float* ellipse_out,
                     float* cutoff_out, float* radii_out, float* scaler_out, float* features_out,
                     int32_t* src_out, void* stream);
+/* The same front end with two launches fewer and the view totals known BEFORE the bandwidth pass needs them:
+ * iso_splat_view_mask_scan = renderable mask (iso_splat_view_mask's rule) + per-chunk counts + their scan: mask_out,
+ * first_idx_out / num_pts_out (n_views int64) and view_total_out (8 int32) are final, the workspace
+ * (iso_splat_front_workspace_bytes) holds the scanned chunk table; iso_splat_front_rows = the compaction + set-up pass
+ * of iso_splat_front alone, on that workspace / mask / first_idx.                                     */
+int iso_splat_view_mask_scan(const float* points, const float* normals, const float* views, int n_views,
+                             int64_t n_points, float znear, float zfar, int backface_culling, int32_t* mask_out,
+                             void* workspace, int64_t workspace_bytes, int64_t* first_idx_out, int64_t* num_pts_out,
+                             int32_t* view_total_out, void* stream);
+int iso_splat_front_rows(const float* points, const float* normals, const float* features, int channels,
+                         int features_from_normals, const int32_t* mask, const float* h, int64_t n_points,
+                         const float* views, const float* projs, int n_views, int image_size, float sigma,
+                         float cutoff, const void* workspace, int64_t workspace_bytes, const int64_t* first_idx,
+                         float* ndc_out, float* ellipse_out, float* cutoff_out, float* radii_out,
+                         float* scaler_out, float* features_out, int32_t* src_out, void* stream);
 /* Gradient of the packed NDC rows of iso_splat_front w.r.t. the WORLD points (the part of the reference's
  * backward that autograd runs through cameras.transform_points in SurfaceSplatting.transform,
  * rasterizer.py:565-582,618: per-point set-up is under no_grad :608-610, so d(ndc)/d(point) is all there is).

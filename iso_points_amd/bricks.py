@@ -115,6 +115,23 @@ def view_mask(points, normals, views, znear=1.0, zfar=100.0, backface_culling=Tr
     return mask, cnt
 
 
+def view_mask_scan(points, normals, views, znear=1.0, zfar=100.0, backface_culling=True):
+    """view_mask + the per-chunk counts and their scan the front end needs, in two launches (iso_splat_view_mask_scan):
+    -> mask (n,) int32, view_total (8,) int32, and the `scanned` tuple (workspace, first_idx (N,) i64, num_points (N,)
+    i64, view_total) SurfaceSplatting.front_setup takes to run its compaction + set-up pass alone."""
+    n, nv = points.shape[0], views.shape[0]
+    dev = points.device
+    mask = torch.empty((n,), dtype=torch.int32, device=dev)
+    ws = torch.empty((_lib.load().iso_splat_front_workspace_bytes(n),), dtype=torch.uint8, device=dev)
+    first = torch.empty((nv,), dtype=torch.int64, device=dev)
+    num = torch.empty((nv,), dtype=torch.int64, device=dev)
+    total = torch.empty((8,), dtype=torch.int32, device=dev)
+    p = _lib.ptr
+    _lib.call("iso_splat_view_mask_scan", p(points), p(normals), p(views), nv, n, float(znear), float(zfar),
+              int(bool(backface_culling)), p(mask), p(ws), ws.numel(), p(first), p(num), p(total), _lib.stream())
+    return mask, total, (ws, first, num, total)
+
+
 def splat_h_fused(grid, mask, view_total, n_views):
     """h (n_views, n_own) f32: written where the mask bit is set, untouched elsewhere."""
     pts = grid.points

@@ -224,6 +224,50 @@ __global__ __launch_bounds__(256) void k_mask_chunk_count(const int32_t* __restr
   if (threadIdx.x < n_views) chunk_cnt[threadIdx.x * n_chunks + blockIdx.x] = s_cnt[threadIdx.x];
 }
 
+// The renderable mask of rasterizer.py:184-254 (k_view_mask in bricks.hip: same expressions) AND the chunk counts
+// in one pass: a workgroup owns the kChunk consecutive points the front end's workgroup of the same index will own.
+__global__ __launch_bounds__(256) void k_view_mask_chunks(const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                          const float* __restrict__ views, int n_views, int64_t P,
+                                                          float znear, float zfar, int backface, int n_chunks,
+                                                          int32_t* __restrict__ mask, int32_t* __restrict__ chunk_cnt) {
+  __shared__ int s_cnt[8];
+  if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * kChunk + threadIdx.x * 4;
+  int local[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = i0 + k;
+    if (i >= P) break;
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (backface) { nx = nrm[i * 3]; ny = nrm[i * 3 + 1]; nz = nrm[i * 3 + 2]; }
+    int m = 0;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      if (v < n_views) {
+        const float* V = views + v * 16;                    // row-vector convention: p_view = [p,1] @ V
+        const float zv = ((x * V[2] + y * V[6]) + z * V[10]) + V[14];
+        bool ok = (zv >= znear) && (zv <= zfar);
+        if (backface) ok = ok && (((nx * V[2] + ny * V[6]) + nz * V[10]) < 0.f);
+        if (ok) { m |= 1 << v; ++local[v]; }
+      }
+    }
+    mask[i] = m;
+  }
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    if (v < n_views) {
+      int c = local[v];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+      if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[v], c);
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n_views) chunk_cnt[threadIdx.x * n_chunks + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
 // one workgroup: exclusive scan of every view's chunk counts in place; first_idx / num_points (i64,
 // the layout _C.splat_points takes) and the int32 view totals
 __global__ __launch_bounds__(1024) void k_mask_chunk_scan(int32_t* __restrict__ chunk_cnt, int n_chunks, int n_views,
@@ -1680,6 +1724,59 @@ extern "C" int iso_splat_front(const float* points, const float* normals, const 
                        features_from_normals, o);
   }
   ISO_CHECK_LAUNCH("iso_splat_front");
+  return ISO_OK;
+}
+
+// The renderable mask, its per-chunk counts and their scan in two launches: what iso_splat_view_mask +
+// the first two launches of iso_splat_front do in five.  The workspace (iso_splat_front_workspace_bytes) then holds
+// the scanned chunk table iso_splat_front_rows expects; first_idx / num_points / view_total are final.
+extern "C" int iso_splat_view_mask_scan(const float* points, const float* normals, const float* views, int n_views,
+                                        int64_t n_points, float znear, float zfar, int backface_culling,
+                                        int32_t* mask_out, void* workspace, int64_t workspace_bytes,
+                                        int64_t* first_idx_out, int64_t* num_pts_out, int32_t* view_total_out,
+                                        void* stream) {
+  ISO_REQUIRE(n_points >= 0 && n_views >= 1 && n_views <= 8, ISO_ERR_UNSUPPORTED, "iso_splat_view_mask_scan: 1..8 views per call");
+  ISO_REQUIRE(views && workspace && first_idx_out && num_pts_out && view_total_out &&
+                  (n_points == 0 || (points && mask_out && (normals || !backface_culling))),
+              ISO_ERR_INVALID, "iso_splat_view_mask_scan: null pointer");
+  ISO_REQUIRE(workspace_bytes >= iso_splat_front_workspace_bytes(n_points), ISO_ERR_WORKSPACE,
+              "iso_splat_view_mask_scan: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_chunks = (int)((n_points + kChunk - 1) / kChunk);
+  int32_t* chunk = (int32_t*)workspace;
+  if (n_points > 0)
+    hipLaunchKernelGGL(k_view_mask_chunks, dim3(n_chunks), dim3(256), 0, s, points, normals, views, n_views, n_points, znear,
+                       zfar, backface_culling, n_chunks, mask_out, chunk);
+  hipLaunchKernelGGL(k_mask_chunk_scan, dim3(1), dim3(1024), 0, s, chunk, n_chunks, n_views, first_idx_out, num_pts_out,
+                     view_total_out);
+  ISO_CHECK_LAUNCH("iso_splat_view_mask_scan");
+  return ISO_OK;
+}
+
+// iso_splat_front after iso_splat_view_mask_scan: the compaction + set-up pass alone (one launch); workspace,
+// first_idx and mask are the ones that call produced.
+extern "C" int iso_splat_front_rows(const float* points, const float* normals, const float* features, int channels,
+                                    int features_from_normals, const int32_t* mask, const float* h, int64_t n_points,
+                                    const float* views, const float* projs, int n_views, int image_size, float sigma,
+                                    float cutoff, const void* workspace, int64_t workspace_bytes, const int64_t* first_idx,
+                                    float* ndc_out, float* ellipse_out, float* cutoff_out, float* radii_out,
+                                    float* scaler_out, float* features_out, int32_t* src_out, void* stream) {
+  ISO_REQUIRE(n_points >= 0 && n_views >= 1 && n_views <= 8 && image_size > 0, ISO_ERR_INVALID,
+              "iso_splat_front_rows: bad sizes (1..8 views per call)");
+  ISO_REQUIRE(channels >= 0 && channels <= 8, ISO_ERR_UNSUPPORTED, "iso_splat_front_rows: channels must be <= 8");
+  ISO_REQUIRE(!features_from_normals || channels == 3, ISO_ERR_INVALID, "iso_splat_front_rows: features_from_normals needs 3 channels");
+  ISO_REQUIRE(first_idx && workspace && workspace_bytes >= iso_splat_front_workspace_bytes(n_points), ISO_ERR_INVALID,
+              "iso_splat_front_rows: workspace / first_idx missing");
+  if (n_points == 0) return ISO_OK;
+  ISO_REQUIRE(points && normals && mask && h && views && projs && ndc_out && ellipse_out && cutoff_out && radii_out &&
+                  scaler_out && (!features_out || features || features_from_normals),
+              ISO_ERR_INVALID, "iso_splat_front_rows: null pointer");
+  const int n_chunks = (int)((n_points + kChunk - 1) / kChunk);
+  FrontOut o{ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out, features_out, src_out};
+  hipLaunchKernelGGL(k_splat_front, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, points, normals, features, channels,
+                     mask, h, n_points, (const int32_t*)workspace, n_chunks, first_idx, views, projs, n_views, image_size,
+                     sigma, cutoff, features_from_normals, o);
+  ISO_CHECK_LAUNCH("iso_splat_front_rows");
   return ISO_OK;
 }
 

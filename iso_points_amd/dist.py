@@ -299,7 +299,7 @@ class IsoCycle(object):
     # -- stage 3: splat front end + forward ------------------------------------------------------
     def _front(self, pts, nrm):
         ss, N, w = self.splat, self.N, self.world
-        mask, cnt = bricks.view_mask(pts, nrm, self.views, ss.znear, ss.zfar, self.rs.backface_culling)
+        mask, cnt, scanned = bricks.view_mask_scan(pts, nrm, self.views, ss.znear, ss.zfar, self.rs.backface_culling)
         counts = None
         if w == 1:
             self.grid.build(pts, nrm, payload=mask, radius=float(ss.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
@@ -315,7 +315,7 @@ class IsoCycle(object):
                                         self.halo_cells_h)
         h = bricks.splat_h_fused(self.grid, mask, view_total, N)
         fr = ss.front_setup(pts, nrm, self.views, self.projs, mask, h, features_from_normals=True, out=self.wire,
-                            capacity=self.rec_cap)
+                            capacity=self.rec_cap, scanned=scanned)
         if w == 1:
             fr["own_first"], fr["own_num"], fr["max_pts"], fr["rows"] = fr["first_idx"], fr["num_points"], self.P, self.rec_cap
             return fr

@@ -456,15 +456,18 @@ class SurfaceSplatting(object):
         if N > 8:
             raise NotImplementedError("front: at most 8 views per pass (SurfaceSplatting.forward runs it in chunks)")
         dev = points.device
-        mask, cnt = bricks.view_mask(points, normals, views, self.znear, self.zfar, rs.backface_culling)
+        mask, cnt, scanned = bricks.view_mask_scan(points, normals, views, self.znear, self.zfar, rs.backface_culling)
         if grid is None:
             grid = bricks.BrickGrid(P, dev)
         grid.build(points, normals, payload=mask, radius=float(self.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
         h = bricks.splat_h_fused(grid, mask, cnt, N)
-        return self.front_setup(points, normals, views, projs, mask, h, features, features_from_normals, out, capacity)
+        return self.front_setup(points, normals, views, projs, mask, h, features, features_from_normals, out, capacity,
+                                scanned=scanned)
 
     def front_setup(self, points, normals, views, projs, mask, h, features=None, features_from_normals=False,
-                    out=None, capacity=None):
+                    out=None, capacity=None, scanned=None):
+        """Compaction + per-point set-up into packed rows.  scanned: the tuple bricks.view_mask_scan returned for this
+        mask (the chunk counts are then already scanned: one launch instead of three)."""
         rs = self.raster_settings
         P, N = points.shape[0], views.shape[0]
         dev = points.device
@@ -484,13 +487,24 @@ class SurfaceSplatting(object):
             feat = torch.empty((cap, C), dtype=torch.float32, device=dev) if C else None
         cutoff = torch.empty((cap,), dtype=torch.float32, device=dev)
         src = torch.empty((cap,), dtype=torch.int32, device=dev)
+        p = _lib.ptr
+        feat_in = p(_f32c(features)) if (features is not None and not features_from_normals) else None
+        if scanned is not None:
+            ws, first, num, view_total = scanned
+            _lib.call("iso_splat_front_rows", p(points), p(normals), feat_in, C, int(bool(features_from_normals)), p(mask),
+                      p(h), P, p(_f32c(views)), p(_f32c(projs)), N, min(image_hw(rs.image_size)),
+                      float(rs.antialiasing_sigma), float(rs.cutoff_threshold), p(ws), ws.numel(), p(first), p(ndc),
+                      p(ellipse), p(cutoff), p(radii), p(scaler), p(feat) if feat is not None else None, p(src),
+                      _lib.stream())
+            return {"ndc": ndc, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "radii": radii, "scaler": scaler,
+                    "features": feat, "src": src, "first_idx": first, "num_points": num, "view_total": view_total,
+                    "mask": mask, "h": h, "wire": out, "capacity": cap}
         first = torch.empty((N,), dtype=torch.int64, device=dev)
         num = torch.empty((N,), dtype=torch.int64, device=dev)
         view_total = torch.empty((8,), dtype=torch.int32, device=dev)
         lib = _lib.load()
         ws_b = lib.iso_splat_front_workspace_bytes(P)
         ws = torch.empty((ws_b,), dtype=torch.uint8, device=dev)
-        p = _lib.ptr
         _lib.call("iso_splat_front", p(points), p(normals), p(_f32c(features)) if (features is not None and not features_from_normals) else None,
                   C, int(bool(features_from_normals)), p(mask), p(h), P, p(_f32c(views)), p(_f32c(projs)), N,
                   min(image_hw(rs.image_size)), float(rs.antialiasing_sigma), float(rs.cutoff_threshold), p(ws), ws_b, p(first),

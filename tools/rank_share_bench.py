@@ -81,6 +81,7 @@ def main():
                 c.halo_cap = max(1024, int(1.5 * max(u["halo_exported"] for u in use)))
                 c.import_cap = max(1024, int(1.5 * max(u["halo_imported"] for u in use)))
                 c.rec_cap = max(1024, int(1.25 * max(u["own_rows"] for u in use)))
+                c.seg_cap = max(1024, int(1.25 * max(u["segment_records"] for u in use)))
                 c._alloc()
         del res
         run_lockstep(ranks)
@@ -102,10 +103,12 @@ def main():
             gens = [c.cycle() for c in ranks]
             reqs = [next(g) for g in gens]
             while True:
-                log.append((reqs[0][0] + ("" if reqs[0][0] == "all_gather" else ":" + reqs[0][2]),
+                log.append((reqs[0][0] + ("" if reqs[0][0] in ("all_gather", "all_to_all") else ":" + reqs[0][2]),
                             reqs[0][1].numel() * reqs[0][1].element_size()))
                 if reqs[0][0] == "all_gather":
                     send = [torch.stack([q[1] for q in reqs])] * world
+                elif reqs[0][0] == "all_to_all":
+                    send = [torch.stack([reqs[s_][1][r_] for s_ in range(world)]) for r_ in range(world)]
                 else:
                     st = torch.stack([q[1] for q in reqs])
                     red = st.sum(0) if reqs[0][2] == "sum" else st.max(0).values
@@ -122,7 +125,9 @@ def main():
             "collectives_bytes_per_rank": log, "bytes_per_rank_total": sum(b for _, b in log),
             "halo_exported_max": max((u.get("halo_exported", 0) for u in use), default=0),
             "halo_imported_max": max((u.get("halo_imported", 0) for u in use), default=0),
-            "own_rows_max": max(u["own_rows"] for u in use), "halo_cells": [ranks[0].halo_cells, ranks[0].halo_cells_h],
+            "own_rows_max": max(u["own_rows"] for u in use),
+            "segment_records_max": max((u.get("segment_records", 0) for u in use), default=0),
+            "band_rows_max": max((u.get("band_rows", 0) for u in use), default=0), "halo_cells": [ranks[0].halo_cells, ranks[0].halo_cells_h],
             "grid_per_rank": [{k: u["grid"][k] for k in ("occupied", "tail", "overflow_bricks", "tail_h", "n")} for u in use]}
         print(world, out["worlds"][str(world)]["slowest_rank_ms"], out["worlds"][str(world)]["compute_ceiling_x"], file=sys.stderr)
         del ranks, res
