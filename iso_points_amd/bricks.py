@@ -11,8 +11,12 @@ import torch
 
 from . import _lib
 
-RESAMPLE_CELL = 0.8        # fine cell = 0.8 r  (r = knn_k * sqrt(diag / P)): measured optimum at 1 M points
-H_CELL_SCALE = 5.0         # fine cell = 5 sqrt(diag / P) for the K = 7 bandwidth query
+import os as _os
+
+# (ISO_RESAMPLE_CELL / ISO_H_CELL_SCALE: development overrides for parameter sweeps, tools/ab_cycle.sh)
+RESAMPLE_CELL = float(_os.environ.get("ISO_RESAMPLE_CELL", "0.8"))   # fine cell = 0.8 r  (r = knn_k * sqrt(diag / P)): measured optimum at 1 M points
+H_CELL_SCALE = float(_os.environ.get("ISO_H_CELL_SCALE", "6.0"))      # fine cell = 6 sqrt(diag / P) for the K = 7 bandwidth query: the cell then covers the 0.01 radius
+                                                                     # inside which seven neighbours settle h (no uncertified counts: h + tail 272 -> 247 us at 1 M points)
 
 
 def points_bbox(points):

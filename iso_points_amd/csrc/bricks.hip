@@ -637,7 +637,11 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
     BrickGeo g;
     const int C = stage_brick<true>(S, h, off, rec0, rec1, b, g);
     if (C < 0) { brick_to_tail(h, off, rec0, b, tail, counters, 1, 1); continue; }
+#ifdef BK_DBG_NOQUERY          // timing experiment (tools/build_variant.sh): staging only
+    const int nq = 0;
+#else
     const int nq = S.qpre[16];
+#endif
     for (int t = threadIdx.x; t < nq; t += BK_THREADS) {
       const int pos = query_slot(S, t);
       const float4 q = S.rec0[pos];
@@ -1004,7 +1008,11 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? 5 : 4) void k_brick_h(
     constexpr int VS = NV <= 4 ? 8 : 1;                 // staged view masks: one byte per view when they fit a word
     const int C = stage_brick<false, VS>(S, h, off, rec0, rec1, b, g);
     if (C < 0) { brick_to_tail(h, off, rec0, b, tail, counters, 3, 8); continue; }
+#ifdef BK_DBG_NOQUERY
+    const int nq = 0;
+#else
     const int nq = S.qpre[16];
+#endif
     for (int t0 = 0; t0 < nq; t0 += BK_THREADS) {
       const int t = t0 + threadIdx.x;
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
