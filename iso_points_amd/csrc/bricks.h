@@ -71,6 +71,14 @@ __device__ __forceinline__ int bk_fine(float p, float mn, float inv_f, int nf) {
   return c < 0 ? 0 : (c >= nf ? nf - 1 : c);
 }
 
+// index of the sub-cell (SUB per fine cell and axis) of p: floor(SUB * t) with t as in bk_fine, so that
+// bk_sub<SUB>(p) / SUB == bk_fine(p) (doubling t is exact in f32; same clamps)
+template <int SUB>
+__device__ __forceinline__ int bk_sub(float p, float mn, float inv_f, int nf) {
+  const int c = (int)floorf(((p - mn) * inv_f) * (float)SUB);
+  return c < 0 ? 0 : (c >= nf * SUB ? nf * SUB - 1 : c);
+}
+
 __device__ __forceinline__ unsigned bk_med3u(unsigned a, unsigned b, unsigned c) {
   unsigned r;
   asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));

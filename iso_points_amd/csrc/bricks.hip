@@ -19,6 +19,7 @@
 // one v_med3_u32 per slot and candidate.  Truncated keys order like d2 up to 2^-13 relative, so the
 // exact (d2, id) order is restored afterwards on the M survivors; the list is certified complete
 // when the first key beyond the K-th differs from it in the kept bits (else: tail kernel).
+#include <type_traits>
 #include "bricks.h"
 
 #pragma clang fp contract(off)
@@ -209,6 +210,13 @@ __global__ void k_bricks_init(int32_t* __restrict__ counters, int32_t* __restric
   if (i0 < 64) counters[i0] = i0 == kMagicAt ? kBrickMagic : 0;
 }
 
+// F.normalize(n, dim=-1): n / max(|n|, 1e-12) (levelset_sampling.py:258), stored in rec1 in place of the raw normal
+__device__ __forceinline__ void bk_unit_normal(float& ux, float& uy, float& uz) {
+  float un = sqrtf((ux * ux + uy * uy) + uz * uz);
+  un = un > 1e-12f ? un : 1e-12f;
+  ux = ux / un; uy = uy / un; uz = uz / un;
+}
+
 __device__ __forceinline__ int brick_of(const BrickHdr& h, float x, float y, float z) {
   const int fx = bk_fine(x, h.mn[0], h.inv_f, h.nf[0]);
   const int fy = bk_fine(y, h.mn[1], h.inv_f, h.nf[1]);
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256) void k_brick_scatter(const float* __restrict__
     const int64_t dst = (int64_t)off[BK_CPB * brick_of(h, x, y, z) + ((unsigned)sl >> 28)] + (sl & 0x0fffffff);
     rec0[dst] = make_float4(x, y, z, __int_as_float(h.id_base + (int)i));
     float4 u = make_float4(0.f, 0.f, 0.f, __int_as_float(payload ? payload[i] : 0));
-    if (nrm) { u.x = nrm[i * 3]; u.y = nrm[i * 3 + 1]; u.z = nrm[i * 3 + 2]; }
+    if (nrm) { u.x = nrm[i * 3]; u.y = nrm[i * 3 + 1]; u.z = nrm[i * 3 + 2]; bk_unit_normal(u.x, u.y, u.z); }
     rec1[dst] = u;
   }
 }
@@ -318,7 +326,9 @@ __global__ __launch_bounds__(256) void k_brick_scatter_recs(const float4* __rest
     const int sl = slot[h.n_own + j];
     const int64_t dst = (int64_t)off[BK_CPB * brick_of(h, p.x, p.y, p.z) + ((unsigned)sl >> 28)] + (sl & 0x0fffffff);
     rec0[dst] = p;
-    rec1[dst] = imp1[j];
+    float4 u = imp1[j];                                  // an exported record carries the raw normal
+    bk_unit_normal(u.x, u.y, u.z);
+    rec1[dst] = u;
   }
 }
 
@@ -399,18 +409,25 @@ __global__ __launch_bounds__(256) void k_brick_offsets(const BrickHdr* __restric
 // ---- staging of one brick + halo into LDS -------------------------------------------------------
 // WITH_NRM: rec1 (normals) staged next to rec0 (resample); otherwise one record per candidate whose
 // w is rec1's payload (the view mask) with bit 31 = "imported, not a query" (bandwidth kernel).
-template <bool WITH_NRM>
+// SUB: the LDS sort runs on SUB x SUB x SUB sub-cells per fine cell (the global grid and everything outside the
+// workgroup know fine cells only).  SUB = 2 (resample): a query walks a 4 x 4 x 4 window of HALF cells picked by the
+// half of its own half cell it lies in -- every point within 0.75 fine cells of the query is inside (1.5 half cells to
+// each face), 1.6 r wide at the 0.8 r cell against the 2.4 r of a 3 x 3 x 3 walk of whole cells: 44 % of the candidates.
+template <bool WITH_NRM, int SUB = 1>
 struct BrickStage {
+  static constexpr int NL = 6 * SUB;                // local (sub-)cells per axis: the brick + one fine cell of halo
+  static constexpr int NCELL = NL * NL * NL;
+  static constexpr int NQRUN = 16 * SUB * SUB;      // z-runs of the brick's own (sub-)cells
   float4 rec0[BK_CAP];
   int src[WITH_NRM ? BK_CAP : 1];     // WITH_NRM: position of the staged record in the brick-sorted arrays (its rec1 is read
                                       // from there by the few that need it: staging it cost 16 KB of LDS = three workgroups per CU)
   int gid[WITH_NRM ? 1 : BK_CAP];
-  int cstart[220];   // [217] used: local fine cell -> first staged slot
-  int ccur[216];
+  int cstart[NCELL + 4];   // [NCELL + 1] used: local (sub-)cell -> first staged slot
+  int ccur[NCELL];
   int run_i0[9];
   int run_pre[10];
-  int qbeg[16];
-  int qpre[17];
+  int qbeg[NQRUN];
+  int qpre[NQRUN + 1];
 };
 
 struct BrickGeo { int bx, by, bz, ox, oy, oz; };
@@ -423,15 +440,17 @@ constexpr int BK_RAW = 8;
 
 // VS (bandwidth kernel only): bit stride of the view mask in the staged record -- 1: as stored; 8: view v at bit
 // 8 v (up to four views), so that masked records add up to four 8-bit per-view counters in one register.
-template <bool WITH_NRM, int VS = 1>
-__device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int32_t* __restrict__ off,
+template <bool WITH_NRM, int VS = 1, int SUB = 1>
+__device__ int stage_brick(BrickStage<WITH_NRM, SUB>& S, const BrickHdr& h, const int32_t* __restrict__ off,
                            const float4* __restrict__ rec0, const float4* __restrict__ rec1, int b, BrickGeo& g) {
+  typedef BrickStage<WITH_NRM, SUB> St;
+  constexpr int NL = St::NL, NCELL = St::NCELL;
   const int tid = threadIdx.x;
   const int nbx = h.nb[0], nby = h.nb[1], nbz = h.nb[2];
   g.bz = b % nbz; g.by = (b / nbz) % nby; g.bx = b / (nbz * nby);
   g.ox = 4 * g.bx - 1; g.oy = 4 * g.by - 1; g.oz = 4 * g.bz - 1;
   __syncthreads();                                   // the previous brick's readers are done
-  if (tid < 216) S.ccur[tid] = 0;
+  for (int c = tid; c < NCELL; c += BK_THREADS) S.ccur[c] = 0;
   if (tid < 9) {
     const int x = g.bx + tid / 3 - 1, y = g.by + tid % 3 - 1;
     int i0 = 0, len = 0;
@@ -457,10 +476,10 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
     return S.run_i0[run] + (j - S.run_pre[run]);
   };
   auto cell_of = [&](const float4& p) {
-    const int lx = bk_fine(p.x, h.mn[0], h.inv_f, h.nf[0]) - g.ox;
-    const int ly = bk_fine(p.y, h.mn[1], h.inv_f, h.nf[1]) - g.oy;
-    const int lz = bk_fine(p.z, h.mn[2], h.inv_f, h.nf[2]) - g.oz;
-    return ((unsigned)lx < 6u && (unsigned)ly < 6u && (unsigned)lz < 6u) ? (lx * 6 + ly) * 6 + lz : -1;
+    const int lx = bk_sub<SUB>(p.x, h.mn[0], h.inv_f, h.nf[0]) - SUB * g.ox;
+    const int ly = bk_sub<SUB>(p.y, h.mn[1], h.inv_f, h.nf[1]) - SUB * g.oy;
+    const int lz = bk_sub<SUB>(p.z, h.mn[2], h.inv_f, h.nf[2]) - SUB * g.oz;
+    return ((unsigned)lx < (unsigned)NL && (unsigned)ly < (unsigned)NL && (unsigned)lz < (unsigned)NL) ? (lx * NL + ly) * NL + lz : -1;
   };
   auto store = [&](int pos, const float4& p, int at, float uw) {
     if (WITH_NRM) {
@@ -477,18 +496,16 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
     }
   };
   auto scan_cells = [&]() {
-    if (tid < 64) {                                  // exclusive scan of the 216 counters by one wave
-      int v[4], s = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { const int c = tid * 4 + k; v[k] = c < 216 ? S.ccur[c] : 0; s += v[k]; }
-      int ex = wave_incl_scan_i(s) - s;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = tid * 4 + k;
-        if (c < 216) { S.cstart[c] = ex; S.ccur[c] = ex; }
-        ex += v[k];
+    if (tid < 64) {                                  // exclusive scan of the NCELL counters by one wave
+      constexpr int PER = (NCELL + 63) / 64;
+      int sum = 0;
+      for (int k = 0; k < PER; ++k) { const int c = tid * PER + k; sum += c < NCELL ? S.ccur[c] : 0; }
+      int ex = wave_incl_scan_i(sum) - sum;
+      for (int k = 0; k < PER; ++k) {
+        const int c = tid * PER + k;
+        if (c < NCELL) { const int v = S.ccur[c]; S.cstart[c] = ex; S.ccur[c] = ex; ex += v; }
       }
-      if (tid == 53) S.cstart[216] = ex;
+      if (tid == 63) S.cstart[NCELL] = ex;
     }
   };
   if (total_raw <= BK_THREADS * BK_RAW) {
@@ -509,7 +526,7 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
     __syncthreads();
     scan_cells();
     __syncthreads();
-    if (S.cstart[216] > BK_CAP) return -1;
+    if (S.cstart[NCELL] > BK_CAP) return -1;
     const float* __restrict__ rec1w = reinterpret_cast<const float*>(rec1) + 3;     // the payload word of a second record
     float uw[BK_RAW];
 #pragma unroll
@@ -526,7 +543,7 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
     __syncthreads();
     scan_cells();
     __syncthreads();
-    if (S.cstart[216] > BK_CAP) return -1;
+    if (S.cstart[NCELL] > BK_CAP) return -1;
     for (int j = tid; j < total_raw; j += BK_THREADS) {
       const int i = index_of(j);
       const float4 p = rec0[i];
@@ -534,27 +551,31 @@ __device__ int stage_brick(BrickStage<WITH_NRM>& S, const BrickHdr& h, const int
       if (c >= 0) store(atomicAdd(&S.ccur[c], 1), p, i, WITH_NRM ? 0.f : rec1[i].w);
     }
   }
-  if (tid < 16) {                                    // the brick's own 4x4x4 fine cells: 16 contiguous z-runs
+  constexpr int NQ = St::NQRUN, QA = 4 * SUB;        // the brick's own (sub-)cells: QA x QA contiguous z-runs of QA
+  int qlen = 0;
+  if (tid < NQ) {
     // (cstart is final since the scan; ccur is being advanced by the scatter above)
-    const int c = ((1 + tid / 4) * 6 + (1 + tid % 4)) * 6 + 1;
+    const int c = ((SUB + tid / QA) * NL + (SUB + tid % QA)) * NL + SUB;
     S.qbeg[tid] = S.cstart[c];
-    S.qpre[tid + 1] = S.cstart[c + 4] - S.cstart[c];
+    qlen = S.cstart[c + QA] - S.cstart[c];
+  }
+  if (tid < 64) {                                    // exclusive prefix of the run lengths (NQ <= 64: one wave)
+    const int inc = wave_incl_scan_i(qlen);
+    if (tid < NQ) S.qpre[tid + 1] = inc;
+    if (tid == 0) S.qpre[0] = 0;
   }
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    S.qpre[0] = 0;
-    for (int k = 1; k <= 16; ++k) { run += S.qpre[k]; S.qpre[k] = run; }
-  }
-  __syncthreads();
-  return S.cstart[216];
+  return S.cstart[NCELL];
 }
 
-template <bool WITH_NRM>
-__device__ __forceinline__ int query_slot(const BrickStage<WITH_NRM>& S, int t) {
-  int r = 0;
-  while (t >= S.qpre[r + 1]) ++r;
-  return S.qbeg[r] + (t - S.qpre[r]);
+template <bool WITH_NRM, int SUB>
+__device__ __forceinline__ int query_slot(const BrickStage<WITH_NRM, SUB>& S, int t) {
+  int lo = 0, hi = BrickStage<WITH_NRM, SUB>::NQRUN;         // the run r with qpre[r] <= t < qpre[r + 1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (S.qpre[mid] <= t) lo = mid; else hi = mid;
+  }
+  return S.qbeg[lo] + (t - S.qpre[lo]);
 }
 
 // The 3x3x3 fine cells around local cell (lx,ly,lz) = nine contiguous slot ranges of the staged
@@ -562,12 +583,34 @@ __device__ __forceinline__ int query_slot(const BrickStage<WITH_NRM>& S, int t) 
 // used; `two` false: the second is a repeat of the first and must be ignored); the bounds of the next
 // range are requested while the current one is walked.
 template <bool WITH_NRM, class Body>
-__device__ __forceinline__ void walk_candidates(const BrickStage<WITH_NRM>& S, int lx, int ly, int lz, Body&& body) {
+__device__ __forceinline__ void walk_candidates(const BrickStage<WITH_NRM, 1>& S, int lx, int ly, int lz, Body&& body) {
   auto cell0 = [&](int c9) { return ((lx + c9 / 3 - 1) * 6 + (ly + c9 % 3 - 1)) * 6 + (lz - 1); };
   int a = S.cstart[cell0(0)], e = S.cstart[cell0(0) + 3];
   for (int c9 = 0; c9 < 9; ++c9) {
     int na = 0, ne = 0;
     if (c9 < 8) { na = S.cstart[cell0(c9 + 1)]; ne = S.cstart[cell0(c9 + 1) + 3]; }
+    for (int i = a; i < e; i += 2) {
+      const bool two = i + 1 < e;
+      const int i1 = two ? i + 1 : i;
+      const float4 c0 = S.rec0[i];
+      const float4 c1 = S.rec0[i1];
+      body(c0, i, c1, i1, two);
+    }
+    a = na; e = ne;
+  }
+}
+
+// SUB = 2: the NW x NW x NW window of half cells whose first cell is (wx, wy, wz) = NW^2 contiguous slot ranges of NW
+// half cells each (NW = 4: the query's own window; NW = 6: the 3 x 3 x 3 fine cells around its cell); same
+// two-candidates-per-trip protocol.
+template <int NW, bool WITH_NRM, class Body>
+__device__ __forceinline__ void walk_window(const BrickStage<WITH_NRM, 2>& S, int wx, int wy, int wz, Body&& body) {
+  constexpr int NL = BrickStage<WITH_NRM, 2>::NL;
+  auto cell0 = [&](int c) { return ((wx + c / NW) * NL + (wy + c % NW)) * NL + wz; };
+  int a = S.cstart[cell0(0)], e = S.cstart[cell0(0) + NW];
+  for (int c = 0; c < NW * NW; ++c) {
+    int na = 0, ne = 0;
+    if (c < NW * NW - 1) { na = S.cstart[cell0(c + 1)]; ne = S.cstart[cell0(c + 1) + NW]; }
     for (int i = a; i < e; i += 2) {
       const bool two = i + 1 < e;
       const int i1 = two ? i + 1 : i;
@@ -596,10 +639,10 @@ __device__ void brick_to_tail(const BrickHdr& h, const int32_t* __restrict__ off
 struct Repulse {
   float px, py, pz, inv_sigma;
   float sw = 0.f, mx = 0.f, my = 0.f, mz = 0.f;
+  // (ux, uy, uz): the neighbour's UNIT normal -- F.normalize of levelset_sampling.py:258 is applied once per point when
+  // the records are written (bk_unit_normal in the scatter kernels) instead of once per (query, neighbour) pair here:
+  // the same operations on the same operands, so the same bits, and three IEEE divisions + a square root fewer per pair
   __device__ __forceinline__ void add(float qx, float qy, float qz, float ux, float uy, float uz) {
-    float un = sqrtf((ux * ux + uy * uy) + uz * uz);        // F.normalize: v / max(|v|, 1e-12)
-    un = un > 1e-12f ? un : 1e-12f;
-    ux = ux / un; uy = uy / un; uz = uz / un;
     const float dx = px - qx, dy = py - qy, dz = pz - qz;
     const float d2 = (dx * dx + dy * dy) + dz * dz;
     const float w = expf(-d2 * inv_sigma);
@@ -629,31 +672,54 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
     const float4* __restrict__ rec0, const float4* __restrict__ rec1, int K, float* __restrict__ out,
     int64_t* __restrict__ idx_out, float* __restrict__ d2_out, int32_t* __restrict__ tail,
     int32_t* __restrict__ counters) {
-  __shared__ BrickStage<true> S;
+  __shared__ BrickStage<true, 2> S;
+  __shared__ int s_unc[BK_THREADS], s_nunc;
   const BrickHdr h = *hp;
   const int n_list = counters[0];
   for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
     const int b = list[li];
     BrickGeo g;
-    const int C = stage_brick<true>(S, h, off, rec0, rec1, b, g);
+    if (threadIdx.x == 0) s_nunc = 0;                  // (stage_brick starts with a barrier)
+    const int C = stage_brick<true, 1, 2>(S, h, off, rec0, rec1, b, g);
     if (C < 0) { brick_to_tail(h, off, rec0, b, tail, counters, 1, 1); continue; }
 #ifdef BK_DBG_NOQUERY          // timing experiment (tools/build_variant.sh): staging only
     const int nq = 0;
 #else
-    const int nq = S.qpre[16];
+    const int nq = S.qpre[BrickStage<true, 2>::NQRUN];
 #endif
-    for (int t = threadIdx.x; t < nq; t += BK_THREADS) {
-      const int pos = query_slot(S, t);
+    // One query, start to finish.  WIDE = false: the 4 x 4 x 4 window of half cells picked by the half of its own half
+    // cell the query lies in: two below and one above on the axes where it lies in the lower half, one below and two
+    // above otherwise -- every point within (2 - m) half cells is inside, m = the largest distance of the query from
+    // the middle plane of its half cell over the axes (0 <= m <= 1/2): 0.75 .. 1 fine cells.  WIDE = true: the 3 x 3 x 3
+    // fine cells around its cell (6^3 half cells; everything within one fine cell), for the few queries the first
+    // window cannot certify.  Returns false when the result could not be certified (nothing is written then).
+    auto one_query = [&](int pos, auto wide_tag) -> bool {
+      constexpr bool WIDE = decltype(wide_tag)::value;
       const float4 q = S.rec0[pos];
       const int gid = __float_as_int(q.w);
-      if (gid < h.id_base || gid >= h.id_base + h.n_own) continue;          // imported halo point
-      const int lx = bk_fine(q.x, h.mn[0], h.inv_f, h.nf[0]) - g.ox;
-      const int ly = bk_fine(q.y, h.mn[1], h.inv_f, h.nf[1]) - g.oy;
-      const int lz = bk_fine(q.z, h.mn[2], h.inv_f, h.nf[2]) - g.oz;
+      int wx, wy, wz;
+      float mfrac = 0.f;
+      {
+        auto win = [&](float pc, float mn, int nf, int o) {
+          const float t2 = ((pc - mn) * h.inv_f) * 2.0f;
+          int sc = (int)floorf(t2);
+          sc = sc < 0 ? 0 : (sc >= 2 * nf ? 2 * nf - 1 : sc);
+          if (WIDE) return 2 * (sc >> 1) - 2 * o - 2;                 // the fine cell below the query's
+          const float fr = t2 - (float)sc;
+          const bool low = fr < 0.5f;
+          mfrac = fmaxf(mfrac, low ? fr : 1.0f - fr);
+          return sc - 2 * o - (low ? 2 : 1);
+        };
+        wx = win(q.x, h.mn[0], h.nf[0], g.ox);
+        wy = win(q.y, h.mn[1], h.nf[1], g.oy);
+        wz = win(q.z, h.mn[2], h.nf[2], g.oz);
+      }
+      float gq2 = h.g2;                                               // (0.999 f)^2: the wide window
+      if (!WIDE) { const float gq = (2.0f - mfrac) * 0.5f; gq2 = (gq * gq) * h.g2; }
       unsigned key[M];
 #pragma unroll
       for (int j = 0; j < M; ++j) key[j] = 0xffffffffu;
-      walk_candidates(S, lx, ly, lz, [&](const float4& c0, int i0, const float4& c1, int i1, bool two) {
+      auto visit = [&](const float4& c0, int i0, const float4& c1, int i1, bool two) {
         const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
         const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
         const unsigned ka = (__float_as_uint(da) & ~1023u) | (unsigned)i0;
@@ -664,7 +730,9 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
 #pragma unroll
         for (int j = M - 1; j >= 1; --j) key[j] = bk_med3u(key[j - 1], kb, key[j]);
         key[0] = min(key[0], kb);
-      });
+      };
+      if (WIDE) walk_window<6>(S, wx, wy, wz, visit);
+      else walk_window<4>(S, wx, wy, wz, visit);
       // exact (d2, id) order of the survivors
       float d[M];
       int id[M], ps[M];
@@ -696,9 +764,9 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
 #pragma unroll
       for (int j = 0; j < M; ++j) if (j == K - 1) { kK = key[j]; dK = d[j]; }
       const bool cert_list = key[M - 1] == 0xffffffffu || (key[M - 1] >> 10) > (kK >> 10);
-      const bool cert_geo = h.g_covers_r || (dK < FLT_MAX && dK <= h.g2);
+      const bool cert_geo = gq2 >= h.r2 || (dK < FLT_MAX && dK <= gq2);
+      if (!(cert_list && cert_geo)) return false;
       const int row = gid - h.id_base;
-      if (!(cert_list && cert_geo)) { tail[atomicAdd(&counters[1], 1)] = row; continue; }
       Repulse R;
       R.px = q.x; R.py = q.y; R.pz = q.z; R.inv_sigma = h.inv_sigma;
       // the normals of the K - 1 neighbours come from the brick-sorted array (four requests in flight)
@@ -729,6 +797,24 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
             if (d2_out) d2_out[(int64_t)row * (K - 1) + j - 1] = d[j] < FLT_MAX ? d[j] : -1.0f;
           }
       }
+      return true;
+    };
+    auto to_tail = [&](int pos) { tail[atomicAdd(&counters[1], 1)] = __float_as_int(S.rec0[pos].w) - h.id_base; };
+    for (int t = threadIdx.x; t < nq; t += BK_THREADS) {
+      const int pos = query_slot(S, t);
+      const int gid = __float_as_int(S.rec0[pos].w);
+      if (gid < h.id_base || gid >= h.id_base + h.n_own) continue;          // imported halo point
+      if (!one_query(pos, std::false_type())) {
+        // (~0.1 % of the queries of a uniform cloud) queued for the wide window: done by densely packed lanes below
+        const int at = atomicAdd(&s_nunc, 1);
+        if (at < BK_THREADS) s_unc[at] = pos; else to_tail(pos);
+      }
+    }
+    __syncthreads();
+    const int n_unc = min(s_nunc, BK_THREADS);
+    for (int u = threadIdx.x; u < n_unc; u += BK_THREADS) {
+      const int pos = s_unc[u];
+      if (!one_query(pos, std::true_type())) to_tail(pos);                   // beyond one fine cell: rings of bricks
     }
   }
 }
@@ -993,7 +1079,7 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? 5 : 4) void k_brick_h(
     const float4* __restrict__ rec0, const float4* __restrict__ rec1, const int32_t* __restrict__ view_total,
     int n_views, float* __restrict__ h_out /*(n_views, n_own)*/, int32_t* __restrict__ tail,
     int32_t* __restrict__ counters) {
-  __shared__ BrickStage<false> S;
+  __shared__ BrickStage<false, 1> S;
   const BrickHdr h = *hp;
   const int n_list = counters[0];
   bool small_cloud[NV];
@@ -1006,7 +1092,7 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? 5 : 4) void k_brick_h(
     const int b = list[li];
     BrickGeo g;
     constexpr int VS = NV <= 4 ? 8 : 1;                 // staged view masks: one byte per view when they fit a word
-    const int C = stage_brick<false, VS>(S, h, off, rec0, rec1, b, g);
+    const int C = stage_brick<false, VS, 1>(S, h, off, rec0, rec1, b, g);
     if (C < 0) { brick_to_tail(h, off, rec0, b, tail, counters, 3, 8); continue; }
 #ifdef BK_DBG_NOQUERY
     const int nq = 0;
