@@ -983,7 +983,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
 // first.  heavy[h] = (tile, first scratch slot, slices).  counters: [0] items, [1] heavy tiles.
 constexpr int kSlice = 1024, kTargetItems = 2048;
 __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
-                                                     int ty_rows, int n_clouds, int max_slots,
+                                                     int ty_rows, int n_clouds, int max_slots, int target_items,
                                                      int4* __restrict__ items, int4* __restrict__ heavy,
                                                      int32_t* __restrict__ counters) {
   __shared__ int hist[64], base[64];
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int sl0 = (s_slots / kTargetItems + 255) / 256 * 256;
+    int sl0 = (s_slots / target_items + 255) / 256 * 256;
     s_slice = sl0 < 256 ? 256 : (sl0 > kSlice ? kSlice : sl0);
   }
   __syncthreads();
@@ -1916,8 +1916,10 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
     scratch = (float*)(heavy + tiles);
   }
   if (items) {
+    static int target = -1;               // ISO_RASTER_ITEMS: development override of the work-item target (sweeps)
+    if (target < 0) { const char* e = getenv("ISO_RASTER_ITEMS"); target = e ? atoi(e) : kTargetItems; if (target < 1) target = kTargetItems; }
     hipLaunchKernelGGL(k_tile_items, dim3(1), dim3(1024), 0, s, tile_off, F, tile_row_begin, ty_rows, n_clouds, max_slots,
-                       items, heavy, counters);
+                       target, items, heavy, counters);
   } else {
     // the fill cursors are dead now: their array takes the heaviest-first tile order
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tile_off, F, tile_row_begin, ty_rows, n_clouds,
