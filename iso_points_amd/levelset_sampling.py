@@ -402,7 +402,9 @@ class UniformProjection(LevelSetProjection):
                 # tree + repulsion in one kernel on the brick grid (csrc/bricks.hip); the neighbour lists are
                 # only materialised when a later iteration re-uses them (:262-266) or the caller asks for them
                 from . import bricks
-                grid = bricks.BrickGrid(P, points.device)
+                grid = getattr(self, "_grid", None)          # the workspace (a few hundred MB at 1 M points, cleared once)
+                if grid is None or grid.n_own != P or grid.ws.device != points.device:     # is kept between calls
+                    grid = self._grid = bricks.BrickGrid(P, points.device)
                 grid.build(points[0].contiguous(), normals_init[0].contiguous(), knn_k=self.knn_k)
                 keep = sample_iters > 1 or self.materialize_knn
                 moved, idx_f, d2_f = bricks.resample_fused(grid, self.knn_k + 1, want_idx=keep)

@@ -458,7 +458,9 @@ class SurfaceSplatting(object):
         dev = points.device
         mask, cnt, scanned = bricks.view_mask_scan(points, normals, views, self.znear, self.zfar, rs.backface_culling)
         if grid is None:
-            grid = bricks.BrickGrid(P, dev)
+            grid = getattr(self, "_grid", None)              # kept between calls (allocated and cleared once per size)
+            if grid is None or grid.n_own != P or grid.ws.device != dev:
+                grid = self._grid = bricks.BrickGrid(P, dev)
         grid.build(points, normals, payload=mask, radius=float(self.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
         h = bricks.splat_h_fused(grid, mask, cnt, N)
         return self.front_setup(points, normals, views, projs, mask, h, features, features_from_normals, out, capacity,
