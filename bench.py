@@ -495,11 +495,13 @@ def main():
     counts = cyc.active_counts()
     # ~2 s of back-to-back cycles outside the timed region, so that an external utilisation sampler (the driver's
     # rocm-smi samples) sees the GPU at work: the timed region itself lasts a fraction of a second
-    t_busy = time.perf_counter()
-    while time.perf_counter() - t_busy < float(os.environ.get("ISO_BENCH_BUSY_S", "2.0")):
-        for _ in range(8):
-            cyc.step()
-        torch.cuda.synchronize()
+    # (a FIXED number of cycles: with N ranks every step holds collectives, so all ranks must run the same count -- a
+    # wall-clock bound would let them disagree and hang)
+    busy_steps = int(float(os.environ.get("ISO_BENCH_BUSY_S", "2.0")) / max(ms_per_step * 1e-3, 1e-4))
+    busy_steps = comm.max_int(min(busy_steps, 2000), dev)
+    for _ in range(busy_steps):
+        cyc.step()
+    torch.cuda.synchronize()
     evals_per_step = sum(sum(c) for c in counts)          # this rank's share
     flop_per_step = evals_per_step * FLOP_PER_EVAL
     launches_per_step = siren_launches / max(args.steps, 1)
