@@ -11,6 +11,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libisopoints_hip.so")
+if os.environ.get("ISO_DEV_LIB"):        # development aid (tools/build_variant.sh): another build of the same library
+    LIB_PATH = os.path.abspath(os.environ["ISO_DEV_LIB"])
 
 _c = ctypes
 _P = _c.c_void_p

@@ -827,11 +827,19 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
 // farther than that from the query are dropped before their records are read (a stray point of the SIREN level
 // set 0.15 off the surface would otherwise scan the whole shell of bricks that reaches the surface anywhere).
 struct WalkGeo { float qx, qy, qz, mnx, mny, mnz, B; };
+#ifndef BK_WALK_ITEMS
+#define BK_WALK_ITEMS 8     // record loads a lane keeps in flight (4 until round 3: a stray query's few thousand records were a
+#endif                      // chain of ~40 batch latencies)
 
+// bk_walk_shell: the bricks at Chebyshev distance rin + 1 .. rho from the query's brick (rin = rho - 1: one ring;
+// rin = -1: the whole cube).  A query that found too little in rings 0 and 1 -- a stray point -- takes all the remaining
+// rings up to the radius as ONE shell: a ring is a chain of two dependent global latencies (brick bounds, records), five
+// rings one after the other were the critical path of the bandwidth tail kernel (150 us in the SIREN cycle for a few
+// thousand stray queries).
 template <class Fetch, class Body, class Bound>
-__device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz, int nbx, int nby, int nbz,
-                                             const int32_t* __restrict__ off, int lane, const WalkGeo& G,
-                                             Fetch&& fetch, Body&& body, Bound&& bound) {
+__device__ __forceinline__ void bk_walk_shell(int rin, int rho, int qbx, int qby, int qbz, int nbx, int nby, int nbz,
+                                              const int32_t* __restrict__ off, int lane, const WalkGeo& G,
+                                              Fetch&& fetch, Body&& body, Bound&& bound) {
   const int x0 = max(qbx - rho, 0), x1 = min(qbx + rho, nbx - 1);
   const int y0 = max(qby - rho, 0), y1 = min(qby + rho, nby - 1);
   if (x0 > x1 || y0 > y1) return;
@@ -848,7 +856,7 @@ __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz,
     };
     if (col < ncols) {
       const int x = x0 + col / ny, y = y0 + col % ny;
-      const bool edge = (x == qbx - rho) || (x == qbx + rho) || (y == qby - rho) || (y == qby + rho);
+      const bool edge = x < qbx - rin || x > qbx + rin || y < qby - rin || y > qby + rin;   // outside the inner square
       const int cb = (x * nby + y) * nbz;
       const float gx = gap(G.qx, G.mnx, x, x), gy = gap(G.qy, G.mny, y, y);
       const float gxy2 = gx * gx + gy * gy;
@@ -856,10 +864,11 @@ __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz,
       if (edge) {
         const int za = max(qbz - rho, 0), zb = min(qbz + rho, nbz - 1);
         if (za <= zb && !beyond(za, zb)) { s0 = off[BK_CPB * (cb + za)]; e0 = off[BK_CPB * (cb + zb + 1)]; }
-      } else {
-        const int za = qbz - rho, zb = qbz + rho;
-        if (za >= 0 && !beyond(za, za)) { s0 = off[BK_CPB * (cb + za)]; e0 = off[BK_CPB * (cb + za + 1)]; }
-        if (zb < nbz && !beyond(zb, zb)) { s1 = off[BK_CPB * (cb + zb)]; e1 = off[BK_CPB * (cb + zb + 1)]; }
+      } else {                                            // two caps: below and above the inner cube
+        const int a0 = max(qbz - rho, 0), a1 = qbz - rin - 1;
+        const int b0 = qbz + rin + 1, b1 = min(qbz + rho, nbz - 1);
+        if (a0 <= a1 && !beyond(a0, a1)) { s0 = off[BK_CPB * (cb + a0)]; e0 = off[BK_CPB * (cb + a1 + 1)]; }
+        if (b0 <= b1 && !beyond(b0, b1)) { s1 = off[BK_CPB * (cb + b0)]; e1 = off[BK_CPB * (cb + b1 + 1)]; }
       }
     }
     // a lane finds the column of its item in the prefix sums of the column lengths
@@ -868,10 +877,11 @@ __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz,
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
     const int ex = inc - len, total = __shfl(inc, 63);
-    for (int j0 = 0; j0 < total; j0 += 256) {                // four items per lane and trip: their loads overlap
-      int at[4];
+    constexpr int NU = BK_WALK_ITEMS;                        // items per lane and trip: their loads overlap
+    for (int j0 = 0; j0 < total; j0 += 64 * NU) {
+      int at[NU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const int j = j0 + u * 64 + lane;
         int c = 0;
 #pragma unroll
@@ -884,14 +894,21 @@ __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz,
         const int r = j - cex;
         at[u] = j < total ? (r < cl0 ? cs0 + r : cs1 + (r - cl0)) : -1;
       }
-      decltype(fetch(0)) rec[4];                             // loads first (no control flow in between), then the work
+      decltype(fetch(0)) rec[NU];                            // loads first (no control flow in between), then the work
 #pragma unroll
-      for (int u = 0; u < 4; ++u) rec[u] = fetch(at[u] >= 0 ? at[u] : 0);
+      for (int u = 0; u < NU; ++u) rec[u] = fetch(at[u] >= 0 ? at[u] : 0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < NU; ++u)
         if (at[u] >= 0) body(at[u], rec[u]);
     }
   }
+}
+
+template <class Fetch, class Body, class Bound>
+__device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz, int nbx, int nby, int nbz,
+                                             const int32_t* __restrict__ off, int lane, const WalkGeo& G,
+                                             Fetch&& fetch, Body&& body, Bound&& bound) {
+  bk_walk_shell(rho - 1, rho, qbx, qby, qbz, nbx, nby, nbz, off, lane, G, fetch, body, bound);
 }
 
 template <int KMAX>
@@ -1248,22 +1265,27 @@ __global__ __launch_bounds__(64) void k_brick_h_tail(
       for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
       return fminf(h.r2, fminf(m, kth_seen));
     };
-    for (int rho = 0; rho <= rho_max; ++rho) {
-      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo,
-                   [&](int i) { float4 c = rec0[i]; c.w = rec1[i].w; return c; },        // position + view mask
-                   [&](int, const float4& c) {
-        if (!((__float_as_int(c.w) >> v) & 1)) return;
-        const float d2 = bk_d2(qx, qy, qz, c.x, c.y, c.z);
-        if (d2 < h.r2) best.push(d2);
-      }, far2);
+    auto fetch = [&](int i) { float4 c = rec0[i]; c.w = rec1[i].w; return c; };          // position + view mask
+    auto visit = [&](int, const float4& c) {
+      if (!((__float_as_int(c.w) >> v) & 1)) return;
+      const float d2 = bk_d2(qx, qy, qz, c.x, c.y, c.z);
+      if (d2 < h.r2) best.push(d2);
+    };
+    // rings 0 and 1 one after the other (most queries end there); a query that is still open -- a stray point -- takes
+    // every remaining ring up to the radius as one shell (bk_walk_shell)
+    int rho_r = 1;                                          // first ring whose guarantee rho * B covers the radius
+    while (rho_r < rho_max && (float)rho_r * B * 0.999f < h.r) ++rho_r;
+    for (int rho = 0; rho <= min(1, rho_max); ++rho) {
+      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, fetch, visit, far2);
       if (rho >= 1) {
         const float gg = (float)rho * B * 0.999f;
-        if (gg >= h.r) break;
+        if (gg >= h.r) { rho_r = 1; break; }
         wave_merge_f7(best, m7);
         kth_seen = fminf(kth_seen, m7[6]);
-        if (m7[6] < FLT_MAX && m7[6] <= gg * gg) break;
+        if (m7[6] < FLT_MAX && m7[6] <= gg * gg) { rho_r = 1; break; }
       }
     }
+    if (rho_r > 1) bk_walk_shell(1, rho_r, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, fetch, visit, far2);
     wave_merge_f7(best, m7);
     if (lane == 0) {
       h_out[(int64_t)v * h.n_own + row] = h_from_list(m7, small_cloud);
