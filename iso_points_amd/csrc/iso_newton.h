@@ -46,9 +46,11 @@ __device__ __forceinline__ bool iso_trace_move(float f, float dx, float dy, floa
 //   dirs      : sphere tracing (levelset_sampling.py:735-779): store the value, mask = |f| <= tol_valid,
 //               still active = |f| > tol (the caller passes 0.1 * proj_tolerance) and inside the sphere
 //   otherwise : Newton projection (levelset_sampling.py:309-344): normals = g, mask = |f| <= tol
-template <class Args>
+// HAVE_POS: the caller still holds the point's position (q = a.pts[idx], the values it evaluated at) and passes it in
+// instead of having it loaded again here.
+template <class Args, bool HAVE_POS = false>
 __device__ __forceinline__ bool iso_step_finish(const Args& a, int64_t idx, float f, float gx,
-                                                float gy, float gz) {
+                                                float gy, float gz, float qx = 0.f, float qy = 0.f, float qz = 0.f) {
   if (a.eval_only) {
     a.sdf_out[idx] = f;
     if (a.grad_out) { a.grad_out[idx * 3] = gx; a.grad_out[idx * 3 + 1] = gy; a.grad_out[idx * 3 + 2] = gz; }
@@ -58,7 +60,7 @@ __device__ __forceinline__ bool iso_step_finish(const Args& a, int64_t idx, floa
     a.sdf_out[idx] = f;
     a.mask[idx] = fabsf(f) <= a.tol_valid ? 1 : 0;
     if (fabsf(f) > a.tol && a.do_move) {
-      float qx = a.pts[idx * 3], qy = a.pts[idx * 3 + 1], qz = a.pts[idx * 3 + 2];
+      if (!HAVE_POS) { qx = a.pts[idx * 3]; qy = a.pts[idx * 3 + 1]; qz = a.pts[idx * 3 + 2]; }
       if (iso_trace_move(f, a.dirs[idx * 3], a.dirs[idx * 3 + 1], a.dirs[idx * 3 + 2], a.alpha, a.bound,
                          qx, qy, qz)) {
         a.pts[idx * 3] = qx; a.pts[idx * 3 + 1] = qy; a.pts[idx * 3 + 2] = qz;
@@ -71,7 +73,7 @@ __device__ __forceinline__ bool iso_step_finish(const Args& a, int64_t idx, floa
   const bool active = fabsf(f) > a.tol;
   a.mask[idx] = active ? 0 : 1;
   if (active && a.do_move) {
-    float qx = a.pts[idx * 3], qy = a.pts[idx * 3 + 1], qz = a.pts[idx * 3 + 2];
+    if (!HAVE_POS) { qx = a.pts[idx * 3]; qy = a.pts[idx * 3 + 1]; qz = a.pts[idx * 3 + 2]; }
     iso_newton_move(f, gx, gy, gz, qx, qy, qz);
     a.pts[idx * 3] = qx; a.pts[idx * 3 + 1] = qy; a.pts[idx * 3 + 2] = qz;
     return true;

@@ -173,6 +173,9 @@ __global__ void k_siren_pack_f16(const float* __restrict__ raw, float* __restric
 #ifndef X3_LDS_STASH
 #define X3_LDS_STASH 1
 #endif
+#ifndef X3_TILE_PIPE
+#define X3_TILE_PIPE 1     // the tile boundary without its two load chains and its closing barrier (k_siren_step_x3)
+#endif
 #ifndef X3_LDS_SLOT
 #define X3_LDS_SLOT 0      // which stash slot keeps its first LG groups in LDS (0: the longest-lived one)
 #endif
@@ -280,6 +283,37 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 #ifdef X3_DBG_TIMES
   long long* dbg = reinterpret_cast<long long*>(a.stash + (int64_t)gridDim.x * S::kStashPerWg(L)) - NW * 128;
 #endif
+  // Tile boundary (X3_TILE_PIPE).  A tile used to end with two chains of dependent loads during which the whole CU
+  // idled: the epilogue (list entry -> position -> returning atomic of the survivor list; 4.6 k cycles, one and a
+  // half waves busy, the others parked at a closing barrier) and then the next tile's points (list entry -> position,
+  // 2.3 k).  Now the next tile's list entries are requested during reverse stage 0 and its positions before the
+  // barrier that precedes the epilogue; the epilogue takes the position from LDS (`ptl`) and its list entry from a
+  // load issued before that barrier; and the closing barrier is gone -- waves 2..7 start layer 0 of the next tile
+  // while waves 0-1 finish the epilogue (no LDS hazard: `red` is next written after three more barriers, `ptl` by
+  // wave 0 itself, the activation regions were last read before the barrier that ends reverse stage 0's GEMM).
+  int nidx[NB];
+  float npx[NB], npy[NB], npz[NB];
+  auto fetch_idx = [&](int64_t t) {                      // list entries of tile t (-1: beyond the list)
+    int j_e = j;
+    asm volatile("" : "+v"(j_e));
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int64_t slot = slot0 + t * P + 32 * n + j_e;
+      nidx[n] = -1;
+      if (t < n_tiles && slot < count) nidx[n] = a.idx_in ? a.idx_in[slot] : (int)slot;
+    }
+  };
+  auto fetch_pts = [&]() {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      npx[n] = npy[n] = npz[n] = 0.f;
+      if (nidx[n] >= 0) {
+        const int64_t idx = nidx[n];
+        npx[n] = a.pts[idx * 3]; npy[n] = a.pts[idx * 3 + 1]; npz[n] = a.pts[idx * 3 + 2];
+      }
+    }
+  };
+  if constexpr (X3_TILE_PIPE) { fetch_idx(blockIdx.x); fetch_pts(); }
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 #ifdef X3_DBG_TIMES
     const bool dbg_on = blockIdx.x == 0 && tile == (int64_t)gridDim.x;
@@ -291,11 +325,15 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
     asm volatile("" : "+v"(j_e));
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-      const int64_t slot = slot0 + tile * P + 32 * n + j_e;
-      px[n] = py[n] = pz[n] = 0.f;
-      if (slot < count) {
-        const int64_t idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
-        px[n] = a.pts[idx * 3]; py[n] = a.pts[idx * 3 + 1]; pz[n] = a.pts[idx * 3 + 2];
+      if constexpr (X3_TILE_PIPE) {
+        px[n] = npx[n]; py[n] = npy[n]; pz[n] = npz[n];
+      } else {
+        const int64_t slot = slot0 + tile * P + 32 * n + j_e;
+        px[n] = py[n] = pz[n] = 0.f;
+        if (slot < count) {
+          const int64_t idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
+          px[n] = a.pts[idx * 3]; py[n] = a.pts[idx * 3 + 1]; pz[n] = a.pts[idx * 3 + 2];
+        }
       }
       if constexpr (!FWD) {                // kept for the reverse sweep's layer 0 (visible after the barrier below)
         if (w == 0 && h == 0) ptl[32 * n + j_e] = (f32x4){px[n], py[n], pz[n], 0.f};
@@ -550,6 +588,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       X3_STAMP();
       __syncthreads();
       X3_STAMP();
+      if constexpr (X3_TILE_PIPE) fetch_idx(tile + gridDim.x);
       float inv[NB];
       {
         const float iw = 1.0f / a.packed[x16_base(H, L)];
@@ -588,8 +627,12 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
           }
         }
       X3_STAMP();
-      __syncthreads();
+      // (no barrier here with X3_TILE_PIPE: between the one that ends this stage's GEMM and the one after the
+      // reduction nothing reads what the reduction writes)
+      if constexpr (!X3_TILE_PIPE) __syncthreads();
       X3_STAMP();
+    } else {
+      if constexpr (X3_TILE_PIPE) fetch_idx(tile + gridDim.x);
     }
     // ---- reduce head + gradient over the lane halves and the waves -----------------------------
 #pragma unroll
@@ -600,17 +643,27 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       float z = gz[n] + __shfl_xor(gz[n], 32);
       if (h == 0) red[w * P + 32 * n + j] = (f32x4){f, x, y, z};
     }
+    // (the thread / lane ids are made opaque here: everything derived from them -- LDS addresses,
+    // the rank mask of the compaction -- is recomputed per tile instead of being kept live, and
+    // spilled, across the whole tile)
+    int tid_e = tid, lane_e = lane;
+    asm volatile("" : "+v"(tid_e), "+v"(lane_e));
+    int eidx = -1;                              // X3_TILE_PIPE: the epilogue's list entry and position, requested
+    f32x4 qe = {0.f, 0.f, 0.f, 0.f};            // before the barrier (the position while `ptl` still holds this tile)
+    if constexpr (X3_TILE_PIPE) {
+      const int64_t slot = slot0 + tile * P + tid_e;
+      if (tid_e < P && slot < count) {
+        eidx = a.idx_in ? a.idx_in[slot] : (int)slot;
+        if constexpr (!FWD) qe = ptl[tid_e];
+      }
+      fetch_pts();
+    }
     X3_STAMP();
     __syncthreads();
     X3_STAMP();
     // ---- epilogue: thread tid handles point `tid` of the tile ----------------------------------
-    // (the thread / lane ids are made opaque here: everything derived from them -- LDS addresses,
-    // the rank mask of the compaction -- is recomputed per tile instead of being kept live, and
-    // spilled, across the whole tile)
     bool survive = false;
     int64_t idx = -1;
-    int tid_e = tid, lane_e = lane;
-    asm volatile("" : "+v"(tid_e), "+v"(lane_e));
     {
       const int64_t slot = slot0 + tile * P + tid_e;
       if (tid_e < P && slot < count) {
@@ -621,8 +674,14 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
           r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
         }
         const float f = r.x + bL;
-        idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
-        survive = iso_step_finish(a, idx, f, r.y, r.z, r.w);
+        if constexpr (X3_TILE_PIPE) {
+          idx = eidx;
+          if constexpr (!FWD) survive = iso_step_finish<SirenArgs, true>(a, idx, f, r.y, r.z, r.w, qe.x, qe.y, qe.z);
+          else survive = iso_step_finish(a, idx, f, r.y, r.z, r.w);
+        } else {
+          idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
+          survive = iso_step_finish(a, idx, f, r.y, r.z, r.w);
+        }
       }
     }
     if (!a.eval_only && a.do_move) {
@@ -639,7 +698,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       }
     }
     X3_STAMP();
-    __syncthreads();
+    if constexpr (!X3_TILE_PIPE) __syncthreads();
     X3_STAMP();
   }
 }
