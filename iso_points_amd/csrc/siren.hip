@@ -342,11 +342,21 @@ static bool siren_small_tiles_enabled() {
   return v == 1;
 }
 
+static bool siren_merged_shapes_enabled() {      // ISO_SIREN_MERGED=0: the two tile shapes as two launches (A/B)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ISO_SIREN_MERGED"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 // One evaluation of a list whose length only the device knows: for the H = 256 gradient kernels the list is cut at
 // siren_split_point into a 96-point-tile launch and a 32-point-tile launch (per-point results do not depend on the
 // tile shape); everything else is one launch.
 static int run_step_split(SirenArgs a, int hidden, int64_t n, hipStream_t s) {
   const bool split = hidden == 256 && !a.fwd_only && use_x3(hidden, a.L) && siren_small_tiles_enabled();
+  if (split && siren_merged_shapes_enabled()) {
+    a.small_tiles = 0; a.split = 3;
+    return run_step(a, hidden, n, s);
+  }
   a.small_tiles = 0; a.split = split ? 1 : 0;
   int rc = run_step(a, hidden, n, s);
   if (rc != 0 || !split) return rc;

@@ -32,7 +32,8 @@ struct SirenArgs {
   // split != 0 (H = 256 step kernels): the list is served by TWO launches, 96-point tiles for the slots
   // [0, siren_split_point(count)) (split = 1) and 32-point tiles for the rest (split = 2), so that the last, partly
   // filled round of the persistent grid costs a 32-point tile time instead of a 96-point one
-  int split = 0;
+  int split = 0;             // 3: both in one launch (k_siren_step_x3_both)
+  int big_blocks = 0;        // split = 3: workgroups of the 96-point-tile shape (set by the launcher)
 };
 
 // Slots served by the 96-point-tile launch of a split list.  A round of the persistent grid is 256 tiles: 24 576

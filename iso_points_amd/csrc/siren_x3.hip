@@ -215,8 +215,9 @@ struct X3Shape {
 #endif
 
 // FWD: value only (iso_siren_sdf, sphere tracing) -- no stash, no reverse sweep, no w cos(w z)
-template <int H, int NW, int NB, int MINB, bool FWD>
-__global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
+// bid / nblk: this workgroup's index among the nblk workgroups that share the list (the kernels below)
+template <int H, int NW, int NB, bool FWD>
+__device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, const int nblk) {
   using S = X3Shape<H, NW, NB>;
   constexpr int NS = S::NS, NTO = S::NTO, TW = S::TW, SL = S::SL, NG = S::NG, P = S::P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   const int h8 = h * 8;
   const float bL = a.packed[off_bl(H)];
   f32x4* stash = reinterpret_cast<f32x4*>(a.stash) +
-                 ((int64_t)blockIdx.x * NW + w) * (int64_t)(L > 1 ? L : 1) * NG * 128;   // + lane
+                 ((int64_t)bid * NW + w) * (int64_t)(L > 1 ? L : 1) * NG * 128;   // + lane
   f32x4* lst = reinterpret_cast<f32x4*>(smem_raw + S::kActBytes + S::kRedBytes + S::kPtsBytes) + w * (LG * 128) + lane;
 
   // weight images of this wave: forward / transposed image of hidden layer l (two fp16 parts)
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
   const int64_t count = a.split == 1 ? cut : total;
   const int64_t n_tiles = (count - slot0 + P - 1) / P;
 #ifdef X3_DBG_TIMES
-  long long* dbg = reinterpret_cast<long long*>(a.stash + (int64_t)gridDim.x * S::kStashPerWg(L)) - NW * 128;
+  long long* dbg = reinterpret_cast<long long*>(a.stash + (int64_t)nblk * S::kStashPerWg(L)) - NW * 128;
 #endif
   // Tile boundary (X3_TILE_PIPE).  A tile used to end with two chains of dependent loads during which the whole CU
   // idled: the epilogue (list entry -> position -> returning atomic of the survivor list; 4.6 k cycles, one and a
@@ -313,10 +314,10 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       }
     }
   };
-  if constexpr (X3_TILE_PIPE) { fetch_idx(blockIdx.x); fetch_pts(); }
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  if constexpr (X3_TILE_PIPE) { fetch_idx(bid); fetch_pts(); }
+  for (int64_t tile = bid; tile < n_tiles; tile += nblk) {
 #ifdef X3_DBG_TIMES
-    const bool dbg_on = blockIdx.x == 0 && tile == (int64_t)gridDim.x;
+    const bool dbg_on = bid == 0 && tile == (int64_t)nblk;
     int dbg_i = 0;
 #endif
     X3_STAMP();
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       X3_STAMP();
       __syncthreads();
       X3_STAMP();
-      if constexpr (X3_TILE_PIPE) fetch_idx(tile + gridDim.x);
+      if constexpr (X3_TILE_PIPE) fetch_idx(tile + nblk);
       float inv[NB];
       {
         const float iw = 1.0f / a.packed[x16_base(H, L)];
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
       if constexpr (!X3_TILE_PIPE) __syncthreads();
       X3_STAMP();
     } else {
-      if constexpr (X3_TILE_PIPE) fetch_idx(tile + gridDim.x);
+      if constexpr (X3_TILE_PIPE) fetch_idx(tile + nblk);
     }
     // ---- reduce head + gradient over the lane halves and the waves -----------------------------
 #pragma unroll
@@ -704,6 +705,30 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 }
 
 template <int H, int NW, int NB, int MINB, bool FWD>
+__global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
+  x3_step_body<H, NW, NB, FWD>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Both tile shapes of a split list (SirenArgs::split) in ONE launch: workgroups [0, big_blocks) serve the slots below
+// siren_split_point(count) on NB-tile workgroups, the others the rest on one-tile workgroups (their own stash region
+// behind the first group's).  The dispatcher places workgroups in index order, one per CU, so the small tiles start
+// on the CUs that finish their large ones first; a launch that finds nothing to do for one of the shapes costs nothing
+// (issued separately, the idle one of the two launches took ~4.4 us, 15 times per headline cycle).
+template <int H, int NW, int NB, int MINB>
+__global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3_both(SirenArgs a) {
+  if ((int)blockIdx.x < a.big_blocks) {
+    SirenArgs b = a;
+    b.split = 1;
+    x3_step_body<H, NW, NB, false>(b, (int)blockIdx.x, a.big_blocks);
+  } else {
+    SirenArgs b = a;
+    b.split = 2;
+    b.stash = a.stash + (int64_t)a.big_blocks * X3Shape<H, NW, NB>::kStashPerWg(a.L);
+    x3_step_body<H, NW, 1, false>(b, (int)blockIdx.x - a.big_blocks, (int)gridDim.x - a.big_blocks);
+  }
+}
+
+template <int H, int NW, int NB, int MINB, bool FWD>
 int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
   using S = X3Shape<H, NW, NB>;
   static bool attr_done = false;
@@ -720,6 +745,25 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 #endif
   const int blocks = (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
   hipLaunchKernelGGL((k_siren_step_x3<H, NW, NB, MINB, FWD>), dim3(blocks), dim3(64 * NW), S::kLds, s, a);
+  return 0;
+}
+
+template <int H, int NW, int NB, int MINB>
+int launch_x3_both(SirenArgs a, int64_t n_upper, hipStream_t s) {
+  using SB = X3Shape<H, NW, NB>;
+  using SS = X3Shape<H, NW, 1>;
+  constexpr size_t lds = SB::kLds > SS::kLds ? SB::kLds : SS::kLds;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_siren_step_x3_both<H, NW, NB, MINB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const int64_t cap = 256 * MINB;
+  const int64_t tb = (n_upper + SB::P - 1) / SB::P, ts = (n_upper + SS::P - 1) / SS::P;
+  a.big_blocks = (int)(tb < cap ? (tb < 1 ? 1 : tb) : cap);
+  const int small_blocks = (int)(ts < cap ? (ts < 1 ? 1 : ts) : cap);
+  hipLaunchKernelGGL((k_siren_step_x3_both<H, NW, NB, MINB>), dim3(a.big_blocks + small_blocks), dim3(64 * NW), lds, s, a);
   return 0;
 }
 
@@ -742,8 +786,8 @@ int launch_x3(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
 bool siren_x3_supported(int H, int L) { return (H == 256 || H == 128) && L >= 1 && L <= 8; }
 
 int64_t siren_x3_stash_floats(int H, int L) {
-  if (H == 256) {
-    return 256 * X3_MINB256 * X3Shape<256, X3_NW, X3_NB256>::kStashPerWg(L);
+  if (H == 256) {     // both tile shapes of a split list run in one launch: a region each
+    return 256 * X3_MINB256 * (X3Shape<256, X3_NW, X3_NB256>::kStashPerWg(L) + X3Shape<256, X3_NW, 1>::kStashPerWg(L));
   }
   if (H == 128) return 256 * X3_MINB128 * X3Shape<128, 4, 3>::kStashPerWg(L);
   return 0;
@@ -759,6 +803,7 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
 }
 
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
+  if (a.split == 3 && H == 256 && !a.fwd_only) return launch_x3_both<256, X3_NW, X3_NB256, X3_MINB256>(a, n_upper, s);
   if (a.small_tiles && H == 256 && !a.fwd_only) return launch_x3<256, X3_NW, 1, X3_MINB256, false>(a, n_upper, s);
   if (a.fwd_only) {
     if (H == 256) return launch_x3<256, X3_NW, X3_NB256, X3_MINB256, true>(a, n_upper, s);
