@@ -455,6 +455,7 @@ extern "C" int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_
               "iso_siren_sdf_grad: hidden must be 64/128/256 and 0<=n_hidden<=8 (got %d, %d)",
               hidden, n_hidden);
   ISO_REQUIRE(n >= 0, ISO_ERR_INVALID, "iso_siren_sdf_grad: n < 0");
+  ISO_REQUIRE(n < (1ll << 31), ISO_ERR_UNSUPPORTED, "iso_siren_sdf_grad: n must fit int32");
   if (n == 0) return ISO_OK;
   ISO_REQUIRE(pts && sdf_out && packed && workspace, ISO_ERR_INVALID,
               "iso_siren_sdf_grad: null pointer");
