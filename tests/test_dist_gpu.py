@@ -40,7 +40,9 @@ def _models(dev, kind):
 
 @pytest.mark.parametrize("world,P,S,N,kind", [(2, 20000, 64, 2, "sphere"), (4, 60000, 128, 4, "sphere"),
                                               (8, 200000, 256, 4, "sphere"), (3, 30000, 96, 3, "siren"),
-                                              (8, 9000, 64, 1, "sphere"), (3, 20011, 64, 2, "sphere")])
+                                              (8, 9000, 64, 1, "sphere"), (3, 20011, 64, 2, "sphere"),
+                                              (5, 50021, 80, 3, "sphere"), (7, 40000, 112, 5, "sphere"),
+                                              (6, 24000, 48, 6, "siren")])
 def test_lockstep_ranks_equal_single_gpu(dev, world, P, S, N, kind):
     from iso_points_amd.dist import IsoCycle, run_lockstep, shard_bounds, slab_order
     pts, views, projs, rs, target = _scene(dev, P, S, N)
