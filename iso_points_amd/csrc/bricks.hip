@@ -413,15 +413,15 @@ __global__ __launch_bounds__(256) void k_brick_offsets(const BrickHdr* __restric
 // workgroup know fine cells only).  SUB = 2 (resample): a query walks a 4 x 4 x 4 window of HALF cells picked by the
 // half of its own half cell it lies in -- every point within 0.75 fine cells of the query is inside (1.5 half cells to
 // each face), 1.6 r wide at the 0.8 r cell against the 2.4 r of a 3 x 3 x 3 walk of whole cells: 44 % of the candidates.
-template <bool WITH_NRM, int SUB = 1>
+template <bool WITH_NRM, int SUB = 1, int CAP = BK_CAP>
 struct BrickStage {
   static constexpr int NL = 6 * SUB;                // local (sub-)cells per axis: the brick + one fine cell of halo
   static constexpr int NCELL = NL * NL * NL;
   static constexpr int NQRUN = 16 * SUB * SUB;      // z-runs of the brick's own (sub-)cells
-  float4 rec0[BK_CAP];
-  int src[WITH_NRM ? BK_CAP : 1];     // WITH_NRM: position of the staged record in the brick-sorted arrays (its rec1 is read
+  float4 rec0[CAP];
+  int src[WITH_NRM ? CAP : 1];     // WITH_NRM: position of the staged record in the brick-sorted arrays (its rec1 is read
                                       // from there by the few that need it: staging it cost 16 KB of LDS = three workgroups per CU)
-  int gid[WITH_NRM ? 1 : BK_CAP];
+  int gid[WITH_NRM ? 1 : CAP];
   int cstart[NCELL + 4];   // [NCELL + 1] used: local (sub-)cell -> first staged slot
   int ccur[NCELL];
   int run_i0[9];
@@ -440,10 +440,10 @@ constexpr int BK_RAW = 8;
 
 // VS (bandwidth kernel only): bit stride of the view mask in the staged record -- 1: as stored; 8: view v at bit
 // 8 v (up to four views), so that masked records add up to four 8-bit per-view counters in one register.
-template <bool WITH_NRM, int VS = 1, int SUB = 1>
-__device__ int stage_brick(BrickStage<WITH_NRM, SUB>& S, const BrickHdr& h, const int32_t* __restrict__ off,
+template <bool WITH_NRM, int VS = 1, int SUB = 1, int CAP = BK_CAP>
+__device__ int stage_brick(BrickStage<WITH_NRM, SUB, CAP>& S, const BrickHdr& h, const int32_t* __restrict__ off,
                            const float4* __restrict__ rec0, const float4* __restrict__ rec1, int b, BrickGeo& g) {
-  typedef BrickStage<WITH_NRM, SUB> St;
+  typedef BrickStage<WITH_NRM, SUB, CAP> St;
   constexpr int NL = St::NL, NCELL = St::NCELL;
   const int tid = threadIdx.x;
   const int nbx = h.nb[0], nby = h.nb[1], nbz = h.nb[2];
@@ -526,7 +526,7 @@ __device__ int stage_brick(BrickStage<WITH_NRM, SUB>& S, const BrickHdr& h, cons
     __syncthreads();
     scan_cells();
     __syncthreads();
-    if (S.cstart[NCELL] > BK_CAP) return -1;
+    if (S.cstart[NCELL] > CAP) return -1;
     const float* __restrict__ rec1w = reinterpret_cast<const float*>(rec1) + 3;     // the payload word of a second record
     float uw[BK_RAW];
 #pragma unroll
@@ -543,7 +543,7 @@ __device__ int stage_brick(BrickStage<WITH_NRM, SUB>& S, const BrickHdr& h, cons
     __syncthreads();
     scan_cells();
     __syncthreads();
-    if (S.cstart[NCELL] > BK_CAP) return -1;
+    if (S.cstart[NCELL] > CAP) return -1;
     for (int j = tid; j < total_raw; j += BK_THREADS) {
       const int i = index_of(j);
       const float4 p = rec0[i];
@@ -568,9 +568,9 @@ __device__ int stage_brick(BrickStage<WITH_NRM, SUB>& S, const BrickHdr& h, cons
   return S.cstart[NCELL];
 }
 
-template <bool WITH_NRM, int SUB>
-__device__ __forceinline__ int query_slot(const BrickStage<WITH_NRM, SUB>& S, int t) {
-  int lo = 0, hi = BrickStage<WITH_NRM, SUB>::NQRUN;         // the run r with qpre[r] <= t < qpre[r + 1]
+template <bool WITH_NRM, int SUB, int CAP>
+__device__ __forceinline__ int query_slot(const BrickStage<WITH_NRM, SUB, CAP>& S, int t) {
+  int lo = 0, hi = BrickStage<WITH_NRM, SUB, CAP>::NQRUN;         // the run r with qpre[r] <= t < qpre[r + 1]
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (S.qpre[mid] <= t) lo = mid; else hi = mid;
@@ -582,8 +582,8 @@ __device__ __forceinline__ int query_slot(const BrickStage<WITH_NRM, SUB>& S, in
 // block.  body(c0, i0, c1, i1, two): two candidates per trip (both LDS reads issued before either is
 // used; `two` false: the second is a repeat of the first and must be ignored); the bounds of the next
 // range are requested while the current one is walked.
-template <bool WITH_NRM, class Body>
-__device__ __forceinline__ void walk_candidates(const BrickStage<WITH_NRM, 1>& S, int lx, int ly, int lz, Body&& body) {
+template <bool WITH_NRM, int CAP, class Body>
+__device__ __forceinline__ void walk_candidates(const BrickStage<WITH_NRM, 1, CAP>& S, int lx, int ly, int lz, Body&& body) {
   auto cell0 = [&](int c9) { return ((lx + c9 / 3 - 1) * 6 + (ly + c9 % 3 - 1)) * 6 + (lz - 1); };
   int a = S.cstart[cell0(0)], e = S.cstart[cell0(0) + 3];
   for (int c9 = 0; c9 < 9; ++c9) {
@@ -1089,14 +1089,21 @@ __device__ __forceinline__ float h_from_list(const float* d /*7 ascending, FLT_M
   return fminf(fmaxf(0.5f * m, 5e-5f), 0.01f);
 }
 
-// (five waves per SIMD: 277 -> 257 us; the resample kernel above is bound by its instruction count and gains nothing)
+// (five waves per SIMD: 277 -> 257 us with a persistent grid; six with a workgroup per brick, see BK_H_WGS and h_grid();
+// the resample kernel above is bound by its instruction count and gains nothing)
+#ifndef BK_H_CAP
+#define BK_H_CAP BK_CAP
+#endif
+#ifndef BK_H_WGS
+#define BK_H_WGS 6     // workgroups per CU (5 / 6 / 7: 189 / 181 / 196 us with a workgroup per brick)
+#endif
 template <int NV>
-__global__ __launch_bounds__(BK_THREADS, NV <= 4 ? 5 : 4) void k_brick_h(
+__global__ __launch_bounds__(BK_THREADS, NV <= 4 ? BK_H_WGS : 4) void k_brick_h(
     const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off, const int32_t* __restrict__ list,
     const float4* __restrict__ rec0, const float4* __restrict__ rec1, const int32_t* __restrict__ view_total,
     int n_views, float* __restrict__ h_out /*(n_views, n_own)*/, int32_t* __restrict__ tail,
     int32_t* __restrict__ counters) {
-  __shared__ BrickStage<false, 1> S;
+  __shared__ BrickStage<false, 1, BK_H_CAP> S;
   const BrickHdr h = *hp;
   const int n_list = counters[0];
   bool small_cloud[NV];
@@ -1109,7 +1116,7 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? 5 : 4) void k_brick_h(
     const int b = list[li];
     BrickGeo g;
     constexpr int VS = NV <= 4 ? 8 : 1;                 // staged view masks: one byte per view when they fit a word
-    const int C = stage_brick<false, VS, 1>(S, h, off, rec0, rec1, b, g);
+    const int C = stage_brick<false, VS, 1, BK_H_CAP>(S, h, off, rec0, rec1, b, g);
     if (C < 0) { brick_to_tail(h, off, rec0, b, tail, counters, 3, 8); continue; }
 #ifdef BK_DBG_NOQUERY
     const int nq = 0;
@@ -1536,7 +1543,25 @@ extern "C" int iso_halo_import(void* workspace, int64_t n_max, const float* gath
   return ISO_OK;
 }
 
-static int fused_grid() { return 256 * 8; }
+static int env_grid(const char* name, int dflt) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : dflt;
+}
+// Grids of the two fused kernels: a workgroup per brick or two, handed out by the dispatcher as CUs free up.  Bricks differ
+// widely in cost (points per brick, lanes with an open view) and a persistent grid that strides over the list ends with a
+// long tail: measured on the cfg-3a cycle, k_brick_h 241 us at 2048 workgroups, 211 at 3840, 186 at 10240 (flat beyond);
+// k_brick_resample 291 / 287 / 270 us at 1024 / 2048 / >= 4096.  A workgroup past the end of the list reads one counter
+// and leaves.  (ISO_BK_H_GRID / ISO_BK_RESAMPLE_GRID override, tools/sweep_grid.sh)
+static int brick_grid(int forced, int64_t n_own, int cap) {
+  if (forced > 0) return forced;
+  int64_t g = n_own / 48;
+  if (g < 1024) g = 1024;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+static int h_grid(int64_t n_own) { static const int f = env_grid("ISO_BK_H_GRID", 0); return brick_grid(f, n_own, 10240); }
+static int resample_grid(int64_t n_own) { static const int f = env_grid("ISO_BK_RESAMPLE_GRID", 0); return brick_grid(f, n_own, 8192); }
 
 extern "C" int iso_resample_fused(void* workspace, int64_t n_max, const float* points, int64_t n_own,
                                   int k_plus_one, float* points_out, int64_t* idx_out, float* d2_out,
@@ -1550,7 +1575,7 @@ extern "C" int iso_resample_fused(void* workspace, int64_t n_max, const float* p
   hipStream_t s = (hipStream_t)stream;
   const int K = k_plus_one;
 #define ISO_RS(MM)                                                                                           \
-  hipLaunchKernelGGL(k_brick_resample<MM>, dim3(fused_grid()), dim3(BK_THREADS), 0, s, w.hdr, w.off, w.list, \
+  hipLaunchKernelGGL(k_brick_resample<MM>, dim3(resample_grid(n_own)), dim3(BK_THREADS), 0, s, w.hdr, w.off, w.list, \
                      w.rec0, w.rec1, K, points_out, idx_out, d2_out, w.tail, w.counters)
   if (K <= 5) ISO_RS(8);
   else if (K <= 9) ISO_RS(12);
@@ -1588,7 +1613,7 @@ extern "C" int iso_splat_h_fused(void* workspace, int64_t n_max, const float* po
   const BrickWs w = bricks_carve(workspace, n_max);
   hipStream_t s = (hipStream_t)stream;
 #define ISO_H(NV)                                                                                            \
-  hipLaunchKernelGGL(k_brick_h<NV>, dim3(fused_grid()), dim3(BK_THREADS), 0, s, w.hdr, w.off, w.list, w.rec0, \
+  hipLaunchKernelGGL(k_brick_h<NV>, dim3(h_grid(n_own)), dim3(BK_THREADS), 0, s, w.hdr, w.off, w.list, w.rec0, \
                      w.rec1, view_total, n_views, h_out, w.tail, w.counters)
   if (n_views <= 1) ISO_H(1);
   else if (n_views <= 2) ISO_H(2);

@@ -2279,7 +2279,11 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
     hipLaunchKernelGGL(k_z_finish_clouds, dim3(iso_stream_grid(max_pts, 256), n_clouds), dim3(256), 0, s, zacc, zs,
                        first_idx, num_pts, grad_points, terms_log2);
   }
-  hipLaunchKernelGGL(k_splat_backward_heavy, dim3(2048), dim3(256), 0, s, points, radii, search_radius,
+  // one wave per heavy point, four per workgroup; the cost of a point varies with the flagged blocks under its disc, so the
+  // list is spread over many short-lived workgroups instead of a persistent grid (cfg-3a cycle, 154 k heavy points: 144 /
+  // 126 / 109 / 101 / 100 us at 1024 / 2048 / 4096 / 8192 / 16384 workgroups; ISO_HEAVY_GRID overrides)
+  static const int heavy_grid = []() { const char* e = getenv("ISO_HEAVY_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8192; }();
+  hipLaunchKernelGGL(k_splat_backward_heavy, dim3(heavy_grid), dim3(256), 0, s, points, radii, search_radius,
                      first_idx, num_pts, n_clouds, grad_occ, blk, blk2, G, F, rect_mode, radii_s,
                      heavy, heavy_count, grad_points);
   ISO_CHECK_LAUNCH("iso_splat_backward");
