@@ -430,6 +430,22 @@ struct BrickStage {
   int qpre[NQRUN + 1];
 };
 
+// -DBK_DBG_PHASES (timing experiment, tools/diag/brick_phases.py): thread 0 of every workgroup adds the shader-clock time
+// between consecutive marks (barrier waits included) to bk_phase[i]; iso_dbg_brick_phases() reads and clears them.
+#ifdef BK_DBG_PHASES
+__device__ unsigned long long bk_phase[16384 * 8];
+__shared__ unsigned long long s_bk_t, s_bk_acc[8];
+#define BK_PH(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); \
+  if ((i) >= 0) s_bk_acc[(i) < 0 ? 0 : (i)] += t_ - s_bk_t; \
+  else for (int q_ = 0; q_ < 8; ++q_) s_bk_acc[q_] = 0; \
+  s_bk_t = t_; } } while (0)
+#define BK_PH_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 16384) for (int q_ = 0; q_ < 8; ++q_) \
+  bk_phase[blockIdx.x * 8 + q_] += s_bk_acc[q_]; } while (0)
+#else
+#define BK_PH(i) do {} while (0)
+#define BK_PH_FLUSH() do {} while (0)
+#endif
+
 struct BrickGeo { int bx, by, bz, ox, oy, oz; };
 
 // All threads of the workgroup.  Returns the number of staged records, or -1 when they do not fit.
@@ -450,6 +466,7 @@ __device__ int stage_brick(BrickStage<WITH_NRM, SUB, CAP>& S, const BrickHdr& h,
   g.bz = b % nbz; g.by = (b / nbz) % nby; g.bx = b / (nbz * nby);
   g.ox = 4 * g.bx - 1; g.oy = 4 * g.by - 1; g.oz = 4 * g.bz - 1;
   __syncthreads();                                   // the previous brick's readers are done
+  BK_PH(6);
   for (int c = tid; c < NCELL; c += BK_THREADS) S.ccur[c] = 0;
   if (tid < 9) {
     const int x = g.bx + tid / 3 - 1, y = g.by + tid % 3 - 1;
@@ -469,6 +486,7 @@ __device__ int stage_brick(BrickStage<WITH_NRM, SUB, CAP>& S, const BrickHdr& h,
     for (int k = 1; k <= 9; ++k) { run += S.run_pre[k]; S.run_pre[k] = run; }
   }
   __syncthreads();
+  BK_PH(0);
   const int total_raw = S.run_pre[9];
   auto index_of = [&](int j) {
     int run = 0;
@@ -511,30 +529,45 @@ __device__ int stage_brick(BrickStage<WITH_NRM, SUB, CAP>& S, const BrickHdr& h,
   if (total_raw <= BK_THREADS * BK_RAW) {
     int idx[BK_RAW], cell[BK_RAW];
     float4 p[BK_RAW];
+    // slot k of this WAVE holds records only when live(k) -- a scalar test, so the empty slots (on a surface half of the
+    // eight) cost a branch instead of their share of ~1000 predicated-off instructions per wave
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    auto live = [&](int k) { return wbase + k * BK_THREADS < total_raw; };
 #pragma unroll
     for (int k = 0; k < BK_RAW; ++k) {
-      const int j = tid + k * BK_THREADS;
-      idx[k] = j < total_raw ? index_of(j) : -1;
+      idx[k] = -1; cell[k] = -1;
+      p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live(k)) {
+        const int j = tid + k * BK_THREADS;
+        idx[k] = j < total_raw ? index_of(j) : -1;
+      }
     }
 #pragma unroll
-    for (int k = 0; k < BK_RAW; ++k) p[k] = idx[k] >= 0 ? rec0[idx[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < BK_RAW; ++k)
+      if (live(k)) p[k] = idx[k] >= 0 ? rec0[idx[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < BK_RAW; ++k) {
-      cell[k] = idx[k] >= 0 ? cell_of(p[k]) : -1;
-      if (cell[k] >= 0) atomicAdd(&S.ccur[cell[k]], 1);
+      if (live(k)) {
+        cell[k] = idx[k] >= 0 ? cell_of(p[k]) : -1;
+        if (cell[k] >= 0) atomicAdd(&S.ccur[cell[k]], 1);
+      }
     }
     __syncthreads();
+    BK_PH(1);
     scan_cells();
     __syncthreads();
+    BK_PH(2);
     if (S.cstart[NCELL] > CAP) return -1;
     const float* __restrict__ rec1w = reinterpret_cast<const float*>(rec1) + 3;     // the payload word of a second record
     float uw[BK_RAW];
 #pragma unroll
-    for (int k = 0; k < BK_RAW; ++k)                 // (bandwidth kernel) the payload words of the accepted candidates, all in flight
-      uw[k] = (!WITH_NRM && cell[k] >= 0) ? rec1w[4 * (int64_t)idx[k]] : 0.f;
+    for (int k = 0; k < BK_RAW; ++k) {               // (bandwidth kernel) the payload words of the accepted candidates, all in flight
+      uw[k] = 0.f;
+      if (!WITH_NRM && live(k)) uw[k] = cell[k] >= 0 ? rec1w[4 * (int64_t)idx[k]] : 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < BK_RAW; ++k)
-      if (cell[k] >= 0) store(atomicAdd(&S.ccur[cell[k]], 1), p[k], idx[k], uw[k]);
+      if (live(k)) { if (cell[k] >= 0) store(atomicAdd(&S.ccur[cell[k]], 1), p[k], idx[k], uw[k]); }
   } else {                                           // very dense neighbourhood: two passes over global memory
     for (int j = tid; j < total_raw; j += BK_THREADS) {
       const int c = cell_of(rec0[index_of(j)]);
@@ -565,6 +598,7 @@ __device__ int stage_brick(BrickStage<WITH_NRM, SUB, CAP>& S, const BrickHdr& h,
     if (tid == 0) S.qpre[0] = 0;
   }
   __syncthreads();
+  BK_PH(3);
   return S.cstart[NCELL];
 }
 
@@ -578,25 +612,37 @@ __device__ __forceinline__ int query_slot(const BrickStage<WITH_NRM, SUB, CAP>& 
   return S.qbeg[lo] + (t - S.qpre[lo]);
 }
 
-// The 3x3x3 fine cells around local cell (lx,ly,lz) = nine contiguous slot ranges of the staged
-// block.  body(c0, i0, c1, i1, two): two candidates per trip (both LDS reads issued before either is
-// used; `two` false: the second is a repeat of the first and must be ignored); the bounds of the next
-// range are requested while the current one is walked.
+// The 3x3x3 fine cells around local cell (lx,ly,lz) = nine contiguous slot ranges of the staged block, walked as ONE
+// loop per lane: two candidates per trip (both LDS reads issued before either is used; v0 / v1 say which of them
+// exist), and a lane that reaches the end of a range moves on to the next one in the same trip -- the bounds of the
+// range after that are requested then and are there when they are needed.  The first form ran the nine ranges as nine
+// loops: a wave then pays the LONGEST of its lanes' ranges nine times (measured: ~125 trips per wave for ~46 per
+// lane); as one loop it pays the longest total.  An empty range costs its lane one idle trip.
 template <bool WITH_NRM, int CAP, class Body>
 __device__ __forceinline__ void walk_candidates(const BrickStage<WITH_NRM, 1, CAP>& S, int lx, int ly, int lz, Body&& body) {
-  auto cell0 = [&](int c9) { return ((lx + c9 / 3 - 1) * 6 + (ly + c9 % 3 - 1)) * 6 + (lz - 1); };
-  int a = S.cstart[cell0(0)], e = S.cstart[cell0(0) + 3];
-  for (int c9 = 0; c9 < 9; ++c9) {
-    int na = 0, ne = 0;
-    if (c9 < 8) { na = S.cstart[cell0(c9 + 1)]; ne = S.cstart[cell0(c9 + 1) + 3]; }
-    for (int i = a; i < e; i += 2) {
-      const bool two = i + 1 < e;
-      const int i1 = two ? i + 1 : i;
-      const float4 c0 = S.rec0[i];
-      const float4 c1 = S.rec0[i1];
-      body(c0, i, c1, i1, two);
+  constexpr int NL = BrickStage<WITH_NRM, 1, CAP>::NL;
+  int cell = ((lx - 1) * NL + (ly - 1)) * NL + (lz - 1);            // range r: cell + (r / 3) NL^2 + (r % 3) NL, three cells
+  int i = S.cstart[cell], e = S.cstart[cell + 3];
+  cell += NL;
+  int ni = S.cstart[cell], ne = S.cstart[cell + 3];                 // range 1
+  int run = 0, m = 1;                                               // m = (index of the prefetched range) % 3
+  while (run < 9) {
+    const bool v0 = i < e, v1 = i + 1 < e;
+    const int i0 = v0 ? i : 0, i1 = v1 ? i + 1 : i0;
+    float4 c0 = S.rec0[i0];
+    float4 c1 = S.rec0[i1];
+    // both records are consumed HERE as far as the compiler can tell: left to itself it sinks the second read into the
+    // `v1` branch and its payload word into the distance test (three LDS round trips per trip, one after the other)
+    asm volatile("" : "+v"(c0.x), "+v"(c0.y), "+v"(c0.z), "+v"(c0.w), "+v"(c1.x), "+v"(c1.y), "+v"(c1.z), "+v"(c1.w));
+    body(c0, c1, v0, v1);
+    i += 2;
+    if (i >= e) {
+      ++run;
+      i = ni; e = ne;
+      m = m == 2 ? 0 : m + 1;
+      cell += m == 0 ? NL * NL - 2 * NL : NL;
+      if (run < 8) { ni = S.cstart[cell]; ne = S.cstart[cell + 3]; }
     }
-    a = na; e = ne;
   }
 }
 
@@ -673,6 +719,7 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
     int64_t* __restrict__ idx_out, float* __restrict__ d2_out, int32_t* __restrict__ tail,
     int32_t* __restrict__ counters) {
   __shared__ BrickStage<true, 2> S;
+  BK_PH(-1);
   __shared__ int s_unc[BK_THREADS], s_nunc;
   const BrickHdr h = *hp;
   const int n_list = counters[0];
@@ -810,13 +857,17 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
         if (at < BK_THREADS) s_unc[at] = pos; else to_tail(pos);
       }
     }
+    BK_PH(4);
     __syncthreads();
+    BK_PH(5);
     const int n_unc = min(s_nunc, BK_THREADS);
     for (int u = threadIdx.x; u < n_unc; u += BK_THREADS) {
       const int pos = s_unc[u];
       if (!one_query(pos, std::true_type())) to_tail(pos);                   // beyond one fine cell: rings of bricks
     }
+    BK_PH(7);
   }
+  BK_PH_FLUSH();
 }
 
 // ---- rings of bricks around a query (tail kernels: one wave per query) ---------------------------
@@ -1104,6 +1155,7 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? BK_H_WGS : 4) void k_brick_h(
     int n_views, float* __restrict__ h_out /*(n_views, n_own)*/, int32_t* __restrict__ tail,
     int32_t* __restrict__ counters) {
   __shared__ BrickStage<false, 1, BK_H_CAP> S;
+  BK_PH(-1);
   const BrickHdr h = *hp;
   const int n_list = counters[0];
   bool small_cloud[NV];
@@ -1144,24 +1196,25 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? BK_H_WGS : 4) void k_brick_h(
       if (VS == 8 && C <= 255) {                                     // (workgroup-uniform) byte counters cannot overflow
         unsigned acc = 0;
         if (qmask)
-          walk_candidates(S, lx, ly, lz, [&](const float4& c0, int, const float4& c1, int, bool two) {
+          walk_candidates(S, lx, ly, lz, [&](const float4& c0, const float4& c1, bool v0, bool v1) {
             const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
             const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
-            const unsigned ma = da <= t2 ? (__float_as_uint(c0.w) & 0x01010101u) : 0u;
-            const unsigned mb = (two && db <= t2) ? (__float_as_uint(c1.w) & 0x01010101u) : 0u;
+            const unsigned ma = (v0 && da <= t2) ? (__float_as_uint(c0.w) & 0x01010101u) : 0u;
+            const unsigned mb = (v1 && db <= t2) ? (__float_as_uint(c1.w) & 0x01010101u) : 0u;
             acc += ma + mb;
           });
 #pragma unroll
         for (int v = 0; v < NV; ++v) cnt[v] = (int)((acc >> (8 * (v & 3))) & 0xffu);
       } else if (qmask)
-        walk_candidates(S, lx, ly, lz, [&](const float4& c0, int, const float4& c1, int, bool two) {
+        walk_candidates(S, lx, ly, lz, [&](const float4& c0, const float4& c1, bool v0, bool v1) {
           const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
           const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
-          const int ma = da <= t2 ? __float_as_int(c0.w) : 0;
-          const int mb = (two && db <= t2) ? __float_as_int(c1.w) : 0;
+          const int ma = (v0 && da <= t2) ? __float_as_int(c0.w) : 0;
+          const int mb = (v1 && db <= t2) ? __float_as_int(c1.w) : 0;
 #pragma unroll
           for (int v = 0; v < NV; ++v) cnt[v] += ((ma >> (VS * v)) & 1) + ((mb >> (VS * v)) & 1);
         });
+      BK_PH(4);
       bool open_ = false;
 #pragma unroll
       for (int v = 0; v < NV; ++v) open_ = open_ || (((qmask >> (VS * v)) & 1) && !small_cloud[v] && cnt[v] < 7);
@@ -1173,11 +1226,11 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? BK_H_WGS : 4) void k_brick_h(
 #pragma unroll
         for (int j = 0; j < 7; ++j) d[v][j] = FLT_MAX;
       if (open_)
-        walk_candidates(S, lx, ly, lz, [&](const float4& c0, int, const float4& c1, int, bool two) {
+        walk_candidates(S, lx, ly, lz, [&](const float4& c0, const float4& c1, bool v0, bool v1) {
           float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
           float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
-          da = da < h.r2 ? da : FLT_MAX;
-          db = (two && db < h.r2) ? db : FLT_MAX;
+          da = (v0 && da < h.r2) ? da : FLT_MAX;
+          db = (v1 && db < h.r2) ? db : FLT_MAX;
           const int ma = __float_as_int(c0.w), mb = __float_as_int(c1.w);
 #pragma unroll
           for (int v = 0; v < NV; ++v) {
@@ -1191,6 +1244,7 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? BK_H_WGS : 4) void k_brick_h(
             d[v][0] = fminf(d[v][0], kb);
           }
         });
+      BK_PH(5);
       if (qmask) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -1210,6 +1264,7 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? BK_H_WGS : 4) void k_brick_h(
       }
     }
   }
+  BK_PH_FLUSH();
 }
 
 template <int KMAX>
@@ -1562,6 +1617,23 @@ static int brick_grid(int forced, int64_t n_own, int cap) {
 }
 static int h_grid(int64_t n_own) { static const int f = env_grid("ISO_BK_H_GRID", 0); return brick_grid(f, n_own, 10240); }
 static int resample_grid(int64_t n_own) { static const int f = env_grid("ISO_BK_RESAMPLE_GRID", 0); return brick_grid(f, n_own, 8192); }
+
+#ifdef BK_DBG_PHASES
+extern "C" int iso_dbg_brick_phases(double* out16) {
+  static unsigned long long h[16384 * 8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bk_phase), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 16; ++i) out16[i] = 0.0;
+  for (int w = 0; w < 16384; ++w) {
+    bool any = false;
+    for (int i = 0; i < 8; ++i) { out16[i] += (double)h[w * 8 + i]; any = any || h[w * 8 + i]; }
+    if (any) out16[8] += 1.0;                       // workgroups that did any work
+  }
+  void* dp = nullptr;
+  (void)hipGetSymbolAddress(&dp, HIP_SYMBOL(bk_phase));
+  (void)hipMemset(dp, 0, sizeof(h));
+  return 0;
+}
+#endif
 
 extern "C" int iso_resample_fused(void* workspace, int64_t n_max, const float* points, int64_t n_own,
                                   int k_plus_one, float* points_out, int64_t* idx_out, float* d2_out,
