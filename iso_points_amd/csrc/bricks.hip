@@ -740,8 +740,11 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
     // the middle plane of its half cell over the axes (0 <= m <= 1/2): 0.75 .. 1 fine cells.  WIDE = true: the 3 x 3 x 3
     // fine cells around its cell (6^3 half cells; everything within one fine cell), for the few queries the first
     // window cannot certify.  Returns false when the result could not be certified (nothing is written then).
+    // The wide pass runs with a list two entries longer when M = K + 1: a query whose (K + 1)-th key ties with its K-th
+    // fails the list test whatever the window, and would otherwise end in the tail kernel (a wave per query).
     auto one_query = [&](int pos, auto wide_tag) -> bool {
       constexpr bool WIDE = decltype(wide_tag)::value;
+      constexpr int ML = (WIDE && M == 10) ? 12 : M;
       const float4 q = S.rec0[pos];
       const int gid = __float_as_int(q.w);
       int wx, wy, wz;
@@ -763,28 +766,28 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
       }
       float gq2 = h.g2;                                               // (0.999 f)^2: the wide window
       if (!WIDE) { const float gq = (2.0f - mfrac) * 0.5f; gq2 = (gq * gq) * h.g2; }
-      unsigned key[M];
+      unsigned key[ML];
 #pragma unroll
-      for (int j = 0; j < M; ++j) key[j] = 0xffffffffu;
+      for (int j = 0; j < ML; ++j) key[j] = 0xffffffffu;
       auto visit = [&](const float4& c0, int i0, const float4& c1, int i1, bool two) {
         const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
         const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
         const unsigned ka = (__float_as_uint(da) & ~1023u) | (unsigned)i0;
         const unsigned kb = two ? ((__float_as_uint(db) & ~1023u) | (unsigned)i1) : 0xffffffffu;
 #pragma unroll
-        for (int j = M - 1; j >= 1; --j) key[j] = bk_med3u(key[j - 1], ka, key[j]);
+        for (int j = ML - 1; j >= 1; --j) key[j] = bk_med3u(key[j - 1], ka, key[j]);
         key[0] = min(key[0], ka);
 #pragma unroll
-        for (int j = M - 1; j >= 1; --j) key[j] = bk_med3u(key[j - 1], kb, key[j]);
+        for (int j = ML - 1; j >= 1; --j) key[j] = bk_med3u(key[j - 1], kb, key[j]);
         key[0] = min(key[0], kb);
       };
       if (WIDE) walk_window<6>(S, wx, wy, wz, visit);
       else walk_window<4>(S, wx, wy, wz, visit);
       // exact (d2, id) order of the survivors
-      float d[M];
-      int id[M], ps[M];
+      float d[ML];
+      int id[ML], ps[ML];
 #pragma unroll
-      for (int j = 0; j < M; ++j) {
+      for (int j = 0; j < ML; ++j) {
         const bool valid = key[j] != 0xffffffffu;
         ps[j] = valid ? (int)(key[j] & 1023u) : pos;
         const float4 c = S.rec0[ps[j]];
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
       do {
         swapped = false;
 #pragma unroll
-        for (int j = 0; j + 1 < M; ++j) {
+        for (int j = 0; j + 1 < ML; ++j) {
           if (pair_lt(d[j + 1], id[j + 1], d[j], id[j])) {
             const float td = d[j]; d[j] = d[j + 1]; d[j + 1] = td;
             const int ti = id[j]; id[j] = id[j + 1]; id[j + 1] = ti;
@@ -809,8 +812,8 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
       unsigned kK = 0xffffffffu;
       float dK = FLT_MAX;
 #pragma unroll
-      for (int j = 0; j < M; ++j) if (j == K - 1) { kK = key[j]; dK = d[j]; }
-      const bool cert_list = key[M - 1] == 0xffffffffu || (key[M - 1] >> 10) > (kK >> 10);
+      for (int j = 0; j < ML; ++j) if (j == K - 1) { kK = key[j]; dK = d[j]; }
+      const bool cert_list = key[ML - 1] == 0xffffffffu || (key[ML - 1] >> 10) > (kK >> 10);
       const bool cert_geo = gq2 >= h.r2 || (dK < FLT_MAX && dK <= gq2);
       if (!(cert_list && cert_geo)) return false;
       const int row = gid - h.id_base;
@@ -818,19 +821,19 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
       R.px = q.x; R.py = q.y; R.pz = q.z; R.inv_sigma = h.inv_sigma;
       // the normals of the K - 1 neighbours come from the brick-sorted array (four requests in flight)
 #pragma unroll
-      for (int j0 = 1; j0 < M; j0 += 4) {
+      for (int j0 = 1; j0 < ML; j0 += 4) {
         float4 u[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int j = j0 + k;
           u[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (j < M && j < K && d[j < M ? j : 0] < FLT_MAX) u[k] = rec1[S.src[ps[j < M ? j : 0]]];
+          if (j < ML && j < K && d[j < ML ? j : 0] < FLT_MAX) u[k] = rec1[S.src[ps[j < ML ? j : 0]]];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int j = j0 + k;
-          if (j < M && j < K && d[j < M ? j : 0] < FLT_MAX) {
-            const float4 c = S.rec0[ps[j < M ? j : 0]];
+          if (j < ML && j < K && d[j < ML ? j : 0] < FLT_MAX) {
+            const float4 c = S.rec0[ps[j < ML ? j : 0]];
             R.add(c.x, c.y, c.z, u[k].x, u[k].y, u[k].z);
           }
         }
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
       R.finish(out + (int64_t)row * 3);
       if (idx_out) {
 #pragma unroll
-        for (int j = 1; j < M; ++j)
+        for (int j = 1; j < ML; ++j)
           if (j < K) {
             idx_out[(int64_t)row * (K - 1) + j - 1] = d[j] < FLT_MAX ? (int64_t)id[j] : (int64_t)-1;
             if (d2_out) d2_out[(int64_t)row * (K - 1) + j - 1] = d[j] < FLT_MAX ? d[j] : -1.0f;
@@ -1615,6 +1618,7 @@ static int brick_grid(int forced, int64_t n_own, int cap) {
   if (g > cap) g = cap;
   return (int)g;
 }
+static bool resample_m10() { static const int v = env_grid("ISO_BK_RESAMPLE_M10", 1); return v == 1; }   // 2: off (A/B)
 static int h_grid(int64_t n_own) { static const int f = env_grid("ISO_BK_H_GRID", 0); return brick_grid(f, n_own, 10240); }
 static int resample_grid(int64_t n_own) { static const int f = env_grid("ISO_BK_RESAMPLE_GRID", 0); return brick_grid(f, n_own, 8192); }
 
@@ -1649,7 +1653,10 @@ extern "C" int iso_resample_fused(void* workspace, int64_t n_max, const float* p
 #define ISO_RS(MM)                                                                                           \
   hipLaunchKernelGGL(k_brick_resample<MM>, dim3(resample_grid(n_own)), dim3(BK_THREADS), 0, s, w.hdr, w.off, w.list, \
                      w.rec0, w.rec1, K, points_out, idx_out, d2_out, w.tail, w.counters)
+  // (list length K + 1 is the shortest that can certify: the 10-entry list of the default K = 9 fails the list test for
+  // ~0.1 % of the queries -- they take the wide window -- and saves two of twelve insertion steps per candidate)
   if (K <= 5) ISO_RS(8);
+  else if (K == 9 && resample_m10()) ISO_RS(10);
   else if (K <= 9) ISO_RS(12);
   else ISO_RS(16);
 #undef ISO_RS
