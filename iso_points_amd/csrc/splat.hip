@@ -981,7 +981,9 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
 // Work items of a band (see k_raster): tiles with more than 1.5 slices of candidates are cut into slices
 // (<= kSlice candidates each) as long as the scratch slots last; slices first, then the whole tiles heaviest
 // first.  heavy[h] = (tile, first scratch slot, slices).  counters: [0] items, [1] heavy tiles.
-constexpr int kSlice = 1024, kTargetItems = 2048;
+// (kTargetItems, cfg-3a cycle, 1.4 M candidates over 4096 tiles: slices of 1024 / 512 / 256 candidates -- targets 2048 / 3072..5120 /
+// >= 6144 -- raster + merge 288 + 29 / 224 + 37 / 206 + 63 us)
+constexpr int kSlice = 1024, kTargetItems = 4096;
 __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
                                                      int ty_rows, int n_clouds, int max_slots, int target_items,
                                                      int4* __restrict__ items, int4* __restrict__ heavy,
