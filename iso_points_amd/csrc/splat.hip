@@ -1265,12 +1265,15 @@ static inline BlkGeo make_blk(int H, int W) {
   return g;
 }
 
-// Both levels in one launch: one WAVE per 64x64-pixel super block, lane = one of its 8x8 blocks (lane % 8 = block
-// column); a lane reads the 8 rows of its block as 2 x 16 bytes each when the row is aligned, the super block's
-// flag is the ballot of the block flags.  Workgroup 0 also clears the few words the later passes count into
-// (heavy-point list length, z scale): no clearing launches.
+// Gradient maps of the occupancy image, three levels in one launch: one WAVE per 64x64-pixel super block, lane = one
+// of its 8x8 blocks (lane % 8 = block column).  A lane reads the 8 rows of its block as 2 x 16 bytes each when the row
+// is aligned and writes the block's pixel mask (bit 8 ry + rx: that pixel carries a gradient); the flags of a row of
+// eight blocks are one byte (the ballot), the super block's flag says whether any of them is set.  Workgroup 0 also
+// clears the few words the later passes count into (heavy-point list length, z scale): no clearing launches.
 __global__ __launch_bounds__(256) void k_grad_maps(const float* __restrict__ grad_occ, Frame F, BlkGeo G, int N,
-                                                   uint8_t* __restrict__ blk, uint8_t* __restrict__ blk2,
+                                                   unsigned long long* __restrict__ pixmask /*(N, NBy, NBx)*/,
+                                                   uint8_t* __restrict__ rowbytes /*(N, NBy, NB2x)*/,
+                                                   uint8_t* __restrict__ blk2 /*(N, NB2y, NB2x)*/,
                                                    int32_t* __restrict__ clear_a, int n_clear_a,
                                                    int32_t* __restrict__ clear_b, int n_clear_b) {
   if (blockIdx.x == 0) {
@@ -1282,22 +1285,25 @@ __global__ __launch_bounds__(256) void k_grad_maps(const float* __restrict__ gra
   for (int64_t sb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); sb < total; sb += (int64_t)gridDim.x * 4) {
     const int sx = sb % G.NB2x, sy = (sb / G.NB2x) % G.NB2y, n = sb / ((int64_t)G.NB2x * G.NB2y);
     const int bx = sx * 8 + (lane & 7), by = sy * 8 + (lane >> 3);
-    int any = 0;
+    unsigned long long m = 0ull;
     if (bx < G.NBx && by < G.NBy) {
       const int x0 = bx * GB, x1 = min(F.W, x0 + GB);
       for (int y = by * GB; y < min(F.H, (by + 1) * GB); ++y) {
         const float* row = grad_occ + ((int64_t)n * F.H + y) * F.W;
+        unsigned bits = 0u;
         if (x1 - x0 == GB && (((uintptr_t)(row + x0)) & 15) == 0) {
           const float4 a = *reinterpret_cast<const float4*>(row + x0), c = *reinterpret_cast<const float4*>(row + x0 + 4);
-          any |= (a.x != 0.f) | (a.y != 0.f) | (a.z != 0.f) | (a.w != 0.f) | (c.x != 0.f) | (c.y != 0.f) | (c.z != 0.f) |
-                 (c.w != 0.f);
+          bits = (unsigned)(a.x != 0.f) | ((unsigned)(a.y != 0.f) << 1) | ((unsigned)(a.z != 0.f) << 2) | ((unsigned)(a.w != 0.f) << 3) |
+                 ((unsigned)(c.x != 0.f) << 4) | ((unsigned)(c.y != 0.f) << 5) | ((unsigned)(c.z != 0.f) << 6) | ((unsigned)(c.w != 0.f) << 7);
         } else {
-          for (int x = x0; x < x1; ++x) any |= row[x] != 0.0f;
+          for (int x = x0; x < x1; ++x) bits |= (unsigned)(row[x] != 0.0f) << (x - x0);
         }
+        m |= (unsigned long long)bits << (8 * (y - by * GB));
       }
-      blk[((int64_t)n * G.NBy + by) * G.NBx + bx] = (uint8_t)any;
+      pixmask[((int64_t)n * G.NBy + by) * G.NBx + bx] = m;
     }
-    const unsigned long long bal = __ballot(any != 0);
+    const unsigned long long bal = __ballot(m != 0ull);
+    if ((lane & 7) == 0 && by < G.NBy) rowbytes[((int64_t)n * G.NBy + by) * G.NB2x + sx] = (uint8_t)((bal >> (8 * (lane >> 3))) & 0xffull);
     if (lane == 0) blk2[sb] = bal ? 1 : 0;
   }
 }
@@ -1402,25 +1408,28 @@ __global__ __launch_bounds__(256) void k_splat_backward(
   }
 }
 
-// Pass 2, one WAVE per heavy point.  The lanes fetch the flags of the 8x8 blocks of the support together (one
-// ballot per 64 blocks), the flagged blocks are then visited four at a time, one pixel per lane, so that the
-// gradient loads of a round are in flight together (the block-by-block walk was a chain of dependent loads,
-// ~30 L2 latencies per point); lane-private partial sums in ascending block order are combined by a fixed
-// butterfly -> bit-stable (no atomics), independent of how many waves run.
+// Pass 2, eight LANES per heavy point.  Measured on the cfg-3a cycle (tools/diag/heavy_count.py): 154 k heavy points whose
+// discs (29.5 px radius: up to 81 blocks) hold 3.7 flagged blocks and 18 pixels with a gradient each -- the first form
+// spent a wave per point (one pixel per lane, a block per round, a butterfly at the end): ~350 wave instructions for 18
+// useful terms, the kernel was bound by exactly that (54 M VALU instructions per launch = 100 % of the issue rate).
+// Here a lane walks every eighth block row of its point's disc through the row bytes and the flagged blocks through
+// their pixel masks (k_grad_maps) and touches only the pixels that carry a gradient; a lane adds its terms in image
+// order, the eight partial sums meet in a fixed tree -> bit-stable, no atomics, independent of the launch geometry.
+// (one lane per point: 100 -> 64 us, bound by the lane's chain of dependent loads at 2.4 waves per SIMD)
 __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     const float* __restrict__ pts, const float* __restrict__ radii, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num, int n_clouds,
-    const float* __restrict__ grad_occ, const uint8_t* __restrict__ blk,
-    const uint8_t* __restrict__ blk2, BlkGeo G, Frame F,
+    const float* __restrict__ grad_occ, const unsigned long long* __restrict__ pixmask,
+    const uint8_t* __restrict__ rowbytes, BlkGeo G, Frame F,
     int rect_mode, float radii_s, const int32_t* __restrict__ heavy,
     const int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int count = *heavy_count;
-  const int ly = lane >> 3, lx = lane & 7;
-  for (int w = wave; w < count; w += nwaves) {
-    const int64_t p = heavy[w];
+  constexpr int LP = 8;                                   // lanes per point: lane j takes the block rows by0 + j, by0 + j + LP, ...
+  const int j = threadIdx.x & (LP - 1);
+  // (count rounded up: the lanes of a group leave the loop together, the shuffles below need all of them)
+  for (int w = (blockIdx.x * blockDim.x + threadIdx.x) / LP; w < (count + 63) / 64 * 64; w += gridDim.x * blockDim.x / LP) {
+    const bool live = w < count;
+    const int64_t p = live ? heavy[w] : 0;
     int n = 0;
     for (int c = 1; c < n_clouds; ++c) if (p >= first[c]) n = c;     // clouds are packed in order
     const float r = rect_mode ? 0.f : rs[n], r2 = r * r;
@@ -1429,51 +1438,42 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     const float sx = rect_mode ? rx * radii_s : r, sy = rect_mode ? ry * radii_s : r;
     int x0, x1, y0, y1;
     float gx = 0.f, gy = 0.f;
-    if (out_range(px, sx, F.W, F.ex, F.m, x0, x1) && out_range(py, sy, F.H, F.ey, F.m, y0, y1)) {
-      const int bx0 = x0 / GB, by0 = y0 / GB;
-      const int nbx = x1 / GB - bx0 + 1, nb = nbx * (y1 / GB - by0 + 1);
+    if (live && out_range(px, sx, F.W, F.ex, F.m, x0, x1) && out_range(py, sy, F.H, F.ey, F.m, y0, y1)) {
       const float* __restrict__ gimg = grad_occ + (int64_t)n * F.H * F.W;
-      const uint8_t* __restrict__ flags = blk + (int64_t)n * G.NBy * G.NBx;
-      for (int c0 = 0; c0 < nb; c0 += 64) {
-        // lane c: block (bx0 + c % nbx, by0 + c / nbx) of the support, packed as by * 256 + bx (sides <= 2048)
-        const int c = c0 + lane;
-        int mine = 0;
-        bool flagged = false;
-        if (c < nb) {
-          const int by = by0 + c / nbx, bx = bx0 + c % nbx;
-          mine = by * 256 + bx;
-          flagged = flags[by * G.NBx + bx] != 0;
-        }
-        unsigned long long todo = __ballot(flagged);
-        while (todo) {
-          float g[4], dx[4], dy[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            g[u] = 0.f; dx[u] = 0.f; dy[u] = 0.f;
-            if (todo) {                                                   // wave-uniform
-              const int src = __ffsll((long long)todo) - 1;
-              todo &= todo - 1;
-              const int b = __builtin_amdgcn_readlane(mine, src);
-              const int yo = (b >> 8) * GB + ly, xo = (b & 255) * GB + lx;
-              if (yo >= y0 && yo <= y1 && xo >= x0 && xo <= x1) {
-                g[u] = gimg[(int64_t)yo * F.W + xo];
-                dx[u] = ndc_x(F.W - 1 - xo, F) - px;
-                dy[u] = ndc_y(F.H - 1 - yo, F) - py;
-              }
+      const int bx0 = x0 / GB, bx1 = x1 / GB;
+      for (int by = y0 / GB + j; by <= y1 / GB; by += LP) {
+        // rows of the block inside the window, as a mask of whole bytes
+        const int ra = max(y0 - by * GB, 0), rb = min(y1 - by * GB, GB - 1);
+        const unsigned long long rowsel = (rb == 7 ? ~0ull : ((1ull << (8 * (rb + 1))) - 1ull)) & ~((1ull << (8 * ra)) - 1ull);
+        for (int sb = bx0 >> 3; sb <= bx1 >> 3; ++sb) {
+          unsigned flags = rowbytes[((int64_t)n * G.NBy + by) * G.NB2x + sb];
+          const int ka = max(bx0 - sb * 8, 0), kb = min(bx1 - sb * 8, 7);
+          flags &= (0xffu >> (7 - kb)) & (0xffu << ka);
+          while (flags) {
+            const int k = __ffs((int)flags) - 1;
+            flags &= flags - 1;
+            const int bx = sb * 8 + k;
+            // columns of the block inside the window, the same byte in every row
+            const int ca = max(x0 - bx * GB, 0), cb = min(x1 - bx * GB, GB - 1);
+            const unsigned long long colsel = (unsigned long long)((0xffu >> (7 - cb)) & (0xffu << ca)) * 0x0101010101010101ull;
+            unsigned long long m = pixmask[((int64_t)n * G.NBy + by) * G.NBx + bx] & rowsel & colsel;
+            while (m) {
+              const int b = __ffsll((long long)m) - 1;
+              m &= m - 1;
+              const int yo = by * GB + (b >> 3), xo = bx * GB + (b & 7);
+              const float g = gimg[(int64_t)yo * F.W + xo];
+              occ_term(g, ndc_x(F.W - 1 - xo, F) - px, ndc_y(F.H - 1 - yo, F) - py, rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
             }
           }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            occ_term(g[u], dx[u], dy[u], rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
         }
       }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 1; o < LP; o <<= 1) {                    // fixed tree over the LP partial sums
       gx += __shfl_xor(gx, o);
       gy += __shfl_xor(gy, o);
     }
-    if (lane == 0) { grad[p * 3] = gx; grad[p * 3 + 1] = gy; }
+    if (live && j == 0) { grad[p * 3] = gx; grad[p * 3 + 1] = gy; }
   }
 }
 
@@ -2223,7 +2223,8 @@ __global__ void k_z_finish_clouds(const long long* __restrict__ acc, const ZScal
 
 static int64_t bwd_maps_bytes(int n_clouds, int image_size, int image_width) {
   const BlkGeo G = make_blk(image_size, image_width > 0 ? image_width : image_size);
-  return (((int64_t)n_clouds * ((int64_t)G.NBx * G.NBy + (int64_t)G.NB2x * G.NB2y)) + 63) / 64 * 64;   // blk, blk2
+  // pixel masks (8 B per 8x8 block), row bytes (one per eight blocks of a block row), super-block flags
+  return (((int64_t)n_clouds * ((int64_t)G.NBx * G.NBy * 8 + (int64_t)G.NB2x * G.NBy + (int64_t)G.NB2x * G.NB2y)) + 63) / 64 * 64;
 }
 extern "C" int64_t iso_splat_backward_workspace_bytes(int n_clouds, int image_size, int image_width,
                                                       int64_t total_points) {
@@ -2251,8 +2252,9 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
   const BlkGeo G = make_blk(F.H, F.W);
   ISO_REQUIRE(F.H <= 2048 && F.W <= 2048, ISO_ERR_UNSUPPORTED, "iso_splat_backward: image sides must be <= 2048");
   hipStream_t s = (hipStream_t)stream;
-  uint8_t* blk = (uint8_t*)workspace;
-  uint8_t* blk2 = blk + (int64_t)n_clouds * G.NBx * G.NBy;
+  unsigned long long* pixmask = (unsigned long long*)workspace;            // (caller buffers are 16-byte aligned)
+  uint8_t* rowbytes = (uint8_t*)(pixmask + (int64_t)n_clouds * G.NBx * G.NBy);
+  uint8_t* blk2 = rowbytes + (int64_t)n_clouds * G.NB2x * G.NBy;
   int32_t* heavy_count = (int32_t*)((uint8_t*)workspace + bwd_maps_bytes(n_clouds, image_size, image_width));
   int32_t* heavy = heavy_count + 16;
   const bool with_z = grad_zbuf && total_points > 0;
@@ -2261,7 +2263,7 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
   // block maps of the image gradient (both levels, one launch); it also clears the heavy-list length and the z scale
   {
     int gmaps = iso_div_up((int64_t)n_clouds * G.NB2x * G.NB2y, 4);
-    hipLaunchKernelGGL(k_grad_maps, dim3(gmaps < 1 ? 1 : gmaps), dim3(256), 0, s, grad_occ, F, G, n_clouds, blk, blk2,
+    hipLaunchKernelGGL(k_grad_maps, dim3(gmaps < 1 ? 1 : gmaps), dim3(256), 0, s, grad_occ, F, G, n_clouds, pixmask, rowbytes, blk2,
                        heavy_count, 16, with_z ? reinterpret_cast<int32_t*>(zs) : nullptr, 4);
   }
   int gx = iso_div_up(max_pts, 1024); if (gx > 8192) gx = 8192;
@@ -2281,12 +2283,11 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
     hipLaunchKernelGGL(k_z_finish_clouds, dim3(iso_stream_grid(max_pts, 256), n_clouds), dim3(256), 0, s, zacc, zs,
                        first_idx, num_pts, grad_points, terms_log2);
   }
-  // one wave per heavy point, four per workgroup; the cost of a point varies with the flagged blocks under its disc, so the
-  // list is spread over many short-lived workgroups instead of a persistent grid (cfg-3a cycle, 154 k heavy points: 144 /
-  // 126 / 109 / 101 / 100 us at 1024 / 2048 / 4096 / 8192 / 16384 workgroups; ISO_HEAVY_GRID overrides)
-  static const int heavy_grid = []() { const char* e = getenv("ISO_HEAVY_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8192; }();
+  // eight lanes per heavy point; the cost of a point varies with the gradient pixels under its disc, so the list is spread
+  // over short-lived workgroups (a workgroup past the end of the list reads the count and leaves; ISO_HEAVY_GRID overrides)
+  static const int heavy_grid = []() { const char* e = getenv("ISO_HEAVY_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
   hipLaunchKernelGGL(k_splat_backward_heavy, dim3(heavy_grid), dim3(256), 0, s, points, radii, search_radius,
-                     first_idx, num_pts, n_clouds, grad_occ, blk, blk2, G, F, rect_mode, radii_s,
+                     first_idx, num_pts, n_clouds, grad_occ, pixmask, rowbytes, G, F, rect_mode, radii_s,
                      heavy, heavy_count, grad_points);
   ISO_CHECK_LAUNCH("iso_splat_backward");
   return ISO_OK;
