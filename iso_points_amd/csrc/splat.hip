@@ -598,6 +598,36 @@ __device__ __forceinline__ void composite_pixel(const PixK<KMAX>& best, int K, f
   ca.img[pix * (ca.C + 1) + ca.C] = hit ? 1.0f : 0.0f;
 }
 
+// -DRS_DBG_PHASES (timing experiment, tools/diag/raster_phases.py): thread 0 of every workgroup of k_raster adds the
+// shader-clock time between consecutive marks (barrier waits included) to its slot of rs_phase.
+#ifdef RS_DBG_PHASES
+__device__ unsigned long long rs_phase[32768 * 8];
+__shared__ unsigned long long s_rs_t, s_rs_acc[8];
+#define RS_PH(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); \
+  if ((i) >= 0) s_rs_acc[(i) < 0 ? 0 : (i)] += t_ - s_rs_t; \
+  else for (int q_ = 0; q_ < 8; ++q_) s_rs_acc[q_] = 0; \
+  s_rs_t = t_; } } while (0)
+#define RS_PH_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 32768) for (int q_ = 0; q_ < 8; ++q_) \
+  rs_phase[blockIdx.x * 8 + q_] += s_rs_acc[q_]; } while (0)
+extern "C" int iso_dbg_raster_phases(double* out16) {
+  static unsigned long long h[32768 * 8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(rs_phase), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 16; ++i) out16[i] = 0.0;
+  for (int w = 0; w < 32768; ++w) {
+    bool any = false;
+    for (int i = 0; i < 8; ++i) { out16[i] += (double)h[w * 8 + i]; any = any || h[w * 8 + i]; }
+    if (any) out16[8] += 1.0;
+  }
+  void* dp = nullptr;
+  (void)hipGetSymbolAddress(&dp, HIP_SYMBOL(rs_phase));
+  (void)hipMemset(dp, 0, sizeof(h));
+  return 0;
+}
+#else
+#define RS_PH(i) do {} while (0)
+#define RS_PH_FLUSH() do {} while (0)
+#endif
+
 // CP ("candidate parallel"): how the hits of a chunk of 256 candidates reach the pixels.
 //   false: every pixel thread walks the candidates that reach its wave's four rows and tests each one (the first
 //          form: the K-best insertion, ~50 instructions, runs for the whole wave whenever ANY of its lanes is hit --
@@ -713,11 +743,13 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
     };
     s_hits[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_nw[threadIdx.x] = 0;
+    RS_PH(-1);
     fetch(c_begin);
     for (int c0 = c_begin; c0 < cnt; c0 += 256, par ^= 1) {
       const int m = min(256, cnt - c0);
       if ((int)threadIdx.x < m) { s_r0[par % NB][threadIdx.x] = r0; s_r1[par % NB][threadIdx.x] = r1; s_r2[par % NB][threadIdx.x] = make_float2(r2.x, r2.y); }
       __syncthreads();                                    // records visible; the hit counters are zero
+      RS_PH(0);
       fetch(c0 + 256);
       if ((int)threadIdx.x < m) {
         const int k = threadIdx.x;
@@ -748,6 +780,7 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
         }
       }
       __syncthreads();                                    // hit lists complete
+      RS_PH(1);
       const int nh = s_hits[threadIdx.x];
       s_hits[threadIdx.x] = 0;
       if (threadIdx.x == 0) s_nw[par ^ 1] = 0;
@@ -760,7 +793,9 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
           for (int k = 0; k < m; ++k) test_push(k, false);        // an overfull list: every candidate, tested here
         }
       }
+      RS_PH(2);
       if (NB == 1) __syncthreads();                       // one record buffer: all reads done before the next chunk lands
+      RS_PH(3);
     }
     // q of the K survivors (:94; the same expression on the same operands as the hit test): their records are
     // re-read once per tile instead of carrying q through every insertion
@@ -774,6 +809,7 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
         }
       }
     }
+    RS_PH(4);
   } else {
   for (int c0 = c_begin; c0 < cnt; c0 += 256) {
       const int m = min(256, cnt - c0);
@@ -841,6 +877,8 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
       sc[(KMAX + j) * 256 + threadIdx.x] = best.q[j];
       sc[(2 * KMAX + j) * 256 + threadIdx.x] = __int_as_float(best.id[j]);
     }
+    RS_PH(5);
+    RS_PH_FLUSH();
     return;
   }
   if (!inside) return;
@@ -860,6 +898,8 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
     }
   }
   if (ca.scaler) composite_pixel<KMAX>(best, K, z0, depth_thres, hit, ca, pix);
+  RS_PH(5);
+  RS_PH_FLUSH();
 }
 
 // points_per_pixel above 32 (the reference allows 150, rasterization_utils.cuh:18): the K-best list of a pixel does
