@@ -538,7 +538,7 @@ def main():
                        "x-slabs of the cloud (per-point stages; halo cells all-gathered) and tile-row bands "
                        "(per-pixel stages; packed rows all-gathered) x%d ranks, RCCL" % world},
             "roofline": {"bound": "mfma",
-                         "kernel": ("k_siren_step_x3<256,8,3,1,false> (fused SIREN SDF+grad Newton step, split-fp16 MFMA)" if x3
+                         "kernel": ("k_siren_step_x3_both<256,8,3,1> (fused SIREN SDF+grad Newton step, split-fp16 MFMA; 96- and 32-point tiles of a list in one launch)" if x3
                                     else "k_siren_step<16> (fused SIREN SDF+grad Newton step, f32 MFMA)"),
                          "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),

@@ -1452,10 +1452,16 @@ __global__ __launch_bounds__(256) void k_splat_backward(
 // discs (29.5 px radius: up to 81 blocks) hold 3.7 flagged blocks and 18 pixels with a gradient each -- the first form
 // spent a wave per point (one pixel per lane, a block per round, a butterfly at the end): ~350 wave instructions for 18
 // useful terms, the kernel was bound by exactly that (54 M VALU instructions per launch = 100 % of the issue rate).
-// Here a lane walks every eighth block row of its point's disc through the row bytes and the flagged blocks through
-// their pixel masks (k_grad_maps) and touches only the pixels that carry a gradient; a lane adds its terms in image
-// order, the eight partial sums meet in a fixed tree -> bit-stable, no atomics, independent of the launch geometry.
+// Here the eight lanes of a point read the row bytes of its disc (k_grad_maps; 4 block rows x 32 blocks per round, the
+// words requested together) and walk its flagged blocks together; of a block's pixels that carry a gradient (pixel
+// masks) lane j takes those on the diagonals (rx + ry) % 8 = j -- a silhouette arc crosses a block along a row, a column
+// or the other diagonal, and dealing out block rows (or blocks) left such an arc to one or two lanes: 100 -> 43 us on
+// the sparse gradient image of cfg 3a but 159 -> 228 us on the denser one of the SIREN cycle.  A lane adds its terms in
+// image order, the eight partial sums meet in a fixed tree -> bit-stable, no atomics, independent of the launch geometry.
 // (one lane per point: 100 -> 64 us, bound by the lane's chain of dependent loads at 2.4 waves per SIMD)
+#ifndef SB_RY
+#define SB_RY 4      // block rows whose flag words are requested together (1 / 2 / 4 / 8 / 16: 56 / 53 / 54 / 59 / 66 us on cfg 3a)
+#endif
 __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     const float* __restrict__ pts, const float* __restrict__ radii, const float* __restrict__ rs,
     const int64_t* __restrict__ first, const int64_t* __restrict__ num, int n_clouds,
@@ -1464,8 +1470,10 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     int rect_mode, float radii_s, const int32_t* __restrict__ heavy,
     const int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
   const int count = *heavy_count;
-  constexpr int LP = 8;                                   // lanes per point: lane j takes the block rows by0 + j, by0 + j + LP, ...
+  constexpr int LP = 8;                                   // lanes per point
   const int j = threadIdx.x & (LP - 1);
+  unsigned long long diag = 0ull;                         // the pixels of an 8x8 block this lane takes: (rx + ry) % 8 = j
+  for (int ry = 0; ry < 8; ++ry) diag |= 1ull << (8 * ry + ((j - ry) & 7));
   // (count rounded up: the lanes of a group leave the loop together, the shuffles below need all of them)
   for (int w = (blockIdx.x * blockDim.x + threadIdx.x) / LP; w < (count + 63) / 64 * 64; w += gridDim.x * blockDim.x / LP) {
     const bool live = w < count;
@@ -1480,29 +1488,47 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     float gx = 0.f, gy = 0.f;
     if (live && out_range(px, sx, F.W, F.ex, F.m, x0, x1) && out_range(py, sy, F.H, F.ey, F.m, y0, y1)) {
       const float* __restrict__ gimg = grad_occ + (int64_t)n * F.H * F.W;
-      const int bx0 = x0 / GB, bx1 = x1 / GB;
-      for (int by = y0 / GB + j; by <= y1 / GB; by += LP) {
-        // rows of the block inside the window, as a mask of whole bytes
-        const int ra = max(y0 - by * GB, 0), rb = min(y1 - by * GB, GB - 1);
-        const unsigned long long rowsel = (rb == 7 ? ~0ull : ((1ull << (8 * (rb + 1))) - 1ull)) & ~((1ull << (8 * ra)) - 1ull);
-        for (int sb = bx0 >> 3; sb <= bx1 >> 3; ++sb) {
-          unsigned flags = rowbytes[((int64_t)n * G.NBy + by) * G.NB2x + sb];
-          const int ka = max(bx0 - sb * 8, 0), kb = min(bx1 - sb * 8, 7);
-          flags &= (0xffu >> (7 - kb)) & (0xffu << ka);
-          while (flags) {
-            const int k = __ffs((int)flags) - 1;
-            flags &= flags - 1;
-            const int bx = sb * 8 + k;
-            // columns of the block inside the window, the same byte in every row
-            const int ca = max(x0 - bx * GB, 0), cb = min(x1 - bx * GB, GB - 1);
-            const unsigned long long colsel = (unsigned long long)((0xffu >> (7 - cb)) & (0xffu << ca)) * 0x0101010101010101ull;
-            unsigned long long m = pixmask[((int64_t)n * G.NBy + by) * G.NBx + bx] & rowsel & colsel;
-            while (m) {
-              const int b = __ffsll((long long)m) - 1;
-              m &= m - 1;
-              const int yo = by * GB + (b >> 3), xo = bx * GB + (b & 7);
-              const float g = gimg[(int64_t)yo * F.W + xo];
-              occ_term(g, ndc_x(F.W - 1 - xo, F) - px, ndc_y(F.H - 1 - yo, F) - py, rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
+      const int bx0 = x0 / GB, bx1 = x1 / GB, by0 = y0 / GB, by1 = y1 / GB;
+      constexpr int RY = SB_RY;                           // block rows per round: their flag words are requested together
+      for (int cx = bx0 >> 3; cx <= bx1 >> 3; cx += 4) {  // 32 blocks (four row bytes = one unaligned word) per round
+        // blocks of the window in this word, and of those the ones on this lane's diagonals
+        const int ka = max(bx0 - cx * 8, 0), kb = min(bx1 - cx * 8, 31);
+        const unsigned colwin = (0xffffffffu >> (31 - kb)) & (0xffffffffu << ka);
+        for (int byc = by0; byc <= by1; byc += RY) {
+          unsigned fl[RY];
+#pragma unroll
+          for (int t = 0; t < RY; ++t) {
+            fl[t] = 0u;
+            if (byc + t <= by1) {
+              const uint8_t* rp = rowbytes + ((int64_t)n * G.NBy + byc + t) * G.NB2x + cx;
+              unsigned wv;
+              __builtin_memcpy(&wv, rp, 4);               // (bytes past the row's end belong to blocks outside the window)
+              fl[t] = wv & colwin;
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < RY; ++t) {
+            const int by = byc + t;
+            unsigned flags = fl[t];
+            if (!flags) continue;
+            // rows of the block inside the window, as a mask of whole bytes
+            const int ra = max(y0 - by * GB, 0), rb = min(y1 - by * GB, GB - 1);
+            const unsigned long long rowsel = (rb == 7 ? ~0ull : ((1ull << (8 * (rb + 1))) - 1ull)) & ~((1ull << (8 * ra)) - 1ull);
+            while (flags) {
+              const int k = __ffs((int)flags) - 1;
+              flags &= flags - 1;
+              const int bx = cx * 8 + k;
+              // columns of the block inside the window, the same byte in every row
+              const int ca = max(x0 - bx * GB, 0), cb = min(x1 - bx * GB, GB - 1);
+              const unsigned long long colsel = (unsigned long long)((0xffu >> (7 - cb)) & (0xffu << ca)) * 0x0101010101010101ull;
+              unsigned long long m = pixmask[((int64_t)n * G.NBy + by) * G.NBx + bx] & rowsel & colsel & diag;
+              while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int yo = by * GB + (b >> 3), xo = bx * GB + (b & 7);
+                const float g = gimg[(int64_t)yo * F.W + xo];
+                occ_term(g, ndc_x(F.W - 1 - xo, F) - px, ndc_y(F.H - 1 - yo, F) - py, rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
+              }
             }
           }
         }

@@ -9,7 +9,8 @@ from iso_points_amd import _lib
 from iso_points_amd.dist import Comm
 from iso_points_amd.sdf_models import SphereSDF
 dev = torch.device("cuda:0")
-cyc = bench.Cycle(dev, SphereSDF().to(dev), Comm(enabled=False))
+model = bench.fitted_siren(dev) if len(sys.argv) > 1 and sys.argv[1] == "siren" else SphereSDF().to(dev)
+cyc = bench.Cycle(dev, model, Comm(enabled=False))
 cyc.cyc.use_graphs = False
 hip = ctypes.CDLL("libamdhip64.so")
 seen = []
@@ -31,6 +32,9 @@ def spy(name, *a):
         rows = (ctypes.c_uint8 * (N * nby * nb2x))()                      # row bytes: one bit per 8x8 block (k_grad_maps)
         hip.hipMemcpy(rows, ctypes.c_void_p(ws + 8 * N * nby * nbx), N * nby * nb2x, 2)
         flagged = sum(bin(b).count("1") for b in rows)
+        pm = (ctypes.c_uint64 * (N * nby * nbx))()
+        hip.hipMemcpy(pm, ctypes.c_void_p(ws), 8 * N * nby * nbx, 2)
+        print("gradient pixels per view:", [sum(bin(x).count("1") for x in pm[v * nby * nbx:(v + 1) * nby * nbx]) for v in range(N)])
         seen.append((P, cnt.value, rs.value, S, flagged / (N * nby * nbx)))
     return rc
 

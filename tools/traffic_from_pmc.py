@@ -21,8 +21,8 @@ def per_kernel(path, counter):
 def main():
     f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     res = {}
-    for name, key in (("k_siren_step_x3<256, 8, 3", "k_siren_step_x3"), ("k_siren_step<", "k_siren_step")):
-        ks = [k for k in f if name in k]
+    for names, key in ((("k_siren_step_x3_both<256, 8, 3", "k_siren_step_x3<256, 8, 3"), "k_siren_step_x3"), (("k_siren_step<",), "k_siren_step")):
+        ks = [k for name in names for k in f if name in k]
         if not ks:
             continue
         k = ks[0]
