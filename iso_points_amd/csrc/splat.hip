@@ -1521,7 +1521,25 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
               // columns of the block inside the window, the same byte in every row
               const int ca = max(x0 - bx * GB, 0), cb = min(x1 - bx * GB, GB - 1);
               const unsigned long long colsel = (unsigned long long)((0xffu >> (7 - cb)) & (0xffu << ca)) * 0x0101010101010101ull;
-              unsigned long long m = pixmask[((int64_t)n * G.NBy + by) * G.NBx + bx] & rowsel & colsel & diag;
+              const unsigned long long win = rowsel & colsel;
+              unsigned long long m = pixmask[((int64_t)n * G.NBy + by) * G.NBx + bx] & win;
+              if (m == win && bx * GB + GB <= F.W && (F.W & 3) == 0) {
+                // every pixel of the window's part of this block carries a gradient (a dense gradient image): lane j
+                // takes pixel row j as two 16-byte loads, no bit scans
+                if (j >= ra && j <= rb) {
+                  const int yo = by * GB + j;
+                  const float4* rowp = reinterpret_cast<const float4*>(gimg + (int64_t)yo * F.W + bx * GB);
+                  const float4 ga = rowp[0], gb = rowp[1];
+                  const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+                  const float dy = ndc_y(F.H - 1 - yo, F) - py;
+#pragma unroll
+                  for (int rxx = 0; rxx < GB; ++rxx)
+                    if (rxx >= ca && rxx <= cb)
+                      occ_term(gv[rxx], ndc_x(F.W - 1 - (bx * GB + rxx), F) - px, dy, rx, ry, sx, sy, r2, rect_mode, radii_s, gx, gy);
+                }
+                continue;
+              }
+              m &= diag;
               while (m) {
                 const int b = __ffsll((long long)m) - 1;
                 m &= m - 1;
