@@ -890,10 +890,12 @@ struct WalkGeo { float qx, qy, qz, mnx, mny, mnz, B; };
 // rings up to the radius as ONE shell: a ring is a chain of two dependent global latencies (brick bounds, records), five
 // rings one after the other were the critical path of the bandwidth tail kernel (150 us in the SIREN cycle for a few
 // thousand stray queries).
+// part / nparts: the trips of a batch of columns are dealt out to nparts waves that walk the same shell (each of them
+// fetches the bounds and forms the prefix sums itself); 0 / 1 = one wave does everything.
 template <class Fetch, class Body, class Bound>
 __device__ __forceinline__ void bk_walk_shell(int rin, int rho, int qbx, int qby, int qbz, int nbx, int nby, int nbz,
                                               const int32_t* __restrict__ off, int lane, const WalkGeo& G,
-                                              Fetch&& fetch, Body&& body, Bound&& bound) {
+                                              Fetch&& fetch, Body&& body, Bound&& bound, int part = 0, int nparts = 1) {
   const int x0 = max(qbx - rho, 0), x1 = min(qbx + rho, nbx - 1);
   const int y0 = max(qby - rho, 0), y1 = min(qby + rho, nby - 1);
   if (x0 > x1 || y0 > y1) return;
@@ -932,7 +934,7 @@ __device__ __forceinline__ void bk_walk_shell(int rin, int rho, int qbx, int qby
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
     const int ex = inc - len, total = __shfl(inc, 63);
     constexpr int NU = BK_WALK_ITEMS;                        // items per lane and trip: their loads overlap
-    for (int j0 = 0; j0 < total; j0 += 64 * NU) {
+    for (int j0 = part * 64 * NU; j0 < total; j0 += nparts * 64 * NU) {
       int at[NU];
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -961,8 +963,8 @@ __device__ __forceinline__ void bk_walk_shell(int rin, int rho, int qbx, int qby
 template <class Fetch, class Body, class Bound>
 __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz, int nbx, int nby, int nbz,
                                              const int32_t* __restrict__ off, int lane, const WalkGeo& G,
-                                             Fetch&& fetch, Body&& body, Bound&& bound) {
-  bk_walk_shell(rho - 1, rho, qbx, qby, qbz, nbx, nby, nbz, off, lane, G, fetch, body, bound);
+                                             Fetch&& fetch, Body&& body, Bound&& bound, int part = 0, int nparts = 1) {
+  bk_walk_shell(rho - 1, rho, qbx, qby, qbz, nbx, nby, nbz, off, lane, G, fetch, body, bound, part, nparts);
 }
 
 template <int KMAX>
@@ -1301,16 +1303,27 @@ __device__ __forceinline__ void wave_merge_f7(const TopF<7>& best, float* out7) 
   }
 }
 
-__global__ __launch_bounds__(64) void k_brick_h_tail(
+// One WORKGROUP of four waves per uncertified (query, view): a stray point of the SIREN level set finds nothing nearby and
+// scans the whole shell of bricks up to the radius -- ~10 k records, a chain of ~20 batches of loads for one wave, and the
+// longest such chain is what the launch takes (120 us in the SIREN cycle however many workgroups share the few thousand
+// entries).  The four waves deal the batches out among themselves and pool their seven smallest distances through LDS at
+// the ring ends.
+#ifndef BK_TAIL_WAVES
+#define BK_TAIL_WAVES 4
+#endif
+constexpr int kTailWaves = BK_TAIL_WAVES;      // (<= 9: the pooled selection runs in one wave)
+__global__ __launch_bounds__(64 * kTailWaves) void k_brick_h_tail(
     const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off, const float4* __restrict__ rec0,
     const float4* __restrict__ rec1, const float* __restrict__ pts, const int32_t* __restrict__ mask,
     const int32_t* __restrict__ view_total, int n_views, float* __restrict__ h_out,
     const int32_t* __restrict__ tail, const int32_t* __restrict__ counters) {
+  __shared__ float s_m7[2][kTailWaves][8];
   const BrickHdr h = *hp;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int count = counters[3];
   const float B = 4.0f * h.f;
   const int rho_max = max(h.nb[0], max(h.nb[1], h.nb[2]));
+  int pool_buf = 0;
   for (int w = blockIdx.x; w < count; w += gridDim.x) {
     const int row = tail[w] >> 3, v = tail[w] & 7;
     if (v >= n_views || !((mask[row] >> v) & 1)) continue;           // (a whole overflowing brick was queued)
@@ -1330,6 +1343,22 @@ __global__ __launch_bounds__(64) void k_brick_h_tail(
       for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
       return fminf(h.r2, fminf(m, kth_seen));
     };
+    // the seven smallest distances of the workgroup: every wave's seven through LDS, then one more selection
+    auto pool = [&]() {
+      wave_merge_f7(best, m7);
+      if (lane < 7) {
+        float mine = m7[0];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) mine = lane == k ? m7[k] : mine;
+        s_m7[pool_buf][wave][lane] = mine;
+      }
+      __syncthreads();
+      TopF<7> all;
+      all.init();
+      if (lane < 7 * kTailWaves) all.push(s_m7[pool_buf][lane / 7][lane % 7]);
+      wave_merge_f7(all, m7);
+      pool_buf ^= 1;                                        // (the next pool writes the other buffer: no second barrier)
+    };
     auto fetch = [&](int i) { float4 c = rec0[i]; c.w = rec1[i].w; return c; };          // position + view mask
     auto visit = [&](int, const float4& c) {
       if (!((__float_as_int(c.w) >> v) & 1)) return;
@@ -1341,18 +1370,19 @@ __global__ __launch_bounds__(64) void k_brick_h_tail(
     int rho_r = 1;                                          // first ring whose guarantee rho * B covers the radius
     while (rho_r < rho_max && (float)rho_r * B * 0.999f < h.r) ++rho_r;
     for (int rho = 0; rho <= min(1, rho_max); ++rho) {
-      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, fetch, visit, far2);
+      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, fetch, visit, far2, wave, kTailWaves);
       if (rho >= 1) {
         const float gg = (float)rho * B * 0.999f;
         if (gg >= h.r) { rho_r = 1; break; }
-        wave_merge_f7(best, m7);
+        pool();
         kth_seen = fminf(kth_seen, m7[6]);
         if (m7[6] < FLT_MAX && m7[6] <= gg * gg) { rho_r = 1; break; }
       }
     }
-    if (rho_r > 1) bk_walk_shell(1, rho_r, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, fetch, visit, far2);
-    wave_merge_f7(best, m7);
-    if (lane == 0) {
+    if (rho_r > 1)
+      bk_walk_shell(1, rho_r, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, fetch, visit, far2, wave, kTailWaves);
+    pool();
+    if (threadIdx.x == 0) {
       h_out[(int64_t)v * h.n_own + row] = h_from_list(m7, small_cloud);
       const float need = m7[6] < FLT_MAX ? sqrtf(m7[6]) : h.r;
       if (!small_cloud && (qx - need < h.x_lo || qx + need >= h.x_hi)) atomicAdd(const_cast<int32_t*>(&counters[6]), 1);
@@ -1699,7 +1729,7 @@ extern "C" int iso_splat_h_fused(void* workspace, int64_t n_max, const float* po
   else if (n_views <= 4) ISO_H(4);
   else ISO_H(8);
 #undef ISO_H
-  hipLaunchKernelGGL(k_brick_h_tail, dim3(4096), dim3(64), 0, s, w.hdr, w.off, w.rec0, w.rec1, points, mask, view_total,
+  hipLaunchKernelGGL(k_brick_h_tail, dim3(4096), dim3(64 * kTailWaves), 0, s, w.hdr, w.off, w.rec0, w.rec1, points, mask, view_total,
                      n_views, h_out, w.tail, w.counters);
   ISO_CHECK_LAUNCH("iso_splat_h_fused");
   return ISO_OK;
