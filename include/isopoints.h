@@ -469,10 +469,13 @@ int iso_splat_composite(const int32_t* idx, const float* qvalue, const float* oc
  *                           search_radius[n] of grad_occ * d/sdeno(|d|^2,1e-10)
  *                           (visible points; grad>0 pixels outside the splat rect
  *                           skipped), z = sum of grad_zbuf over the slots that list
- *                           the point.  No float atomics: xy sums are lane-private partials
- *                           combined by a fixed butterfly, the z sum is a pixel-major scatter in
- *                           64-bit fixed point (integer atomics, exactly rounded) -> bit-stable.
+ *                           the point.  No float atomics: a point's xy terms are added in image
+ *                           order by eight lanes whose partial sums meet in a fixed tree, the z sum
+ *                           is a pixel-major scatter in 64-bit fixed point (integer atomics, exactly
+ *                           rounded) -> bit-stable.
  *                           total_points = rows of `points` (sizes the heavy-point list).
+ *                           workspace: iso_splat_backward_workspace_bytes, 16-byte aligned (it starts
+ *                           with 64-bit pixel masks of the gradient image).
  * grad_zbuf/idx may be NULL (no z gradient); visible may be NULL (= all).
  * rect_mode = 1 switches the xy support to the slow reference kernel's rectangle
  * |d| <= radii * radii_s (_C._splat_points_occ_backward, rasterize_points.cu:673-760);
