@@ -1024,6 +1024,11 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
 // (kTargetItems, cfg-3a cycle, 1.4 M candidates over 4096 tiles: slices of 1024 / 512 / 256 candidates -- targets 2048 / 3072..5120 /
 // >= 6144 -- raster + merge 288 + 29 / 224 + 37 / 206 + 63 us)
 constexpr int kSlice = 1024, kTargetItems = 4096;
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
                                                      int ty_rows, int n_clouds, int max_slots, int target_items,
                                                      int4* __restrict__ items, int4* __restrict__ heavy,
@@ -1058,7 +1063,8 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
   {
     int mine = 0;
     visit([&](int, int, int c) { mine += c; });
-    if (mine) atomicAdd(&s_slots, mine);
+    mine = wave_sum_i(mine);                              // (a thousand same-address LDS atomics are ~4 us of this single-workgroup kernel)
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_slots, mine);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1072,7 +1078,8 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
     const int sl = s_slice;
     int mine = 0;
     visit([&](int, int, int c) { if (2 * c > 3 * sl) mine += (c + sl - 1) / sl; });
-    if (mine) atomicAdd(&s_slots, mine);
+    mine = wave_sum_i(mine);                              // (a thousand same-address LDS atomics are ~4 us of this single-workgroup kernel)
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_slots, mine);
     __syncthreads();
     const bool fits = s_slots <= max_slots;
     __syncthreads();
