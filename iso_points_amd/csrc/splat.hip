@@ -1530,7 +1530,7 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
               const unsigned long long colsel = (unsigned long long)((0xffu >> (7 - cb)) & (0xffu << ca)) * 0x0101010101010101ull;
               const unsigned long long win = rowsel & colsel;
               unsigned long long m = pixmask[((int64_t)n * G.NBy + by) * G.NBx + bx] & win;
-              if (m == win && bx * GB + GB <= F.W && (F.W & 3) == 0) {
+              if (m == win && bx * GB + GB <= F.W && (F.W & 3) == 0 && (((uintptr_t)gimg) & 15) == 0) {
                 // every pixel of the window's part of this block carries a gradient (a dense gradient image): lane j
                 // takes pixel row j as two 16-byte loads, no bit scans
                 if (j >= ra && j <= rb) {
