@@ -117,3 +117,36 @@ def test_median_in_pieces_over_two_ranks_equals_torch_median(dev, seed):
         rows = radii[int(first[n]):int(first[n]) + lens[n]][vis[int(first[n]):int(first[n]) + lens[n]].bool()]
         ref = rows.reshape(-1).median().item() * 10.0 if rows.numel() else 0.0
         assert out[n].item() == pytest.approx(ref, rel=0, abs=0) or abs(out[n].item() - ref) <= 1e-7 * max(ref, 1e-30)
+
+
+@pytest.mark.parametrize("S,density", [(40, "sparse"), (40, "dense"), (50, "dense"), (64, "ring"), (37, "sparse")])
+def test_occupancy_backward_over_gradient_densities(dev, S, density):
+    """The heavy-point kernel walks pixel masks of the gradient image (eight lanes per point, a row path for blocks that are
+    fully covered, a bit-scan path otherwise): sparse / dense / ring-shaped gradient images, sides that are and are not
+    multiples of 8 and of 4, two clouds, both supports (disc = rasterize_points_backward.cu:156, rectangle =
+    rasterize_points.cu:726-746) against the oracle."""
+    from oracle import splat_oracle as SO
+    from test_splat_gpu import sphere_scene
+    from iso_points_amd.rasterizer import _C
+    from util import rel_err
+    sc = sphere_scene(2500, n_views=2, S=S, seed=91)
+    g = torch.Generator().manual_seed(S)
+    go = torch.randn(2, S, S, generator=g)
+    if density == "sparse":
+        go[torch.rand(2, S, S, generator=g) > 0.02] = 0.0
+    elif density == "ring":
+        ax = (torch.arange(S) + 0.5) / S * 2 - 1
+        rr = (ax[None, :] ** 2 + ax[:, None] ** 2).sqrt()
+        go[:, (rr - 0.6).abs() > 0.04] = 0.0
+    rs = torch.tensor([0.35, 0.2])
+    ref = SO.occ_backward(sc["ndc"], sc["radii"], go, sc["first"], sc["num"], 10.0, rs=rs, mode=2)
+    got = _C._splat_points_occ_fast_cuda_backward(sc["ndc"].to(dev), sc["radii"].to(dev), rs.to(dev), go.to(dev),
+                                                  sc["num"].to(dev), sc["first"].to(dev))
+    assert ref.abs().sum() > 0 and rel_err(got, ref) < 1e-6
+    again = _C._splat_points_occ_fast_cuda_backward(sc["ndc"].to(dev), sc["radii"].to(dev), rs.to(dev), go.to(dev),
+                                                    sc["num"].to(dev), sc["first"].to(dev))
+    assert torch.equal(got, again)                                    # bit-stable from run to run
+    ref_r = SO.occ_backward(sc["ndc"], sc["radii"], go, sc["first"], sc["num"], 6.0, mode=1)
+    got_r = _C._splat_points_occ_backward(sc["ndc"].to(dev), sc["radii"].to(dev), go.to(dev), sc["first"].to(dev),
+                                          sc["num"].to(dev), 6.0, 0.05)
+    assert rel_err(got_r, ref_r) < 1e-6
