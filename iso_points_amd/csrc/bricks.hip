@@ -649,6 +649,9 @@ __device__ __forceinline__ void walk_candidates(const BrickStage<WITH_NRM, 1, CA
 // SUB = 2: the NW x NW x NW window of half cells whose first cell is (wx, wy, wz) = NW^2 contiguous slot ranges of NW
 // half cells each (NW = 4: the query's own window; NW = 6: the 3 x 3 x 3 fine cells around its cell); same
 // two-candidates-per-trip protocol.
+#ifndef BK_RESAMPLE_FLAT
+#define BK_RESAMPLE_FLAT 1
+#endif
 template <int NW, bool WITH_NRM, class Body>
 __device__ __forceinline__ void walk_window(const BrickStage<WITH_NRM, 2>& S, int wx, int wy, int wz, Body&& body) {
   constexpr int NL = BrickStage<WITH_NRM, 2>::NL;
@@ -662,9 +665,36 @@ __device__ __forceinline__ void walk_window(const BrickStage<WITH_NRM, 2>& S, in
       const int i1 = two ? i + 1 : i;
       const float4 c0 = S.rec0[i];
       const float4 c1 = S.rec0[i1];
-      body(c0, i, c1, i1, two);
+      body(c0, i, c1, i1, true, two);
     }
     a = na; e = ne;
+  }
+}
+
+// The same window as ONE loop per lane (see walk_candidates): a wave pays the longest total of its lanes' NW^2 ranges
+// instead of the longest range NW^2 times.  body(c0, i0, c1, i1, v0, v1): v0 / v1 say which of the two records exist.
+template <int NW, bool WITH_NRM, class Body>
+__device__ __forceinline__ void walk_window_flat(const BrickStage<WITH_NRM, 2>& S, int wx, int wy, int wz, Body&& body) {
+  constexpr int NL = BrickStage<WITH_NRM, 2>::NL;
+  int cell = (wx * NL + wy) * NL + wz;                              // range c: cell + (c / NW) NL^2 + (c % NW) NL, NW half cells
+  int i = S.cstart[cell], e = S.cstart[cell + NW];
+  cell += NL;
+  int ni = S.cstart[cell], ne = S.cstart[cell + NW];                // range 1
+  int run = 0, m = 1;                                               // m = (index of the prefetched range) % NW
+  while (run < NW * NW) {
+    const bool v0 = i < e, v1 = i + 1 < e;
+    const int i0 = v0 ? i : 0, i1 = v1 ? i + 1 : i0;
+    const float4 c0 = S.rec0[i0];
+    const float4 c1 = S.rec0[i1];
+    body(c0, i0, c1, i1, v0, v1);
+    i += 2;
+    if (i >= e) {
+      ++run;
+      i = ni; e = ne;
+      m = m == NW - 1 ? 0 : m + 1;
+      cell += m == 0 ? NL * NL - (NW - 1) * NL : NL;
+      if (run < NW * NW - 1) { ni = S.cstart[cell]; ne = S.cstart[cell + NW]; }
+    }
   }
 }
 
@@ -769,11 +799,11 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
       unsigned key[ML];
 #pragma unroll
       for (int j = 0; j < ML; ++j) key[j] = 0xffffffffu;
-      auto visit = [&](const float4& c0, int i0, const float4& c1, int i1, bool two) {
+      auto visit = [&](const float4& c0, int i0, const float4& c1, int i1, bool v0, bool v1) {
         const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
         const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
-        const unsigned ka = (__float_as_uint(da) & ~1023u) | (unsigned)i0;
-        const unsigned kb = two ? ((__float_as_uint(db) & ~1023u) | (unsigned)i1) : 0xffffffffu;
+        const unsigned ka = v0 ? ((__float_as_uint(da) & ~1023u) | (unsigned)i0) : 0xffffffffu;
+        const unsigned kb = v1 ? ((__float_as_uint(db) & ~1023u) | (unsigned)i1) : 0xffffffffu;
 #pragma unroll
         for (int j = ML - 1; j >= 1; --j) key[j] = bk_med3u(key[j - 1], ka, key[j]);
         key[0] = min(key[0], ka);
@@ -782,6 +812,7 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
         key[0] = min(key[0], kb);
       };
       if (WIDE) walk_window<6>(S, wx, wy, wz, visit);
+      else if (BK_RESAMPLE_FLAT) walk_window_flat<4>(S, wx, wy, wz, visit);
       else walk_window<4>(S, wx, wy, wz, visit);
       // exact (d2, id) order of the survivors
       float d[ML];
