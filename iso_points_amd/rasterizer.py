@@ -623,9 +623,11 @@ class SurfaceSplatting(object):
                 cols["features"].append(_f32c(wide_ff)[src])
             elif fr["features"] is not None:
                 cols["features"].append(fr["features"][:jt])
-            P_j = pts.shape[0]
-            cols["h"].append(fr["h"].view(-1)[(torch.arange(nv, device=dev).repeat_interleave(torch.tensor(jl, device=dev))
-                                               * P_j + src)])
+            # the bandwidth of every packed row: view v's rows are a slice (lengths known on the host), gathered view by
+            # view (torch.repeat_interleave over 2 M rows was 0.2 ms of the operator-API cycle)
+            jf0 = [sum(jl[:i]) for i in range(nv)]
+            cols["h"].append(torch.cat([fr["h"][v][src[jf0[v]:jf0[v] + jl[v]]] for v in range(nv)]) if nv > 1
+                             else fr["h"][0][src])
             v_at += nv
         cat = {k: (torch.cat(v, dim=0) if len(v) > 1 else v[0]) if v else None for k, v in cols.items()}
         info = {k: cat[k] for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler")}
