@@ -542,7 +542,8 @@ def main():
                                       "untimed (dist.slab_order); `generator_order` below is the same cycle without it",
                        "parallelism": "1 rank" if world == 1 else
                        "x-slabs of the cloud (per-point stages; halo cells all-gathered) and tile-row bands "
-                       "(per-pixel stages; packed rows all-gathered) x%d ranks, RCCL" % world},
+                       "(per-pixel stages; each packed row sent to the bands it touches by ONE band all-to-all, its z sums "
+                       "and visible flags returned by the reverse all-to-all) x%d ranks, RCCL" % world},
             "roofline": {"bound": "mfma",
                          "kernel": ("k_siren_step_x3_both<256,8,3,1> (fused SIREN SDF+grad Newton step, split-fp16 MFMA; 96- and 32-point tiles of a list in one launch)" if x3
                                     else "k_siren_step<16> (fused SIREN SDF+grad Newton step, f32 MFMA)"),

@@ -237,34 +237,38 @@ def gen_resample(L, m_fit):
 def main():
     install_shims()
     L = load_reference_levelset()
-    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "levelset"):
+    only = [x for x in os.environ.get("ISO_GOLDEN_ONLY", "").split(",") if x]      # parts to regenerate (all if empty)
+
+    def want(part):
+        return not only or part in only
+    if want("levelset"):
         m_fit = gen_projection(L)
         gen_resample(L, m_fit)
-    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "pp"):
+    if want("pp"):
         from make_golden_pp import gen_pp
         gen_pp(L)
-    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "idr"):
+    if want("idr"):
         from make_golden_pp import gen_idr
         gen_idr(L)
-    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "siren_ref"):
+    if want("siren_ref"):
         from make_golden_pp import gen_siren_ref
         gen_siren_ref(L)
-    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "trace"):
+    if want("trace"):
         from make_golden_trace import gen_trace
         gen_trace(L)
-    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "raytrace"):
+    if want("raytrace"):
         from make_golden_raytrace import gen_raytrace
         gen_raytrace(L)
-    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "image"):
+    if want("image"):
         from make_golden_image import gen_image
         gen_image(L)
-    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "sample"):
+    if want("sample"):
         from make_golden_sample import gen_sample
         gen_sample(L)
-    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "ear"):
+    if want("ear"):
         from make_golden_ear import gen_ear
         gen_ear(L)
-    if os.environ.get("ISO_GOLDEN_ONLY", "") in ("", "splat"):
+    if want("splat"):
         from make_golden_splat import gen_splat
         gen_splat()
 

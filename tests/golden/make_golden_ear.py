@@ -3,6 +3,14 @@ EdgeAwareProjection._create_tree / .denoise_normals / .upsample
 (DSS/models/levelset_sampling.py:442-661) through make_golden.py's shims, with the oracle's
 brute-force K-nearest search standing in for pytorch3d.knn_points (absent third-party code).
 usage:  ISO_GOLDEN_ONLY=ear python tests/golden/make_golden.py"""
+import os as _os
+import sys as _sys
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+for _p in (_HERE, _os.path.dirname(_os.path.dirname(_HERE))):      # make_golden.py and the repo root (oracle/)
+    if _p not in _sys.path:
+        _sys.path.insert(0, _p)
+
 from collections import namedtuple
 
 import torch
@@ -54,3 +62,8 @@ def gen_ear(L):
     out = L.EdgeAwareProjection(**kw).project_points(far.clone(), sph)
     npz("ear_driver.npz", points=far, levelset_points=out["levelset_points"], levelset_normals=out["levelset_normals"],
         mask=out["mask"], **{"kw_" + k: v for k, v in kw.items()})
+
+if __name__ == "__main__":          # this part alone: python tests/golden/make_golden_ear.py
+    _os.environ["ISO_GOLDEN_ONLY"] = "ear"
+    import make_golden
+    make_golden.main()

@@ -1,6 +1,14 @@
 """Golden vectors for the image look-up, made by the REFERENCE's own
 get_tensor_values (DSS/utils/__init__.py:325-375) imported through make_golden.py's shims.
 usage:  ISO_GOLDEN_ONLY=image python tests/golden/make_golden.py"""
+import os as _os
+import sys as _sys
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+for _p in (_HERE, _os.path.dirname(_os.path.dirname(_HERE))):      # make_golden.py and the repo root (oracle/)
+    if _p not in _sys.path:
+        _sys.path.insert(0, _p)
+
 import sys
 
 import torch
@@ -29,3 +37,8 @@ def gen_image(L):
     out["sq"], out["p_in"] = sq, pin
     out["sq_index"] = U.get_tensor_values(sq, pin.clone(), grid_sample=False)
     npz("image_values.npz", **out)
+
+if __name__ == "__main__":          # this part alone: python tests/golden/make_golden_image.py
+    _os.environ["ISO_GOLDEN_ONLY"] = "image"
+    import make_golden
+    make_golden.main()

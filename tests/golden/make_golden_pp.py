@@ -4,6 +4,14 @@ DSS/models/levelset_sampling.py:172-233) on small synthetic clouds.
 pytorch3d's Pointclouds / knn_points and torch_cluster.fps are absent third-party code:
 knn_points is shimmed by the oracle's exact brute force, wlop is run with ratio=1.0 (no FPS),
 and the containers by the minimal stand-in below."""
+import os as _os
+import sys as _sys
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+for _p in (_HERE, _os.path.dirname(_os.path.dirname(_HERE))):      # make_golden.py and the repo root (oracle/)
+    if _p not in _sys.path:
+        _sys.path.insert(0, _p)
+
 import os
 import sys
 import types
@@ -191,3 +199,8 @@ def gen_siren_ref(L):
             parts += [lin.weight.detach().reshape(-1), lin.bias.detach().reshape(-1)]
         npz(name, points=x, sdf=sdf, grad=grad, hidden=H, n_layers=NL, raw=torch.cat(parts), T=4,
             fixed_points=res.points, fixed_normals=res.normals)
+
+if __name__ == "__main__":          # this part alone: python tests/golden/make_golden_pp.py
+    _os.environ["ISO_GOLDEN_ONLY"] = "pp,idr,siren_ref"
+    import make_golden
+    make_golden.main()

@@ -3,6 +3,14 @@ RayTracing.forward (DSS/models/levelset_sampling.py:810-1167) imported through m
 shims.  The reference hard-codes `.cuda()` on every temporary; this image has no GPU, so
 Tensor.cuda is the identity while the fixtures are made (a run-time shim, no source edit).
 usage:  ISO_GOLDEN_ONLY=raytrace python tests/golden/make_golden.py"""
+import os as _os
+import sys as _sys
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+for _p in (_HERE, _os.path.dirname(_os.path.dirname(_HERE))):      # make_golden.py and the repo root (oracle/)
+    if _p not in _sys.path:
+        _sys.path.insert(0, _p)
+
 import torch
 
 from oracle import iso_oracle as O
@@ -71,3 +79,8 @@ def gen_raytrace(L):
         npz("raytrace_siren.npz", **out)
     finally:
         torch.Tensor.cuda = real_cuda
+
+if __name__ == "__main__":          # this part alone: python tests/golden/make_golden_raytrace.py
+    _os.environ["ISO_GOLDEN_ONLY"] = "raytrace"
+    import make_golden
+    make_golden.main()

@@ -4,6 +4,14 @@ REFERENCE's own SampleNetwork.forward / DirectionalSamplingNetwork.forward
 sampled points (= the input, numerically) and the gradient of a fixed linear functional of them
 w.r.t. a few of the network's parameters (the only thing these layers exist for).
 usage:  ISO_GOLDEN_ONLY=sample python tests/golden/make_golden.py"""
+import os as _os
+import sys as _sys
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+for _p in (_HERE, _os.path.dirname(_os.path.dirname(_HERE))):      # make_golden.py and the repo root (oracle/)
+    if _p not in _sys.path:
+        _sys.path.insert(0, _p)
+
 import os
 
 import numpy as np
@@ -42,3 +50,8 @@ def gen_sample(L):
     g_dn = selected_grads(net, (out_d * w).sum())
     npz("sample_network.npz", points=pts, w=w, cam=cam, ray=ray, sn_points=out, sn_eval=ev, sn_grads=g_sn,
         dn_points=out_d, dn_eval=ev_d, dn_grads=g_dn)
+
+if __name__ == "__main__":          # this part alone: python tests/golden/make_golden_sample.py
+    _os.environ["ISO_GOLDEN_ONLY"] = "sample"
+    import make_golden
+    make_golden.main()

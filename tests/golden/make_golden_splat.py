@@ -2,6 +2,14 @@
 (SurfaceSplatting._get_per_point_info and the methods it calls, DSS/core/rasterizer.py:344-563)
 on a synthetic scene and store inputs + outputs.  Cameras / point-cloud containers are
 out-of-scope pytorch3d classes; minimal stand-ins give the methods the accessors they use."""
+import os as _os
+import sys as _sys
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+for _p in (_HERE, _os.path.dirname(_os.path.dirname(_HERE))):      # make_golden.py and the repo root (oracle/)
+    if _p not in _sys.path:
+        _sys.path.insert(0, _p)
+
 import os
 import sys
 import types
@@ -102,3 +110,8 @@ def gen_splat():
     scal = torch.rand(50, generator=g)
     out = gather_with_neg_idx(scal, 0, idx.view(-1).long().clone()).view(idx.shape)
     npz("gather_neg_idx.npz", scaler=scal, idx=idx, out=out)
+
+if __name__ == "__main__":          # this part alone: python tests/golden/make_golden_splat.py
+    _os.environ["ISO_GOLDEN_ONLY"] = "splat"
+    import make_golden
+    make_golden.main()

@@ -2,6 +2,14 @@
 SphereTracing.project_points and find_zero_crossing_between_point_pairs
 (DSS/models/levelset_sampling.py:663-808, :1210-1367) imported through make_golden.py's shims.
 usage:  ISO_GOLDEN_ONLY=trace python tests/golden/make_golden.py"""
+import os as _os
+import sys as _sys
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+for _p in (_HERE, _os.path.dirname(_os.path.dirname(_HERE))):      # make_golden.py and the repo root (oracle/)
+    if _p not in _sys.path:
+        _sys.path.insert(0, _p)
+
 import torch
 
 from oracle import iso_oracle as O
@@ -62,3 +70,8 @@ def gen_trace(L):
     npz("trace_idr.npz", ray0=r0, dirs=d, T=12, out_points=out["levelset_points"],
         out_eval=out["network_eval_on_levelset_points"], out_mask=out["mask"], idr_raw=idr.raw_weights(),
         idr_hidden=128, idr_layers=4, idr_freq=4, idr_skip=2)
+
+if __name__ == "__main__":          # this part alone: python tests/golden/make_golden_trace.py
+    _os.environ["ISO_GOLDEN_ONLY"] = "trace"
+    import make_golden
+    make_golden.main()

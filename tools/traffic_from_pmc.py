@@ -27,10 +27,14 @@ def main():
             continue
         k = ks[0]
         n, fs = f[k]
-        ws = w.get(k, (n, 0.0))[1]
-        res[key] = {"kernel": k, "launches": n, "fetch_kib_sum": fs, "write_kib_sum": ws,
-                    "bytes_per_launch": (2 * fs + ws) * 1024.0 / max(n, 1),
-                    "note": "(2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes, per launch; FETCH_SIZE x2: gfx950 correction"}
+        nw, ws = w.get(k, (n, 0.0))
+        # each pass is divided by ITS OWN launch count (the two PMC passes are separate runs of the command and
+        # need not see the same number of launches: round 3's record divided both by the FETCH pass's count)
+        res[key] = {"kernel": k, "launches_fetch_pass": n, "launches_write_pass": nw, "fetch_kib_sum": fs,
+                    "write_kib_sum": ws,
+                    "bytes_per_launch": (2 * fs / max(n, 1) + ws / max(nw, 1)) * 1024.0,
+                    "note": "(2 * FETCH_SIZE / launches of the FETCH pass + WRITE_SIZE / launches of the WRITE pass) KiB "
+                            "-> bytes; FETCH_SIZE x2: gfx950 correction"}
     json.dump(res, open(sys.argv[3], "w"), indent=1)
 
 
