@@ -646,6 +646,45 @@ __device__ __forceinline__ void walk_candidates(const BrickStage<WITH_NRM, 1, CA
   }
 }
 
+// The same nine ranges NEAREST FIRST, with an early exit: the column of the query's own cell, then the columns on the side
+// of the cell the query lies on (sx, sy = +-1), the far side last.  done() is asked at the end of every range; a lane that
+// is done leaves the loop (the wave pays the longest of its lanes' walks).  The bandwidth kernel's counting pass only has
+// to find SEVEN renderable neighbours within 0.01 per view -- in a dense cloud the first or second column holds them, so
+// most of the ~9 ranges are never read (k_brick_h 163 -> see DESIGN.md 3.2).
+template <bool WITH_NRM, int CAP, class Body, class Done>
+__device__ __forceinline__ void walk_candidates_near_first(const BrickStage<WITH_NRM, 1, CAP>& S, int lx, int ly, int lz,
+                                                           int sx, int sy, Body&& body, Done&& done) {
+  constexpr int NL = BrickStage<WITH_NRM, 1, CAP>::NL;
+  // step k visits column (a_k sx, b_k sy): a = 0 1 0 1 -1 0 -1 1 -1, b = 0 0 1 1 0 -1 1 -1 -1 (stored + 1, two bits each)
+  constexpr unsigned KA = 1u | 2u << 2 | 1u << 4 | 2u << 6 | 0u << 8 | 1u << 10 | 0u << 12 | 2u << 14 | 0u << 16;
+  constexpr unsigned KB = 1u | 1u << 2 | 2u << 4 | 2u << 6 | 1u << 8 | 0u << 10 | 2u << 12 | 0u << 14 | 0u << 16;
+  const int base = (lx * NL + ly) * NL + (lz - 1);
+  const int dxs = sx * NL * NL, dys = sy * NL;
+  auto cell_at = [&](int k) {
+    const int a = (int)((KA >> (2 * k)) & 3u) - 1, b = (int)((KB >> (2 * k)) & 3u) - 1;
+    return base + a * dxs + b * dys;
+  };
+  int i = S.cstart[base], e = S.cstart[base + 3];
+  int c = cell_at(1);
+  int ni = S.cstart[c], ne = S.cstart[c + 3];
+  int run = 0;
+  while (run < 9) {
+    const bool v0 = i < e, v1 = i + 1 < e;
+    const int i0 = v0 ? i : 0, i1 = v1 ? i + 1 : i0;
+    float4 c0 = S.rec0[i0];
+    float4 c1 = S.rec0[i1];
+    asm volatile("" : "+v"(c0.x), "+v"(c0.y), "+v"(c0.z), "+v"(c0.w), "+v"(c1.x), "+v"(c1.y), "+v"(c1.z), "+v"(c1.w));
+    body(c0, c1, v0, v1);
+    i += 2;
+    if (i >= e) {
+      ++run;
+      if (done()) run = 9;
+      i = ni; e = ne;
+      if (run < 8) { c = cell_at(run + 1); ni = S.cstart[c]; ne = S.cstart[c + 3]; }
+    }
+  }
+}
+
 // SUB = 2: the NW x NW x NW window of half cells whose first cell is (wx, wy, wz) = NW^2 contiguous slot ranges of NW
 // half cells each (NW = 4: the query's own window; NW = 6: the 3 x 3 x 3 fine cells around its cell); same
 // two-candidates-per-trip protocol.
@@ -1214,41 +1253,55 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? BK_H_WGS : 4) void k_brick_h(
     for (int t0 = 0; t0 < nq; t0 += BK_THREADS) {
       const int t = t0 + threadIdx.x;
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      int qmask = 0, lx = 1, ly = 1, lz = 1, row = 0;
+      int qmask = 0, lx = 1, ly = 1, lz = 1, row = 0, sx = 1, sy = 1;
       if (t < nq) {
         const int pos = query_slot(S, t);
         q = S.rec0[pos];
         qmask = __float_as_int(q.w);
         if (qmask < 0) qmask = 0;                                    // imported halo point: not a query
         row = S.gid[pos] - h.id_base;
-        lx = bk_fine(q.x, h.mn[0], h.inv_f, h.nf[0]) - g.ox;
-        ly = bk_fine(q.y, h.mn[1], h.inv_f, h.nf[1]) - g.oy;
+        const int fx = bk_fine(q.x, h.mn[0], h.inv_f, h.nf[0]), fy = bk_fine(q.y, h.mn[1], h.inv_f, h.nf[1]);
+        lx = fx - g.ox;
+        ly = fy - g.oy;
         lz = bk_fine(q.z, h.mn[2], h.inv_f, h.nf[2]) - g.oz;
+        // the half of its cell the query lies in (only the ORDER of the walk depends on it)
+        sx = ((q.x - h.mn[0]) * h.inv_f - (float)fx) >= 0.5f ? 1 : -1;
+        sy = ((q.y - h.mn[1]) * h.inv_f - (float)fy) >= 0.5f ? 1 : -1;
       }
-      // pass 1: renderable neighbours within kT per view
+      // pass 1: renderable neighbours within kT per view, counted until every view of the query has seven (cnt[v] is
+      // the full count only where it stays below seven -- all the rest of the kernel asks)
       int cnt[NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) cnt[v] = 0;
       if (VS == 8 && C <= 255) {                                     // (workgroup-uniform) byte counters cannot overflow
         unsigned acc = 0;
+        const unsigned need = ((unsigned)qmask & 0x01010101u) << 7;
         if (qmask)
-          walk_candidates(S, lx, ly, lz, [&](const float4& c0, const float4& c1, bool v0, bool v1) {
+          walk_candidates_near_first(S, lx, ly, lz, sx, sy, [&](const float4& c0, const float4& c1, bool v0, bool v1) {
             const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
             const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
             const unsigned ma = (v0 && da <= t2) ? (__float_as_uint(c0.w) & 0x01010101u) : 0u;
             const unsigned mb = (v1 && db <= t2) ? (__float_as_uint(c1.w) & 0x01010101u) : 0u;
             acc += ma + mb;
+          }, [&]() {      // bit 7 of every byte: that counter is >= 7 (no carry between bytes: 0x7f + 0x79 < 0x100)
+            const unsigned ge7 = (((acc & 0x7f7f7f7fu) + 0x79797979u) | acc) & 0x80808080u;
+            return (ge7 & need) == need;
           });
 #pragma unroll
         for (int v = 0; v < NV; ++v) cnt[v] = (int)((acc >> (8 * (v & 3))) & 0xffu);
       } else if (qmask)
-        walk_candidates(S, lx, ly, lz, [&](const float4& c0, const float4& c1, bool v0, bool v1) {
+        walk_candidates_near_first(S, lx, ly, lz, sx, sy, [&](const float4& c0, const float4& c1, bool v0, bool v1) {
           const float da = bk_d2(q.x, q.y, q.z, c0.x, c0.y, c0.z);
           const float db = bk_d2(q.x, q.y, q.z, c1.x, c1.y, c1.z);
           const int ma = (v0 && da <= t2) ? __float_as_int(c0.w) : 0;
           const int mb = (v1 && db <= t2) ? __float_as_int(c1.w) : 0;
 #pragma unroll
           for (int v = 0; v < NV; ++v) cnt[v] += ((ma >> (VS * v)) & 1) + ((mb >> (VS * v)) & 1);
+        }, [&]() {
+          bool all = true;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) all = all && (!((qmask >> (VS * v)) & 1) || cnt[v] >= 7);
+          return all;
         });
       BK_PH(4);
       bool open_ = false;
