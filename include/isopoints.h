@@ -53,6 +53,31 @@ int iso_project_sphere(const float* pts_in, float* pts_out, float* normals_out,
                        float cz, float radius, int max_iters, float tol,
                        void* stream);
 
+/* What a projection launch does ON THE SIDE for the stages that consume its result in the iso-point cycle, so that they
+ * need no pass of their own over the points it has just written (all pointers device memory):
+ *   - the bounding box of the projected points is added to the PENDING BOX of the brick workspace grid_ws (section E;
+ *     required, initialised).  iso_bricks_build_pending then makes the grid's header from it -- no box pass, no
+ *     launch in between; iso_bricks_box_take returns it as 8 floats (what N ranks all-gather) and clears it.
+ *   - views != NULL: the renderable mask of every point (iso_splat_view_mask's rule; normals = the projection's own
+ *     normals_out) -> mask_out, and the renderable points per 256-point tile and view -> front_ws
+ *     (iso_splat_front_workspace_bytes).  The scan of iso_splat_view_mask_scan (chunk table in front_ws, first_idx_out,
+ *     num_pts_out, view_total_out) is done by iso_bricks_build_pending when it is handed the same struct -- the grid
+ *     it builds carries the mask as payload, so the two always go together in the cycle.
+ * Reference: the consumers are UniformProjection._create_tree (levelset_sampling.py:110-140: bbox of the cloud),
+ * SurfaceSplatting._filter_points_with_invalid_depth / backface culling (rasterizer.py:184-254).          */
+typedef struct iso_follow {
+  void* grid_ws; int64_t grid_n_max;
+  const float* views; int n_views; float znear; float zfar; int backface_culling;
+  int32_t* mask_out; void* front_ws; int64_t front_ws_bytes;
+  int64_t* first_idx_out; int64_t* num_pts_out; int32_t* view_total_out;
+} iso_follow;
+
+/* iso_project_sphere + the side work described by *follow (a HOST struct, read during the call). */
+int iso_project_sphere_follow(const float* pts_in, float* pts_out, float* normals_out,
+                              uint8_t* mask_out, int64_t n, float cx, float cy,
+                              float cz, float radius, int max_iters, float tol,
+                              const iso_follow* follow_host, void* stream);
+
 /* SIREN SDF (DSS/models/common.py:90-165): dims 3 -> H -> (H)*n_hidden -> 1,
  * h0 = sin(w0*(W0 x+b0)), hi = sin(w*(Wi h+bi)), sdf = WL h + bL.
  * Weights are handed over exactly as torch stores them (row-major
@@ -554,6 +579,15 @@ int iso_bricks_workspace_init(void* workspace, int64_t n_max, void* stream);
 int iso_bricks_build_whole(const float* points, const float* normals, const int32_t* payload, int64_t n,
                            float radius, int knn_k, float cell_scale, void* workspace,
                            int64_t workspace_bytes, void* stream);
+/* iso_bricks_build_whole without its box pass: the bounding box of `points` is the workspace's PENDING BOX, left there by
+ * the launch that wrote the points (iso_project_*_follow).  follow_host != NULL with views: the per-tile counts that launch
+ * left in follow_host->front_ws are scanned on the side (one workgroup more in the count launch): front_ws, first_idx_out,
+ * num_pts_out, view_total_out as iso_splat_view_mask_scan leaves them.                                  */
+int iso_bricks_build_pending(const float* points, const float* normals, const int32_t* payload, int64_t n,
+                             float radius, int knn_k, float cell_scale, void* workspace,
+                             int64_t workspace_bytes, const iso_follow* follow_host, void* stream);
+/* the pending box as 8 floats (iso_points_bbox layout), cleared afterwards: N ranks all-gather it for iso_bricks_params */
+int iso_bricks_box_take(void* workspace, int64_t n_max, float* box_out, void* stream);
 int iso_bricks_build(const float* points, const float* normals, const int32_t* payload,
                      int64_t n_own, int64_t id_base, const float* import_rec0,
                      const float* import_rec1, const int32_t* import_count, int64_t import_max,

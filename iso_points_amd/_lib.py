@@ -25,6 +25,7 @@ SIGNATURES = {
     "iso_version": (_c.c_char_p, []),
     "iso_last_error": (_c.c_char_p, []),
     "iso_project_sphere": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "iso_project_sphere_follow": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _P]),
     "iso_siren_raw_floats": (_L, [_I, _I]),
     "iso_siren_packed_floats": (_L, [_I, _I]),
     "iso_siren_set_gemm_mode": (_I, [_I]),
@@ -87,6 +88,8 @@ SIGNATURES = {
     "iso_bricks_workspace_bytes": (_L, [_L]),
     "iso_bricks_workspace_init": (_I, [_P, _L, _P]),
     "iso_bricks_build_whole": (_I, [_P, _P, _P, _L, _F, _I, _F, _P, _L, _P]),
+    "iso_bricks_build_pending": (_I, [_P, _P, _P, _L, _F, _I, _F, _P, _L, _P, _P]),
+    "iso_bricks_box_take": (_I, [_P, _L, _P, _P]),
     "iso_bricks_build": (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _L, _P, _L, _F, _I, _F, _P, _L, _P]),
     "iso_bricks_params": (_I, [_P, _I, _L, _L, _L, _F, _I, _F, _P, _L, _P]),
     "iso_halo_export": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _P, _L, _P]),
@@ -121,6 +124,13 @@ SIGNATURES = {
     "iso_splat_front": (_I, [_P, _P, _P, _I, _I, _P, _P, _L, _P, _P, _I, _I, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P,
                              _P, _P, _P, _P, _P]),
 }
+
+class Follow(ctypes.Structure):
+    """include/isopoints.h: iso_follow -- side work of a projection launch (host struct, read during the call)."""
+    _fields_ = [("grid_ws", _P), ("grid_n_max", _L), ("views", _P), ("n_views", _I), ("znear", _F), ("zfar", _F),
+                ("backface_culling", _I), ("mask_out", _P), ("front_ws", _P), ("front_ws_bytes", _L),
+                ("first_idx_out", _P), ("num_pts_out", _P), ("view_total_out", _P)]
+
 
 _lib = None
 

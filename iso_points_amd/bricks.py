@@ -43,13 +43,25 @@ class BrickGrid(object):
         self._seen = [0] * 16          # counter sums already reported by counters_since_last()
 
     def build(self, points, normals=None, payload=None, bbox=None, n_total=None, radius=-1.0, knn_k=8,
-              cell_scale=None, id_base=0, imports=None, params_done=False):
+              cell_scale=None, id_base=0, imports=None, params_done=False, pending=False, follow=None):
         """points (n_own,3) f32 contiguous; imports = (rec0 (m,4), rec1 (m,4), count int32 (1,)) or None.
-        params_done: the header was already written by iso_bricks_params (N ranks)."""
+        params_done: the header was already written by iso_bricks_params (N ranks).
+        pending (one rank, the whole cloud): the bounding box of `points` is the workspace's pending box, left there by
+        the projection launch that wrote them (Follow); follow: that Follow when it also took the renderable mask --
+        the scan of its counts is done on the side."""
         assert points.shape == (self.n_own, 3) and points.dtype == torch.float32 and points.is_contiguous()
         if cell_scale is None:
             cell_scale = RESAMPLE_CELL * knn_k
         p = _lib.ptr
+        if pending:
+            import ctypes
+            assert imports is None and self.import_max == 0 and int(id_base) == 0
+            fs = follow.struct() if (follow is not None and follow.views is not None) else None
+            _lib.call("iso_bricks_build_pending", p(points), p(normals), p(payload), self.n_own, float(radius), int(knn_k),
+                      float(cell_scale), p(self.ws), self.ws_bytes, ctypes.byref(fs) if fs is not None else None,
+                      _lib.stream())
+            self.points = points
+            return self
         whole = (not params_done and bbox is None and imports is None and self.import_max == 0 and int(id_base) == 0
                  and (n_total is None or int(n_total) == self.n_own))
         if whole:                 # one rank, the whole cloud: the build takes the bounding box itself
@@ -78,8 +90,9 @@ class BrickGrid(object):
         """The grid's 16 device-side counters summed over every grid built on this workspace since the previous call
         (current grid + the sticky sums the header writes keep, minus what was reported before)."""
         c = self.ws[256:384].cpu().view(torch.int32).tolist()
-        tot = [c[i] + c[16 + i] for i in range(16)]
-        out = [tot[i] - self._seen[i] for i in range(16)]
+        # the device sums are int32 and wrap (slot 0 adds ~1e5 occupied bricks per grid): differences modulo 2^32
+        tot = [(c[i] + c[16 + i]) & 0xffffffff for i in range(16)]
+        out = [(tot[i] - self._seen[i]) & 0xffffffff for i in range(16)]
         self._seen = tot
         return out
 
@@ -91,6 +104,51 @@ class BrickGrid(object):
         return {"f": f[8], "r": f[9], "inv_sigma": f[12], "diag": f[13], "nb": i[16:19], "n_bricks": i[19],
                 "n": i[23], "n_own": i[24], "id_base": i[25], "g_covers_r": i[26], "occupied": c[0],
                 "tail": c[1], "overflow_bricks": c[2], "tail_h": c[3]}
+
+
+class Follow(object):
+    """What a projection launch does on the side for the stages that consume its points (include/isopoints.h:
+    iso_follow): the bounding box of the result goes to the PENDING BOX of `grid`'s workspace -- the grid is then built
+    with grid.build(..., pending=True[, follow=this]) without a box pass -- and, with `views`, the renderable mask and
+    the per-tile counts whose scan that build does on the side (`mask`, `total`, `scanned`: as view_mask_scan returns
+    them, valid after the build).  Holds the tensors the calls write; `struct()` is the ctypes argument."""
+
+    def __init__(self, grid, n, views=None, znear=1.0, zfar=100.0, backface_culling=True):
+        dev = grid.ws.device
+        self.grid, self.n = grid, int(n)
+        self.done = False          # set by the projection: True when its route did the side work
+        self.views = None
+        self.mask = self.total = self.scanned = None
+        self.znear, self.zfar, self.backface = float(znear), float(zfar), bool(backface_culling)
+        if views is not None:
+            nv = views.shape[0]
+            self.views = views.detach().float().contiguous()
+            self.mask = torch.empty((self.n,), dtype=torch.int32, device=dev)
+            ws = torch.empty((_lib.load().iso_splat_front_workspace_bytes(self.n),), dtype=torch.uint8, device=dev)
+            first = torch.empty((nv,), dtype=torch.int64, device=dev)
+            num = torch.empty((nv,), dtype=torch.int64, device=dev)
+            self.total = torch.empty((8,), dtype=torch.int32, device=dev)
+            self.scanned = (ws, first, num, self.total)
+
+    def struct(self):
+        p = lambda t: (t.data_ptr() if t is not None else None)          # noqa: E731
+        f = _lib.Follow()
+        f.grid_ws, f.grid_n_max = p(self.grid.ws), self.grid.n_max
+        f.views = p(self.views)
+        f.n_views = self.views.shape[0] if self.views is not None else 0
+        f.znear, f.zfar, f.backface_culling = self.znear, self.zfar, int(self.backface)
+        if self.views is not None:
+            ws, first, num, total = self.scanned
+            f.mask_out, f.front_ws, f.front_ws_bytes = p(self.mask), p(ws), ws.numel()
+            f.first_idx_out, f.num_pts_out, f.view_total_out = p(first), p(num), p(total)
+        return f
+
+
+def box_take(grid):
+    """The pending box of the grid's workspace as (8,) f32 [min xyz, 0, max xyz, 0]; cleared."""
+    mm = torch.empty((8,), dtype=torch.float32, device=grid.ws.device)
+    _lib.call("iso_bricks_box_take", _lib.ptr(grid.ws), grid.n_max, _lib.ptr(mm), _lib.stream())
+    return mm
 
 
 def resample_fused(grid, k_plus_one, want_idx=False):

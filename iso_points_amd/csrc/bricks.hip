@@ -25,6 +25,7 @@
 #pragma clang fp contract(off)
 
 // ------------------------------------------------------------------------------------------------
+constexpr int kScan1MaxWords = 2048;        // = kScan1Max (k_brick_offsets1): chunk totals the one-launch scan keeps zeroed
 BrickWs bricks_carve(void* ws, int64_t n_max) {
   BrickWs w;
   if (n_max < 1) n_max = 1;
@@ -34,7 +35,7 @@ BrickWs bricks_carve(void* ws, int64_t n_max) {
   char* p = (char*)ws;
   int64_t o = 0;
   w.hdr = (BrickHdr*)(p + o); o += al(sizeof(BrickHdr));
-  w.counters = (int32_t*)(p + o); o += al(64);
+  w.counters = (int32_t*)(p + o); o += al(4 * kCounterInts);
   w.cnt = (int32_t*)(p + o); o += al(4 * w.G);
   w.off = (int32_t*)(p + o); o += al(4 * w.G);
   w.slot = (int32_t*)(p + o); o += al(4 * n_max);
@@ -42,7 +43,7 @@ BrickWs bricks_carve(void* ws, int64_t n_max) {
   w.rec1 = (float4*)(p + o); o += al(16 * n_max);
   w.list = (int32_t*)(p + o); o += al(4 * (w.G < n_max ? w.G : n_max));
   w.tail = (int32_t*)(p + o); o += al(4 * 8 * n_max);
-  w.scan_ws_bytes = iso_prefix_sum_workspace_bytes(w.G, 1);
+  w.scan_ws_bytes = iso_prefix_sum_workspace_bytes(w.G, 1) + 4 * (kScan1MaxWords + (w.G + 2047) / 2048);
   w.scan_ws = (void*)(p + o); o += al(w.scan_ws_bytes);
   w.bytes = o;
   return w;
@@ -62,74 +63,7 @@ __device__ __forceinline__ int wave_incl_scan_i(int v) {
 
 // ---- header ------------------------------------------------------------------------------------
 // bbox: [min xyz, 0, max xyz, 0] (iso_points_bbox layout; for N ranks the caller reduces it first)
-// Counter block of the workspace (64 ints): [0..15] the grid's counters (BrickWs::counters; reset by every header
-// write), [16..31] their sums over all earlier grids on this workspace ("sticky": a header write adds the counters it
-// is about to reset, so that overflows / uncertified queries of a whole cycle -- several grids -- can be read once,
-// afterwards, without an accumulation pass per grid), [32..37] bounding-box accumulators of iso_bricks_build_whole
-// (order-preserving keys, min as max of the complement: all-zero = empty), [38] the init mark.
-constexpr int kStickyAt = 16, kBoxAt = 32, kMagicAt = 38;
-constexpr int kBrickMagic = 0x1b71c5;
-
-__device__ __forceinline__ unsigned bk_f2key(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float bk_key2f(unsigned k) {
-  const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-  return __uint_as_float(u);
-}
-
-// header for the box [mn, mn + ext] (one thread)
-__device__ void bricks_write_header(const float* mn_in, const float* mx_in, int64_t n_total, int64_t n_own, int64_t id_base,
-                                    float radius, int knn_k, float cell_scale, int nb_cap, BrickHdr* __restrict__ h,
-                                    int32_t* __restrict__ counters) {
-  float mn[3], ext[3];
-  for (int a = 0; a < 3; ++a) {
-    mn[a] = mn_in[a]; ext[a] = mx_in[a] - mn_in[a]; if (!(ext[a] >= 0.f)) ext[a] = 0.f;
-  }
-  const float diag = sqrtf((ext[0] * ext[0] + ext[1] * ext[1]) + ext[2] * ext[2]);
-  const float np = (float)(n_total > 0 ? n_total : 1);
-  const float spacing = sqrtf(diag / np);
-  const float r = radius > 0.f ? radius : spacing * (float)knn_k;      // levelset_sampling.py:129-131
-  float f = cell_scale * spacing;
-  if (r > 0.f && f > r * 1.002f) f = r * 1.002f;                        // g = 0.999 f >= r: nothing to gain beyond
-  const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
-  const float fmin = emax / (4.0f * (float)(nb_cap - 1)) * 1.0001f;
-  if (f < fmin) f = fmin;
-  if (!(f > 1e-20f)) f = 1.0f;                                          // degenerate cloud: one brick
-  const float inv_f = 1.0f / f;
-  int nb[3];
-  for (int a = 0; a < 3; ++a) {
-    int nf = (int)floorf(ext[a] * inv_f) + 1;
-    nb[a] = (nf + 3) / 4;
-    if (nb[a] > nb_cap) nb[a] = nb_cap;
-    if (nb[a] < 1) nb[a] = 1;
-    h->nb[a] = nb[a];
-    h->nf[a] = 4 * nb[a];
-    h->mn[a] = mn[a];
-  }
-  const int nbr = nb[0] * nb[1] * nb[2];
-  h->inv_f = inv_f;
-  h->nbx_f = (float)nb[0]; h->nby_f = (float)nb[1]; h->nbz_f = (float)nb[2];
-  h->total_f = (float)(BK_CPB * nbr + 1);
-  h->f = f; h->r = r; h->r2 = r * r;
-  const float g = 0.999f * f;
-  h->g2 = g * g;
-  h->inv_sigma = np / diag;                                              // levelset_sampling.py:256
-  h->diag = diag; h->spacing = spacing; h->pad0 = 0.f;
-  h->n_bricks = nbr;
-  h->n = (int)n_own;                                                     // + imported, added by k_brick_count_recs
-  h->n_own = (int)n_own; h->id_base = (int)id_base;
-  h->g_covers_r = g >= r ? 1 : 0;
-  h->n_total = (int)n_total;
-  h->x_lo = -FLT_MAX; h->x_hi = FLT_MAX;
-  for (int i = 0; i < 16; ++i) { counters[kStickyAt + i] += counters[i]; counters[i] = 0; }
-}
-
-// ---- header ------------------------------------------------------------------------------------
-// bbox: [min xyz, 0, max xyz, 0] (iso_points_bbox layout; for N ranks the caller reduces it first)
-__global__ void k_bricks_params(const float* __restrict__ bbox, int n_boxes, int64_t n_total, int64_t n_own, int64_t id_base,
-                                float radius, int knn_k, float cell_scale, int nb_cap, BrickHdr* __restrict__ h,
+__global__ void k_bricks_params(const float* __restrict__ bbox, int n_boxes, BrickParams q, BrickHdr* __restrict__ h,
                                 int32_t* __restrict__ counters) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float mn[3], mx[3];
@@ -138,29 +72,15 @@ __global__ void k_bricks_params(const float* __restrict__ bbox, int n_boxes, int
     for (int k = 1; k < n_boxes; ++k) { lo = fminf(lo, bbox[k * 8 + a]); hi = fmaxf(hi, bbox[k * 8 + 4 + a]); }
     mn[a] = lo; mx[a] = hi;
   }
-  bricks_write_header(mn, mx, n_total, n_own, id_base, radius, knn_k, cell_scale, nb_cap, h, counters);
+  bricks_store_header(bricks_header(mn, mx, q), h, counters);
 }
 
-// the cloud's own box (iso_bricks_build_whole): accumulated by k_brick_bbox into the counter block, decoded here,
-// accumulators back to "empty"
-__global__ void k_bricks_params_self(int64_t n_total, int64_t n_own, int64_t id_base, float radius, int knn_k,
-                                     float cell_scale, int nb_cap, BrickHdr* __restrict__ h, int32_t* __restrict__ counters) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  unsigned* acc = reinterpret_cast<unsigned*>(counters) + kBoxAt;
-  float mn[3], mx[3];
-  for (int a = 0; a < 3; ++a) {
-    mn[a] = acc[a] ? bk_key2f(~acc[a]) : 0.f;
-    mx[a] = acc[3 + a] ? bk_key2f(acc[3 + a]) : 0.f;
-    acc[a] = 0u; acc[3 + a] = 0u;
-  }
-  bricks_write_header(mn, mx, n_total, n_own, id_base, radius, knn_k, cell_scale, nb_cap, h, counters);
-}
-
-// bounding box of a packed (n,3) cloud into the counter block: flat float index (consecutive lanes read consecutive
-// dwords; the grid stride is a multiple of 3 floats, so a thread stays on one axis and keeps four loads in flight),
-// registers -> wave shuffles -> LDS -> six atomics per workgroup
+// Bounding box of a packed (n,3) cloud into the workspace's PENDING BOX (bricks.h): flat float index (consecutive lanes
+// read consecutive dwords; the grid stride is a multiple of 3 floats, so a thread stays on one axis and keeps four loads
+// in flight), registers -> wave shuffles -> LDS -> six atomics per workgroup on one of kBoxCopies copies.  The header is
+// made from it by the count pass that follows.
 __global__ __launch_bounds__(256) void k_brick_bbox(const float* __restrict__ p, int64_t n, int32_t* __restrict__ counters) {
-  __shared__ float s_mn[4][3], s_mx[4][3];
+  __shared__ float s_box[4][6];
   const int64_t nfl = n * 3;
   const int64_t stride = (int64_t)gridDim.x * 256;            // a multiple of 3 (launcher)
   const int64_t i_first = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -173,41 +93,31 @@ __global__ __launch_bounds__(256) void k_brick_bbox(const float* __restrict__ p,
   }
   for (; i < nfl; i += stride) { const float v = p[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
   const int ax = (int)(i_first % 3);
+  BkBox box;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { box.lo[c] = ax == c ? lo : FLT_MAX; box.hi[c] = ax == c ? hi : -FLT_MAX; }
+  box.commit(counters, s_box);
+}
+
+// the pending box as 8 floats (iso_points_bbox layout): what N ranks all-gather before iso_bricks_params; cleared
+__global__ __launch_bounds__(256) void k_brick_box_take(int32_t* __restrict__ counters, float* __restrict__ box_out) {
+  __shared__ unsigned s_red[8];
   float mn[3], mx[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { mn[c] = ax == c ? lo : FLT_MAX; mx[c] = ax == c ? hi : -FLT_MAX; }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
-      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
-    }
-  }
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { s_mn[w][a] = mn[a]; s_mx[w][a] = mx[a]; }
-  }
+  bk_box_read(counters, s_red, mn, mx);
   __syncthreads();
-  if (threadIdx.x < 3) {
-    const int a = threadIdx.x;
-    float l = s_mn[0][a], u = s_mx[0][a];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) { l = fminf(l, s_mn[k][a]); u = fmaxf(u, s_mx[k][a]); }
-    unsigned* acc = reinterpret_cast<unsigned*>(counters) + kBoxAt;
-    if (l <= u) {                                             // (a workgroup without a value on this axis: nothing)
-      atomicMax(&acc[a], ~bk_f2key(l));
-      atomicMax(&acc[3 + a], bk_f2key(u));
-    }
+  bk_box_clear(counters);
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < 3; ++c) { box_out[c] = mn[c]; box_out[4 + c] = mx[c]; }
+    box_out[3] = 0.f; box_out[7] = 0.f;
   }
 }
 
 // zero the whole table once (iso_bricks_workspace_init); afterwards the offsets pass leaves it zeroed
-__global__ void k_bricks_init(int32_t* __restrict__ counters, int32_t* __restrict__ cnt, int64_t G) {
+__global__ void k_bricks_init(int32_t* __restrict__ counters, int32_t* __restrict__ cnt, int64_t G, unsigned* __restrict__ scan_ws) {
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 < kScan1MaxWords) scan_ws[i0] = 0u;
   for (int64_t i = i0; i < G; i += (int64_t)gridDim.x * blockDim.x) cnt[i] = 0;
-  if (i0 < 64) counters[i0] = i0 == kMagicAt ? kBrickMagic : 0;
+  for (int64_t i = i0; i < kCounterInts; i += (int64_t)gridDim.x * blockDim.x) counters[i] = i == kMagicAt ? kBrickMagic : 0;
 }
 
 // F.normalize(n, dim=-1): n / max(|n|, 1e-12) (levelset_sampling.py:258), stored in rec1 in place of the raw normal
@@ -247,7 +157,7 @@ __device__ __forceinline__ void brick_count_round(const BrickHdr& h, int64_t bas
     e[k] = -1; rk[k] = 0;
     if (i < n) {
       float x, y, z;
-      pos(i, x, y, z);
+      pos(i, k, x, y, z);
       const int key = BK_CPB * brick_of(h, x, y, z) + oct;
       unsigned at = ((unsigned)key * 2654435761u) >> 21;          // 11 bits
       bool found = false;
@@ -274,14 +184,46 @@ __device__ __forceinline__ void brick_count_round(const BrickHdr& h, int64_t bas
   __syncthreads();
 }
 
+// pending != 0: the header is not written yet -- it is made HERE from the workspace's pending box, by every workgroup
+// for itself (sixteen 32-byte words from L2 + a few dozen scalar operations; a launch of its own cost 5 us, a "last workgroup
+// writes it" tail in the pass that took the box 7 us); the last workgroup also stores it for the launches that follow and
+// retires the counters of the previous grid.
+// job != null: workgroup 0 of the grid does not count -- it runs the chunk scan of the splat front end beside
+// the others (ChunkScanJob, below).
+struct ChunkScanJob {
+  const int32_t* tile_cnt;   // (n_views, n_tiles) renderable points per 256-point tile (follow.h) -- or null
+  int32_t* chunk;            // (n_views, n_chunks) out: exclusive offsets per 1024-point chunk (k_mask_chunk_scan's table)
+  int n_tiles, n_chunks, n_views;   // n_tiles: row stride of tile_cnt (= 4 n_chunks)
+  int n_real;                       // tiles the cloud really has: ceil(n / 256)
+  int64_t* first; int64_t* num; int32_t* view_total;
+};
+__device__ void chunk_scan_job(const ChunkScanJob& j);
+
 __global__ __launch_bounds__(256) void k_brick_count(const float* __restrict__ pts, int64_t n,
-                                                     const BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
-                                                     int32_t* __restrict__ slot) {
+                                                     BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
+                                                     int32_t* __restrict__ slot, int pending, BrickParams q,
+                                                     int32_t* __restrict__ counters, ChunkScanJob job) {
   __shared__ int t_key[kCntTab], t_cnt[kCntTab];
-  const BrickHdr h = *hp;
-  for (int64_t base = (int64_t)blockIdx.x * 1024; base < n; base += (int64_t)gridDim.x * 1024)
+  __shared__ BrickHdr s_h;
+  const bool scan_wg = job.chunk && blockIdx.x == 0;
+  if (scan_wg && gridDim.x > 1) { chunk_scan_job(job); return; }        // (needs no header; another workgroup stores it)
+  if (pending) {
+    __shared__ unsigned s_red[8];
+    float mn[3], mx[3];
+    bk_box_read(counters, s_red, mn, mx);
+    if (threadIdx.x == 0) {
+      s_h = bricks_header(mn, mx, q);
+      if (blockIdx.x == gridDim.x - 1) bricks_store_header(s_h, hp, counters);
+    }
+    __syncthreads();
+  }
+  if (scan_wg) { chunk_scan_job(job); return; }
+  const BrickHdr h = pending ? s_h : *hp;
+  const int n_wg = job.chunk ? gridDim.x - 1 : gridDim.x;
+  // (the scan job, if any, is workgroup 0: it has the longest chain of dependent steps of the launch and starts first)
+  for (int64_t base = (int64_t)(blockIdx.x - (job.chunk ? 1 : 0)) * 1024; base < n; base += (int64_t)n_wg * 1024)
     brick_count_round(h, base, n, cnt, slot, t_key, t_cnt,
-                      [&](int64_t i, float& x, float& y, float& z) { x = pts[i * 3]; y = pts[i * 3 + 1]; z = pts[i * 3 + 2]; });
+                      [&](int64_t i, int, float& x, float& y, float& z) { x = pts[i * 3]; y = pts[i * 3 + 1]; z = pts[i * 3 + 2]; });
 }
 
 // imported halo records (count on the device); same aggregation
@@ -295,7 +237,7 @@ __global__ __launch_bounds__(256) void k_brick_count_recs(const float4* __restri
   if (blockIdx.x == 0 && threadIdx.x == 0) hp->n = h.n_own + (int)m;
   for (int64_t base = (int64_t)blockIdx.x * 1024; base < m; base += (int64_t)gridDim.x * 1024)
     brick_count_round(h, base, m, cnt, slot + h.n_own, t_key, t_cnt,
-                      [&](int64_t j, float& x, float& y, float& z) { const float4 p = imp0[j]; x = p.x; y = p.y; z = p.z; });
+                      [&](int64_t j, int, float& x, float& y, float& z) { const float4 p = imp0[j]; x = p.x; y = p.y; z = p.z; });
 }
 
 __global__ __launch_bounds__(256) void k_brick_scatter(const float* __restrict__ pts, const float* __restrict__ nrm,
@@ -378,6 +320,7 @@ __global__ __launch_bounds__(256) void k_brick_offsets(const BrickHdr* __restric
   const int len = BK_CPB * nb + 1;
   const int c0 = blockIdx.x * BS_CHUNK;
   if (c0 >= len) return;
+  if (blockIdx.x == 0) bk_box_clear(counters);
   int before = 0;
   for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) before += sums[i];
   int base;
@@ -403,6 +346,115 @@ __global__ __launch_bounds__(256) void k_brick_offsets(const BrickHdr* __restric
     if (i < len) off[i] = ex;
     ex += vals[k];
     if (vals[k] > 0 && i < nb) list[at++] = i;
+  }
+}
+
+// The two passes above as ONE launch for tables of up to kScan1Max chunks (2048 workgroups of this size are resident at
+// once -- 8 per CU --, so a workgroup may wait for the ones before it; BK_NB_MAX bricks per axis are 2001 chunks): a workgroup publishes its chunk total (bit 31 = "there") with an
+// agent-scope store, adds up the totals of the chunks before it as they appear (a few hundred words, polled by 256 lanes),
+// and goes on as k_brick_offsets does.  The workgroup that finishes last clears the totals: `sums` is zero on entry and
+// zero again on exit (iso_bricks_workspace_init clears it once).
+constexpr int kScan1Max = 2048;
+static_assert(kScan1Max == kScan1MaxWords, "bricks_carve sizes the zeroed words");
+__global__ __launch_bounds__(256) void k_brick_offsets1(const BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
+                                                        int32_t* __restrict__ off, unsigned* __restrict__ sums,
+                                                        int32_t* __restrict__ list, int32_t* __restrict__ counters) {
+  __shared__ int lds[4], s_base, s_last;
+  const int nb = hp->n_bricks;
+  const int len = BK_CPB * nb + 1;
+  const int c0 = blockIdx.x * BS_CHUNK;
+  if (c0 >= len) return;
+  if (blockIdx.x == 0) bk_box_clear(counters);      // every reader of the pending box (the count pass) is done
+  const int n_active = (len + BS_CHUNK - 1) / BS_CHUNK;
+  int vals[BS_ITEMS], v = 0, occ = 0;
+#pragma unroll
+  for (int k = 0; k < BS_ITEMS; ++k) {
+    const int i = c0 + threadIdx.x * BS_ITEMS + k;
+    vals[k] = 0;
+    if (i < len) { vals[k] = cnt[i]; cnt[i] = 0; }
+    v += vals[k];
+    occ += (vals[k] > 0 && i < nb) ? 1 : 0;
+  }
+  int tot, occ_tot;
+  int ex = block_excl_scan_256(v, tot, lds);
+  if (threadIdx.x == 0) __hip_atomic_store(&sums[blockIdx.x], 0x80000000u | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int before = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) {
+    unsigned t;
+    while (!((t = __hip_atomic_load(&sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x80000000u)) __builtin_amdgcn_s_sleep(1);
+    before += (int)(t & 0x7fffffffu);
+  }
+  int base;
+  block_excl_scan_256(before, base, lds);                       // base = total of the chunks before this one
+  ex += base;
+  int at = block_excl_scan_256(occ, occ_tot, lds);
+  if (threadIdx.x == 0) s_base = occ_tot ? atomicAdd(&counters[0], occ_tot) : 0;
+  __syncthreads();
+  at += s_base;
+#pragma unroll
+  for (int k = 0; k < BS_ITEMS; ++k) {
+    const int i = c0 + threadIdx.x * BS_ITEMS + k;
+    if (i < len) off[i] = ex;
+    ex += vals[k];
+    if (vals[k] > 0 && i < nb) list[at++] = i;
+  }
+  // everyone has read the totals it needs once it is here; the last one clears them
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* arrive = reinterpret_cast<unsigned*>(counters) + kArriveAt;
+    const unsigned prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == (unsigned)n_active - 1u;
+    if (s_last) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (s_last)
+    for (int i = threadIdx.x; i < n_active; i += 256) __hip_atomic_store(&sums[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The chunk scan of the splat front end (k_mask_chunk_scan in splat.hip: exclusive scan of every view's per-chunk counts,
+// first_idx / num_points as the packed layout of _C.splat_points takes them, view totals) by ONE workgroup of 256 that
+// rides in the count launch of the grid the front end needs anyway.  The counts come per 256-point tile (four tiles per
+// chunk) from the launch that took the mask (follow.h).
+__device__ void chunk_scan_job(const ChunkScanJob& j) {
+  __shared__ int s_tot[8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // a WAVE per view (no workgroup barrier inside the scan): a lane takes four consecutive chunks per step -- sixteen tile
+  // counts, four 16-byte loads, all requested before the first is used -- and the wave scans 256 chunks per step
+  for (int v = w; v < j.n_views; v += 4) {
+    const int32_t* tc = j.tile_cnt + (int64_t)v * j.n_tiles;
+    int32_t* row = j.chunk + (int64_t)v * j.n_chunks;
+    int carry = 0;
+    for (int c0 = 0; c0 < j.n_chunks; c0 += 256) {
+      int val[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = c0 + 4 * lane + q;
+        val[q] = 0;
+        if (i < j.n_chunks) {
+          if (4 * i + 3 < j.n_real) { const int4 c = *reinterpret_cast<const int4*>(tc + 4 * i); val[q] = (c.x + c.y) + (c.z + c.w); }
+          else for (int k = 0; 4 * i + k < j.n_real; ++k) val[q] += tc[4 * i + k];
+        }
+      }
+      const int mine = (val[0] + val[1]) + (val[2] + val[3]);
+      int inc = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+      int ex = carry + inc - mine;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = c0 + 4 * lane + q;
+        if (i < j.n_chunks) row[i] = ex;
+        ex += val[q];
+      }
+      carry += __shfl(inc, 63);
+    }
+    if (lane == 0) s_tot[v] = carry;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int v = 0; v < j.n_views; ++v) { j.first[v] = run; j.num[v] = s_tot[v]; j.view_total[v] = s_tot[v]; run += s_tot[v]; }
+    for (int v = j.n_views; v < 8; ++v) j.view_total[v] = 0;
   }
 }
 
@@ -1588,7 +1640,7 @@ extern "C" int iso_bricks_workspace_init(void* workspace, int64_t n_max, void* s
   ISO_REQUIRE(workspace && n_max >= 0, ISO_ERR_INVALID, "iso_bricks_workspace_init: bad arguments");
   ISO_REQUIRE(((uintptr_t)workspace & 255) == 0, ISO_ERR_INVALID, "iso_bricks_workspace_init: workspace must be 256-B aligned");
   const BrickWs w = bricks_carve(workspace, n_max);
-  hipLaunchKernelGGL(k_bricks_init, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, (hipStream_t)stream, w.counters, w.cnt, w.G);
+  hipLaunchKernelGGL(k_bricks_init, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, (hipStream_t)stream, w.counters, w.cnt, w.G, (unsigned*)w.scan_ws);
   ISO_CHECK_LAUNCH("iso_bricks_workspace_init");
   return ISO_OK;
 }
@@ -1596,18 +1648,25 @@ extern "C" int iso_bricks_workspace_init(void* workspace, int64_t n_max, void* s
 // count -> offsets (+ work list, counters left zeroed) -> scatter, on a header that is already written
 static int bricks_fill(const BrickWs& w, const float* points, const float* normals, const int32_t* payload, int64_t n_own,
                        const float* import_rec0, const float* import_rec1, const int32_t* import_count,
-                       int64_t import_max, hipStream_t s) {
-  if (n_own > 0)
-    hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 1024)), dim3(256), 0, s, points, n_own, w.hdr, w.cnt,
-                       w.slot);
+                       int64_t import_max, hipStream_t s, bool pending = false, BrickParams q = BrickParams{0, 0, 0, 0.f, 0, 0.f, 0},
+                       ChunkScanJob job = ChunkScanJob{nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr}) {
+  if (n_own > 0 || pending || job.chunk)        // (a pending header is written by this pass, whatever the cloud holds)
+    hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 1024) + (job.chunk ? 1 : 0)), dim3(256), 0, s, points, n_own,
+                       w.hdr, w.cnt, w.slot, pending ? 1 : 0, q, w.counters, job);
   if (import_max > 0)
     hipLaunchKernelGGL(k_brick_count_recs, dim3(iso_stream_grid(import_max, 1024)), dim3(256), 0, s,
                        (const float4*)import_rec0, import_count, import_max, w.hdr, w.cnt, w.slot);
   const int chunks = (int)((w.G + BS_CHUNK - 1) / BS_CHUNK);
-  ISO_REQUIRE(w.scan_ws_bytes >= (int64_t)chunks * 4, ISO_ERR_WORKSPACE, "iso_bricks_build: scan workspace too small");
-  hipLaunchKernelGGL(k_brick_sums, dim3(chunks), dim3(256), 0, s, w.hdr, w.cnt, (int32_t*)w.scan_ws);
-  hipLaunchKernelGGL(k_brick_offsets, dim3(chunks), dim3(256), 0, s, w.hdr, w.cnt, w.off, (const int32_t*)w.scan_ws, w.list,
-                     w.counters);
+  ISO_REQUIRE(w.scan_ws_bytes >= (int64_t)(chunks + kScan1Max) * 4, ISO_ERR_WORKSPACE, "iso_bricks_build: scan workspace too small");
+  if (chunks <= kScan1Max) {            // one launch (the totals are zero on entry and left zero)
+    hipLaunchKernelGGL(k_brick_offsets1, dim3(chunks), dim3(256), 0, s, w.hdr, w.cnt, w.off, (unsigned*)w.scan_ws, w.list,
+                       w.counters);
+  } else {
+    int32_t* sums2 = (int32_t*)w.scan_ws + kScan1Max;       // (behind the words the one-launch form keeps zeroed)
+    hipLaunchKernelGGL(k_brick_sums, dim3(chunks), dim3(256), 0, s, w.hdr, w.cnt, sums2);
+    hipLaunchKernelGGL(k_brick_offsets, dim3(chunks), dim3(256), 0, s, w.hdr, w.cnt, w.off, (const int32_t*)sums2, w.list,
+                       w.counters);
+  }
   if (n_own > 0)
     hipLaunchKernelGGL(k_brick_scatter, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, normals, payload,
                        n_own, w.hdr, w.off, w.slot, w.rec0, w.rec1);
@@ -1636,37 +1695,85 @@ extern "C" int iso_bricks_build(const float* points, const float* normals, const
               (long long)workspace_bytes, (long long)w.bytes);
   hipStream_t s = (hipStream_t)stream;
   if (bbox)        // NULL: the header was written by iso_bricks_params (N ranks: between it and here the halo exchange)
-    hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, s, bbox, 1, n_total, n_own, id_base, radius, knn_k,
-                       cell_scale, w.nb_cap, w.hdr, w.counters);
+    hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, s, bbox, 1,
+                       BrickParams{n_total, n_own, id_base, radius, knn_k, cell_scale, w.nb_cap}, w.hdr, w.counters);
   int rc = bricks_fill(w, points, normals, payload, n_own, import_rec0, import_rec1, import_count, import_max, s);
   if (rc != ISO_OK) return rc;
   ISO_CHECK_LAUNCH("iso_bricks_build");
   return ISO_OK;
 }
 
+static int build_whole_checks(const char* who, const float* points, int64_t n, float radius, int knn_k, float cell_scale,
+                              void* workspace, int64_t workspace_bytes, BrickWs& w) {
+  ISO_REQUIRE(n >= 0 && workspace && (points || n == 0), ISO_ERR_INVALID, "%s: bad arguments", who);
+  ISO_REQUIRE(cell_scale > 0.f && (radius > 0.f || knn_k > 0), ISO_ERR_INVALID,
+              "%s: cell_scale and radius / knn_k must be positive", who);
+  ISO_REQUIRE(((uintptr_t)workspace & 255) == 0, ISO_ERR_INVALID, "%s: workspace must be 256-B aligned", who);
+  ISO_REQUIRE(n < (1ll << 28), ISO_ERR_UNSUPPORTED, "%s: ids must stay below 2^28", who);
+  w = bricks_carve(workspace, n);
+  ISO_REQUIRE(workspace_bytes >= w.bytes, ISO_ERR_WORKSPACE, "%s: workspace too small (%lld < %lld)", who,
+              (long long)workspace_bytes, (long long)w.bytes);
+  return ISO_OK;
+}
+
 extern "C" int iso_bricks_build_whole(const float* points, const float* normals, const int32_t* payload, int64_t n,
                                       float radius, int knn_k, float cell_scale, void* workspace,
                                       int64_t workspace_bytes, void* stream) {
-  ISO_REQUIRE(n >= 0 && workspace && (points || n == 0), ISO_ERR_INVALID, "iso_bricks_build_whole: bad arguments");
-  ISO_REQUIRE(cell_scale > 0.f && (radius > 0.f || knn_k > 0), ISO_ERR_INVALID,
-              "iso_bricks_build_whole: cell_scale and radius / knn_k must be positive");
-  ISO_REQUIRE(((uintptr_t)workspace & 255) == 0, ISO_ERR_INVALID, "iso_bricks_build_whole: workspace must be 256-B aligned");
-  ISO_REQUIRE(n < (1ll << 28), ISO_ERR_UNSUPPORTED, "iso_bricks_build_whole: ids must stay below 2^28");
-  const BrickWs w = bricks_carve(workspace, n);
-  ISO_REQUIRE(workspace_bytes >= w.bytes, ISO_ERR_WORKSPACE, "iso_bricks_build_whole: workspace too small (%lld < %lld)",
-              (long long)workspace_bytes, (long long)w.bytes);
+  BrickWs w;
+  int rc = build_whole_checks("iso_bricks_build_whole", points, n, radius, knn_k, cell_scale, workspace, workspace_bytes, w);
+  if (rc != ISO_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (n > 0) {
-    int gx = iso_div_up(n * 3, 256 * 4);       // four loads per thread and round; a stride of a multiple of 3 floats;
-    if (gx > 255) gx = 255;                    // six same-address atomics per workgroup: more workgroups cost more than they read
+    int gx = iso_div_up(n * 3, 256 * 4);       // four loads per thread and round; a stride of a multiple of 3 floats
+    if (gx > 1023) gx = 1023;
     if (gx >= 3) gx -= gx % 3; else gx = 3;
     hipLaunchKernelGGL(k_brick_bbox, dim3(gx), dim3(256), 0, s, points, n, w.counters);
   }
-  hipLaunchKernelGGL(k_bricks_params_self, dim3(1), dim3(64), 0, s, n, n, (int64_t)0, radius, knn_k, cell_scale, w.nb_cap,
-                     w.hdr, w.counters);
-  int rc = bricks_fill(w, points, normals, payload, n, nullptr, nullptr, nullptr, 0, s);
+  rc = bricks_fill(w, points, normals, payload, n, nullptr, nullptr, nullptr, 0, s, true,
+                   BrickParams{n, n, 0, radius, knn_k, cell_scale, w.nb_cap});
   if (rc != ISO_OK) return rc;
   ISO_CHECK_LAUNCH("iso_bricks_build_whole");
+  return ISO_OK;
+}
+
+// front workspace (iso_splat_front_workspace_bytes): [chunk table 8 x (n_chunks + 1) ints][tile table 8 x (4 n_chunks + 4) ints]
+static inline int32_t* front_tile_table(void* front_ws, int64_t n_points) {
+  const int64_t n_chunks = (n_points + 1023) / 1024;
+  return (int32_t*)front_ws + 8 * (n_chunks + 1);
+}
+
+extern "C" int iso_bricks_build_pending(const float* points, const float* normals, const int32_t* payload, int64_t n,
+                                        float radius, int knn_k, float cell_scale, void* workspace,
+                                        int64_t workspace_bytes, const iso_follow* f, void* stream) {
+  BrickWs w;
+  int rc = build_whole_checks("iso_bricks_build_pending", points, n, radius, knn_k, cell_scale, workspace, workspace_bytes, w);
+  if (rc != ISO_OK) return rc;
+  ChunkScanJob job{nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr};
+  if (f && f->views) {
+    ISO_REQUIRE(f->n_views >= 1 && f->n_views <= 8 && f->front_ws && f->first_idx_out && f->num_pts_out && f->view_total_out,
+                ISO_ERR_INVALID, "iso_bricks_build_pending: follow: mask part incomplete");
+    ISO_REQUIRE(f->front_ws_bytes >= iso_splat_front_workspace_bytes(n), ISO_ERR_WORKSPACE,
+                "iso_bricks_build_pending: follow.front_ws too small");
+    job.n_chunks = (int)((n + 1023) / 1024);
+    job.n_tiles = 4 * job.n_chunks;                     // row stride of the tile table (follow.h)
+    job.n_real = (int)((n + 255) / 256);
+    job.n_views = f->n_views;
+    job.tile_cnt = front_tile_table(f->front_ws, n);
+    job.chunk = (int32_t*)f->front_ws;
+    job.first = f->first_idx_out; job.num = f->num_pts_out; job.view_total = f->view_total_out;
+  }
+  rc = bricks_fill(w, points, normals, payload, n, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, true,
+                   BrickParams{n, n, 0, radius, knn_k, cell_scale, w.nb_cap}, job);
+  if (rc != ISO_OK) return rc;
+  ISO_CHECK_LAUNCH("iso_bricks_build_pending");
+  return ISO_OK;
+}
+
+extern "C" int iso_bricks_box_take(void* workspace, int64_t n_max, float* box_out, void* stream) {
+  ISO_REQUIRE(workspace && box_out && n_max >= 0, ISO_ERR_INVALID, "iso_bricks_box_take: bad arguments");
+  const BrickWs w = bricks_carve(workspace, n_max);
+  hipLaunchKernelGGL(k_brick_box_take, dim3(1), dim3(256), 0, (hipStream_t)stream, w.counters, box_out);
+  ISO_CHECK_LAUNCH("iso_bricks_box_take");
   return ISO_OK;
 }
 
@@ -1677,8 +1784,8 @@ extern "C" int iso_bricks_params(const float* boxes, int n_boxes, int64_t n_tota
   ISO_REQUIRE(cell_scale > 0.f && (radius > 0.f || knn_k > 0), ISO_ERR_INVALID,
               "iso_bricks_params: cell_scale and radius / knn_k must be positive");
   const BrickWs w = bricks_carve(workspace, n_max);
-  hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, (hipStream_t)stream, boxes, n_boxes, n_total, n_own, id_base,
-                     radius, knn_k, cell_scale, w.nb_cap, w.hdr, w.counters);
+  hipLaunchKernelGGL(k_bricks_params, dim3(1), dim3(64), 0, (hipStream_t)stream, boxes, n_boxes,
+                     BrickParams{n_total, n_own, id_base, radius, knn_k, cell_scale, w.nb_cap}, w.hdr, w.counters);
   ISO_CHECK_LAUNCH("iso_bricks_params");
   return ISO_OK;
 }

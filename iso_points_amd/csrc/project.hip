@@ -7,9 +7,12 @@
 // each lane then picks its own xyz out of LDS (stride 3 dwords: odd, so
 // conflict-free).  The whole T-iteration Newton loop runs in registers with a
 // per-lane `active` flag; nothing goes back to HBM between iterations.
+#include <stdlib.h>
 #include "iso_common.h"
 #include "iso_tile.h"
 #include "iso_newton.h"
+#include "bricks.h"
+#include "follow.h"
 
 namespace {
 
@@ -65,6 +68,55 @@ __global__ __launch_bounds__(BLOCK) void k_project_sphere(
     if (t < cnt) mask_out[base + t] = conv ? 1 : 0;
     __syncthreads();
   }
+}
+
+// The same projection with the side work of follow.h (bounding box -> pending box of the grid workspace; renderable mask
+// and per-tile counts), taken from the registers that hold the results.
+template <int BLOCK, int NV>
+__global__ __launch_bounds__(BLOCK) void k_project_sphere_follow(
+    const float* __restrict__ pts_in, float* __restrict__ pts_out, float* __restrict__ nrm_out,
+    uint8_t* __restrict__ mask_out, int64_t n, SphereSdf sdf, int max_iters, float tol, FollowArgs fa) {
+  static_assert(BLOCK == kFollowTile, "one tile of the count table per workgroup round");
+  __shared__ __attribute__((aligned(16))) float tile[BLOCK * 3];
+  __shared__ float s_box[BLOCK / 64][6];
+  __shared__ int s_cnt[2 * (BLOCK / 64)][8];
+  const int t = threadIdx.x;
+  const int64_t n_tiles = (n + BLOCK - 1) / BLOCK;
+  FollowState<NV> fs;
+  fs.init(fa);
+  for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const int64_t base = tl * BLOCK;
+    const int cnt = (int)((n - base) < BLOCK ? (n - base) : BLOCK);
+    iso_tile_load3<BLOCK>(pts_in, base, cnt, tile);
+    __syncthreads();
+    float px = 0.f, py = 0.f, pz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    bool conv = false;
+    if (t < cnt) {
+      px = tile[3 * t + 0];
+      py = tile[3 * t + 1];
+      pz = tile[3 * t + 2];
+      for (int it = 0;; ++it) {
+        float f;
+        sdf.eval(px, py, pz, f, nx, ny, nz);
+        if (!(fabsf(f) > tol)) { conv = true; break; }
+        if (it == max_iters) break;
+        iso_newton_move(f, nx, ny, nz, px, py, pz);
+      }
+      fs.point(fa, base + t, px, py, pz, nx, ny, nz);
+    }
+    __syncthreads();
+    if (t < cnt) { tile[3 * t] = px; tile[3 * t + 1] = py; tile[3 * t + 2] = pz; }
+    __syncthreads();
+    iso_tile_store3<BLOCK>(pts_out, base, cnt, tile);
+    __syncthreads();
+    if (t < cnt) { tile[3 * t] = nx; tile[3 * t + 1] = ny; tile[3 * t + 2] = nz; }
+    __syncthreads();
+    iso_tile_store3<BLOCK>(nrm_out, base, cnt, tile);
+    if (t < cnt) mask_out[base + t] = conv ? 1 : 0;
+    __syncthreads();
+    fs.tile_done(fa, tl, s_cnt);
+  }
+  fs.finish(fa, s_box);
 }
 
 // Sphere tracing against the analytic sphere (SphereTracing.project_points,
@@ -130,6 +182,34 @@ extern "C" int iso_project_sphere(const float* pts_in, float* pts_out,
                      dim3(BLOCK), 0, (hipStream_t)stream, pts_in, pts_out,
                      normals_out, mask_out, n, sdf, max_iters, tol);
   ISO_CHECK_LAUNCH("iso_project_sphere");
+  return ISO_OK;
+}
+
+extern "C" int iso_project_sphere_follow(const float* pts_in, float* pts_out, float* normals_out, uint8_t* mask_out,
+                                         int64_t n, float cx, float cy, float cz, float radius, int max_iters,
+                                         float tol, const iso_follow* f, void* stream) {
+  ISO_REQUIRE(n >= 0 && max_iters >= 0, ISO_ERR_INVALID, "iso_project_sphere_follow: bad n / max_iters");
+  ISO_REQUIRE(f, ISO_ERR_INVALID, "iso_project_sphere_follow: follow is NULL (use iso_project_sphere)");
+  ISO_REQUIRE(n == 0 || (pts_in && pts_out && normals_out && mask_out), ISO_ERR_INVALID,
+              "iso_project_sphere_follow: null pointer");
+  FollowArgs fa;
+  const int rc = follow_args(*f, n, normals_out != nullptr, "iso_project_sphere_follow", fa);
+  if (rc != ISO_OK) return rc;
+  if (n == 0) return ISO_OK;                             // (nothing to add to the pending box, no tile to count)
+  constexpr int BLOCK = 256;
+  SphereSdf sdf{cx, cy, cz, radius};
+  // (one round of resident workgroups, each looping over its tiles: the box is committed once per workgroup)
+  static const int cap = []() { const char* e = getenv("ISO_FOLLOW_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+  int follow_grid = iso_stream_grid(n, BLOCK);
+  if (follow_grid > cap) follow_grid = cap;
+#define ISO_PSF(NV)                                                                                                    \
+  hipLaunchKernelGGL((k_project_sphere_follow<BLOCK, NV>), dim3(follow_grid), dim3(BLOCK), 0, (hipStream_t)stream, \
+                     pts_in, pts_out, normals_out, mask_out, n, sdf, max_iters, tol, fa)
+  if (fa.n_views == 0) ISO_PSF(0);
+  else if (fa.n_views <= 4) ISO_PSF(4);
+  else ISO_PSF(8);
+#undef ISO_PSF
+  ISO_CHECK_LAUNCH("iso_project_sphere_follow");
   return ISO_OK;
 }
 

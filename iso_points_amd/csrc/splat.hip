@@ -1727,7 +1727,10 @@ extern "C" int iso_splat_setup(const float* points, const float* normals, const 
 
 extern "C" int64_t iso_splat_front_workspace_bytes(int64_t n_points) {
   if (n_points < 0) n_points = 0;
-  return 8 * 4 * ((n_points + kChunk - 1) / kChunk + 1);
+  // [chunk table 8 x (n_chunks + 1) ints][per-tile counts 8 x (4 n_chunks + 4) ints: filled by a projection launch with
+  //  iso_follow, scanned into the chunk table by iso_bricks_build_pending]
+  const int64_t n_chunks = (n_points + kChunk - 1) / kChunk;
+  return 8 * 4 * (n_chunks + 1) + 8 * 4 * (4 * n_chunks + 4);
 }
 
 // ---- gradient of the packed NDC rows w.r.t. the world points ---------------------------------------

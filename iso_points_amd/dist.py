@@ -253,12 +253,13 @@ class IsoCycle(object):
             self.med_ws = torch.zeros((lib.iso_splat_median_radius_workspace_bytes(N),), dtype=torch.uint8, device=dev)
 
     # -- stage 1/2: projection + resample -------------------------------------------------
-    def _project(self, pts_local, T):
+    def _project(self, pts_local, T, follow=None):
         """Newton projection of the own points, bracketed by marks (bench.py times the SDF kernel
-        between them; in graph mode they are segment boundaries)."""
+        between them; in graph mode they are segment boundaries).  follow: bricks.Follow, the side work of the launch
+        for the stage that consumes its points (follow.done says whether the model's route did it)."""
         if self.marks:
             yield ("mark", "project_begin", T)
-        r = self.proj._project_points(self.model, pts_local, self.num_local, proj_max_iters=T)
+        r = self.proj._project_points(self.model, pts_local, self.num_local, proj_max_iters=T, follow=follow)
         if self.marks:
             yield ("mark", "project_end", T)
         return r
@@ -277,11 +278,15 @@ class IsoCycle(object):
         g.build(pts, nrm, payload=payload, params_done=True, id_base=self.lo, n_total=self.P,
                 imports=(self.imp0, self.imp1, self.imp_count))
 
-    def _resample(self, pts, nrm):
-        """FRNN K+1 query + tangent-plane repulsion of the own points (levelset_sampling.py:254-284)."""
+    def _resample(self, pts, nrm, pending=False):
+        """FRNN K+1 query + tangent-plane repulsion of the own points (levelset_sampling.py:254-284).  pending: the
+        projection that produced pts left their bounding box in the grid's workspace (bricks.Follow)."""
         cs = bricks.RESAMPLE_CELL * self.knn_k
         if self.world == 1:
-            self.grid.build(pts, nrm, knn_k=self.knn_k, cell_scale=cs)
+            if pending:
+                self.grid.build(pts, nrm, knn_k=self.knn_k, cell_scale=cs, pending=True)
+            else:
+                self.grid.build(pts, nrm, knn_k=self.knn_k, cell_scale=cs)
         else:
             box = bricks.points_bbox(pts)
             boxes = yield ("all_gather", box)
@@ -291,18 +296,36 @@ class IsoCycle(object):
 
     def project_resample(self):
         """Generator: stages 1 and 2 -> ProjectionResult of the own points."""
-        r0 = yield from self._project(self.pts0_local, 10)
-        moved = yield from self._resample(r0.points[0].contiguous(), r0.normals[0].contiguous())
-        r1 = yield from self._project(moved.view(1, -1, 3), 3)
+        one = self.world == 1 and not getattr(self, "no_follow", False)      # (no_follow: A/B and tests)
+        ss = self.splat
+        # one rank: the projections leave the bounding box of what they write in the grid's workspace (the next build
+        # makes its header from it); the second one also takes the renderable mask (bricks.Follow)
+        f0 = bricks.Follow(self.grid, self.n_own) if one else None
+        r0 = yield from self._project(self.pts0_local, 10, follow=f0)
+        moved = yield from self._resample(r0.points[0].contiguous(), r0.normals[0].contiguous(),
+                                          pending=bool(f0 is not None and f0.done))
+        f1 = bricks.Follow(self.grid, self.n_own, views=self.views, znear=ss.znear, zfar=ss.zfar,
+                           backface_culling=self.rs.backface_culling) if one else None
+        r1 = yield from self._project(moved.view(1, -1, 3), 3, follow=f1)
+        self._follow1 = f1 if (f1 is not None and f1.done) else None
         return r1
 
     # -- stage 3: splat front end + forward ------------------------------------------------------
     def _front(self, pts, nrm):
         ss, N, w = self.splat, self.N, self.world
-        mask, cnt, scanned = bricks.view_mask_scan(pts, nrm, self.views, ss.znear, ss.zfar, self.rs.backface_culling)
+        f1 = getattr(self, "_follow1", None)
+        self._follow1 = None
+        if f1 is not None:                 # mask, scan and the grid's header came with the projection
+            mask, cnt, scanned = f1.mask, f1.total, f1.scanned
+        else:
+            mask, cnt, scanned = bricks.view_mask_scan(pts, nrm, self.views, ss.znear, ss.zfar, self.rs.backface_culling)
         counts = None
         if w == 1:
-            self.grid.build(pts, nrm, payload=mask, radius=float(ss.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
+            if f1 is not None:
+                self.grid.build(pts, nrm, payload=mask, radius=float(ss.frnn_radius), cell_scale=bricks.H_CELL_SCALE,
+                                pending=True, follow=f1)
+            else:
+                self.grid.build(pts, nrm, payload=mask, radius=float(ss.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
             view_total = cnt
         else:
             box = bricks.points_bbox(pts)

@@ -204,8 +204,10 @@ class UniformProjection(LevelSetProjection):
             return torch.cat(evals, 0).view(shp[:-1]), torch.cat(grads, 0).view(shp)
 
     # -- projection --------------------------------------------------------------------
-    def _project_packed(self, model, pts, proj_max_iters, proj_tolerance, **forward_kwargs):
-        """pts (n,3) f32 contiguous on the GPU -> points, normals, mask(bool)."""
+    def _project_packed(self, model, pts, proj_max_iters, proj_tolerance, follow=None, **forward_kwargs):
+        """pts (n,3) f32 contiguous on the GPU -> points, normals, mask(bool).  follow: bricks.Follow -- side work of
+        the launch for the next stages of the cycle (iso_follow); returns False in `follow.done` when this model's route
+        cannot do it (the caller then runs the stand-alone passes)."""
         n = pts.shape[0]
         dev = pts.device
         out = torch.empty_like(pts)
@@ -221,9 +223,18 @@ class UniformProjection(LevelSetProjection):
                 cached = ((model.center._version, model.center.data_ptr()), [float(x) for x in model.center.tolist()])
                 model._iso_center = cached
             c = cached[1]
+            if follow is not None:
+                import ctypes
+                fs = follow.struct()
+                _lib.call("iso_project_sphere_follow", p(pts), p(out), p(normals), p(mask), n, c[0], c[1], c[2],
+                          float(model.radius), int(proj_max_iters), float(proj_tolerance), ctypes.byref(fs), _lib.stream())
+                follow.done = True
+                return out, normals, mask
             _lib.call("iso_project_sphere", p(pts), p(out), p(normals), p(mask), n, c[0], c[1], c[2],
                       float(model.radius), int(proj_max_iters), float(proj_tolerance), _lib.stream())
             return out, normals, mask
+        if follow is not None:
+            follow.done = False
         if siren_spec(model) is not None and not forward_kwargs:
             ps = self._packed_cache if (self.reuse_packed and isinstance(self._packed_cache, PackedSiren)
                                         and self._packed_for is model) else PackedSiren(model, dev)
@@ -273,9 +284,10 @@ class UniformProjection(LevelSetProjection):
             points_packed[not_converged] = active_pts - move
         return points_packed, normals_packed, ~not_converged
 
-    def _project_points(self, model, points, num_points, proj_max_iters=None, proj_tolerance=None,
+    def _project_points(self, model, points, num_points, proj_max_iters=None, proj_tolerance=None, follow=None,
                         **forward_kwargs) -> ProjectionResult:
-        """points (B,P,3) padded, num_points (B,) -> ProjectionResult(points, normals, mask)."""
+        """points (B,P,3) padded, num_points (B,) -> ProjectionResult(points, normals, mask).  follow (not in the
+        reference's signature; one full cloud only): see _project_packed."""
         proj_max_iters = proj_max_iters or self.proj_max_iters
         proj_tolerance = proj_tolerance or self.proj_tolerance
         if not points.is_cuda:
@@ -283,7 +295,7 @@ class UniformProjection(LevelSetProjection):
         lens = host_lengths(num_points)
         packed = padded_to_packed(points.detach().float(), lens).contiguous()
         with torch.no_grad():
-            pts, normals, valid = self._project_packed(model, packed, proj_max_iters, proj_tolerance,
+            pts, normals, valid = self._project_packed(model, packed, proj_max_iters, proj_tolerance, follow=follow,
                                                        **forward_kwargs)
         return ProjectionResult(packed_to_padded(pts, lens), packed_to_padded(normals, lens),
                                 packed_to_padded(valid, lens, pad_value=False))
