@@ -125,8 +125,12 @@ class Cycle(object):
 
     def siren_stats(self):
         """(ms, launches) of the timed SIREN projections: HIP events on the launch stream."""
+        from iso_points_amd import _lib
+        lib = _lib.load()
         ms = sum(a.elapsed_time(b) for a, b, _ in self.ev)
-        launches = sum(T + 1 for _, _, T in self.ev)
+        # launches really issued: the late Newton iterations of a projection are ONE tail launch (iso_siren_set_tail_from)
+        launches = sum(lib.iso_siren_step_launches(HIDDEN, LAYERS, T) if lib.iso_siren_get_gemm_mode() == 1 else T + 1
+                       for _, _, T in self.ev)
         return ms, launches
 
     def active_counts(self):
@@ -545,7 +549,7 @@ def main():
                        "(per-pixel stages; each packed row sent to the bands it touches by ONE band all-to-all, its z sums "
                        "and visible flags returned by the reverse all-to-all) x%d ranks, RCCL" % world},
             "roofline": {"bound": "mfma",
-                         "kernel": ("k_siren_step_x3_both<256,8,3,1> (fused SIREN SDF+grad Newton step, split-fp16 MFMA; 96- and 32-point tiles of a list in one launch)" if x3
+                         "kernel": ("k_siren_step_x3_both<256,8,3,1> (fused SIREN SDF+grad Newton step, split-fp16 MFMA; 96- and 32-point tiles of a list in one launch) + k_siren_tail_x3 (the late iterations of a projection in one launch)" if x3
                                     else "k_siren_step<16> (fused SIREN SDF+grad Newton step, f32 MFMA)"),
                          "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),

@@ -101,6 +101,14 @@ int iso_siren_pack_weights(const float* raw, float* packed, int hidden,
  * Shapes mode 1 does not cover run in mode 0.  ISO_SIREN_GEMM=f32 in the environment selects 0. */
 int iso_siren_set_gemm_mode(int mode);
 int iso_siren_get_gemm_mode(void);
+/* Newton tail of iso_project_siren (H = 256, split-fp16 mode): the iterations from `first_tail_iteration` on run as ONE
+ * launch whose workgroups iterate the survivors of their own tiles until none is left (the reference leaves its loop
+ * when nothing is active, levelset_sampling.py:329) -- instead of one launch per iteration, most of them for a few
+ * hundred points or none.  -1: the default (4 for max_iters >= 6, else 2), 0: never (a launch per iteration), k >= 1.
+ * Results do not depend on it (a point's evaluation does not depend on the tile it sits in).              */
+int iso_siren_set_tail_from(int first_tail_iteration);
+/* step-kernel launches one iso_project_siren call with these arguments issues (max_iters + 1 without the tail) */
+int iso_siren_step_launches(int hidden, int n_hidden, int max_iters);
 /* scratch for the per-wave activation-derivative stash */
 int64_t iso_project_siren_workspace_bytes(int64_t n, int hidden, int n_hidden);
 int iso_project_siren(const float* pts_in, float* pts_out, float* normals_out,

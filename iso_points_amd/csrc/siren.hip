@@ -330,10 +330,18 @@ extern "C" int iso_siren_pack_weights(const float* raw, float* packed, int hidde
   return ISO_OK;
 }
 
-// workspace: [stash floats][idx A n][idx B n][counts 64]
+// Newton tail: private survivor lists of the tail launch's workgroups, two of tail_cap entries each (a workgroup's share of
+// a list is at most ceil(tiles / blocks) tiles of 32) + their two counters
+static int64_t tail_cap_of(int64_t n) {
+  const int64_t blocks = siren_x3_tail_blocks(), tiles = (n + 31) / 32;
+  return ((tiles + blocks - 1) / blocks + 1) * 32;
+}
+static int64_t tail_ints(int64_t n) { return siren_x3_tail_blocks() * (2 * tail_cap_of(n) + 2); }
+
+// workspace: [stash floats][idx A n][idx B n][tail lists + counters][counts 64]
 extern "C" int64_t iso_project_siren_workspace_bytes(int64_t n, int hidden, int n_hidden) {
   if (n < 0) n = 0;
-  return stash_floats_any(hidden, n_hidden) * 4 + 2 * n * 4 + 64 * 4 + 64;
+  return stash_floats_any(hidden, n_hidden) * 4 + 2 * n * 4 + tail_ints(n) * 4 + 64 * 4 + 64;
 }
 
 static bool siren_small_tiles_enabled() {
@@ -366,13 +374,51 @@ static int run_step_split(SirenArgs a, int hidden, int64_t n, hipStream_t s) {
 
 // The iteration driver shared by the Newton projection and sphere tracing: launch `it` evaluates
 // the list launch it-1 left (device-side counts, no host read), the last one does not move.
+// From which iteration on the Newton projection runs as ONE tail launch (k_siren_tail_x3): the lists of the first
+// iterations are long (launch-per-iteration, 96-point tiles), the late ones a few hundred points or none.  T >= 6: after
+// four launches; shorter projections (the T = 3 re-projection of resample): after two.  ISO_SIREN_TAIL_FROM overrides
+// (0: never, the launch-per-iteration form).
+static int g_tail_from = -2;       // -1: default policy, 0: never, k > 0: from iteration k
+static int siren_tail_from(int max_iters) {
+  if (g_tail_from == -2) { const char* e = getenv("ISO_SIREN_TAIL_FROM"); g_tail_from = e ? atoi(e) : -1; }
+  if (g_tail_from == 0) return max_iters + 1;
+  if (g_tail_from > 0) return g_tail_from;
+  return max_iters >= 6 ? 4 : 2;
+}
+extern "C" int iso_siren_step_launches(int hidden, int n_hidden, int max_iters) {
+  if (max_iters < 0) return 0;
+  const bool can_tail = hidden == 256 && use_x3(hidden, n_hidden) && siren_small_tiles_enabled();
+  const int from = can_tail ? siren_tail_from(max_iters) : max_iters + 1;
+  return from <= max_iters && from > 0 ? from + 1 : max_iters + 1;
+}
+extern "C" int iso_siren_set_tail_from(int first_tail_iteration) {
+  ISO_REQUIRE(first_tail_iteration >= -1, ISO_ERR_INVALID, "iso_siren_set_tail_from: -1 (default), 0 (never) or an iteration >= 1");
+  g_tail_from = first_tail_iteration;
+  return ISO_OK;
+}
+
+__global__ void k_zero_tail(int32_t* c, int n, int32_t* tc, int m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) c[i] = 0;
+  if (i < m) tc[i] = 0;
+}
+
+// The iteration driver shared by the Newton projection and sphere tracing: launch `it` evaluates
+// the list launch it-1 left (device-side counts, no host read), the last one does not move.
 static int run_iterations(SirenArgs a, int hidden, int64_t n, int max_iters, void* workspace,
                           hipStream_t s, const char* who) {
   float* stash = (float*)workspace;
   int32_t* idxA = (int32_t*)(stash + stash_floats_any(hidden, a.L));
   int32_t* idxB = idxA + n;
-  int32_t* counts = idxB + n;  // counts[it] = size of the list consumed by launch `it`
-  hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, s, counts, 64);
+  int32_t* tail = idxB + n;
+  int32_t* counts = tail + tail_ints(n);  // counts[it] = size of the list consumed by launch `it`
+  const int blocks = siren_x3_tail_blocks();
+  const int64_t cap = tail_cap_of(n);
+  int32_t* tail_counts = tail + (int64_t)blocks * 2 * cap;
+  const bool can_tail = hidden == 256 && !a.dirs && !a.fwd_only && use_x3(hidden, a.L) && siren_small_tiles_enabled();
+  const int tail_from = can_tail ? siren_tail_from(max_iters) : max_iters + 1;
+  hipLaunchKernelGGL(k_zero_tail, dim3((2 * blocks + 255) / 256), dim3(256), 0, s, counts, 64, tail_counts,
+                     tail_from <= max_iters ? 2 * blocks : 0);
   a.stash = stash; a.n = n; a.eval_only = 0; a.sdf_out = a.dirs ? a.sdf_out : nullptr; a.grad_out = nullptr;
   for (int it = 0; it <= max_iters; ++it) {
     a.idx_in = (it == 0) ? nullptr : ((it & 1) ? idxA : idxB);
@@ -380,6 +426,12 @@ static int run_iterations(SirenArgs a, int hidden, int64_t n, int max_iters, voi
     a.idx_out = (it & 1) ? idxB : idxA;
     a.count_out = counts + it + 1;
     a.do_move = (it < max_iters) ? 1 : 0;
+    if (it >= tail_from && it > 0) {        // iterations it .. max_iters in one launch
+      a.tail_lists = tail; a.tail_counts = tail_counts; a.iter_counts = counts; a.tail_cap = (int)cap;
+      a.it_first = it; a.it_last = max_iters;
+      ISO_REQUIRE(siren_x3_launch_tail(a, hidden, s) == 0, ISO_ERR_UNSUPPORTED, "%s: no tail kernel for hidden size %d", who, hidden);
+      break;
+    }
     ISO_REQUIRE(run_step_split(a, hidden, n, s) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size %d", who, hidden);
   }
   return ISO_OK;

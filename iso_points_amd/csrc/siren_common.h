@@ -34,6 +34,12 @@ struct SirenArgs {
   // filled round of the persistent grid costs a 32-point tile time instead of a 96-point one
   int split = 0;             // 3: both in one launch (k_siren_step_x3_both)
   int big_blocks = 0;        // split = 3: workgroups of the 96-point-tile shape (set by the launcher)
+  // Newton tail (k_siren_tail_x3): ONE launch runs iterations it_first .. it_last; a workgroup keeps the survivors of
+  // its own tiles in a private pair of lists and iterates them alone -- no launch, no grid-wide step per iteration
+  int32_t* tail_lists = nullptr;   // [blocks][2][tail_cap] private survivor lists
+  int32_t* tail_counts = nullptr;  // [blocks][2] their lengths (zero on entry of the launch: cleared by k_zero_counts' sibling)
+  int32_t* iter_counts = nullptr;  // counts[it] of the projection (diagnostics: points evaluated by iteration it)
+  int tail_cap = 0, it_first = 0, it_last = 0;
 };
 
 // Slots served by the 96-point-tile launch of a split list.  A round of the persistent grid is 256 tiles: 24 576
@@ -89,4 +95,6 @@ bool siren_x3_supported(int H, int L);
 int64_t siren_x3_stash_floats(int H, int L);
 void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s);
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s);
+int siren_x3_tail_blocks();                                          // workgroups of the Newton-tail launch
+int siren_x3_launch_tail(const SirenArgs& a, int H, hipStream_t s);  // H = 256 only
 

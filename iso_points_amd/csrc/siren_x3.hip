@@ -216,8 +216,9 @@ struct X3Shape {
 
 // FWD: value only (iso_siren_sdf, sphere tracing) -- no stash, no reverse sweep, no w cos(w z)
 // bid / nblk: this workgroup's index among the nblk workgroups that share the list (the kernels below)
+// sid: index of the workgroup's stash region (= bid unless the caller runs private lists, see k_siren_tail_x3)
 template <int H, int NW, int NB, bool FWD>
-__device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, const int nblk) {
+__device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, const int nblk, const int sid) {
   using S = X3Shape<H, NW, NB>;
   constexpr int NS = S::NS, NTO = S::NTO, TW = S::TW, SL = S::SL, NG = S::NG, P = S::P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -250,7 +251,7 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
   const int h8 = h * 8;
   const float bL = a.packed[off_bl(H)];
   f32x4* stash = reinterpret_cast<f32x4*>(a.stash) +
-                 ((int64_t)bid * NW + w) * (int64_t)(L > 1 ? L : 1) * NG * 128;   // + lane
+                 ((int64_t)sid * NW + w) * (int64_t)(L > 1 ? L : 1) * NG * 128;   // + lane
   f32x4* lst = reinterpret_cast<f32x4*>(smem_raw + S::kActBytes + S::kRedBytes + S::kPtsBytes) + w * (LG * 128) + lane;
 
   // weight images of this wave: forward / transposed image of hidden layer l (two fp16 parts)
@@ -274,7 +275,8 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
   u32x4 A[4][TW][3];                     // weight-fragment pipeline, carried across stages
   x3_prefetch_a<TW, NTO, FP>(A, fwd_img(0), 0, lane);
 
-  const int64_t total = a.count_in ? (int64_t)(*a.count_in) : a.n;
+  // (agent-scope load: in the Newton tail the count was written by this workgroup's own atomics a moment ago)
+  const int64_t total = a.count_in ? (int64_t)__hip_atomic_load(a.count_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.n;
   if (total <= a.cnt_lo || total > a.cnt_hi) return;       // the other tile shape serves this list (uniform)
   // this launch's share of the list: slots [slot0, count)  (SirenArgs::split)
   const int64_t cut = a.split ? siren_split_point(total) : total;
@@ -706,7 +708,7 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
 
 template <int H, int NW, int NB, int MINB, bool FWD>
 __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
-  x3_step_body<H, NW, NB, FWD>(a, (int)blockIdx.x, (int)gridDim.x);
+  x3_step_body<H, NW, NB, FWD>(a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // Both tile shapes of a split list (SirenArgs::split) in ONE launch: workgroups [0, big_blocks) serve the slots below
@@ -719,13 +721,53 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3_both(SirenArgs 
   if ((int)blockIdx.x < a.big_blocks) {
     SirenArgs b = a;
     b.split = 1;
-    x3_step_body<H, NW, NB, false>(b, (int)blockIdx.x, a.big_blocks);
+    x3_step_body<H, NW, NB, false>(b, (int)blockIdx.x, a.big_blocks, (int)blockIdx.x);
   } else {
     SirenArgs b = a;
     b.split = 2;
     b.stash = a.stash + (int64_t)a.big_blocks * X3Shape<H, NW, NB>::kStashPerWg(a.L);
-    x3_step_body<H, NW, 1, false>(b, (int)blockIdx.x - a.big_blocks, (int)gridDim.x - a.big_blocks);
+    x3_step_body<H, NW, 1, false>(b, (int)blockIdx.x - a.big_blocks, (int)gridDim.x - a.big_blocks,
+                                  (int)blockIdx.x - a.big_blocks);
   }
+}
+
+// The Newton tail in ONE launch (levelset_sampling.py:306-341: the reference leaves its loop when nothing is active; a
+// launch per iteration issued all T + 1 of them, the late ones for a few hundred points or none).  Iteration it_first
+// is taken from the list the previous launch left, dealt out tile by tile (32 points) as always; but a workgroup puts
+// the survivors of ITS tiles on a private list and goes on with them alone -- evaluate, move, keep the survivors --
+// until none is left or iteration it_last (the evaluation without a move) is done.  A point's result does not depend
+// on the tile it sits in, so the results are those of the launch-per-iteration form, bit for bit.  Between two rounds
+// one workgroup barrier (the epilogue's atomics and list entries of the slower waves must have landed).
+template <int H, int NW, int MINB>
+__global__ __launch_bounds__(64 * NW, MINB) void k_siren_tail_x3(SirenArgs a) {
+  const int b = blockIdx.x, nblk = gridDim.x;
+  int32_t* lists = a.tail_lists + (int64_t)b * 2 * a.tail_cap;
+  int32_t* cnts = a.tail_counts + b * 2;
+  SirenArgs r = a;
+  r.split = 0; r.small_tiles = 1; r.cnt_lo = -1; r.cnt_hi = INT64_MAX;
+  // round 0: this workgroup's tiles of the global list
+  r.idx_out = lists; r.count_out = cnts;
+  r.do_move = a.it_first < a.it_last ? 1 : 0;
+  x3_step_body<H, NW, 1, false>(r, b, nblk, b);
+  int cur = 0;
+  for (int it = a.it_first + 1; it <= a.it_last; ++it) {
+    __syncthreads();
+    const int m = __hip_atomic_load(&cnts[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m == 0) break;                                     // (workgroup-uniform)
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&cnts[cur ^ 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.iter_counts) atomicAdd(&a.iter_counts[it], m);
+    }
+    __syncthreads();
+    r.idx_in = lists + (int64_t)cur * a.tail_cap; r.count_in = cnts + cur;
+    r.idx_out = lists + (int64_t)(cur ^ 1) * a.tail_cap; r.count_out = cnts + (cur ^ 1);
+    r.do_move = it < a.it_last ? 1 : 0;
+    x3_step_body<H, NW, 1, false>(r, 0, 1, b);
+    cur ^= 1;
+  }
+  // leave the private counters at zero for the next launch on this workspace
+  __syncthreads();
+  if (threadIdx.x == 0) { cnts[0] = 0; cnts[1] = 0; }
 }
 
 template <int H, int NW, int NB, int MINB, bool FWD>
@@ -800,6 +842,21 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
     hipLaunchKernelGGL(k_siren_wscale, dim3(L), dim3(256), 0, s, raw, packed, H, L);
     hipLaunchKernelGGL(k_siren_pack_f16, dim3(iso_stream_grid(2 * (int64_t)L * H * H, 256)), dim3(256), 0, s, raw, packed, H, L);
   }
+}
+
+int siren_x3_tail_blocks() { return 256 * X3_MINB256; }
+
+int siren_x3_launch_tail(const SirenArgs& a, int H, hipStream_t s) {
+  if (H != 256) return -1;
+  using SS = X3Shape<256, X3_NW, 1>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_siren_tail_x3<256, X3_NW, X3_MINB256>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SS::kLds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_siren_tail_x3<256, X3_NW, X3_MINB256>), dim3(siren_x3_tail_blocks()), dim3(64 * X3_NW), SS::kLds, s, a);
+  return 0;
 }
 
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {

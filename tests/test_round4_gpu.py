@@ -110,3 +110,46 @@ def test_cycle_with_follow_equals_cycle_without(dev):
     assert torch.equal(fra["first_idx"], frb["first_idx"]) and torch.equal(fra["num_points"], frb["num_points"])
     rows = int((fra["first_idx"][-1] + fra["num_points"][-1]).item())      # (rows beyond the clouds are not written)
     assert rows > 0 and torch.equal(ga[:rows], gb[:rows])
+
+
+@pytest.mark.parametrize("fitted,P,T", [(False, 150001, 10), (True, 200003, 10), (True, 70001, 3), (False, 999, 4)])
+def test_newton_tail_in_one_launch_equals_a_launch_per_iteration(dev, fitted, P, T):
+    """k_siren_tail_x3 (iterations k..T of the projection in one launch, workgroups iterating the survivors of their own
+    tiles) against the launch-per-iteration form: points, normals, masks and the per-iteration active counts, bit for
+    bit, for chaotic random weights (lists stay long: the tail takes over long lists) and for a fitted network (lists
+    die out), from every iteration the tail can start at."""
+    from iso_points_amd import _lib
+    from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
+    from iso_points_amd.sdf_models import Siren
+    from oracle import iso_oracle as O
+    lib = _lib.load()
+    torch.manual_seed(0)
+    m = Siren(hidden_size=256, n_layers=3).to(dev)
+    if fitted:
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        g = torch.Generator(device="cpu").manual_seed(0)
+        for _ in range(150):
+            x = ((torch.rand(4096, 3, generator=g) - 0.5) * 3.0).to(dev)
+            loss = ((m(x).sdf - (x.norm(dim=-1, keepdim=True) - 1.0)) ** 2).mean()
+            opt.zero_grad(); loss.backward(); opt.step()
+    for prm in m.parameters():
+        prm.requires_grad_(False)
+    pts = _cloud(P, 3, dev).view(1, P, 3)
+    proj = UniformProjection()
+    n_off = lib.iso_project_siren_workspace_bytes(P, 256, 3) - 64 * 4 - 64
+
+    def run(k):
+        lib.iso_siren_set_tail_from(k)
+        try:
+            r = proj._project_points(m, pts, full_lengths(pts), proj_max_iters=T)
+            torch.cuda.synchronize()
+            counts = proj._packed_cache._ws[n_off:n_off + 64 * 4].view(torch.int32)[1:T + 1].tolist()
+        finally:
+            lib.iso_siren_set_tail_from(-1)
+        return r, counts
+
+    ref, c_ref = run(0)
+    for k in [-1] + list(range(1, T + 1)):
+        out, c = run(k)
+        assert torch.equal(out.points, ref.points) and torch.equal(out.normals, ref.normals) and torch.equal(out.mask, ref.mask), k
+        assert c == c_ref, (k, c, c_ref)
