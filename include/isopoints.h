@@ -485,6 +485,25 @@ int iso_splat_render(const float* points, const float* ellipse, const float* cut
                      const float* features, int channels, int norm_weighted, float eps,
                      float* image_out, void* stream);
 
+/* The reference's two-stage raster interface, DSS._C._rasterize_coarse / _rasterize_fine (DSS/csrc/ext.cpp:11-12;
+ * dispatchers rasterize_points.h:167,257; kernels rasterize_points.cu:293-441, :503-596).  No Python caller in the
+ * reference (splat_points runs both internally); here they are a compatibility surface beside iso_splat_forward, whose
+ * own binning is the tile lists of iso_splat_bin_count.
+ *   coarse: bin_points_out (N, B, B, M) int32, B = 1 + (image_size - 1) / bin_size: bin (by, bx) lists the packed
+ *           indices of its cloud's points with z >= 0 whose box [p - r, p + r] overlaps the bin (extent = PixToNdc of
+ *           its first / last pixel -+ half a pixel, non-strict), ascending (the reference: arrival order of its atomics
+ *           on the GPU, ascending on the CPU), -1 behind them; *overflow_out is set to 1 when a bin had more than M
+ *           (cut at M; never cleared here).
+ *   fine:   per pixel the K front-most hits among the entries of its bin (negative entries skipped), tests and outputs
+ *           of iso_splat_forward: fine(coarse(x)) == iso_splat_forward(x) bit for bit when no bin overflowed.  K <= 32. */
+int iso_rasterize_coarse(const float* points, const float* radii, const int64_t* first_idx, const int64_t* num_pts,
+                         int n_clouds, int image_size, int bin_size, int max_points_per_bin, int32_t* bin_points_out,
+                         int32_t* overflow_out, void* stream);
+int iso_rasterize_fine(const float* points, const float* ellipse, const float* cutoff, const float* radii,
+                       int64_t n_points, const int32_t* bin_points, int n_clouds, int max_points_per_bin,
+                       float depth_merging_thres, int image_size, int bin_size, int points_per_pixel,
+                       int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out, void* stream);
+
 /* renderer.py:53-78: w = exp(-0.5 q) * scaler[idx] (0 where idx < 0);
  * image[..., c] = sum_k w f / max(sum_k w, eps) (norm_weighted) or sum_k w f;
  * image[..., channels] = occupancy.  frag_scaler_out (n_pixels,K) may be NULL.  */
@@ -676,7 +695,12 @@ int iso_splat_front_rows(const float* points, const float* normals, const float*
                          const float* views, const float* projs, int n_views, int image_size, float sigma,
                          float cutoff, const void* workspace, int64_t workspace_bytes, const int64_t* first_idx,
                          float* ndc_out, float* ellipse_out, float* cutoff_out, float* radii_out,
-                         float* scaler_out, float* features_out, int32_t* src_out, void* stream);
+                         float* scaler_out, float* features_out, int32_t* src_out,
+                         uint8_t* visible_zero_out /* (rows) or NULL: the rows' "visible" flags of the backward pass
+                                                      (iso_splat_mark_visible), cleared here instead of by a fill */,
+                         int64_t row_capacity /* rows the output arrays hold; <= 0: num_points.sum() rows, whatever that is */,
+                         int32_t* overflow_out /* set to 1 when rows were dropped at row_capacity (never cleared here), or NULL */,
+                         void* stream);
 /* Gradient of the packed NDC rows of iso_splat_front w.r.t. the WORLD points (the part of the reference's
  * backward that autograd runs through cameras.transform_points in SurfaceSplatting.transform,
  * rasterizer.py:565-582,618: per-point set-up is under no_grad :608-610, so d(ndc)/d(point) is all there is).

@@ -119,10 +119,12 @@ SIGNATURES = {
     "iso_insert_fathers": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P]),
     "iso_insert_children": (_I, [_P, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P]),
     "iso_splat_points_backward": (_I, [_P, _L, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "iso_rasterize_coarse": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "iso_rasterize_fine": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P]),
     "iso_splat_front_workspace_bytes": (_L, [_L]),
     "iso_splat_view_mask_scan": (_I, [_P, _P, _P, _I, _L, _F, _F, _I, _P, _P, _L, _P, _P, _P, _P]),
     "iso_splat_front_rows": (_I, [_P, _P, _P, _I, _I, _P, _P, _L, _P, _P, _I, _I, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P,
-                                  _P, _P, _P]),
+                                  _P, _P, _P, _L, _P, _P]),
     "iso_splat_front": (_I, [_P, _P, _P, _I, _I, _P, _P, _L, _P, _P, _I, _I, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P,
                              _P, _P, _P, _P, _P]),
 }

@@ -205,7 +205,9 @@ __device__ __forceinline__ void gemm_x3(IP imgw, const float* __restrict__ bias_
 #ifndef X3_GEMM_PRIO
 #define X3_GEMM_PRIO 0
 #endif
+#ifndef X3_STATIC_PRIO
   __builtin_amdgcn_s_setprio(X3_GEMM_PRIO);
+#endif
 #ifdef X3_KROLLED
 #pragma unroll 1
 #endif
@@ -265,7 +267,9 @@ __device__ __forceinline__ void gemm_x3(IP imgw, const float* __restrict__ bias_
     }
   }
   // the next stage starts again at set 0: with KS % 4 == 0 the rotation is already aligned
+#ifndef X3_STATIC_PRIO
   __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 }  // namespace

@@ -308,6 +308,9 @@ struct FrontOut {
   float* ndc; float* ellipse; float* cutoff; float* radii; float* scaler;
   float* feat;      // (cap, C) packed features or null
   int32_t* src;     // (cap) original point of a packed row, or null
+  uint8_t* vis0;    // (cap) "visible" flags of the backward pass, cleared here row by row (or null): no fill launch
+  int64_t cap;      // rows the arrays hold (<= 0: whatever comes); rows beyond are dropped and *overflow is set
+  int32_t* overflow;
 };
 
 __global__ __launch_bounds__(256) void k_splat_front(const float* __restrict__ pts, const float* __restrict__ nrm,
@@ -371,6 +374,11 @@ __global__ __launch_bounds__(256) void k_splat_front(const float* __restrict__ p
     const int cnt = s_w[v][0] + s_w[v][1] + s_w[v][2] + s_w[v][3];
     if (cnt == 0) continue;                                                      // workgroup-uniform
     const int64_t p0 = first[v] + chunk_off[(int64_t)v * n_chunks + blockIdx.x];
+    int wcnt = cnt;                                       // rows of this chunk and view that fit the arrays
+    if (o.cap > 0 && p0 + cnt > o.cap) {
+      wcnt = p0 < o.cap ? (int)(o.cap - p0) : 0;
+      if (threadIdx.x == 0 && o.overflow) *o.overflow = 1;
+    }
     int lr = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) if (q == v) lr = rank[q];
@@ -388,25 +396,26 @@ __global__ __launch_bounds__(256) void k_splat_front(const float* __restrict__ p
         s_src[lr] = (int32_t)i;
         if (stage_feat)
           for (int c = 0; c < Cs; ++c) s_ft[lr * Cs + c] = f[k][c];
-        else if (o.feat)
+        else if (o.feat && lr < wcnt)
           for (int c = 0; c < C; ++c)
             o.feat[(p0 + lr) * C + c] = feat_from_normal ? (c < 3 ? f[k][c] : 0.f) : feat_in[i * C + c];
         ++lr;
       }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < cnt * 3; j += 256) {
+    for (int j = threadIdx.x; j < wcnt * 3; j += 256) {
       o.ndc[p0 * 3 + j] = s_ndc[j];
       o.ellipse[p0 * 3 + j] = s_el[j];
     }
-    for (int j = threadIdx.x; j < cnt * 2; j += 256) o.radii[p0 * 2 + j] = s_rad[j];
-    for (int j = threadIdx.x; j < cnt; j += 256) {
+    for (int j = threadIdx.x; j < wcnt * 2; j += 256) o.radii[p0 * 2 + j] = s_rad[j];
+    for (int j = threadIdx.x; j < wcnt; j += 256) {
       o.cutoff[p0 + j] = cutoffC;
       o.scaler[p0 + j] = s_sc[j];
       if (o.src) o.src[p0 + j] = s_src[j];
+      if (o.vis0) o.vis0[p0 + j] = 0;
     }
     if (stage_feat)
-      for (int j = threadIdx.x; j < cnt * Cs; j += 256) o.feat[p0 * Cs + j] = s_ft[j];
+      for (int j = threadIdx.x; j < wcnt * Cs; j += 256) o.feat[p0 * Cs + j] = s_ft[j];
     __syncthreads();
   }
 }
@@ -445,6 +454,16 @@ __global__ void k_bin(const float* __restrict__ pts, const float* __restrict__ r
 // a workgroup walks kBinChunk consecutive points, counts them per tile in LDS, reserves one range per
 // touched tile with a single global atomic and (FILL) hands out the slots from LDS.  The hot tiles on
 // a silhouette otherwise take thousands of same-address global atomics.
+// The work items of the raster pass (tile_items_body, below) only need the tile offsets, not the filled pair list: the
+// FILL launch carries them as one more workgroup (blockIdx = (gridDim.x - 1, 0)) instead of a single-workgroup launch
+// of its own between the fill and the raster (14 us of the cfg-3a cycle).
+struct TileItemsJob {          // what k_tile_items takes; items == null: no job
+  int ty_rows, n_clouds, max_slots, target_items;
+  int4* items; int4* heavy; int32_t* counters;
+};
+__device__ void tile_items_body(const int32_t* __restrict__ tile_off, Frame F, int ty_begin, int ty_rows, int n_clouds,
+                                int max_slots, int target_items, int4* __restrict__ items, int4* __restrict__ heavy,
+                                int32_t* __restrict__ counters);
 constexpr int kBinChunk = 2048;      // rows per workgroup: 8 per thread -- with 8192 a 512^2 x 4 job was 245 workgroups of 32 sequential rows per thread, latency bound
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin_lds(const float* __restrict__ pts, const float* __restrict__ radii,
@@ -452,8 +471,14 @@ __global__ __launch_bounds__(256) void k_bin_lds(const float* __restrict__ pts, 
                                                  Frame F, int ty_begin, int ty_end,
                                                  int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ tile_off,
                                                  int32_t* __restrict__ pairs, int64_t capacity,
-                                                 int32_t* __restrict__ overflow) {
+                                                 int32_t* __restrict__ overflow, TileItemsJob job) {
   extern __shared__ int lh[];          // Tx*Ty
+  if (FILL && job.items && blockIdx.x == gridDim.x - 1) {           // the extra workgroup(s) of the launch
+    if (blockIdx.y == 0)
+      tile_items_body(tile_off, F, ty_begin, job.ty_rows, job.n_clouds, job.max_slots, job.target_items, job.items,
+                      job.heavy, job.counters);
+    return;
+  }
   const int TT = F.Tx * F.Ty;
   const int n = blockIdx.y;
   const int64_t len = num[n], base = first[n];
@@ -493,18 +518,23 @@ __global__ __launch_bounds__(256) void k_bin_lds(const float* __restrict__ pts, 
   });
 }
 
+// returns true when the launch carried `job` (the caller then issues no k_tile_items launch)
 template <bool FILL>
-void launch_bin(const float* points, const float* radii, const int64_t* first_idx, const int64_t* num_pts,
+bool launch_bin(const float* points, const float* radii, const int64_t* first_idx, const int64_t* num_pts,
                 int n_clouds, int64_t max_pts, Frame F, int ty0, int ty1, int32_t* tile_cnt,
-                const int32_t* tile_off, int32_t* pairs, int64_t capacity, int32_t* overflow, hipStream_t s) {
+                const int32_t* tile_off, int32_t* pairs, int64_t capacity, int32_t* overflow, hipStream_t s,
+                TileItemsJob job = TileItemsJob{0, 0, 0, 0, nullptr, nullptr, nullptr}) {
   if (F.Tx * F.Ty <= 4096) {
-    hipLaunchKernelGGL(k_bin_lds<FILL>, dim3(iso_div_up(max_pts, kBinChunk), n_clouds), dim3(256),
+    const bool carry = FILL && job.items != nullptr;
+    hipLaunchKernelGGL(k_bin_lds<FILL>, dim3(iso_div_up(max_pts, kBinChunk) + (carry ? 1 : 0), n_clouds), dim3(256),
                        (size_t)F.Tx * F.Ty * sizeof(int), s, points, radii, first_idx, num_pts, F, ty0, ty1, tile_cnt,
-                       tile_off, pairs, capacity, overflow);
+                       tile_off, pairs, capacity, overflow, job);
+    return carry;
   } else {
     int gx = iso_div_up(max_pts, 256); if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(k_bin<FILL>, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, first_idx, num_pts, F,
                        ty0, ty1, tile_cnt, tile_off, pairs, capacity, overflow);
+    return false;
   }
 }
 
@@ -993,6 +1023,111 @@ __global__ __launch_bounds__(256) void k_raster_deep(
 
 // Tiles of the band [ty_begin, ty_begin+ty_rows) of every cloud, heaviest first (64 buckets of the
 // candidate count; the order inside a bucket is arbitrary -- it only affects scheduling).
+// ---- the reference's two-stage interface: DSS._C._rasterize_coarse / _rasterize_fine (ext.cpp:11-12) --------------
+// coarse (RasterizePointsCoarseCudaKernel, rasterize_points.cu:293-441): bin (by, bx) of cloud n -- bin_size x bin_size
+// pixels -- lists the PACKED indices of the cloud's points with z >= 0 whose box [p - r, p + r] overlaps the bin's NDC
+// extent (PixToNdc of its first / last pixel -+ half a pixel, both comparisons non-strict), -1 behind them.  The
+// reference's order inside a bin is the arrival order of its atomics; here: ascending index (the order of the
+// reference's CPU path, rasterize_points_cpu.cpp:190-222).  A bin that would hold more than M entries is cut at M and
+// *overflow is set (the CUDA reference writes past the bin, its CPU path raises "Got too many points per bin").
+// One workgroup per (bin, cloud): it walks the cloud in index order, 256 points a round, and compacts the hits with
+// ballots -- the table is a compatibility surface, not the cycle's path (that is the tile lists of k_bin_lds).
+__global__ __launch_bounds__(256) void k_coarse_bins(const float* __restrict__ pts, const float* __restrict__ radii,
+                                                     const int64_t* __restrict__ first, const int64_t* __restrict__ num,
+                                                     int S, int bin_size, int B, int M, int32_t* __restrict__ bin_points,
+                                                     int32_t* __restrict__ overflow) {
+  __shared__ int s_w[4];
+  const int n = blockIdx.y, by = blockIdx.x / B, bx = blockIdx.x % B;
+  const float half_pix = 1.0f / (float)S;
+  auto pix2ndc = [&](int i) { return -1 + (2 * i + 1.0f) / S; };          // rasterization_utils.cuh:8-11
+  const float bx0 = pix2ndc(bx * bin_size) - half_pix, bx1 = pix2ndc((bx + 1) * bin_size - 1) + half_pix;
+  const float by0 = pix2ndc(by * bin_size) - half_pix, by1 = pix2ndc((by + 1) * bin_size - 1) + half_pix;
+  int32_t* out = bin_points + (((int64_t)n * B + by) * B + bx) * M;
+  const int64_t len = num[n], base = first[n];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int64_t filled = 0;
+  for (int64_t i0 = 0; i0 < len; i0 += 256) {
+    const int64_t i = i0 + threadIdx.x;
+    bool hit = false;
+    if (i < len) {
+      const int64_t p = base + i;
+      const float px = pts[p * 3], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
+      if (!(pz < 0)) {                                                    // :349 (a NaN depth is not "behind")
+        const float rx = radii[p * 2], ry = radii[p * 2 + 1];
+        const float px0 = px - rx, px1 = px + rx, py0 = py - ry, py1 = py + ry;
+        hit = (py0 <= by1) && (by0 <= py1) && (px0 <= bx1) && (bx0 <= px1);   // :366,:378
+      }
+    }
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) s_w[w] = __popcll(bal);
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (k < w) before += s_w[k]; tot += s_w[k]; }
+    if (hit) {
+      const int64_t slot = filled + before + __popcll(bal & ((1ull << lane) - 1ull));
+      if (slot < M) out[slot] = (int32_t)(base + i);
+      else *overflow = 1;
+    }
+    filled += tot;
+    __syncthreads();
+  }
+  for (int64_t k = (filled < M ? filled : M) + threadIdx.x; k < M; k += 256) out[k] = -1;
+}
+
+// fine (RasterizePointsFineCudaKernel, rasterize_points.cu:503-596): every pixel tests the entries of ITS bin (negative
+// entries skipped wherever they stand, :567-571) exactly as the naive kernel tests every point (CheckPixelInsidePoint
+// :79-97) and keeps the K front-most hits -- by (z, index), the total order of every raster path here; then the
+// depth-merging cut and the outputs of k_raster.  One thread per pixel.
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_fine_bins(const float* __restrict__ pts, const float* __restrict__ ellipse,
+                                                   const float* __restrict__ cutoff, const float* __restrict__ radii,
+                                                   const int32_t* __restrict__ bin_points, int N, int B, int M, int bin_size,
+                                                   Frame F, int K, float depth_thres, int64_t n_points,
+                                                   int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out,
+                                                   float* __restrict__ q_out, float* __restrict__ occ_out) {
+  const int64_t npix = (int64_t)N * F.H * F.W;
+  for (int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pid < npix; pid += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(pid / ((int64_t)F.H * F.W));
+    const int yi = (int)((pid / F.W) % F.H), xi = (int)(pid % F.W);
+    const int by = yi / bin_size, bx = xi / bin_size;
+    const float xf = ndc_x(xi, F), yf = ndc_y(yi, F);
+    const int32_t* bins = bin_points + (((int64_t)n * B + by) * B + bx) * M;
+    PixK<KMAX> best;
+    best.init();
+    float wz = FLT_MAX;
+    int wi = 0x7fffffff;
+    for (int m = 0; m < M; ++m) {
+      const int p = bins[m];
+      if (p < 0 || p >= n_points) continue;
+      const float pz = pts[(int64_t)p * 3 + 2];
+      if (!(pz >= 0.f)) continue;                          // behind the camera (:87-88) or NaN, as every raster path here
+      const float dx = xf - pts[(int64_t)p * 3], dy = yf - pts[(int64_t)p * 3 + 1];
+      if (fabsf(dx) > radii[(int64_t)p * 2] || fabsf(dy) > radii[(int64_t)p * 2 + 1]) continue;                 // :92
+      const float q = ellipse[(int64_t)p * 3] * dx * dx + ellipse[(int64_t)p * 3 + 1] * dx * dy + ellipse[(int64_t)p * 3 + 2] * dy * dy;   // :94
+      if (q > cutoff[p]) continue;                                                                                // :96
+      if (pz < wz || (pz == wz && p < wi)) {
+        best.push(pz, p, q, K);
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wz = best.z[j]; wi = best.id[j]; }
+      }
+    }
+    const int yo = F.H - 1 - yi, xo = F.W - 1 - xi;        // :577-580
+    const int64_t pix = ((int64_t)n * F.H + yo) * F.W + xo;
+    const float z0 = best.z[0];
+    occ_out[pix] = z0 < FLT_MAX ? 1.0f : 0.0f;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < K) {
+        const bool ok = best.z[j] < FLT_MAX && !((best.z[j] - z0) > depth_thres);
+        idx_out[pix * K + j] = ok ? best.id[j] : -1;
+        zbuf_out[pix * K + j] = ok ? best.z[j] : -1.0f;
+        q_out[pix * K + j] = ok ? best.q[j] : -1.0f;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
                                                      int ty_rows, int n_clouds, int32_t* __restrict__ order) {
   const int T = F.Tx, TY = F.Ty;
@@ -1029,10 +1164,11 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-__global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
-                                                     int ty_rows, int n_clouds, int max_slots, int target_items,
-                                                     int4* __restrict__ items, int4* __restrict__ heavy,
-                                                     int32_t* __restrict__ counters) {
+// one workgroup of any size that is a multiple of 64
+__device__ void tile_items_body(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
+                                int ty_rows, int n_clouds, int max_slots, int target_items,
+                                int4* __restrict__ items, int4* __restrict__ heavy,
+                                int32_t* __restrict__ counters) {
   __shared__ int hist[64], base[64];
   __shared__ int s_slots, s_heavy, s_slice;
   const int T = F.Tx, TY = F.Ty;
@@ -1114,6 +1250,12 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
   visit([&](int, int tile, int c) {
     if (slices_of(c) == 1) items[atomicAdd(&base[bucket_of(c)], 1)] = make_int4(tile, 0, 1, 0);
   });
+}
+__global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
+                                                     int ty_rows, int n_clouds, int max_slots, int target_items,
+                                                     int4* __restrict__ items, int4* __restrict__ heavy,
+                                                     int32_t* __restrict__ counters) {
+  tile_items_body(tile_off, F, ty_begin, ty_rows, n_clouds, max_slots, target_items, items, heavy, counters);
 }
 
 // K-best of a heavy tile's pixels from the K-best lists of its slices (same (z, idx) order: the result
@@ -1814,7 +1956,7 @@ extern "C" int iso_splat_front(const float* points, const float* normals, const 
   hipLaunchKernelGGL(k_mask_chunk_scan, dim3(1), dim3(1024), 0, s, chunk, n_chunks, n_views, first_idx_out, num_pts_out,
                      view_total_out);
   if (n_points > 0) {
-    FrontOut o{ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out, features_out, src_out};
+    FrontOut o{ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out, features_out, src_out, nullptr, 0, nullptr};
     hipLaunchKernelGGL(k_splat_front, dim3(n_chunks), dim3(256), 0, s, points, normals, features, channels, mask, h,
                        n_points, chunk, n_chunks, first_idx_out, views, projs, n_views, image_size, sigma, cutoff,
                        features_from_normals, o);
@@ -1856,7 +1998,8 @@ extern "C" int iso_splat_front_rows(const float* points, const float* normals, c
                                     const float* views, const float* projs, int n_views, int image_size, float sigma,
                                     float cutoff, const void* workspace, int64_t workspace_bytes, const int64_t* first_idx,
                                     float* ndc_out, float* ellipse_out, float* cutoff_out, float* radii_out,
-                                    float* scaler_out, float* features_out, int32_t* src_out, void* stream) {
+                                    float* scaler_out, float* features_out, int32_t* src_out, uint8_t* visible_zero_out,
+                                    int64_t row_capacity, int32_t* overflow_out, void* stream) {
   ISO_REQUIRE(n_points >= 0 && n_views >= 1 && n_views <= 8 && image_size > 0, ISO_ERR_INVALID,
               "iso_splat_front_rows: bad sizes (1..8 views per call)");
   ISO_REQUIRE(channels >= 0 && channels <= 8, ISO_ERR_UNSUPPORTED, "iso_splat_front_rows: channels must be <= 8");
@@ -1868,7 +2011,7 @@ extern "C" int iso_splat_front_rows(const float* points, const float* normals, c
                   scaler_out && (!features_out || features || features_from_normals),
               ISO_ERR_INVALID, "iso_splat_front_rows: null pointer");
   const int n_chunks = (int)((n_points + kChunk - 1) / kChunk);
-  FrontOut o{ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out, features_out, src_out};
+  FrontOut o{ndc_out, ellipse_out, cutoff_out, radii_out, scaler_out, features_out, src_out, visible_zero_out, row_capacity, overflow_out};
   hipLaunchKernelGGL(k_splat_front, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, points, normals, features, channels,
                      mask, h, n_points, (const int32_t*)workspace, n_chunks, first_idx, views, projs, n_views, image_size,
                      sigma, cutoff, features_from_normals, o);
@@ -1980,27 +2123,15 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
   ISO_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end && tile_row_end <= F.Ty,
               ISO_ERR_INVALID, "iso_splat_forward: bad tile row band");
   if (tile_row_begin == tile_row_end) return ISO_OK;
-  if (max_pts > 0) {
-    ISO_REQUIRE(points && ellipse && cutoff && radii, ISO_ERR_INVALID, "iso_splat_forward: null pointer");
-    launch_bin<true>(points, radii, first_idx, num_pts, n_clouds, max_pts, F, tile_row_begin,
-                     tile_row_end, tile_cursor, tile_off, pairs, pair_capacity, overflow_flag, s);
-  }
   const int ty_rows = tile_row_end - tile_row_begin;
   const int tiles = n_clouds * T * ty_rows;
   const int K = points_per_pixel;
-  if (K > 32) {                               // lists too deep for registers: one workgroup per tile, lists in the outputs
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tile_off, F, tile_row_begin, ty_rows, n_clouds, tile_cursor);
-    hipLaunchKernelGGL(k_raster_deep, dim3(tiles), dim3(256), 0, s, points, ellipse, cutoff, radii, tile_cursor, tile_off, pairs,
-                       pair_capacity, F, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);
-    ISO_CHECK_LAUNCH("iso_splat_forward");
-    return ISO_OK;
-  }
   const int KM = K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 16 ? 16 : 32));
   // workspace (optional): work items with the heavy tiles cut into slices
   //   [counters 64 B][items int4 (tiles + slots)][heavy int4 (tiles)][scratch slots * 3 * KM * 256 floats]
   int max_slots = 0;
   int4* items = nullptr; int4* heavy = nullptr; int32_t* counters = nullptr; float* scratch = nullptr;
-  if (workspace && tiles > 0) {
+  if (workspace && tiles > 0 && K <= 32) {
     const int64_t per_slot = 16 + (int64_t)3 * KM * 256 * 4;
     const int64_t fixed = 64 + (int64_t)32 * tiles;
     int64_t slots = workspace_bytes > fixed ? (workspace_bytes - fixed) / per_slot : 0;
@@ -2011,11 +2142,27 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
     heavy = items + tiles + max_slots;
     scratch = (float*)(heavy + tiles);
   }
+  static int target = -1;               // ISO_RASTER_ITEMS: development override of the work-item target (sweeps)
+  if (target < 0) { const char* e = getenv("ISO_RASTER_ITEMS"); target = e ? atoi(e) : kTargetItems; if (target < 1) target = kTargetItems; }
+  bool items_done = false;
+  if (max_pts > 0) {
+    ISO_REQUIRE(points && ellipse && cutoff && radii, ISO_ERR_INVALID, "iso_splat_forward: null pointer");
+    // the fill launch also makes the raster's work items (one more workgroup: they only need the offsets)
+    items_done = launch_bin<true>(points, radii, first_idx, num_pts, n_clouds, max_pts, F, tile_row_begin,
+                                  tile_row_end, tile_cursor, tile_off, pairs, pair_capacity, overflow_flag, s,
+                                  TileItemsJob{ty_rows, n_clouds, max_slots, target, items, heavy, counters});
+  }
+  if (K > 32) {                               // lists too deep for registers: one workgroup per tile, lists in the outputs
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tile_off, F, tile_row_begin, ty_rows, n_clouds, tile_cursor);
+    hipLaunchKernelGGL(k_raster_deep, dim3(tiles), dim3(256), 0, s, points, ellipse, cutoff, radii, tile_cursor, tile_off, pairs,
+                       pair_capacity, F, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);
+    ISO_CHECK_LAUNCH("iso_splat_forward");
+    return ISO_OK;
+  }
   if (items) {
-    static int target = -1;               // ISO_RASTER_ITEMS: development override of the work-item target (sweeps)
-    if (target < 0) { const char* e = getenv("ISO_RASTER_ITEMS"); target = e ? atoi(e) : kTargetItems; if (target < 1) target = kTargetItems; }
-    hipLaunchKernelGGL(k_tile_items, dim3(1), dim3(1024), 0, s, tile_off, F, tile_row_begin, ty_rows, n_clouds, max_slots,
-                       target, items, heavy, counters);
+    if (!items_done)
+      hipLaunchKernelGGL(k_tile_items, dim3(1), dim3(1024), 0, s, tile_off, F, tile_row_begin, ty_rows, n_clouds, max_slots,
+                         target, items, heavy, counters);
   } else {
     // the fill cursors are dead now: their array takes the heaviest-first tile order
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tile_off, F, tile_row_begin, ty_rows, n_clouds,
@@ -2077,6 +2224,51 @@ extern "C" int iso_splat_render(const float* points, const float* ellipse, const
                             image_size, image_width, points_per_pixel, tile_row_begin, tile_row_end, tile_cursor, tile_off, pairs,
                             pair_capacity, overflow_flag, idx_out, zbuf_out, qvalue_out, occ_out, workspace,
                             workspace_bytes, stream);
+}
+
+extern "C" int iso_rasterize_coarse(const float* points, const float* radii, const int64_t* first_idx,
+                                    const int64_t* num_pts, int n_clouds, int image_size, int bin_size,
+                                    int max_points_per_bin, int32_t* bin_points_out, int32_t* overflow_out, void* stream) {
+  ISO_REQUIRE(n_clouds >= 0 && image_size > 0 && bin_size > 0 && max_points_per_bin >= 0, ISO_ERR_INVALID,
+              "iso_rasterize_coarse: bad sizes");
+  const int B = 1 + (image_size - 1) / bin_size;
+  if (n_clouds == 0 || max_points_per_bin == 0) return ISO_OK;
+  ISO_REQUIRE(points && radii && first_idx && num_pts && bin_points_out && overflow_out, ISO_ERR_INVALID,
+              "iso_rasterize_coarse: null pointer");
+  hipLaunchKernelGGL(k_coarse_bins, dim3(B * B, n_clouds), dim3(256), 0, (hipStream_t)stream, points, radii, first_idx,
+                     num_pts, image_size, bin_size, B, max_points_per_bin, bin_points_out, overflow_out);
+  ISO_CHECK_LAUNCH("iso_rasterize_coarse");
+  return ISO_OK;
+}
+
+extern "C" int iso_rasterize_fine(const float* points, const float* ellipse, const float* cutoff, const float* radii,
+                                  int64_t n_points, const int32_t* bin_points, int n_clouds, int max_points_per_bin,
+                                  float depth_merging_thres, int image_size, int bin_size, int points_per_pixel,
+                                  int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out, void* stream) {
+  ISO_REQUIRE(n_clouds >= 0 && image_size > 0 && bin_size > 0 && max_points_per_bin >= 0 && n_points >= 0, ISO_ERR_INVALID,
+              "iso_rasterize_fine: bad sizes");
+  ISO_REQUIRE(points_per_pixel >= 1 && points_per_pixel <= 32, ISO_ERR_UNSUPPORTED,
+              "iso_rasterize_fine: points_per_pixel must be in [1,32] (deeper lists: iso_splat_forward), got %d", points_per_pixel);
+  if (n_clouds == 0) return ISO_OK;
+  ISO_REQUIRE(idx_out && zbuf_out && qvalue_out && occ_out && (max_points_per_bin == 0 || bin_points) &&
+                  (n_points == 0 || (points && ellipse && cutoff && radii)),
+              ISO_ERR_INVALID, "iso_rasterize_fine: null pointer");
+  const Frame F = make_frame(image_size, image_size);
+  const int B = 1 + (image_size - 1) / bin_size;
+  const int64_t npix = (int64_t)n_clouds * image_size * image_size;
+  const int K = points_per_pixel;
+  hipStream_t s = (hipStream_t)stream;
+#define ISO_FINE(KM_)                                                                                               \
+  hipLaunchKernelGGL(k_fine_bins<KM_>, dim3(iso_stream_grid(npix, 256)), dim3(256), 0, s, points, ellipse, cutoff, radii, \
+                     bin_points, n_clouds, B, max_points_per_bin, bin_size, F, K, depth_merging_thres, n_points, idx_out,  \
+                     zbuf_out, qvalue_out, occ_out)
+  if (K <= 4) ISO_FINE(4);
+  else if (K <= 8) ISO_FINE(8);
+  else if (K <= 16) ISO_FINE(16);
+  else ISO_FINE(32);
+#undef ISO_FINE
+  ISO_CHECK_LAUNCH("iso_rasterize_fine");
+  return ISO_OK;
 }
 
 extern "C" int iso_splat_composite(const int32_t* idx, const float* qvalue, const float* occ,

@@ -209,6 +209,7 @@ class IsoCycle(object):
     def _alloc(self):
         dev, w = self.dev, self.world
         self._segs = None             # captured graphs hold the old buffers
+        self.splat._row_overflow = None   # (the front end's sticky row-capacity flag: a fresh one with the new buffers)
         self.grid = bricks.BrickGrid(self.n_own, dev, import_max=self.import_cap)
         if w > 1:
             self.exp_buf = torch.zeros((2 * (self.halo_cap + 1) * 4,), dtype=torch.float32, device=dev)
@@ -216,6 +217,9 @@ class IsoCycle(object):
             self.imp1 = torch.empty((self.import_cap, 4), dtype=torch.float32, device=dev)
             self.imp_count = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.wire = torch.empty((12 * self.rec_cap,), dtype=torch.float32, device=dev)
+        if w == 1:
+            from .rasterizer import median_radius_workspace
+            self.med_ws1 = median_radius_workspace(self.N, dev)     # this cycle's own (graphs capture it; zero on entry / exit)
         if w > 1:
             lib, N = _lib.load(), self.N
             i64 = dict(dtype=torch.int64, device=dev)
@@ -386,7 +390,7 @@ class IsoCycle(object):
             rs.depth_merging_threshold, S, K, 0, 0, tile_rows=self.band if many else None,
             out=self.frag if many else None, image_out=self.img_out if many else None,
             max_pts=fr["max_pts"], pair_capacity=self.pair_cap, overflow_out=self._ovf,
-            composite_with=(fr["scaler"], fr["features"], True, 1e-4))
+            composite_with=(fr["scaler"], fr["features"], True, 1e-4), tile_cnt_ws=self._tile_cnt_ws(self.N * T * _lib.load().iso_splat_tiles_per_side(W) + 1))
         if not many:
             return PointFragments(idx, zbuf, qv, None, occ), img
         self._idx_l = idx
@@ -394,6 +398,13 @@ class IsoCycle(object):
         _lib.call("iso_splat_band_remap", _lib.ptr(idx), _lib.ptr(self.gid), self.N, H * W, y0 * W, (y1 - y0) * W, K,
                   _lib.ptr(self.idx_g), _lib.stream())
         return PointFragments(self.idx_g, zbuf, qv, None, occ), img
+
+    def _tile_cnt_ws(self, n_ints):
+        """This cycle's own zero-on-entry tile counters (the raster call leaves them zero; graphs capture the buffer)."""
+        ws = getattr(self, "_tile_cnt", None)
+        if ws is None or ws.numel() < 4 * n_ints:
+            ws = self._tile_cnt = torch.zeros((4 * n_ints,), dtype=torch.uint8, device=self.dev)
+        return ws
 
     def band_rows(self):
         """Output-image pixel rows [y0, y1) of this rank's tile-row band (the image is flipped)."""
@@ -413,7 +424,8 @@ class IsoCycle(object):
         first, num = fr["first_idx"], fr["num_points"]
         scal = float(self.rs.radii_backward_scaler)
         if self.world == 1:
-            vis, rs_ = _visible_and_radius(idx, fr["radii"], first, num, scal, max_pts=fr["max_pts"])
+            vis, rs_ = _visible_and_radius(idx, fr["radii"], first, num, scal, max_pts=fr["max_pts"], vis=fr.get("visible"),
+                                           med_ws=self.med_ws1)
             return _C._backward(fr["ndc"], fr["radii"], occ_grad_band, first, num, visible=vis, rs=rs_, idx=idx,
                                 grad_zbuf=zbuf_grad_band, max_pts=fr["max_pts"], rows_covered=True)
         dev, p = idx.device, _lib.ptr
@@ -577,11 +589,15 @@ class IsoCycle(object):
             u["band_rows"] = int((self.lay_l[0, self.N - 1] + self.lay_l[1, self.N - 1]).item())       # rows this band received
         if fr is not None:
             u["own_rows"] = int(fr["own_num"].sum().item())
+            own = fr.get("own", fr)
+            if own.get("row_overflow") is not None:
+                u["row_overflow"] = int(own["row_overflow"].item())          # the front end dropped rows at rec_cap
         return u
 
     def check(self, fr=None, usage=None):
         u = usage if usage is not None else self.usage(fr)
-        bad = [k for k in ("halo_export_overflow", "halo_import_overflow", "halo_uncertified", "pair_overflow", "band_overflow")
+        bad = [k for k in ("halo_export_overflow", "halo_import_overflow", "halo_uncertified", "pair_overflow", "band_overflow",
+                           "row_overflow")
                if u.get(k)]
         if self.world > 1 and (u["halo_exported"] > self.halo_cap or u["halo_imported"] > self.import_cap):
             bad.append("halo capacity")

@@ -106,7 +106,7 @@ class _CNamespace(object):
                      num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel,
                      bin_size=0, max_points_per_bin=0, tile_rows=None, out=None, max_pts=None,
                      pair_capacity=None, overflow_out=None, split_heavy_tiles=True, composite_with=None,
-                     image_out=None):
+                     image_out=None, tile_cnt_ws=None):
         """-> (idx i32 (N,S,S,K), zbuf, qvalue f32 (N,S,S,K), occupancy f32 (N,S,S)).
         max_pts (upper bound of the points of a cloud) + pair_capacity (upper bound of the point-tile
         pairs): with both given nothing is read back to the host; an overflow of the pair list sets
@@ -156,7 +156,10 @@ class _CNamespace(object):
         maxp = int(max_pts) if max_pts is not None else _max_pts(num)
         p, s = _lib.ptr, _lib.stream()
         # counts -> offsets + cleared cursors in one launch; the counter array is cleared by the pass that reads it
-        tile_cnt = _zeroed_workspace("tile_cnt", dev, 4 * (ntiles + 1)).view(torch.int32)
+        # (tile_cnt_ws: the caller's own zero-on-entry buffer of >= 4 (ntiles + 1) bytes -- owners that capture graphs keep
+        #  theirs; default: one kept per device and stream)
+        own_cnt = tile_cnt_ws is not None
+        tile_cnt = (tile_cnt_ws[:4 * (ntiles + 1)] if own_cnt else _zeroed_workspace("tile_cnt", dev, 4 * (ntiles + 1))).view(torch.int32)
         tile_off = torch.empty((ntiles + 1,), dtype=torch.int32, device=dev)
         cursor = torch.empty((ntiles + 1,), dtype=torch.int32, device=dev)   # [ntiles] = overflow flag
         try:
@@ -164,7 +167,9 @@ class _CNamespace(object):
                       p(tile_cnt), s)
             _lib.call("iso_splat_tile_offsets", p(tile_cnt), p(tile_off), p(cursor), ntiles + 1, s)
         except Exception:
-            _ZEROED.pop(("tile_cnt", dev.index, 4 * (ntiles + 1)), None)     # it may hold counts: never reuse it
+            if not own_cnt:                                   # it may hold counts: never reuse it
+                for k in [k for k, v in _ZEROED.items() if v.data_ptr() == tile_cnt.data_ptr()]:
+                    _ZEROED.pop(k, None)
             raise
         if pair_capacity is None:
             total = int(tile_off[ntiles].item())      # the one host read of the forward pass
@@ -258,27 +263,81 @@ class _CNamespace(object):
                   idx.shape[-1], _lib.ptr(point_z_grad), _lib.stream())
 
     @staticmethod
-    def _rasterize_coarse(*a, **k):
-        raise NotImplementedError("the reference's two-stage bin table (N,B,B,M) is replaced by the "
-                                  "internal tile binning of splat_points")
+    def _rasterize_coarse(points, radii, cloud_to_packed_first_idx, num_points_per_cloud, image_size, bin_size,
+                          max_points_per_bin):
+        """-> bin_points int32 (N, B, B, M), B = 1 + (image_size - 1) // bin_size (RasterizePointsCoarse,
+        rasterize_points.h:167-214 / rasterize_points.cu:293-499): per bin the packed indices of the points with
+        z >= 0 whose box overlaps the bin, ascending, -1 behind them.  Raises like the reference for >= 22 bins per
+        side (rasterize_points.cu:462-468) and for a bin with more than max_points_per_bin points
+        (rasterize_points_cpu.cpp:207-210; one host read of the flag)."""
+        if not points.is_cuda:
+            raise RuntimeError("iso_points_amd._C._rasterize_coarse: tensors must be on the GPU; there is no CPU path")
+        S, bs, M = int(image_size), int(bin_size), int(max_points_per_bin)
+        if bs <= 0 or S <= 0:
+            raise RuntimeError("_rasterize_coarse: image_size and bin_size must be positive")
+        B = 1 + (S - 1) // bs
+        if B >= 22:
+            raise RuntimeError("Got %d; that's too many!" % B)
+        if points.ndim != 2 or points.shape[1] != 3 or radii.shape != (points.shape[0], 2):
+            raise RuntimeError("points (P,3) and radii (P,2) expected")
+        N = num_points_per_cloud.shape[0]
+        dev = points.device
+        bins = torch.empty((N, B, B, M), dtype=torch.int32, device=dev)
+        ovf = torch.zeros((1,), dtype=torch.int32, device=dev)
+        p = _lib.ptr
+        _lib.call("iso_rasterize_coarse", p(_f32c(points)), p(_f32c(radii)), p(_i64c(cloud_to_packed_first_idx)),
+                  p(_i64c(num_points_per_cloud)), N, S, bs, M, p(bins), p(ovf), _lib.stream())
+        if M > 0 and int(ovf.item()):
+            raise RuntimeError("Got too many points per bin")
+        return bins
 
-    _rasterize_fine = _rasterize_coarse
+    @staticmethod
+    def _rasterize_fine(points, ellipse_params, cutoff_thres, radii, bin_points, depth_merging_thres, image_size,
+                        bin_size, points_per_pixel):
+        """-> (idx, zbuf, qvalue, occupancy) from a bin table (RasterizePointsFine, rasterize_points.h:257-340 /
+        rasterize_points.cu:503-673): _rasterize_fine(_rasterize_coarse(...)) == splat_points(...) bit for bit."""
+        if not points.is_cuda:
+            raise RuntimeError("iso_points_amd._C._rasterize_fine: tensors must be on the GPU; there is no CPU path")
+        K, S, bs = int(points_per_pixel), int(image_size), int(bin_size)
+        if K > kMaxPointsPerPixel or K < 1:
+            raise RuntimeError("Must have num_closest <= %d" % kMaxPointsPerPixel)
+        if K > 32:
+            raise NotImplementedError("_rasterize_fine: points_per_pixel > 32 is served by splat_points (lists in global memory)")
+        P = points.shape[0]
+        if bin_points.ndim != 4 or bin_points.shape[1] != bin_points.shape[2] or bin_points.shape[1] != 1 + (S - 1) // bs:
+            raise RuntimeError("bin_points (N, B, B, M) with B = 1 + (image_size - 1) // bin_size expected")
+        if ellipse_params.shape != (P, 3) or radii.shape != (P, 2) or cutoff_thres.shape != (P,):
+            raise RuntimeError("ellipse_params (P,3), radii (P,2), cutoff_thres (P,) expected")
+        N, M = bin_points.shape[0], bin_points.shape[3]
+        dev = points.device
+        idx = torch.empty((N, S, S, K), dtype=torch.int32, device=dev)
+        zbuf = torch.empty((N, S, S, K), dtype=torch.float32, device=dev)
+        qv = torch.empty((N, S, S, K), dtype=torch.float32, device=dev)
+        occ = torch.empty((N, S, S), dtype=torch.float32, device=dev)
+        p = _lib.ptr
+        _lib.call("iso_rasterize_fine", p(_f32c(points)), p(_f32c(ellipse_params)), p(_f32c(cutoff_thres)), p(_f32c(radii)),
+                  P, p(bin_points.to(torch.int32).contiguous()), N, M, float(depth_merging_thres), S, bs, K, p(idx), p(zbuf),
+                  p(qv), p(occ), _lib.stream())
+        return idx, zbuf, qv, occ
 
 
 _C = _CNamespace()
 
 
 # ----------------------------------------------------------------------------- autograd op
-def _visible_and_radius(idx, radii, first_idx, num_points, radii_s, max_pts=None):
+def _visible_and_radius(idx, radii, first_idx, num_points, radii_s, max_pts=None, vis=None, med_ws=None):
     """rasterizer.py:850-856,884: visible set + per-cloud r = median(visible radii) * radii_s,
-    computed on the device (sort + device-side index, no host sync)."""
+    computed on the device (sort + device-side index, no host sync).  vis: (P,) uint8 whose rows of the clouds are
+    already zero (the front end clears them: front_setup's "visible"); med_ws: the caller's own zero-on-entry
+    workspace for the median (see median_radius)."""
     P = radii.shape[0]
     dev = radii.device
-    vis = torch.zeros((P,), dtype=torch.uint8, device=dev)
+    if vis is None:
+        vis = torch.zeros((P,), dtype=torch.uint8, device=dev)
     npix = idx.numel() // idx.shape[-1]
     _lib.call("iso_splat_mark_visible", _lib.ptr(idx.contiguous()), npix, idx.shape[-1], _lib.ptr(vis),
               _lib.stream())
-    return vis, median_radius(vis, radii, first_idx, num_points, radii_s, max_pts=max_pts)
+    return vis, median_radius(vis, radii, first_idx, num_points, radii_s, max_pts=max_pts, ws=med_ws)
 
 
 _ZEROED = {}
@@ -286,22 +345,35 @@ _ZEROED = {}
 
 def _zeroed_workspace(tag, dev, nbytes):
     """A workspace for the entry points whose contract is "zero on entry, left zero on exit" (they clear what they
-    have read instead of starting with a clearing pass): cleared once, when it is first made, and kept per device
-    (a buffer made in eager mode keeps its address under graph capture and replay).  Calls that share one must be
-    ordered -- one stream, or streams the caller synchronises -- as torch's own cached workspaces require."""
-    key = (tag, dev.index, int(nbytes))
+    have read instead of starting with a clearing pass): cleared once, when it is first made, and kept per device AND
+    STREAM -- two calls on different streams would otherwise share counters in flight.  Never made while the stream is
+    capturing (the buffer would live in the graph's private pool and be handed to eager code later): a caller that
+    captures passes its own workspace (`ws=` of median_radius; IsoCycle does)."""
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (tag, dev.index, int(nbytes), int(stream))
     ws = _ZEROED.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("iso_points_amd: %s needs a zero-initialised workspace and none exists for this stream yet: "
+                               "allocate one before capturing and pass it (ws=...)" % tag)
         ws = torch.zeros((int(nbytes),), dtype=torch.uint8, device=dev)
         _ZEROED[key] = ws
     return ws
 
 
-def median_radius(vis, radii, first_idx, num_points, radii_s, max_pts=None):
-    """(N,) device tensor r_n = median(visible radii of cloud n) * radii_s (iso_splat_median_radius)."""
+def median_radius_workspace(n_clouds, dev):
+    """A private zero-on-entry / zero-on-exit workspace for median_radius (owners that capture graphs keep their own)."""
+    return torch.zeros((_lib.load().iso_splat_median_radius_workspace_bytes(int(n_clouds)),), dtype=torch.uint8, device=dev)
+
+
+def median_radius(vis, radii, first_idx, num_points, radii_s, max_pts=None, ws=None):
+    """(N,) device tensor r_n = median(visible radii of cloud n) * radii_s (iso_splat_median_radius).  ws: the caller's
+    own workspace (median_radius_workspace); default: one kept per device and stream."""
     dev = radii.device
     N = num_points.shape[0]
-    ws = _zeroed_workspace("median_radius", dev, _lib.load().iso_splat_median_radius_workspace_bytes(N))
+    own = ws is not None
+    if not own:
+        ws = _zeroed_workspace("median_radius", dev, _lib.load().iso_splat_median_radius_workspace_bytes(N))
     ws_b = ws.numel()
     out = torch.empty((N,), dtype=torch.float32, device=dev)
     p = _lib.ptr
@@ -310,7 +382,9 @@ def median_radius(vis, radii, first_idx, num_points, radii_s, max_pts=None):
                   int(max_pts) if max_pts is not None else _max_pts(num_points), float(radii_s), p(ws), ws_b, p(out),
                   _lib.stream())
     except Exception:
-        _ZEROED.pop(("median_radius", dev.index, ws_b), None)       # the histograms may be dirty: never reuse them
+        if not own:       # the histograms may be dirty: never reuse them
+            for k in [k for k, v in _ZEROED.items() if v is ws]:
+                _ZEROED.pop(k, None)
         raise
     return out
 
@@ -493,14 +567,18 @@ class SurfaceSplatting(object):
         feat_in = p(_f32c(features)) if (features is not None and not features_from_normals) else None
         if scanned is not None:
             ws, first, num, view_total = scanned
+            visible = torch.empty((cap,), dtype=torch.uint8, device=dev)       # rows of the clouds cleared by the launch
+            ovf = getattr(self, "_row_overflow", None)                         # sticky flag: rows beyond `capacity` dropped
+            if ovf is None or ovf.device != dev:
+                ovf = self._row_overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
             _lib.call("iso_splat_front_rows", p(points), p(normals), feat_in, C, int(bool(features_from_normals)), p(mask),
                       p(h), P, p(_f32c(views)), p(_f32c(projs)), N, min(image_hw(rs.image_size)),
                       float(rs.antialiasing_sigma), float(rs.cutoff_threshold), p(ws), ws.numel(), p(first), p(ndc),
                       p(ellipse), p(cutoff), p(radii), p(scaler), p(feat) if feat is not None else None, p(src),
-                      _lib.stream())
+                      p(visible), cap, p(ovf), _lib.stream())
             return {"ndc": ndc, "ellipse_params": ellipse, "cutoff_threshold": cutoff, "radii": radii, "scaler": scaler,
                     "features": feat, "src": src, "first_idx": first, "num_points": num, "view_total": view_total,
-                    "mask": mask, "h": h, "wire": out, "capacity": cap}
+                    "mask": mask, "h": h, "wire": out, "capacity": cap, "visible": visible, "row_overflow": ovf}
         first = torch.empty((N,), dtype=torch.int64, device=dev)
         num = torch.empty((N,), dtype=torch.int64, device=dev)
         view_total = torch.empty((8,), dtype=torch.int32, device=dev)

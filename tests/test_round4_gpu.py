@@ -153,3 +153,79 @@ def test_newton_tail_in_one_launch_equals_a_launch_per_iteration(dev, fitted, P,
         out, c = run(k)
         assert torch.equal(out.points, ref.points) and torch.equal(out.normals, ref.normals) and torch.equal(out.mask, ref.mask), k
         assert c == c_ref, (k, c, c_ref)
+
+
+def test_front_rows_respects_the_row_capacity(dev):
+    """rows beyond `capacity` are dropped and reported, never written (the arrays end there); the rows that
+    fit are the rows of the unbounded call, and the 'visible' flags of the rows come back cleared."""
+    from iso_points_amd import bricks
+    from iso_points_amd.cameras import look_at_view, perspective
+    from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    P, N = 30011, 3
+    pts = _cloud(P, 5, dev, jitter=0.02)
+    nrm = torch.nn.functional.normalize(pts, dim=-1).contiguous()
+    views = _views(dev, N)
+    projs = (views @ perspective(30.0).to(dev)).contiguous()
+    ss = SurfaceSplatting(raster_settings=PointsRasterizationSettings(image_size=128, points_per_pixel=8))
+    mask, cnt, scanned = bricks.view_mask_scan(pts, nrm, views)
+    grid = bricks.BrickGrid(P, dev).build(pts, nrm, payload=mask, radius=0.2, cell_scale=bricks.H_CELL_SCALE)
+    h = bricks.splat_h_fused(grid, mask, cnt, N)
+    full = ss.front_setup(pts, nrm, views, projs, mask, h, features_from_normals=True, scanned=scanned)
+    rows = int(full["num_points"].sum().item())
+    assert int(full["row_overflow"].item()) == 0 and (full["visible"][:rows] == 0).all()
+    cap = rows - 1234
+    guard = torch.full((12 * cap + 4096,), 7.0, device=dev)
+    small = ss.front_setup(pts, nrm, views, projs, mask, h, features_from_normals=True, scanned=scanned, out=guard, capacity=cap)
+    torch.cuda.synchronize()
+    assert int(small["row_overflow"].item()) == 1
+    assert (guard[12 * cap:] == 7.0).all()
+    # whole views that fit are identical; the view that is cut is identical up to the cut
+    first = full["first_idx"].tolist()
+    for k in ("ndc", "ellipse_params", "radii", "scaler"):
+        v0 = min(int(first[1]), cap)
+        assert torch.equal(small[k][:v0], full[k][:v0]), k
+    ss._row_overflow = None
+
+
+@pytest.mark.parametrize("S,bin_size,P,K", [(64, 16, 3000, 8), (100, 32, 20000, 5), (256, 16, 40000, 8), (33, 8, 500, 3)])
+def test_rasterize_fine_of_coarse_is_splat_points(dev, S, bin_size, P, K):
+    """DSS._C._rasterize_coarse / _rasterize_fine (ext.cpp:11-12): the bin table against a numpy restatement of
+    rasterize_points.cu:341-385 (same float32 expressions), and fine(coarse(x)) == splat_points(x) bit for bit."""
+    import numpy as np
+    from iso_points_amd.rasterizer import _C
+    from splat_util import random_splats
+    sc = random_splats(P, N=2, seed=S + P)
+    pts, el, cut, rad, first, num = (sc[k].to(dev) for k in ("ndc", "ellipse", "cutoff", "radii", "first", "num"))
+    M = int(num.max().item())
+    bins = _C._rasterize_coarse(pts, rad, first, num, S, bin_size, M)
+    B = 1 + (S - 1) // bin_size
+    assert bins.shape == (2, B, B, M) and bins.dtype == torch.int32
+    # numpy restatement (float32 throughout)
+    p, r = pts.cpu().numpy().astype(np.float32), rad.cpu().numpy().astype(np.float32)
+    f32 = np.float32
+    half = f32(1.0) / f32(S)
+    def ndc(i):
+        return f32(-1) + (f32(2 * i) + f32(1.0)) / f32(S)
+    got = bins.cpu().numpy()
+    for n in range(2):
+        a, b = int(first[n]), int(first[n] + num[n])
+        px0, px1 = p[a:b, 0] - r[a:b, 0], p[a:b, 0] + r[a:b, 0]
+        py0, py1 = p[a:b, 1] - r[a:b, 1], p[a:b, 1] + r[a:b, 1]
+        front = ~(p[a:b, 2] < 0)
+        for by in range(B):
+            y0, y1 = ndc(by * bin_size) - half, ndc((by + 1) * bin_size - 1) + half
+            for bx in range(B):
+                x0, x1 = ndc(bx * bin_size) - half, ndc((bx + 1) * bin_size - 1) + half
+                hit = front & (py0 <= y1) & (y0 <= py1) & (px0 <= x1) & (x0 <= px1)
+                want = (np.nonzero(hit)[0] + a).astype(np.int32)
+                row = got[n, by, bx]
+                assert (row[:len(want)] == want).all() and (row[len(want):] == -1).all(), (n, by, bx)
+    ref = _C.splat_points(pts, el, cut, rad, first, num, 0.05, S, K, 0, 0)
+    out = _C._rasterize_fine(pts, el, cut, rad, bins, 0.05, S, bin_size, K)
+    for a, b, name in zip(out, ref, ("idx", "zbuf", "qvalue", "occupancy")):
+        assert torch.equal(a, b), name
+    # the reference's limits: too many bins per side, too many points in a bin
+    with pytest.raises(RuntimeError):
+        _C._rasterize_coarse(pts, rad, first, num, 512, 16, 8)
+    with pytest.raises(RuntimeError):
+        _C._rasterize_coarse(pts, rad, first, num, S, bin_size, 3)
