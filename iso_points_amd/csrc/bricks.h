@@ -29,11 +29,13 @@ struct BrickHdr {                      // device resident, 32 dwords
   int pad1[2];                         // 30..31
 };
 
-// counters per brick (a power of two <= 8; a brick's records are the union of its counters' ranges).  Eight spread the
-// same-address atomics of the counting pass when it issued one per point; since it aggregates per workgroup in LDS
-// one is faster in every case measured (scan / zero / list walk an eighth of the table: 1.876 -> 1.833 ms per
-// cfg-3a cycle; unsorted 1 M-point cloud: build 0.137 -> 0.123 ms).
-constexpr int BK_CPB = 1;
+// Counters per brick: one per SUB-BRICK of 2x2x2 fine cells (sub = (sx * 2 + sy) * 2 + sz, sx = bit 1 of the fine x cell
+// inside the brick, ...): the records of brick b are [off[8 b], off[8 (b + 1)]), those of its sub-brick s
+// [off[8 b + s], off[8 b + s + 1]).  A workgroup that stages brick b + one fine cell of halo then loads, of a neighbouring
+// brick, only the sub-bricks that touch b -- half of a face neighbour, a quarter of an edge neighbour, an eighth of a
+// corner neighbour: 4 bricks' worth of records on a surface instead of 9 (the loads and cell counts of the staging were
+// 35 % of the bandwidth kernel and 18 % of the resample kernel).
+constexpr int BK_CPB = 8;
 constexpr int BK_CAP = 1024;           // staged candidates per brick (10-bit slot field of the selection keys)
 constexpr int BK_THREADS = 256;
 constexpr int BK_NB_MAX = 160;         // bricks per axis, hard cap

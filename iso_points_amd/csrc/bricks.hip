@@ -43,7 +43,7 @@ BrickWs bricks_carve(void* ws, int64_t n_max) {
   w.rec1 = (float4*)(p + o); o += al(16 * n_max);
   w.list = (int32_t*)(p + o); o += al(4 * (w.G < n_max ? w.G : n_max));
   w.tail = (int32_t*)(p + o); o += al(4 * 8 * n_max);
-  w.scan_ws_bytes = iso_prefix_sum_workspace_bytes(w.G, 1) + 4 * (kScan1MaxWords + (w.G + 2047) / 2048);
+  w.scan_ws_bytes = iso_prefix_sum_workspace_bytes(w.G, 1) + 4 * (kScan1MaxWords + (w.G + 1023) / 1024);
   w.scan_ws = (void*)(p + o); o += al(w.scan_ws_bytes);
   w.bytes = o;
   return w;
@@ -133,13 +133,21 @@ __device__ __forceinline__ int brick_of(const BrickHdr& h, float x, float y, flo
   const int fz = bk_fine(z, h.mn[2], h.inv_f, h.nf[2]);
   return ((fx >> 2) * h.nb[1] + (fy >> 2)) * h.nb[2] + (fz >> 2);
 }
+// counter of a point: BK_CPB * brick + sub-brick (bricks.h)
+__device__ __forceinline__ int counter_of(const BrickHdr& h, float x, float y, float z) {
+  const int fx = bk_fine(x, h.mn[0], h.inv_f, h.nf[0]);
+  const int fy = bk_fine(y, h.mn[1], h.inv_f, h.nf[1]);
+  const int fz = bk_fine(z, h.mn[2], h.inv_f, h.nf[2]);
+  const int brick = ((fx >> 2) * h.nb[1] + (fy >> 2)) * h.nb[2] + (fz >> 2);
+  return BK_CPB * brick + ((((fx >> 1) & 1) * 2 + ((fy >> 1) & 1)) * 2 + ((fz >> 1) & 1));
+}
 
 // Arrival slot of a record inside its brick (own points: packed (n,3) f32; imported halo records: float4).  The records
 // of brick b are [off[BK_CPB b], off[BK_CPB (b + 1)]) whatever the order inside.  A workgroup first counts its 1024
 // records per brick in an LDS hash table and then reserves each brick's range with ONE returning global atomic (a
 // record order with any spatial coherence -- the cycle's clouds run along a z-order curve -- puts many of a round's
 // records in the same brick; one returning atomic per record was the whole cost of this pass).  All records of a
-// workgroup use the same one of the brick's BK_CPB counters; slot = rank | counter << 28; a record that finds no table
+// workgroup that fall into one counter (sub-brick) get consecutive ranks; slot = rank; a record that finds no table
 // entry within kCntProbe probes takes its rank from global memory directly.
 constexpr int kCntTab = 2048, kCntProbe = 16;
 
@@ -147,7 +155,6 @@ constexpr int kCntTab = 2048, kCntProbe = 16;
 template <class Pos>
 __device__ __forceinline__ void brick_count_round(const BrickHdr& h, int64_t base, int64_t n, int32_t* __restrict__ cnt,
                                                   int32_t* __restrict__ slot_out, int* t_key, int* t_cnt, Pos&& pos) {
-  const int oct = blockIdx.x & (BK_CPB - 1);
   for (int j = threadIdx.x; j < kCntTab; j += 256) { t_key[j] = -1; t_cnt[j] = 0; }
   __syncthreads();
   int e[4], rk[4];
@@ -158,7 +165,7 @@ __device__ __forceinline__ void brick_count_round(const BrickHdr& h, int64_t bas
     if (i < n) {
       float x, y, z;
       pos(i, k, x, y, z);
-      const int key = BK_CPB * brick_of(h, x, y, z) + oct;
+      const int key = counter_of(h, x, y, z);
       unsigned at = ((unsigned)key * 2654435761u) >> 21;          // 11 bits
       bool found = false;
       for (int t = 0; t < kCntProbe && !found; ++t) {
@@ -179,7 +186,7 @@ __device__ __forceinline__ void brick_count_round(const BrickHdr& h, int64_t bas
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int64_t i = base + k * 256 + threadIdx.x;
-    if (i < n) slot_out[i] = ((e[k] >= 0 ? t_cnt[e[k]] : 0) + rk[k]) | (oct << 28);
+    if (i < n) slot_out[i] = (e[k] >= 0 ? t_cnt[e[k]] : 0) + rk[k];       // rank inside the point's counter (sub-brick)
   }
   __syncthreads();
 }
@@ -248,8 +255,7 @@ __global__ __launch_bounds__(256) void k_brick_scatter(const float* __restrict__
   const BrickHdr h = *hp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
-    const int sl = slot[i];                                           // rank | counter << 28 (k_brick_count)
-    const int64_t dst = (int64_t)off[BK_CPB * brick_of(h, x, y, z) + ((unsigned)sl >> 28)] + (sl & 0x0fffffff);
+    const int64_t dst = (int64_t)off[counter_of(h, x, y, z)] + slot[i];            // slot: rank inside the counter (k_brick_count)
     rec0[dst] = make_float4(x, y, z, __int_as_float(h.id_base + (int)i));
     float4 u = make_float4(0.f, 0.f, 0.f, __int_as_float(payload ? payload[i] : 0));
     if (nrm) { u.x = nrm[i * 3]; u.y = nrm[i * 3 + 1]; u.z = nrm[i * 3 + 2]; bk_unit_normal(u.x, u.y, u.z); }
@@ -265,8 +271,7 @@ __global__ __launch_bounds__(256) void k_brick_scatter_recs(const float4* __rest
   const int64_t m = h.n - h.n_own;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
     const float4 p = imp0[j];
-    const int sl = slot[h.n_own + j];
-    const int64_t dst = (int64_t)off[BK_CPB * brick_of(h, p.x, p.y, p.z) + ((unsigned)sl >> 28)] + (sl & 0x0fffffff);
+    const int64_t dst = (int64_t)off[counter_of(h, p.x, p.y, p.z)] + slot[h.n_own + j];
     rec0[dst] = p;
     float4 u = imp1[j];                                  // an exported record carries the raw normal
     bk_unit_normal(u.x, u.y, u.z);
@@ -279,8 +284,11 @@ __global__ __launch_bounds__(256) void k_brick_scatter_recs(const float4* __rest
 // block of the second pass adds up the totals of the chunks before it -- and the second pass also does what two
 // more launches did: it leaves the counters ZEROED for the next build and appends the occupied bricks to the work
 // list, one returning atomic per 2048 bricks; the order of the list only affects scheduling.)
-constexpr int BS_ITEMS = 8, BS_CHUNK = 256 * BS_ITEMS;
-static_assert(BK_CPB == 1, "the offsets pass lists brick i when counter i is non-zero");
+// The unit of the scan is the BRICK: a chunk is BS_CHUNK bricks (a thread takes BS_ITEMS of them, BK_CPB counters each, as
+// 16-byte loads), so that the number of chunks -- and of workgroups that wait for one another in the one-launch form -- stays
+// <= 2001 whatever BK_CPB is.
+constexpr int BS_ITEMS = 4, BS_CHUNK = 256 * BS_ITEMS;
+static_assert(BK_CPB == 8, "a brick's counters are two 16-byte words");
 
 __device__ __forceinline__ int block_excl_scan_256(int v, int& total, int* lds /*>= 4*/) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -295,18 +303,56 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int& total, int* lds /
   return base + inc - v;
 }
 
-__global__ __launch_bounds__(256) void k_brick_sums(const BrickHdr* __restrict__ hp, const int32_t* __restrict__ cnt,
-                                                    int32_t* __restrict__ sums) {
-  __shared__ int lds[4];
-  const int len = BK_CPB * hp->n_bricks + 1;
-  const int c0 = blockIdx.x * BS_CHUNK;
-  if (c0 >= len) return;
+// a thread's BS_ITEMS bricks of chunk `chunk`: their counters (zeroed behind the read when ZERO) and the brick totals
+template <bool ZERO>
+__device__ __forceinline__ int brick_counters_load(int32_t* __restrict__ cnt, int chunk, int nb, int (&c)[BS_ITEMS][BK_CPB],
+                                                   int (&tot)[BS_ITEMS]) {
   int v = 0;
 #pragma unroll
   for (int k = 0; k < BS_ITEMS; ++k) {
-    const int i = c0 + threadIdx.x * BS_ITEMS + k;
-    if (i < len) v += cnt[i];
+    const int brick = chunk * BS_CHUNK + threadIdx.x * BS_ITEMS + k;
+    tot[k] = 0;
+#pragma unroll
+    for (int q = 0; q < BK_CPB; ++q) c[k][q] = 0;
+    if (brick < nb) {
+      int4* p = reinterpret_cast<int4*>(cnt + (int64_t)BK_CPB * brick);
+      const int4 a = p[0], b = p[1];
+      c[k][0] = a.x; c[k][1] = a.y; c[k][2] = a.z; c[k][3] = a.w; c[k][4] = b.x; c[k][5] = b.y; c[k][6] = b.z; c[k][7] = b.w;
+      if (ZERO) { p[0] = make_int4(0, 0, 0, 0); p[1] = make_int4(0, 0, 0, 0); }
+#pragma unroll
+      for (int q = 0; q < BK_CPB; ++q) tot[k] += c[k][q];
+    }
+    v += tot[k];
   }
+  return v;
+}
+// offsets of those bricks' counters from the exclusive prefix `ex` of the thread, occupied bricks appended at list[at..]
+__device__ __forceinline__ void brick_offsets_store(int32_t* __restrict__ off, int32_t* __restrict__ list, int chunk, int nb,
+                                                    const int (&c)[BS_ITEMS][BK_CPB], const int (&tot)[BS_ITEMS], int ex, int at) {
+#pragma unroll
+  for (int k = 0; k < BS_ITEMS; ++k) {
+    const int brick = chunk * BS_CHUNK + threadIdx.x * BS_ITEMS + k;
+    if (brick < nb) {
+      int o[BK_CPB];
+#pragma unroll
+      for (int q = 0; q < BK_CPB; ++q) { o[q] = ex; ex += c[k][q]; }
+      int4* p = reinterpret_cast<int4*>(off + (int64_t)BK_CPB * brick);
+      p[0] = make_int4(o[0], o[1], o[2], o[3]);
+      p[1] = make_int4(o[4], o[5], o[6], o[7]);
+      if (tot[k] > 0) list[at++] = brick;
+    } else if (brick == nb) {
+      off[(int64_t)BK_CPB * nb] = ex;                    // the sentinel behind the last brick
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_brick_sums(const BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
+                                                    int32_t* __restrict__ sums) {
+  __shared__ int lds[4];
+  const int nb = hp->n_bricks;
+  if ((int)blockIdx.x * BS_CHUNK > nb) return;
+  int c[BS_ITEMS][BK_CPB], t[BS_ITEMS];
+  const int v = brick_counters_load<false>(cnt, blockIdx.x, nb, c, t);
   int tot;
   block_excl_scan_256(v, tot, lds);
   if (threadIdx.x == 0) sums[blockIdx.x] = tot;
@@ -317,43 +363,31 @@ __global__ __launch_bounds__(256) void k_brick_offsets(const BrickHdr* __restric
                                                        int32_t* __restrict__ list, int32_t* __restrict__ counters) {
   __shared__ int lds[4], s_base;
   const int nb = hp->n_bricks;
-  const int len = BK_CPB * nb + 1;
-  const int c0 = blockIdx.x * BS_CHUNK;
-  if (c0 >= len) return;
+  if ((int)blockIdx.x * BS_CHUNK > nb) return;           // (chunk nb / BS_CHUNK also holds the sentinel)
   if (blockIdx.x == 0) bk_box_clear(counters);
   int before = 0;
   for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) before += sums[i];
   int base;
   block_excl_scan_256(before, base, lds);                       // base = total of the chunks before this one
-  int vals[BS_ITEMS], v = 0, occ = 0;
+  int c[BS_ITEMS][BK_CPB], t[BS_ITEMS];
+  const int v = brick_counters_load<true>(cnt, blockIdx.x, nb, c, t);
+  int occ = 0;
 #pragma unroll
-  for (int k = 0; k < BS_ITEMS; ++k) {
-    const int i = c0 + threadIdx.x * BS_ITEMS + k;
-    vals[k] = 0;
-    if (i < len) { vals[k] = cnt[i]; cnt[i] = 0; }
-    v += vals[k];
-    occ += (vals[k] > 0 && i < nb) ? 1 : 0;
-  }
+  for (int k = 0; k < BS_ITEMS; ++k) occ += t[k] > 0 ? 1 : 0;
   int tot, occ_tot;
-  int ex = base + block_excl_scan_256(v, tot, lds);
+  const int ex = base + block_excl_scan_256(v, tot, lds);
   int at = block_excl_scan_256(occ, occ_tot, lds);
   if (threadIdx.x == 0) s_base = occ_tot ? atomicAdd(&counters[0], occ_tot) : 0;
   __syncthreads();
-  at += s_base;
-#pragma unroll
-  for (int k = 0; k < BS_ITEMS; ++k) {
-    const int i = c0 + threadIdx.x * BS_ITEMS + k;
-    if (i < len) off[i] = ex;
-    ex += vals[k];
-    if (vals[k] > 0 && i < nb) list[at++] = i;
-  }
+  brick_offsets_store(off, list, blockIdx.x, nb, c, t, ex, at + s_base);
 }
 
-// The two passes above as ONE launch for tables of up to kScan1Max chunks (2048 workgroups of this size are resident at
-// once -- 8 per CU --, so a workgroup may wait for the ones before it; BK_NB_MAX bricks per axis are 2001 chunks): a workgroup publishes its chunk total (bit 31 = "there") with an
-// agent-scope store, adds up the totals of the chunks before it as they appear (a few hundred words, polled by 256 lanes),
-// and goes on as k_brick_offsets does.  The workgroup that finishes last clears the totals: `sums` is zero on entry and
-// zero again on exit (iso_bricks_workspace_init clears it once).
+// The two passes above as ONE launch (2048 workgroups of this size are resident at once -- 8 per CU --, so a workgroup may
+// wait for the ones before it; BK_NB_MAX bricks per axis are <= 4001 chunks of which the first <= 2048 do the waiting: the
+// host takes the two-launch form beyond): a workgroup publishes its chunk total (bit 31 = "there") with an agent-scope
+// store, adds up the totals of the chunks before it as they appear (polled by 256 lanes), and goes on as k_brick_offsets
+// does.  The workgroup that finishes last clears the totals: `sums` is zero on entry and zero again on exit
+// (iso_bricks_workspace_init clears it once).
 constexpr int kScan1Max = 2048;
 static_assert(kScan1Max == kScan1MaxWords, "bricks_carve sizes the zeroed words");
 __global__ __launch_bounds__(256) void k_brick_offsets1(const BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
@@ -361,28 +395,22 @@ __global__ __launch_bounds__(256) void k_brick_offsets1(const BrickHdr* __restri
                                                         int32_t* __restrict__ list, int32_t* __restrict__ counters) {
   __shared__ int lds[4], s_base, s_last;
   const int nb = hp->n_bricks;
-  const int len = BK_CPB * nb + 1;
-  const int c0 = blockIdx.x * BS_CHUNK;
-  if (c0 >= len) return;
+  if ((int)blockIdx.x * BS_CHUNK > nb) return;
   if (blockIdx.x == 0) bk_box_clear(counters);      // every reader of the pending box (the count pass) is done
-  const int n_active = (len + BS_CHUNK - 1) / BS_CHUNK;
-  int vals[BS_ITEMS], v = 0, occ = 0;
+  const int n_active = nb / BS_CHUNK + 1;
+  int c[BS_ITEMS][BK_CPB], t[BS_ITEMS];
+  const int v = brick_counters_load<true>(cnt, blockIdx.x, nb, c, t);
+  int occ = 0;
 #pragma unroll
-  for (int k = 0; k < BS_ITEMS; ++k) {
-    const int i = c0 + threadIdx.x * BS_ITEMS + k;
-    vals[k] = 0;
-    if (i < len) { vals[k] = cnt[i]; cnt[i] = 0; }
-    v += vals[k];
-    occ += (vals[k] > 0 && i < nb) ? 1 : 0;
-  }
+  for (int k = 0; k < BS_ITEMS; ++k) occ += t[k] > 0 ? 1 : 0;
   int tot, occ_tot;
   int ex = block_excl_scan_256(v, tot, lds);
   if (threadIdx.x == 0) __hip_atomic_store(&sums[blockIdx.x], 0x80000000u | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int before = 0;
   for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) {
-    unsigned t;
-    while (!((t = __hip_atomic_load(&sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x80000000u)) __builtin_amdgcn_s_sleep(1);
-    before += (int)(t & 0x7fffffffu);
+    unsigned q;
+    while (!((q = __hip_atomic_load(&sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x80000000u)) __builtin_amdgcn_s_sleep(1);
+    before += (int)(q & 0x7fffffffu);
   }
   int base;
   block_excl_scan_256(before, base, lds);                       // base = total of the chunks before this one
@@ -390,14 +418,7 @@ __global__ __launch_bounds__(256) void k_brick_offsets1(const BrickHdr* __restri
   int at = block_excl_scan_256(occ, occ_tot, lds);
   if (threadIdx.x == 0) s_base = occ_tot ? atomicAdd(&counters[0], occ_tot) : 0;
   __syncthreads();
-  at += s_base;
-#pragma unroll
-  for (int k = 0; k < BS_ITEMS; ++k) {
-    const int i = c0 + threadIdx.x * BS_ITEMS + k;
-    if (i < len) off[i] = ex;
-    ex += vals[k];
-    if (vals[k] > 0 && i < nb) list[at++] = i;
-  }
+  brick_offsets_store(off, list, blockIdx.x, nb, c, t, ex, at + s_base);
   // everyone has read the totals it needs once it is here; the last one clears them
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -465,6 +486,10 @@ __device__ void chunk_scan_job(const ChunkScanJob& j) {
 // workgroup know fine cells only).  SUB = 2 (resample): a query walks a 4 x 4 x 4 window of HALF cells picked by the
 // half of its own half cell it lies in -- every point within 0.75 fine cells of the query is inside (1.5 half cells to
 // each face), 1.6 r wide at the 0.8 r cell against the 2.4 r of a 3 x 3 x 3 walk of whole cells: 44 % of the candidates.
+// Runs of the brick-sorted arrays a workgroup stages: per (x slot, y slot, neighbour in z) the sub-bricks that touch the
+// brick -- x slot 0..3 = (brick x - 1, sub x 1), (x, 0), (x, 1), (x + 1, 0); same in y; in z the whole sub-brick column of
+// the brick itself, the upper sub-bricks of the one below, the lower ones of the one above.
+constexpr int kStageRuns = 48;
 template <bool WITH_NRM, int SUB = 1, int CAP = BK_CAP>
 struct BrickStage {
   static constexpr int NL = 6 * SUB;                // local (sub-)cells per axis: the brick + one fine cell of halo
@@ -476,8 +501,8 @@ struct BrickStage {
   int gid[WITH_NRM ? 1 : CAP];
   int cstart[NCELL + 4];   // [NCELL + 1] used: local (sub-)cell -> first staged slot
   int ccur[NCELL];
-  int run_i0[9];
-  int run_pre[10];
+  int run_i0[kStageRuns];
+  int run_pre[kStageRuns + 1];
   int qbeg[NQRUN];
   int qpre[NQRUN + 1];
 };
@@ -520,30 +545,38 @@ __device__ int stage_brick(BrickStage<WITH_NRM, SUB, CAP>& S, const BrickHdr& h,
   __syncthreads();                                   // the previous brick's readers are done
   BK_PH(6);
   for (int c = tid; c < NCELL; c += BK_THREADS) S.ccur[c] = 0;
-  if (tid < 9) {
-    const int x = g.bx + tid / 3 - 1, y = g.by + tid % 3 - 1;
+  if (tid < kStageRuns) {
+    const int xs = tid / 12, ys = (tid / 3) % 4, dz = tid % 3 - 1;
+    const int x = g.bx + (xs + 1) / 2 - 1, sx = xs == 0 ? 1 : (xs == 3 ? 0 : xs - 1);      // xs 0..3 -> (dx, sub x) = (-1,1) (0,0) (0,1) (+1,0)
+    const int y = g.by + (ys + 1) / 2 - 1, sy = ys == 0 ? 1 : (ys == 3 ? 0 : ys - 1);
+    const int z = g.bz + dz;
     int i0 = 0, len = 0;
-    if (x >= 0 && x < nbx && y >= 0 && y < nby) {
-      const int z0 = max(g.bz - 1, 0), z1 = min(g.bz + 1, nbz - 1);
-      i0 = off[BK_CPB * ((x * nby + y) * nbz + z0)];
-      len = off[BK_CPB * ((x * nby + y) * nbz + z1 + 1)] - i0;
+    if (x >= 0 && x < nbx && y >= 0 && y < nby && z >= 0 && z < nbz) {
+      const int c = BK_CPB * ((x * nby + y) * nbz + z) + (sx * 2 + sy) * 2;
+      const int lo = dz < 0 ? 1 : 0, hi = dz > 0 ? 0 : 1;                // sub z: both of the own brick, the near one of a neighbour
+      i0 = off[c + lo];
+      len = off[c + hi + 1] - i0;
     }
     S.run_i0[tid] = i0;
     S.run_pre[tid + 1] = len;
   }
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    S.run_pre[0] = 0;
-    for (int k = 1; k <= 9; ++k) { run += S.run_pre[k]; S.run_pre[k] = run; }
+  if (tid < 64) {                                    // exclusive prefix of the run lengths (one wave)
+    const int len = tid < kStageRuns ? S.run_pre[tid + 1] : 0;
+    const int inc = wave_incl_scan_i(len);
+    if (tid < kStageRuns) S.run_pre[tid + 1] = inc;
+    if (tid == 0) S.run_pre[0] = 0;
   }
   __syncthreads();
   BK_PH(0);
-  const int total_raw = S.run_pre[9];
-  auto index_of = [&](int j) {
-    int run = 0;
-    while (j >= S.run_pre[run + 1]) ++run;
-    return S.run_i0[run] + (j - S.run_pre[run]);
+  const int total_raw = S.run_pre[kStageRuns];
+  auto index_of = [&](int j) {                       // the run r with run_pre[r] <= j < run_pre[r + 1]
+    int lo = 0, hi = kStageRuns;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (S.run_pre[mid] <= j) lo = mid; else hi = mid;
+    }
+    return S.run_i0[lo] + (j - S.run_pre[lo]);
   };
   auto cell_of = [&](const float4& p) {
     const int lx = bk_sub<SUB>(p.x, h.mn[0], h.inv_f, h.nf[0]) - SUB * g.ox;
@@ -1656,7 +1689,7 @@ static int bricks_fill(const BrickWs& w, const float* points, const float* norma
   if (import_max > 0)
     hipLaunchKernelGGL(k_brick_count_recs, dim3(iso_stream_grid(import_max, 1024)), dim3(256), 0, s,
                        (const float4*)import_rec0, import_count, import_max, w.hdr, w.cnt, w.slot);
-  const int chunks = (int)((w.G + BS_CHUNK - 1) / BS_CHUNK);
+  const int chunks = (int)(((w.G - 1) / BK_CPB + 1 + BS_CHUNK - 1) / BS_CHUNK);      // chunks of BS_CHUNK bricks (+ the sentinel)
   ISO_REQUIRE(w.scan_ws_bytes >= (int64_t)(chunks + kScan1Max) * 4, ISO_ERR_WORKSPACE, "iso_bricks_build: scan workspace too small");
   if (chunks <= kScan1Max) {            // one launch (the totals are zero on entry and left zero)
     hipLaunchKernelGGL(k_brick_offsets1, dim3(chunks), dim3(256), 0, s, w.hdr, w.cnt, w.off, (unsigned*)w.scan_ws, w.list,
