@@ -1047,16 +1047,22 @@ struct WalkGeo { float qx, qy, qz, mnx, mny, mnz, B; };
 // thousand stray queries).
 // part / nparts: the trips of a batch of columns are dealt out to nparts waves that walk the same shell (each of them
 // fetches the bounds and forms the prefix sums itself); 0 / 1 = one wave does everything.
-template <class Fetch, class Body, class Bound>
+// Two bounds.  bound(), asked once per 64 columns, decides which runs enter the index space the trips are dealt from: with
+// nparts > 1 it must return the SAME value in every cooperating wave (else the waves would number the records
+// differently and visit some twice and others never).  local(), asked before every trip, is the wave's own, sharper
+// knowledge (its lanes' K-th distance so far): runs whose box lies beyond it stay in the index space but are not loaded.
+template <class Fetch, class Body, class Bound, class Local>
 __device__ __forceinline__ void bk_walk_shell(int rin, int rho, int qbx, int qby, int qbz, int nbx, int nby, int nbz,
                                               const int32_t* __restrict__ off, int lane, const WalkGeo& G,
-                                              Fetch&& fetch, Body&& body, Bound&& bound, int part = 0, int nparts = 1) {
+                                              Fetch&& fetch, Body&& body, Bound&& bound, Local&& local,
+                                              int part = 0, int nparts = 1) {
   const int x0 = max(qbx - rho, 0), x1 = min(qbx + rho, nbx - 1);
   const int y0 = max(qby - rho, 0), y1 = min(qby + rho, nby - 1);
   if (x0 > x1 || y0 > y1) return;
   const int ny = y1 - y0 + 1, ncols = (x1 - x0 + 1) * ny;
   for (int c0 = 0; c0 < ncols; c0 += 64) {
     int s0 = 0, e0 = 0, s1 = 0, e1 = 0;                  // this lane's column: one z-run (edge) or two caps
+    float dm0 = FLT_MAX, dm1 = FLT_MAX;                  // squared distance from the query to the boxes of the runs
     const int col = c0 + lane;
     const float far2 = bound();
     // squared distance from the query to bricks [b0, b1] of one axis, shortened by a margin that covers the
@@ -1071,15 +1077,19 @@ __device__ __forceinline__ void bk_walk_shell(int rin, int rho, int qbx, int qby
       const int cb = (x * nby + y) * nbz;
       const float gx = gap(G.qx, G.mnx, x, x), gy = gap(G.qy, G.mny, y, y);
       const float gxy2 = gx * gx + gy * gy;
-      auto beyond = [&](int za, int zb) { const float gz = gap(G.qz, G.mnz, za, zb); return gxy2 + gz * gz > far2; };
+      auto box2 = [&](int za, int zb) { const float gz = gap(G.qz, G.mnz, za, zb); return gxy2 + gz * gz; };
+      // the bricks of the column that a ball of far2 around the query can reach (same margin as gap(): never too few)
+      const float dz = sqrtf(fmaxf(far2 - gxy2, 0.f)) + 1e-3f * G.B;
+      const int zc0 = (int)fmaxf(floorf((G.qz - dz - G.mnz) / G.B), 0.f);
+      const int zc1 = (int)fminf(floorf((G.qz + dz - G.mnz) / G.B), (float)(nbz - 1));
       if (edge) {
-        const int za = max(qbz - rho, 0), zb = min(qbz + rho, nbz - 1);
-        if (za <= zb && !beyond(za, zb)) { s0 = off[BK_CPB * (cb + za)]; e0 = off[BK_CPB * (cb + zb + 1)]; }
+        const int za = max(max(qbz - rho, 0), zc0), zb = min(min(qbz + rho, nbz - 1), zc1);
+        if (za <= zb && (dm0 = box2(za, zb)) <= far2) { s0 = off[BK_CPB * (cb + za)]; e0 = off[BK_CPB * (cb + zb + 1)]; }
       } else {                                            // two caps: below and above the inner cube
-        const int a0 = max(qbz - rho, 0), a1 = qbz - rin - 1;
-        const int b0 = qbz + rin + 1, b1 = min(qbz + rho, nbz - 1);
-        if (a0 <= a1 && !beyond(a0, a1)) { s0 = off[BK_CPB * (cb + a0)]; e0 = off[BK_CPB * (cb + a1 + 1)]; }
-        if (b0 <= b1 && !beyond(b0, b1)) { s1 = off[BK_CPB * (cb + b0)]; e1 = off[BK_CPB * (cb + b1 + 1)]; }
+        const int a0 = max(max(qbz - rho, 0), zc0), a1 = min(qbz - rin - 1, zc1);
+        const int b0 = max(qbz + rin + 1, zc0), b1 = min(min(qbz + rho, nbz - 1), zc1);
+        if (a0 <= a1 && (dm0 = box2(a0, a1)) <= far2) { s0 = off[BK_CPB * (cb + a0)]; e0 = off[BK_CPB * (cb + a1 + 1)]; }
+        if (b0 <= b1 && (dm1 = box2(b0, b1)) <= far2) { s1 = off[BK_CPB * (cb + b0)]; e1 = off[BK_CPB * (cb + b1 + 1)]; }
       }
     }
     // a lane finds the column of its item in the prefix sums of the column lengths
@@ -1090,6 +1100,8 @@ __device__ __forceinline__ void bk_walk_shell(int rin, int rho, int qbx, int qby
     const int ex = inc - len, total = __shfl(inc, 63);
     constexpr int NU = BK_WALK_ITEMS;                        // items per lane and trip: their loads overlap
     for (int j0 = part * 64 * NU; j0 < total; j0 += nparts * 64 * NU) {
+      const float near2 = local();
+      const int live = (dm0 <= near2 ? 1 : 0) | (dm1 <= near2 ? 2 : 0);
       int at[NU];
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -1102,8 +1114,10 @@ __device__ __forceinline__ void bk_walk_shell(int rin, int rho, int qbx, int qby
           if (cand < 64 && v <= j) c = cand;
         }
         const int cs0 = __shfl(s0, c), cl0 = __shfl(len0, c), cs1 = __shfl(s1, c), cex = __shfl(ex, c);
+        const int clive = __shfl(live, c);
         const int r = j - cex;
         at[u] = j < total ? (r < cl0 ? cs0 + r : cs1 + (r - cl0)) : -1;
+        if (!(clive & (r < cl0 ? 1 : 2))) at[u] = -1;
       }
       decltype(fetch(0)) rec[NU];                            // loads first (no control flow in between), then the work
 #pragma unroll
@@ -1115,11 +1129,12 @@ __device__ __forceinline__ void bk_walk_shell(int rin, int rho, int qbx, int qby
   }
 }
 
-template <class Fetch, class Body, class Bound>
+template <class Fetch, class Body, class Bound, class Local>
 __device__ __forceinline__ void bk_walk_ring(int rho, int qbx, int qby, int qbz, int nbx, int nby, int nbz,
                                              const int32_t* __restrict__ off, int lane, const WalkGeo& G,
-                                             Fetch&& fetch, Body&& body, Bound&& bound, int part = 0, int nparts = 1) {
-  bk_walk_shell(rho - 1, rho, qbx, qby, qbz, nbx, nby, nbz, off, lane, G, fetch, body, bound, part, nparts);
+                                             Fetch&& fetch, Body&& body, Bound&& bound, Local&& local,
+                                             int part = 0, int nparts = 1) {
+  bk_walk_shell(rho - 1, rho, qbx, qby, qbz, nbx, nby, nbz, off, lane, G, fetch, body, bound, local, part, nparts);
 }
 
 template <int KMAX>
@@ -1212,7 +1227,7 @@ __global__ __launch_bounds__(64) void k_brick_resample_tail(
             for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wd = best.d[j]; wi = best.id[j]; }
           }
         }
-      }, far2);
+      }, far2, far2);
       if (rho >= 1) {
         const float gg = (float)rho * B * 0.999f;
         if (gg >= h.r) break;
@@ -1472,6 +1487,13 @@ __device__ __forceinline__ void wave_merge_f7(const TopF<7>& best, float* out7) 
   }
 }
 
+// What the clamp of h_from_list makes of the search: 0.5 d2 >= 0.01 for every d2 >= kHSat, so a list that holds ANY
+// distance in [kHSat, r2) among its entries 1..6 gives h = 0.01 whatever the others are.  The tail search therefore keeps
+// exact distances only below kHSat and a flag "some renderable point lies in [kHSat, r2)": once the flag is up nothing
+// beyond sqrt(kHSat) = 0.141 can change the result (r = 0.2 in the reference's settings: half the shell's volume).
+// (0.5f * 0.02f == 0.01f exactly: the two constants share their mantissa.)
+constexpr float kHSat = 0.02f;
+
 // One WORKGROUP of four waves per uncertified (query, view): a stray point of the SIREN level set finds nothing nearby and
 // scans the whole shell of bricks up to the radius -- ~10 k records, a chain of ~20 batches of loads for one wave, and the
 // longest such chain is what the launch takes (120 us in the SIREN cycle however many workgroups share the few thousand
@@ -1486,7 +1508,7 @@ __global__ __launch_bounds__(64 * kTailWaves) void k_brick_h_tail(
     const float4* __restrict__ rec1, const float* __restrict__ pts, const int32_t* __restrict__ mask,
     const int32_t* __restrict__ view_total, int n_views, float* __restrict__ h_out,
     const int32_t* __restrict__ tail, const int32_t* __restrict__ counters) {
-  __shared__ float s_m7[2][kTailWaves][8];
+  __shared__ float s_m7[2][kTailWaves][8];     // [.][.][7]: the wave saw a distance in [kHSat, r2)
   const BrickHdr h = *hp;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int count = counters[3];
@@ -1506,54 +1528,67 @@ __global__ __launch_bounds__(64 * kTailWaves) void k_brick_h_tail(
     float m7[7];
     const WalkGeo geo = {qx, qy, qz, h.mn[0], h.mn[1], h.mn[2], B};
     float kth_seen = FLT_MAX;
-    auto far2 = [&]() {                                     // a lane's own 7th distance bounds the query's
+    bool sat = false;                                       // this lane met a distance in [kHSat, r2)
+    bool sat_any = false;                                   // ... some lane of the workgroup did (as far as this wave knows)
+    bool sat_all = false;                                   // sat_any as of the last pool(): the same in every wave
+    auto far2 = [&]() {                                     // a lane's own 7th distance bounds the query's (this wave's view)
       float m = best.d[6];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
-      return fminf(h.r2, fminf(m, kth_seen));
+      sat_any = sat_any || __any(sat);
+      return fminf(sat_any ? kHSat : h.r2, fminf(m, kth_seen));
     };
+    auto far2_all = [&]() { return fminf(sat_all ? kHSat : h.r2, kth_seen); };    // what all four waves agree on
     // the seven smallest distances of the workgroup: every wave's seven through LDS, then one more selection
     auto pool = [&]() {
       wave_merge_f7(best, m7);
-      if (lane < 7) {
+      sat_any = sat_any || __any(sat);
+      if (lane < 8) {
         float mine = m7[0];
 #pragma unroll
         for (int k = 1; k < 7; ++k) mine = lane == k ? m7[k] : mine;
-        s_m7[pool_buf][wave][lane] = mine;
+        s_m7[pool_buf][wave][lane] = lane == 7 ? (sat_any ? 1.f : 0.f) : mine;
       }
       __syncthreads();
       TopF<7> all;
       all.init();
       if (lane < 7 * kTailWaves) all.push(s_m7[pool_buf][lane / 7][lane % 7]);
       wave_merge_f7(all, m7);
+#pragma unroll
+      for (int k = 0; k < kTailWaves; ++k) sat_any = sat_any || s_m7[pool_buf][k][7] != 0.f;
+      sat_all = sat_any;
       pool_buf ^= 1;                                        // (the next pool writes the other buffer: no second barrier)
     };
     auto fetch = [&](int i) { float4 c = rec0[i]; c.w = rec1[i].w; return c; };          // position + view mask
     auto visit = [&](int, const float4& c) {
       if (!((__float_as_int(c.w) >> v) & 1)) return;
       const float d2 = bk_d2(qx, qy, qz, c.x, c.y, c.z);
-      if (d2 < h.r2) best.push(d2);
+      if (d2 < kHSat) { if (d2 < h.r2) best.push(d2); }
+      else if (d2 < h.r2) sat = true;
     };
     // rings 0 and 1 one after the other (most queries end there); a query that is still open -- a stray point -- takes
     // every remaining ring up to the radius as one shell (bk_walk_shell)
     int rho_r = 1;                                          // first ring whose guarantee rho * B covers the radius
     while (rho_r < rho_max && (float)rho_r * B * 0.999f < h.r) ++rho_r;
     for (int rho = 0; rho <= min(1, rho_max); ++rho) {
-      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, fetch, visit, far2, wave, kTailWaves);
+      bk_walk_ring(rho, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, fetch, visit, far2_all, far2, wave, kTailWaves);
       if (rho >= 1) {
         const float gg = (float)rho * B * 0.999f;
         if (gg >= h.r) { rho_r = 1; break; }
         pool();
         kth_seen = fminf(kth_seen, m7[6]);
         if (m7[6] < FLT_MAX && m7[6] <= gg * gg) { rho_r = 1; break; }
+        if (sat_any && kHSat <= gg * gg) { rho_r = 1; break; }          // everything below kHSat was seen
       }
     }
     if (rho_r > 1)
-      bk_walk_shell(1, rho_r, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, fetch, visit, far2, wave, kTailWaves);
+      bk_walk_shell(1, rho_r, qbx, qby, qbz, h.nb[0], h.nb[1], h.nb[2], off, lane, geo, fetch, visit, far2_all, far2, wave, kTailWaves);
     pool();
     if (threadIdx.x == 0) {
-      h_out[(int64_t)v * h.n_own + row] = h_from_list(m7, small_cloud);
-      const float need = m7[6] < FLT_MAX ? sqrtf(m7[6]) : h.r;
+      // fewer than seven below kHSat and something in [kHSat, r2): entry 1..6 of the full list holds a value >= kHSat
+      const bool saturated = m7[6] == FLT_MAX && sat_any && !small_cloud;
+      h_out[(int64_t)v * h.n_own + row] = saturated ? 0.01f : h_from_list(m7, small_cloud);
+      const float need = m7[6] < FLT_MAX ? sqrtf(m7[6]) : (sat_any ? fminf(sqrtf(kHSat), h.r) : h.r);
       if (!small_cloud && (qx - need < h.x_lo || qx + need >= h.x_hi)) atomicAdd(const_cast<int32_t*>(&counters[6]), 1);
     }
   }

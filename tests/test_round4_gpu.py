@@ -229,3 +229,67 @@ def test_rasterize_fine_of_coarse_is_splat_points(dev, S, bin_size, P, K):
         _C._rasterize_coarse(pts, rad, first, num, 512, 16, 8)
     with pytest.raises(RuntimeError):
         _C._rasterize_coarse(pts, rad, first, num, S, bin_size, 3)
+
+
+def _h_fused_vs_standalone(dev, pts, nrm, n_views, cell_scale=None, image_size=64):
+    """splat_h_fused against the K = 7 query of each filtered view cloud + vrk_h (rasterizer.py:256-300 of the
+    reference); returns the grid header."""
+    from iso_points_amd.bricks import BrickGrid, H_CELL_SCALE, splat_h_fused, view_mask
+    from iso_points_amd.cameras import look_at_view
+    from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting
+    from iso_points_amd.levelset_sampling import with_host_lengths
+    P = pts.shape[0]
+    views = torch.stack([look_at_view(3.0, 20.0, 360.0 / n_views * i) for i in range(n_views)]).to(dev).contiguous()
+    ss = SurfaceSplatting(raster_settings=PointsRasterizationSettings(image_size=image_size))
+    flags, off, lens = ss.filter_renderable(pts, nrm, views)
+    tot = sum(lens)
+    mask, cnt = view_mask(pts, nrm, views)
+    grid = BrickGrid(P, dev).build(pts, nrm, payload=mask, radius=ss.frnn_radius,
+                                   cell_scale=H_CELL_SCALE if cell_scale is None else cell_scale)
+    h = splat_h_fused(grid, mask, cnt, n_views)
+    first = [sum(lens[:i]) for i in range(n_views)]
+    num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
+    fst = with_host_lengths(torch.tensor(first, dtype=torch.int64, device=dev), first)
+    ss.per_point_info(ss.compact(pts, flags, off, P, tot), ss.compact(nrm, flags, off, P, tot), fst, num, views, views)
+    fl = flags[:-1].view(n_views, P).bool()
+    got = torch.cat([h[v][fl[v]] for v in range(n_views)])
+    bad = (got != ss._Vrk_h).nonzero().flatten()
+    assert bad.numel() == 0, (bad.numel(), got[bad[:8]].tolist(), ss._Vrk_h[bad[:8]].tolist())
+    return grid.header()
+
+
+def test_h_tail_stray_points_at_every_distance(dev):
+    """The bandwidth tail search keeps exact distances only below 0.02 (where the clamp of vrk_h still lets them through)
+    and otherwise asks whether ANY renderable point lies in [0.02, r^2): stray points at distances on both sides of
+    sqrt(0.02) = 0.1414 and of r = 0.2 from a dense sphere, stray pairs / triples whose mutual distances straddle the
+    same marks, far from anything else."""
+    g = torch.Generator().manual_seed(41)
+    base = torch.nn.functional.normalize(torch.randn(60000, 3, generator=g), dim=-1)
+    stray = []
+    for k, d in enumerate([0.02, 0.05, 0.1, 0.13, 0.1405, 0.1414, 0.1416, 0.142, 0.15, 0.19, 0.1999, 0.2, 0.2001, 0.25, 0.4]):
+        u = torch.nn.functional.normalize(torch.randn(40, 3, generator=g), dim=-1)
+        stray.append(u * (1.0 + d))
+        stray.append(u[:10] * (1.0 - d))
+    far = torch.tensor([[3.0, 0.0, 0.0], [0.0, 3.0, 0.5], [0.0, -3.0, 0.5], [2.0, 2.0, 2.0]])
+    groups = []
+    for c, d in zip(far, [0.05, 0.141, 0.142, 0.199]):                  # pairs and a triple, isolated from the sphere
+        groups += [c[None], c[None] + torch.tensor([[d, 0.0, 0.0]]), c[None] + torch.tensor([[0.0, 0.21, 0.0]])]
+    pts = torch.cat([base] + stray + groups)
+    pts = pts[torch.randperm(pts.shape[0], generator=g)]
+    nrm = torch.nn.functional.normalize(pts, dim=-1)
+    hdr = _h_fused_vs_standalone(dev, pts.to(dev).contiguous(), nrm.to(dev).contiguous(), 4)
+    assert hdr["tail_h"] > 100, hdr
+
+
+def test_h_tail_of_overfull_bricks(dev):
+    """Bricks too full to stage send all their queries to the tail kernel, whose four waves then share thousands of
+    records per ring: every record must be visited exactly once whatever each wave has found so far."""
+    g = torch.Generator().manual_seed(42)
+    base = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g), dim=-1)
+    clump = torch.tensor([[0.0, 0.0, 1.0]]) + 0.004 * torch.randn(6000, 3, generator=g)       # 6000 points in one brick
+    clump2 = torch.tensor([[0.6, 0.0, 0.8]]) + 0.02 * torch.randn(9000, 3, generator=g)
+    pts = torch.cat([base, clump, clump2])
+    pts = pts[torch.randperm(pts.shape[0], generator=g)]
+    nrm = torch.nn.functional.normalize(pts, dim=-1)
+    hdr = _h_fused_vs_standalone(dev, pts.to(dev).contiguous(), nrm.to(dev).contiguous(), 3)
+    assert hdr["overflow_bricks"] > 0 and hdr["tail_h"] > 1000, hdr

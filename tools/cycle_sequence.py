@@ -9,7 +9,11 @@ def main():
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
     # the last occurrence of the first kernel of a cycle (k_project_sphere: two per cycle -> take the one before last pair)
     marks = [i for i, r in enumerate(rows) if "k_project_sphere" in r[0]]
-    a, b = marks[-4], marks[-2]                 # one full cycle: from its first projection to the next cycle's
+    if marks:
+        a, b = marks[-4], marks[-2]             # one full cycle: from its first projection to the next cycle's
+    else:                                       # SIREN cycle: its first projection packs the weights (k_siren_wscale)
+        marks = [i for i, r in enumerate(rows) if "k_siren_wscale" in r[0]]
+        a, b = marks[-3], marks[-2]
     seq = rows[a:b]
     t0 = seq[0][1]
     lines, prev_end, busy = [], seq[0][1], 0.0

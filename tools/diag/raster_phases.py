@@ -9,7 +9,8 @@ from iso_points_amd import _lib
 from iso_points_amd.dist import Comm
 from iso_points_amd.sdf_models import SphereSDF
 dev = torch.device("cuda:0")
-cyc = bench.Cycle(dev, SphereSDF().to(dev), Comm(enabled=False))
+siren = "siren" in sys.argv[1:]        # the headline cycle instead of cfg 3a
+cyc = bench.Cycle(dev, bench.fitted_siren(dev) if siren else SphereSDF().to(dev), Comm(enabled=False))
 cyc.cyc.use_graphs = False
 lib = _lib.load()
 buf = (ctypes.c_double * 16)()
