@@ -600,6 +600,10 @@ int64_t iso_bricks_workspace_bytes(int64_t n_max);
  * adds what it resets -- so that a caller can check the overflow / certification counters of a whole cycle of several
  * grids with one read afterwards.                                                                    */
 int iso_bricks_workspace_init(void* workspace, int64_t n_max, void* stream);
+/* Diagnostic, synchronises `stream`: ISO_ERR_INVALID when iso_bricks_workspace_init never ran on this workspace (it
+ * leaves a mark in the counter block).  A build on such a workspace counts into whatever the memory held and gives a
+ * wrong grid with no other sign; the builds themselves cannot check (the mark lives on the device).             */
+int iso_bricks_workspace_check(const void* workspace, int64_t n_max, void* stream);
 /* iso_bricks_build for ONE rank that holds the whole cloud (n_total = n, id_base = 0, no imports): the bounding box
  * is taken by the build itself -- no iso_points_bbox pass, no 8-float round trip (six launches per grid instead of
  * twelve).  Same grid, same results as iso_points_bbox + iso_bricks_build.                          */

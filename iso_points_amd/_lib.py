@@ -89,6 +89,7 @@ SIGNATURES = {
     "iso_splat_zbuf_backward": (_I, [_P, _P, _L, _I, _P, _P]),
     "iso_bricks_workspace_bytes": (_L, [_L]),
     "iso_bricks_workspace_init": (_I, [_P, _L, _P]),
+    "iso_bricks_workspace_check": (_I, [_P, _L, _P]),
     "iso_bricks_build_whole": (_I, [_P, _P, _P, _L, _F, _I, _F, _P, _L, _P]),
     "iso_bricks_build_pending": (_I, [_P, _P, _P, _L, _F, _I, _F, _P, _L, _P, _P]),
     "iso_bricks_box_take": (_I, [_P, _L, _P, _P]),

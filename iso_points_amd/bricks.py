@@ -96,7 +96,12 @@ class BrickGrid(object):
         self._seen = tot
         return out
 
+    def check_initialised(self):
+        """Raises when iso_bricks_workspace_init never ran on the workspace (host sync; include/isopoints.h)."""
+        _lib.call("iso_bricks_workspace_check", _lib.ptr(self.ws), self.n_max, _lib.stream())
+
     def header(self):
+        self.check_initialised()
         raw = self.ws[:128].cpu()
         f = raw.view(torch.float32).tolist()
         i = raw.view(torch.int32).tolist()

@@ -1713,6 +1713,21 @@ extern "C" int iso_bricks_workspace_init(void* workspace, int64_t n_max, void* s
   return ISO_OK;
 }
 
+// Diagnostic (synchronises the stream): did iso_bricks_workspace_init ever run on this workspace?  A build on a workspace
+// that was never initialised counts into whatever the memory held and produces a wrong grid without any other sign.
+extern "C" int iso_bricks_workspace_check(const void* workspace, int64_t n_max, void* stream) {
+  ISO_REQUIRE(workspace && n_max >= 0, ISO_ERR_INVALID, "iso_bricks_workspace_check: bad arguments");
+  ISO_REQUIRE(((uintptr_t)workspace & 255) == 0, ISO_ERR_INVALID, "iso_bricks_workspace_check: workspace must be 256-B aligned");
+  const BrickWs w = bricks_carve(const_cast<void*>(workspace), n_max);
+  int32_t magic = 0;
+  ISO_REQUIRE(hipMemcpyAsync(&magic, w.counters + kMagicAt, sizeof(magic), hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
+                  hipStreamSynchronize((hipStream_t)stream) == hipSuccess,
+              ISO_ERR_LAUNCH, "iso_bricks_workspace_check: could not read the workspace");
+  ISO_REQUIRE(magic == kBrickMagic, ISO_ERR_INVALID,
+              "iso_bricks_workspace_check: the workspace was never initialised (iso_bricks_workspace_init)");
+  return ISO_OK;
+}
+
 // count -> offsets (+ work list, counters left zeroed) -> scatter, on a header that is already written
 static int bricks_fill(const BrickWs& w, const float* points, const float* normals, const int32_t* payload, int64_t n_own,
                        const float* import_rec0, const float* import_rec1, const int32_t* import_count,

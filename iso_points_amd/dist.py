@@ -345,6 +345,7 @@ class IsoCycle(object):
                             capacity=self.rec_cap, scanned=scanned)
         if w == 1:
             fr["own_first"], fr["own_num"], fr["max_pts"], fr["rows"] = fr["first_idx"], fr["num_points"], self.P, self.rec_cap
+            fr["local_first"] = fr["first_idx"]
             return fr
         # the band exchange (csrc/band.hip): every own row goes to the ranks whose band of tile rows it touches
         p, lib_call = _lib.ptr, _lib.call
@@ -417,8 +418,10 @@ class IsoCycle(object):
     # -- stage 4: compositing + loss gradient + backward ------------------------------------------
     def backward(self, frags, fr, occ_grad_band, zbuf_grad_band):
         """occ_grad / zbuf_grad are valid on this rank's band (zero elsewhere).  Returns grad (rows,3):
-        d loss / d (NDC x, y, z) of this rank's OWN packed rows fr['own_first'][v] .. + fr['own_num'][v]
-        (all rows for world == 1); fr['src'] maps own rows to own points."""
+        d loss / d (NDC x, y, z) of this rank's OWN packed rows, in the layout of the rank's own arrays: view v's rows
+        are fr['local_first'][v] .. + fr['own_num'][v] (fr['own_first'] is their place in the GLOBAL layout of all ranks'
+        rows, which no tensor on a rank has; for world == 1 the two coincide and cover all rows); fr['src'] maps own rows
+        to own points."""
         idx = frags.idx
         N, S, _, K = idx.shape
         first, num = fr["first_idx"], fr["num_points"]

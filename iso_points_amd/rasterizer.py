@@ -532,9 +532,16 @@ class SurfaceSplatting(object):
         dev = points.device
         mask, cnt, scanned = bricks.view_mask_scan(points, normals, views, self.znear, self.zfar, rs.backface_culling)
         if grid is None:
-            grid = getattr(self, "_grid", None)              # kept between calls (allocated and cleared once per size)
-            if grid is None or grid.n_own != P or grid.ws.device != dev:
-                grid = self._grid = bricks.BrickGrid(P, dev)
+            # kept between calls, one per cloud size (a workspace is laid out for ITS size and starts from cleared
+            # counters: allocated and cleared once); a batch of clouds of different sizes alternates between a few
+            grids = self.__dict__.setdefault("_grids", {})
+            key = (P, str(dev))
+            grid = grids.pop(key, None)
+            if grid is None:
+                while len(grids) >= 4:
+                    grids.pop(next(iter(grids)))             # the least recently used size
+                grid = bricks.BrickGrid(P, dev)
+            grids[key] = grid                                # most recently used last
         grid.build(points, normals, payload=mask, radius=float(self.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
         h = bricks.splat_h_fused(grid, mask, cnt, N)
         return self.front_setup(points, normals, views, projs, mask, h, features, features_from_normals, out, capacity,
@@ -612,21 +619,34 @@ class SurfaceSplatting(object):
             return [(points, normals, features)]
         cloud = points
         B = len(cloud)
-        feats = None
-        if features is not None:
-            feats = [features] if B == 1 else None
         if B == 1:
-            f = feats[0] if feats else (cloud.features_packed() if hasattr(cloud, "features_packed") else None)
+            f = features if features is not None else (cloud.features_packed() if hasattr(cloud, "features_packed") else None)
             return [(cloud.points_packed(), cloud.normals_packed(), f)]
         if hasattr(cloud, "points_list"):
             pl, nl = cloud.points_list(), cloud.normals_list()
             fl = cloud.features_list() if hasattr(cloud, "features_list") else None
-            return [(pl[b], nl[b], fl[b] if fl else None) for b in range(B)]
-        first = [int(x) for x in cloud.cloud_to_packed_first_idx().tolist()]
-        num = [int(x) for x in cloud.num_points_per_cloud().tolist()]
-        pp, nn = cloud.points_packed(), cloud.normals_packed()
-        ff = cloud.features_packed() if hasattr(cloud, "features_packed") else None
-        return [(pp[f0:f0 + n], nn[f0:f0 + n], ff[f0:f0 + n] if ff is not None else None) for f0, n in zip(first, num)]
+            num = [int(x.shape[0]) for x in pl]
+        else:
+            first = [int(x) for x in cloud.cloud_to_packed_first_idx().tolist()]
+            num = [int(x) for x in cloud.num_points_per_cloud().tolist()]
+            pp, nn = cloud.points_packed(), cloud.normals_packed()
+            ff = cloud.features_packed() if hasattr(cloud, "features_packed") else None
+            pl, nl = [pp[f0:f0 + n] for f0, n in zip(first, num)], [nn[f0:f0 + n] for f0, n in zip(first, num)]
+            fl = [ff[f0:f0 + n] for f0, n in zip(first, num)] if ff is not None else None
+        if features is not None:
+            # features= beside a container of B clouds: a list of B tensors, or ONE packed tensor in the container's
+            # cloud order (split at the cloud lengths) -- anything else is an error, never silently dropped
+            if isinstance(features, (list, tuple)):
+                if len(features) != B or any(int(f.shape[0]) != n for f, n in zip(features, num)):
+                    raise ValueError("features: expected %d tensors of %s rows" % (B, num))
+                fl = list(features)
+            else:
+                if int(features.shape[0]) != sum(num):
+                    raise ValueError("features: a packed tensor for %d clouds needs %d rows, got %d"
+                                     % (B, sum(num), int(features.shape[0])))
+                at = [sum(num[:b]) for b in range(B)]
+                fl = [features[a:a + n] for a, n in zip(at, num)]
+        return [(pl[b], nl[b], fl[b] if fl else None) for b in range(B)]
 
     def forward(self, points, normals=None, cameras=None, features=None):
         """SurfaceSplatting.forward (rasterizer.py:584-661).  points / normals: (P,3) tensors of ONE cloud, or a
@@ -668,7 +688,13 @@ class SurfaceSplatting(object):
         first = with_host_lengths(torch.tensor(fl, dtype=torch.int64, device=dev), fl)
         flags_jobs = [((fr["mask"][None] >> torch.arange(v1 - v0, device=dev)[:, None]) & 1).to(torch.int32)
                       for (fr, _, _, _, _), (_, v0, v1) in zip(parts, jobs)]
-        flags = torch.cat(flags_jobs, dim=0) if B == 1 else flags_jobs
+        if B == 1:
+            flags = torch.cat(flags_jobs, dim=0)                       # (N, P)
+        else:                                                          # (B, max P): a cloud's row is zero past its length
+            pmax = max(int(f.shape[1]) for f in flags_jobs)
+            flags = torch.zeros((B, pmax), dtype=torch.int32, device=dev)
+            for b, f in enumerate(flags_jobs):
+                flags[b, :f.shape[1]] = f[0]
         if tot == 0:
             idx = torch.full((N, S, W, K), -1, dtype=torch.int32, device=dev)
             neg = torch.full((N, S, W, K), -1.0, dtype=torch.float32, device=dev)

@@ -293,3 +293,16 @@ def test_h_tail_of_overfull_bricks(dev):
     nrm = torch.nn.functional.normalize(pts, dim=-1)
     hdr = _h_fused_vs_standalone(dev, pts.to(dev).contiguous(), nrm.to(dev).contiguous(), 3)
     assert hdr["overflow_bricks"] > 0 and hdr["tail_h"] > 1000, hdr
+
+
+def test_brick_workspace_check_tells_an_uninitialised_workspace(dev):
+    """iso_bricks_workspace_check: ISO_ERR_INVALID until iso_bricks_workspace_init has run on the workspace."""
+    from iso_points_amd import _lib
+    lib = _lib.load()
+    n = 5000
+    nbytes = int(lib.iso_bricks_workspace_bytes(n))
+    ws = torch.full((nbytes,), 0x55, dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError):
+        _lib.call("iso_bricks_workspace_check", _lib.ptr(ws), n, _lib.stream())
+    _lib.call("iso_bricks_workspace_init", _lib.ptr(ws), n, _lib.stream())
+    _lib.call("iso_bricks_workspace_check", _lib.ptr(ws), n, _lib.stream())

@@ -574,12 +574,25 @@ def test_forward_batch_of_clouds(dev):
 
     ss = SurfaceSplatting(raster_settings=PointsRasterizationSettings(image_size=S, points_per_pixel=K))
     frags, filt = ss.forward(Clouds(), cameras=(views.to(dev), projs.to(dev)))
-    assert frags.idx.shape == (3, S, S, K) and isinstance(filt["flags"], list) and len(filt["flags"]) == 3
+    # flags: one (B, max P) tensor, a cloud's row zero past its length (a tensor as for one cloud, not a list)
+    assert frags.idx.shape == (3, S, S, K) and tuple(filt["flags"].shape) == (3, 4000)
     first = filt["first_idx"].tolist()
+    # features= beside a container: ONE packed tensor in cloud order or a list of B tensors -- same rows either way
+    feats = [torch.rand(q.shape[0], 3, device=dev) for q in pl]
+    fr_p, filt_p = ss.forward(Clouds(), cameras=(views.to(dev), projs.to(dev)), features=torch.cat(feats))
+    fr_l, filt_l = ss.forward(Clouds(), cameras=(views.to(dev), projs.to(dev)), features=feats)
+    assert torch.equal(filt_p["features"], filt_l["features"]) and torch.equal(fr_p.idx, frags.idx)
+    with pytest.raises(ValueError):
+        ss.forward(Clouds(), cameras=(views.to(dev), projs.to(dev)), features=torch.cat(feats)[:-1])
+    with pytest.raises(ValueError):
+        ss.forward(Clouds(), cameras=(views.to(dev), projs.to(dev)), features=feats[:2])
+    assert len(ss._grids) == 3                       # one cached workspace per cloud size, reused by the calls above
     for b in range(3):
-        one, f1 = ss.forward(pl[b], nl[b], cameras=(views[b:b + 1].to(dev), projs[b:b + 1].to(dev)))
+        one, f1 = ss.forward(pl[b], nl[b], cameras=(views[b:b + 1].to(dev), projs[b:b + 1].to(dev)), features=feats[b])
         n = int(f1["num_points"][0])
         assert int(filt["num_points"][b]) == n == int(scs[b]["num"][b])
+        assert torch.equal(filt_p["features"][first[b]:first[b] + n], f1["features"])
+        assert torch.equal(filt["flags"][b, :pl[b].shape[0]], f1["flags"][0]) and not filt["flags"][b, pl[b].shape[0]:].any()
         for k in ("ndc", "radii", "ellipse_params", "scaler", "points", "normals"):
             assert torch.equal(filt[k][first[b]:first[b] + n], f1[k]), k
         i1 = one.idx[0]
