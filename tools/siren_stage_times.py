@@ -28,10 +28,10 @@ for _ in range(3):
               ps.omega_first, ps.omega_hidden, _lib.ptr(ws), ws.numel(), _lib.stream())
 torch.cuda.synchronize()
 NG = 48 // NW
-stash_floats = 256 * NW * (L + 1) * NG * 512
+stash_floats = 256 * NW * L * NG * 512          # X3Shape::kStashPerWg(L) x the 256 workgroups of the 96-point shape
 tail = ws[: stash_floats * 4].view(torch.int64)[-NW * 128:].cpu().view(NW, 128)
 names = ["start", "pts"] + ["skew", "L0"]
-for w in (0, NW // 2):
+for w in range(NW) if os.environ.get("X3_ALL_WAVES") else (0, NW // 2):
     t = tail[w]
     n = int((t != 0).sum())
     d = (t[1:n] - t[:n - 1]).tolist()
