@@ -485,6 +485,20 @@ int iso_splat_render(const float* points, const float* ellipse, const float* cut
                      const float* features, int channels, int norm_weighted, float eps,
                      float* image_out, void* stream);
 
+/* iso_splat_render that also leaves the visible flags of the backward pass (iso_splat_mark_visible: rasterizer.py:850-853
+ * of the reference marks the points listed in the pixels' lists) while it writes the lists: visible_out (P,) uint8, ZERO
+ * on entry over the rows of the clouds (iso_splat_front_rows clears them), NULL = iso_splat_render.               */
+int iso_splat_render_visible(const float* points, const float* ellipse, const float* cutoff,
+                             const float* radii, const int64_t* first_idx, const int64_t* num_pts,
+                             int n_clouds, int64_t max_pts, float depth_merging_thres, int image_size,
+                             int image_width, int points_per_pixel, int tile_row_begin, int tile_row_end,
+                             int32_t* tile_cursor, const int32_t* tile_off,
+                             int32_t* pairs, int64_t pair_capacity, int32_t* overflow_flag,
+                             int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out,
+                             void* workspace, int64_t workspace_bytes, const float* scaler,
+                             const float* features, int channels, int norm_weighted, float eps,
+                             float* image_out, uint8_t* visible_out, void* stream);
+
 /* The reference's two-stage raster interface, DSS._C._rasterize_coarse / _rasterize_fine (DSS/csrc/ext.cpp:11-12;
  * dispatchers rasterize_points.h:167,257; kernels rasterize_points.cu:293-441, :503-596).  No Python caller in the
  * reference (splat_points runs both internally); here they are a compatibility surface beside iso_splat_forward, whose

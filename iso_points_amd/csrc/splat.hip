@@ -35,6 +35,19 @@
 
 #pragma clang fp contract(off)
 
+// Riders (workgroups past the kernel's own grid, see iso_splat_backward): work of the z pass that depends on nothing the
+// host kernel of the launch does, only on launches before it.
+struct ZScale;
+struct ZRider {                  // k_splat_backward's: max |grad_zbuf| (k_z_absmax's pass); k_splat_backward_heavy's: the
+  const float* gz; int64_t n;    // conversion of the fixed-point sums (k_z_finish_clouds's pass)
+  ZScale* zs; int blocks;        // blocks == 0: no riders
+  const long long* acc; float* grad; int terms_log2;
+};
+__device__ void z_absmax_body(const float* __restrict__ gz, int64_t n, ZScale* __restrict__ zs, int block, int nblocks);
+__device__ void z_finish_body(const long long* __restrict__ acc, const ZScale* __restrict__ zs, const int64_t* __restrict__ first,
+                              const int64_t* __restrict__ num, int n_clouds, float* __restrict__ grad, int terms_log2,
+                              int block, int nblocks);
+
 namespace {
 
 __device__ __forceinline__ float esqrt_arg(float x) {  // eps_sqrt, mathHelper.py:20-25
@@ -599,6 +612,7 @@ struct CompositeArgs {
   float* img;            // (N,S,S,C+1)
   int C, norm;
   float eps;
+  uint8_t* vis;          // null, or (P,) flags: every point written to a pixel's list is marked 1 (k_mark_visible's pass)
 };
 
 template <int KMAX>
@@ -925,6 +939,7 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
       idx_out[pix * K + j] = ok ? best.id[j] : -1;
       zbuf_out[pix * K + j] = ok ? best.z[j] : -1.0f;
       q_out[pix * K + j] = ok ? best.q[j] : -1.0f;
+      if (ok && ca.vis) ca.vis[best.id[j]] = 1;
     }
   }
   if (ca.scaler) composite_pixel<KMAX>(best, K, z0, depth_thres, hit, ca, pix);
@@ -1010,6 +1025,7 @@ __global__ __launch_bounds__(256) void k_raster_deep(
       for (int c = 0; c < 8; ++c) if (c < ca.C) acc[c] += w * ca.feat[(int64_t)p * ca.C + c];
       sw += w;
     }
+    if (ok && ca.vis) ca.vis[li[j]] = 1;
     if (!ok) { li[j] = -1; lz[j] = -1.0f; lq[j] = -1.0f; }
   }
   if (ca.scaler) {
@@ -1309,6 +1325,7 @@ __global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ h
         idx_out[pix * K + j] = ok ? best.id[j] : -1;
         zbuf_out[pix * K + j] = ok ? best.z[j] : -1.0f;
         q_out[pix * K + j] = ok ? best.q[j] : -1.0f;
+        if (ok && ca.vis) ca.vis[best.id[j]] = 1;
       }
     }
     if (ca.scaler) composite_pixel<KMAX>(best, K, z0, depth_thres, hit, ca, pix);
@@ -1536,7 +1553,12 @@ __global__ __launch_bounds__(256) void k_splat_backward(
     const int64_t* __restrict__ first, const int64_t* __restrict__ num,
     const uint8_t* __restrict__ blk2, BlkGeo G, Frame F, int rect_mode, float radii_s,
     int32_t* __restrict__ heavy, int32_t* __restrict__ heavy_count, float* __restrict__ grad,
-    long long* __restrict__ zacc /* fixed-point z accumulators, cleared here row by row (NULL: none) */) {
+    long long* __restrict__ zacc /* fixed-point z accumulators, cleared here row by row (NULL: none) */,
+    ZRider rider, int own_blocks) {
+  if ((int)blockIdx.x >= own_blocks) {                 // riders: blockIdx.y == 0 only
+    if (blockIdx.y == 0) z_absmax_body(rider.gz, rider.n, rider.zs, blockIdx.x - own_blocks, rider.blocks);
+    return;
+  }
   const int n = blockIdx.y;
   const int64_t len = num[n], base = first[n];
   const float r = rect_mode ? 0.f : rs[n];
@@ -1544,7 +1566,7 @@ __global__ __launch_bounds__(256) void k_splat_backward(
   // 1024 points per round and workgroup: the heavy list is appended to with ONE returning atomic per round
   // (one per 256 points made ~8 k same-address atomics the critical path of the kernel)
   __shared__ int s_wcnt[4][4], s_base;
-  const int64_t span = (int64_t)gridDim.x * 1024;
+  const int64_t span = (int64_t)own_blocks * 1024;
   for (int64_t i0 = (int64_t)blockIdx.x * 1024; i0 < len; i0 += span) {
     bool is_heavy[4];
     int64_t pp[4];
@@ -1617,14 +1639,18 @@ __global__ __launch_bounds__(256) void k_splat_backward_heavy(
     const float* __restrict__ grad_occ, const unsigned long long* __restrict__ pixmask,
     const uint8_t* __restrict__ rowbytes, BlkGeo G, Frame F,
     int rect_mode, float radii_s, const int32_t* __restrict__ heavy,
-    const int32_t* __restrict__ heavy_count, float* __restrict__ grad) {
+    const int32_t* __restrict__ heavy_count, float* __restrict__ grad, ZRider rider, int own_blocks) {
+  if ((int)blockIdx.x >= own_blocks) {
+    z_finish_body(rider.acc, rider.zs, first, num, n_clouds, rider.grad, rider.terms_log2, blockIdx.x - own_blocks, rider.blocks);
+    return;
+  }
   const int count = *heavy_count;
   constexpr int LP = 8;                                   // lanes per point
   const int j = threadIdx.x & (LP - 1);
   unsigned long long diag = 0ull;                         // the pixels of an 8x8 block this lane takes: (rx + ry) % 8 = j
   for (int ry = 0; ry < 8; ++ry) diag |= 1ull << (8 * ry + ((j - ry) & 7));
   // (count rounded up: the lanes of a group leave the loop together, the shuffles below need all of them)
-  for (int w = (blockIdx.x * blockDim.x + threadIdx.x) / LP; w < (count + 63) / 64 * 64; w += gridDim.x * blockDim.x / LP) {
+  for (int w = (blockIdx.x * blockDim.x + threadIdx.x) / LP; w < (count + 63) / 64 * 64; w += own_blocks * blockDim.x / LP) {
     const bool live = w < count;
     const int64_t p = live ? heavy[w] : 0;
     int n = 0;
@@ -2198,7 +2224,7 @@ extern "C" int iso_splat_forward(const float* points, const float* ellipse, cons
                                  int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
                                  float* zbuf_out, float* qvalue_out, float* occ_out, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
-  CompositeArgs ca{nullptr, nullptr, nullptr, 0, 0, 0.f};
+  CompositeArgs ca{nullptr, nullptr, nullptr, 0, 0, 0.f, nullptr};
   return splat_forward_impl(ca, points, ellipse, cutoff, radii, first_idx, num_pts, n_clouds, max_pts, depth_merging_thres,
                             image_size, image_width, points_per_pixel, tile_row_begin, tile_row_end, tile_cursor, tile_off, pairs,
                             pair_capacity, overflow_flag, idx_out, zbuf_out, qvalue_out, occ_out, workspace,
@@ -2217,9 +2243,28 @@ extern "C" int iso_splat_render(const float* points, const float* ellipse, const
                                 float* zbuf_out, float* qvalue_out, float* occ_out, void* workspace,
                                 int64_t workspace_bytes, const float* scaler, const float* features, int channels,
                                 int norm_weighted, float eps, float* image_out, void* stream) {
+  return iso_splat_render_visible(points, ellipse, cutoff, radii, first_idx, num_pts, n_clouds, max_pts, depth_merging_thres,
+                                  image_size, image_width, points_per_pixel, tile_row_begin, tile_row_end, tile_cursor, tile_off,
+                                  pairs, pair_capacity, overflow_flag, idx_out, zbuf_out, qvalue_out, occ_out, workspace,
+                                  workspace_bytes, scaler, features, channels, norm_weighted, eps, image_out, nullptr, stream);
+}
+
+// ... and the visible flags of the backward pass (iso_splat_mark_visible) while the lists are written: visible_out (P,)
+// uint8, ZERO on entry over the rows of the clouds (the front end clears them), 1 afterwards for every point that a
+// pixel's list holds.
+extern "C" int iso_splat_render_visible(const float* points, const float* ellipse, const float* cutoff,
+                                        const float* radii, const int64_t* first_idx,
+                                        const int64_t* num_pts, int n_clouds, int64_t max_pts,
+                                        float depth_merging_thres, int image_size, int image_width, int points_per_pixel,
+                                        int tile_row_begin, int tile_row_end, int32_t* tile_cursor,
+                                        const int32_t* tile_off, int32_t* pairs,
+                                        int64_t pair_capacity, int32_t* overflow_flag, int32_t* idx_out,
+                                        float* zbuf_out, float* qvalue_out, float* occ_out, void* workspace,
+                                        int64_t workspace_bytes, const float* scaler, const float* features, int channels,
+                                        int norm_weighted, float eps, float* image_out, uint8_t* visible_out, void* stream) {
   ISO_REQUIRE(channels >= 0 && channels <= 8, ISO_ERR_UNSUPPORTED, "iso_splat_render: channels must be <= 8");
   ISO_REQUIRE(scaler && image_out && (features || channels == 0), ISO_ERR_INVALID, "iso_splat_render: null pointer");
-  CompositeArgs ca{scaler, features, image_out, channels, norm_weighted, eps};
+  CompositeArgs ca{scaler, features, image_out, channels, norm_weighted, eps, visible_out};
   return splat_forward_impl(ca, points, ellipse, cutoff, radii, first_idx, num_pts, n_clouds, max_pts, depth_merging_thres,
                             image_size, image_width, points_per_pixel, tile_row_begin, tile_row_end, tile_cursor, tile_off, pairs,
                             pair_capacity, overflow_flag, idx_out, zbuf_out, qvalue_out, occ_out, workspace,
@@ -2401,20 +2446,28 @@ extern "C" int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbu
 // the exactly rounded sum (error <= 2^-44 max|grad| per term), bit-stable from run to run.
 struct ZScale { unsigned max_bits; int exp2; };
 
-__global__ __launch_bounds__(256) void k_z_absmax(const float* __restrict__ gz0, int64_t n, ZScale* __restrict__ zs,
-                                                  int64_t view_stride = 0) {
-  const float* __restrict__ gz = gz0 + (int64_t)blockIdx.y * view_stride;
+__device__ void z_absmax_body(const float* __restrict__ gz, int64_t n, ZScale* __restrict__ zs, int block, int nblocks) {
   __shared__ unsigned sm[4];
   unsigned m = 0u;
   const int64_t n4 = n / 4;
   const uint4* g4 = reinterpret_cast<const uint4*>(gz);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)nblocks * blockDim.x;
+  int64_t i = (int64_t)block * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {                    // four requests in flight
+    const uint4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+    const unsigned a = max(max(v0.x & 0x7fffffffu, v0.y & 0x7fffffffu), max(v0.z & 0x7fffffffu, v0.w & 0x7fffffffu));
+    const unsigned b = max(max(v1.x & 0x7fffffffu, v1.y & 0x7fffffffu), max(v1.z & 0x7fffffffu, v1.w & 0x7fffffffu));
+    const unsigned c = max(max(v2.x & 0x7fffffffu, v2.y & 0x7fffffffu), max(v2.z & 0x7fffffffu, v2.w & 0x7fffffffu));
+    const unsigned d = max(max(v3.x & 0x7fffffffu, v3.y & 0x7fffffffu), max(v3.z & 0x7fffffffu, v3.w & 0x7fffffffu));
+    m = max(m, max(max(a, b), max(c, d)));
+  }
+  for (; i < n4; i += stride) {
     const uint4 v = g4[i];                                          // |x| as ordered bits (NaN/Inf on top)
     const unsigned a = max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), b = max(v.z & 0x7fffffffu, v.w & 0x7fffffffu);
     m = max(m, max(a, b));
   }
-  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    m = max(m, __float_as_uint(gz[i]) & 0x7fffffffu);
+  for (int64_t t = n4 * 4 + (int64_t)block * blockDim.x + threadIdx.x; t < n; t += stride)
+    m = max(m, __float_as_uint(gz[t]) & 0x7fffffffu);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
@@ -2423,6 +2476,11 @@ __global__ __launch_bounds__(256) void k_z_absmax(const float* __restrict__ gz0,
     m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
     if (m) atomicMax(&zs->max_bits, m);
   }
+}
+
+__global__ __launch_bounds__(256) void k_z_absmax(const float* __restrict__ gz0, int64_t n, ZScale* __restrict__ zs,
+                                                  int64_t view_stride = 0) {
+  z_absmax_body(gz0 + (int64_t)blockIdx.y * view_stride, n, zs, blockIdx.x, gridDim.x);
 }
 
 // terms_log2 = ceil(log2(max number of slots that can list one point)) = ceil(log2(S*S)): every term is
@@ -2493,18 +2551,26 @@ __global__ void k_z_finish(const long long* __restrict__ acc, const ZScale* __re
 
 // the same over the rows of the clouds only (grid.y = cloud): rows of the packed arrays that belong to no cloud keep
 // what the caller put there, as in the xy pass
+__device__ void z_finish_body(const long long* __restrict__ acc, const ZScale* __restrict__ zs, const int64_t* __restrict__ first,
+                              const int64_t* __restrict__ num, int n_clouds, float* __restrict__ grad, int terms_log2,
+                              int block, int nblocks) {
+  const int e = z_exponent(zs->max_bits, terms_log2);
+  for (int c = 0; c < n_clouds; ++c) {
+    const int64_t len = num[c], base = first[c];
+    for (int64_t i = (int64_t)block * blockDim.x + threadIdx.x; i < len; i += (int64_t)nblocks * blockDim.x) {
+      const int64_t p = base + i;
+      const long long a = acc[p];
+      float z = (float)ldexp((double)a, -e);
+      if (a >= (1ll << 61) || a <= -(1ll << 61)) z = __builtin_nanf("");
+      grad[p * 3 + 2] = z;
+    }
+  }
+}
+
 __global__ void k_z_finish_clouds(const long long* __restrict__ acc, const ZScale* __restrict__ zs,
                                   const int64_t* __restrict__ first, const int64_t* __restrict__ num,
                                   float* __restrict__ grad, int terms_log2) {
-  const int e = z_exponent(zs->max_bits, terms_log2);
-  const int64_t len = num[blockIdx.y], base = first[blockIdx.y];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = base + i;
-    const long long a = acc[p];
-    float z = (float)ldexp((double)a, -e);
-    if (a >= (1ll << 61) || a <= -(1ll << 61)) z = __builtin_nanf("");
-    grad[p * 3 + 2] = z;
-  }
+  z_finish_body(acc, zs, first + blockIdx.y, num + blockIdx.y, 1, grad, terms_log2, blockIdx.x, gridDim.x);
 }
 
 static int64_t bwd_maps_bytes(int n_clouds, int image_size, int image_width) {
@@ -2553,28 +2619,31 @@ extern "C" int iso_splat_backward(const float* points, const float* radii, const
                        heavy_count, 16, with_z ? reinterpret_cast<int32_t*>(zs) : nullptr, 4);
   }
   int gx = iso_div_up(max_pts, 1024); if (gx > 8192) gx = 8192;
-  // xy part point-major (z written as 0, the z accumulators of the rows cleared), then the z part pixel-major in fixed point
-  hipLaunchKernelGGL(k_splat_backward, dim3(gx, n_clouds), dim3(256), 0, s, points, radii, visible,
-                     search_radius, first_idx, num_pts, blk2, G, F, rect_mode, radii_s, heavy,
-                     heavy_count, grad_points, with_z ? zacc : nullptr);
+  // The z part (pixel-major, fixed point) is three passes -- max |grad_zbuf|, scatter, conversion -- of which only the
+  // scatter is a launch of its own: the maximum rides in the xy launch below (it reads nothing that launch writes; the
+  // scale was cleared by k_grad_maps), the conversion in the heavy-point launch at the end (which writes x and y only).
+  const int64_t npix = (int64_t)n_clouds * F.H * F.W;
+  int terms_log2 = 0;
+  while ((1ll << terms_log2) < (int64_t)F.H * F.W) ++terms_log2;
+  ZRider r1{nullptr, 0, zs, 0, nullptr, nullptr, 0}, r2 = r1;
   if (with_z) {
-    const int64_t npix = (int64_t)n_clouds * F.H * F.W;
     int gm = iso_div_up(npix * points_per_pixel, 256 * 16); if (gm > 1024) gm = 1024; if (gm < 1) gm = 1;
-    hipLaunchKernelGGL(k_z_absmax, dim3(gm), dim3(256), 0, s, grad_zbuf, npix * points_per_pixel, zs);
-    int terms_log2 = 0;
-    while ((1ll << terms_log2) < (int64_t)F.H * F.W) ++terms_log2;
-    // the exponent is derived from the maximum inside the two kernels that need it (no scale launch in between)
+    r1 = ZRider{grad_zbuf, npix * points_per_pixel, zs, gm, nullptr, nullptr, 0};
+    r2 = ZRider{nullptr, 0, zs, iso_stream_grid(total_points, 256), zacc, grad_points, terms_log2};
+  }
+  // xy part point-major (z written as 0, the z accumulators of the rows cleared)
+  hipLaunchKernelGGL(k_splat_backward, dim3(gx + r1.blocks, n_clouds), dim3(256), 0, s, points, radii, visible,
+                     search_radius, first_idx, num_pts, blk2, G, F, rect_mode, radii_s, heavy,
+                     heavy_count, grad_points, with_z ? zacc : nullptr, r1, gx);
+  if (with_z)      // the exponent is derived from the maximum inside the kernels that need it (no scale launch in between)
     hipLaunchKernelGGL(k_z_scatter, dim3(iso_stream_grid(npix, 256)), dim3(256), 0, s, idx, grad_zbuf,
                        points_per_pixel, npix, zs, zacc, (int64_t)0, terms_log2);
-    hipLaunchKernelGGL(k_z_finish_clouds, dim3(iso_stream_grid(max_pts, 256), n_clouds), dim3(256), 0, s, zacc, zs,
-                       first_idx, num_pts, grad_points, terms_log2);
-  }
   // eight lanes per heavy point; the cost of a point varies with the gradient pixels under its disc, so the list is spread
   // over short-lived workgroups (a workgroup past the end of the list reads the count and leaves; ISO_HEAVY_GRID overrides)
   static const int heavy_grid = []() { const char* e = getenv("ISO_HEAVY_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
-  hipLaunchKernelGGL(k_splat_backward_heavy, dim3(heavy_grid), dim3(256), 0, s, points, radii, search_radius,
+  hipLaunchKernelGGL(k_splat_backward_heavy, dim3(heavy_grid + r2.blocks), dim3(256), 0, s, points, radii, search_radius,
                      first_idx, num_pts, n_clouds, grad_occ, pixmask, rowbytes, G, F, rect_mode, radii_s,
-                     heavy, heavy_count, grad_points);
+                     heavy, heavy_count, grad_points, r2, heavy_grid);
   ISO_CHECK_LAUNCH("iso_splat_backward");
   return ISO_OK;
 }

@@ -391,8 +391,10 @@ class IsoCycle(object):
             rs.depth_merging_threshold, S, K, 0, 0, tile_rows=self.band if many else None,
             out=self.frag if many else None, image_out=self.img_out if many else None,
             max_pts=fr["max_pts"], pair_capacity=self.pair_cap, overflow_out=self._ovf,
-            composite_with=(fr["scaler"], fr["features"], True, 1e-4), tile_cnt_ws=self._tile_cnt_ws(self.N * T * _lib.load().iso_splat_tiles_per_side(W) + 1))
+            composite_with=(fr["scaler"], fr["features"], True, 1e-4), tile_cnt_ws=self._tile_cnt_ws(self.N * T * _lib.load().iso_splat_tiles_per_side(W) + 1),
+            mark_visible=None if many else fr.get("visible"))       # one rank: the visible flags of the backward pass
         if not many:
+            fr["visible_marked"] = fr.get("visible") is not None
             return PointFragments(idx, zbuf, qv, None, occ), img
         self._idx_l = idx
         y0, y1 = self.band_rows()
@@ -428,7 +430,7 @@ class IsoCycle(object):
         scal = float(self.rs.radii_backward_scaler)
         if self.world == 1:
             vis, rs_ = _visible_and_radius(idx, fr["radii"], first, num, scal, max_pts=fr["max_pts"], vis=fr.get("visible"),
-                                           med_ws=self.med_ws1)
+                                           med_ws=self.med_ws1, marked=bool(fr.get("visible_marked")))
             return _C._backward(fr["ndc"], fr["radii"], occ_grad_band, first, num, visible=vis, rs=rs_, idx=idx,
                                 grad_zbuf=zbuf_grad_band, max_pts=fr["max_pts"], rows_covered=True)
         dev, p = idx.device, _lib.ptr

@@ -106,8 +106,10 @@ class _CNamespace(object):
                      num_points_per_cloud, depth_merging_thres, image_size, points_per_pixel,
                      bin_size=0, max_points_per_bin=0, tile_rows=None, out=None, max_pts=None,
                      pair_capacity=None, overflow_out=None, split_heavy_tiles=True, composite_with=None,
-                     image_out=None, tile_cnt_ws=None):
+                     image_out=None, tile_cnt_ws=None, mark_visible=None):
         """-> (idx i32 (N,S,S,K), zbuf, qvalue f32 (N,S,S,K), occupancy f32 (N,S,S)).
+        mark_visible (with composite_with): (P,) uint8, zero over the clouds' rows on entry -- the backward pass's
+        visible flags, set while the lists are written (pass them on as _visible_and_radius(..., marked=True)).
         max_pts (upper bound of the points of a cloud) + pair_capacity (upper bound of the point-tile
         pairs): with both given nothing is read back to the host; an overflow of the pair list sets
         the int32 flag appended to `overflow_out` (checked by the caller when convenient).
@@ -186,10 +188,11 @@ class _CNamespace(object):
             img = image_out if image_out is not None else (
                 torch.empty((N, S, W, C + 1), dtype=torch.float32, device=dev) if band == (0, T)
                 else torch.zeros((N, S, W, C + 1), dtype=torch.float32, device=dev))
-            _lib.call("iso_splat_render", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
+            # mark_visible: (P,) uint8, zero over the clouds' rows -- the lists' points are marked while they are written
+            _lib.call("iso_splat_render_visible", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
                       float(depth_merging_thres), S, W, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
                       _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), p(rws), rws_b,
-                      p(_f32c(sc_)), p(_f32c(ft_)), C, int(bool(norm_)), float(eps_), p(img), s)
+                      p(_f32c(sc_)), p(_f32c(ft_)), C, int(bool(norm_)), float(eps_), p(img), p(mark_visible), s)
             return idx, zbuf, qv, occ, img
         _lib.call("iso_splat_forward", p(pts), p(el), p(cu), p(ra), p(first), p(num), N, maxp,
                   float(depth_merging_thres), S, W, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
@@ -325,18 +328,21 @@ _C = _CNamespace()
 
 
 # ----------------------------------------------------------------------------- autograd op
-def _visible_and_radius(idx, radii, first_idx, num_points, radii_s, max_pts=None, vis=None, med_ws=None):
+def _visible_and_radius(idx, radii, first_idx, num_points, radii_s, max_pts=None, vis=None, med_ws=None, marked=False):
     """rasterizer.py:850-856,884: visible set + per-cloud r = median(visible radii) * radii_s,
     computed on the device (sort + device-side index, no host sync).  vis: (P,) uint8 whose rows of the clouds are
-    already zero (the front end clears them: front_setup's "visible"); med_ws: the caller's own zero-on-entry
-    workspace for the median (see median_radius)."""
+    already zero (the front end clears them: front_setup's "visible"); marked: the raster call has set the flags
+    already (splat_points(mark_visible=vis)); med_ws: the caller's own zero-on-entry workspace for the median (see
+    median_radius)."""
     P = radii.shape[0]
     dev = radii.device
     if vis is None:
+        assert not marked
         vis = torch.zeros((P,), dtype=torch.uint8, device=dev)
     npix = idx.numel() // idx.shape[-1]
-    _lib.call("iso_splat_mark_visible", _lib.ptr(idx.contiguous()), npix, idx.shape[-1], _lib.ptr(vis),
-              _lib.stream())
+    if not marked:
+        _lib.call("iso_splat_mark_visible", _lib.ptr(idx.contiguous()), npix, idx.shape[-1], _lib.ptr(vis),
+                  _lib.stream())
     return vis, median_radius(vis, radii, first_idx, num_points, radii_s, max_pts=max_pts, ws=med_ws)
 
 
