@@ -97,4 +97,7 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s);
 int siren_x3_tail_blocks();                                          // workgroups of the Newton-tail launch
 int siren_x3_launch_tail(const SirenArgs& a, int H, hipStream_t s);  // H = 256 only
+// ---- siren_ps.hip: the point-stationary form of the H = 256 step (bit-identical results) -------
+bool siren_ps_supported(int H, int L);
+int siren_ps_launch(const SirenArgs& a, int64_t n_upper, hipStream_t s);
 

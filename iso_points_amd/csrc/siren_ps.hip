@@ -1,0 +1,489 @@
+// Fused SIREN SDF + gradient Newton step, "point-stationary" form (H = 256, gfx950).
+//
+// Same arithmetic as siren_x3.hip (split-fp16 operands, three fp16 MFMA products per f32 product, f32 accumulate; the
+// reference semantics are Siren.forward DSS/models/common.py:140-165 under autograd.grad in
+// UniformProjection._compute_sdf_and_grad, levelset_sampling.py:142-170) -- every accumulator sees the same operations in the
+// same order, so results are bit-identical to k_siren_step_x3 -- but the work is cut the other way round:
+//   * siren_x3.hip splits the OUTPUT FEATURES of a layer over eight waves; the activations of a tile live in LDS and
+//     every stage is [GEMM | barrier | sin/cos/split | barrier]: matrix and vector pipes take turns (MFMA busy 40 %).
+//   * here a wave owns 32 POINTS and all 256 features of them.  The activations of a layer never leave the wave's
+//     registers (the D layout of v_mfma_f32_32x32x16_f16 is the B layout of the next layer, siren_common.h), the WEIGHTS
+//     are what is shared: the four waves of a workgroup (one per SIMD) stream every fragment once from L2 into a
+//     double-buffered LDS ring and all read it from there.  A layer is computed output-tile pair by output-tile pair, and
+//     the vector work of pair t - 1 (range reduction, v_sin / v_cos, the fp16 cuts, the stash) is issued by the same wave
+//     between the MFMAs of pair t -- plain f32 VALU instructions co-issue behind a 32x32x16 MFMA of their own wave
+//     (tools/probes/coissue.hip: 104 of them behind 24 MFMAs cost 5-7 %), which two waves of a SIMD do not do for each other.
+//   * no barrier separates GEMM from activation any more; the only workgroup barrier is the ring hand-over, once per
+//     four K-steps (24 MFMAs).
+// LDS: ring 2 x 16 KiB | per wave 24 KiB staging of the next layer's input (K-steps 0..11; 12..15 go straight to
+// registers) | W0 / head / bias vectors in K-order.  Registers: one wave per SIMD, 512 per lane.
+#include <stdlib.h>
+#include <type_traits>
+#include "siren_common.h"
+#include "iso_newton.h"
+#include "mlp_common.h"
+#include "mfma_split.h"
+
+namespace {
+
+constexpr int PS_W = 4;                       // waves per workgroup
+constexpr int PS_P = 32 * PS_W;               // points per workgroup
+constexpr int PS_H = 256;
+constexpr int kPsRingBytes = 2 * 16 * 1024;
+constexpr int kPsYU4 = 12 * 2 * 64;           // u32x4 entries of one wave's staging region
+constexpr int kPsYBytes = PS_W * kPsYU4 * 16;
+constexpr int kPsConstFloats = (5 + 8) * PS_H;
+constexpr size_t kPsLds = (size_t)kPsRingBytes + kPsYBytes + (size_t)kPsConstFloats * 4;
+
+typedef const __attribute__((address_space(1))) u32x4* ps_gimg;
+typedef __attribute__((address_space(1))) f32x4* ps_gf4;
+
+enum { PK_NONE = -1, PK_FWD_MID = 0, PK_FWD_TOP = 1, PK_REV_MID = 2, PK_REV0 = 3 };
+
+// registers of the activation group in flight (8 values per lane) and the per-lane context of a stage
+struct PsR {
+  float x[8], t[8], n[8], f[8], s[8], c[8], r[8], b[8];
+  unsigned h[4], l[4];
+  float mx;
+};
+struct PsC {
+  float w_in, w;          // s = sin(w_in z), c = w cos(w_in z)
+  float scale;            // scale of the fp16 cut
+  float inv;              // reverse stages: takes the scales of the accumulator out
+  float amax;             // max |adjoint| over this lane's features
+  float fp;               // head partial of the current output tile
+  float gx, gy, gz;       // gradient partials of the current output tile
+  float qx, qy, qz;       // the point
+  f32x4 wl0, wl1;         // head weights of the group
+  f32x4 sv0, sv1;         // derivative stash of the group
+  f32x4 wv[8];            // rows of W0 of the group
+};
+
+// ---- the activation programs: one instruction-sized operation per index, step-major over the eight values -----------------
+template <int KIND> struct PsCnt;
+template <> struct PsCnt<PK_FWD_MID> { static constexpr int NS = 14; static constexpr int c[14] = {8, 8, 8, 8, 8, 8, 8, 8, 4, 8, 4, 8, 8, 4}; };
+template <> struct PsCnt<PK_FWD_TOP> { static constexpr int NS = 20; static constexpr int c[20] = {8, 8, 8, 8, 8, 8, 8, 8, 4, 8, 4, 2, 2, 8, 4, 8, 4, 8, 8, 4}; };
+template <> struct PsCnt<PK_REV_MID> { static constexpr int NS = 8; static constexpr int c[8] = {8, 8, 4, 8, 4, 8, 8, 4}; };
+template <> struct PsCnt<PK_REV0> { static constexpr int NS = 22; static constexpr int c[22] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 4, 8, 8, 8, 8, 8, 8, 8, 8}; };
+template <int KIND> constexpr int ps_total() { int t = 0; for (int s = 0; s < PsCnt<KIND>::NS; ++s) t += PsCnt<KIND>::c[s]; return t; }
+template <int KIND> constexpr int ps_step_of(int i) { int s = 0; while (i >= PsCnt<KIND>::c[s]) { i -= PsCnt<KIND>::c[s]; ++s; } return s; }
+template <int KIND> constexpr int ps_elem_of(int i) { int s = 0; while (i >= PsCnt<KIND>::c[s]) { i -= PsCnt<KIND>::c[s]; ++s; } return i; }
+// first operation after the sin / cos chain (what the large-argument path runs again)
+template <int KIND> constexpr int ps_post() { return KIND == PK_REV0 ? 108 : 68; }
+
+constexpr float kRevHi = 0.159154936671257019043f, kRevLo = 6.4206383167e-9f;     // 1 / (2 pi), two terms (iso_sin_wcos8)
+
+// the two-way fp16 cut of split8_f16, operation by operation: v -> (h, l) under `scale`
+template <int S, int E>
+__device__ __forceinline__ void ps_split_op(PsR& R, const float (&v)[8], float scale) {
+  if constexpr (S == 0) R.r[E] = v[E] * scale;
+  if constexpr (S == 1) R.h[E] = __builtin_bit_cast(unsigned, __builtin_convertvector(((f32x2){R.r[2 * E], R.r[2 * E + 1]}), f16x2));
+  if constexpr (S == 2) R.t[E] = (float)(__builtin_bit_cast(f16x2, R.h[E >> 1])[E & 1]);
+  if constexpr (S == 3) R.r[E] = R.r[E] - R.t[E];
+  if constexpr (S == 4) R.l[E] = __builtin_bit_cast(unsigned, __builtin_convertvector(((f32x2){R.r[2 * E], R.r[2 * E + 1]}), f16x2));
+}
+// range reduction + hardware sin / cos of iso_sin_wcos8 / iso_wcos8 (mlp_common.h), operation by operation
+template <int S, int E, bool WITH_SIN>
+__device__ __forceinline__ void ps_sincos_op(PsR& R, float zin, const PsC& cx) {
+  if constexpr (S == 0) R.x[E] = zin * cx.w_in;
+  if constexpr (S == 1) R.t[E] = R.x[E] * kRevHi;
+  if constexpr (S == 2) R.n[E] = rintf(R.t[E]);
+  if constexpr (S == 3) R.f[E] = __builtin_fmaf(R.x[E], kRevHi, -R.n[E]);
+  if constexpr (S == 4) R.f[E] = __builtin_fmaf(R.x[E], kRevLo, R.f[E]);
+  if constexpr (S == 5 && WITH_SIN) R.s[E] = __builtin_amdgcn_sinf(R.f[E]);
+  if constexpr (S == 6) R.c[E] = __builtin_amdgcn_cosf(R.f[E]);
+  if constexpr (S == 7) R.c[E] = R.c[E] * cx.w;
+  if constexpr (S == 8) R.mx = __builtin_fmaxf(R.mx, __builtin_fmaxf(__builtin_fabsf(R.x[2 * E]), __builtin_fabsf(R.x[2 * E + 1])));
+}
+
+template <int KIND, int I>
+__device__ __forceinline__ void ps_op(PsR& R, PsC& cx, const float (&z)[8]) {
+  constexpr int S = ps_step_of<KIND>(I), E = ps_elem_of<KIND>(I);
+  if constexpr (KIND == PK_FWD_MID) {
+    if constexpr (S <= 8) ps_sincos_op<S, E, true>(R, z[E < 8 ? E : 0], cx);
+    else ps_split_op<S - 9, E>(R, R.s, cx.scale);
+  }
+  if constexpr (KIND == PK_FWD_TOP) {
+    if constexpr (S <= 8) ps_sincos_op<S, E, true>(R, z[E < 8 ? E : 0], cx);
+    // head dot product (k_siren_step_x3: f0 = (w0 h0 + w1 h1) + (w2 h2 + w3 h3), f1 likewise, fp += f0 + f1) ...
+    if constexpr (S == 9) R.r[E] = (E < 4 ? cx.wl0[E & 3] : cx.wl1[E & 3]) * R.s[E];
+    if constexpr (S == 10) R.t[E] = R.r[2 * E] + R.r[2 * E + 1];
+    if constexpr (S == 11) R.n[E] = R.t[2 * E] + R.t[2 * E + 1];
+    if constexpr (S == 12) { if constexpr (E == 0) R.n[2] = R.n[0] + R.n[1]; else cx.fp = cx.fp + R.n[2]; }
+    // ... and the seed of the adjoint: head weight * w cos(w z)
+    if constexpr (S == 13) R.s[E] = (E < 4 ? cx.wl0[E & 3] : cx.wl1[E & 3]) * R.c[E];
+    if constexpr (S == 14) cx.amax = __builtin_fmaxf(cx.amax, __builtin_fmaxf(__builtin_fabsf(R.s[2 * E]), __builtin_fabsf(R.s[2 * E + 1])));
+    if constexpr (S >= 15) ps_split_op<S - 15, E>(R, R.s, cx.scale);
+  }
+  if constexpr (KIND == PK_REV_MID) {
+    if constexpr (S == 0) R.t[E] = z[E] * cx.inv;
+    if constexpr (S == 1) R.s[E] = R.t[E] * (E < 4 ? cx.sv0[E & 3] : cx.sv1[E & 3]);
+    if constexpr (S == 2) cx.amax = __builtin_fmaxf(cx.amax, __builtin_fmaxf(__builtin_fabsf(R.s[2 * E]), __builtin_fabsf(R.s[2 * E + 1])));
+    if constexpr (S >= 3) ps_split_op<S - 3, E>(R, R.s, cx.scale);
+  }
+  if constexpr (KIND == PK_REV0) {
+    // z0 = W0 x + b0 again (the expression of the forward sweep), its w cos, then d sdf / d x
+    if constexpr (S == 0) R.t[E] = cx.wv[E].x * cx.qx;
+    if constexpr (S == 1) R.n[E] = cx.wv[E].y * cx.qy;
+    if constexpr (S == 2) R.t[E] = R.t[E] + R.n[E];
+    if constexpr (S == 3) R.n[E] = cx.wv[E].z * cx.qz;
+    if constexpr (S == 4) R.t[E] = R.t[E] + R.n[E];
+    if constexpr (S == 5) R.b[E] = R.t[E] + cx.wv[E].w;
+    if constexpr (S >= 6 && S <= 13) ps_sincos_op<(S - 6 < 5 ? S - 6 : S - 5), E, false>(R, R.b[E < 8 ? E : 0], cx);
+    if constexpr (S == 14) R.t[E] = z[E] * cx.inv;
+    if constexpr (S == 15) R.s[E] = R.t[E] * R.c[E];
+    if constexpr (S == 16) R.r[E] = cx.wv[E].x * R.s[E];
+    if constexpr (S == 17) R.f[E] = cx.wv[E].y * R.s[E];
+    if constexpr (S == 18) R.n[E] = cx.wv[E].z * R.s[E];
+    if constexpr (S == 19) cx.gx = cx.gx + R.r[E];
+    if constexpr (S == 20) cx.gy = cx.gy + R.f[E];
+    if constexpr (S == 21) cx.gz = cx.gz + R.n[E];
+  }
+}
+template <int KIND, int LO, int HI>
+__device__ __forceinline__ void ps_ops(PsR& R, PsC& cx, const float (&z)[8]) {
+  if constexpr (LO < HI) { ps_op<KIND, LO>(R, cx, z); ps_ops<KIND, LO + 1, HI>(R, cx, z); }
+}
+
+template <int N, class F>
+__device__ __forceinline__ void ps_for(F&& f) {
+  if constexpr (N > 0) { ps_for<N - 1>(f); f(std::integral_constant<int, N - 1>()); }
+}
+
+// ---- the step ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, const int nblk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* ring = reinterpret_cast<u32x4*>(smem_raw);                                  // [2][4 K-steps][4 fragments][64]
+  float* cst = reinterpret_cast<float*>(smem_raw + kPsRingBytes + kPsYBytes);        // [W0k 4H][WLk H][bias_k H] x L
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, h = lane >> 5, j = lane & 31, h8 = h * 8;
+  u32x4* ybase = reinterpret_cast<u32x4*>(smem_raw + kPsRingBytes) + w * kPsYU4 + lane;   // [12][2][64]
+  u32x4* rl = ring + lane;
+  const int L = a.L;
+  const int NST = 2 * L;                                                             // GEMM stages per tile
+  const f32x4* W0s = reinterpret_cast<const f32x4*>(cst) + h8;                       // + s * 16 + e
+  const float* WLs = cst + 4 * PS_H + h8;                                            // + s * 16
+  const float bL = a.packed[off_bl(PS_H)];
+  ps_gf4 stash = (ps_gf4)(a.stash) + ((int64_t)bid * PS_W + w) * (int64_t)(L > 1 ? L : 1) * (16 * 2 * 64) + lane;
+  const float* hdr = a.packed + x16_base(PS_H, L);
+  auto img_of = [&](int st) {
+    const int64_t off = st < L ? x16_off_layer(PS_H, L, st) : x16_off_bw(PS_H, L, NST - 1 - st);
+    return (ps_gimg)(a.packed + off) + lane;
+  };
+
+  // K-order vectors into LDS (all waves; visible after the first barrier below)
+  {
+    const float* X = a.packed + x3_base(PS_H, L);
+    for (int i = tid; i < (5 + L) * PS_H; i += 64 * PS_W) cst[i] = X[i];
+  }
+
+  const int64_t total = a.count_in ? (int64_t)__hip_atomic_load(a.count_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.n;
+  if (total <= a.cnt_lo || total > a.cnt_hi) return;
+  const int64_t n_tiles = (total + PS_P - 1) / PS_P;
+  if (bid >= n_tiles) return;
+
+  // ---- the weight ring ---------------------------------------------------------------------------------------------------
+  // chunk qq of a tile = stage qq / 16, output-tile pair (qq / 4) % 4, K-steps 4 (qq % 4) .. + 3; this wave moves K-step
+  // 4 (qq % 4) + w of it: four fragments (two tiles x two parts), contiguous in the image
+  u32x4 stg[4];
+  auto load_chunk = [&](int qq) {
+    if (qq >= 16 * NST) qq -= 16 * NST;                    // the next tile's first chunks
+    const int st = qq >> 4, Tp = (qq >> 2) & 3, c = qq & 3;
+    ps_gimg p = img_of(st) + (16 * (4 * c + w) + 4 * Tp) * 64;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) stg[f] = p[f * 64];
+  };
+  auto write_chunk = [&](int slot) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) rl[((slot * 4 + w) * 4 + f) * 64] = stg[f];
+  };
+  load_chunk(0); write_chunk(0);
+  load_chunk(1); write_chunk(1);
+  load_chunk(2);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  int q = 0;                                               // chunk being multiplied (uniform; even per tile, so the slots keep their parity)
+
+  u32x4 Xh[16], Xl[16];                                    // input of the current stage: B operands, high / low parts
+  u32x4 A[2][4];                                           // weight fragments of a K-step: (tile u, part) = f >> 1, f & 1
+  f32x16 acc[2], accP[2];
+  PsR R;
+  PsC cx;
+  f32x4 sv_n0, sv_n1;                                      // the next group's stash (reverse stages)
+  float ftot = 0.f, gtx = 0.f, gty = 0.f, gtz = 0.f;
+  float bscale = 1.f;
+
+  auto ldA = [&](u32x4 (&Ar)[4], int slot, int k) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) Ar[f] = rl[((slot * 4 + k) * 4 + f) * 64];
+  };
+
+  // One chunk: K-steps 4 C .. 4 C + 3 of the pair being multiplied (6 MFMAs each), group C of the pair before it activated
+  // between them.  The ring hand-over sits in front of the MFMAs of the chunk's LAST K-step, whose fragments are in
+  // registers by then: behind the barrier this wave refills the slot it has just finished with (chunk q + 2, requested one
+  // chunk ago), requests chunk q + 3, asks for the first fragments of chunk q + 1 and multiplies while they arrive.
+  auto chunk = [&](auto kind_c, auto c_c, const float (&z)[8]) {
+    constexpr int KIND = decltype(kind_c)::value, C = decltype(c_c)::value;
+    ps_for<4>([&](auto k_c) {
+      constexpr int k = decltype(k_c)::value, s = 4 * C + k;
+      if constexpr (k == 3) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        write_chunk(q & 1);
+        load_chunk(q + 3);
+        ldA(A[0], (q + 1) & 1, 0);
+      } else {
+        ldA(A[(k + 1) & 1], q & 1, k + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ps_for<6>([&](auto m_c) {
+        constexpr int m = decltype(m_c)::value, u = m & 1;
+        constexpr int f = u * 2 + (m < 2 ? 1 : 0);
+        const u32x4& Bv = (m >= 2 && m < 4) ? Xl[s] : Xh[s];
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[k & 1][f]), __builtin_bit_cast(f16x8, Bv), acc[u], 0, 0, 0);
+        if constexpr (KIND != PK_NONE) {
+          constexpr int T = ps_total<KIND>(), i = 6 * k + m;
+          ps_ops<KIND, (i * T) / 24, ((i + 1) * T) / 24>(R, cx, z);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    ++q;
+  };
+
+  // the group's inputs that come from memory; results of a finished group
+  auto group_begin = [&](auto kind_c, int sg /* K-step of the next layer this group makes: 4 pair + g */, int stl) {
+    constexpr int KIND = decltype(kind_c)::value;
+    R.mx = 0.f;
+    if constexpr (KIND == PK_FWD_TOP) {
+      if ((sg & 1) == 0) cx.fp = 0.f;
+      cx.wl0 = *reinterpret_cast<const f32x4*>(WLs + sg * 16);
+      cx.wl1 = *reinterpret_cast<const f32x4*>(WLs + sg * 16 + 4);
+    }
+    if constexpr (KIND == PK_REV_MID) {
+      cx.sv0 = sv_n0; cx.sv1 = sv_n1;
+      const int nx = sg + 1 < 16 ? sg + 1 : 15;
+      sv_n0 = stash[((stl * 16 + nx) * 2 + 0) * 64];
+      sv_n1 = stash[((stl * 16 + nx) * 2 + 1) * 64];
+    }
+    if constexpr (KIND == PK_REV0) {
+      if ((sg & 1) == 0) { cx.gx = 0.f; cx.gy = 0.f; cx.gz = 0.f; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cx.wv[e] = W0s[sg * 16 + e];
+    }
+  };
+  // ends a group: large arguments (|w z| >= 1e4: libm's reduction, as iso_sin_wcos8 does), the stash, per-tile sums;
+  // returns with R.h / R.l = the group's entry of the next stage's input
+  auto group_end = [&](auto kind_c, const float (&z)[8], int sg, int stl, float fp0, float am0, float g0x, float g0y, float g0z) {
+    constexpr int KIND = decltype(kind_c)::value;
+    if constexpr (KIND == PK_FWD_MID || KIND == PK_FWD_TOP) {
+      if (__builtin_expect(__any(!(R.mx < 1.0e4f)), 0)) {
+        float zz[8], ss[8], cc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zz[e] = z[e];
+        iso_sin_wcos8(cx.w_in, cx.w, zz, ss, cc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { R.s[e] = ss[e]; R.c[e] = cc[e]; }
+        cx.fp = fp0; cx.amax = am0;
+        ps_ops<KIND, ps_post<KIND>(), ps_total<KIND>()>(R, cx, z);
+      }
+    }
+    if constexpr (KIND == PK_REV0) {
+      if (__builtin_expect(__any(!(R.mx < 1.0e4f)), 0)) {
+        float zz[8], cc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zz[e] = R.b[e];
+        iso_wcos8(cx.w_in, cx.w, zz, cc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) R.c[e] = cc[e];
+        cx.gx = g0x; cx.gy = g0y; cx.gz = g0z;
+        ps_ops<KIND, ps_post<KIND>(), ps_total<KIND>()>(R, cx, z);
+      }
+    }
+    if constexpr (KIND == PK_FWD_MID) {
+      stash[((stl * 16 + sg) * 2 + 0) * 64] = (f32x4){R.c[0], R.c[1], R.c[2], R.c[3]};
+      stash[((stl * 16 + sg) * 2 + 1) * 64] = (f32x4){R.c[4], R.c[5], R.c[6], R.c[7]};
+    }
+    if constexpr (KIND == PK_FWD_TOP) {
+      if (sg & 1) {                                          // the output tile is complete: the order of k_siren_step_x3's reduction
+        const float sT = cx.fp + __shfl_xor(cx.fp, 32);
+        ftot = sg == 1 ? sT : ftot + sT;
+      }
+    }
+    if constexpr (KIND == PK_REV0) {
+      if (sg & 1) {
+        const float sx = cx.gx + __shfl_xor(cx.gx, 32), sy = cx.gy + __shfl_xor(cx.gy, 32), sz = cx.gz + __shfl_xor(cx.gz, 32);
+        gtx = sg == 1 ? sx : gtx + sx;
+        gty = sg == 1 ? sy : gty + sy;
+        gtz = sg == 1 ? sz : gtz + sz;
+      }
+    }
+  };
+  auto hl_hi = [&]() { return (u32x4){R.h[0], R.h[1], R.h[2], R.h[3]}; };
+  auto hl_lo = [&]() { return (u32x4){R.l[0], R.l[1], R.l[2], R.l[3]}; };
+
+  // One GEMM stage + the activation of its outputs.  stl: stash slot written (forward) / read (reverse); bias: K-order bias
+  // in LDS or null; zscale multiplies it.
+  auto stage = [&](auto kind_c, int stl, const float* bias, float zscale) {
+    constexpr int KIND = decltype(kind_c)::value;
+    constexpr bool MAKES_INPUT = KIND != PK_REV0;
+    auto init_acc = [&](int Tp) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (bias) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const float* bp = bias + (2 * (2 * Tp + u) + p) * 16 + h8;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(bp), hi = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[u][8 * p + e] = lo[e] * zscale; acc[u][8 * p + 4 + e] = hi[e] * zscale; }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+        }
+      }
+    };
+    float zdummy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    using none_t = std::integral_constant<int, PK_NONE>;
+    // pair 0: nothing to activate yet
+    init_acc(0);
+    if constexpr (KIND == PK_REV_MID) {                      // the first group's stash
+      sv_n0 = stash[((stl * 16 + 0) * 2 + 0) * 64];
+      sv_n1 = stash[((stl * 16 + 0) * 2 + 1) * 64];
+    }
+    ps_for<4>([&](auto c_c) { chunk(none_t(), c_c, zdummy); });
+#pragma unroll 1
+    for (int Tp = 1; Tp < 4; ++Tp) {
+      accP[0] = acc[0]; accP[1] = acc[1];
+      init_acc(Tp);
+      ps_for<4>([&](auto g_c) {
+        constexpr int g = decltype(g_c)::value;
+        float z[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = accP[g >> 1][8 * (g & 1) + e];
+        const int sg = 4 * (Tp - 1) + g;
+        const float fp0 = cx.fp, am0 = cx.amax, g0x = cx.gx, g0y = cx.gy, g0z = cx.gz;
+        group_begin(kind_c, sg, stl);
+        chunk(kind_c, g_c, z);
+        group_end(kind_c, z, sg, stl, (sg & 1) ? fp0 : 0.f, am0, (sg & 1) ? g0x : 0.f, (sg & 1) ? g0y : 0.f, (sg & 1) ? g0z : 0.f);
+        if constexpr (MAKES_INPUT) {
+          ybase[(sg * 2 + 0) * 64] = hl_hi();
+          ybase[(sg * 2 + 1) * 64] = hl_lo();
+        }
+      });
+    }
+    // the last pair: no GEMM left in this stage to hide behind; its entries go straight to registers
+    accP[0] = acc[0]; accP[1] = acc[1];
+    ps_for<4>([&](auto g_c) {
+      constexpr int g = decltype(g_c)::value;
+      float z[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = accP[g >> 1][8 * (g & 1) + e];
+      const int sg = 12 + g;
+      const float fp0 = cx.fp, am0 = cx.amax, g0x = cx.gx, g0y = cx.gy, g0z = cx.gz;
+      group_begin(kind_c, sg, stl);
+      ps_ops<KIND, 0, ps_total<KIND>()>(R, cx, z);
+      group_end(kind_c, z, sg, stl, (sg & 1) ? fp0 : 0.f, am0, (sg & 1) ? g0x : 0.f, (sg & 1) ? g0y : 0.f, (sg & 1) ? g0z : 0.f);
+      if constexpr (MAKES_INPUT) { Xh[12 + g] = hl_hi(); Xl[12 + g] = hl_lo(); }
+    });
+    if constexpr (MAKES_INPUT) {
+#pragma unroll
+      for (int s = 0; s < 12; ++s) { Xh[s] = ybase[(s * 2 + 0) * 64]; Xl[s] = ybase[(s * 2 + 1) * 64]; }
+    }
+  };
+
+  // scale of the adjoint seed (uniform): |W_head[f] * w cos| <= max |W_head| * w
+  const float seed_scale = x3_scale_for(hdr[16] * a.wh * 1.01f);
+
+  ldA(A[0], 0, 0);
+  for (int64_t tile = bid; tile < n_tiles; tile += nblk) {
+    q = 0;
+    // ---- the tile's points: lane (h, j) holds point 32 w + j -------------------------------------------------------------
+    int64_t idx = -1;
+    {
+      const int64_t slot = tile * PS_P + 32 * w + j;
+      if (slot < total) idx = a.idx_in ? (int64_t)a.idx_in[slot] : slot;
+    }
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (idx >= 0) { px = a.pts[idx * 3]; py = a.pts[idx * 3 + 1]; pz = a.pts[idx * 3 + 2]; }
+    // ---- layer 0 (3 -> H) on the VALU, straight into the B operands of hidden layer 0 ------------------------------------
+    ps_for<16>([&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
+      f32x4 wv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[e] = W0s[s * 16 + e];
+      float zz[8], hv[8], sv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) zz[e] = ((wv[e].x * px + wv[e].y * py) + wv[e].z * pz) + wv[e].w;
+      iso_sin_wcos8(a.w0, a.w0, zz, hv, sv);
+      (void)sv;
+      split8_f16(hv, Xh[s], Xl[s]);
+    });
+    // ---- hidden layers, forward ------------------------------------------------------------------------------------------
+    for (int l = 0; l < L; ++l) {
+      const float zscale = kActScale * hdr[l];
+      cx.w_in = a.wh / zscale; cx.w = a.wh;
+      const float* bias = cst + (5 + l) * PS_H;
+      if (l + 1 < L) {
+        cx.scale = kActScale;
+        stage(std::integral_constant<int, PK_FWD_MID>(), l, bias, zscale);
+      } else {
+        cx.scale = seed_scale; cx.amax = 0.f; cx.fp = 0.f;
+        stage(std::integral_constant<int, PK_FWD_TOP>(), l, bias, zscale);
+        bscale = seed_scale;
+      }
+    }
+    // ---- hidden layers, reverse --------------------------------------------------------------------------------------------
+    for (int l = L - 1; l >= 1; --l) {
+      const float M = __builtin_fmaxf(cx.amax, __shfl_xor(cx.amax, 32));       // max over all features of the point
+      const float iw = 1.0f / hdr[l];
+      const float grow = hdr[8 + l] * a.wh * 1.01f;
+      cx.inv = iw / bscale;
+      const float nscale = x3_scale_for(M * grow);
+      cx.scale = nscale; cx.amax = 0.f;
+      stage(std::integral_constant<int, PK_REV_MID>(), l - 1, nullptr, 1.0f);
+      bscale = nscale;
+    }
+    {
+      const float iw = 1.0f / hdr[0];
+      cx.inv = iw / bscale;
+      cx.w_in = a.w0; cx.w = a.w0;
+      cx.qx = px; cx.qy = py; cx.qz = pz;
+      cx.gx = cx.gy = cx.gz = 0.f;
+      stage(std::integral_constant<int, PK_REV0>(), 0, nullptr, 1.0f);
+    }
+    // ---- epilogue: lane (0, j) finishes point j ----------------------------------------------------------------------------
+    bool survive = false;
+    if (h == 0 && idx >= 0) survive = iso_step_finish<SirenArgs, true>(a, idx, ftot + bL, gtx, gty, gtz, px, py, pz);
+    if (!a.eval_only && a.do_move) {
+      const unsigned long long bal = __ballot(survive);
+      if (bal) {
+        int base = 0;
+        const int leader = __ffsll((long long)bal) - 1;
+        if (lane == leader) base = atomicAdd(a.count_out, __popcll(bal));
+        base = __shfl(base, leader);
+        if (survive) a.idx_out[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)idx;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * PS_W, 1) void k_siren_step_ps(SirenArgs a) {
+  ps_step_body(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+}  // namespace
+
+bool siren_ps_supported(int H, int L) { return H == 256 && L >= 2 && L <= 8; }
+
+int siren_ps_launch(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_siren_step_ps), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPsLds);
+    attr_done = true;
+  }
+  const int64_t tiles = (n_upper + PS_P - 1) / PS_P;
+  const int blocks = (int)(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
+  hipLaunchKernelGGL(k_siren_step_ps, dim3(blocks), dim3(64 * PS_W), kPsLds, s, a);
+  return 0;
+}

@@ -862,7 +862,16 @@ int siren_x3_launch_tail(const SirenArgs& a, int H, hipStream_t s) {
   return 0;
 }
 
+// ISO_SIREN_PS=1 (A/B): the gradient step of H = 256 lists on the point-stationary kernel (siren_ps.hip), whole list
+static bool siren_ps_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ISO_SIREN_PS"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
+  if (siren_ps_enabled() && H == 256 && !a.fwd_only && siren_ps_supported(H, a.L) && (a.split == 3 || (a.split == 0 && !a.small_tiles)))
+    return siren_ps_launch(a, n_upper, s);
   if (a.split == 3 && H == 256 && !a.fwd_only) return launch_x3_both<256, X3_NW, X3_NB256, X3_MINB256>(a, n_upper, s);
   if (a.small_tiles && H == 256 && !a.fwd_only) return launch_x3<256, X3_NW, 1, X3_MINB256, false>(a, n_upper, s);
   if (a.fwd_only) {
