@@ -2,23 +2,21 @@
 //
 // Same arithmetic as siren_x3.hip (split-fp16 operands, three fp16 MFMA products per f32 product, f32 accumulate; the
 // reference semantics are Siren.forward DSS/models/common.py:140-165 under autograd.grad in
-// UniformProjection._compute_sdf_and_grad, levelset_sampling.py:142-170) -- every accumulator and every sum sees the same
-// operations in the same order, so results are BIT-IDENTICAL to k_siren_step_x3 (tests/test_siren_ps_gpu.py) and the two
-// kernels can serve parts of one list -- but the work is cut the other way round:
+// UniformProjection._compute_sdf_and_grad, levelset_sampling.py:142-170) -- every accumulator sees the same operations in the
+// same order, so results are bit-identical to k_siren_step_x3 -- but the work is cut the other way round:
 //   * siren_x3.hip splits the OUTPUT FEATURES of a layer over eight waves; the activations of a tile live in LDS and
 //     every stage is [GEMM | barrier | sin/cos/split | barrier]: matrix and vector pipes take turns (MFMA busy 40 %).
-//   * here a wave owns 32 POINTS and all 256 features of them.  The input of a layer sits in the wave's registers as B
-//     operands (the D layout of v_mfma_f32_32x32x16_f16 is the B layout of the next layer, siren_common.h); a layer is
-//     computed output-tile pair by output-tile pair, and the vector work of pair t - 1 (range reduction, v_sin / v_cos,
-//     the fp16 cuts, the stash) is issued by the SAME wave between the MFMAs of pair t: plain f32 VALU instructions
-//     co-issue behind a 32x32x16 MFMA of their own wave (tools/probes/coissue.hip: 104 of them behind 24 MFMAs cost
-//     5-7 %), which the two waves of a SIMD do not do for each other.  No barrier between GEMM and activation.
-//   * the weight fragments come straight from L2 / L1 into registers, PS_PD K-steps ahead; the four waves of a workgroup
-//     (one per SIMD, 512 registers each) walk the same image in step -- one barrier per stage keeps them together -- so
-//     three of four requests are L1 hits.  (First form: fragments shared through a double-buffered LDS ring, one barrier
-//     per four K-steps: 6 % slower, tools/experiments/siren_ps_ring.hip and profiles/HISTORY.md.)
-// LDS: per wave 24 KiB staging of the next layer's input (K-steps 0..11; 12..15 go straight to registers) | W0 / head /
-// bias vectors in K-order.
+//   * here a wave owns 32 POINTS and all 256 features of them.  The activations of a layer never leave the wave's
+//     registers (the D layout of v_mfma_f32_32x32x16_f16 is the B layout of the next layer, siren_common.h), the WEIGHTS
+//     are what is shared: the four waves of a workgroup (one per SIMD) stream every fragment once from L2 into a
+//     double-buffered LDS ring and all read it from there.  A layer is computed output-tile pair by output-tile pair, and
+//     the vector work of pair t - 1 (range reduction, v_sin / v_cos, the fp16 cuts, the stash) is issued by the same wave
+//     between the MFMAs of pair t -- plain f32 VALU instructions co-issue behind a 32x32x16 MFMA of their own wave
+//     (tools/probes/coissue.hip: 104 of them behind 24 MFMAs cost 5-7 %), which two waves of a SIMD do not do for each other.
+//   * no barrier separates GEMM from activation any more; the only workgroup barrier is the ring hand-over, once per
+//     four K-steps (24 MFMAs).
+// LDS: ring 2 x 16 KiB | per wave 24 KiB staging of the next layer's input (K-steps 0..11; 12..15 go straight to
+// registers) | W0 / head / bias vectors in K-order.  Registers: one wave per SIMD, 512 per lane.
 #include <stdlib.h>
 #include <type_traits>
 #include "siren_common.h"
@@ -28,19 +26,17 @@
 
 namespace {
 
-#ifndef PS_PD
-#define PS_PD 3                               // K-steps a weight fragment is requested ahead of its MFMAs (3 or 7)
-#endif
-#ifndef PS_STAGE_BARRIER
-#define PS_STAGE_BARRIER 1                    // the waves of a workgroup start every stage together (L1 reuse of the fragments)
+#ifndef PS_STG
+#define PS_STG 2                              // chunks of weights in flight between L2 and the ring (1, 2 or 4)
 #endif
 constexpr int PS_W = 4;                       // waves per workgroup
 constexpr int PS_P = 32 * PS_W;               // points per workgroup
 constexpr int PS_H = 256;
+constexpr int kPsRingBytes = 2 * 16 * 1024;
 constexpr int kPsYU4 = 12 * 2 * 64;           // u32x4 entries of one wave's staging region
 constexpr int kPsYBytes = PS_W * kPsYU4 * 16;
 constexpr int kPsConstFloats = (5 + 8) * PS_H;
-constexpr size_t kPsLds = (size_t)kPsYBytes + (size_t)kPsConstFloats * 4;
+constexpr size_t kPsLds = (size_t)kPsRingBytes + kPsYBytes + (size_t)kPsConstFloats * 4;
 
 typedef const __attribute__((address_space(1))) u32x4* ps_gimg;
 typedef __attribute__((address_space(1))) f32x4* ps_gf4;
@@ -60,7 +56,6 @@ __device__ long long ps_dbg[4 * 64];
 #define PS_STAMP2() do {} while (0)
 #endif
 
-static_assert(16 % (PS_PD + 1) == 0, "the register sets of the fragments rotate with the K-steps of a pair");
 enum { PK_NONE = -1, PK_FWD_MID = 0, PK_FWD_TOP = 1, PK_REV_MID = 2, PK_REV0 = 3 };
 
 // registers of the activation group in flight (8 values per lane) and the per-lane context of a stage
@@ -171,17 +166,6 @@ __device__ __forceinline__ void ps_ops(PsR& R, PsC& cx, const float (&z)[8]) {
   if constexpr (LO < HI) { ps_op<KIND, LO>(R, cx, z); ps_ops<KIND, LO + 1, HI>(R, cx, z); }
 }
 
-// |w z| >= 1e4 somewhere in the wave (never seen with trained SIRENs): libm's reduction, as iso_sin_wcos8 does -- ONE copy of
-// that code for all call sites (inlined 40 times it was a third of the kernel's instructions); buf = z[8] | s[8] | c[8]
-__device__ __attribute__((noinline)) void ps_big_sincos(float w_in, float w, float* buf) {
-  float z[8], sv[8], cv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) z[e] = buf[e];
-  iso_sin_wcos8(w_in, w, z, sv, cv);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { buf[8 + e] = sv[e]; buf[16 + e] = cv[e]; }
-}
-
 template <int N, class F>
 __device__ __forceinline__ void ps_for(F&& f) {
   if constexpr (N > 0) { ps_for<N - 1>(f); f(std::integral_constant<int, N - 1>()); }
@@ -190,11 +174,13 @@ __device__ __forceinline__ void ps_for(F&& f) {
 // ---- the step ----------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* cst = reinterpret_cast<float*>(smem_raw + kPsYBytes);                       // [W0k 4H][WLk H][bias_k H] x L
+  u32x4* ring = reinterpret_cast<u32x4*>(smem_raw);                                  // [2][4 K-steps][4 fragments][64]
+  float* cst = reinterpret_cast<float*>(smem_raw + kPsRingBytes + kPsYBytes);        // [W0k 4H][WLk H][bias_k H] x L
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, h = lane >> 5, j = lane & 31, h8 = h * 8;
-  u32x4* ybase = reinterpret_cast<u32x4*>(smem_raw) + w * kPsYU4 + lane;             // [12][2][64]
+  u32x4* ybase = reinterpret_cast<u32x4*>(smem_raw + kPsRingBytes) + w * kPsYU4 + lane;   // [12][2][64]
+  u32x4* rl = ring + lane;
   const int L = a.L;
   const int NST = 2 * L;                                                             // GEMM stages per tile
   const f32x4* W0s = reinterpret_cast<const f32x4*>(cst) + h8;                       // + s * 16 + e
@@ -217,26 +203,38 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
   const int64_t n_tiles = (total + PS_P - 1) / PS_P;
   if (bid >= n_tiles) return;
 
+  // ---- the weight ring ---------------------------------------------------------------------------------------------------
+  // chunk qq of a tile = stage qq / 16, output-tile pair (qq / 4) % 4, K-steps 4 (qq % 4) .. + 3; this wave moves K-step
+  // 4 (qq % 4) + w of it: four fragments (two tiles x two parts), contiguous in the image
 #ifdef PS_DBG_TIMES
   bool dbg_on = false;
   int dbg_i = 0;
 #endif
-  __syncthreads();                                         // the K-order vectors are in LDS
-
-  // K-step K of a tile = stage K / 64, output-tile pair (K / 16) % 4, step K % 16: four fragments (two tiles x two
-  // parts), contiguous in the image.  Requested PS_PD K-steps ahead into a rotation of PS_PD + 1 register sets.
-  u32x4 AD[PS_PD + 1][4];
-  auto load_a = [&](u32x4 (&Ar)[4], int K) {
-    if (K >= 64 * NST) K -= 64 * NST;                      // the next tile's first K-steps
-    const ps_gimg pa = img_of(K >> 6) + (16 * (K & 15) + 4 * ((K >> 4) & 3)) * 64;
+  u32x4 stg[PS_STG][4];
+  auto load_chunk = [&](u32x4 (&sg)[4], int qq) {
+    if (qq >= 16 * NST) qq -= 16 * NST;                    // the next tile's first chunks
+    const int st = qq >> 4, Tp = (qq >> 2) & 3, c = qq & 3;
+    ps_gimg p = img_of(st) + (16 * (4 * c + w) + 4 * Tp) * 64;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) Ar[f] = pa[f * 64];
+    for (int f = 0; f < 4; ++f) sg[f] = p[f * 64];
   };
+  auto write_chunk = [&](const u32x4 (&sg)[4], int slot) {
 #pragma unroll
-  for (int d = 0; d < PS_PD; ++d) load_a(AD[d], d);
-  int q = 0;                                               // chunk (four K-steps) being multiplied (uniform)
+    for (int f = 0; f < 4; ++f) rl[((slot * 4 + w) * 4 + f) * 64] = sg[f];
+  };
+  // chunks 0 and 1 go straight to the ring; chunks 2 .. 1 + PS_STG wait in registers (chunk n in buffer n % PS_STG)
+  load_chunk(stg[0], 0); write_chunk(stg[0], 0);
+  load_chunk(stg[0], 1); write_chunk(stg[0], 1);
+#pragma unroll
+  for (int d = 0; d < PS_STG; ++d) load_chunk(stg[(2 + d) % PS_STG], 2 + d);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  int q = 0;                                               // chunk being multiplied (uniform; even per tile, so the slots keep their parity)
 
   u32x4 Xh[16], Xl[16];                                    // input of the current stage: B operands, high / low parts
+#ifdef PS_DIRECT
+  u32x4 AD[4][4];
+#endif
+  u32x4 A[2][4];                                           // weight fragments of a K-step: (tile u, part) = f >> 1, f & 1
   f32x16 acc[2], accP[2];
   PsR R;
   PsC cx;
@@ -244,19 +242,55 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
   float ftot = 0.f, gtx = 0.f, gty = 0.f, gtz = 0.f;
   float bscale = 1.f;
 
+  auto ldA = [&](u32x4 (&Ar)[4], int slot, int k) {
+#ifdef PS_DBG_NOLDA
+    return;
+#endif
+#pragma unroll
+    for (int f = 0; f < 4; ++f) Ar[f] = rl[((slot * 4 + k) * 4 + f) * 64];
+  };
+
   // One chunk: K-steps 4 C .. 4 C + 3 of the pair being multiplied (6 MFMAs each), group C of the pair before it activated
-  // between them, one slice of its program behind every MFMA.
+  // between them.  The ring hand-over sits in front of the MFMAs of the chunk's LAST K-step, whose fragments are in
+  // registers by then: behind the barrier this wave refills the slot it has just finished with (chunk q + 2, requested one
+  // chunk ago), requests chunk q + 3, asks for the first fragments of chunk q + 1 and multiplies while they arrive.
   auto chunk = [&](auto kind_c, auto c_c, const float (&z)[8]) {
     constexpr int KIND = decltype(kind_c)::value, C = decltype(c_c)::value;
     ps_for<4>([&](auto k_c) {
       constexpr int k = decltype(k_c)::value, s = 4 * C + k;
-      load_a(AD[(s + PS_PD) % (PS_PD + 1)], 4 * q + k + PS_PD);
+#ifdef PS_DIRECT
+      {   // experiment: fragments straight from L2 / L1 into registers, three K-steps ahead (no ring, no barrier)
+        int qn = q, sn = s + 3;
+        if (sn >= 16) { sn -= 16; qn = q + 4 - C; if (qn >= 16 * NST) qn -= 16 * NST; }
+        const ps_gimg pa = img_of(qn >> 4) + (16 * sn + 4 * ((qn >> 2) & 3)) * 64;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) AD[(s + 3) & 3][f] = pa[f * 64];
+      }
+#else
+      if constexpr (k == 3) {
+#ifndef PS_DBG_NOBAR
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#ifndef PS_DBG_NOSTREAM
+        write_chunk(stg[(C + 2) % PS_STG], q & 1);
+        load_chunk(stg[(C + 2) % PS_STG], q + 2 + PS_STG);
+#endif
+        ldA(A[0], (q + 1) & 1, 0);
+      } else {
+        ldA(A[(k + 1) & 1], q & 1, k + 1);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       ps_for<6>([&](auto m_c) {
         constexpr int m = decltype(m_c)::value, u = m & 1;
-        constexpr int f = u * 2 + (m < 2 ? 1 : 0);         // W_l x_h, W_h x_l, W_h x_h: the order of gemm_x3
+        constexpr int f = u * 2 + (m < 2 ? 1 : 0);
         const u32x4& Bv = (m >= 2 && m < 4) ? Xl[s] : Xh[s];
-        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, AD[s % (PS_PD + 1)][f]), __builtin_bit_cast(f16x8, Bv), acc[u], 0, 0, 0);
+#ifdef PS_DIRECT
+        const u32x4& Av = AD[s & 3][f];
+#else
+        const u32x4& Av = A[k & 1][f];
+#endif
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Av), __builtin_bit_cast(f16x8, Bv), acc[u], 0, 0, 0);
         if constexpr (KIND != PK_NONE) {
           constexpr int T = ps_total<KIND>(), i = 6 * k + m;
           ps_ops<KIND, (i * T) / 24, ((i + 1) * T) / 24>(R, cx, z);
@@ -293,15 +327,27 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
   auto group_end = [&](auto kind_c, const float (&z)[8], int sg, int stl, float fp0, float am0, float g0x, float g0y, float g0z) {
     constexpr int KIND = decltype(kind_c)::value;
 #ifndef PS_NO_BIGFIX
-    if constexpr (KIND == PK_FWD_MID || KIND == PK_FWD_TOP || KIND == PK_REV0) {
+    if constexpr (KIND == PK_FWD_MID || KIND == PK_FWD_TOP) {
       if (__builtin_expect(__any(!(R.mx < 1.0e4f)), 0)) {
-        float buf[24];
+        float zz[8], ss[8], cc[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) buf[e] = KIND == PK_REV0 ? R.b[e] : z[e];
-        ps_big_sincos(cx.w_in, cx.w, buf);
+        for (int e = 0; e < 8; ++e) zz[e] = z[e];
+        iso_sin_wcos8(cx.w_in, cx.w, zz, ss, cc);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { if (KIND != PK_REV0) R.s[e] = buf[8 + e]; R.c[e] = buf[16 + e]; }
-        cx.fp = fp0; cx.amax = am0; cx.gx = g0x; cx.gy = g0y; cx.gz = g0z;
+        for (int e = 0; e < 8; ++e) { R.s[e] = ss[e]; R.c[e] = cc[e]; }
+        cx.fp = fp0; cx.amax = am0;
+        ps_ops<KIND, ps_post<KIND>(), ps_total<KIND>()>(R, cx, z);
+      }
+    }
+    if constexpr (KIND == PK_REV0) {
+      if (__builtin_expect(__any(!(R.mx < 1.0e4f)), 0)) {
+        float zz[8], cc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zz[e] = R.b[e];
+        iso_wcos8(cx.w_in, cx.w, zz, cc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) R.c[e] = cc[e];
+        cx.gx = g0x; cx.gy = g0y; cx.gz = g0z;
         ps_ops<KIND, ps_post<KIND>(), ps_total<KIND>()>(R, cx, z);
       }
     }
@@ -350,9 +396,6 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
         }
       }
     };
-#if PS_STAGE_BARRIER
-    asm volatile("s_barrier" ::: "memory");
-#endif
     float zdummy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     using none_t = std::integral_constant<int, PK_NONE>;
     // pair 0: nothing to activate yet
@@ -408,6 +451,13 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
   // scale of the adjoint seed (uniform): |W_head[f] * w cos| <= max |W_head| * w
   const float seed_scale = x3_scale_for(hdr[16] * a.wh * 1.01f);
 
+#ifdef PS_DIRECT
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) AD[d][f] = (img_of(0) + (16 * d) * 64)[f * 64];
+#endif
+  ldA(A[0], 0, 0);
   for (int64_t tile = bid; tile < n_tiles; tile += nblk) {
     q = 0;
 #ifdef PS_DBG_TIMES
@@ -423,9 +473,9 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
     }
     float px = 0.f, py = 0.f, pz = 0.f;
     if (idx >= 0) { px = a.pts[idx * 3]; py = a.pts[idx * 3 + 1]; pz = a.pts[idx * 3 + 2]; }
-    // ---- layer 0 (3 -> H) on the VALU: K-steps 0..11 of hidden layer 0's input through the staging region (one rolled
-    // copy of the code), 12..15 straight into registers ----------------------------------------------------------------
-    auto layer0 = [&](int s, u32x4& oh, u32x4& ol) {
+    // ---- layer 0 (3 -> H) on the VALU, straight into the B operands of hidden layer 0 ------------------------------------
+    ps_for<16>([&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
       f32x4 wv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) wv[e] = W0s[s * 16 + e];
@@ -434,17 +484,8 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
       for (int e = 0; e < 8; ++e) zz[e] = ((wv[e].x * px + wv[e].y * py) + wv[e].z * pz) + wv[e].w;
       iso_sin_wcos8(a.w0, a.w0, zz, hv, sv);
       (void)sv;
-      split8_f16(hv, oh, ol);
-    };
-#pragma unroll 1
-    for (int s = 0; s < 12; ++s) {
-      u32x4 oh, ol;
-      layer0(s, oh, ol);
-      ybase[(s * 2 + 0) * 64] = oh; ybase[(s * 2 + 1) * 64] = ol;
-    }
-    ps_for<4>([&](auto g_c) { constexpr int g = decltype(g_c)::value; layer0(12 + g, Xh[12 + g], Xl[12 + g]); });
-#pragma unroll
-    for (int s = 0; s < 12; ++s) { Xh[s] = ybase[(s * 2 + 0) * 64]; Xl[s] = ybase[(s * 2 + 1) * 64]; }
+      split8_f16(hv, Xh[s], Xl[s]);
+    });
     PS_STAMP();
     // ---- hidden layers, forward ------------------------------------------------------------------------------------------
     for (int l = 0; l < L; ++l) {

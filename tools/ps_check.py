@@ -21,7 +21,8 @@ def run(out):
         torch.manual_seed(L)
         m = Siren(hidden_size=256, n_layers=L).to(dev)
         ps = PackedSiren(m, dev)
-        for P in (1, 31, 128, 129, 4097, 100003, 1000000):
+        sizes = (1, 31, 128, 129, 4097, 100003) if os.environ.get("PS_CHECK_SMALL") else (1, 31, 128, 129, 4097, 100003, 1000000)
+        for P in sizes:
             g = torch.Generator().manual_seed(P)
             pts = (torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1) *
                    (0.7 + 0.6 * torch.rand(P, 1, generator=g))).to(dev).contiguous()
@@ -48,7 +49,7 @@ def run(out):
                 ts.sort()
                 print("L=%d  1M evaluations: %.3f ms (min %.3f)" % (L, ts[len(ts) // 2], ts[0]), flush=True)
         # a projection (device-side lists, moves, compaction)
-        P = 200000
+        P = 50000 if os.environ.get("PS_CHECK_SMALL") else 200000
         g = torch.Generator().manual_seed(7)
         pts = (torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1) * 0.9).to(dev).contiguous()
         outp = torch.empty_like(pts)
