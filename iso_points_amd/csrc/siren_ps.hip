@@ -394,7 +394,9 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
       const int sg = 12 + g;
       const float fp0 = cx.fp, am0 = cx.amax, g0x = cx.gx, g0y = cx.gy, g0z = cx.gz;
       group_begin(kind_c, sg, stl);
+#ifndef PS_DBG_NOEPI
       ps_ops<KIND, 0, ps_total<KIND>()>(R, cx, z);
+#endif
       group_end(kind_c, z, sg, stl, (sg & 1) ? fp0 : 0.f, am0, (sg & 1) ? g0x : 0.f, (sg & 1) ? g0y : 0.f, (sg & 1) ? g0z : 0.f);
       if constexpr (MAKES_INPUT) { Xh[12 + g] = hl_hi(); Xl[12 + g] = hl_lo(); }
     });
