@@ -40,6 +40,7 @@ struct SirenArgs {
   int32_t* tail_counts = nullptr;  // [blocks][2] their lengths (zero on entry of the launch: cleared by k_zero_counts' sibling)
   int32_t* iter_counts = nullptr;  // counts[it] of the projection (diagnostics: points evaluated by iteration it)
   int tail_cap = 0, it_first = 0, it_last = 0;
+  int ps_guard = 0;          // 1: this launch follows one of k_siren_step_ps on the same list and only works where that one declines
 };
 
 // Slots served by the 96-point-tile launch of a split list.  A round of the persistent grid is 256 tiles: 24 576
@@ -80,7 +81,9 @@ __host__ __device__ inline int64_t x3_off_layer(int H, int L, int l) {
 // ---- images in split fp16 (siren_x3.hip), appended to the K-order section --------------------
 //   [24 floats: 0..7  2^s_l, the power-of-two scale of hidden layer l
 //               8..15 c_l = max over input features f of sum_k |W_l[k][f]|  (growth bound of the adjoint)
-//               16    max |W_head| ]
+//               16    max |W_head|
+//               17..21 r_l = max_f (sum_k |W_l[f][k]| + |b_l[f]|), hidden layers 0..4 (bound of a hidden layer's pre-activation)
+//               22, 23 max_f sum_c |W_0[f][c]|, max_f |b_0[f]|                      (the same for layer 0, per unit of max |x_c|) ]
 //   [ per hidden layer: FW16 H*H ][ per hidden layer: BW16 H*H ]                       (float units)
 // FW16 / BW16: uint4 index ((s*NTO + To)*2 + part)*64 + lane, 8 fp16 each (part 0/1 = high / low
 // 11+11 bits of 2^s_l * W resp. its transpose), lane = 32h'+row:  W[32To+row][x3_feat(s,8h'+e)].
@@ -98,6 +101,17 @@ int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s);
 int siren_x3_tail_blocks();                                          // workgroups of the Newton-tail launch
 int siren_x3_launch_tail(const SirenArgs& a, int H, hipStream_t s);  // H = 256 only
 // ---- siren_ps.hip: the point-stationary form of the H = 256 step (bit-identical results) -------
+// Which lists it serves (decided on the device by both kernels from the same data, so exactly one of them works): at
+// least kPsMinList points -- a list is dealt out in tiles of 128 points over 256 workgroups, the last round is partly
+// filled -- and hidden layers whose sine arguments provably stay below the large-argument threshold of iso_sin_wcos8
+// (|w z| < 1e4: the kernel has no such path for them; true for every trained SIREN, r_l w ~ 10..100).
+constexpr int64_t kPsMinList = 3 * 256 * 128;
+__host__ __device__ inline bool siren_ps_takes(int64_t count, int L, const float* hdr /* packed + x16_base */, float wh) {
+  if (count < kPsMinList) return false;
+  float r = 0.f;
+  for (int l = 0; l < L; ++l) r = hdr[17 + l] > r ? hdr[17 + l] : r;
+  return (wh * r) * 1.01f < 1.0e4f;
+}
 bool siren_ps_supported(int H, int L);
 int siren_ps_launch(const SirenArgs& a, int64_t n_upper, hipStream_t s);
 

@@ -40,7 +40,11 @@ constexpr int PS_H = 256;
 constexpr int kPsYU4 = 12 * 2 * 64;           // u32x4 entries of one wave's staging region
 constexpr int kPsYBytes = PS_W * kPsYU4 * 16;
 constexpr int kPsConstFloats = (5 + 8) * PS_H;
-constexpr size_t kPsLds = (size_t)kPsYBytes + (size_t)kPsConstFloats * 4;
+#ifndef PS_LDS_STASH
+#define PS_LDS_STASH 6                        // groups (of 16) of stash slot 0 that stay in LDS: 2 KiB per group and wave
+#endif
+constexpr size_t kPsLds = (size_t)kPsYBytes + (size_t)kPsConstFloats * 4 + (size_t)PS_W * PS_LDS_STASH * 2048;
+static_assert(kPsLds <= 163840, "LDS of a gfx950 CU");
 
 typedef const __attribute__((address_space(1))) u32x4* ps_gimg;
 typedef __attribute__((address_space(1))) f32x4* ps_gf4;
@@ -67,7 +71,6 @@ enum { PK_NONE = -1, PK_FWD_MID = 0, PK_FWD_TOP = 1, PK_REV_MID = 2, PK_REV0 = 3
 struct PsR {
   float x[8], t[8], n[8], f[8], s[8], c[8], r[8], b[8];
   unsigned h[4], l[4];
-  float mx;
 };
 struct PsC {
   float w_in, w;          // s = sin(w_in z), c = w cos(w_in z)
@@ -84,15 +87,15 @@ struct PsC {
 
 // ---- the activation programs: one instruction-sized operation per index, step-major over the eight values -----------------
 template <int KIND> struct PsCnt;
-template <> struct PsCnt<PK_FWD_MID> { static constexpr int NS = 14; static constexpr int c[14] = {8, 8, 8, 8, 8, 8, 8, 8, 4, 8, 4, 8, 8, 4}; };
-template <> struct PsCnt<PK_FWD_TOP> { static constexpr int NS = 20; static constexpr int c[20] = {8, 8, 8, 8, 8, 8, 8, 8, 4, 8, 4, 2, 2, 8, 4, 8, 4, 8, 8, 4}; };
+template <> struct PsCnt<PK_FWD_MID> { static constexpr int NS = 13; static constexpr int c[13] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 4, 8, 8, 4}; };
+template <> struct PsCnt<PK_FWD_TOP> { static constexpr int NS = 19; static constexpr int c[19] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 4, 2, 2, 8, 4, 8, 4, 8, 8, 4}; };
 template <> struct PsCnt<PK_REV_MID> { static constexpr int NS = 8; static constexpr int c[8] = {8, 8, 4, 8, 4, 8, 8, 4}; };
-template <> struct PsCnt<PK_REV0> { static constexpr int NS = 22; static constexpr int c[22] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 4, 8, 8, 8, 8, 8, 8, 8, 8}; };
+template <> struct PsCnt<PK_REV0> { static constexpr int NS = 21; static constexpr int c[21] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8}; };
 template <int KIND> constexpr int ps_total() { int t = 0; for (int s = 0; s < PsCnt<KIND>::NS; ++s) t += PsCnt<KIND>::c[s]; return t; }
 template <int KIND> constexpr int ps_step_of(int i) { int s = 0; while (i >= PsCnt<KIND>::c[s]) { i -= PsCnt<KIND>::c[s]; ++s; } return s; }
 template <int KIND> constexpr int ps_elem_of(int i) { int s = 0; while (i >= PsCnt<KIND>::c[s]) { i -= PsCnt<KIND>::c[s]; ++s; } return i; }
 // first operation after the sin / cos chain (what the large-argument path runs again)
-template <int KIND> constexpr int ps_post() { return KIND == PK_REV0 ? 108 : 68; }
+template <int KIND> constexpr int ps_post() { return KIND == PK_REV0 ? 104 : 64; }
 
 // Every operation's result is pinned where it is produced (an empty asm the compiler may not move or drop): left to
 // itself LLVM sinks the whole chain behind the large-argument branch of group_end, i.e. out from between the MFMAs.
@@ -119,27 +122,26 @@ __device__ __forceinline__ void ps_sincos_op(PsR& R, float zin, const PsC& cx) {
   if constexpr (S == 5 && WITH_SIN) { R.s[E] = __builtin_amdgcn_sinf(R.f[E]); PS_PIN(R.s[E]); }
   if constexpr (S == 6) { R.c[E] = __builtin_amdgcn_cosf(R.f[E]); PS_PIN(R.c[E]); }
   if constexpr (S == 7) { R.c[E] = R.c[E] * cx.w; PS_PIN(R.c[E]); }
-  if constexpr (S == 8) { R.mx = __builtin_fmaxf(R.mx, __builtin_fmaxf(__builtin_fabsf(R.x[2 * E]), __builtin_fabsf(R.x[2 * E + 1]))); PS_PIN(R.mx); }
 }
 
 template <int KIND, int I>
 __device__ __forceinline__ void ps_op(PsR& R, PsC& cx, const float (&z)[8]) {
   constexpr int S = ps_step_of<KIND>(I), E = ps_elem_of<KIND>(I);
   if constexpr (KIND == PK_FWD_MID) {
-    if constexpr (S <= 8) ps_sincos_op<S, E, true>(R, z[E < 8 ? E : 0], cx);
-    else ps_split_op<S - 9, E>(R, R.s, cx.scale);
+    if constexpr (S <= 7) ps_sincos_op<S, E, true>(R, z[E], cx);
+    else ps_split_op<S - 8, E>(R, R.s, cx.scale);
   }
   if constexpr (KIND == PK_FWD_TOP) {
-    if constexpr (S <= 8) ps_sincos_op<S, E, true>(R, z[E < 8 ? E : 0], cx);
+    if constexpr (S <= 7) ps_sincos_op<S, E, true>(R, z[E], cx);
     // head dot product (k_siren_step_x3: f0 = (w0 h0 + w1 h1) + (w2 h2 + w3 h3), f1 likewise, fp += f0 + f1) ...
-    if constexpr (S == 9) { R.r[E] = (E < 4 ? cx.wl0[E & 3] : cx.wl1[E & 3]) * R.s[E]; PS_PIN(R.r[E]); }
-    if constexpr (S == 10) { R.t[E] = R.r[2 * E] + R.r[2 * E + 1]; PS_PIN(R.t[E]); }
-    if constexpr (S == 11) { R.n[E] = R.t[2 * E] + R.t[2 * E + 1]; PS_PIN(R.n[E]); }
-    if constexpr (S == 12) { if constexpr (E == 0) { R.n[2] = R.n[0] + R.n[1]; PS_PIN(R.n[2]); } else { cx.fp = cx.fp + R.n[2]; PS_PIN(cx.fp); } }
+    if constexpr (S == 8) { R.r[E] = (E < 4 ? cx.wl0[E & 3] : cx.wl1[E & 3]) * R.s[E]; PS_PIN(R.r[E]); }
+    if constexpr (S == 9) { R.t[E] = R.r[2 * E] + R.r[2 * E + 1]; PS_PIN(R.t[E]); }
+    if constexpr (S == 10) { R.n[E] = R.t[2 * E] + R.t[2 * E + 1]; PS_PIN(R.n[E]); }
+    if constexpr (S == 11) { if constexpr (E == 0) { R.n[2] = R.n[0] + R.n[1]; PS_PIN(R.n[2]); } else { cx.fp = cx.fp + R.n[2]; PS_PIN(cx.fp); } }
     // ... and the seed of the adjoint: head weight * w cos(w z)
-    if constexpr (S == 13) { R.s[E] = (E < 4 ? cx.wl0[E & 3] : cx.wl1[E & 3]) * R.c[E]; PS_PIN(R.s[E]); }
-    if constexpr (S == 14) { cx.amax = __builtin_fmaxf(cx.amax, __builtin_fmaxf(__builtin_fabsf(R.s[2 * E]), __builtin_fabsf(R.s[2 * E + 1]))); PS_PIN(cx.amax); }
-    if constexpr (S >= 15) ps_split_op<S - 15, E>(R, R.s, cx.scale);
+    if constexpr (S == 12) { R.s[E] = (E < 4 ? cx.wl0[E & 3] : cx.wl1[E & 3]) * R.c[E]; PS_PIN(R.s[E]); }
+    if constexpr (S == 13) { cx.amax = __builtin_fmaxf(cx.amax, __builtin_fmaxf(__builtin_fabsf(R.s[2 * E]), __builtin_fabsf(R.s[2 * E + 1]))); PS_PIN(cx.amax); }
+    if constexpr (S >= 14) ps_split_op<S - 14, E>(R, R.s, cx.scale);
   }
   if constexpr (KIND == PK_REV_MID) {
     if constexpr (S == 0) { R.t[E] = z[E] * cx.inv; PS_PIN(R.t[E]); }
@@ -155,31 +157,20 @@ __device__ __forceinline__ void ps_op(PsR& R, PsC& cx, const float (&z)[8]) {
     if constexpr (S == 3) { R.n[E] = cx.wv[E].z * cx.qz; PS_PIN(R.n[E]); }
     if constexpr (S == 4) { R.t[E] = R.t[E] + R.n[E]; PS_PIN(R.t[E]); }
     if constexpr (S == 5) { R.b[E] = R.t[E] + cx.wv[E].w; PS_PIN(R.b[E]); }
-    if constexpr (S >= 6 && S <= 13) ps_sincos_op<(S - 6 < 5 ? S - 6 : S - 5), E, false>(R, R.b[E < 8 ? E : 0], cx);
-    if constexpr (S == 14) { R.t[E] = z[E] * cx.inv; PS_PIN(R.t[E]); }
-    if constexpr (S == 15) { R.s[E] = R.t[E] * R.c[E]; PS_PIN(R.s[E]); }
-    if constexpr (S == 16) { R.r[E] = cx.wv[E].x * R.s[E]; PS_PIN(R.r[E]); }
-    if constexpr (S == 17) { R.f[E] = cx.wv[E].y * R.s[E]; PS_PIN(R.f[E]); }
-    if constexpr (S == 18) { R.n[E] = cx.wv[E].z * R.s[E]; PS_PIN(R.n[E]); }
-    if constexpr (S == 19) { cx.gx = cx.gx + R.r[E]; PS_PIN(cx.gx); }
-    if constexpr (S == 20) { cx.gy = cx.gy + R.f[E]; PS_PIN(cx.gy); }
-    if constexpr (S == 21) { cx.gz = cx.gz + R.n[E]; PS_PIN(cx.gz); }
+    if constexpr (S >= 6 && S <= 12) ps_sincos_op<(S - 6 < 5 ? S - 6 : S - 5), E, false>(R, R.b[E], cx);
+    if constexpr (S == 13) { R.t[E] = z[E] * cx.inv; PS_PIN(R.t[E]); }
+    if constexpr (S == 14) { R.s[E] = R.t[E] * R.c[E]; PS_PIN(R.s[E]); }
+    if constexpr (S == 15) { R.r[E] = cx.wv[E].x * R.s[E]; PS_PIN(R.r[E]); }
+    if constexpr (S == 16) { R.f[E] = cx.wv[E].y * R.s[E]; PS_PIN(R.f[E]); }
+    if constexpr (S == 17) { R.n[E] = cx.wv[E].z * R.s[E]; PS_PIN(R.n[E]); }
+    if constexpr (S == 18) { cx.gx = cx.gx + R.r[E]; PS_PIN(cx.gx); }
+    if constexpr (S == 19) { cx.gy = cx.gy + R.f[E]; PS_PIN(cx.gy); }
+    if constexpr (S == 20) { cx.gz = cx.gz + R.n[E]; PS_PIN(cx.gz); }
   }
 }
 template <int KIND, int LO, int HI>
 __device__ __forceinline__ void ps_ops(PsR& R, PsC& cx, const float (&z)[8]) {
   if constexpr (LO < HI) { ps_op<KIND, LO>(R, cx, z); ps_ops<KIND, LO + 1, HI>(R, cx, z); }
-}
-
-// |w z| >= 1e4 somewhere in the wave (never seen with trained SIRENs): libm's reduction, as iso_sin_wcos8 does -- ONE copy of
-// that code for all call sites (inlined 40 times it was a third of the kernel's instructions); buf = z[8] | s[8] | c[8]
-__device__ __attribute__((noinline)) void ps_big_sincos(float w_in, float w, float* buf) {
-  float z[8], sv[8], cv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) z[e] = buf[e];
-  iso_sin_wcos8(w_in, w, z, sv, cv);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { buf[8 + e] = sv[e]; buf[16 + e] = cv[e]; }
 }
 
 template <int N, class F>
@@ -202,6 +193,15 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
   const float bL = a.packed[off_bl(PS_H)];
   ps_gf4 stash = (ps_gf4)(a.stash) + ((int64_t)bid * PS_W + w) * (int64_t)(L > 1 ? L : 1) * (16 * 2 * 64) + lane;
   const float* hdr = a.packed + x16_base(PS_H, L);
+  f32x4* lst = reinterpret_cast<f32x4*>(smem_raw + kPsYBytes + kPsConstFloats * 4) + w * (PS_LDS_STASH * 2 * 64) + lane;
+  auto stash_get = [&](int stl, int g, f32x4& v0, f32x4& v1) {
+    if (PS_LDS_STASH > 0 && stl == 0 && g < PS_LDS_STASH) { v0 = lst[(g * 2 + 0) * 64]; v1 = lst[(g * 2 + 1) * 64]; }
+    else { v0 = stash[((stl * 16 + g) * 2 + 0) * 64]; v1 = stash[((stl * 16 + g) * 2 + 1) * 64]; }
+  };
+  auto stash_put = [&](int stl, int g, const f32x4& v0, const f32x4& v1) {
+    if (PS_LDS_STASH > 0 && stl == 0 && g < PS_LDS_STASH) { lst[(g * 2 + 0) * 64] = v0; lst[(g * 2 + 1) * 64] = v1; }
+    else { stash[((stl * 16 + g) * 2 + 0) * 64] = v0; stash[((stl * 16 + g) * 2 + 1) * 64] = v1; }
+  };
   // images of the GEMM stages: forward layers 0 .. L-1, then the transposed ones L-1 .. 0 (contiguous: siren_common.h)
   const ps_gimg img0 = (ps_gimg)(a.packed + x16_off_layer(PS_H, L, 0)) + lane;
   auto img_of = [&](int st) { return img0 + (st < L ? st : 3 * L - 1 - st) * (PS_H * PS_H / 4); };
@@ -213,7 +213,7 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
   }
 
   const int64_t total = a.count_in ? (int64_t)__hip_atomic_load(a.count_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.n;
-  if (total <= a.cnt_lo || total > a.cnt_hi) return;
+  if (!siren_ps_takes(total, L, hdr, a.wh)) return;        // the launch that follows (ps_guard) does this list
   const int64_t n_tiles = (total + PS_P - 1) / PS_P;
   if (bid >= n_tiles) return;
 
@@ -243,6 +243,7 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
   f32x4 sv_n0, sv_n1;                                      // the next group's stash (reverse stages)
   float ftot = 0.f, gtx = 0.f, gty = 0.f, gtz = 0.f;
   float bscale = 1.f;
+  bool unsafe0 = false;                                    // this tile has a point whose layer-0 arguments may be large
 
   // One chunk: K-steps 4 C .. 4 C + 3 of the pair being multiplied (6 MFMAs each), group C of the pair before it activated
   // between them, one slice of its program behind every MFMA.
@@ -270,7 +271,6 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
   // the group's inputs that come from memory; results of a finished group
   auto group_begin = [&](auto kind_c, int sg /* K-step of the next layer this group makes: 4 pair + g */, int stl) {
     constexpr int KIND = decltype(kind_c)::value;
-    R.mx = 0.f;
     if constexpr (KIND == PK_FWD_TOP) {
       if ((sg & 1) == 0) cx.fp = 0.f;
       cx.wl0 = *reinterpret_cast<const f32x4*>(WLs + sg * 16);
@@ -279,8 +279,7 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
     if constexpr (KIND == PK_REV_MID) {
       cx.sv0 = sv_n0; cx.sv1 = sv_n1;
       const int nx = sg + 1 < 16 ? sg + 1 : 15;
-      sv_n0 = stash[((stl * 16 + nx) * 2 + 0) * 64];
-      sv_n1 = stash[((stl * 16 + nx) * 2 + 1) * 64];
+      stash_get(stl, nx, sv_n0, sv_n1);
     }
     if constexpr (KIND == PK_REV0) {
       if ((sg & 1) == 0) { cx.gx = 0.f; cx.gy = 0.f; cx.gz = 0.f; }
@@ -290,25 +289,25 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
   };
   // ends a group: large arguments (|w z| >= 1e4: libm's reduction, as iso_sin_wcos8 does), the stash, per-tile sums;
   // returns with R.h / R.l = the group's entry of the next stage's input
-  auto group_end = [&](auto kind_c, const float (&z)[8], int sg, int stl, float fp0, float am0, float g0x, float g0y, float g0z) {
+  auto group_end = [&](auto kind_c, const float (&z)[8], int sg, int stl, float g0x, float g0y, float g0z) {
     constexpr int KIND = decltype(kind_c)::value;
-#ifndef PS_NO_BIGFIX
-    if constexpr (KIND == PK_FWD_MID || KIND == PK_FWD_TOP || KIND == PK_REV0) {
-      if (__builtin_expect(__any(!(R.mx < 1.0e4f)), 0)) {
-        float buf[24];
+    // Large arguments (|w z| >= 1e4: libm's reduction, as iso_sin_wcos8 does).  Hidden layers: none by siren_ps_takes.
+    // Layer 0: only in waves whose points are far enough out for it (unsafe0, from the bound of siren_common.h) -- they
+    // take cos again through iso_wcos8, which repeats the fast path bit for bit where that one applies.
+    if constexpr (KIND == PK_REV0) {
+      if (__builtin_expect(unsafe0, 0)) {
+        float zz[8], cc[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) buf[e] = KIND == PK_REV0 ? R.b[e] : z[e];
-        ps_big_sincos(cx.w_in, cx.w, buf);
+        for (int e = 0; e < 8; ++e) zz[e] = R.b[e];
+        iso_wcos8(cx.w_in, cx.w, zz, cc);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { if (KIND != PK_REV0) R.s[e] = buf[8 + e]; R.c[e] = buf[16 + e]; }
-        cx.fp = fp0; cx.amax = am0; cx.gx = g0x; cx.gy = g0y; cx.gz = g0z;
+        for (int e = 0; e < 8; ++e) R.c[e] = cc[e];
+        cx.gx = g0x; cx.gy = g0y; cx.gz = g0z;
         ps_ops<KIND, ps_post<KIND>(), ps_total<KIND>()>(R, cx, z);
       }
     }
-#endif
     if constexpr (KIND == PK_FWD_MID) {
-      stash[((stl * 16 + sg) * 2 + 0) * 64] = (f32x4){R.c[0], R.c[1], R.c[2], R.c[3]};
-      stash[((stl * 16 + sg) * 2 + 1) * 64] = (f32x4){R.c[4], R.c[5], R.c[6], R.c[7]};
+      stash_put(stl, sg, (f32x4){R.c[0], R.c[1], R.c[2], R.c[3]}, (f32x4){R.c[4], R.c[5], R.c[6], R.c[7]});
     }
     if constexpr (KIND == PK_FWD_TOP) {
       if (sg & 1) {                                          // the output tile is complete: the order of k_siren_step_x3's reduction
@@ -358,8 +357,7 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
     // pair 0: nothing to activate yet
     init_acc(0);
     if constexpr (KIND == PK_REV_MID) {                      // the first group's stash
-      sv_n0 = stash[((stl * 16 + 0) * 2 + 0) * 64];
-      sv_n1 = stash[((stl * 16 + 0) * 2 + 1) * 64];
+      stash_get(stl, 0, sv_n0, sv_n1);
     }
     ps_for<4>([&](auto c_c) { chunk(none_t(), c_c, zdummy); });
     PS_STAMP2();
@@ -373,10 +371,10 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = accP[g >> 1][8 * (g & 1) + e];
         const int sg = 4 * (Tp - 1) + g;
-        const float fp0 = cx.fp, am0 = cx.amax, g0x = cx.gx, g0y = cx.gy, g0z = cx.gz;
+        const float g0x = cx.gx, g0y = cx.gy, g0z = cx.gz;
         group_begin(kind_c, sg, stl);
         chunk(kind_c, g_c, z);
-        group_end(kind_c, z, sg, stl, (sg & 1) ? fp0 : 0.f, am0, (sg & 1) ? g0x : 0.f, (sg & 1) ? g0y : 0.f, (sg & 1) ? g0z : 0.f);
+        group_end(kind_c, z, sg, stl, (sg & 1) ? g0x : 0.f, (sg & 1) ? g0y : 0.f, (sg & 1) ? g0z : 0.f);
         if constexpr (MAKES_INPUT) {
           ybase[(sg * 2 + 0) * 64] = hl_hi();
           ybase[(sg * 2 + 1) * 64] = hl_lo();
@@ -392,12 +390,12 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] = accP[g >> 1][8 * (g & 1) + e];
       const int sg = 12 + g;
-      const float fp0 = cx.fp, am0 = cx.amax, g0x = cx.gx, g0y = cx.gy, g0z = cx.gz;
+      const float g0x = cx.gx, g0y = cx.gy, g0z = cx.gz;
       group_begin(kind_c, sg, stl);
 #ifndef PS_DBG_NOEPI
       ps_ops<KIND, 0, ps_total<KIND>()>(R, cx, z);
 #endif
-      group_end(kind_c, z, sg, stl, (sg & 1) ? fp0 : 0.f, am0, (sg & 1) ? g0x : 0.f, (sg & 1) ? g0y : 0.f, (sg & 1) ? g0z : 0.f);
+      group_end(kind_c, z, sg, stl, (sg & 1) ? g0x : 0.f, (sg & 1) ? g0y : 0.f, (sg & 1) ? g0z : 0.f);
       if constexpr (MAKES_INPUT) { Xh[12 + g] = hl_hi(); Xl[12 + g] = hl_lo(); }
     });
     PS_STAMP2();
@@ -425,6 +423,11 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
     }
     float px = 0.f, py = 0.f, pz = 0.f;
     if (idx >= 0) { px = a.pts[idx * 3]; py = a.pts[idx * 3 + 1]; pz = a.pts[idx * 3 + 2]; }
+    {
+      const float pm = __builtin_fmaxf(__builtin_fabsf(px), __builtin_fmaxf(__builtin_fabsf(py), __builtin_fabsf(pz)));
+      const bool fin = (px == px) && (py == py) && (pz == pz);
+      unsafe0 = __any(!fin || !((a.w0 * (hdr[22] * pm + hdr[23])) * 1.01f < 1.0e4f));
+    }
     // ---- layer 0 (3 -> H) on the VALU: K-steps 0..11 of hidden layer 0's input through the staging region (one rolled
     // copy of the code), 12..15 straight into registers ----------------------------------------------------------------
     auto layer0 = [&](int s, u32x4& oh, u32x4& ol) {
@@ -513,7 +516,7 @@ extern "C" int iso_dbg_ps_times(long long* out) {
 }
 #endif
 
-bool siren_ps_supported(int H, int L) { return H == 256 && L >= 2 && L <= 8; }
+bool siren_ps_supported(int H, int L) { return H == 256 && L >= 2 && L <= 5; }   // (the bounds of siren_ps_takes: five slots)
 
 int siren_ps_launch(const SirenArgs& a, int64_t n_upper, hipStream_t s) {
   static bool attr_done = false;

@@ -41,6 +41,8 @@
 
 #include "mfma_split.h"
 
+static bool siren_ps_enabled();
+
 namespace {
 
 // s = sin(w_in * z), c = w * cos(w_in * z); w_in = w / (accumulator scale), an exact power-of-two quotient
@@ -138,6 +140,59 @@ __global__ void k_siren_wscale(const float* __restrict__ raw, float* __restrict_
       __syncthreads();
     }
     if (threadIdx.x == 0) packed[x16_base(H, L) + 16] = s_m[0];
+  }
+}
+
+// Bounds of the sine arguments for k_siren_step_ps (siren_ps_takes, siren_common.h; header slots 17..23); one workgroup per
+// hidden layer.  Only launched when that kernel is enabled.
+__global__ void k_siren_ps_bounds(const float* __restrict__ raw, float* __restrict__ packed, int H, int L) {
+  __shared__ float s_m[256];
+  const int l = blockIdx.x;
+  const int64_t HH = (int64_t)H * H;
+  const float* Wl = raw + (int64_t)H * 4 + (int64_t)l * (HH + H);
+  // r_l = max_f (sum_k |W_l[f][k]| + |b_l[f]|): |W_l h + b_l| <= r_l for |h| <= 1 -- with it a kernel knows that no argument
+  // of a hidden sine can reach the large-argument path (siren_ps_takes, siren_common.h); layers 0..4 have a slot
+  if (l < 5) {
+    float rs = 0.f;
+    for (int f = threadIdx.x; f < H; f += 256) {
+      float t = fabsf(Wl[HH + f]);
+#pragma unroll 16
+      for (int k = 0; k < H; ++k) t += fabsf(Wl[(int64_t)f * H + k]);
+      rs = (t == t && t > rs) ? t : (t == t ? rs : 3.0e38f);
+    }
+    s_m[threadIdx.x] = rs;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) s_m[threadIdx.x] = fmaxf(s_m[threadIdx.x], s_m[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) packed[x16_base(H, L) + 17 + l] = s_m[0];
+  }
+  if (l == 0) {
+    // layer 0: |W_0 x + b_0| <= (max_f sum_c |W_0[f][c]|) max|x_c| + max_f |b_0[f]|
+    __syncthreads();
+    float a0 = 0.f, b0m = 0.f;
+    for (int f = threadIdx.x; f < H; f += 256) {
+      const float t = (fabsf(raw[f * 3]) + fabsf(raw[f * 3 + 1])) + fabsf(raw[f * 3 + 2]);
+      const float b = fabsf(raw[(int64_t)H * 3 + f]);
+      a0 = (t == t) ? fmaxf(a0, t) : 3.0e38f;
+      b0m = (b == b) ? fmaxf(b0m, b) : 3.0e38f;
+    }
+    s_m[threadIdx.x] = a0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) s_m[threadIdx.x] = fmaxf(s_m[threadIdx.x], s_m[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) packed[x16_base(H, L) + 22] = s_m[0];
+    __syncthreads();
+    s_m[threadIdx.x] = b0m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) s_m[threadIdx.x] = fmaxf(s_m[threadIdx.x], s_m[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) packed[x16_base(H, L) + 23] = s_m[0];
   }
 }
 
@@ -281,6 +336,7 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
   // (agent-scope load: in the Newton tail the count was written by this workgroup's own atomics a moment ago)
   const int64_t total = a.count_in ? (int64_t)__hip_atomic_load(a.count_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.n;
   if (total <= a.cnt_lo || total > a.cnt_hi) return;       // the other tile shape serves this list (uniform)
+  if (a.ps_guard && H == 256 && siren_ps_takes(total, L, a.packed + x16_base(H, L), a.wh)) return;   // k_siren_step_ps has done it
   // this launch's share of the list: slots [slot0, count)  (SirenArgs::split)
   const int64_t cut = a.split ? siren_split_point(total) : total;
   const int64_t slot0 = a.split == 2 ? cut : 0;
@@ -843,6 +899,7 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
   hipLaunchKernelGGL(k_siren_pack_x3, dim3(iso_stream_grid(words, 256)), dim3(256), 0, s, raw, packed, H, L);
   if (L > 0) {
     hipLaunchKernelGGL(k_siren_wscale, dim3(L), dim3(256), 0, s, raw, packed, H, L);
+    if (siren_ps_enabled() && siren_ps_supported(H, L)) hipLaunchKernelGGL(k_siren_ps_bounds, dim3(L), dim3(256), 0, s, raw, packed, H, L);
     hipLaunchKernelGGL(k_siren_pack_f16, dim3(iso_stream_grid(2 * (int64_t)L * H * H, 256)), dim3(256), 0, s, raw, packed, H, L);
   }
 }
@@ -862,7 +919,8 @@ int siren_x3_launch_tail(const SirenArgs& a, int H, hipStream_t s) {
   return 0;
 }
 
-// ISO_SIREN_PS=1 (A/B): the gradient step of H = 256 lists on the point-stationary kernel (siren_ps.hip), whole list
+// ISO_SIREN_PS=1: lists the point-stationary kernel takes (siren_ps_takes) are served by it; the launch of this file's
+// kernels that follows carries ps_guard and returns at once for them
 static bool siren_ps_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("ISO_SIREN_PS"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -870,8 +928,14 @@ static bool siren_ps_enabled() {
 }
 
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
-  if (siren_ps_enabled() && H == 256 && !a.fwd_only && siren_ps_supported(H, a.L) && (a.split == 3 || (a.split == 0 && !a.small_tiles)))
-    return siren_ps_launch(a, n_upper, s);
+  if (siren_ps_enabled() && H == 256 && !a.fwd_only && !a.dirs && siren_ps_supported(H, a.L) && n_upper >= kPsMinList &&
+      (a.split == 3 || (a.split == 0 && !a.small_tiles)) && a.cnt_lo < 0 && a.cnt_hi == INT64_MAX) {
+    siren_ps_launch(a, n_upper, s);
+    SirenArgs g = a;
+    g.ps_guard = 1;
+    if (g.split == 3) return launch_x3_both<256, X3_NW, X3_NB256, X3_MINB256>(g, n_upper, s);
+    return launch_x3<256, X3_NW, X3_NB256, X3_MINB256, false>(g, n_upper, s);
+  }
   if (a.split == 3 && H == 256 && !a.fwd_only) return launch_x3_both<256, X3_NW, X3_NB256, X3_MINB256>(a, n_upper, s);
   if (a.small_tiles && H == 256 && !a.fwd_only) return launch_x3<256, X3_NW, 1, X3_MINB256, false>(a, n_upper, s);
   if (a.fwd_only) {

@@ -49,7 +49,7 @@ def run(out):
                 ts.sort()
                 print("L=%d  1M evaluations: %.3f ms (min %.3f)" % (L, ts[len(ts) // 2], ts[0]), flush=True)
         # a projection (device-side lists, moves, compaction)
-        P = 50000 if os.environ.get("PS_CHECK_SMALL") else 200000
+        P = 120000 if os.environ.get("PS_CHECK_SMALL") else 200000
         g = torch.Generator().manual_seed(7)
         pts = (torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1) * 0.9).to(dev).contiguous()
         outp = torch.empty_like(pts)
