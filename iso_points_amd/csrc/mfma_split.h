@@ -47,13 +47,38 @@ __device__ __forceinline__ float x3_scale_for(float bound) {
 constexpr float kActScale = 4096.0f;             // 2^12
 
 // two-way fp16 cut of scale * v, step-major over the four pairs (a packed op whose result feeds the next
-// instruction costs a wait state, mlp_common.h); scale is a power of two
+// instruction costs a wait state, mlp_common.h); scale is a power of two.
+// The low part l = f16(x - f32(h)) is ONE instruction per value: v_fma_mixlo_f16 / v_fma_mixhi_f16 compute 1.0 * x - h in
+// f32 from the fp16 half of h in place (the difference is exact) and round it to fp16 into the low / high half of the
+// destination -- bit for bit what the conversion back, the subtraction and the second conversion gave (three half-rate
+// instructions per value before; tools/probes/mix_split.hip: no mismatch in 2^20 values), 16 instead of 24 instructions per cut.
+#ifndef X3_MIX_SPLIT
+#define X3_MIX_SPLIT 1
+#endif
+__device__ __forceinline__ unsigned x3_low_half_pair(float x0, float x1, unsigned h) {
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, 1.0, %1, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(h));
+  asm("v_fma_mixhi_f16 %0, 1.0, %1, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(h));
+  return l;
+}
 __device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, float scale = kActScale) {
-  f32x2 x[4], f[4];
-  f16x2 h[4], l[4];
+  f32x2 x[4];
+  f16x2 h[4];
   const f32x2 sc = {scale, scale};
   ISO_X4(x[p] = ((f32x2){v[2 * p], v[2 * p + 1]}) * sc);
   ISO_X4(h[p] = __builtin_convertvector(x[p], f16x2));
+#if X3_MIX_SPLIT
+  unsigned l[4];
+  ISO_X4(asm("v_fma_mixlo_f16 %0, 1.0, %1, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l[p]) : "v"(x[p].x), "v"(__builtin_bit_cast(unsigned, h[p]))));
+  ISO_X4(asm("v_fma_mixhi_f16 %0, 1.0, %1, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l[p]) : "v"(x[p].y), "v"(__builtin_bit_cast(unsigned, h[p]))));
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    hi[d] = __builtin_bit_cast(unsigned, h[d]);
+    lo[d] = l[d];
+  }
+#else
+  f32x2 f[4];
+  f16x2 l[4];
   ISO_X4(f[p] = __builtin_convertvector(h[p], f32x2));
   ISO_X4(x[p] = x[p] - f[p]);
   ISO_X4(l[p] = __builtin_convertvector(x[p], f16x2));
@@ -62,6 +87,7 @@ __device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4
     hi[d] = __builtin_bit_cast(unsigned, h[d]);
     lo[d] = __builtin_bit_cast(unsigned, l[d]);
   }
+#endif
 }
 
 // Timing experiments only (tools/build_variant.sh): -DX3_DBG_NOSINCOS / NOMMA / NOSTASH knock out

@@ -87,9 +87,9 @@ struct PsC {
 
 // ---- the activation programs: one instruction-sized operation per index, step-major over the eight values -----------------
 template <int KIND> struct PsCnt;
-template <> struct PsCnt<PK_FWD_MID> { static constexpr int NS = 13; static constexpr int c[13] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 4, 8, 8, 4}; };
-template <> struct PsCnt<PK_FWD_TOP> { static constexpr int NS = 19; static constexpr int c[19] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 4, 2, 2, 8, 4, 8, 4, 8, 8, 4}; };
-template <> struct PsCnt<PK_REV_MID> { static constexpr int NS = 8; static constexpr int c[8] = {8, 8, 4, 8, 4, 8, 8, 4}; };
+template <> struct PsCnt<PK_FWD_MID> { static constexpr int NS = 12; static constexpr int c[12] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 4, 4, 4}; };
+template <> struct PsCnt<PK_FWD_TOP> { static constexpr int NS = 18; static constexpr int c[18] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 4, 2, 2, 8, 4, 8, 4, 4, 4}; };
+template <> struct PsCnt<PK_REV_MID> { static constexpr int NS = 7; static constexpr int c[7] = {8, 8, 4, 8, 4, 4, 4}; };
 template <> struct PsCnt<PK_REV0> { static constexpr int NS = 21; static constexpr int c[21] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8}; };
 template <int KIND> constexpr int ps_total() { int t = 0; for (int s = 0; s < PsCnt<KIND>::NS; ++s) t += PsCnt<KIND>::c[s]; return t; }
 template <int KIND> constexpr int ps_step_of(int i) { int s = 0; while (i >= PsCnt<KIND>::c[s]) { i -= PsCnt<KIND>::c[s]; ++s; } return s; }
@@ -102,14 +102,13 @@ template <int KIND> constexpr int ps_post() { return KIND == PK_REV0 ? 104 : 64;
 #define PS_PIN(v) asm volatile("" : "+v"(v))
 constexpr float kRevHi = 0.159154936671257019043f, kRevLo = 6.4206383167e-9f;     // 1 / (2 pi), two terms (iso_sin_wcos8)
 
-// the two-way fp16 cut of split8_f16, operation by operation: v -> (h, l) under `scale`
+// the two-way fp16 cut of split8_f16 (mfma_split.h), operation by operation: v -> (h, l) under `scale`
 template <int S, int E>
 __device__ __forceinline__ void ps_split_op(PsR& R, const float (&v)[8], float scale) {
   if constexpr (S == 0) { R.r[E] = v[E] * scale; PS_PIN(R.r[E]); }
   if constexpr (S == 1) { R.h[E] = __builtin_bit_cast(unsigned, __builtin_convertvector(((f32x2){R.r[2 * E], R.r[2 * E + 1]}), f16x2)); PS_PIN(R.h[E]); }
-  if constexpr (S == 2) { R.t[E] = (float)(__builtin_bit_cast(f16x2, R.h[E >> 1])[E & 1]); PS_PIN(R.t[E]); }
-  if constexpr (S == 3) { R.r[E] = R.r[E] - R.t[E]; PS_PIN(R.r[E]); }
-  if constexpr (S == 4) { R.l[E] = __builtin_bit_cast(unsigned, __builtin_convertvector(((f32x2){R.r[2 * E], R.r[2 * E + 1]}), f16x2)); PS_PIN(R.l[E]); }
+  if constexpr (S == 2) asm volatile("v_fma_mixlo_f16 %0, 1.0, %1, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(R.l[E]) : "v"(R.r[2 * E]), "v"(R.h[E]));
+  if constexpr (S == 3) asm volatile("v_fma_mixhi_f16 %0, 1.0, %1, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(R.l[E]) : "v"(R.r[2 * E + 1]), "v"(R.h[E]));
 }
 // range reduction + hardware sin / cos of iso_sin_wcos8 / iso_wcos8 (mlp_common.h), operation by operation
 template <int S, int E, bool WITH_SIN>
