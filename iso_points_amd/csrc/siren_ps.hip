@@ -194,10 +194,22 @@ __device__ __forceinline__ void ps_step_body(const SirenArgs& a, const int bid, 
   const float* hdr = a.packed + x16_base(PS_H, L);
   f32x4* lst = reinterpret_cast<f32x4*>(smem_raw + kPsYBytes + kPsConstFloats * 4) + w * (PS_LDS_STASH * 2 * 64) + lane;
   auto stash_get = [&](int stl, int g, f32x4& v0, f32x4& v1) {
+#ifdef PS_DBG_NOSTASH      // timing experiment: no derivative stash at all (results wrong by construction)
+    v0 = v1 = (f32x4){1.f, 1.f, 1.f, (float)g}; return;
+#endif
+#ifdef PS_DBG_HALFSTASH    // timing experiment: slot 0 costs nothing (the upper bound of keeping it on chip)
+    if (stl == 0) { v0 = v1 = (f32x4){1.f, 1.f, 1.f, (float)g}; return; }
+#endif
     if (PS_LDS_STASH > 0 && stl == 0 && g < PS_LDS_STASH) { v0 = lst[(g * 2 + 0) * 64]; v1 = lst[(g * 2 + 1) * 64]; }
     else { v0 = stash[((stl * 16 + g) * 2 + 0) * 64]; v1 = stash[((stl * 16 + g) * 2 + 1) * 64]; }
   };
   auto stash_put = [&](int stl, int g, const f32x4& v0, const f32x4& v1) {
+#ifdef PS_DBG_NOSTASH
+    return;
+#endif
+#ifdef PS_DBG_HALFSTASH
+    if (stl == 0) return;
+#endif
     if (PS_LDS_STASH > 0 && stl == 0 && g < PS_LDS_STASH) { lst[(g * 2 + 0) * 64] = v0; lst[(g * 2 + 1) * 64] = v1; }
     else { stash[((stl * 16 + g) * 2 + 0) * 64] = v0; stash[((stl * 16 + g) * 2 + 1) * 64] = v1; }
   };
