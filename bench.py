@@ -36,6 +36,8 @@ FLOP_PER_EVAL = 2.0 * (2 * LAYERS * HIDDEN * HIDDEN + 2 * 3 * HIDDEN + 2 * HIDDE
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA
 PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md: dense bf16 MFMA (2.5 PF); 16x the f32 rate
 SUSTAINED_FP16_TFLOPS = 2516.6 * 1.66 / 2.4   # measured: dense fp16 MFMA on all 256 CUs clocks at 1.66 GHz (tools/probes/clock.hip)
+SUSTAINED_FP16_RANDOM_TFLOPS = 1580.0         # the same with operands that change with every MFMA and are random fp16 numbers
+                                              # (tools/probes/mfma_power.hip, profiles/r04_mfma_power_probe.txt: 1.50 GHz)
 X3_PASSES = 3                      # fp16 MFMA passes per f32 product in the split-operand mode (siren_x3.hip): both
                                    # operands cut into two fp16 numbers, W_l x_h + W_h x_l + W_h x_h; the fp16 and bf16
                                    # MFMA peaks are equal
@@ -573,6 +575,8 @@ def main():
                          # profiles/r02_clock_probe.txt); frac_of_sustained prices the executed rate against that
                          "sustained_peak": round(SUSTAINED_FP16_TFLOPS / X3_PASSES, 1) if x3 else None,
                          "frac_of_sustained": round(ach / (SUSTAINED_FP16_TFLOPS / X3_PASSES), 4) if x3 else None,
+                         # ... and on operands like the kernel's own (noise-like fp16 halves, new ones for every MFMA)
+                         "frac_of_sustained_random_operands": round(ach / (SUSTAINED_FP16_RANDOM_TFLOPS / X3_PASSES), 4) if x3 else None,
                          "launches_per_step": launches_per_step,
                          "avg_launch_ms": round(siren_ms / max(siren_launches, 1), 4),
                          "point_evals_per_step_rank0": evals_per_step,
