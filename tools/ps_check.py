@@ -17,7 +17,7 @@ def run(out):
     from iso_points_amd.sdf_models import PackedSiren, Siren
     dev = torch.device("cuda:0")
     res = {}
-    for L in (3, 2):
+    for L in (3, 2, 4, 5):
         torch.manual_seed(L)
         m = Siren(hidden_size=256, n_layers=L).to(dev)
         ps = PackedSiren(m, dev)
