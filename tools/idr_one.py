@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 from oracle import iso_oracle as O
 from iso_points_amd import _lib
 if os.environ.get("ISO_DEV_LIB"):

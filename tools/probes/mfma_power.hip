@@ -11,6 +11,7 @@
 // hipcc --offload-arch=gfx950 -O2 mfma_power.hip -o mfma_power && ./mfma_power
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -79,8 +80,38 @@ void run(const char* name, int blocks, int threads, float* sink) {
          name, blocks, threads / 256, ms, cycles / (ms * 1e6), tflops, tflops / 3);
 }
 
-int main() {
+// mfma_power long MODE SECONDS: 256 workgroups x 1 wave/SIMD of mode MODE back to back for SECONDS (for tools/power_probe.py)
+template <int MODE>
+void run_long(const char* name, float seconds, float* sink) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256), 0, 0, sink, 1000);
+  hipDeviceSynchronize();
+  const int iters = 100000;
+  double total = 0; int n = 0;
+  while (total < seconds * 1e3) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256), 0, 0, sink, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    total += ms; ++n;
+  }
+  const double cycles = (double)iters * 24 * 32;
+  printf("%s: %d launches, %.1f ms each -> %.2f GHz-equivalent, %.0f TFLOP/s fp16\n", name, n, total / n, cycles / (total / n * 1e6),
+         256.0 * 4 * cycles / 32 * 32768.0 / (total / n * 1e-3) / 1e12);
+}
+
+int main(int argc, char** argv) {
   float* sink; hipMalloc((void**)&sink, 64);
+  if (argc >= 4 && argv[1][0] == 'l') {
+    const int mode = atoi(argv[2]); const float sec = atof(argv[3]);
+    if (mode == 0) run_long<0>("one smooth set", sec, sink);
+    else if (mode == 1) run_long<1>("8 smooth sets", sec, sink);
+    else if (mode == 2) run_long<2>("8 random sets", sec, sink);
+    else run_long<3>("zeros", sec, sink);
+    return 0;
+  }
   for (int threads : {256, 512}) {
     for (int blocks : {8, 256}) {
       run<3>("zeros", blocks, threads, sink);
