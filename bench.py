@@ -238,6 +238,9 @@ def generator_order_cycle(dev, model, comm, steps=3):
             "note": "same cycle, input cloud in generator (random) order"}
 
 
+OPAPI_STEP_HOOK = None
+
+
 def operator_api_cycle(dev, model, steps=3):
     """The same configs[2] workload through the reference's OPERATOR signatures, the way train_mvr.py would drive them
     -- no IsoCycle, no fused orchestration, no graphs, host reads where the reference's API has them:
@@ -246,7 +249,7 @@ def operator_api_cycle(dev, model, steps=3):
     [rasterizer.py:584-661] -> composite [renderer.py:36-82] -> the cycle's loss -> autograd .backward() down to the
     world points.  (project_points drops the points that did not converge before it resamples, as the reference does;
     the headline cycle resamples all of them.)"""
-    from iso_points_amd.levelset_sampling import UniformProjection
+    from iso_points_amd.levelset_sampling import UniformProjection, mask_padded_to_list
     from iso_points_amd.rasterizer import PointsRasterizationSettings, SurfaceSplatting, composite
     from iso_points_amd.dist import sphere_silhouette, slab_order
     rs = PointsRasterizationSettings(image_size=IMAGE, points_per_pixel=KPIX, cutoff_threshold=1.0,
@@ -262,9 +265,9 @@ def operator_api_cycle(dev, model, steps=3):
 
     def step():
         out = proj.project_points(pts0, model, skip_upsampling=True)
-        m = out["mask"][0]
-        x = out["levelset_points"][0][m].detach().requires_grad_(True)
-        nrm = out["levelset_normals"][0][m]
+        # the converged points, as combined_modeling.py:452-453 takes them (mask_padded_to_list of DSS/utils)
+        x = mask_padded_to_list(out["levelset_points"], out["mask"])[0].detach().requires_grad_(True)
+        nrm = mask_padded_to_list(out["levelset_normals"], out["mask"])[0]
         kept[0] = x.shape[0]
         frags, filt = ss.forward(x, nrm)
         feat = 0.5 * (torch.nn.functional.normalize(filt["normals"], dim=-1) + 1.0)
@@ -280,6 +283,9 @@ def operator_api_cycle(dev, model, steps=3):
     # misses the caching allocator (seen once in five bench runs: 23 ms instead of 16) would skew a mean of three
     times = []
     for _ in range(max(steps, 5)):
+        if OPAPI_STEP_HOOK is not None:
+            OPAPI_STEP_HOOK()                    # tools/opapi_only.py trace: a marker kernel between steps
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         step()
         torch.cuda.synchronize()

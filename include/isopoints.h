@@ -518,6 +518,11 @@ int iso_rasterize_fine(const float* points, const float* ellipse, const float* c
                        float depth_merging_thres, int image_size, int bin_size, int points_per_pixel,
                        int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out, void* stream);
 
+/* DSS/utils/__init__.py:172-185 (gather_with_neg_idx) for one float per point, as SurfaceSplatting.forward uses it for
+ * the fragments' scaler (rasterizer.py:635-637): out[i] = idx[i] >= 0 ? values[idx[i]] : 0, i < n.  idx and out 16-byte
+ * aligned.                                                                                                            */
+int iso_gather_neg_idx(const float* values, const int32_t* idx, int64_t n, float* out, void* stream);
+
 /* renderer.py:53-78: w = exp(-0.5 q) * scaler[idx] (0 where idx < 0);
  * image[..., c] = sum_k w f / max(sum_k w, eps) (norm_weighted) or sum_k w f;
  * image[..., channels] = occupancy.  frag_scaler_out (n_pixels,K) may be NULL.  */

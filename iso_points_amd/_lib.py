@@ -81,6 +81,7 @@ SIGNATURES = {
                               _L, _P, _P, _I, _I, _F, _P, _P]),
     "iso_splat_render_visible": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _F, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P,
                                       _L, _P, _P, _I, _I, _F, _P, _P, _P]),
+    "iso_gather_neg_idx": (_I, [_P, _P, _L, _P, _P]),
     "iso_splat_composite": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _P, _P]),
     "iso_splat_composite_backward": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
     "iso_splat_mark_visible": (_I, [_P, _L, _I, _P, _P]),

@@ -1334,6 +1334,56 @@ __global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ h
 
 // ---------------------------------------------------------------- compositing
 // w = exp(-0.5 q) * scaler[idx]; out[...,c] = sum w f / max(sum w, eps) ; out[...,C] = occupancy
+// The same compositing with the K fragments of a pixel in registers (K = 4 or 8, C <= 3: the cycle's shapes): the lists are
+// read with 16-byte loads and ALL the gathers of a pixel (scaler + features of K points) are requested before the first is
+// used -- the generic loop below waits for each fragment's gathers in turn (119 -> see profiles/HISTORY.md, round 5).
+// Same operations in the same order per pixel: bit-identical to k_composite.
+template <int K>
+__global__ __launch_bounds__(256) void k_composite_k(const int32_t* __restrict__ idx, const float* __restrict__ qv,
+                                                     const float* __restrict__ occ, const float* __restrict__ scaler,
+                                                     const float* __restrict__ feat, int C, int norm, float eps,
+                                                     int64_t npix, float* __restrict__ frag_scaler, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  int p[K];
+  float q[K];
+#pragma unroll
+  for (int v = 0; v < K / 4; ++v) {
+    const int4 a = reinterpret_cast<const int4*>(idx + i * K)[v];
+    const float4 b = reinterpret_cast<const float4*>(qv + i * K)[v];
+    p[4 * v] = a.x; p[4 * v + 1] = a.y; p[4 * v + 2] = a.z; p[4 * v + 3] = a.w;
+    q[4 * v] = b.x; q[4 * v + 1] = b.y; q[4 * v + 2] = b.z; q[4 * v + 3] = b.w;
+  }
+  float s[K], f[K][3];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int64_t pc = p[k] >= 0 ? p[k] : 0;               // (a point always exists when any fragment does; row 0 otherwise unused)
+    s[k] = p[k] >= 0 ? scaler[pc] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f[k][c] = (c < C && p[k] >= 0) ? feat[pc * C + c] : 0.f;
+  }
+  float sw = 0.f, acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (p[k] >= 0) {
+      const float w = expf(-0.5f * q[k]) * s[k];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) if (c < C) acc[c] += w * f[k][c];
+      sw += w;
+    }
+  }
+  if (frag_scaler) {
+#pragma unroll
+    for (int v = 0; v < K / 4; ++v)
+      reinterpret_cast<float4*>(frag_scaler + i * K)[v] = make_float4(s[4 * v], s[4 * v + 1], s[4 * v + 2], s[4 * v + 3]);
+  }
+  float d = 1.0f;
+  if (norm) d = sw > eps ? sw : eps;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) if (c < C) out[i * (C + 1) + c] = norm ? acc[c] / d : acc[c];
+  out[i * (C + 1) + C] = occ[i];
+}
+
 __global__ void k_composite(const int32_t* __restrict__ idx, const float* __restrict__ qv,
                             const float* __restrict__ occ, const float* __restrict__ scaler,
                             const float* __restrict__ feat, int K, int C, int norm, float eps,
@@ -2316,6 +2366,36 @@ extern "C" int iso_rasterize_fine(const float* points, const float* ellipse, con
   return ISO_OK;
 }
 
+namespace {
+// DSS/utils/__init__.py:172-185 (gather_with_neg_idx) for one float per point: out[i] = idx[i] >= 0 ? values[idx[i]] : 0.
+// Four entries per thread (16-byte loads of idx, 16-byte stores).
+__global__ __launch_bounds__(256) void k_gather_neg_idx(const float* __restrict__ values, const int32_t* __restrict__ idx,
+                                                        int64_t n, float* __restrict__ out) {
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 + 3 < n) {
+    const int4 k = *reinterpret_cast<const int4*>(idx + i0);
+    float4 r;
+    r.x = k.x >= 0 ? values[k.x] : 0.f;
+    r.y = k.y >= 0 ? values[k.y] : 0.f;
+    r.z = k.z >= 0 ? values[k.z] : 0.f;
+    r.w = k.w >= 0 ? values[k.w] : 0.f;
+    *reinterpret_cast<float4*>(out + i0) = r;
+  } else {
+    for (int64_t i = i0; i < n; ++i) { const int k = idx[i]; out[i] = k >= 0 ? values[k] : 0.f; }
+  }
+}
+}  // namespace
+
+extern "C" int iso_gather_neg_idx(const float* values, const int32_t* idx, int64_t n, float* out, void* stream) {
+  ISO_REQUIRE(n >= 0, ISO_ERR_INVALID, "iso_gather_neg_idx: bad size");
+  if (n == 0) return ISO_OK;
+  ISO_REQUIRE(values && idx && out, ISO_ERR_INVALID, "iso_gather_neg_idx: null pointer");
+  ISO_REQUIRE((((uintptr_t)idx | (uintptr_t)out) & 15) == 0, ISO_ERR_INVALID, "iso_gather_neg_idx: idx / out must be 16-byte aligned");
+  hipLaunchKernelGGL(k_gather_neg_idx, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, values, idx, n, out);
+  ISO_CHECK_LAUNCH("iso_gather_neg_idx");
+  return ISO_OK;
+}
+
 extern "C" int iso_splat_composite(const int32_t* idx, const float* qvalue, const float* occ,
                                    const float* scaler, const float* features, int64_t n_pixels,
                                    int points_per_pixel, int channels, int norm_weighted, float eps,
@@ -2325,6 +2405,14 @@ extern "C" int iso_splat_composite(const int32_t* idx, const float* qvalue, cons
   if (n_pixels == 0) return ISO_OK;
   ISO_REQUIRE(idx && qvalue && occ && scaler && image_out && (features || channels == 0),
               ISO_ERR_INVALID, "iso_splat_composite: null pointer");
+  const bool aligned = (((uintptr_t)idx | (uintptr_t)qvalue | (uintptr_t)frag_scaler_out) & 15) == 0;
+  if (aligned && channels <= 3 && points_per_pixel == 8)
+    hipLaunchKernelGGL(k_composite_k<8>, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, qvalue,
+                       occ, scaler, features, channels, norm_weighted, eps, n_pixels, frag_scaler_out, image_out);
+  else if (aligned && channels <= 3 && points_per_pixel == 4)
+    hipLaunchKernelGGL(k_composite_k<4>, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, qvalue,
+                       occ, scaler, features, channels, norm_weighted, eps, n_pixels, frag_scaler_out, image_out);
+  else
   hipLaunchKernelGGL(k_composite, dim3(iso_stream_grid(n_pixels, 256)), dim3(256), 0,
                      (hipStream_t)stream, idx, qvalue, occ, scaler, features, points_per_pixel,
                      channels, norm_weighted, eps, n_pixels, frag_scaler_out, image_out);

@@ -51,6 +51,17 @@ def host_lengths(num_points):
     return h
 
 
+def true_counts(mask):
+    """Host list of the number of True entries per cloud of a (B, P) bool mask: one device reduction + one host read,
+    remembered on the tensor (keyed on its version, like with_host_lengths)."""
+    h = getattr(mask, "_iso_true", None)
+    if h is None or getattr(mask, "_iso_true_version", None) != mask._version:
+        B = mask.shape[0]
+        h = [int(x) for x in mask.reshape(B, -1).sum(dim=1).tolist()]
+        mask._iso_true, mask._iso_true_version = h, mask._version
+    return h
+
+
 def full_lengths(points):
     B, P = points.shape[0], points.shape[1]
     return with_host_lengths(torch.full((B,), P, dtype=torch.long, device=points.device), [P] * B)
@@ -103,8 +114,7 @@ def packed_to_padded(packed, lens, pad_value=0):
 
 def reduce_mask_padded(values, mask):
     """DSS/utils/__init__.py:149-169: drop the masked-out rows of each cloud, re-pad with 0."""
-    B = values.shape[0]
-    counts = [int(x) for x in mask.view(B, -1).sum(dim=1).tolist()]
+    counts = true_counts(mask)                       # one host read per mask tensor, not one per call
     packed = values[mask]
     return packed_to_padded(packed, counts)
 
@@ -236,8 +246,11 @@ class UniformProjection(LevelSetProjection):
         if follow is not None:
             follow.done = False
         if siren_spec(model) is not None and not forward_kwargs:
-            ps = self._packed_cache if (self.reuse_packed and isinstance(self._packed_cache, PackedSiren)
-                                        and self._packed_for is model) else PackedSiren(model, dev)
+            # the packed weight image is re-used while the weights are the ones it was made from (storage + in-place
+            # version of every tensor: sdf_models.weights_key), or on the caller's word (reuse_packed)
+            pc = self._packed_cache
+            ps = pc if (isinstance(pc, PackedSiren) and self._packed_for is model
+                        and (self.reuse_packed or pc.current(model, dev))) else PackedSiren(model, dev)
             self._packed_for = model
             ws = ps.workspace(n)
             _lib.call("iso_project_siren", p(pts), p(out), p(normals), p(mask), n, p(ps.packed),
@@ -451,13 +464,18 @@ class UniformProjection(LevelSetProjection):
         wanted = lengths                                              # upsample() refills to the input count
 
         def converged(res):
+            # keep the converged points (:59-65).  ONE host read -- the number of them per cloud -- decides: all of
+            # them (the usual case on a fitted network) -> the result as it is, no copy; else one compaction
+            n_true = true_counts(res.mask)
+            if all(n == int(res.mask.shape[1]) for n in n_true):
+                return res, with_host_lengths(torch.tensor(n_true, dtype=torch.long, device=res.mask.device), n_true)
             kept = _filter_projection_result(res)
-            return kept, kept.mask.sum(dim=-1)
+            return kept, with_host_lengths(torch.tensor(n_true, dtype=torch.long, device=res.mask.device), n_true)
 
         with torch.no_grad():
             res = self._project_points(model, cloud, lengths, proj_max_iters=proj_max_iters or self.proj_max_iters,
                                        **forward_kwargs)
-            if not res.mask.any():
+            if sum(true_counts(res.mask)) == 0:                       # `not mask.any()` (:396), the count is re-used below
                 return {"levelset_points": res.points, "mask": res.mask}
             if not skip_resampling:
                 res, lengths = converged(res)
@@ -810,8 +828,12 @@ def find_zero_crossing_between_point_pairs(p0, p1, network, n_secant_steps=8, n_
 
 
 def mask_padded_to_list(values, mask):
-    """DSS/utils/__init__.py:119-146 for padded inputs: per cloud, the rows where mask is True."""
-    return [values[b][mask[b]] for b in range(values.shape[0])]
+    """DSS/utils/__init__.py:119-146 for padded inputs: per cloud, the rows where mask is True.  The number of True
+    rows per cloud is read from the device once per mask tensor (true_counts); a cloud whose mask is all True is
+    returned as it is (no boolean-index pass: nonzero + gather + a host read of its own, 0.1 ms at 1 M points)."""
+    n_true = true_counts(mask)
+    P = int(mask.shape[1]) if mask.ndim > 1 else 0
+    return [values[b] if n_true[b] == P else values[b][mask[b]] for b in range(values.shape[0])]
 
 
 def sample_uniform_iso_points(model, n_points, init_points=None, bounding_sphere_radius=1.0, generator=None,

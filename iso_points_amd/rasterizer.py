@@ -415,7 +415,9 @@ class EllipticalRasterizer(autograd.Function):
                                       "reference either: its backward unpacks 8 saved tensors where 4 were "
                                       "saved (rasterizer.py:774-776 vs :807-809)")
         ctx.save_for_backward(pts_screen, radii, idx, cloud_to_packed_first_idx, num_points_per_cloud)
-        ctx.mark_non_differentiable(idx)
+        # no gradient flows back through idx or qvalue: backward ignores qvalue_grad exactly as the reference does (:784) --
+        # saying so here spares a compositor behind this op the gradient of its weights with respect to q (8 M terms)
+        ctx.mark_non_differentiable(idx, qvalue_map)
         return idx, zbuf, qvalue_map, occ_map
 
     @staticmethod
@@ -463,7 +465,19 @@ class SurfaceSplatting(object):
         self.raster_settings = raster_settings or PointsRasterizationSettings()
         self.frnn_radius = frnn_radius
         self.znear, self.zfar = znear, zfar
-        self._Vrk_h = None
+        self._Vrk_h_value, self._Vrk_h_maker = None, None
+
+    @property
+    def _Vrk_h(self):
+        """The K = 7 bandwidth of every packed row of the last forward / per_point_info call (rasterizer.py:367-386 keeps it
+        on the object); after forward() it is gathered from the per-view bandwidths on first access."""
+        if self._Vrk_h_value is None and self._Vrk_h_maker is not None:
+            self._Vrk_h_value, self._Vrk_h_maker = self._Vrk_h_maker(), None
+        return self._Vrk_h_value
+
+    @_Vrk_h.setter
+    def _Vrk_h(self, value):
+        self._Vrk_h_value, self._Vrk_h_maker = value, None
 
     def filter_renderable(self, points, normals, views):
         """-> flags (N,P) int32, offsets (N*P) int32 exclusive scan, lens (host list)."""
@@ -686,63 +700,87 @@ class SurfaceSplatting(object):
                 fr = self.front(pts, nrm, views[v0:v1], projs[v0:v1], features=None if wide else ff)
             parts.append((fr, pts, nrm, pp, ff if wide else None))
         # exact-size results: ONE host read of every job's row counts
-        counts = torch.cat([fr["num_points"] for fr, _, _, _, _ in parts]).tolist()
+        one = len(parts) == 1
+        counts = (parts[0][0]["num_points"] if one else torch.cat([fr["num_points"] for fr, _, _, _, _ in parts])).tolist()
         lens = [int(x) for x in counts]
         tot = sum(lens)
         fl = [sum(lens[:i]) for i in range(N)]
-        num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
-        first = with_host_lengths(torch.tensor(fl, dtype=torch.int64, device=dev), fl)
-        flags_jobs = [((fr["mask"][None] >> torch.arange(v1 - v0, device=dev)[:, None]) & 1).to(torch.int32)
-                      for (fr, _, _, _, _), (_, v0, v1) in zip(parts, jobs)]
-        if B == 1:
-            flags = torch.cat(flags_jobs, dim=0)                       # (N, P)
-        else:                                                          # (B, max P): a cloud's row is zero past its length
-            pmax = max(int(f.shape[1]) for f in flags_jobs)
+        if one:                # the front end's own device-side layout (no host -> device copies of what the device has)
+            num = with_host_lengths(parts[0][0]["num_points"], lens)
+            first = with_host_lengths(parts[0][0]["first_idx"], fl)
+        else:
+            num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
+            first = with_host_lengths(torch.tensor(fl, dtype=torch.int64, device=dev), fl)
+
+        def make_flags():
+            flags_jobs = [((fr["mask"][None] >> torch.arange(v1 - v0, device=dev)[:, None]) & 1).to(torch.int32)
+                          for (fr, _, _, _, _), (_, v0, v1) in zip(parts, jobs)]
+            if B == 1:
+                return torch.cat(flags_jobs, dim=0) if len(flags_jobs) > 1 else flags_jobs[0]      # (N, P)
+            pmax = max(int(f.shape[1]) for f in flags_jobs)          # (B, max P): a cloud's row is zero past its length
             flags = torch.zeros((B, pmax), dtype=torch.int32, device=dev)
             for b, f in enumerate(flags_jobs):
                 flags[b, :f.shape[1]] = f[0]
+            return flags
+
         if tot == 0:
+            flags = make_flags()
             idx = torch.full((N, S, W, K), -1, dtype=torch.int32, device=dev)
             neg = torch.full((N, S, W, K), -1.0, dtype=torch.float32, device=dev)
             occ = torch.zeros((N, S, W), dtype=torch.float32, device=dev)
             return PointFragments(idx, neg, neg.clone(), neg.clone(), occ), {"num_points": num, "first_idx": first,
                                                                              "flags": flags}
-        cols = {k: [] for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler", "ndc", "src", "features",
-                                "points", "normals", "h")}
+        # Columns of the packed rows.  What the raster needs is built now; the rest of the reference's `filtered` dictionary
+        # (gathered points / normals / wide features, int64 src, flags, visibility, the rows' bandwidths) on first access.
+        cols = {k: [] for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler", "ndc", "features")}
+        spans = []                                                     # per job: (first view's offset into lens, views, rows)
         v_at = 0
         for (fr, pts, nrm, pp, wide_ff), (_, v0, v1) in zip(parts, jobs):
             nv = v1 - v0
             jl = lens[v_at:v_at + nv]
             jt = sum(jl)
+            spans.append((v_at, nv, jt))
             for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler"):
                 cols[k].append(fr[k][:jt])
             ndc = fr["ndc"][:jt]
             if pp.requires_grad:
                 # the reference's gradient reaches the world points through cameras.transform_points (:618); the
-                # set-up is under no_grad (:608-610)
-                jf = [sum(jl[:i]) for i in range(nv)]
+                # set-up is under no_grad (:608-610).  (first / num of the job's rows: the front end's device tensors)
                 ndc = _WorldToRows.apply(pp, ndc, views[v0:v1], projs[v0:v1], fr["mask"], fr["src"],
-                                         torch.tensor(jf, dtype=torch.int64, device=dev),
-                                         torch.tensor(jl, dtype=torch.int64, device=dev))
+                                         fr["first_idx"], fr["num_points"])
             cols["ndc"].append(ndc)
-            src = fr["src"][:jt].long()
-            cols["src"].append(src)
-            cols["points"].append(pts[src])
-            cols["normals"].append(nrm[src])
-            if wide_ff is not None:
-                cols["features"].append(_f32c(wide_ff)[src])
-            elif fr["features"] is not None:
+            if wide_ff is None and fr["features"] is not None:
                 cols["features"].append(fr["features"][:jt])
+            v_at += nv
+
+        def src_of(j):
+            return parts[j][0]["src"][:spans[j][2]].long()
+
+        def gathered(which):
+            def make():
+                out = []
+                for j, (fr, pts, nrm, pp, wide_ff) in enumerate(parts):
+                    x = {"points": pts, "normals": nrm, "features": _f32c(wide_ff) if wide_ff is not None else None}[which]
+                    out.append(x[src_of(j)])
+                return torch.cat(out, dim=0) if len(out) > 1 else out[0]
+            return make
+
+        def make_h():
             # the bandwidth of every packed row: view v's rows are a slice (lengths known on the host), gathered view by
             # view (torch.repeat_interleave over 2 M rows was 0.2 ms of the operator-API cycle)
-            jf0 = [sum(jl[:i]) for i in range(nv)]
-            cols["h"].append(torch.cat([fr["h"][v][src[jf0[v]:jf0[v] + jl[v]]] for v in range(nv)]) if nv > 1
-                             else fr["h"][0][src])
-            v_at += nv
+            out = []
+            for j, (fr, _, _, _, _) in enumerate(parts):
+                v_at, nv, jt = spans[j]
+                jl = lens[v_at:v_at + nv]
+                jf0 = [sum(jl[:i]) for i in range(nv)]
+                src = src_of(j)
+                out.append(torch.cat([fr["h"][v][src[jf0[v]:jf0[v] + jl[v]]] for v in range(nv)]) if nv > 1 else fr["h"][0][src])
+            return torch.cat(out, dim=0) if len(out) > 1 else out[0]
+
         cat = {k: (torch.cat(v, dim=0) if len(v) > 1 else v[0]) if v else None for k, v in cols.items()}
         info = {k: cat[k] for k in ("radii", "ellipse_params", "cutoff_threshold", "scaler")}
         ndc = cat["ndc"]
-        self._Vrk_h = cat["h"]
+        self._Vrk_h_maker, self._Vrk_h_value = make_h, None
         idx, zbuf, qv, occ = rasterize_elliptical_points(
             PackedClouds(ndc, first, num), info["ellipse_params"], info["cutoff_threshold"], info["radii"],
             depth_merging_threshold=rs.depth_merging_threshold, image_size=rs.image_size, points_per_pixel=K,
@@ -750,12 +788,20 @@ class SurfaceSplatting(object):
             radii_backward_scaler=rs.radii_backward_scaler, clip_pts_grad=rs.clip_pts_grad)
         frag_scaler = gather_with_neg_idx(info["scaler"], idx)
         frags = PointFragments(idx, zbuf, qv, frag_scaler, occ)
-        vis = torch.zeros((tot,), dtype=torch.uint8, device=dev)
-        _lib.call("iso_splat_mark_visible", _lib.ptr(idx), N * S * W, K, _lib.ptr(vis), _lib.stream())
-        filtered = {"points": cat["points"], "normals": cat["normals"], "features": cat["features"], "ndc": ndc,
-                    "num_points": num, "first_idx": first, "flags": flags, "visibility": vis.bool(), "src": cat["src"],
-                    **info}
-        return frags, filtered
+
+        def make_vis():
+            vis = torch.zeros((tot,), dtype=torch.uint8, device=dev)
+            _lib.call("iso_splat_mark_visible", _lib.ptr(idx), N * S * W, K, _lib.ptr(vis), _lib.stream())
+            return vis.bool()
+
+        makers = {"points": gathered("points"), "normals": gathered("normals"), "flags": make_flags, "visibility": make_vis,
+                  "src": lambda: (torch.cat([src_of(j) for j in range(len(parts))]) if len(parts) > 1 else src_of(0))}
+        eager = {"ndc": ndc, "num_points": num, "first_idx": first, **info}
+        if any(wide is not None for _, _, _, _, wide in parts):
+            makers["features"] = gathered("features")
+        else:
+            eager["features"] = cat["features"]
+        return frags, LazyDict(eager, makers)
 
 
 class _WorldToRows(autograd.Function):
@@ -780,9 +826,63 @@ class _WorldToRows(autograd.Function):
 
 
 def gather_with_neg_idx(values, idx):
-    """utils/__init__.py:172-185: values[idx], 0 where idx < 0."""
+    """utils/__init__.py:172-185: values[idx], 0 where idx < 0.  One float per point and int32 indices on the GPU (the
+    fragments' scaler, rasterizer.py:635-637): one kernel (iso_gather_neg_idx) instead of five elementwise passes."""
+    if (values.is_cuda and values.ndim == 1 and values.dtype == torch.float32 and idx.dtype == torch.int32
+            and idx.is_contiguous() and not values.requires_grad):
+        out = torch.empty(idx.shape, dtype=torch.float32, device=idx.device)
+        _lib.call("iso_gather_neg_idx", _lib.ptr(values.contiguous()), _lib.ptr(idx), idx.numel(), _lib.ptr(out), _lib.stream())
+        return out
     g = values[idx.long().clamp(min=0)]
     return torch.where(idx >= 0, g, torch.zeros_like(g))
+
+
+class LazyDict(dict):
+    """A dict whose listed entries are computed on first access (`makers`: key -> thunk).  SurfaceSplatting.forward
+    returns the reference's `filtered` dictionary this way: a caller that only reads the scaler and the normals does
+    not pay for the gathered points, the flags, the visibility marks ... (0.4 ms of torch glue at 2 M rows).  Iterating,
+    copying or unpacking the dict materialises everything."""
+
+    def __init__(self, eager, makers):
+        super().__init__(eager)
+        self._makers = dict(makers)
+
+    def __missing__(self, key):
+        mk = self._makers.pop(key, None)
+        if mk is None:
+            raise KeyError(key)
+        v = mk()
+        super().__setitem__(key, v)
+        return v
+
+    def _all(self):
+        for k in list(self._makers):
+            self[k]
+        return self
+
+    def __contains__(self, key):
+        return super().__contains__(key) or key in self._makers
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return super(LazyDict, self._all()).keys()
+
+    def values(self):
+        return super(LazyDict, self._all()).values()
+
+    def items(self):
+        return super(LazyDict, self._all()).items()
+
+    def __iter__(self):
+        return super(LazyDict, self._all()).__iter__()
+
+    def __len__(self):
+        return super().__len__() + len(self._makers)
+
+    def copy(self):
+        return dict(self._all())
 
 
 class _Composite(autograd.Function):
@@ -807,6 +907,10 @@ class _Composite(autograd.Function):
         N, S, S2, K = idx.shape
         C = ft.shape[1]
         need = ctx.needs_input_grad
+        if not (need[1] or need[3] or need[4]):
+            # only the occupancy channel carries a gradient (features, scaler and q are constants of this graph -- the
+            # splat op declares its qvalue non-differentiable): dL/docc is the image gradient's last channel, no kernel
+            return None, None, (grad_img[..., C].contiguous() if need[2] else None), None, None, None, None
         g = _f32c(grad_img)
         gq = torch.empty_like(qv) if need[1] else None
         gocc = torch.empty((N, S, S2), dtype=torch.float32, device=idx.device) if need[2] else None

@@ -115,14 +115,26 @@ def siren_spec(model):
     return lins, omegas[0], (omegas[1] if len(omegas) > 1 else omegas[0])
 
 
+def weights_key(lins, device):
+    """Identity of a network's weights as the packed images see them: storage address and in-place version of every
+    weight / bias.  An optimiser step (in-place) or a re-assigned .data changes it; nothing else does."""
+    return (str(device),) + tuple((t.data_ptr(), t._version) for lin in lins for t in (lin.weight, lin.bias))
+
+
 class PackedSiren(object):
-    """Device-side MFMA weight image of a SIREN (iso_siren_pack_weights)."""
+    """Device-side MFMA weight image of a SIREN (iso_siren_pack_weights).  `key` = weights_key at packing time: a
+    caller holding an image re-uses it as long as `current(model)` says the weights are the ones it was made from."""
+
+    def current(self, model, device):
+        spec = siren_spec(model)
+        return spec is not None and weights_key(spec[0], device) == self.key
 
     def __init__(self, model, device):
         spec = siren_spec(model)
         if spec is None:
             raise ValueError("model is not a SIREN the fused kernel supports")
         lins, self.omega_first, self.omega_hidden = spec
+        self.key = weights_key(lins, device)
         self.model_hidden = lins[0].out_features
         # the fused kernels exist for H = 64 / 128 / 256: any other width runs as the next one up with ZERO rows and
         # columns added -- a padded unit has z = 0, sin(0) = 0 and feeds zero columns, so value and gradient are those

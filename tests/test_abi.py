@@ -54,3 +54,23 @@ def test_product_refuses_cpu_tensors():
     x = torch.rand(1, 10, 3)
     with pytest.raises(RuntimeError):
         frnn.frnn_grid_points(x, x, K=3, r=0.5)
+
+
+def test_no_vgpr_spills_in_the_raster_kernels():
+    """Code-object metadata of the built library (tools/spill_check.py): the candidate-parallel raster kernels of the cycle
+    (K <= 8) must not spill vector registers -- a build of k_raster<8, true> with two spilled VGPRs returned stale list
+    entries for pixels with depth ties (profiles/HISTORY.md, round 5)."""
+    import importlib.util
+    import shutil
+    import pytest
+    if not shutil.which("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no ROCm llvm tools")
+    from iso_points_amd import _lib
+    spec = importlib.util.spec_from_file_location("spill_check", os.path.join(ROOT, "tools", "spill_check.py"))
+    sc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sc)
+    ks = sc.kernels(_lib.LIB_PATH)
+    assert len(ks) > 100, "code objects not found in the library"
+    raster = [k for k in ks if "8k_rasterILi4ELb1" in k[0] or "8k_rasterILi8ELb1" in k[0]]
+    assert len(raster) == 2, [k[0] for k in ks if "raster" in k[0]]
+    assert all(k[1] == 0 for k in raster), raster

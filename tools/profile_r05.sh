@@ -82,7 +82,8 @@ if has idr; then
   done
 fi
 if has opapi; then
-  DB=$(run_prof opapi "--stats" python tools/opapi_only.py 6)
-  python $REPO/tools/cycle_sequence.py $DB $OUT/r05_opapi_sequence.txt | tail -1
-  grep -i "operator" /tmp/rp_opapi.log | tail -3
+  TAGO=${OPAPI_TAG:-r05_opapi}
+  DB=$(run_prof opapi "" python tools/opapi_only.py 6 trace)
+  grep -i "operator API" /tmp/rp_opapi.log | cut -c1-200
+  python $REPO/tools/opapi_sequence.py $DB $OUT/${TAGO}_sequence.txt | tail -1
 fi
