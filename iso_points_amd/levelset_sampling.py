@@ -57,7 +57,7 @@ def true_counts(mask):
     h = getattr(mask, "_iso_true", None)
     if h is None or getattr(mask, "_iso_true_version", None) != mask._version:
         B = mask.shape[0]
-        h = [int(x) for x in mask.reshape(B, -1).sum(dim=1).tolist()]
+        h = [int(x) for x in torch.count_nonzero(mask.reshape(B, -1), dim=1).tolist()]
         mask._iso_true, mask._iso_true_version = h, mask._version
     return h
 
@@ -467,8 +467,8 @@ class UniformProjection(LevelSetProjection):
             # keep the converged points (:59-65).  ONE host read -- the number of them per cloud -- decides: all of
             # them (the usual case on a fitted network) -> the result as it is, no copy; else one compaction
             n_true = true_counts(res.mask)
-            if all(n == int(res.mask.shape[1]) for n in n_true):
-                return res, with_host_lengths(torch.tensor(n_true, dtype=torch.long, device=res.mask.device), n_true)
+            if n_true == host_lengths(lengths):                       # nothing dropped: the lengths tensor as it is
+                return res, lengths
             kept = _filter_projection_result(res)
             return kept, with_host_lengths(torch.tensor(n_true, dtype=torch.long, device=res.mask.device), n_true)
 

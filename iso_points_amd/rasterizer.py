@@ -164,19 +164,24 @@ class _CNamespace(object):
         tile_cnt = (tile_cnt_ws[:4 * (ntiles + 1)] if own_cnt else _zeroed_workspace("tile_cnt", dev, 4 * (ntiles + 1))).view(torch.int32)
         tile_off = torch.empty((ntiles + 1,), dtype=torch.int32, device=dev)
         cursor = torch.empty((ntiles + 1,), dtype=torch.int32, device=dev)   # [ntiles] = overflow flag
-        try:
-            _lib.call("iso_splat_bin_count", p(pts), p(ra), p(first), p(num), N, maxp, S, W, band[0], band[1],
-                      p(tile_cnt), s)
-            _lib.call("iso_splat_tile_offsets", p(tile_cnt), p(tile_off), p(cursor), ntiles + 1, s)
-        except Exception:
-            if not own_cnt:                                   # it may hold counts: never reuse it
-                for k in [k for k, v in _ZEROED.items() if v.data_ptr() == tile_cnt.data_ptr()]:
-                    _ZEROED.pop(k, None)
-            raise
-        if pair_capacity is None:
-            total = int(tile_off[ntiles].item())      # the one host read of the forward pass
+        binned = getattr(num_points_per_cloud, "_iso_binned", None)      # SurfaceSplatting.forward: see prebin()
+        if binned is not None and binned[0] == (S, W, band, N, P):
+            tile_off, cursor, total = binned[1]
+            del num_points_per_cloud._iso_binned
         else:
-            total = int(pair_capacity)
+            try:
+                _lib.call("iso_splat_bin_count", p(pts), p(ra), p(first), p(num), N, maxp, S, W, band[0], band[1],
+                          p(tile_cnt), s)
+                _lib.call("iso_splat_tile_offsets", p(tile_cnt), p(tile_off), p(cursor), ntiles + 1, s)
+            except Exception:
+                if not own_cnt:                                   # it may hold counts: never reuse it
+                    for k in [k for k, v in _ZEROED.items() if v.data_ptr() == tile_cnt.data_ptr()]:
+                        _ZEROED.pop(k, None)
+                raise
+            if pair_capacity is None:
+                total = int(tile_off[ntiles].item())      # the one host read of the forward pass
+            else:
+                total = int(pair_capacity)
         pairs = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
         if overflow_out is not None:
             overflow_out.append(cursor[ntiles:])
@@ -198,6 +203,32 @@ class _CNamespace(object):
                   float(depth_merging_thres), S, W, K, band[0], band[1], p(cursor), p(tile_off), p(pairs), total,
                   _lib.ctypes.c_void_p(cursor.data_ptr() + 4 * ntiles), p(idx), p(zbuf), p(qv), p(occ), p(rws), rws_b, s)
         return idx, zbuf, qv, occ
+
+    @staticmethod
+    def prebin(points, radii, first, num, max_pts, image_size):
+        """The count pass and the tile offsets of splat_points on arrays whose row counts only the device knows yet
+        (first / num (N,) int64 device tensors, max_pts >= every cloud's rows): SurfaceSplatting.forward issues them before
+        its one host read, which then brings back the row counts AND the pair total (tile_off[-1]) -- splat_points no
+        longer stops the queue between the offsets and the fill.  Returns (tile_off, cursor); attach
+        ((S, W, band, N, rows), (tile_off, cursor, total)) to the num tensor splat_points will be given as `_iso_binned`."""
+        S, W = image_hw(image_size)
+        dev = points.device
+        N = num.shape[0]
+        lib = _lib.load()
+        T, TW = lib.iso_splat_tiles_per_side(S), lib.iso_splat_tiles_per_side(W)
+        ntiles = N * T * TW
+        p, s = _lib.ptr, _lib.stream()
+        tile_cnt = _zeroed_workspace("tile_cnt", dev, 4 * (ntiles + 1)).view(torch.int32)
+        tile_off = torch.empty((ntiles + 1,), dtype=torch.int32, device=dev)
+        cursor = torch.empty((ntiles + 1,), dtype=torch.int32, device=dev)
+        try:
+            _lib.call("iso_splat_bin_count", p(points), p(radii), p(first), p(num), N, int(max_pts), S, W, 0, T, p(tile_cnt), s)
+            _lib.call("iso_splat_tile_offsets", p(tile_cnt), p(tile_off), p(cursor), ntiles + 1, s)
+        except Exception:
+            for k in [k for k, v in _ZEROED.items() if v.data_ptr() == tile_cnt.data_ptr()]:
+                _ZEROED.pop(k, None)
+            raise
+        return tile_off, cursor, (S, W, (0, T), N)
 
     @staticmethod
     def _splat_points_naive(points, ellipse_params, cutoff_thres, radii, cloud_to_packed_first_idx,
@@ -428,8 +459,11 @@ class EllipticalRasterizer(autograd.Function):
         if occ_grad is None:
             occ_grad = torch.zeros(idx.shape[:3], dtype=torch.float32, device=idx.device)
         vis, rs = _visible_and_radius(idx, radii, first_idx, num_points, ctx.radii_backward_scaler)
+        # the clouds tile the rows [0, P) (host lengths): every row is written by the kernels, no zero fill of the result
+        fl, nl = ctx.host
+        covered = sum(nl) == pts_screen.shape[0] and all(fl[i] == sum(nl[:i]) for i in range(len(nl)))
         grads = _C._backward(pts_screen, radii, occ_grad, first_idx, num_points, visible=vis, rs=rs,
-                             idx=idx, grad_zbuf=zbuf_grad)
+                             idx=idx, grad_zbuf=zbuf_grad, rows_covered=covered)
         return (grads, None, None, None, None, None, None, None, None, None, None, None)
 
 
@@ -701,13 +735,25 @@ class SurfaceSplatting(object):
             parts.append((fr, pts, nrm, pp, ff if wide else None))
         # exact-size results: ONE host read of every job's row counts
         one = len(parts) == 1
+        binned = None
+        if one and min(S, W) > 0:
+            # one job: the raster's count pass + tile offsets run on the front end's capacity-sized arrays BEFORE the host
+            # read below, which then also brings the pair total (no second stop of the queue inside splat_points)
+            fr0 = parts[0][0]
+            with torch.no_grad():
+                binned = _C.prebin(fr0["ndc"], fr0["radii"], fr0["first_idx"], fr0["num_points"], parts[0][1].shape[0],
+                                   rs.image_size)
         counts = (parts[0][0]["num_points"] if one else torch.cat([fr["num_points"] for fr, _, _, _, _ in parts])).tolist()
         lens = [int(x) for x in counts]
         tot = sum(lens)
+        if binned is not None:
+            binned = (binned[2] + (tot,), (binned[0], binned[1], int(binned[0][-1].item())))
         fl = [sum(lens[:i]) for i in range(N)]
         if one:                # the front end's own device-side layout (no host -> device copies of what the device has)
             num = with_host_lengths(parts[0][0]["num_points"], lens)
             first = with_host_lengths(parts[0][0]["first_idx"], fl)
+            if binned is not None and tot > 0:
+                num._iso_binned = binned
         else:
             num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
             first = with_host_lengths(torch.tensor(fl, dtype=torch.int64, device=dev), fl)
