@@ -7,9 +7,9 @@
 //     CU, so it is the small-cloud form.
 //   * k_fps_grid (clouds of >= 8 k points): a cooperative launch of up to 256 workgroups; every
 //     thread keeps its <= 16 points AND their min-distances in registers (nothing is read from
-//     memory inside the loop except the winner's coordinates), the workgroup maxima meet in one
-//     64-bit atomicMax on (distance bits, ~index) and a counter barrier: ~2 device-scope atomics
-//     per workgroup and iteration instead of 16 B x len of traffic.
+//     memory inside the loop except the winner's coordinates); the workgroup maxima -- 64-bit keys
+//     (distance bits, ~index) -- meet through one store per workgroup and one polling load per lane of
+//     wave 0 (no atomics, no counter barrier: see the comment at the kernel).
 #include <float.h>
 #include <stdlib.h>
 #include "iso_common.h"
@@ -74,11 +74,16 @@ __global__ __launch_bounds__(FPS_BLOCK) void k_fps(const float* __restrict__ pts
 }
 
 // ---- grid-wide form ----------------------------------------------------------------------------
-// control block (device memory, zeroed before the launch): [0] arrival counter (u32, monotone),
-// [8..32) three rotating 64-bit maximum slots (iteration s uses slot s % 3; workgroup 0 clears
-// slot (s+2) % 3 after barrier s -- it was last read before barrier s and is next written after
-// barrier s+1).
-struct FpsCtl { unsigned int arrived; unsigned int pad; unsigned long long slot[3]; };
+// The workgroups agree on an iteration's winner through ONE round trip of plain memory operations: workgroup b stores its
+// best key to slots[s & 1][b] (one agent-scope 8-byte store), wave 0 of every workgroup polls all nb slots (a slot per
+// lane and trip) until each carries the iteration's tag, and reduces them with shuffles -- every workgroup computes the
+// same maximum.  Until round 5 this was an atomicMax on one word + an arrival counter + a poll of the counter + a load of
+// the maximum: four dependent device-scope round trips (5.0 us per sample at 500 k points, of which the distance update
+// is 0.7).  Key = (distance bits : ~index); the index is < 2^31, so bit 31 of ~index is always set and carries the tag
+// ((s >> 1) & 1) ^ 1 instead: a slot is rewritten every second iteration, its previous content has the other tag, and the
+// zeroed control block matches neither iteration 0 nor 1.
+constexpr int kFpsMaxGrid = 256;
+struct FpsCtl { unsigned long long slot[2][kFpsMaxGrid]; };
 
 template <int PPT>
 __global__ __launch_bounds__(FPS_BLOCK) void k_fps_grid(const float* __restrict__ p, const int64_t* __restrict__ lengths,
@@ -91,6 +96,7 @@ __global__ __launch_bounds__(FPS_BLOCK) void k_fps_grid(const float* __restrict_
   const int64_t ns = n_samples[n] < len ? n_samples[n] : len;
   if (len <= 0 || ns <= 0) return;                      // uniform over the grid
   const int t = threadIdx.x;
+  const int lane = t & 63;
   const unsigned nb = gridDim.x;
   const int64_t stride = (int64_t)nb * FPS_BLOCK;
   const int64_t first = (int64_t)blockIdx.x * FPS_BLOCK + t;
@@ -107,42 +113,63 @@ __global__ __launch_bounds__(FPS_BLOCK) void k_fps_grid(const float* __restrict_
     if (blockIdx.x == 0 && t == 0) out[s] = cur;
     if (s + 1 == ns) break;
     const float cx = p[(int64_t)cur * 3], cy = p[(int64_t)cur * 3 + 1], cz = p[(int64_t)cur * 3 + 2];
-    unsigned long long key = 0;
+    // a thread's points are in ascending index order: the first strict maximum is its (largest distance, lowest index)
+    float bm = -1.0f;
+    int bk = 0;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
       const float d = (dx * dx + dy * dy) + dz * dz;
       const float m = fminf(mind[k], d);
       mind[k] = m;
-      // (distance bits, ~index): the largest key is the largest distance, lowest index among equals
-      const unsigned long long kk = m < 0.f ? 0ull
-          : (((unsigned long long)__float_as_uint(m) << 32) | (unsigned)(0xffffffffu - (unsigned)(first + k * stride)));
-      key = kk > key ? kk : key;
+      if (m > bm) { bm = m; bk = k; }
     }
+    // (distance bits, ~index): the largest key is the largest distance, lowest index among equals; 0 = no point
+    unsigned long long key = bm < 0.f ? 0ull
+        : (((unsigned long long)__float_as_uint(bm) << 32) | (unsigned)(0xffffffffu - (unsigned)(first + bk * stride)));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned long long ok = __shfl_xor(key, o);
       key = ok > key ? ok : key;
     }
-    if ((t & 63) == 0) s_key[t >> 6] = key;
+    if (lane == 0) s_key[t >> 6] = key;
     __syncthreads();
-    if (t == 0) {
-      unsigned long long best = s_key[0];
-      for (int w = 1; w < FPS_BLOCK / 64; ++w) best = s_key[w] > best ? s_key[w] : best;
-      unsigned long long* slot = &ctl->slot[s % 3];
-      __hip_atomic_fetch_max(slot, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned target = nb * (unsigned)(s + 1);
-      while (__hip_atomic_load(&ctl->arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
-        __builtin_amdgcn_s_sleep(1);
-      const unsigned long long win = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (blockIdx.x == 0)
-        __hip_atomic_store(&ctl->slot[(s + 2) % 3], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_cur = (int)(0xffffffffu - (unsigned)(win & 0xffffffffull));
+    if (t < 64) {                                       // wave 0: the workgroup's maximum, the exchange, the winner
+      unsigned long long best = lane < FPS_BLOCK / 64 ? s_key[lane] : 0ull;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const unsigned long long ok = __shfl_xor(best, o);
+        best = ok > best ? ok : best;
+      }
+      const unsigned long long tag = (unsigned long long)((((unsigned)s >> 1) & 1u) ^ 1u) << 31;
+      const unsigned long long tmask = 1ull << 31;
+      unsigned long long* slots = ctl->slot[s & 1];
+      if (lane == 0)
+        __hip_atomic_store(&slots[blockIdx.x], (best & ~tmask) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long win = 0;
+      for (unsigned b0 = 0; b0 < nb; b0 += 64) {
+        const unsigned b = b0 + lane;
+        unsigned long long v = tag;                    // lanes beyond the grid: a matching tag, the smallest key
+        if (b < nb) {
+          v = __hip_atomic_load(&slots[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while ((v & tmask) != tag) {
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(&slots[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        win = v > win ? v : win;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ok = __shfl_xor(win, o);
+        win = ok > win ? ok : win;
+      }
+      // every key of the iteration carries the same tag bit, so the order of (distance, ~index) is untouched; the bit is
+      // part of ~index (always 1 there): put it back
+      if (lane == 0) s_cur = (int)(0xffffffffu - ((unsigned)(win & 0xffffffffull) | 0x80000000u));
     }
     __syncthreads();
     cur = s_cur;
-    __syncthreads();
   }
 }
 
@@ -156,13 +183,13 @@ hipError_t launch_fps_grid(int nb, const float* p, const int64_t* lengths, const
 }
 
 constexpr int64_t kFpsGridMin = 8192;     // below: one workgroup is faster than grid-wide barriers
-constexpr int kFpsCtlFloats = 16;          // control block at the end of the workspace
+constexpr int kFpsCtlFloats = sizeof(FpsCtl) / 4;   // control block at the end of the workspace
 
 }  // namespace
 
 extern "C" int64_t iso_farthest_point_sampling_work_floats(int n_clouds, int64_t p_stride) {
   if (n_clouds < 0 || p_stride < 0) return 0;
-  return (int64_t)n_clouds * p_stride + kFpsCtlFloats;
+  return (int64_t)n_clouds * p_stride + kFpsCtlFloats + 2;
 }
 
 extern "C" int iso_farthest_point_sampling(const float* points, const int64_t* lengths,
@@ -180,10 +207,13 @@ extern "C" int iso_farthest_point_sampling(const float* points, const int64_t* l
     // grid-wide form, cloud after cloud; the smallest grid that keeps <= 8 points per thread
     // (measured: 2.8 us per sample up to 50 k points, 5.0 at 500 k, 7.1 at 1 M -- the barrier's atomic
     // round trips, not the arithmetic; fewer, fatter workgroups are not faster)
-    int64_t nb = (p_stride + FPS_BLOCK * 8 - 1) / (FPS_BLOCK * 8);
+    static int ppt_target = 0;                       // ISO_FPS_PPT: development override (points per thread the grid is sized for)
+    if (ppt_target == 0) { const char* e = getenv("ISO_FPS_PPT"); ppt_target = e ? atoi(e) : 8; if (ppt_target < 1 || ppt_target > 16) ppt_target = 8; }
+    int64_t nb = (p_stride + FPS_BLOCK * ppt_target - 1) / (FPS_BLOCK * ppt_target);
     nb = nb < 2 ? 2 : (nb > 256 ? 256 : nb);
     const int64_t ppt = (p_stride + nb * FPS_BLOCK - 1) / (nb * FPS_BLOCK);
-    FpsCtl* ctl = reinterpret_cast<FpsCtl*>(work + (int64_t)n_clouds * p_stride);
+    // (8-byte slots: the control block starts at the next 8-byte boundary; kFpsCtlFloats leaves room for it)
+    FpsCtl* ctl = reinterpret_cast<FpsCtl*>(((uintptr_t)(work + (int64_t)n_clouds * p_stride) + 7) & ~(uintptr_t)7);
     bool refused = false;
     for (int n = 0; n < n_clouds; ++n) {
       (void)hipMemsetAsync(ctl, 0, sizeof(FpsCtl), st);
