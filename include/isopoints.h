@@ -509,7 +509,8 @@ int iso_splat_render_visible(const float* points, const float* ellipse, const fl
  *           on the GPU, ascending on the CPU), -1 behind them; *overflow_out is set to 1 when a bin had more than M
  *           (cut at M; never cleared here).
  *   fine:   per pixel the K front-most hits among the entries of its bin (negative entries skipped), tests and outputs
- *           of iso_splat_forward: fine(coarse(x)) == iso_splat_forward(x) bit for bit when no bin overflowed.  K <= 32. */
+ *           of iso_splat_forward: fine(coarse(x)) == iso_splat_forward(x) bit for bit when no bin overflowed.  K <= 150 (above 32: the
+ *           lists are kept in the output arrays, as in iso_splat_forward). */
 int iso_rasterize_coarse(const float* points, const float* radii, const int64_t* first_idx, const int64_t* num_pts,
                          int n_clouds, int image_size, int bin_size, int max_points_per_bin, int32_t* bin_points_out,
                          int32_t* overflow_out, void* stream);

@@ -1144,6 +1144,61 @@ __global__ __launch_bounds__(256) void k_fine_bins(const float* __restrict__ pts
   }
 }
 
+// k_fine_bins for points_per_pixel above 32 (the reference's bound is 150, rasterization_utils.cuh:18, checked at
+// rasterize_points.cu:246-251): as in k_raster_deep the pixel's list lives in its rows of the output arrays and a hit is
+// inserted by shifting the tail there.  Same walk over the bin, same tests, same (z, index) order, same cut.
+__global__ __launch_bounds__(256) void k_fine_bins_deep(const float* __restrict__ pts, const float* __restrict__ ellipse,
+                                                        const float* __restrict__ cutoff, const float* __restrict__ radii,
+                                                        const int32_t* __restrict__ bin_points, int N, int B, int M,
+                                                        int bin_size, Frame F, int K, float depth_thres, int64_t n_points,
+                                                        int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out,
+                                                        float* __restrict__ q_out, float* __restrict__ occ_out) {
+  const int64_t npix = (int64_t)N * F.H * F.W;
+  for (int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pid < npix; pid += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(pid / ((int64_t)F.H * F.W));
+    const int yi = (int)((pid / F.W) % F.H), xi = (int)(pid % F.W);
+    const int by = yi / bin_size, bx = xi / bin_size;
+    const float xf = ndc_x(xi, F), yf = ndc_y(yi, F);
+    const int32_t* bins = bin_points + (((int64_t)n * B + by) * B + bx) * M;
+    const int yo = F.H - 1 - yi, xo = F.W - 1 - xi;        // :577-580
+    const int64_t pix = ((int64_t)n * F.H + yo) * F.W + xo;
+    int32_t* const li = idx_out + pix * K;
+    float* const lz = zbuf_out + pix * K;
+    float* const lq = q_out + pix * K;
+    int have = 0;
+    float wz = FLT_MAX;
+    int wi = 0x7fffffff;
+    for (int m = 0; m < M; ++m) {
+      const int p = bins[m];
+      if (p < 0 || p >= n_points) continue;
+      const float pz = pts[(int64_t)p * 3 + 2];
+      if (!(pz >= 0.f)) continue;
+      const float dx = xf - pts[(int64_t)p * 3], dy = yf - pts[(int64_t)p * 3 + 1];
+      if (fabsf(dx) > radii[(int64_t)p * 2] || fabsf(dy) > radii[(int64_t)p * 2 + 1]) continue;                 // :92
+      const float q = ellipse[(int64_t)p * 3] * dx * dx + ellipse[(int64_t)p * 3 + 1] * dx * dy + ellipse[(int64_t)p * 3 + 2] * dy * dy;   // :94
+      if (q > cutoff[p]) continue;                                                                                // :96
+      if (have == K && !(pz < wz || (pz == wz && p < wi))) continue;
+      int j = have < K ? have : K - 1;
+      while (j > 0) {
+        const float zj = lz[j - 1];
+        const int ij = li[j - 1];
+        if (!(pz < zj || (pz == zj && p < ij))) break;
+        lz[j] = zj; li[j] = ij; lq[j] = lq[j - 1];
+        --j;
+      }
+      lz[j] = pz; li[j] = p; lq[j] = q;
+      if (have < K) ++have;
+      if (have == K) { wz = lz[K - 1]; wi = li[K - 1]; }
+    }
+    const float z0 = have > 0 ? lz[0] : FLT_MAX;
+    occ_out[pix] = have > 0 ? 1.0f : 0.0f;
+    for (int j = 0; j < K; ++j) {
+      const bool ok = j < have && !((lz[j] - z0) > depth_thres);
+      if (!ok) { li[j] = -1; lz[j] = -1.0f; lq[j] = -1.0f; }
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ tile_off, Frame F, int ty_begin,
                                                      int ty_rows, int n_clouds, int32_t* __restrict__ order) {
   const int T = F.Tx, TY = F.Ty;
@@ -2342,8 +2397,8 @@ extern "C" int iso_rasterize_fine(const float* points, const float* ellipse, con
                                   int32_t* idx_out, float* zbuf_out, float* qvalue_out, float* occ_out, void* stream) {
   ISO_REQUIRE(n_clouds >= 0 && image_size > 0 && bin_size > 0 && max_points_per_bin >= 0 && n_points >= 0, ISO_ERR_INVALID,
               "iso_rasterize_fine: bad sizes");
-  ISO_REQUIRE(points_per_pixel >= 1 && points_per_pixel <= 32, ISO_ERR_UNSUPPORTED,
-              "iso_rasterize_fine: points_per_pixel must be in [1,32] (deeper lists: iso_splat_forward), got %d", points_per_pixel);
+  ISO_REQUIRE(points_per_pixel >= 1 && points_per_pixel <= 150, ISO_ERR_UNSUPPORTED,
+              "iso_rasterize_fine: points_per_pixel must be in [1,150] (rasterization_utils.cuh:18), got %d", points_per_pixel);
   if (n_clouds == 0) return ISO_OK;
   ISO_REQUIRE(idx_out && zbuf_out && qvalue_out && occ_out && (max_points_per_bin == 0 || bin_points) &&
                   (n_points == 0 || (points && ellipse && cutoff && radii)),
@@ -2360,7 +2415,11 @@ extern "C" int iso_rasterize_fine(const float* points, const float* ellipse, con
   if (K <= 4) ISO_FINE(4);
   else if (K <= 8) ISO_FINE(8);
   else if (K <= 16) ISO_FINE(16);
-  else ISO_FINE(32);
+  else if (K <= 32) ISO_FINE(32);
+  else                                          // lists too deep for registers: kept in the output arrays
+    hipLaunchKernelGGL(k_fine_bins_deep, dim3(iso_stream_grid(npix, 256)), dim3(256), 0, s, points, ellipse, cutoff, radii,
+                       bin_points, n_clouds, B, max_points_per_bin, bin_size, F, K, depth_merging_thres, n_points, idx_out,
+                       zbuf_out, qvalue_out, occ_out);
 #undef ISO_FINE
   ISO_CHECK_LAUNCH("iso_rasterize_fine");
   return ISO_OK;

@@ -335,8 +335,6 @@ class _CNamespace(object):
         K, S, bs = int(points_per_pixel), int(image_size), int(bin_size)
         if K > kMaxPointsPerPixel or K < 1:
             raise RuntimeError("Must have num_closest <= %d" % kMaxPointsPerPixel)
-        if K > 32:
-            raise NotImplementedError("_rasterize_fine: points_per_pixel > 32 is served by splat_points (lists in global memory)")
         P = points.shape[0]
         if bin_points.ndim != 4 or bin_points.shape[1] != bin_points.shape[2] or bin_points.shape[1] != 1 + (S - 1) // bs:
             raise RuntimeError("bin_points (N, B, B, M) with B = 1 + (image_size - 1) // bin_size expected")

@@ -187,7 +187,8 @@ def test_front_rows_respects_the_row_capacity(dev):
     ss._row_overflow = None
 
 
-@pytest.mark.parametrize("S,bin_size,P,K", [(64, 16, 3000, 8), (100, 32, 20000, 5), (256, 16, 40000, 8), (33, 8, 500, 3)])
+@pytest.mark.parametrize("S,bin_size,P,K", [(64, 16, 3000, 8), (100, 32, 20000, 5), (256, 16, 40000, 8), (33, 8, 500, 3),
+                                            (64, 16, 6000, 64), (48, 16, 4000, 150)])   # K > 32: lists in the output arrays
 def test_rasterize_fine_of_coarse_is_splat_points(dev, S, bin_size, P, K):
     """DSS._C._rasterize_coarse / _rasterize_fine (ext.cpp:11-12): the bin table against a numpy restatement of
     rasterize_points.cu:341-385 (same float32 expressions), and fine(coarse(x)) == splat_points(x) bit for bit."""
