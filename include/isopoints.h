@@ -615,14 +615,17 @@ int iso_splat_zbuf_backward(const int32_t* idx, const float* grad_zbuf, int64_t 
 int64_t iso_bricks_workspace_bytes(int64_t n_max);
 /* Once per workspace, before its first build: zeroes the brick counters and the counter block.  Every build leaves
  * the brick counters zeroed again (the offsets pass clears what it has read), so no build starts with a clearing
- * pass.  The counter block (64 ints at byte 256 of the workspace): [0..15] counters of the current grid (slots as
+ * pass.  The counter block (576 ints at byte 256 of the workspace; behind it, also at a fixed offset, the 2048 zero-on-entry
+ * chunk totals of the brick scan): [0..15] counters of the current grid (slots as
  * documented below), [16..31] "sticky" sums of the counters of all earlier grids on this workspace -- a header write
  * adds what it resets -- so that a caller can check the overflow / certification counters of a whole cycle of several
  * grids with one read afterwards.                                                                    */
 int iso_bricks_workspace_init(void* workspace, int64_t n_max, void* stream);
 /* Diagnostic, synchronises `stream`: ISO_ERR_INVALID when iso_bricks_workspace_init never ran on this workspace (it
  * leaves a mark in the counter block).  A build on such a workspace counts into whatever the memory held and gives a
- * wrong grid with no other sign; the builds themselves cannot check (the mark lives on the device).             */
+ * wrong grid with no other sign; the builds themselves cannot check (the mark lives on the device).  Also refuses a
+ * workspace whose arrival words or scan totals are not zero (an aborted build left them set: every later build on it
+ * would compute wrong offsets).                                                                                  */
 int iso_bricks_workspace_check(const void* workspace, int64_t n_max, void* stream);
 /* iso_bricks_build for ONE rank that holds the whole cloud (n_total = n, id_base = 0, no imports): the bounding box
  * is taken by the build itself -- no iso_points_bbox pass, no 8-float round trip (six launches per grid instead of

@@ -59,6 +59,9 @@ struct BrickWs {      // carved out of one caller-owned workspace
   float4* rec1;       // [n_max]
   int32_t* list;      // [min(G, n_max)]
   int32_t* tail;      // [8 n_max]
+  unsigned* scan1;    // [kScan1MaxWords] chunk totals of the one-launch scan (k_brick_offsets1): zero on entry, left zero;
+                      // at a FIXED offset (right behind the counter block) -- a caller may carve with n < the n_max of
+                      // iso_bricks_workspace_init (iso_bricks_build_whole does) and must still find the zeroed words
   void* scan_ws;
   int64_t scan_ws_bytes;
   int nb_cap;

@@ -25,7 +25,7 @@
 #pragma clang fp contract(off)
 
 // ------------------------------------------------------------------------------------------------
-constexpr int kScan1MaxWords = 2048;        // = kScan1Max (k_brick_offsets1): chunk totals the one-launch scan keeps zeroed
+constexpr int kScan1MaxWords = 2048;        // = kScan1Max (k_brick_offsets1): chunk totals the one-launch scan keeps zeroed (BrickWs::scan1)
 BrickWs bricks_carve(void* ws, int64_t n_max) {
   BrickWs w;
   if (n_max < 1) n_max = 1;
@@ -36,6 +36,7 @@ BrickWs bricks_carve(void* ws, int64_t n_max) {
   int64_t o = 0;
   w.hdr = (BrickHdr*)(p + o); o += al(sizeof(BrickHdr));
   w.counters = (int32_t*)(p + o); o += al(4 * kCounterInts);
+  w.scan1 = (unsigned*)(p + o); o += al(4 * kScan1MaxWords);          // fixed offset: independent of n_max
   w.cnt = (int32_t*)(p + o); o += al(4 * w.G);
   w.off = (int32_t*)(p + o); o += al(4 * w.G);
   w.slot = (int32_t*)(p + o); o += al(4 * n_max);
@@ -43,7 +44,7 @@ BrickWs bricks_carve(void* ws, int64_t n_max) {
   w.rec1 = (float4*)(p + o); o += al(16 * n_max);
   w.list = (int32_t*)(p + o); o += al(4 * (w.G < n_max ? w.G : n_max));
   w.tail = (int32_t*)(p + o); o += al(4 * 8 * n_max);
-  w.scan_ws_bytes = iso_prefix_sum_workspace_bytes(w.G, 1) + 4 * (kScan1MaxWords + (w.G + 1023) / 1024);
+  w.scan_ws_bytes = iso_prefix_sum_workspace_bytes(w.G, 1) + 4 * (kScan1MaxWords + (w.G + 1023) / 1024);   // (sums of the two-launch scan)
   w.scan_ws = (void*)(p + o); o += al(w.scan_ws_bytes);
   w.bytes = o;
   return w;
@@ -1708,7 +1709,7 @@ extern "C" int iso_bricks_workspace_init(void* workspace, int64_t n_max, void* s
   ISO_REQUIRE(workspace && n_max >= 0, ISO_ERR_INVALID, "iso_bricks_workspace_init: bad arguments");
   ISO_REQUIRE(((uintptr_t)workspace & 255) == 0, ISO_ERR_INVALID, "iso_bricks_workspace_init: workspace must be 256-B aligned");
   const BrickWs w = bricks_carve(workspace, n_max);
-  hipLaunchKernelGGL(k_bricks_init, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, (hipStream_t)stream, w.counters, w.cnt, w.G, (unsigned*)w.scan_ws);
+  hipLaunchKernelGGL(k_bricks_init, dim3(iso_stream_grid(w.G, 256)), dim3(256), 0, (hipStream_t)stream, w.counters, w.cnt, w.G, w.scan1);
   ISO_CHECK_LAUNCH("iso_bricks_workspace_init");
   return ISO_OK;
 }
@@ -1719,12 +1720,22 @@ extern "C" int iso_bricks_workspace_check(const void* workspace, int64_t n_max, 
   ISO_REQUIRE(workspace && n_max >= 0, ISO_ERR_INVALID, "iso_bricks_workspace_check: bad arguments");
   ISO_REQUIRE(((uintptr_t)workspace & 255) == 0, ISO_ERR_INVALID, "iso_bricks_workspace_check: workspace must be 256-B aligned");
   const BrickWs w = bricks_carve(const_cast<void*>(workspace), n_max);
-  int32_t magic = 0;
-  ISO_REQUIRE(hipMemcpyAsync(&magic, w.counters + kMagicAt, sizeof(magic), hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
+  // the counter block up to the pending box + the chunk totals of the one-launch scan (both at fixed offsets)
+  static int32_t host[kBoxAt + kScan1MaxWords];
+  ISO_REQUIRE(hipMemcpyAsync(host, w.counters, 4 * kBoxAt, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
+                  hipMemcpyAsync(host + kBoxAt, w.scan1, 4 * kScan1MaxWords, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
                   hipStreamSynchronize((hipStream_t)stream) == hipSuccess,
               ISO_ERR_LAUNCH, "iso_bricks_workspace_check: could not read the workspace");
-  ISO_REQUIRE(magic == kBrickMagic, ISO_ERR_INVALID,
+  ISO_REQUIRE(host[kMagicAt] == kBrickMagic, ISO_ERR_INVALID,
               "iso_bricks_workspace_check: the workspace was never initialised (iso_bricks_workspace_init)");
+  // what the builds rely on finding zero (an aborted launch, or a build on dirty memory, leaves them set and every later
+  // build on the workspace then computes wrong offsets): the arrival words and the scan's chunk totals
+  for (int i = kArriveAt; i < kArriveAt + 17; ++i)
+    ISO_REQUIRE(host[i] == 0, ISO_ERR_INVALID, "iso_bricks_workspace_check: arrival word %d is not zero (an aborted build?): "
+                "re-initialise the workspace", i - kArriveAt);
+  for (int i = 0; i < kScan1MaxWords; ++i)
+    ISO_REQUIRE(host[kBoxAt + i] == 0, ISO_ERR_INVALID, "iso_bricks_workspace_check: chunk total %d of the brick scan is not zero "
+                "(an aborted build?): re-initialise the workspace", i);
   return ISO_OK;
 }
 
@@ -1742,7 +1753,7 @@ static int bricks_fill(const BrickWs& w, const float* points, const float* norma
   const int chunks = (int)(((w.G - 1) / BK_CPB + 1 + BS_CHUNK - 1) / BS_CHUNK);      // chunks of BS_CHUNK bricks (+ the sentinel)
   ISO_REQUIRE(w.scan_ws_bytes >= (int64_t)(chunks + kScan1Max) * 4, ISO_ERR_WORKSPACE, "iso_bricks_build: scan workspace too small");
   if (chunks <= kScan1Max) {            // one launch (the totals are zero on entry and left zero)
-    hipLaunchKernelGGL(k_brick_offsets1, dim3(chunks), dim3(256), 0, s, w.hdr, w.cnt, w.off, (unsigned*)w.scan_ws, w.list,
+    hipLaunchKernelGGL(k_brick_offsets1, dim3(chunks), dim3(256), 0, s, w.hdr, w.cnt, w.off, w.scan1, w.list,
                        w.counters);
   } else {
     int32_t* sums2 = (int32_t*)w.scan_ws + kScan1Max;       // (behind the words the one-launch form keeps zeroed)

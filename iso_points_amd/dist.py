@@ -298,21 +298,35 @@ class IsoCycle(object):
         moved, _, _ = bricks.resample_fused(self.grid, self.knn_k + 1)
         return moved
 
-    def project_resample(self):
-        """Generator: stages 1 and 2 -> ProjectionResult of the own points."""
+    def project_resample(self, front_follows=False):
+        """Generator: stages 1 and 2 -> ProjectionResult of the own points.  front_follows: the caller runs `_front` on the
+        result next (cycle() does): only then does the second projection leave its bounding box / renderable mask behind
+        for that build -- a stand-alone call must not leave a pending box in the grid's workspace (the next projection
+        with a Follow would union its box with the stale one)."""
         one = self.world == 1 and not getattr(self, "no_follow", False)      # (no_follow: A/B and tests)
         ss = self.splat
+        self._drop_stale_box()
         # one rank: the projections leave the bounding box of what they write in the grid's workspace (the next build
         # makes its header from it); the second one also takes the renderable mask (bricks.Follow)
         f0 = bricks.Follow(self.grid, self.n_own) if one else None
         r0 = yield from self._project(self.pts0_local, 10, follow=f0)
+        self._box_pending = bool(f0 is not None and f0.done)
         moved = yield from self._resample(r0.points[0].contiguous(), r0.normals[0].contiguous(),
-                                          pending=bool(f0 is not None and f0.done))
+                                          pending=self._box_pending)
+        self._box_pending = False                                            # consumed by the build
         f1 = bricks.Follow(self.grid, self.n_own, views=self.views, znear=ss.znear, zfar=ss.zfar,
-                           backface_culling=self.rs.backface_culling) if one else None
+                           backface_culling=self.rs.backface_culling) if (one and front_follows) else None
         r1 = yield from self._project(moved.view(1, -1, 3), 3, follow=f1)
         self._follow1 = f1 if (f1 is not None and f1.done) else None
+        self._box_pending = self._follow1 is not None
         return r1
+
+    def _drop_stale_box(self):
+        """A pending box nobody consumed (an exception between a Follow projection and its build): taken out, so that the
+        next Follow projection starts from an empty box."""
+        if getattr(self, "_box_pending", False):
+            bricks.box_take(self.grid)
+            self._box_pending = False
 
     # -- stage 3: splat front end + forward ------------------------------------------------------
     def _front(self, pts, nrm):
@@ -328,6 +342,7 @@ class IsoCycle(object):
             if f1 is not None:
                 self.grid.build(pts, nrm, payload=mask, radius=float(ss.frnn_radius), cell_scale=bricks.H_CELL_SCALE,
                                 pending=True, follow=f1)
+                self._box_pending = False                                    # consumed by the build
             else:
                 self.grid.build(pts, nrm, payload=mask, radius=float(ss.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
             view_total = cnt
@@ -477,7 +492,7 @@ class IsoCycle(object):
         image with the own band filled, gradient of the packed rows, fragments, front-end dict)."""
         # the SDF weights are packed once per cycle (they change once per optimiser step), not per projection
         self.proj.reuse_packed, self.proj._packed_cache = True, None
-        r1 = yield from self.project_resample()
+        r1 = yield from self.project_resample(front_follows=True)
         fr = yield from self._front(r1.points[0].contiguous(), r1.normals[0].contiguous())
         if self.marks:
             yield ("mark", "front_end", 0)

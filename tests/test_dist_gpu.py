@@ -240,3 +240,38 @@ def test_bench_line_of_two_ranks(dev, launcher):
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["vs_baseline"] is None
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     assert d["config"]["parallelism"] == "2 ranks" or "2" in d["config"]["parallelism"]
+
+
+def test_standalone_project_resample_leaves_no_pending_box(dev):
+    """project_resample() driven on its own (bench.active_counts, tools) on a follow-capable model used to
+    leave the second projection's bounding box pending in the grid's workspace; the next Follow projection then unioned
+    its box with the stale one and the grid's radius / spacing silently differed from the no-follow route.  Two
+    stand-alone calls, then a whole cycle, must equal the no_follow route bit for bit -- and a box left behind by an
+    aborted sequence is dropped."""
+    from iso_points_amd import bricks
+    from iso_points_amd.dist import IsoCycle, slab_order, _Single
+    pts, views, projs, rs, tgt = _scene(dev, 30000, 128, 2)
+    pts = pts[:, slab_order(pts[0], 1)].contiguous()
+    model = _models(dev, "sphere")
+    a = IsoCycle(model, pts, views, projs, raster_settings=rs, comm=_Single(), target=tgt)
+    b = IsoCycle(model, pts, views, projs, raster_settings=rs, comm=_Single(), target=tgt)
+    b.no_follow = True
+    for _ in range(2):
+        ra, rb = a.run(a.project_resample()), b.run(b.project_resample())
+        assert torch.equal(ra.points, rb.points) and torch.equal(ra.normals, rb.normals)
+        assert not a._box_pending
+    # an aborted sequence: a Follow projection whose build never ran
+    from iso_points_amd.sdf_models import SphereSDF
+    f = bricks.Follow(a.grid, a.n_own)
+    small, a.model = a.model, SphereSDF(radius=3.0).to(dev)
+    a.run(a._project(a.pts0_local, 10, follow=f))                # the box of a sphere three times as large, left pending
+    a.model = small
+    assert f.done
+    a._box_pending = True
+    ca, cb = a.run(a.cycle()), b.run(b.cycle())
+    assert torch.equal(ca[0].points, cb[0].points), "resampled points differ"
+    assert torch.equal(ca[1], cb[1]), "images differ"
+    tot = int(ca[4]["num_points"].sum().item())
+    assert torch.equal(ca[2][:tot], cb[2][:tot]), "gradients differ"
+    ha, hb = a.grid.header(), b.grid.header()
+    assert ha == hb, (ha, hb)

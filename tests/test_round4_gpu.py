@@ -307,3 +307,39 @@ def test_brick_workspace_check_tells_an_uninitialised_workspace(dev):
         _lib.call("iso_bricks_workspace_check", _lib.ptr(ws), n, _lib.stream())
     _lib.call("iso_bricks_workspace_init", _lib.ptr(ws), n, _lib.stream())
     _lib.call("iso_bricks_workspace_check", _lib.ptr(ws), n, _lib.stream())
+
+
+def test_brick_workspace_check_tells_a_dirty_workspace_and_small_clouds_find_the_scan_words(dev):
+    """(a) the check also refuses a workspace whose arrival words / scan totals are not zero (what an aborted
+    build leaves behind); (b) the zero-on-entry chunk totals of the one-launch brick scan sit at a fixed offset, so a
+    build of n < n_max points on a workspace initialised for n_max (iso_bricks_build_whole carves with n) finds them:
+    its grid equals the grid of a workspace initialised for exactly n."""
+    from iso_points_amd import _lib, bricks
+    from util import sphere_cloud
+    lib = _lib.load()
+    n_max, n = 60000, 7000
+    ws = torch.full((int(lib.iso_bricks_workspace_bytes(n_max)),), 0x55, dtype=torch.uint8, device=dev)
+    _lib.call("iso_bricks_workspace_init", _lib.ptr(ws), n_max, _lib.stream())
+    _lib.call("iso_bricks_workspace_check", _lib.ptr(ws), n_max, _lib.stream())
+    pts = sphere_cloud(n, seed=2)[0].to(dev).contiguous()
+    nrm = torch.nn.functional.normalize(pts, dim=-1).contiguous()
+    small = torch.full((int(lib.iso_bricks_workspace_bytes(n)),), 0x55, dtype=torch.uint8, device=dev)
+    _lib.call("iso_bricks_workspace_init", _lib.ptr(small), n, _lib.stream())
+    for w in (ws, small):
+        _lib.call("iso_bricks_build_whole", _lib.ptr(pts), _lib.ptr(nrm), None, n, -1.0, 8, bricks.RESAMPLE_CELL * 8, _lib.ptr(w),
+                  w.numel(), _lib.stream())
+    outs = []
+    for w in (ws, small):
+        out = torch.empty_like(pts)
+        _lib.call("iso_resample_fused", _lib.ptr(w), n, _lib.ptr(pts), n, 9, _lib.ptr(out), None, None, _lib.stream())
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    _lib.call("iso_bricks_workspace_check", _lib.ptr(ws), n_max, _lib.stream())
+    # a dirty arrival word (counter block: int 40 at byte 256) / a dirty scan total (right behind the 576-int block)
+    for byte in (256 + 4 * 40, 256 + 4 * 576):
+        saved = ws[byte:byte + 4].clone()
+        ws[byte:byte + 4] = 1
+        with pytest.raises(RuntimeError):
+            _lib.call("iso_bricks_workspace_check", _lib.ptr(ws), n_max, _lib.stream())
+        ws[byte:byte + 4] = saved
+    _lib.call("iso_bricks_workspace_check", _lib.ptr(ws), n_max, _lib.stream())
