@@ -543,7 +543,9 @@ def main():
             "scaling": "strong",            # 1 M points in total for every N (BASELINE.json: the same cycle at 1 and 8 GPUs)
             # no run of this command on more than one GPU exists in the builder's records (one GPU per lease): the N > 1 path
             # is verified bit-identical in lock-step / over gloo only; its compute ceiling: profiles/r04_rank_share_*.json
-            "scaling_measured": False,
+            # (true only when this very run has N > 1 ranks on N distinct GPUs over RCCL: tests/test_rccl_gpu.py)
+            "scaling_measured": bool(world > 1 and not os.environ.get("ISO_BENCH_ONE_DEVICE")
+                                     and os.environ.get("ISO_BENCH_BACKEND", "nccl") == "nccl"),
             "vs_baseline": None,
             "dtype": "f32-class (split-fp16 operands, 2^-22: hidden-layer products from two fp16 parts per f32 operand "
                      "under exact power-of-two scales, 3 fp16-MFMA passes, f32 accumulate; everything else f32)" if x3 else "f32",

@@ -87,3 +87,10 @@ if has opapi; then
   grep -i "operator API" /tmp/rp_opapi.log | cut -c1-200
   python $REPO/tools/opapi_sequence.py $DB $OUT/${TAGO}_sequence.txt | tail -1
 fi
+if has rankseq; then
+  # what ONE rank of an 8-rank run launches per cycle (markers around rank 3's segments)
+  for K in siren sphere; do
+    DB=$(ISO_WORLDS=8 ISO_TRACE_RANK=3 run_prof rseq_$K "" python tools/rank_share_bench.py $K 1000000 1)
+    python $REPO/tools/rank_sequence.py $DB $OUT/${RANKSEQ_TAG:-r05}_rank3_of_8_${K}_sequence.txt | tail -1
+  done
+fi

@@ -41,6 +41,25 @@ class Timer(object):
         return [sum(a.elapsed_time(b) for a, b in evs) for evs in self.ev]
 
 
+class TraceTimer(Timer):
+    """ISO_TRACE_RANK=r: the segments of rank r are bracketed by marker kernels (torch.cuda._sleep -> spin_kernel) so that
+    tools/rank_sequence.py can list what ONE rank launches per cycle from a rocprofv3 kernel trace."""
+    def __init__(self, world, rank):
+        super().__init__(world)
+        self.rank = rank
+
+    @contextlib.contextmanager
+    def __call__(self, r):
+        if r == self.rank:
+            torch.cuda._sleep(2000)
+        try:
+            with super().__call__(r):
+                yield
+        finally:                                  # (the rank's last segment ends with StopIteration)
+            if r == self.rank:
+                torch.cuda._sleep(2000)
+
+
 class LogComm(object):
     """records the requests one rank yields (bytes per collective)"""
     def __init__(self):
@@ -90,7 +109,8 @@ def main():
                 c.use_graphs = True
         for _ in range(3):
             run_lockstep(ranks)
-        tm = Timer(world)
+        tr = os.environ.get("ISO_TRACE_RANK")
+        tm = Timer(world) if tr is None else TraceTimer(world, min(int(tr), world - 1))
         for _ in range(steps):
             res = run_lockstep(ranks, timer=tm)
         ms = [t / steps for t in tm.per_rank_ms()]
