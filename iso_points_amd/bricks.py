@@ -19,10 +19,10 @@ H_CELL_SCALE = float(_os.environ.get("ISO_H_CELL_SCALE", "6.0"))      # fine cel
                                                                      # inside which seven neighbours settle h (no uncertified counts: h + tail 272 -> 247 us at 1 M points)
 
 
-def points_bbox(points):
-    """(8,) f32 [min xyz, 0, max xyz, 0] of a packed (n,3) cloud, on the device (no host sync)."""
+def points_bbox(points, out=None):
+    """(8,) f32 [min xyz, 0, max xyz, 0] of a packed (n,3) cloud, on the device (no host sync); out: where to write it."""
     pts = points.detach().float().contiguous().view(-1, 3)
-    mm = torch.empty((8,), dtype=torch.float32, device=pts.device)
+    mm = out if out is not None else torch.empty((8,), dtype=torch.float32, device=pts.device)
     _lib.call("iso_points_bbox", _lib.ptr(pts), None, 1, pts.shape[0], _lib.ptr(mm), _lib.stream())
     return mm
 
@@ -182,7 +182,7 @@ def view_mask(points, normals, views, znear=1.0, zfar=100.0, backface_culling=Tr
     return mask, cnt
 
 
-def view_mask_scan(points, normals, views, znear=1.0, zfar=100.0, backface_culling=True):
+def view_mask_scan(points, normals, views, znear=1.0, zfar=100.0, backface_culling=True, total_out=None):
     """view_mask + the per-chunk counts and their scan the front end needs, in two launches (iso_splat_view_mask_scan):
     -> mask (n,) int32, view_total (8,) int32, and the `scanned` tuple (workspace, first_idx (N,) i64, num_points (N,)
     i64, view_total) SurfaceSplatting.front_setup takes to run its compaction + set-up pass alone."""
@@ -192,7 +192,7 @@ def view_mask_scan(points, normals, views, znear=1.0, zfar=100.0, backface_culli
     ws = torch.empty((_lib.load().iso_splat_front_workspace_bytes(n),), dtype=torch.uint8, device=dev)
     first = torch.empty((nv,), dtype=torch.int64, device=dev)
     num = torch.empty((nv,), dtype=torch.int64, device=dev)
-    total = torch.empty((8,), dtype=torch.int32, device=dev)
+    total = total_out if total_out is not None else torch.empty((8,), dtype=torch.int32, device=dev)   # (8,) int32, contiguous
     p = _lib.ptr
     _lib.call("iso_splat_view_mask_scan", p(points), p(normals), p(views), nv, n, float(znear), float(zfar),
               int(bool(backface_culling)), p(mask), p(ws), ws.numel(), p(first), p(num), p(total), _lib.stream())

@@ -333,10 +333,14 @@ class IsoCycle(object):
         ss, N, w = self.splat, self.N, self.world
         f1 = getattr(self, "_follow1", None)
         self._follow1 = None
+        msg = None
         if f1 is not None:                 # mask, scan and the grid's header came with the projection
             mask, cnt, scanned = f1.mask, f1.total, f1.scanned
         else:
-            mask, cnt, scanned = bricks.view_mask_scan(pts, nrm, self.views, ss.znear, ss.zfar, self.rs.backface_culling)
+            if w > 1:                      # the view totals straight into the message the ranks all-gather below
+                msg = torch.empty((16,), dtype=torch.float32, device=pts.device)   # [box (8) | renderable points per view (8 x i32)]
+            mask, cnt, scanned = bricks.view_mask_scan(pts, nrm, self.views, ss.znear, ss.zfar, self.rs.backface_culling,
+                                                       total_out=msg[8:].view(torch.int32) if msg is not None else None)
         counts = None
         if w == 1:
             if f1 is not None:
@@ -347,8 +351,8 @@ class IsoCycle(object):
                 self.grid.build(pts, nrm, payload=mask, radius=float(ss.frnn_radius), cell_scale=bricks.H_CELL_SCALE)
             view_total = cnt
         else:
-            box = bricks.points_bbox(pts)
-            msg = torch.cat([box, cnt.view(torch.float32)])
+            bricks.points_bbox(pts, out=msg[:8])
+            box = msg[:8]
             got = yield ("all_gather", msg)
             boxes = got[:, :8].contiguous()
             counts = got[:, 8:].contiguous().view(torch.int32)                     # (world, 8)
@@ -508,7 +512,12 @@ class IsoCycle(object):
         if self.world == 1:
             occ_grad = torch.add(cgrad[0], alpha, alpha=cgrad[2])
         else:
-            occ_grad = torch.zeros_like(alpha)
+            # zero outside the rank's band for good (made once): a cycle only rewrites the band's rows
+            og = getattr(self, "_occ_grad", None)
+            if og is None or og.shape != alpha.shape or self._occ_band != (y0, y1):
+                og, self._occ_band = torch.zeros_like(alpha), (y0, y1)
+                self._occ_grad = og
+            occ_grad = og
             torch.add(cgrad[0][:, y0:y1], alpha[:, y0:y1], alpha=cgrad[2], out=occ_grad[:, y0:y1])
         zbuf_grad = cgrad[1]
         grad = yield from self.backward(frags, fr, occ_grad, zbuf_grad)

@@ -58,16 +58,32 @@ put("cfg2_siren_100k_project_resample", ms=t, Mpoints_s=1e5 / t / 1e3, converged
 # cfg 4: 4 M points, IDR 8x512 (geometric init), projection T=10: whole cloud on one GPU and the 1/8 share
 torch.manual_seed(0)
 idr = O.IdrSDF(hidden_size=512, n_layers=8, skip_in=(4,), num_frequencies=6).to(dev)
-for P, tag in ((4000000, "whole"), (500000, "one_of_8_shards")):
-    g = torch.Generator().manual_seed(4)
-    x = (torch.nn.functional.normalize(torch.randn(1, P, 3, generator=g), dim=-1) * 0.6 +
-         0.03 * (torch.rand(1, P, 3, generator=g) - 0.5)).to(dev)
-    n = full_lengths(x)
-    pr = UniformProjection(proj_max_iters=10)
-    r = pr._project_points(idr, x, n, proj_max_iters=10)
-    t = timeit(lambda: pr._project_points(idr, x, n, proj_max_iters=10), warm=1, rep=3)
-    put("cfg4_idr8x512_project_T10_%s" % tag, points=P, ms=t, Mpoints_s=P / t / 1e3, converged=float(r.mask.float().mean()))
-    del x
+# (the strong-scaling showcase: the projection is per-point work with no exchange; world N = the slowest of the N x-slab
+#  shards of the SAME 4 M cloud, each projected alone on this GPU -- the per-rank compute of an N-GPU run)
+from iso_points_amd.dist import slab_order, shard_bounds
+g = torch.Generator().manual_seed(4)
+P4 = 4000000
+x4 = (torch.nn.functional.normalize(torch.randn(1, P4, 3, generator=g), dim=-1) * 0.6 +
+      0.03 * (torch.rand(1, P4, 3, generator=g) - 0.5)).to(dev)
+pr = UniformProjection(proj_max_iters=10)
+pr.reuse_packed = True
+t_whole = None
+for world in (1, 2, 4, 8):
+    order = slab_order(x4[0], world)
+    xs = x4[:, order].contiguous()
+    worst, conv = 0.0, 1.0
+    for rank in (range(world) if world <= 2 else (0, world // 2, world - 1)):       # first, middle and last slab
+        lo, hi = shard_bounds(P4, world, rank)
+        x = xs[:, lo:hi].contiguous()
+        n = full_lengths(x)
+        r = pr._project_points(idr, x, n, proj_max_iters=10)
+        t = timeit(lambda: pr._project_points(idr, x, n, proj_max_iters=10), warm=1, rep=3)
+        worst, conv = max(worst, t), min(conv, float(r.mask.float().mean()))
+        del x
+    t_whole = worst if world == 1 else t_whole
+    put("cfg4_idr8x512_project_T10_world%d" % world, points_per_rank=P4 // world, slowest_shard_ms=worst,
+        Mpoints_s=P4 / worst / 1e3, compute_ceiling_x=t_whole / worst, converged=conv)
+del x4, xs
 
 # cfg 5: 500 k iso-points, loss-weighted insert around 5 000 FPS reference points, splat fwd/bwd at the
 # reference's largest square images (it cannot do 1200 x 1600: square only, <= 1344)

@@ -110,10 +110,14 @@ def main():
         for _ in range(3):
             run_lockstep(ranks)
         tr = os.environ.get("ISO_TRACE_RANK")
-        tm = Timer(world) if tr is None else TraceTimer(world, min(int(tr), world - 1))
+        per_step = []
         for _ in range(steps):
+            tm = Timer(world) if tr is None else TraceTimer(world, min(int(tr), world - 1))
             res = run_lockstep(ranks, timer=tm)
-        ms = [t / steps for t in tm.per_rank_ms()]
+            per_step.append(tm.per_rank_ms())
+        # a rank's time = the MEDIAN of its per-step sums (one stall of the process in one of five steps -- seen once: 12 ms
+        # for a 2.7 ms rank -- must not become the job's figure)
+        ms = [sorted(st[r] for st in per_step)[len(per_step) // 2] for r in range(world)]
         use = [c.check(o[4]) for c, o in zip(ranks, res)]
         # bytes each rank contributes per collective: replay rank 0's generator requests
         log = []
