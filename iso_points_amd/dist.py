@@ -512,12 +512,7 @@ class IsoCycle(object):
         if self.world == 1:
             occ_grad = torch.add(cgrad[0], alpha, alpha=cgrad[2])
         else:
-            # zero outside the rank's band for good (made once): a cycle only rewrites the band's rows
-            og = getattr(self, "_occ_grad", None)
-            if og is None or og.shape != alpha.shape or self._occ_band != (y0, y1):
-                og, self._occ_band = torch.zeros_like(alpha), (y0, y1)
-                self._occ_grad = og
-            occ_grad = og
+            occ_grad = torch.zeros_like(alpha)          # (all-reduced IN PLACE below: a fresh one every cycle)
             torch.add(cgrad[0][:, y0:y1], alpha[:, y0:y1], alpha=cgrad[2], out=occ_grad[:, y0:y1])
         zbuf_grad = cgrad[1]
         grad = yield from self.backward(frags, fr, occ_grad, zbuf_grad)
