@@ -576,6 +576,7 @@ struct PixK {
   // selects; this form takes one `<` and one `==` per level (the id compare only when some lane of the wave
   // meets an equal depth), the depths move with one v_med3_f32 per level and the ids with two selects.
   __device__ __forceinline__ void push_zi(float cz, int ci, int K) {
+#ifdef RS_OLD_PUSH
     bool lt[KMAX], eq[KMAX];
     bool tie = false;
 #pragma unroll
@@ -596,6 +597,34 @@ struct PixK {
     }
     id[0] = lt[0] ? ci : id[0];
     z[0] = lt[0] ? cz : z[0];
+#else
+    // Depths here are >= +0 and never NaN (binning drops z < 0 and NaN, the caller adds +0.0f so that -0 is +0): their
+    // float order is the order of their bit patterns as unsigned integers, and (z, id) "less" is three integer compares
+    // whose masks go straight into the selects -- no tie pass, no ballot, no boolean arrays in vector registers (the
+    // first form compiled to ~200 instructions per insertion; knock-outs of round 5: the insertions were 98 of the
+    // kernel's 207 us).
+    const unsigned cu = __float_as_uint(cz);
+    bool m[KMAX];
+    const bool full = K == KMAX;                        // (uniform: the usual case drops the slot test)
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      const unsigned zu = __float_as_uint(z[j]);
+      // `|` and `&`, not `||` and `&&`: three compares and two mask operations, no branch per level
+      m[j] = (full | (j < K)) & ((cu < zu) | ((cu == zu) & (ci < id[j])));
+    }
+#pragma unroll
+    for (int j = KMAX - 1; j >= 1; --j) {
+      // (sorted list, all slots live: the new z[j] is the middle one of z[j-1], cz, z[j])
+#ifdef RS_MED3
+      z[j] = full ? __builtin_amdgcn_fmed3f(z[j - 1], cz, z[j]) : (m[j - 1] ? z[j - 1] : (m[j] ? cz : z[j]));
+#else
+      z[j] = m[j - 1] ? z[j - 1] : (m[j] ? cz : z[j]);
+#endif
+      id[j] = m[j - 1] ? id[j - 1] : (m[j] ? ci : id[j]);
+    }
+    z[0] = m[0] ? cz : z[0];
+    id[0] = m[0] ? ci : id[0];
+#endif
   }
 };
 
@@ -684,16 +713,23 @@ extern "C" int iso_dbg_raster_phases(double* out16) {
 // (32 / 24 / 16-entry lists: 316 / 333 / 429 us against 302; wide boxes from 24 / 48 / 96 / 192 pixels: 367 / 302 / 294 /
 // 298 us, and 124 / 98 / 75 / 74 us for a rank's band at N = 8, where the items with many grazing splats set the time)
 constexpr int kHitList = 40, kWideArea = 96;
+#ifndef RS_HITS_PER_TRIP
+#define RS_HITS_PER_TRIP 1
+#endif
 
-template <int KMAX, bool CP>
+// KFULL: points_per_pixel == KMAX (4 / 8 / 16 / 32: the usual settings) -- K is then a compile-time constant and the
+// per-slot `j < K` tests, the selection of the list's last live entry and their scalar branches fold away (a third of
+// the instructions of an insertion).
+template <int KMAX, bool CP, bool KFULL = false>
 __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
     const float* __restrict__ pts, const float* __restrict__ ellipse,
     const float* __restrict__ cutoff, const float* __restrict__ radii,
     const int32_t* __restrict__ tile_order, const int4* __restrict__ items, const int32_t* __restrict__ item_count,
     float* __restrict__ scratch, const int32_t* __restrict__ tile_off,
     const int32_t* __restrict__ pairs, int64_t capacity, Frame F,
-    int K, float depth_thres, int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out,
+    int K_arg, float depth_thres, int32_t* __restrict__ idx_out, float* __restrict__ zbuf_out, float* __restrict__ q_out,
     float* __restrict__ occ_out, CompositeArgs ca) {
+  const int K = KFULL ? KMAX : K_arg;
   constexpr int NSOA = CP ? 1 : 256;
   __shared__ float s_px[NSOA], s_py[NSOA], s_pz[NSOA], s_a[NSOA], s_b[NSOA], s_c[NSOA], s_rx[NSOA], s_ry[NSOA], s_cut[NSOA];
   __shared__ int s_id[NSOA];
@@ -702,7 +738,7 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
   __shared__ short s_list[4][NSOA];
   __shared__ int s_cntw[4][4];       // [source wave][target wave]
   __shared__ int s_hits[CP ? 256 : 1];                      // CP: hits of the chunk per pixel
-  __shared__ unsigned char s_hit[CP ? 256 : 1][CP ? kHitList : 1];
+  __shared__ __attribute__((aligned(16))) unsigned char s_hit[CP ? 256 : 1][CP ? kHitList : 1];
   // workgroups take the tiles of the band heaviest first (k_tile_order): a tile on the sphere's
   // silhouette holds 8x the mean number of candidates and would otherwise finish long after the rest
   // a work item = a tile, or -- for the tiles that hold many times the mean number of candidates (a
@@ -753,6 +789,9 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
     __shared__ float2 s_r2[NB][256];
     __shared__ short s_wide[2][256];
     __shared__ int s_nw[2];
+#ifdef RS_ROWS4
+    __shared__ unsigned short s_box[256];
+#endif
     float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0;
     auto fetch = [&](int c0) {
       if (c0 + (int)threadIdx.x < cnt) {
@@ -774,7 +813,7 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
         const float q = c1v.x * dx * dx + c1v.y * dx * dy + c1v.z * dy * dy;      // :94
         if (q > c1v.w) return;                                                    // :96
       }
-      const float pz = c0v.z;
+      const float pz = c0v.z + 0.0f;                     // (-0 -> +0: push_zi orders depths by their bit patterns)
       const int id = __float_as_int(c0v.w);
       if (pz < wz || (pz == wz && id < wi)) {
         best.push_zi(pz, id, K);
@@ -792,10 +831,59 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
     for (int c0 = c_begin; c0 < cnt; c0 += 256, par ^= 1) {
       const int m = min(256, cnt - c0);
       if ((int)threadIdx.x < m) { s_r0[par % NB][threadIdx.x] = r0; s_r1[par % NB][threadIdx.x] = r1; s_r2[par % NB][threadIdx.x] = make_float2(r2.x, r2.y); }
+#ifdef RS_ROWS4
+      // FOUR LANES PER CANDIDATE (rows y0 + s, y0 + s + 4, ... of its box for lane s): the box is taken from the registers
+      // the record is written from (no barrier of its own), the lanes of a wave then walk a quarter of sixteen boxes
+      // each instead of one of sixty-four whole boxes -- the widest box of the wave no longer sets its time
+      if ((int)threadIdx.x < m) {
+        int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
+        const bool any = pixel_range(r0.x, r2.x, F.W, F.ex, F.m, x0, x1) && pixel_range(r0.y, r2.y, F.H, F.ey, F.m, y0, y1);
+        x0 = max(x0, tx * TILE); x1 = min(x1, tx * TILE + TILE - 1);
+        y0 = max(y0, ty * TILE); y1 = min(y1, ty * TILE + TILE - 1);
+        unsigned short bx = 0x000fu;                      // x0 = 15 > x1 = 0: "nothing"
+        if (any && x0 <= x1 && y0 <= y1) {
+          if ((x1 - x0 + 1) * (y1 - y0 + 1) > kWideArea) s_wide[par][atomicAdd(&s_nw[par], 1)] = (short)threadIdx.x;
+          else bx = (unsigned short)((x0 - tx * TILE) | ((x1 - tx * TILE) << 4) | ((y0 - ty * TILE) << 8) | ((y1 - ty * TILE) << 12));
+        }
+        s_box[threadIdx.x] = bx;
+      }
+      __syncthreads();                                    // records + boxes visible; the hit counters are zero
+      RS_PH(0);
+      fetch(c0 + 256);
+#pragma unroll 1
+      for (int k = (int)(threadIdx.x >> 2); k < m; k += 64) {
+        const unsigned bx = s_box[k];
+        const int lx0 = bx & 15, lx1 = (bx >> 4) & 15, ly0 = (bx >> 8) & 15, ly1 = (bx >> 12) & 15;
+        if (lx0 > lx1) continue;
+        const int sub = threadIdx.x & 3;
+        if (ly0 + sub > ly1) continue;
+        const float4 c0v = s_r0[par % NB][k], c1v = s_r1[par % NB][k];
+        const float2 c2v = s_r2[par % NB][k];
+        for (int ly = ly0 + sub; ly <= ly1; ly += 4) {
+          const float dy = ndc_y(ty * TILE + ly, F) - c0v.y;
+          if (fabsf(dy) > c2v.y) continue;
+          for (int lxx = lx0; lxx <= lx1; ++lxx) {
+            const float dx = ndc_x(tx * TILE + lxx, F) - c0v.x;
+            if (fabsf(dx) > c2v.x) continue;
+            const float q = c1v.x * dx * dx + c1v.y * dx * dy + c1v.z * dy * dy;
+            if (q > c1v.w) continue;
+            const int pl = ly * TILE + lxx;
+            const int slot = atomicAdd(&s_hits[pl], 1);
+            if (slot < kHitList) s_hit[pl][slot] = (unsigned char)k;
+          }
+        }
+      }
+      if (false) {
+#else
       __syncthreads();                                    // records visible; the hit counters are zero
       RS_PH(0);
       fetch(c0 + 256);
+#ifdef RS_KO_A        // timing experiment (results wrong): no candidate phase
+      if (false) {
+#else
       if ((int)threadIdx.x < m) {
+#endif
+#endif
         const int k = threadIdx.x;
         const float4 c0v = s_r0[par % NB][k], c1v = s_r1[par % NB][k];
         const float2 c2v = s_r2[par % NB][k];
@@ -810,6 +898,23 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
             for (int y = y0; y <= y1; ++y) {
               const float dy = ndc_y(y, F) - c0v.y;
               if (fabsf(dy) > c2v.y) continue;
+#ifdef RS_PAIRS
+              // two pixels per trip: both returning LDS atomics are issued before either slot is used (a hit is otherwise
+              // a chain test -> atomic -> wait -> store, one pixel after the other)
+              for (int x = x0; x <= x1; x += 2) {
+                const float dxa = ndc_x(x, F) - c0v.x, dxb = ndc_x(x + 1, F) - c0v.x;
+                const float qa = c1v.x * dxa * dxa + c1v.y * dxa * dy + c1v.z * dy * dy;
+                const float qb = c1v.x * dxb * dxb + c1v.y * dxb * dy + c1v.z * dy * dy;
+                const bool ha = !(fabsf(dxa) > c2v.x) && !(qa > c1v.w);
+                const bool hb = x + 1 <= x1 && !(fabsf(dxb) > c2v.x) && !(qb > c1v.w);
+                const int pl = (y - ty * TILE) * TILE + (x - tx * TILE);
+                int sa = kHitList, sb = kHitList;
+                if (ha) sa = atomicAdd(&s_hits[pl], 1);
+                if (hb) sb = atomicAdd(&s_hits[pl + 1], 1);
+                if (sa < kHitList) s_hit[pl][sa] = (unsigned char)k;
+                if (sb < kHitList) s_hit[pl + 1][sb] = (unsigned char)k;
+              }
+#else
               for (int x = x0; x <= x1; ++x) {
                 const float dx = ndc_x(x, F) - c0v.x;
                 if (fabsf(dx) > c2v.x) continue;
@@ -819,6 +924,7 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
                 const int slot = atomicAdd(&s_hits[pl], 1);
                 if (slot < kHitList) s_hit[pl][slot] = (unsigned char)k;
               }
+#endif
             }
           }
         }
@@ -828,9 +934,45 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
       const int nh = s_hits[threadIdx.x];
       s_hits[threadIdx.x] = 0;
       if (threadIdx.x == 0) s_nw[par ^ 1] = 0;
+#ifdef RS_KO_B          // timing experiment (results wrong): no insertions
+      if (false) {
+#else
       if (inside) {
+#endif
         if (nh <= kHitList) {
+#if RS_HITS_PER_TRIP == 1
           for (int i = 0; i < nh; ++i) test_push(s_hit[threadIdx.x][i], true);
+#else
+          // RS_HITS_PER_TRIP hits per trip: their list bytes come as one read and the (z, id) records are requested
+          // together -- one hit per trip is a chain of two dependent LDS round trips per insertion
+          constexpr int HPT = RS_HITS_PER_TRIP;
+          for (int i = 0; i < nh; i += HPT) {
+            unsigned kk;
+            if (HPT == 2) kk = *reinterpret_cast<const unsigned short*>(&s_hit[threadIdx.x][i]);
+            else kk = *reinterpret_cast<const unsigned*>(&s_hit[threadIdx.x][i]);
+            float2 zi[HPT];
+#pragma unroll
+            for (int u = 0; u < HPT; ++u) {
+              const float4* rp = &s_r0[par % NB][(kk >> (8 * u)) & 255u];
+              zi[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(rp) + 2);       // (z, id)
+            }
+#pragma unroll
+            for (int u = 0; u < HPT; ++u) {
+              if (i + u < nh) {
+                const float pz = zi[u].x + 0.0f;         // (-0 -> +0: push_zi orders depths by their bit patterns)
+                const int id = __float_as_int(zi[u].y);
+                if (pz < wz || (pz == wz && id < wi)) {
+                  best.push_zi(pz, id, K);
+                  if (K == KMAX) { wz = best.z[KMAX - 1]; wi = best.id[KMAX - 1]; }
+                  else {
+#pragma unroll
+                    for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wz = best.z[j]; wi = best.id[j]; }
+                  }
+                }
+              }
+            }
+          }
+#endif
           const int nw = s_nw[par];
           for (int i = 0; i < nw; ++i) test_push(s_wide[par][i], false);
         } else {
@@ -843,6 +985,10 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
     }
     // q of the K survivors (:94; the same expression on the same operands as the hit test): their records are
     // re-read once per tile instead of carrying q through every insertion
+#ifdef RS_KO_EPI        // timing experiment (results wrong): no epilogue
+    if (best.z[0] == 12345.f) occ_out[0] = 1.f;
+    return;
+#endif
     if (inside) {
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) {
@@ -2300,7 +2446,11 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
                        tile_cursor);
   }
 #define ISO_LAUNCH_R(KM_)                                                                            \
-  if (raster_cp())                                                                                   \
+  if (raster_cp() && K == KM_)                                                                   \
+    hipLaunchKernelGGL((k_raster<KM_, true, true>), dim3(tiles + max_slots), dim3(256), 0, s, points, ellipse, cutoff, radii, \
+                       tile_cursor, items, counters, scratch, tile_off, pairs, pair_capacity, F,                \
+                       K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);             \
+  else if (raster_cp())                                                                                   \
     hipLaunchKernelGGL((k_raster<KM_, true>), dim3(tiles + max_slots), dim3(256), 0, s, points, ellipse, cutoff, radii, \
                        tile_cursor, items, counters, scratch, tile_off, pairs, pair_capacity, F,                \
                        K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);             \

@@ -71,6 +71,6 @@ def test_no_vgpr_spills_in_the_raster_kernels():
     spec.loader.exec_module(sc)
     ks = sc.kernels(_lib.LIB_PATH)
     assert len(ks) > 100, "code objects not found in the library"
-    raster = [k for k in ks if "8k_rasterILi4ELb1" in k[0] or "8k_rasterILi8ELb1" in k[0]]
-    assert len(raster) == 2, [k[0] for k in ks if "raster" in k[0]]
+    raster = [k for k in ks if "8k_rasterILi4ELb1ELb" in k[0] or "8k_rasterILi8ELb1ELb" in k[0]]
+    assert len(raster) == 4, [k[0] for k in ks if "raster" in k[0]]
     assert all(k[1] == 0 for k in raster), raster
