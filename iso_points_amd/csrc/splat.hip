@@ -571,6 +571,27 @@ struct PixK {
       }
     }
   }
+  // The same insertion in the form of push_zi (below): depths >= +0 and never NaN, masks of integer compares straight
+  // into the selects.  For lists that are merged (k_raster_merge): entries come from lists made by push_zi.
+  __device__ __forceinline__ void push_q(float cz, int ci, float cq, int K) {
+    const unsigned cu = __float_as_uint(cz);
+    bool m[KMAX];
+    const bool full = K == KMAX;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      const unsigned zu = __float_as_uint(z[j]);
+      m[j] = (full | (j < K)) & ((cu < zu) | ((cu == zu) & (ci < id[j])));
+    }
+#pragma unroll
+    for (int j = KMAX - 1; j >= 1; --j) {
+      z[j] = m[j - 1] ? z[j - 1] : (m[j] ? cz : z[j]);
+      q[j] = m[j - 1] ? q[j - 1] : (m[j] ? cq : q[j]);
+      id[j] = m[j - 1] ? id[j - 1] : (m[j] ? ci : id[j]);
+    }
+    z[0] = m[0] ? cz : z[0];
+    q[0] = m[0] ? cq : q[0];
+    id[0] = m[0] ? ci : id[0];
+  }
   // The same insertion for the (z, id) part only (the caller recomputes q for the K survivors at the end).
   // Compares are half-rate instructions here and the swap chain above spends three per level plus six
   // selects; this form takes one `<` and one `==` per level (the id compare only when some lane of the wave
@@ -1048,7 +1069,7 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
           if (fabsf(dx) > s_rx[k] || fabsf(dy) > s_ry[k]) continue;  // rasterize_points.cu:92
           const float q = s_a[k] * dx * dx + s_b[k] * dx * dy + s_c[k] * dy * dy;  // :94
           if (q > s_cut[k]) continue;                                              // :96
-          const float pz = s_pz[k];
+          const float pz = s_pz[k] + 0.0f;            // (-0 -> +0: the slice merge orders depths by their bit patterns)
           const int id = s_id[k];
           if (pz < wz || (pz == wz && id < wi)) {
             best.push(pz, id, q, K);
@@ -1477,12 +1498,13 @@ __global__ __launch_bounds__(1024) void k_tile_items(const int32_t* __restrict__
 
 // K-best of a heavy tile's pixels from the K-best lists of its slices (same (z, idx) order: the result
 // does not depend on how the list was cut), then the depth-merging cut and the outputs of k_raster.
-template <int KMAX>
+template <int KMAX, bool KFULL = false>
 __global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ heavy, const int32_t* __restrict__ counters,
-                                                      const float* __restrict__ scratch, Frame F, int K,
+                                                      const float* __restrict__ scratch, Frame F, int K_arg,
                                                       float depth_thres, int32_t* __restrict__ idx_out,
                                                       float* __restrict__ zbuf_out, float* __restrict__ q_out,
                                                       float* __restrict__ occ_out, CompositeArgs ca) {
+  const int K = KFULL ? KMAX : K_arg;
   const int nh = counters[1];
   for (int hI = blockIdx.x; hI < nh; hI += gridDim.x) {
     const int4 hv = heavy[hI];
@@ -1510,7 +1532,7 @@ __global__ __launch_bounds__(256) void k_raster_merge(const int4* __restrict__ h
       } else {
 #pragma unroll
         for (int j = 0; j < KMAX; ++j)
-          if (j < K && zz[j] < FLT_MAX) best.push(zz[j], ii[j], qq[j], K);
+          if (j < K && zz[j] < FLT_MAX) best.push_q(zz[j], ii[j], qq[j], K);   // (slice lists hold depths >= +0)
       }
     }
     if (xi >= F.W || yi >= F.H) continue;
@@ -2458,7 +2480,10 @@ static int splat_forward_impl(CompositeArgs ca, const float* points, const float
     hipLaunchKernelGGL((k_raster<KM_, false>), dim3(tiles + max_slots), dim3(256), 0, s, points, ellipse, cutoff, radii, \
                        tile_cursor, items, counters, scratch, tile_off, pairs, pair_capacity, F,                \
                        K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);             \
-  if (items)                                                                                          \
+  if (items && K == KM_)                                                                              \
+    hipLaunchKernelGGL((k_raster_merge<KM_, true>), dim3(tiles < 1024 ? tiles : 1024), dim3(256), 0, s, heavy, counters, scratch, \
+                       F, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca);              \
+  else if (items)                                                                                     \
     hipLaunchKernelGGL(k_raster_merge<KM_>, dim3(tiles < 1024 ? tiles : 1024), dim3(256), 0, s, heavy, counters, scratch, \
                        F, K, depth_merging_thres, idx_out, zbuf_out, qvalue_out, occ_out, ca)
   if (K <= 4) { ISO_LAUNCH_R(4); }
