@@ -41,7 +41,11 @@
 
 #include "mfma_split.h"
 
+#ifdef ISO_WITH_SIREN_PS      // tools/experiments/siren_ps: the point-stationary step, not part of the product library
 static bool siren_ps_enabled();
+#else
+static inline bool siren_ps_enabled() { return false; }
+#endif
 
 namespace {
 
@@ -899,7 +903,9 @@ void siren_x3_pack(const float* raw, float* packed, int H, int L, hipStream_t s)
   hipLaunchKernelGGL(k_siren_pack_x3, dim3(iso_stream_grid(words, 256)), dim3(256), 0, s, raw, packed, H, L);
   if (L > 0) {
     hipLaunchKernelGGL(k_siren_wscale, dim3(L), dim3(256), 0, s, raw, packed, H, L);
+#ifdef ISO_WITH_SIREN_PS
     if (siren_ps_enabled() && siren_ps_supported(H, L)) hipLaunchKernelGGL(k_siren_ps_bounds, dim3(L), dim3(256), 0, s, raw, packed, H, L);
+#endif
     hipLaunchKernelGGL(k_siren_pack_f16, dim3(iso_stream_grid(2 * (int64_t)L * H * H, 256)), dim3(256), 0, s, raw, packed, H, L);
   }
 }
@@ -921,13 +927,16 @@ int siren_x3_launch_tail(const SirenArgs& a, int H, hipStream_t s) {
 
 // ISO_SIREN_PS=1: lists the point-stationary kernel takes (siren_ps_takes) are served by it; the launch of this file's
 // kernels that follows carries ps_guard and returns at once for them
+#ifdef ISO_WITH_SIREN_PS
 static bool siren_ps_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("ISO_SIREN_PS"); v = (e && e[0] == '1') ? 1 : 0; }
   return v == 1;
 }
+#endif
 
 int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
+#ifdef ISO_WITH_SIREN_PS
   if (siren_ps_enabled() && H == 256 && !a.fwd_only && !a.dirs && siren_ps_supported(H, a.L) && n_upper >= kPsMinList &&
       (a.split == 3 || (a.split == 0 && !a.small_tiles)) && a.cnt_lo < 0 && a.cnt_hi == INT64_MAX) {
     siren_ps_launch(a, n_upper, s);
@@ -936,6 +945,7 @@ int siren_x3_launch(const SirenArgs& a, int H, int64_t n_upper, hipStream_t s) {
     if (g.split == 3) return launch_x3_both<256, X3_NW, X3_NB256, X3_MINB256>(g, n_upper, s);
     return launch_x3<256, X3_NW, X3_NB256, X3_MINB256, false>(g, n_upper, s);
   }
+#endif
   if (a.split == 3 && H == 256 && !a.fwd_only) return launch_x3_both<256, X3_NW, X3_NB256, X3_MINB256>(a, n_upper, s);
   if (a.small_tiles && H == 256 && !a.fwd_only) return launch_x3<256, X3_NW, 1, X3_MINB256, false>(a, n_upper, s);
   if (a.fwd_only) {

@@ -60,7 +60,7 @@ if has power; then
   # verdict r4 item 4: socket power + gfx clock (amdsmi, ~50 Hz) during >= 3 s of each kernel
   ( cd $REPO && timeout 600 python tools/power_probe.py $OUT/r05_power_siren.txt \
       "siren_x3_both=python tools/siren_loop.py 4" \
-      "siren_ps=ISO_SIREN_PS=1 python tools/siren_loop.py 4" \
+      "siren_ps=ISO_DEV_LIB=tools/variants/libiso_siren_ps.so ISO_SIREN_PS=1 python tools/siren_loop.py 4" \
       "siren_f32_mfma=ISO_SIREN_GEMM=f32 python tools/siren_loop.py 4" \
       "mfma_zeros=tools/probes/mfma_power long 3 4" \
       "mfma_smooth=tools/probes/mfma_power long 1 4" \
