@@ -2841,9 +2841,12 @@ __global__ void k_z_scatter(const int32_t* __restrict__ idx0, const float* __res
     const float4* __restrict__ gz4 = reinterpret_cast<const float4*>(gz);
     const int64_t nq = npix * (K / 4);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+      // the gradient first: four slots without one (a loss on the front-most depth: every second quad) need no index read,
+      // and the two loads of a quad that has one are independent
+      const float4 g = gz4[i];
+      if (g.x == 0.0f && g.y == 0.0f && g.z == 0.0f && g.w == 0.0f) continue;
       const int4 p = idx4[i];
       if (p.x < 0) continue;                                         // -1 padding is a suffix of a pixel's list
-      const float4 g = gz4[i];
       z_scatter_one(p.x, g.x, e, acc);
       if (p.y >= 0) z_scatter_one(p.y, g.y, e, acc);
       if (p.z >= 0) z_scatter_one(p.z, g.z, e, acc);
