@@ -17,6 +17,7 @@ import math
 from collections import namedtuple
 from typing import Optional
 
+import os as _os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -475,12 +476,29 @@ class UniformProjection(LevelSetProjection):
         with torch.no_grad():
             res = self._project_points(model, cloud, lengths, proj_max_iters=proj_max_iters or self.proj_max_iters,
                                        **forward_kwargs)
+            optimistic = None
+            if (not skip_resampling and res.mask.is_cuda and res.mask.shape[0] == 1 and not _os.environ.get("ISO_OPAPI_SYNC")
+                    and host_lengths(lengths) == [int(res.mask.shape[1])]):
+                # On a fitted network every point converges: the resampling is ISSUED on the whole result before the host
+                # knows the number of converged points (the count's kernel is in the queue, its read comes after the
+                # resampling has been queued, so the GPU does not wait for the host between the two stages).  A count that
+                # says otherwise discards this work and takes the reference's order below.
+                c1 = torch.count_nonzero(res.mask.reshape(1, -1), dim=1)
+                optimistic = self.resample(model, res.points, res.normals, lengths,
+                                           sample_iters=sample_iters or self.sample_iters, **forward_kwargs)
+                c2 = torch.count_nonzero(optimistic.mask.reshape(1, -1), dim=1)
+                both = torch.stack([c1, c2]).tolist()                   # ONE host read for both masks
+                res.mask._iso_true, res.mask._iso_true_version = [int(both[0][0])], res.mask._version
+                optimistic.mask._iso_true, optimistic.mask._iso_true_version = [int(both[1][0])], optimistic.mask._version
             if sum(true_counts(res.mask)) == 0:                       # `not mask.any()` (:396), the count is re-used below
                 return {"levelset_points": res.points, "mask": res.mask}
             if not skip_resampling:
-                res, lengths = converged(res)
-                res = self.resample(model, res.points, res.normals, lengths,
-                                    sample_iters=sample_iters or self.sample_iters, **forward_kwargs)
+                if optimistic is not None and true_counts(res.mask) == host_lengths(lengths):
+                    res = optimistic
+                else:
+                    res, lengths = converged(res)
+                    res = self.resample(model, res.points, res.normals, lengths,
+                                        sample_iters=sample_iters or self.sample_iters, **forward_kwargs)
             if not skip_upsampling:
                 res, lengths = converged(res)
                 if ref_pcl is not None:                               # :411-424: children of the flagged regions

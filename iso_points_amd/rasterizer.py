@@ -16,6 +16,7 @@ All arithmetic runs in libisopoints_hip.so (include/isopoints.h section D).
 """
 from typing import NamedTuple, Optional
 
+import os
 import torch
 import torch.autograd as autograd
 
@@ -132,6 +133,11 @@ class _CNamespace(object):
             raise RuntimeError("ellipse_params (P,3), radii (P,2), cutoff_thres (P,) expected")
         dev = points.device
         N = num_points_per_cloud.shape[0]
+        done = getattr(num_points_per_cloud, "_iso_done", None)          # SurfaceSplatting.forward: rasterised already
+        if done is not None:
+            del num_points_per_cloud._iso_done
+            if done[0] == (S, W, N, K, P) and tile_rows is None and out is None and composite_with is None:
+                return done[1]
         pts, el, cu, ra = _f32c(points), _f32c(ellipse_params), _f32c(cutoff_thres), _f32c(radii)
         first, num = _i64c(cloud_to_packed_first_idx), _i64c(num_points_per_cloud)
         if hasattr(num_points_per_cloud, "_iso_host") and num is not num_points_per_cloud:
@@ -741,16 +747,44 @@ class SurfaceSplatting(object):
             with torch.no_grad():
                 binned = _C.prebin(fr0["ndc"], fr0["radii"], fr0["first_idx"], fr0["num_points"], parts[0][1].shape[0],
                                    rs.image_size)
-        counts = (parts[0][0]["num_points"] if one else torch.cat([fr["num_points"] for fr, _, _, _, _ in parts])).tolist()
+        early, ovf = None, []
+        cap_pairs = int(getattr(self, "_pair_cap", 0))
+        if binned is not None and cap_pairs > 0 and not os.environ.get("ISO_OPAPI_SYNC"):      # (the variable: A/B of the two orders)
+            # ... and with a pair capacity known from earlier calls (1.25 x the largest total seen) the fill and the raster
+            # themselves are ISSUED before the read, on the capacity-sized arrays (the kernels take the row counts from the
+            # device): the host reads row counts, pair total and overflow flag while the GPU rasterises.  An overflow
+            # (a frame with > 1.25 x the pairs of every earlier one) discards the result and takes the exact path.
+            fr0 = parts[0][0]
+            with torch.no_grad():
+                fr0["num_points"]._iso_binned = (binned[2] + (int(fr0["ndc"].shape[0]),), (binned[0], binned[1], cap_pairs))
+                early = _C.splat_points(fr0["ndc"], fr0["ellipse_params"], fr0["cutoff_threshold"], fr0["radii"],
+                                        fr0["first_idx"], fr0["num_points"], rs.depth_merging_threshold, rs.image_size, K,
+                                        max_pts=parts[0][1].shape[0], overflow_out=ovf)
+        if one and binned is not None:
+            extra = [binned[0][-1:].long()] + ([ovf[0].reshape(1).long()] if early is not None else [])
+            both = torch.cat([parts[0][0]["num_points"]] + extra).tolist()          # ONE host read
+            counts, total_pairs = both[:N], int(both[N])
+            if early is not None and (int(both[N + 1]) != 0 or total_pairs > cap_pairs):
+                early = None                                                        # pair list overflowed: exact path below
+                with torch.no_grad():                                               # (the counters were consumed: count again)
+                    fr0 = parts[0][0]
+                    binned = _C.prebin(fr0["ndc"], fr0["radii"], fr0["first_idx"], fr0["num_points"], parts[0][1].shape[0],
+                                       rs.image_size)
+                    total_pairs = int(binned[0][-1].item())
+            self._pair_cap = max(cap_pairs, int(1.25 * total_pairs) + 4096)
+        else:
+            counts = (parts[0][0]["num_points"] if one else torch.cat([fr["num_points"] for fr, _, _, _, _ in parts])).tolist()
         lens = [int(x) for x in counts]
         tot = sum(lens)
         if binned is not None:
-            binned = (binned[2] + (tot,), (binned[0], binned[1], int(binned[0][-1].item())))
+            binned = (binned[2] + (tot,), (binned[0], binned[1], total_pairs))
         fl = [sum(lens[:i]) for i in range(N)]
         if one:                # the front end's own device-side layout (no host -> device copies of what the device has)
             num = with_host_lengths(parts[0][0]["num_points"], lens)
             first = with_host_lengths(parts[0][0]["first_idx"], fl)
-            if binned is not None and tot > 0:
+            if early is not None and tot > 0:
+                num._iso_done = ((S, W, N, K, tot), early)
+            elif binned is not None and tot > 0:
                 num._iso_binned = binned
         else:
             num = with_host_lengths(torch.tensor(lens, dtype=torch.int64, device=dev), lens)
