@@ -37,7 +37,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA
 PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md: dense bf16 MFMA (2.5 PF); 16x the f32 rate
 SUSTAINED_FP16_TFLOPS = 2516.6 * 1.66 / 2.4   # measured: dense fp16 MFMA on all 256 CUs clocks at 1.66 GHz (tools/probes/clock.hip)
 SUSTAINED_FP16_RANDOM_TFLOPS = 1580.0         # the same with operands that change with every MFMA and are random fp16 numbers
-                                              # (tools/probes/mfma_power.hip, profiles/r04_mfma_power_probe.txt: 1.50 GHz)
+                                              # (tools/probes/mfma_power.hip, profiles/r04_mfma_power_probe.txt, r05_power_siren.txt: 1.50-1.55 GHz)
 X3_PASSES = 3                      # fp16 MFMA passes per f32 product in the split-operand mode (siren_x3.hip): both
                                    # operands cut into two fp16 numbers, W_l x_h + W_h x_l + W_h x_h; the fp16 and bf16
                                    # MFMA peaks are equal
@@ -542,7 +542,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",            # 1 M points in total for every N (BASELINE.json: the same cycle at 1 and 8 GPUs)
             # no run of this command on more than one GPU exists in the builder's records (one GPU per lease): the N > 1 path
-            # is verified bit-identical in lock-step / over gloo only; its compute ceiling: profiles/r04_rank_share_*.json
+            # is verified bit-identical in lock-step / over gloo only; its compute ceiling: profiles/r05_rank_share_*.json
             # (true only when this very run has N > 1 ranks on N distinct GPUs over RCCL: tests/test_rccl_gpu.py)
             "scaling_measured": bool(world > 1 and not os.environ.get("ISO_BENCH_ONE_DEVICE")
                                      and os.environ.get("ISO_BENCH_BACKEND", "nccl") == "nccl"),
