@@ -729,20 +729,22 @@ extern "C" int iso_dbg_raster_phases(double* out16) {
 //   true:  thread t walks the few pixels of candidate t's bounding box inside the tile, tests them exactly as the
 //          pixel thread would (same expressions on the same operands) and appends t to the hit list of every pixel
 //          it covers (LDS counters); the pixel threads then insert only their own hits.  The K-best rule is a total
-//          order on (z, id), so the arrival order in the lists does not matter.  Candidates whose box covers more
-//          than kWideArea pixels, and pixels whose list overflows, take the first form.
-// (32 / 24 / 16-entry lists: 316 / 333 / 429 us against 302; wide boxes from 24 / 48 / 96 / 192 pixels: 367 / 302 / 294 /
-// 298 us, and 124 / 98 / 75 / 74 us for a rank's band at N = 8, where the items with many grazing splats set the time)
-constexpr int kHitList = 40, kWideArea = 96;
-#ifndef RS_HITS_PER_TRIP
-#define RS_HITS_PER_TRIP 1
-#endif
+//          order on (z, id), so the arrival order in the lists does not matter.  A pixel's first kHitList hits of a
+//          chunk go to its list, the others set the candidate's bit in the pixel's mask (s_more: 256 bits), which the
+//          pixel thread walks after its list.  Up to kWideCap candidates per chunk whose box covers more than
+//          kWideArea pixels take the first form (tested by every pixel thread).
+// (Round 4, when a pixel with more hits than list entries tested ALL 256 candidates: 32 / 24 / 16-entry lists 316 / 333 /
+// 429 us against 302 with 40; wide boxes from 24 / 48 / 96 / 192 pixels: 367 / 302 / 294 / 298 us.  Round 5 knock-outs at the
+// scale of one rank's band of 8, SIREN surface: that overfull path was 43 of the kernel's 98 us -- a silhouette tile
+// holds pixels with more than 40 hits in nearly every chunk, and each of them kept its whole wave for 256 tests.)
+constexpr int kHitList = 32, kWideArea = 96, kWideCap = 32;
 
 // KFULL: points_per_pixel == KMAX (4 / 8 / 16 / 32: the usual settings) -- K is then a compile-time constant and the
 // per-slot `j < K` tests, the selection of the list's last live entry and their scalar branches fold away (a third of
-// the instructions of an insertion).
+// the instructions of an insertion).  (Seven workgroups per CU leave 72 vector registers; the runtime-K form needs one
+// more and takes six -- a raster kernel must not spill, tests/test_abi.py.)
 template <int KMAX, bool CP, bool KFULL = false>
-__global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
+__global__ __launch_bounds__(256, (CP && KMAX <= 8) ? (KFULL ? 7 : 6) : 1) void k_raster(
     const float* __restrict__ pts, const float* __restrict__ ellipse,
     const float* __restrict__ cutoff, const float* __restrict__ radii,
     const int32_t* __restrict__ tile_order, const int4* __restrict__ items, const int32_t* __restrict__ item_count,
@@ -759,7 +761,8 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
   __shared__ short s_list[4][NSOA];
   __shared__ int s_cntw[4][4];       // [source wave][target wave]
   __shared__ int s_hits[CP ? 256 : 1];                      // CP: hits of the chunk per pixel
-  __shared__ __attribute__((aligned(16))) unsigned char s_hit[CP ? 256 : 1][CP ? kHitList : 1];
+  __shared__ __attribute__((aligned(16))) unsigned char s_hit[CP ? 256 : 1][CP ? kHitList : 1];   // the first kHitList of them
+  __shared__ unsigned s_more[CP ? 8 : 1][CP ? 256 : 1];     // the others: bit k % 32 of word [k / 32][pixel]
   // workgroups take the tiles of the band heaviest first (k_tile_order): a tile on the sphere's
   // silhouette holds 8x the mean number of candidates and would otherwise finish long after the rest
   // a work item = a tile, or -- for the tiles that hold many times the mean number of candidates (a
@@ -801,39 +804,28 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
     cnt = min(cnt, (int)((int64_t)chunks * (slice + 1) / nslices) * 256);
   }
   if constexpr (CP) {
-    // records of a chunk: {x, y, z, id} {a, b, c, cutoff} {rx, ry}; the next chunk's records are requested (into
-    // registers) while this one is worked on
+    // records of a chunk: {x, y, z, id} in LDS (the pixel threads read depth and id of their hits); {a, b, c, cutoff}
+    // {rx, ry} stay in the registers of the thread that walks the candidate's box -- only the few wide candidates put
+    // theirs in a small table for the pixel threads.  The next chunk's records are requested (into registers) while
+    // this one is worked on.
     // ONE record buffer (a third barrier per chunk): 22.5 KB of LDS instead of 37 put seven workgroups on a CU
     // instead of four -- 387 -> 302 us; the kernel is bound by what the resident waves can overlap
-    constexpr int NB = 1;
-    __shared__ float4 s_r0[NB][256], s_r1[NB][256];
-    __shared__ float2 s_r2[NB][256];
-    __shared__ short s_wide[2][256];
+    __shared__ float4 s_r0[256];
+    __shared__ short s_wide[2][kWideCap];
+    __shared__ float s_wrec[2][kWideCap][6];              // {a, b, c, cutoff, rx, ry}
     __shared__ int s_nw[2];
-#ifdef RS_ROWS4
-    __shared__ unsigned short s_box[256];
-#endif
-    float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0;
+    float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+    float2 r2 = {0.f, 0.f};
     auto fetch = [&](int c0) {
       if (c0 + (int)threadIdx.x < cnt) {
         const int p = pairs[off + c0 + threadIdx.x];
         r0 = make_float4(pts[(int64_t)p * 3], pts[(int64_t)p * 3 + 1], pts[(int64_t)p * 3 + 2], __int_as_float(p));
         r1 = make_float4(ellipse[(int64_t)p * 3], ellipse[(int64_t)p * 3 + 1], ellipse[(int64_t)p * 3 + 2], cutoff[p]);
-        r2 = make_float4(radii[(int64_t)p * 2], radii[(int64_t)p * 2 + 1], 0.f, 0.f);
+        r2 = make_float2(radii[(int64_t)p * 2], radii[(int64_t)p * 2 + 1]);
       }
     };
     int par = 0;
-    auto test_push = [&](int k, bool exact_hit) {
-      const float4 c0v = s_r0[par % NB][k], c1v = s_r1[par % NB][k];
-      const float dx = xf - c0v.x, dy = yf - c0v.y;
-      if (!exact_hit) {
-        const float2 c2v = s_r2[par % NB][k];
-        if (fabsf(dx) > c2v.x || fabsf(dy) > c2v.y) return;                        // rasterize_points.cu:92
-      }
-      if (!exact_hit) {
-        const float q = c1v.x * dx * dx + c1v.y * dx * dy + c1v.z * dy * dy;      // :94
-        if (q > c1v.w) return;                                                    // :96
-      }
+    auto push_if_better = [&](const float4& c0v) {
       const float pz = c0v.z + 0.0f;                     // (-0 -> +0: push_zi orders depths by their bit patterns)
       const int id = __float_as_int(c0v.w);
       if (pz < wz || (pz == wz && id < wi)) {
@@ -845,57 +837,27 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
         }
       }
     };
+    auto hit_push = [&](int k) { push_if_better(s_r0[k]); };                      // a listed hit: it passed the tests already
+    auto wide_push = [&](int i) {                                                  // entry i of the wide table, tested here
+      const float4 c0v = s_r0[s_wide[par][i]];
+      const float* wr = s_wrec[par][i];
+      const float dx = xf - c0v.x, dy = yf - c0v.y;
+      if (fabsf(dx) > wr[4] || fabsf(dy) > wr[5]) return;                          // rasterize_points.cu:92
+      const float q = wr[0] * dx * dx + wr[1] * dx * dy + wr[2] * dy * dy;          // :94
+      if (q > wr[3]) return;                                                       // :96
+      push_if_better(c0v);
+    };
     s_hits[threadIdx.x] = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s_more[w][threadIdx.x] = 0u;
     if (threadIdx.x < 2) s_nw[threadIdx.x] = 0;
     RS_PH(-1);
     fetch(c_begin);
     for (int c0 = c_begin; c0 < cnt; c0 += 256, par ^= 1) {
       const int m = min(256, cnt - c0);
-      if ((int)threadIdx.x < m) { s_r0[par % NB][threadIdx.x] = r0; s_r1[par % NB][threadIdx.x] = r1; s_r2[par % NB][threadIdx.x] = make_float2(r2.x, r2.y); }
-#ifdef RS_ROWS4
-      // FOUR LANES PER CANDIDATE (rows y0 + s, y0 + s + 4, ... of its box for lane s): the box is taken from the registers
-      // the record is written from (no barrier of its own), the lanes of a wave then walk a quarter of sixteen boxes
-      // each instead of one of sixty-four whole boxes -- the widest box of the wave no longer sets its time
-      if ((int)threadIdx.x < m) {
-        int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
-        const bool any = pixel_range(r0.x, r2.x, F.W, F.ex, F.m, x0, x1) && pixel_range(r0.y, r2.y, F.H, F.ey, F.m, y0, y1);
-        x0 = max(x0, tx * TILE); x1 = min(x1, tx * TILE + TILE - 1);
-        y0 = max(y0, ty * TILE); y1 = min(y1, ty * TILE + TILE - 1);
-        unsigned short bx = 0x000fu;                      // x0 = 15 > x1 = 0: "nothing"
-        if (any && x0 <= x1 && y0 <= y1) {
-          if ((x1 - x0 + 1) * (y1 - y0 + 1) > kWideArea) s_wide[par][atomicAdd(&s_nw[par], 1)] = (short)threadIdx.x;
-          else bx = (unsigned short)((x0 - tx * TILE) | ((x1 - tx * TILE) << 4) | ((y0 - ty * TILE) << 8) | ((y1 - ty * TILE) << 12));
-        }
-        s_box[threadIdx.x] = bx;
-      }
-      __syncthreads();                                    // records + boxes visible; the hit counters are zero
-      RS_PH(0);
-      fetch(c0 + 256);
-#pragma unroll 1
-      for (int k = (int)(threadIdx.x >> 2); k < m; k += 64) {
-        const unsigned bx = s_box[k];
-        const int lx0 = bx & 15, lx1 = (bx >> 4) & 15, ly0 = (bx >> 8) & 15, ly1 = (bx >> 12) & 15;
-        if (lx0 > lx1) continue;
-        const int sub = threadIdx.x & 3;
-        if (ly0 + sub > ly1) continue;
-        const float4 c0v = s_r0[par % NB][k], c1v = s_r1[par % NB][k];
-        const float2 c2v = s_r2[par % NB][k];
-        for (int ly = ly0 + sub; ly <= ly1; ly += 4) {
-          const float dy = ndc_y(ty * TILE + ly, F) - c0v.y;
-          if (fabsf(dy) > c2v.y) continue;
-          for (int lxx = lx0; lxx <= lx1; ++lxx) {
-            const float dx = ndc_x(tx * TILE + lxx, F) - c0v.x;
-            if (fabsf(dx) > c2v.x) continue;
-            const float q = c1v.x * dx * dx + c1v.y * dx * dy + c1v.z * dy * dy;
-            if (q > c1v.w) continue;
-            const int pl = ly * TILE + lxx;
-            const int slot = atomicAdd(&s_hits[pl], 1);
-            if (slot < kHitList) s_hit[pl][slot] = (unsigned char)k;
-          }
-        }
-      }
-      if (false) {
-#else
+      const float4 c0v = r0, c1v = r1;                    // this thread's candidate of the chunk
+      const float2 c2v = r2;
+      if ((int)threadIdx.x < m) s_r0[threadIdx.x] = r0;
       __syncthreads();                                    // records visible; the hit counters are zero
       RS_PH(0);
       fetch(c0 + 256);
@@ -904,48 +866,34 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
 #else
       if ((int)threadIdx.x < m) {
 #endif
-#endif
         const int k = threadIdx.x;
-        const float4 c0v = s_r0[par % NB][k], c1v = s_r1[par % NB][k];
-        const float2 c2v = s_r2[par % NB][k];
         int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
         const bool any = pixel_range(c0v.x, c2v.x, F.W, F.ex, F.m, x0, x1) && pixel_range(c0v.y, c2v.y, F.H, F.ey, F.m, y0, y1);
         x0 = max(x0, tx * TILE); x1 = min(x1, tx * TILE + TILE - 1);
         y0 = max(y0, ty * TILE); y1 = min(y1, ty * TILE + TILE - 1);
-        if (any && x0 <= x1 && y0 <= y1) {
-          if ((x1 - x0 + 1) * (y1 - y0 + 1) > kWideArea) {
-            s_wide[par][atomicAdd(&s_nw[par], 1)] = (short)k;
-          } else {
-            for (int y = y0; y <= y1; ++y) {
-              const float dy = ndc_y(y, F) - c0v.y;
-              if (fabsf(dy) > c2v.y) continue;
-#ifdef RS_PAIRS
-              // two pixels per trip: both returning LDS atomics are issued before either slot is used (a hit is otherwise
-              // a chain test -> atomic -> wait -> store, one pixel after the other)
-              for (int x = x0; x <= x1; x += 2) {
-                const float dxa = ndc_x(x, F) - c0v.x, dxb = ndc_x(x + 1, F) - c0v.x;
-                const float qa = c1v.x * dxa * dxa + c1v.y * dxa * dy + c1v.z * dy * dy;
-                const float qb = c1v.x * dxb * dxb + c1v.y * dxb * dy + c1v.z * dy * dy;
-                const bool ha = !(fabsf(dxa) > c2v.x) && !(qa > c1v.w);
-                const bool hb = x + 1 <= x1 && !(fabsf(dxb) > c2v.x) && !(qb > c1v.w);
-                const int pl = (y - ty * TILE) * TILE + (x - tx * TILE);
-                int sa = kHitList, sb = kHitList;
-                if (ha) sa = atomicAdd(&s_hits[pl], 1);
-                if (hb) sb = atomicAdd(&s_hits[pl + 1], 1);
-                if (sa < kHitList) s_hit[pl][sa] = (unsigned char)k;
-                if (sb < kHitList) s_hit[pl + 1][sb] = (unsigned char)k;
-              }
-#else
-              for (int x = x0; x <= x1; ++x) {
-                const float dx = ndc_x(x, F) - c0v.x;
-                if (fabsf(dx) > c2v.x) continue;
-                const float q = c1v.x * dx * dx + c1v.y * dx * dy + c1v.z * dy * dy;
-                if (q > c1v.w) continue;
-                const int pl = (y - ty * TILE) * TILE + (x - tx * TILE);
-                const int slot = atomicAdd(&s_hits[pl], 1);
-                if (slot < kHitList) s_hit[pl][slot] = (unsigned char)k;
-              }
-#endif
+        bool walk = any && x0 <= x1 && y0 <= y1;
+        if (walk && (x1 - x0 + 1) * (y1 - y0 + 1) > kWideArea) {
+          const int ws = atomicAdd(&s_nw[par], 1);
+          if (ws < kWideCap) {                            // (a full table: the box is walked like the others)
+            s_wide[par][ws] = (short)k;
+            float* wr = s_wrec[par][ws];
+            wr[0] = c1v.x; wr[1] = c1v.y; wr[2] = c1v.z; wr[3] = c1v.w; wr[4] = c2v.x; wr[5] = c2v.y;
+            walk = false;
+          }
+        }
+        if (walk) {
+          for (int y = y0; y <= y1; ++y) {
+            const float dy = ndc_y(y, F) - c0v.y;
+            if (fabsf(dy) > c2v.y) continue;
+            for (int x = x0; x <= x1; ++x) {
+              const float dx = ndc_x(x, F) - c0v.x;
+              if (fabsf(dx) > c2v.x) continue;
+              const float q = c1v.x * dx * dx + c1v.y * dx * dy + c1v.z * dy * dy;
+              if (q > c1v.w) continue;
+              const int pl = (y - ty * TILE) * TILE + (x - tx * TILE);
+              const int slot = atomicAdd(&s_hits[pl], 1);
+              if (slot < kHitList) s_hit[pl][slot] = (unsigned char)k;
+              else atomicOr(&s_more[k >> 5][pl], 1u << (k & 31));         // beyond the list: the pixel's bit mask
             }
           }
         }
@@ -960,48 +908,25 @@ __global__ __launch_bounds__(256, (CP && KMAX <= 8) ? 7 : 1) void k_raster(
 #else
       if (inside) {
 #endif
-        if (nh <= kHitList) {
-#if RS_HITS_PER_TRIP == 1
-          for (int i = 0; i < nh; ++i) test_push(s_hit[threadIdx.x][i], true);
-#else
-          // RS_HITS_PER_TRIP hits per trip: their list bytes come as one read and the (z, id) records are requested
-          // together -- one hit per trip is a chain of two dependent LDS round trips per insertion
-          constexpr int HPT = RS_HITS_PER_TRIP;
-          for (int i = 0; i < nh; i += HPT) {
-            unsigned kk;
-            if (HPT == 2) kk = *reinterpret_cast<const unsigned short*>(&s_hit[threadIdx.x][i]);
-            else kk = *reinterpret_cast<const unsigned*>(&s_hit[threadIdx.x][i]);
-            float2 zi[HPT];
-#pragma unroll
-            for (int u = 0; u < HPT; ++u) {
-              const float4* rp = &s_r0[par % NB][(kk >> (8 * u)) & 255u];
-              zi[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(rp) + 2);       // (z, id)
-            }
-#pragma unroll
-            for (int u = 0; u < HPT; ++u) {
-              if (i + u < nh) {
-                const float pz = zi[u].x + 0.0f;         // (-0 -> +0: push_zi orders depths by their bit patterns)
-                const int id = __float_as_int(zi[u].y);
-                if (pz < wz || (pz == wz && id < wi)) {
-                  best.push_zi(pz, id, K);
-                  if (K == KMAX) { wz = best.z[KMAX - 1]; wi = best.id[KMAX - 1]; }
-                  else {
-#pragma unroll
-                    for (int j = 0; j < KMAX; ++j) if (j == K - 1) { wz = best.z[j]; wi = best.id[j]; }
-                  }
-                }
-              }
+        const int nl = min(nh, kHitList);
+        for (int i = 0; i < nl; ++i) hit_push(s_hit[threadIdx.x][i]);
+        if (nh > kHitList) {
+#pragma unroll 1
+          for (int w = 0; w < 8; ++w) {
+            unsigned mm = s_more[w][threadIdx.x];
+            s_more[w][threadIdx.x] = 0u;
+            while (mm) {
+              const int b = __ffs((int)mm) - 1;
+              mm &= mm - 1u;
+              hit_push(w * 32 + b);
             }
           }
-#endif
-          const int nw = s_nw[par];
-          for (int i = 0; i < nw; ++i) test_push(s_wide[par][i], false);
-        } else {
-          for (int k = 0; k < m; ++k) test_push(k, false);        // an overfull list: every candidate, tested here
         }
+        const int nw = min(s_nw[par], kWideCap);
+        for (int i = 0; i < nw; ++i) wide_push(i);
       }
       RS_PH(2);
-      if (NB == 1) __syncthreads();                       // one record buffer: all reads done before the next chunk lands
+      __syncthreads();                                    // one record buffer: all reads done before the next chunk lands
       RS_PH(3);
     }
     // q of the K survivors (:94; the same expression on the same operands as the hit test): their records are
