@@ -92,11 +92,19 @@ __global__ void k_siren_wscale(const float* __restrict__ raw, float* __restrict_
   const int l = blockIdx.x;
   const int64_t HH = (int64_t)H * H;
   const float* Wl = raw + (int64_t)H * 4 + (int64_t)l * (HH + H);
-  float m = 0.f;
-#pragma unroll 16
-  for (int64_t i = threadIdx.x; i < HH; i += 256) {        // (16 loads in flight: the loop is a latency chain otherwise)
-    const float a = fabsf(Wl[i]);
-    m = (a == a && a > m) ? a : m;
+  // ONE pass over the layer (column f of thread f, rows in order: coalesced across the workgroup, 32 loads in flight --
+  // the loop is a latency chain otherwise): the maximum for the scale and the column sums for c_l below.  (Two passes
+  // with 16 loads in flight were 17 us per cycle; the weights change every step, so this runs every cycle.)
+  float m = 0.f, cs = 0.f;
+  for (int f = threadIdx.x; f < H; f += 256) {
+    float t = 0.f;
+#pragma unroll 32
+    for (int k = 0; k < H; ++k) {
+      const float a = fabsf(Wl[(int64_t)k * H + f]);
+      m = (a == a && a > m) ? a : m;
+      t += a;
+    }
+    cs = fmaxf(cs, t);
   }
   s_m[threadIdx.x] = m;
   __syncthreads();
@@ -118,13 +126,6 @@ __global__ void k_siren_wscale(const float* __restrict__ raw, float* __restrict_
   }
   __syncthreads();
   // c_l = max_f sum_k |W_l[k][f]|: |(W_l^T a)[f]| <= c_l max|a|
-  float cs = 0.f;
-  for (int f = threadIdx.x; f < H; f += 256) {
-    float t = 0.f;
-#pragma unroll 16
-    for (int k = 0; k < H; ++k) t += fabsf(Wl[(int64_t)k * H + f]);
-    cs = fmaxf(cs, t);
-  }
   s_m[threadIdx.x] = cs;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
