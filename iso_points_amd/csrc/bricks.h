@@ -26,7 +26,7 @@ struct BrickHdr {                      // device resident, 32 dwords
   int nf[3]; int n;                    // 20..23  fine cells per axis (4 nb), points in the grid (own + imported)
   int n_own; int id_base; int g_covers_r; int n_total;  // 24..27
   float x_lo, x_hi;                    // 28..29  N ranks: x-range inside which this rank holds EVERY point of the cloud
-  int pad1[2];                         // 30..31
+  int own_bx_lo, own_bx_hi;            // 30..31  N ranks: brick columns (x) that can hold points of this rank -- the others hold imported records only
 };
 
 // Counters per brick: one per SUB-BRICK of 2x2x2 fine cells (sub = (sx * 2 + sy) * 2 + sz, sx = bit 1 of the fine x cell
@@ -268,7 +268,7 @@ __device__ inline BrickHdr bricks_header(const float* mn_in, const float* mx_in,
   h.g_covers_r = g >= r ? 1 : 0;
   h.n_total = (int)q.n_total;
   h.x_lo = -FLT_MAX; h.x_hi = FLT_MAX;
-  h.pad1[0] = h.pad1[1] = 0;
+  h.own_bx_lo = 0; h.own_bx_hi = 0x7fffffff;
   return h;
 }
 // one thread, once per grid: store the header, move the counters of the previous grid to the sticky block

@@ -329,7 +329,8 @@ __device__ __forceinline__ int brick_counters_load(int32_t* __restrict__ cnt, in
 }
 // offsets of those bricks' counters from the exclusive prefix `ex` of the thread, occupied bricks appended at list[at..]
 __device__ __forceinline__ void brick_offsets_store(int32_t* __restrict__ off, int32_t* __restrict__ list, int chunk, int nb,
-                                                    const int (&c)[BS_ITEMS][BK_CPB], const int (&tot)[BS_ITEMS], int ex, int at) {
+                                                    const int (&c)[BS_ITEMS][BK_CPB], const int (&tot)[BS_ITEMS], int ex, int at,
+                                                    const bool (&listed)[BS_ITEMS]) {
 #pragma unroll
   for (int k = 0; k < BS_ITEMS; ++k) {
     const int brick = chunk * BS_CHUNK + threadIdx.x * BS_ITEMS + k;
@@ -340,10 +341,21 @@ __device__ __forceinline__ void brick_offsets_store(int32_t* __restrict__ off, i
       int4* p = reinterpret_cast<int4*>(off + (int64_t)BK_CPB * brick);
       p[0] = make_int4(o[0], o[1], o[2], o[3]);
       p[1] = make_int4(o[4], o[5], o[6], o[7]);
-      if (tot[k] > 0) list[at++] = brick;
+      if (listed[k]) list[at++] = brick;
     } else if (brick == nb) {
       off[(int64_t)BK_CPB * nb] = ex;                    // the sentinel behind the last brick
     }
+  }
+}
+
+// bricks of the work list: occupied, and in a brick column (x-major brick ids) that can hold points of this rank
+__device__ __forceinline__ void brick_listed(const BrickHdr& h, int chunk, const int (&tot)[BS_ITEMS], bool (&listed)[BS_ITEMS]) {
+  const int per_col = h.nb[1] * h.nb[2];
+#pragma unroll
+  for (int k = 0; k < BS_ITEMS; ++k) {
+    const int brick = chunk * BS_CHUNK + threadIdx.x * BS_ITEMS + k;
+    const int bx = brick / per_col;
+    listed[k] = tot[k] > 0 && bx >= h.own_bx_lo && bx <= h.own_bx_hi;
   }
 }
 
@@ -373,14 +385,16 @@ __global__ __launch_bounds__(256) void k_brick_offsets(const BrickHdr* __restric
   int c[BS_ITEMS][BK_CPB], t[BS_ITEMS];
   const int v = brick_counters_load<true>(cnt, blockIdx.x, nb, c, t);
   int occ = 0;
+  bool listed[BS_ITEMS];
+  brick_listed(*hp, blockIdx.x, t, listed);
 #pragma unroll
-  for (int k = 0; k < BS_ITEMS; ++k) occ += t[k] > 0 ? 1 : 0;
+  for (int k = 0; k < BS_ITEMS; ++k) occ += listed[k] ? 1 : 0;
   int tot, occ_tot;
   const int ex = base + block_excl_scan_256(v, tot, lds);
   int at = block_excl_scan_256(occ, occ_tot, lds);
   if (threadIdx.x == 0) s_base = occ_tot ? atomicAdd(&counters[0], occ_tot) : 0;
   __syncthreads();
-  brick_offsets_store(off, list, blockIdx.x, nb, c, t, ex, at + s_base);
+  brick_offsets_store(off, list, blockIdx.x, nb, c, t, ex, at + s_base, listed);
 }
 
 // The two passes above as ONE launch (2048 workgroups of this size are resident at once -- 8 per CU --, so a workgroup may
@@ -402,8 +416,10 @@ __global__ __launch_bounds__(256) void k_brick_offsets1(const BrickHdr* __restri
   int c[BS_ITEMS][BK_CPB], t[BS_ITEMS];
   const int v = brick_counters_load<true>(cnt, blockIdx.x, nb, c, t);
   int occ = 0;
+  bool listed[BS_ITEMS];
+  brick_listed(*hp, blockIdx.x, t, listed);
 #pragma unroll
-  for (int k = 0; k < BS_ITEMS; ++k) occ += t[k] > 0 ? 1 : 0;
+  for (int k = 0; k < BS_ITEMS; ++k) occ += listed[k] ? 1 : 0;
   int tot, occ_tot;
   int ex = block_excl_scan_256(v, tot, lds);
   if (threadIdx.x == 0) __hip_atomic_store(&sums[blockIdx.x], 0x80000000u | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(256) void k_brick_offsets1(const BrickHdr* __restri
   int at = block_excl_scan_256(occ, occ_tot, lds);
   if (threadIdx.x == 0) s_base = occ_tot ? atomicAdd(&counters[0], occ_tot) : 0;
   __syncthreads();
-  brick_offsets_store(off, list, blockIdx.x, nb, c, t, ex, at + s_base);
+  brick_offsets_store(off, list, blockIdx.x, nb, c, t, ex, at + s_base, listed);
   // everyone has read the totals it needs once it is here; the last one clears them
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1665,6 +1681,10 @@ __global__ __launch_bounds__(256) void k_halo_import(const float4* __restrict__ 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       hp->x_lo = lo <= 0 ? -FLT_MAX : h.mn[0] + (float)lo * h.f;
       hp->x_hi = hi >= h.nf[0] - 1 ? FLT_MAX : h.mn[0] + (float)(hi + 1) * h.f;
+      // the work list of the fused kernels (k_brick_offsets*) skips the bricks outside the rank's own columns: their
+      // records are candidates only, and a workgroup that staged one found no query (half the list at N = 8)
+      hp->own_bx_lo = (lo + halo) >> 2;
+      hp->own_bx_hi = (hi - halo) >> 2;
     }
     return;
   }
