@@ -338,15 +338,22 @@ static int64_t tail_cap_of(int64_t n) {
 }
 static int64_t tail_ints(int64_t n) { return siren_x3_tail_blocks() * (2 * tail_cap_of(n) + 2); }
 
-// workspace: [stash floats][idx A n][idx B n][tail lists + counters][counts 64]
+// workspace: [stash floats][idx A n][idx B n][tail lists + counters][counts 64][tile counters: two per launch]
+constexpr int kTileCtrInts = 128;     // (max_iters <= 60: 61 launches)
 extern "C" int64_t iso_project_siren_workspace_bytes(int64_t n, int hidden, int n_hidden) {
   if (n < 0) n = 0;
-  return stash_floats_any(hidden, n_hidden) * 4 + 2 * n * 4 + tail_ints(n) * 4 + 64 * 4 + 64;
+  return stash_floats_any(hidden, n_hidden) * 4 + 2 * n * 4 + tail_ints(n) * 4 + (64 + kTileCtrInts) * 4 + 64;
 }
 
 static bool siren_small_tiles_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("ISO_SIREN_SMALL_TILES"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
+static bool siren_dynamic_tiles_enabled() {     // ISO_SIREN_DYN_TILES=0: static tile assignment (A/B)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ISO_SIREN_DYN_TILES"); v = (e && e[0] == '0') ? 0 : 1; }
   return v == 1;
 }
 
@@ -366,6 +373,7 @@ static int run_step_split(SirenArgs a, int hidden, int64_t n, hipStream_t s) {
     return run_step(a, hidden, n, s);
   }
   a.small_tiles = 0; a.split = split ? 1 : 0;
+  a.tile_ctr = nullptr;                      // (the counters are per launch of k_siren_step_x3_both)
   int rc = run_step(a, hidden, n, s);
   if (rc != 0 || !split) return rc;
   a.small_tiles = 1; a.split = 2;
@@ -417,8 +425,10 @@ static int run_iterations(SirenArgs a, int hidden, int64_t n, int max_iters, voi
   int32_t* tail_counts = tail + (int64_t)blocks * 2 * cap;
   const bool can_tail = hidden == 256 && !a.dirs && !a.fwd_only && use_x3(hidden, a.L) && siren_small_tiles_enabled();
   const int tail_from = can_tail ? siren_tail_from(max_iters) : max_iters + 1;
-  hipLaunchKernelGGL(k_zero_tail, dim3((2 * blocks + 255) / 256), dim3(256), 0, s, counts, 64, tail_counts,
+  int32_t* tile_ctr = counts + 64;          // [launch][2]: drawn from by the workgroups of k_siren_step_x3_both (zeroed with the counts)
+  hipLaunchKernelGGL(k_zero_tail, dim3((2 * blocks + 255) / 256), dim3(256), 0, s, counts, 64 + kTileCtrInts, tail_counts,
                      tail_from <= max_iters ? 2 * blocks : 0);
+  const bool dyn_tiles = siren_dynamic_tiles_enabled() && 2 * (max_iters + 1) <= kTileCtrInts;
   a.stash = stash; a.n = n; a.eval_only = 0; a.sdf_out = a.dirs ? a.sdf_out : nullptr; a.grad_out = nullptr;
   for (int it = 0; it <= max_iters; ++it) {
     a.idx_in = (it == 0) ? nullptr : ((it & 1) ? idxA : idxB);
@@ -426,6 +436,7 @@ static int run_iterations(SirenArgs a, int hidden, int64_t n, int max_iters, voi
     a.idx_out = (it & 1) ? idxB : idxA;
     a.count_out = counts + it + 1;
     a.do_move = (it < max_iters) ? 1 : 0;
+    a.tile_ctr = dyn_tiles ? tile_ctr + 2 * it : nullptr;
     if (it >= tail_from && it > 0) {        // iterations it .. max_iters in one launch
       a.tail_lists = tail; a.tail_counts = tail_counts; a.iter_counts = counts; a.tail_cap = (int)cap;
       a.it_first = it; a.it_last = max_iters;

@@ -40,6 +40,9 @@ struct SirenArgs {
   int32_t* tail_counts = nullptr;  // [blocks][2] their lengths (zero on entry of the launch: cleared by k_zero_counts' sibling)
   int32_t* iter_counts = nullptr;  // counts[it] of the projection (diagnostics: points evaluated by iteration it)
   int tail_cap = 0, it_first = 0, it_last = 0;
+  // k_siren_step_x3_both: two counters (96-point tiles, 32-point tiles), ZERO when the launch starts; null: static tile
+  // assignment.  A workgroup draws its next tile from them (x3_step_body) instead of taking every nblk-th.
+  int32_t* tile_ctr = nullptr;
   int ps_guard = 0;          // 1: this launch follows one of k_siren_step_ps on the same list and only works where that one declines
 };
 

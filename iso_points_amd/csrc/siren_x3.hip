@@ -381,7 +381,15 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
     }
   };
   if constexpr (X3_TILE_PIPE) { fetch_idx(bid); fetch_pts(); }
-  for (int64_t tile = bid; tile < n_tiles; tile += nblk) {
+  // Which tile comes next.  Static: bid + k nblk -- every CU takes the same number of tiles, and the launch ends with the
+  // slowest XCD (under the power cap the eight XCDs of one MI355X ran this kernel 6.8 % apart, tools/diag/x3_end_times.py).
+  // Dynamic (a.tile_ctr, reverse kernels): thread 0 draws the next tile from a counter (zero when the launch starts) while
+  // stage 0's GEMM runs and hands it to the workgroup through LDS at the barrier that ends that GEMM.  A point's result
+  // does not depend on the tile it sits in or on the workgroup that takes the tile.
+  __shared__ int s_next_tile;
+  const bool dyn = !FWD && X3_TILE_PIPE && a.tile_ctr != nullptr;
+  int64_t next_tile = 0;
+  for (int64_t tile = bid; tile < n_tiles; tile = next_tile) {
 #ifdef X3_DBG_TIMES
     const bool dbg_on = bid == 0 && tile == (int64_t)nblk;
     int dbg_i = 0;
@@ -651,11 +659,15 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
     // stage 0: d sdf / d x = W_0^T [ (W_1^T a_1) * w0 cos(w0 z_0) ] -- z_0 = W_0 x + b_0 is formed again from the point
     // (three FMAs; the same expression on the same operands as in the forward sweep) instead of being stashed
     if constexpr (!FWD) {
+      int drawn = 0;
+      if (dyn && tid == 0) drawn = nblk + atomicAdd(a.tile_ctr, 1);
       gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, FP>(rev_img(0), nullptr, act + lane, acc, w, 0, A, fwd_img(0), 0, lane);
+      if (dyn && tid == 0) s_next_tile = drawn;
       X3_STAMP();
       __syncthreads();
       X3_STAMP();
-      if constexpr (X3_TILE_PIPE) fetch_idx(tile + nblk);
+      next_tile = dyn ? (int64_t)s_next_tile : tile + nblk;
+      if constexpr (X3_TILE_PIPE) fetch_idx(next_tile);
       float inv[NB];
       {
         const float iw = 1.0f / a.packed[x16_base(H, L)];
@@ -699,7 +711,8 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
       if constexpr (!X3_TILE_PIPE) __syncthreads();
       X3_STAMP();
     } else {
-      if constexpr (X3_TILE_PIPE) fetch_idx(tile + nblk);
+      next_tile = tile + nblk;
+      if constexpr (X3_TILE_PIPE) fetch_idx(next_tile);
     }
     // ---- reduce head + gradient over the lane halves and the waves -----------------------------
 #pragma unroll
@@ -770,9 +783,27 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
   }
 }
 
+// -DX3_DBG_END (timing experiment, tools/diag/x3_end_times.py): thread 0 of every workgroup of k_siren_step_x3 leaves the
+// constant-rate clock at its start and end and the XCD it ran on
+#ifdef X3_DBG_END
+__device__ unsigned long long x3_end[2048 * 3];
+extern "C" int iso_dbg_x3_end(unsigned long long* out, int n_blocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(x3_end), sizeof(unsigned long long) * 3 * n_blocks) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int H, int NW, int NB, int MINB, bool FWD>
 __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
+#ifdef X3_DBG_END
+  const unsigned long long t0 = wall_clock64();
+#endif
   x3_step_body<H, NW, NB, FWD>(a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
+#ifdef X3_DBG_END
+  if (threadIdx.x == 0 && blockIdx.x < 2048) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    x3_end[blockIdx.x * 3] = t0; x3_end[blockIdx.x * 3 + 1] = wall_clock64(); x3_end[blockIdx.x * 3 + 2] = xcc;
+  }
+#endif
 }
 
 // Both tile shapes of a split list (SirenArgs::split) in ONE launch: workgroups [0, big_blocks) serve the slots below
@@ -782,6 +813,15 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 // (issued separately, the idle one of the two launches took ~4.4 us, 15 times per headline cycle).
 template <int H, int NW, int NB, int MINB>
 __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3_both(SirenArgs a) {
+#ifdef X3_DBG_END
+  const unsigned long long t0 = wall_clock64();
+  struct EndStamp { unsigned long long t0; __device__ ~EndStamp() {
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      x3_end[blockIdx.x * 3] = t0; x3_end[blockIdx.x * 3 + 1] = wall_clock64(); x3_end[blockIdx.x * 3 + 2] = xcc;
+    } } } stamp{t0};
+#endif
   if ((int)blockIdx.x < a.big_blocks) {
     SirenArgs b = a;
     b.split = 1;
@@ -789,6 +829,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3_both(SirenArgs 
   } else {
     SirenArgs b = a;
     b.split = 2;
+    if (a.tile_ctr) b.tile_ctr = a.tile_ctr + 1;
     b.stash = a.stash + (int64_t)a.big_blocks * X3Shape<H, NW, NB>::kStashPerWg(a.L);
     x3_step_body<H, NW, 1, false>(b, (int)blockIdx.x - a.big_blocks, (int)gridDim.x - a.big_blocks,
                                   (int)blockIdx.x - a.big_blocks);
@@ -808,7 +849,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_tail_x3(SirenArgs a) {
   int32_t* lists = a.tail_lists + (int64_t)b * 2 * a.tail_cap;
   int32_t* cnts = a.tail_counts + b * 2;
   SirenArgs r = a;
-  r.split = 0; r.small_tiles = 1; r.cnt_lo = -1; r.cnt_hi = INT64_MAX;
+  r.split = 0; r.small_tiles = 1; r.cnt_lo = -1; r.cnt_hi = INT64_MAX; r.tile_ctr = nullptr;
   // round 0: this workgroup's tiles of the global list
   r.idx_out = lists; r.count_out = cnts;
   r.do_move = a.it_first < a.it_last ? 1 : 0;
