@@ -656,10 +656,16 @@ extern "C" int iso_idr_pack_weights(const float* raw, float* packed, int hidden,
 
 extern "C" int64_t iso_project_idr_workspace_bytes(int64_t n, int hidden, int n_layers) {
   if (n < 0) n = 0;
-  return idr_stash_floats(hidden, n_layers) * 4 + 2 * n * 4 + 64 * 4 + 64;
+  return idr_stash_floats(hidden, n_layers) * 4 + 2 * n * 4 + 128 * 4 + 64;      // [stash][idx A][idx B][counts 64][tile counters 64]
 }
 
 struct IdrTrace { const float* dirs; float alpha, bound; };
+
+static bool idr_dynamic_tiles_enabled() {        // ISO_IDR_DYN_TILES=0: every gridDim-th tile (A/B)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ISO_IDR_DYN_TILES"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
 
 static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint8_t* mask_out,
                    float* sdf_out, float* grad_out, int64_t n, const float* packed, int hidden,
@@ -695,7 +701,7 @@ static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint
     ISO_REQUIRE(run(a) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size", who);
   } else {
     if (pts_out != pts_in) (void)hipMemcpyAsync(pts_out, pts_in, (size_t)n * 12, hipMemcpyDeviceToDevice, st);
-    hipLaunchKernelGGL(k_idr_zero, dim3(1), dim3(64), 0, st, counts, 64);
+    hipLaunchKernelGGL(k_idr_zero, dim3(2), dim3(64), 0, st, counts, 128);
     if (trace) {                         // levelset_sampling.py:764,790: active above 0.1 tol, valid up to tol
       a.dirs = trace->dirs; a.alpha = trace->alpha; a.bound = trace->bound;
       a.tol = 0.1f * tol; a.tol_valid = tol; a.fwd_only = 1;
@@ -708,6 +714,7 @@ static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint
       a.count_out = counts + it + 1;
       a.do_move = (it < max_iters) ? 1 : 0;
       a.eval_only = 0;
+      a.tile_ctr = (x16 && it < 64 && idr_dynamic_tiles_enabled()) ? counts + 64 + it : nullptr;
       ISO_REQUIRE(run(a) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size", who);
     }
   }

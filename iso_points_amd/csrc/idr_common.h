@@ -120,6 +120,9 @@ struct IdrArgs {
   const float* dirs = nullptr;
   float alpha = 1.f, bound = 0.f, tol_valid = 0.f;
   int fwd_only = 0;          // 1: the gradient is not needed
+  // k_idr_step_x16: a counter, ZERO when the launch starts, the workgroups draw their next tile from (null: every
+  // gridDim-th tile -- the launch then ends with the slowest XCD, see x3_step_body in siren_x3.hip)
+  int32_t* tile_ctr = nullptr;
 };
 
 }  // namespace

@@ -243,7 +243,13 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
 #ifdef I16_DBG_TIMES
   long long* dbg = reinterpret_cast<long long*>(a.stash + (int64_t)gridDim.x * S::kStashPerWg(nL)) - NW * 128;
 #endif
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // (the next tile: every gridDim-th, or drawn from a.tile_ctr by thread 0 at the top of this one and handed over
+  // through LDS at the tile's last two barriers)
+  __shared__ int s_next_tile;
+  int64_t next_tile = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile = next_tile) {
+    int drawn = 0;
+    if (a.tile_ctr && tid == 0) drawn = (int)gridDim.x + atomicAdd(a.tile_ctr, 1);
 #ifdef I16_DBG_TIMES
     const bool dbg_on = blockIdx.x == 0 && tile == (int64_t)gridDim.x;
     int dbg_i = 0;
@@ -530,7 +536,9 @@ __global__ __launch_bounds__(512, 1) void k_idr_step_x16(IdrArgs a) {
       float z = gz[n] + __shfl_xor(gz[n], 32);
       if (h == 0) red[w * P + 32 * n + j] = (f32x4){f, x, y, z};
     }
+    if (a.tile_ctr && tid == 0) s_next_tile = drawn;
     __syncthreads();
+    next_tile = a.tile_ctr ? (int64_t)s_next_tile : tile + gridDim.x;
     bool survive = false;
     int64_t idx = -1;
     {
