@@ -142,7 +142,7 @@ class Cycle(object):
         lib = _lib.load()
         cyc = self.cyc
         n = cyc.pts0_local.shape[1]
-        off = lib.iso_project_siren_workspace_bytes(n, HIDDEN, LAYERS) - 64 * 4 - 64
+        off = lib.iso_project_siren_counts_offset(n, HIDDEN, LAYERS)
         counts = []
 
         def hook(T):

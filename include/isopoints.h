@@ -111,6 +111,9 @@ int iso_siren_set_tail_from(int first_tail_iteration);
 int iso_siren_step_launches(int hidden, int n_hidden, int max_iters);
 /* scratch for the per-wave activation-derivative stash */
 int64_t iso_project_siren_workspace_bytes(int64_t n, int hidden, int n_hidden);
+/* diagnostics: byte offset, inside that workspace, of the 64 int32 counters a projection leaves behind -- [it] = points
+ * evaluated by iteration it (it >= 1; iteration 0 evaluates all n) */
+int64_t iso_project_siren_counts_offset(int64_t n, int hidden, int n_hidden);
 int iso_project_siren(const float* pts_in, float* pts_out, float* normals_out,
                       uint8_t* mask_out, int64_t n, const float* packed,
                       int hidden, int n_hidden, float omega_first,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "iso_siren_step_launches": (_I, [_I, _I, _I]),
     "iso_siren_pack_weights": (_I, [_P, _P, _I, _I, _P]),
     "iso_project_siren_workspace_bytes": (_L, [_L, _I, _I]),
+    "iso_project_siren_counts_offset": (_L, [_L, _I, _I]),
     "iso_project_siren": (_I, [_P, _P, _P, _P, _L, _P, _I, _I, _F, _F, _I, _F, _P, _L, _P]),
     "iso_siren_sdf_grad": (_I, [_P, _P, _P, _L, _P, _I, _I, _F, _F, _P, _L, _P]),
     "iso_idr_raw_floats": (_L, [_I, _I, _I, _I]),

@@ -345,6 +345,11 @@ extern "C" int64_t iso_project_siren_workspace_bytes(int64_t n, int hidden, int 
   return stash_floats_any(hidden, n_hidden) * 4 + 2 * n * 4 + tail_ints(n) * 4 + (64 + kTileCtrInts) * 4 + 64;
 }
 
+extern "C" int64_t iso_project_siren_counts_offset(int64_t n, int hidden, int n_hidden) {
+  if (n < 0) n = 0;
+  return stash_floats_any(hidden, n_hidden) * 4 + 2 * n * 4 + tail_ints(n) * 4;
+}
+
 static bool siren_small_tiles_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("ISO_SIREN_SMALL_TILES"); v = (e && e[0] == '0') ? 0 : 1; }

@@ -136,7 +136,7 @@ def test_newton_tail_in_one_launch_equals_a_launch_per_iteration(dev, fitted, P,
         prm.requires_grad_(False)
     pts = _cloud(P, 3, dev).view(1, P, 3)
     proj = UniformProjection()
-    n_off = lib.iso_project_siren_workspace_bytes(P, 256, 3) - 64 * 4 - 64
+    n_off = lib.iso_project_siren_counts_offset(P, 256, 3)
 
     def run(k):
         lib.iso_siren_set_tail_from(k)
@@ -149,6 +149,7 @@ def test_newton_tail_in_one_launch_equals_a_launch_per_iteration(dev, fitted, P,
         return r, counts
 
     ref, c_ref = run(0)
+    assert 0 < c_ref[0] <= P and all(x >= y for x, y in zip(c_ref, c_ref[1:])), c_ref      # (the counters, not some other words)
     for k in [-1] + list(range(1, T + 1)):
         out, c = run(k)
         assert torch.equal(out.points, ref.points) and torch.equal(out.normals, ref.normals) and torch.equal(out.mask, ref.mask), k
