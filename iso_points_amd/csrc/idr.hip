@@ -698,6 +698,10 @@ static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint
     a.idx_in = nullptr; a.count_in = nullptr; a.idx_out = nullptr; a.count_out = nullptr;
     a.do_move = 0; a.eval_only = 1;
     a.fwd_only = grad_out ? 0 : 1;
+    if (x16 && idr_dynamic_tiles_enabled()) {            // one tile counter, zeroed ahead of the launch
+      hipLaunchKernelGGL(k_idr_zero, dim3(1), dim3(64), 0, st, counts + 64, 1);
+      a.tile_ctr = counts + 64;
+    }
     ISO_REQUIRE(run(a) == 0, ISO_ERR_UNSUPPORTED, "%s: unsupported hidden size", who);
   } else {
     if (pts_out != pts_in) (void)hipMemcpyAsync(pts_out, pts_in, (size_t)n * 12, hipMemcpyDeviceToDevice, st);

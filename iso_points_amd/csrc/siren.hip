@@ -536,6 +536,13 @@ extern "C" int iso_siren_sdf_grad(const float* pts, float* sdf_out, float* grad_
   a.packed = packed; a.stash = (float*)workspace; a.n = n; a.L = n_hidden;
   a.w0 = omega_first; a.wh = omega_hidden; a.tol = 0.f; a.do_move = 0; a.eval_only = 1;
   a.fwd_only = grad_out ? 0 : 1;       // value only: forward sweep only where the kernel has one
+  // a workspace of the projection's size (what the Python side allocates) has room for the two tile counters
+  if (hidden == 256 && !a.fwd_only && siren_dynamic_tiles_enabled() &&
+      workspace_bytes >= iso_project_siren_workspace_bytes(n, hidden, n_hidden)) {
+    int32_t* ctr = (int32_t*)((char*)workspace + iso_project_siren_counts_offset(n, hidden, n_hidden)) + 64;
+    hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, (hipStream_t)stream, ctr, 2);
+    a.tile_ctr = ctr;
+  }
   ISO_REQUIRE(run_step_split(a, hidden, n, (hipStream_t)stream) == 0, ISO_ERR_UNSUPPORTED,
               "iso_siren_sdf_grad: unsupported hidden size %d", hidden);
   ISO_CHECK_LAUNCH("iso_siren_sdf_grad");
