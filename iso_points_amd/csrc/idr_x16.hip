@@ -21,6 +21,12 @@
 #include <float.h>
 #include "idr_common.h"
 #include "iso_newton.h"
+// weight fragments requested TWO K-steps ahead here (three in the SIREN kernel): with two output tiles per wave a set is
+// 16 registers, and the fourth set was paid for in spills (124 -> 100 spilled VGPRs; 1 M evaluations 29.1 -> 28.4 ms;
+// one K-step ahead: 27.5-28.5, not steadier)
+#ifndef X3_KAD
+#define X3_KAD 2
+#endif
 #include "mfma_split.h"
 
 static_assert(kAP == 2, "idr_x16.hip is written for the two-part fp16 layout");
