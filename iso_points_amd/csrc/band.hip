@@ -27,7 +27,11 @@ namespace {
 
 constexpr int kRec = 13;             // floats per record on the wire
 constexpr int kHdr = 16;             // ints in front of a segment: [0..7] records per view, [8] records wanted (unclipped)
-constexpr int kChunkRows = 1024;     // rows per workgroup: 256 lanes x 4 consecutive rows
+#ifndef BAND_ROWS_PER_LANE
+#define BAND_ROWS_PER_LANE 2      // (4 / 2 / 1: count + scan + fill of a rank of 8 = 35.6 / 29.4 / 30.9 us -- the scan walks capacity / chunk entries)
+#endif
+constexpr int kRowsPerLane = BAND_ROWS_PER_LANE;
+constexpr int kChunkRows = 256 * kRowsPerLane;     // rows per workgroup: 256 lanes x kRowsPerLane consecutive rows
 constexpr int kMaxWorld = 64;
 
 struct BandGeo { int world, rank, n_views, ty; };
@@ -64,11 +68,11 @@ __global__ __launch_bounds__(256) void k_band_count(const float* __restrict__ nd
   if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const int64_t len = num[v], base = first[v];
-  const int64_t i0 = (int64_t)c * kChunkRows + threadIdx.x * 4;
+  const int64_t i0 = (int64_t)c * kChunkRows + threadIdx.x * kRowsPerLane;
   int local[8];                                     // (world <= 8 fast path; more destinations go straight to LDS)
 #pragma unroll
   for (int d = 0; d < 8; ++d) local[d] = 0;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < kRowsPerLane; ++k) {
     const int64_t i = i0 + k;
     if (i >= len) break;
     const int64_t p = base + i;
@@ -97,16 +101,25 @@ __global__ __launch_bounds__(1024) void k_band_scan(int32_t* __restrict__ chunk_
                                                     int32_t* __restrict__ flags) {
   __shared__ int s_cnt[kMaxWorld * 8];
   const int t = threadIdx.x;
-  if (t < world * n_views) {
-    const int d = t / n_views, v = t % n_views;
-    int run = 0;
-    for (int c = 0; c < n_chunks; ++c) {
-      int32_t* e = chunk_cnt + ((int64_t)v * n_chunks + c) * world + d;
-      const int x = *e;
-      *e = run;
-      run += x;
+  // a wave per (destination, view), 64 chunks per trip (a thread per pair walking the chunks one after the other was a
+  // chain of n_chunks dependent loads: 20 us of a rank's cycle)
+  {
+    const int lane = t & 63, n_waves = (int)blockDim.x >> 6;
+    for (int pair = t >> 6; pair < world * n_views; pair += n_waves) {
+      const int d = pair / n_views, v = pair % n_views;
+      int run = 0;
+      for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+        const int c = c0 + lane;
+        int32_t* e = chunk_cnt + ((int64_t)v * n_chunks + c) * world + d;
+        const int x = c < n_chunks ? *e : 0;
+        int inc = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        if (c < n_chunks) *e = run + inc - x;
+        run += __shfl(inc, 63);
+      }
+      if (lane == 0) s_cnt[d * 8 + v] = run;
     }
-    s_cnt[d * 8 + v] = run;
   }
   __syncthreads();
   if (t < world) {
@@ -141,9 +154,9 @@ __global__ __launch_bounds__(256) void k_band_fill(const float* __restrict__ ndc
   const int v = blockIdx.y, c = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t len = num[v], base = first[v];
-  const int64_t i0 = (int64_t)c * kChunkRows + threadIdx.x * 4;
-  unsigned long long m[4];
-  for (int k = 0; k < 4; ++k) {
+  const int64_t i0 = (int64_t)c * kChunkRows + threadIdx.x * kRowsPerLane;
+  unsigned long long m[kRowsPerLane];
+  for (int k = 0; k < kRowsPerLane; ++k) {
     const int64_t i = i0 + k;
     m[k] = 0ull;
     if (i < len) {
@@ -153,37 +166,62 @@ __global__ __launch_bounds__(256) void k_band_fill(const float* __restrict__ ndc
       if (vis_own) vis_own[p] = 0;
     }
   }
-  for (int d = 0; d < world; ++d) {
-    // rank of each of this thread's rows among the chunk's rows for destination d, in row order
-    int mine = 0;
+  // rank of each of this thread's rows among the chunk's rows for a destination, in row order: nine destinations per
+  // round -- three 10-bit counters to a word, three wave scans, ONE barrier (a scan and two barriers per destination
+  // were 21 us of a rank's cycle at world 8)
+  for (int d0 = 0; d0 < world; d0 += 9) {
+    unsigned mine[3], inc[3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) mine += (int)((m[k] >> d) & 1ull);
-    int inc = mine;
+    for (int j = 0; j < 3; ++j) {
+      mine[j] = 0u;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane == 63) s_w[w][d] = inc;
-    __syncthreads();
-    int before = inc - mine;
-    for (int ww = 0; ww < w; ++ww) before += s_w[ww][d];
-    int slot = seg_base[d * (n_views + 1) + v] + chunk_off[((int64_t)v * n_chunks + c) * world + d] + before;
-    float* seg = send + (int64_t)d * seg_floats + kHdr;
+      for (int q = 0; q < 3; ++q) {
+        const int d = d0 + 3 * j + q;
+        if (d < world) {
+          unsigned cnt = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (!((m[k] >> d) & 1ull)) continue;
-      if (slot < cap_pair) {
-        const int64_t p = base + i0 + k;
-        float* r = seg + (int64_t)slot * kRec;
-        r[0] = ndc[p * 3]; r[1] = ndc[p * 3 + 1]; r[2] = ndc[p * 3 + 2];
-        r[3] = ellipse[p * 3]; r[4] = ellipse[p * 3 + 1]; r[5] = ellipse[p * 3 + 2];
-        r[6] = radii[p * 2]; r[7] = radii[p * 2 + 1];
-        r[8] = scaler[p];
-        r[9] = feat[p * 3]; r[10] = feat[p * 3 + 1]; r[11] = feat[p * 3 + 2];
-        r[12] = __int_as_float((int)(gid_first[v] + i0 + k));
-        sent_row[(int64_t)d * cap_pair + slot] = (int32_t)p;
+          for (int k = 0; k < kRowsPerLane; ++k) cnt += (unsigned)((m[k] >> d) & 1ull);
+          mine[j] |= cnt << (10 * q);
+        }
       }
-      ++slot;
+      inc[j] = mine[j];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc[j], o); if (lane >= o) inc[j] += t; }
+      if (lane == 63) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) if (d0 + 3 * j + q < world) s_w[w][d0 + 3 * j + q] = (int)((inc[j] >> (10 * q)) & 1023u);
+      }
     }
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int d = d0 + 3 * j + q;
+        if (d >= world || ((mine[j] >> (10 * q)) & 1023u) == 0u) continue;
+        int before = (int)(((inc[j] - mine[j]) >> (10 * q)) & 1023u);
+        for (int ww = 0; ww < w; ++ww) before += s_w[ww][d];
+        int slot = seg_base[d * (n_views + 1) + v] + chunk_off[((int64_t)v * n_chunks + c) * world + d] + before;
+        float* seg = send + (int64_t)d * seg_floats + kHdr;
+#pragma unroll
+        for (int k = 0; k < kRowsPerLane; ++k) {
+          if (!((m[k] >> d) & 1ull)) continue;
+          if (slot < cap_pair) {
+            const int64_t p = base + i0 + k;
+            float* r = seg + (int64_t)slot * kRec;
+            r[0] = ndc[p * 3]; r[1] = ndc[p * 3 + 1]; r[2] = ndc[p * 3 + 2];
+            r[3] = ellipse[p * 3]; r[4] = ellipse[p * 3 + 1]; r[5] = ellipse[p * 3 + 2];
+            r[6] = radii[p * 2]; r[7] = radii[p * 2 + 1];
+            r[8] = scaler[p];
+            r[9] = feat[p * 3]; r[10] = feat[p * 3 + 1]; r[11] = feat[p * 3 + 2];
+            r[12] = __int_as_float((int)(gid_first[v] + i0 + k));
+            sent_row[(int64_t)d * cap_pair + slot] = (int32_t)p;
+          }
+          ++slot;
+        }
+      }
+    }
+    if (d0 + 9 < world) __syncthreads();                  // (s_w is written again in the next round)
   }
 }
 
