@@ -231,17 +231,23 @@ __global__ void k_band_layout(const float* __restrict__ recv, int world, int n_v
                               int64_t cap_local, int64_t* __restrict__ first_l, int64_t* __restrict__ num_l,
                               int32_t* __restrict__ place /*[world][n_views][2]: local row, slot of the first record*/,
                               int32_t* __restrict__ flags) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // the nine header words of every segment at once (one thread reading them as it went was a chain of dependent loads)
+  __shared__ int s_hdr[kMaxWorld][9];
+  if (blockIdx.x != 0) return;
+  for (int i = threadIdx.x; i < world * 9; i += blockDim.x)
+    s_hdr[i / 9][i % 9] = reinterpret_cast<const int32_t*>(recv + (int64_t)(i / 9) * seg_floats)[i % 9];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   int64_t run = 0;
   int over = 0;
   for (int s = 0; s < world; ++s) {
-    const int32_t* hdr = reinterpret_cast<const int32_t*>(recv + (int64_t)s * seg_floats);
+    const int* hdr = s_hdr[s];
     if (hdr[8] > cap_pair) over = 1;                    // the sender clipped this segment (it flagged it too)
   }
   for (int v = 0; v < n_views; ++v) {
     first_l[v] = run;
     for (int s = 0; s < world; ++s) {
-      const int32_t* hdr = reinterpret_cast<const int32_t*>(recv + (int64_t)s * seg_floats);
+      const int* hdr = s_hdr[s];
       int slot0 = 0;
       for (int vv = 0; vv < v; ++vv) slot0 += hdr[vv];
       int64_t c = hdr[v];
