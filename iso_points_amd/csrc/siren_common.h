@@ -43,6 +43,7 @@ struct SirenArgs {
   // k_siren_step_x3_both: two counters (96-point tiles, 32-point tiles), ZERO when the launch starts; null: static tile
   // assignment.  A workgroup draws its next tile from them (x3_step_body) instead of taking every nblk-th.
   int32_t* tile_ctr = nullptr;
+  int draw_first = 0;        // 1: the first tile of a workgroup comes from the counter too (no tile is anyone's by index)
   int ps_guard = 0;          // 1: this launch follows one of k_siren_step_ps on the same list and only works where that one declines
 };
 

@@ -358,6 +358,7 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
   // load issued before that barrier; and the closing barrier is gone -- waves 2..7 start layer 0 of the next tile
   // while waves 0-1 finish the epilogue (no LDS hazard: `red` is next written after three more barriers, `ptl` by
   // wave 0 itself, the activation regions were last read before the barrier that ends reverse stage 0's GEMM).
+  __shared__ int s_next_tile, s_first_tile;
   int nidx[NB];
   float npx[NB], npy[NB], npz[NB];
   auto fetch_idx = [&](int64_t t) {                      // list entries of tile t (-1: beyond the list)
@@ -380,16 +381,22 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
       }
     }
   };
-  if constexpr (X3_TILE_PIPE) { fetch_idx(bid); fetch_pts(); }
+  int64_t first_tile = bid;
+  if (!FWD && X3_TILE_PIPE && a.tile_ctr != nullptr && a.draw_first) {       // (uniform) the first tile is drawn as well
+    if (tid == 0) s_first_tile = atomicAdd(a.tile_ctr, 1);
+    __syncthreads();
+    first_tile = s_first_tile;
+  }
+  if constexpr (X3_TILE_PIPE) { fetch_idx(first_tile); fetch_pts(); }
   // Which tile comes next.  Static: bid + k nblk -- every CU takes the same number of tiles, and the launch ends with the
   // slowest XCD (under the power cap the eight XCDs of one MI355X ran this kernel 6.8 % apart, tools/diag/x3_end_times.py).
   // Dynamic (a.tile_ctr, reverse kernels): thread 0 draws the next tile from a counter (zero when the launch starts) while
   // stage 0's GEMM runs and hands it to the workgroup through LDS at the barrier that ends that GEMM.  A point's result
   // does not depend on the tile it sits in or on the workgroup that takes the tile.
-  __shared__ int s_next_tile;
   const bool dyn = !FWD && X3_TILE_PIPE && a.tile_ctr != nullptr;
+  const int draw_base = a.draw_first ? 0 : nblk;
   int64_t next_tile = 0;
-  for (int64_t tile = bid; tile < n_tiles; tile = next_tile) {
+  for (int64_t tile = first_tile; tile < n_tiles; tile = next_tile) {
 #ifdef X3_DBG_TIMES
     const bool dbg_on = bid == 0 && tile == (int64_t)nblk;
     int dbg_i = 0;
@@ -660,7 +667,7 @@ __device__ __forceinline__ void x3_step_body(const SirenArgs& a, const int bid, 
     // (three FMAs; the same expression on the same operands as in the forward sweep) instead of being stashed
     if constexpr (!FWD) {
       int drawn = 0;
-      if (dyn && tid == 0) drawn = nblk + atomicAdd(a.tile_ctr, 1);
+      if (dyn && tid == 0) drawn = draw_base + atomicAdd(a.tile_ctr, 1);
       gemm_x3<TW, NB, NTO, NS, kZero, IL, BP, FP>(rev_img(0), nullptr, act + lane, acc, w, 0, A, fwd_img(0), 0, lane);
       if (dyn && tid == 0) s_next_tile = drawn;
       X3_STAMP();
@@ -811,6 +818,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3(SirenArgs a) {
 // behind the first group's).  The dispatcher places workgroups in index order, one per CU, so the small tiles start
 // on the CUs that finish their large ones first; a launch that finds nothing to do for one of the shapes costs nothing
 // (issued separately, the idle one of the two launches took ~4.4 us, 15 times per headline cycle).
+#ifndef X3_BIG_TAKES_SMALL
+#define X3_BIG_TAKES_SMALL 1
+#endif
 template <int H, int NW, int NB, int MINB>
 __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3_both(SirenArgs a) {
 #ifdef X3_DBG_END
@@ -822,17 +832,30 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_siren_step_x3_both(SirenArgs 
       x3_end[blockIdx.x * 3] = t0; x3_end[blockIdx.x * 3 + 1] = wall_clock64(); x3_end[blockIdx.x * 3 + 2] = xcc;
     } } } stamp{t0};
 #endif
-  if ((int)blockIdx.x < a.big_blocks) {
+  const bool big = (int)blockIdx.x < a.big_blocks;
+  const int small_blocks = (int)gridDim.x - a.big_blocks;
+  if (big) {
     SirenArgs b = a;
     b.split = 1;
     x3_step_body<H, NW, NB, false>(b, (int)blockIdx.x, a.big_blocks, (int)blockIdx.x);
-  } else {
+  }
+  // Drawn tiles (a.tile_ctr): a workgroup of the large shape that finds no large tile left goes on with the small ones
+  // (its own stash region, participant small_blocks + blockIdx of small_blocks + big_blocks) -- the large workgroups end
+  // within one tile time (68 us) of each other, and the small tiles are what the early ones fill that time with
+  // (headline cycle 13.33-13.38 -> 13.22-13.25 ms; with half a round to one and a half rounds of the large tiles' points
+  // handed to the small ones on top: 13.26-13.28).
+  if (!big || (X3_BIG_TAKES_SMALL && a.tile_ctr != nullptr)) {
+    if (big) __syncthreads();              // (the last large tile's epilogue reads LDS the other shape lays out differently)
     SirenArgs b = a;
     b.split = 2;
     if (a.tile_ctr) b.tile_ctr = a.tile_ctr + 1;
-    b.stash = a.stash + (int64_t)a.big_blocks * X3Shape<H, NW, NB>::kStashPerWg(a.L);
-    x3_step_body<H, NW, 1, false>(b, (int)blockIdx.x - a.big_blocks, (int)gridDim.x - a.big_blocks,
-                                  (int)blockIdx.x - a.big_blocks);
+    const bool joint = X3_BIG_TAKES_SMALL && a.tile_ctr != nullptr;
+    b.draw_first = joint ? 1 : 0;          // (a workgroup that joins late must not own a tile nobody else may take)
+    const int bid = big ? small_blocks + (int)blockIdx.x : (int)blockIdx.x - a.big_blocks;
+    const int nblk = joint ? small_blocks + a.big_blocks : small_blocks;
+    if (big) b.stash = a.stash + (int64_t)blockIdx.x * X3Shape<H, NW, NB>::kStashPerWg(a.L);
+    else b.stash = a.stash + (int64_t)a.big_blocks * X3Shape<H, NW, NB>::kStashPerWg(a.L);
+    x3_step_body<H, NW, 1, false>(b, bid, nblk, big ? 0 : bid);
   }
 }
 
