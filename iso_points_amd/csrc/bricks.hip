@@ -207,12 +207,27 @@ struct ChunkScanJob {
 };
 __device__ void chunk_scan_job(const ChunkScanJob& j);
 
+// imported halo records (N ranks): the LAST `blocks` workgroups of the count / scatter launch take them (launches of their
+// own were 8 + 6 us per grid at the size of a rank's share of eight); blocks == 0: none
+struct ImportJob { const float4* rec0; const float4* rec1; const int32_t* count; int64_t max; int blocks; };
+
 __global__ __launch_bounds__(256) void k_brick_count(const float* __restrict__ pts, int64_t n,
                                                      BrickHdr* __restrict__ hp, int32_t* __restrict__ cnt,
                                                      int32_t* __restrict__ slot, int pending, BrickParams q,
-                                                     int32_t* __restrict__ counters, ChunkScanJob job) {
+                                                     int32_t* __restrict__ counters, ChunkScanJob job, ImportJob imp) {
   __shared__ int t_key[kCntTab], t_cnt[kCntTab];
   __shared__ BrickHdr s_h;
+  if (imp.blocks && (int)blockIdx.x >= (int)gridDim.x - imp.blocks) {      // (only with a header that is already written)
+    const int bid = (int)blockIdx.x - ((int)gridDim.x - imp.blocks);
+    const BrickHdr h = *hp;
+    int64_t m = *imp.count;
+    if (m > imp.max) m = imp.max;
+    if (bid == 0 && threadIdx.x == 0) hp->n = h.n_own + (int)m;
+    for (int64_t base = (int64_t)bid * 1024; base < m; base += (int64_t)imp.blocks * 1024)
+      brick_count_round(h, base, m, cnt, slot + h.n_own, t_key, t_cnt,
+                        [&](int64_t j, int, float& x, float& y, float& z) { const float4 p = imp.rec0[j]; x = p.x; y = p.y; z = p.z; });
+    return;
+  }
   const bool scan_wg = job.chunk && blockIdx.x == 0;
   if (scan_wg && gridDim.x > 1) { chunk_scan_job(job); return; }        // (needs no header; another workgroup stores it)
   if (pending) {
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(256) void k_brick_count(const float* __restrict__ p
   }
   if (scan_wg) { chunk_scan_job(job); return; }
   const BrickHdr h = pending ? s_h : *hp;
-  const int n_wg = job.chunk ? gridDim.x - 1 : gridDim.x;
+  const int n_wg = (int)gridDim.x - imp.blocks - (job.chunk ? 1 : 0);
   // (the scan job, if any, is workgroup 0: it has the longest chain of dependent steps of the launch and starts first)
   for (int64_t base = (int64_t)(blockIdx.x - (job.chunk ? 1 : 0)) * 1024; base < n; base += (int64_t)n_wg * 1024)
     brick_count_round(h, base, n, cnt, slot, t_key, t_cnt,
@@ -252,9 +267,23 @@ __global__ __launch_bounds__(256) void k_brick_scatter(const float* __restrict__
                                                        const int32_t* __restrict__ payload, int64_t n,
                                                        const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off,
                                                        const int32_t* __restrict__ slot, float4* __restrict__ rec0,
-                                                       float4* __restrict__ rec1) {
+                                                       float4* __restrict__ rec1, ImportJob imp) {
   const BrickHdr h = *hp;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  if (imp.blocks && (int)blockIdx.x >= (int)gridDim.x - imp.blocks) {
+    const int bid = (int)blockIdx.x - ((int)gridDim.x - imp.blocks);
+    const int64_t m = h.n - h.n_own;
+    for (int64_t j = (int64_t)bid * blockDim.x + threadIdx.x; j < m; j += (int64_t)imp.blocks * blockDim.x) {
+      const float4 p = imp.rec0[j];
+      const int64_t dst = (int64_t)off[counter_of(h, p.x, p.y, p.z)] + slot[h.n_own + j];
+      rec0[dst] = p;
+      float4 u = imp.rec1[j];                              // an exported record carries the raw normal
+      bk_unit_normal(u.x, u.y, u.z);
+      rec1[dst] = u;
+    }
+    return;
+  }
+  const int n_wg = (int)gridDim.x - imp.blocks;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)n_wg * blockDim.x) {
     const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
     const int64_t dst = (int64_t)off[counter_of(h, x, y, z)] + slot[i];            // slot: rank inside the counter (k_brick_count)
     rec0[dst] = make_float4(x, y, z, __int_as_float(h.id_base + (int)i));
@@ -1764,10 +1793,18 @@ static int bricks_fill(const BrickWs& w, const float* points, const float* norma
                        const float* import_rec0, const float* import_rec1, const int32_t* import_count,
                        int64_t import_max, hipStream_t s, bool pending = false, BrickParams q = BrickParams{0, 0, 0, 0.f, 0, 0.f, 0},
                        ChunkScanJob job = ChunkScanJob{nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, nullptr}) {
+  // imported records ride in the launches of the own points when the header is there already (the N-rank path: it is
+  // written before the halo exchange)
+  const bool ride = import_max > 0 && n_own > 0 && !pending && !job.chunk;
+  const ImportJob none{nullptr, nullptr, nullptr, 0, 0};
+  const ImportJob imp_c{(const float4*)import_rec0, (const float4*)import_rec1, import_count, import_max,
+                        ride ? iso_stream_grid(import_max, 1024) : 0};
+  const ImportJob imp_s{(const float4*)import_rec0, (const float4*)import_rec1, import_count, import_max,
+                        ride ? iso_stream_grid(import_max, 256) : 0};
   if (n_own > 0 || pending || job.chunk)        // (a pending header is written by this pass, whatever the cloud holds)
-    hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 1024) + (job.chunk ? 1 : 0)), dim3(256), 0, s, points, n_own,
-                       w.hdr, w.cnt, w.slot, pending ? 1 : 0, q, w.counters, job);
-  if (import_max > 0)
+    hipLaunchKernelGGL(k_brick_count, dim3(iso_stream_grid(n_own, 1024) + (job.chunk ? 1 : 0) + imp_c.blocks), dim3(256), 0, s,
+                       points, n_own, w.hdr, w.cnt, w.slot, pending ? 1 : 0, q, w.counters, job, ride ? imp_c : none);
+  if (import_max > 0 && !ride)
     hipLaunchKernelGGL(k_brick_count_recs, dim3(iso_stream_grid(import_max, 1024)), dim3(256), 0, s,
                        (const float4*)import_rec0, import_count, import_max, w.hdr, w.cnt, w.slot);
   const int chunks = (int)(((w.G - 1) / BK_CPB + 1 + BS_CHUNK - 1) / BS_CHUNK);      // chunks of BS_CHUNK bricks (+ the sentinel)
@@ -1782,9 +1819,9 @@ static int bricks_fill(const BrickWs& w, const float* points, const float* norma
                        w.counters);
   }
   if (n_own > 0)
-    hipLaunchKernelGGL(k_brick_scatter, dim3(iso_stream_grid(n_own, 256)), dim3(256), 0, s, points, normals, payload,
-                       n_own, w.hdr, w.off, w.slot, w.rec0, w.rec1);
-  if (import_max > 0)
+    hipLaunchKernelGGL(k_brick_scatter, dim3(iso_stream_grid(n_own, 256) + imp_s.blocks), dim3(256), 0, s, points, normals, payload,
+                       n_own, w.hdr, w.off, w.slot, w.rec0, w.rec1, ride ? imp_s : none);
+  if (import_max > 0 && !ride)
     hipLaunchKernelGGL(k_brick_scatter_recs, dim3(iso_stream_grid(import_max, 256)), dim3(256), 0, s,
                        (const float4*)import_rec0, (const float4*)import_rec1, w.hdr, w.off, w.slot, w.rec0, w.rec1);
   return ISO_OK;
