@@ -107,6 +107,11 @@ int iso_siren_get_gemm_mode(void);
  * hundred points or none.  -1: the default (4 for max_iters >= 6, else 2), 0: never (a launch per iteration), k >= 1.
  * Results do not depend on it (a point's evaluation does not depend on the tile it sits in).              */
 int iso_siren_set_tail_from(int first_tail_iteration);
+/* Which tile a workgroup of the step kernels takes next: drawn from a per-launch counter (1, the default: the XCDs of one
+ * GPU do not run alike under the power cap, equal static shares end with the slowest) or every gridDim-th (0).  -1: back to
+ * the environment (ISO_SIREN_DYN_TILES / ISO_IDR_DYN_TILES = 0) or the default.  Results do not depend on it. */
+int iso_siren_set_drawn_tiles(int on);
+int iso_idr_set_drawn_tiles(int on);
 /* step-kernel launches one iso_project_siren call with these arguments issues (max_iters + 1 without the tail) */
 int iso_siren_step_launches(int hidden, int n_hidden, int max_iters);
 /* scratch for the per-wave activation-derivative stash */

@@ -31,6 +31,8 @@ SIGNATURES = {
     "iso_siren_set_gemm_mode": (_I, [_I]),
     "iso_siren_get_gemm_mode": (_I, []),
     "iso_siren_set_tail_from": (_I, [_I]),
+    "iso_siren_set_drawn_tiles": (_I, [_I]),
+    "iso_idr_set_drawn_tiles": (_I, [_I]),
     "iso_siren_step_launches": (_I, [_I, _I, _I]),
     "iso_siren_pack_weights": (_I, [_P, _P, _I, _I, _P]),
     "iso_project_siren_workspace_bytes": (_L, [_L, _I, _I]),

@@ -661,10 +661,15 @@ extern "C" int64_t iso_project_idr_workspace_bytes(int64_t n, int hidden, int n_
 
 struct IdrTrace { const float* dirs; float alpha, bound; };
 
-static bool idr_dynamic_tiles_enabled() {        // ISO_IDR_DYN_TILES=0: every gridDim-th tile (A/B)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ISO_IDR_DYN_TILES"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
+static int g_idr_dyn_tiles = -1;                 // -1: from ISO_IDR_DYN_TILES (default on), 0 / 1: iso_idr_set_drawn_tiles
+static bool idr_dynamic_tiles_enabled() {        // off: every gridDim-th tile (A/B, tests)
+  if (g_idr_dyn_tiles < 0) { const char* e = getenv("ISO_IDR_DYN_TILES"); g_idr_dyn_tiles = (e && e[0] == '0') ? 0 : 1; }
+  return g_idr_dyn_tiles == 1;
+}
+extern "C" int iso_idr_set_drawn_tiles(int on) {
+  ISO_REQUIRE(on >= -1 && on <= 1, ISO_ERR_INVALID, "iso_idr_set_drawn_tiles: -1 (environment / default), 0 or 1");
+  g_idr_dyn_tiles = on;
+  return ISO_OK;
 }
 
 static int idr_run(const float* pts_in, float* pts_out, float* normals_out, uint8_t* mask_out,

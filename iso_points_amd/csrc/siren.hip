@@ -356,10 +356,15 @@ static bool siren_small_tiles_enabled() {
   return v == 1;
 }
 
-static bool siren_dynamic_tiles_enabled() {     // ISO_SIREN_DYN_TILES=0: static tile assignment (A/B)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ISO_SIREN_DYN_TILES"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
+static int g_siren_dyn_tiles = -1;              // -1: from ISO_SIREN_DYN_TILES (default on), 0 / 1: iso_siren_set_drawn_tiles
+static bool siren_dynamic_tiles_enabled() {     // off: static tile assignment (A/B, tests)
+  if (g_siren_dyn_tiles < 0) { const char* e = getenv("ISO_SIREN_DYN_TILES"); g_siren_dyn_tiles = (e && e[0] == '0') ? 0 : 1; }
+  return g_siren_dyn_tiles == 1;
+}
+extern "C" int iso_siren_set_drawn_tiles(int on) {
+  ISO_REQUIRE(on >= -1 && on <= 1, ISO_ERR_INVALID, "iso_siren_set_drawn_tiles: -1 (environment / default), 0 or 1");
+  g_siren_dyn_tiles = on;
+  return ISO_OK;
 }
 
 static bool siren_merged_shapes_enabled() {      // ISO_SIREN_MERGED=0: the two tile shapes as two launches (A/B)

@@ -68,3 +68,62 @@ def test_forward_issued_before_the_host_read_equals_the_exact_path_and_survives_
     fr, _ = ss.forward(x, small.clone(), cameras=(views, projs))
     (fr.occupancy.sum() + fr.zbuf[..., 0].sum()).backward()
     assert x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("K", [8, 5])
+@pytest.mark.parametrize("case", ["pile", "wide", "pile_wide"])
+def test_raster_piles_deeper_than_the_hit_list(dev, K, case):
+    """k_raster's candidate-parallel path: the first 32 hits of a pixel per 256-candidate chunk go to its byte list, the
+    others to the pixel's 256-bit mask; up to 32 candidates per chunk with boxes over 96 pixels go to the wide table, the
+    ones beyond it are walked like the others.  Scenes that overflow each of them, bit for bit against the oracle
+    (K = 8: the compile-time-K kernel; K = 5: the runtime-K one)."""
+    from oracle import splat_oracle as SO
+    from iso_points_amd.rasterizer import _C
+    from splat_util import random_splats
+    S = 48
+    sc = random_splats(5000, N=2, seed=11 + K)
+    if "pile" in case:
+        sc["ndc"][:, :2] *= 0.08                       # everything on a patch of ~4 x 4 pixels: hundreds of hits per pixel and chunk
+    if "wide" in case:
+        sc["ellipse"] = (sc["ellipse"] / 36.0).contiguous()      # six times the extent: boxes of 10 - 30 pixels
+        sc["radii"] = (sc["radii"] * 6.0).contiguous()
+    ref = SO.splat_forward(sc["ndc"], sc["ellipse"], sc["cutoff"], sc["radii"], sc["first"], sc["num"], 0.08, S, K, bbox_or=True)
+    got = _C.splat_points(sc["ndc"].to(dev), sc["ellipse"].to(dev), sc["cutoff"].to(dev), sc["radii"].to(dev),
+                          sc["first"].to(dev), sc["num"].to(dev), 0.08, S, K, 0, 0)
+    for g, r, nm in zip(got, ref, ("idx", "zbuf", "qvalue", "occupancy")):
+        assert torch.equal(g.cpu(), r), "%s differs (%d entries)" % (nm, (g.cpu() != r).sum().item())
+    hit = (ref[0][..., 0] >= 0).float().mean().item()
+    assert hit > (0.002 if case == "pile" else 0.05), hit           # (the scene does land on the image)
+
+
+def test_drawn_tiles_equal_static_shares(dev):
+    """The step kernels' workgroups draw their next tile from a counter (siren_x3.hip / idr_x16.hip); a point's result
+    does not depend on the tile it sits in or on the workgroup that takes it: projections and evaluations are
+    bit-identical with every gridDim-th tile (iso_*_set_drawn_tiles(0)), for sizes around the tile shapes' rounds."""
+    from iso_points_amd import _lib
+    from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
+    from iso_points_amd.sdf_models import Siren, siren_sdf_and_grad, idr_sdf_and_grad
+    from oracle import iso_oracle as O
+    lib = _lib.load()
+    torch.manual_seed(3)
+    siren = Siren(hidden_size=256, n_layers=3).to(dev)
+    idr = O.IdrSDF(hidden_size=256, n_layers=4, skip_in=(2,), num_frequencies=4).to(dev)
+    for prm in list(siren.parameters()) + list(idr.parameters()):
+        prm.requires_grad_(False)
+    proj = UniformProjection()
+    for P in (20000, 24576 + 96, 70001):
+        pts = (sphere_cloud(P, seed=P) * 0.9).to(dev)
+        outs = []
+        for on in (1, 0):
+            assert lib.iso_siren_set_drawn_tiles(on) == 0 and lib.iso_idr_set_drawn_tiles(on) == 0
+            try:
+                r = proj._project_points(siren, pts, full_lengths(pts), proj_max_iters=6)
+                s, g = siren_sdf_and_grad(siren, pts[0])
+                ri = proj._project_points(idr, pts, full_lengths(pts), proj_max_iters=3)
+                si, gi = idr_sdf_and_grad(idr, pts[0])
+                torch.cuda.synchronize()
+            finally:
+                lib.iso_siren_set_drawn_tiles(-1); lib.iso_idr_set_drawn_tiles(-1)
+            outs.append((r.points, r.normals, r.mask, s, g, ri.points, ri.mask, si, gi))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), P
