@@ -1548,7 +1548,10 @@ constexpr float kHSat = 0.02f;
 #ifndef BK_TAIL_WAVES
 #define BK_TAIL_WAVES 4
 #endif
-constexpr int kTailWaves = BK_TAIL_WAVES;      // (<= 9: the pooled selection runs in one wave)
+// (kTailWaves <= 9: the pooled selection runs in one wave.  Eight waves instead of four: a rank's share of eight 51 -> 40 us,
+// the 1 M-point cycle 72-75 -> 83-86 -- the launcher takes eight for clouds below kTailWideBelow points.)
+constexpr int64_t kTailWideBelow = 300000;
+template <int kTailWaves>
 __global__ __launch_bounds__(64 * kTailWaves) void k_brick_h_tail(
     const BrickHdr* __restrict__ hp, const int32_t* __restrict__ off, const float4* __restrict__ rec0,
     const float4* __restrict__ rec1, const float* __restrict__ pts, const int32_t* __restrict__ mask,
@@ -2071,7 +2074,11 @@ extern "C" int iso_splat_h_fused(void* workspace, int64_t n_max, const float* po
   else if (n_views <= 4) ISO_H(4);
   else ISO_H(8);
 #undef ISO_H
-  hipLaunchKernelGGL(k_brick_h_tail, dim3(4096), dim3(64 * kTailWaves), 0, s, w.hdr, w.off, w.rec0, w.rec1, points, mask, view_total,
+  if (n_own < kTailWideBelow)
+    hipLaunchKernelGGL((k_brick_h_tail<2 * BK_TAIL_WAVES>), dim3(4096), dim3(64 * 2 * BK_TAIL_WAVES), 0, s, w.hdr, w.off, w.rec0, w.rec1, points, mask, view_total,
+                     n_views, h_out, w.tail, w.counters);
+  else
+    hipLaunchKernelGGL((k_brick_h_tail<BK_TAIL_WAVES>), dim3(4096), dim3(64 * BK_TAIL_WAVES), 0, s, w.hdr, w.off, w.rec0, w.rec1, points, mask, view_total,
                      n_views, h_out, w.tail, w.counters);
   ISO_CHECK_LAUNCH("iso_splat_h_fused");
   return ISO_OK;
