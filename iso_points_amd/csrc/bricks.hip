@@ -592,7 +592,12 @@ __device__ int stage_brick(BrickStage<WITH_NRM, SUB, CAP>& S, const BrickHdr& h,
   BK_PH(6);
   for (int c = tid; c < NCELL; c += BK_THREADS) S.ccur[c] = 0;
   if (tid < kStageRuns) {
-    const int xs = tid / 12, ys = (tid / 3) % 4, dz = tid % 3 - 1;
+    // (rt: the thread index behind an opaque move -- the run's offsets below depend on the thread only, so the compiler
+    // hoists them out of the caller's brick loop and then SPILLS them across it: five scratch registers in
+    // k_brick_resample, eight in k_brick_h, reloaded once per brick; recomputing 48 lanes' worth per brick is free)
+    int rt = tid;
+    asm volatile("" : "+v"(rt));
+    const int xs = rt / 12, ys = (rt / 3) % 4, dz = rt % 3 - 1;
     const int x = g.bx + (xs + 1) / 2 - 1, sx = xs == 0 ? 1 : (xs == 3 ? 0 : xs - 1);      // xs 0..3 -> (dx, sub x) = (-1,1) (0,0) (0,1) (+1,0)
     const int y = g.by + (ys + 1) / 2 - 1, sy = ys == 0 ? 1 : (ys == 3 ? 0 : ys - 1);
     const int z = g.bz + dz;
@@ -718,9 +723,11 @@ __device__ int stage_brick(BrickStage<WITH_NRM, SUB, CAP>& S, const BrickHdr& h,
   constexpr int NQ = St::NQRUN, QA = 4 * SUB;        // the brick's own (sub-)cells: QA x QA contiguous z-runs of QA
   int qlen = 0;
   if (tid < NQ) {
-    // (cstart is final since the scan; ccur is being advanced by the scatter above)
-    const int c = ((SUB + tid / QA) * NL + (SUB + tid % QA)) * NL + SUB;
-    S.qbeg[tid] = S.cstart[c];
+    // (cstart is final since the scan; ccur is being advanced by the scatter above; qt: opaque as rt above)
+    int qt = tid;
+    asm volatile("" : "+v"(qt));
+    const int c = ((SUB + qt / QA) * NL + (SUB + qt % QA)) * NL + SUB;
+    S.qbeg[qt] = S.cstart[c];
     qlen = S.cstart[c + QA] - S.cstart[c];
   }
   if (tid < 64) {                                    // exclusive prefix of the run lengths (NQ <= 64: one wave)

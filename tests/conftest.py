@@ -18,3 +18,14 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["split16", "f32"])
+def gemm_mode(request):
+    """Both ways of forming the hidden-layer products (include/isopoints.h: iso_siren_set_gemm_mode)."""
+    from iso_points_amd import _lib
+    lib = _lib.load()
+    before = lib.iso_siren_get_gemm_mode()
+    _lib.call("iso_siren_set_gemm_mode", 1 if request.param == "split16" else 0)
+    yield request.param
+    _lib.call("iso_siren_set_gemm_mode", before)

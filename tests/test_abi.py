@@ -56,10 +56,7 @@ def test_product_refuses_cpu_tensors():
         frnn.frnn_grid_points(x, x, K=3, r=0.5)
 
 
-def test_no_vgpr_spills_in_the_raster_kernels():
-    """Code-object metadata of the built library (tools/spill_check.py): the candidate-parallel raster kernels of the cycle
-    (K <= 8) must not spill vector registers -- a build of k_raster<8, true> with two spilled VGPRs returned stale list
-    entries for pixels with depth ties (profiles/HISTORY.md, round 5)."""
+def _code_object_kernels():
     import importlib.util
     import shutil
     import pytest
@@ -71,6 +68,59 @@ def test_no_vgpr_spills_in_the_raster_kernels():
     spec.loader.exec_module(sc)
     ks = sc.kernels(_lib.LIB_PATH)
     assert len(ks) > 100, "code objects not found in the library"
-    raster = [k for k in ks if "8k_rasterILi4ELb1ELb" in k[0] or "8k_rasterILi8ELb1ELb" in k[0]]
-    assert len(raster) == 4, [k[0] for k in ks if "raster" in k[0]]
-    assert all(k[1] == 0 for k in raster), raster
+    return ks
+
+
+def test_no_private_memory_in_the_raster_kernels():
+    """Code-object metadata of the built library (tools/spill_check.py): the candidate-parallel raster kernels of the cycle
+    (K <= 8) and the merge kernels must use NO private (scratch) memory at all -- neither spilled registers nor a stack
+    object.  Round 5 met a build of k_raster<8, true> (merge folded in, the slice's own K-best list carried in registers
+    into the swap-chain insertion) that returned stale ids on depth ties; round 6 took it apart
+    (tools/probes/spill_kit, profiles/r06_spill_repro_*.txt): the same source WITHOUT the two spilled registers fails the
+    same way, every failing build keeps a PAIR of list entries in an 8-byte private-memory object that SROA could not
+    promote (a load through a phi of two pointers), every bit-stable build keeps the list entirely in registers or
+    entirely in memory.  So the guard is "no private segment", which covers both."""
+    ks = _code_object_kernels()
+    raster = [k for k in ks if "8k_rasterILi4ELb1ELb" in k[0] or "8k_rasterILi8ELb1ELb" in k[0]
+              or "14k_raster_mergeILi4E" in k[0] or "14k_raster_mergeILi8E" in k[0]]
+    assert len(raster) == 8, [k[0] for k in ks if "raster" in k[0]]
+    assert all(k[1] == 0 and k[3] == 0 for k in raster), raster
+
+
+# VGPR spills that are known and pinned by a repeat-stress test at full size (tests/test_round6_gpu.py); the number is the
+# ceiling a rebuild may not exceed without a look.  Everything else in the library must not spill.
+SPILL_ALLOWED = {
+    "20k_siren_step_x3_bothILi256ELi8ELi3ELi1E": (99, "test_siren_step_repeat_stress_1m"),
+    "15k_siren_step_x3ILi256ELi8ELi3ELi1ELb0E": (91, "test_siren_step_repeat_stress_1m"),
+    "14k_idr_step_x16ILi512ELi2ELb0E": (100, "test_idr_step_repeat_stress_1m"),
+    "14k_idr_step_x16ILi512ELi2ELb1E": (32, "test_idr_step_repeat_stress_1m"),
+    "14k_idr_step_x16ILi256ELi3ELb0E": (83, "test_idr_step_repeat_stress_1m"),
+    "14k_idr_step_x16ILi256ELi3ELb1E": (20, "test_idr_step_repeat_stress_1m"),
+    "10k_idr_stepILi8E": (1, "test_idr_step_repeat_stress_1m"),
+    "10k_idr_stepILi16E": (232, "test_idr_step_repeat_stress_1m"),
+    "10k_fps_gridILi16E": (922, "test_fps_repeat_stress_500k"),
+    "16k_brick_resampleILi16E": (32, "test_resample_k12_repeat_stress"),      # K + 1 in 10..13: not on the cycle
+    "9k_brick_hILi2E": (1, "test_bandwidth_two_views_repeat_stress"),         # two views: not on the cycle
+}
+
+
+def test_vgpr_spills_only_where_allowed_and_pinned():
+    """No kernel of the library spills vector registers except the allow-list above, and no allow-listed kernel spills more
+    than recorded; each entry names the -m gpu repeat-stress test that pins its results bit for bit at full size."""
+    ks = _code_object_kernels()
+    src = open(os.path.join(ROOT, "tests", "test_round6_gpu.py")).read()
+    seen = set()
+    for name, vg, sg, priv in ks:
+        if vg == 0:
+            continue
+        key = [k for k in SPILL_ALLOWED if k in name]
+        assert key, "kernel %s spills %d VGPRs (%d B/lane of scratch) and is not on the allow-list" % (name, vg, priv)
+        limit, test = SPILL_ALLOWED[key[0]]
+        assert vg <= limit, "%s: %d spilled VGPRs, recorded ceiling %d" % (name, vg, limit)
+        assert ("def %s(" % test) in src, test
+        seen.add(key[0])
+    # the cycle's own non-MFMA kernels, by name: zero
+    for pat in ("16k_brick_resampleILi10E", "9k_brick_hILi4E", "13k_splat_front", "16k_splat_backward", "22k_splat_backward_heavy",
+                "9k_bin_ldsILb", "11k_z_scatter", "13k_brick_count", "15k_brick_scatter", "16k_brick_offsets1"):
+        hit = [k for k in ks if pat in k[0]]
+        assert hit and all(k[1] == 0 for k in hit), (pat, hit)
