@@ -114,3 +114,158 @@ def test_bandwidth_two_views_repeat_stress(dev):
         h = splat_h_fused(grid, mask, cnt, n_views)
         return (h.clone(),)
     _assert_repeats(run, 10, "fused bandwidth, two views")
+
+
+# ---- the object the bench times, end to end -----------------------------------------------------------------------------
+def _cycle_case(dev, sdf, tol, P=20000, S=256, NV=2, K=8):
+    O = _O()
+    from util import fitted_siren
+    from iso_points_amd.cameras import look_at_view, perspective
+    from iso_points_amd.dist import IsoCycle, slab_order, sphere_silhouette
+    from iso_points_amd.rasterizer import PointsRasterizationSettings
+    from iso_points_amd.sdf_models import SphereSDF
+    if sdf == "sphere":
+        m_cpu, m_gpu = O.SphereSDF(), SphereSDF().to(dev)
+    else:
+        import copy
+        m_cpu = fitted_siren(O, 256, 3, seed=0, fit=200)
+        m_gpu = copy.deepcopy(m_cpu).to(dev)          # (graph capture: the weights must be on the device already)
+    pts0 = sphere_cloud(P, seed=41)
+    pts0 = pts0[:, slab_order(pts0[0], 1, local="cell")].contiguous()
+    views = torch.stack([look_at_view(3.0, 20.0, 360.0 / NV * i) for i in range(NV)]).to(dev)
+    projs = views @ perspective(30.0).to(dev)
+    rs = PointsRasterizationSettings(image_size=S, points_per_pixel=K, cutoff_threshold=1.0, depth_merging_threshold=0.05,
+                                     radii_backward_scaler=10, backface_culling=True, Vrk_isotropic=True, bin_size=None)
+    cyc = IsoCycle(m_gpu, pts0.to(dev), views, projs, raster_settings=rs, knn_k=8,
+                   target=sphere_silhouette(S, NV, 3.0, 30.0, dev))
+    cyc.proj.proj_tolerance = tol
+    return O, m_cpu, m_gpu, pts0, views, projs, rs, cyc
+
+
+def _snap(out):
+    r1, img, grad, frags, fr = out
+    tot = int(fr["num_points"].sum().item())
+    return {"points": r1.points.clone(), "normals": r1.normals.clone(), "mask": r1.mask.clone(), "img": img.clone(),
+            "grad": grad[:tot].clone(), "idx": frags.idx.clone(), "zbuf": frags.zbuf.clone(), "qvalue": frags.qvalue.clone(),
+            "occ": frags.occupancy.clone(), "ndc": fr["ndc"][:tot].clone(), "radii": fr["radii"][:tot].clone(),
+            "ellipse": fr["ellipse_params"][:tot].clone(), "cutoff": fr["cutoff_threshold"][:tot].clone(),
+            "scaler": fr["scaler"][:tot].clone(), "features": fr["features"][:tot].clone(),
+            "first": fr["first_idx"].clone(), "num": fr["num_points"].clone(), "tot": tot}
+
+
+def _same(a, b, what):
+    for k in a:
+        if k == "tot":
+            assert a[k] == b[k], what
+            continue
+        assert torch.equal(_bits(a[k]), _bits(b[k])), "%s: %s differs in %d entries" % (what, k, int((_bits(a[k]) != _bits(b[k])).sum()))
+
+
+@pytest.mark.parametrize("sdf,tol", [("sphere", 5e-5), ("siren", 5e-5), ("siren", 1e-30)])
+def test_iso_cycle_end_to_end(dev, sdf, tol):
+    """IsoCycle.step() -- the fused orchestration bench.py times (levelset_sampling.py:353-439 -> rasterizer.py:584-661 ->
+    renderer.py:36-82 -> rasterizer.py:784-973), eager and replayed from HIP graphs -- as ONE chain against
+      (1) itself replayed: every bit;
+      (2) the operator-API chain on the same inputs (_project_points -> resample -> SurfaceSplatting.forward -> composite ->
+          autograd backward with the cycle's loss gradient): every bit of the points, normals, masks, per-pixel lists,
+          depths, q-values, occupancy, the image's alpha and the gradients of the packed rows; rgb to 1e-6 (the API's
+          caller normalises the feature normals in torch, the fused front end in its own kernel);
+      (3) the ORACLE's chain: stages 1 + 2 from the same start (tol 1e-30: every point within 1e-5 at a fixed iteration
+          count, chained outliers attributed by cause -- none unexplained; the default tolerance: the stop-flip criterion
+          of tests/util.py), then the oracle's splat stages fed with the cycle's own rows, link by link: per-row set-up to
+          1e-5, lists bit-exact, compositing and row gradients to 1e-5."""
+    from oracle import splat_oracle as SO
+    from util import assert_projection_close, classify_chain_outliers, rel_err
+    from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
+    from iso_points_amd.rasterizer import SurfaceSplatting, composite
+    O, m_cpu, m_gpu, pts0, views, projs, rs, cyc = _cycle_case(dev, sdf, tol)
+    P, S, NV, K = pts0.shape[1], 256, 2, 8
+    A = _snap(cyc.step())
+    assert A["tot"] > P // 2 and A["occ"].sum() > 1000
+    # (1) the same cycle replayed from its captured graphs, twice
+    cyc.use_graphs = True
+    _same(A, _snap(cyc.step()), "graph replay")
+    _same(A, _snap(cyc.step()), "second graph replay")
+    # (2) the operator-API chain
+    g0 = pts0.to(dev)
+    proj = UniformProjection(proj_max_iters=10, proj_tolerance=tol, knn_k=8, sample_iters=1)
+    r0 = proj._project_points(m_gpu, g0, full_lengths(g0), proj_max_iters=10)
+    r1 = proj.resample(m_gpu, r0.points, r0.normals, full_lengths(g0), sample_iters=1)
+    for k, v in (("points", r1.points), ("normals", r1.normals), ("mask", r1.mask)):
+        assert torch.equal(_bits(v), _bits(A[k])), "operator chain: %s differ in %d entries" % (k, int((_bits(v) != _bits(A[k])).sum()))
+    x = r1.points[0].detach().clone().requires_grad_(True)
+    ss = SurfaceSplatting(cameras=(views, projs), raster_settings=rs)
+    frags, filt = ss.forward(x, r1.normals[0])
+    feat = 0.5 * (torch.nn.functional.normalize(filt["normals"], dim=-1) + 1.0)
+    img = composite(frags, filt["scaler"], feat)
+    for k, v in (("idx", frags.idx), ("zbuf", frags.zbuf), ("qvalue", frags.qvalue), ("occ", frags.occupancy), ("ndc", filt["ndc"]),
+                 ("radii", filt["radii"]), ("ellipse", filt["ellipse_params"]), ("scaler", filt["scaler"])):
+        assert torch.equal(_bits(v.detach()), _bits(A[k])), "operator chain: %s differs in %d entries" % (
+            k, int((_bits(v.detach()) != _bits(A[k])).sum()))
+    assert torch.equal(_bits(img[..., 3].detach().contiguous()), _bits(A["img"][..., 3].contiguous()))
+    assert rel_err(img[..., :3], A["img"][..., :3]) < 1e-6
+    # the cycle's loss gradient (dist.IsoCycle.cycle: c (alpha - target) and 1e-3 / #pixels on the front-most depth)
+    cgrad = cyc._loss_constants(A["img"][..., 3], A["zbuf"], 0, S)
+    grad_img = torch.zeros_like(img)
+    grad_img[..., 3] = torch.add(cgrad[0], A["img"][..., 3], alpha=cgrad[2])
+    filt["ndc"].retain_grad()
+    torch.autograd.backward([img, frags.zbuf], [grad_img, cgrad[1]])
+    assert torch.equal(_bits(filt["ndc"].grad), _bits(A["grad"])), "row gradients differ in %d entries, max %g" % (
+        int((_bits(filt["ndc"].grad) != _bits(A["grad"])).sum()), (filt["ndc"].grad - A["grad"]).abs().max().item())
+    assert torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0
+    # (3) the oracle's chain, stages 1 + 2
+    num = torch.tensor([P])
+    f0 = O.project_points(m_cpu, pts0, num, proj_max_iters=10, proj_tolerance=tol)
+    f1 = O.resample(m_cpu, f0.points, f0.normals, num, sample_iters=1, knn_k=8, proj_tolerance=tol)
+    if tol < 1e-20 or sdf == "sphere":
+        e0 = (r0.points.cpu().double() - f0.points.double()).abs().amax(-1) / f0.points.abs().max()
+        assert e0.max().item() <= 1e-5, "projection at a fixed iteration count: %d points beyond 1e-5 (max %g)" % (
+            int((e0 > 1e-5).sum()), e0.max().item())
+    else:
+        assert_projection_close(r0.points, f0.points)
+    e1 = ((A["points"].cpu().double() - f1.points.double()).abs().amax(-1) / f1.points.abs().max())[0]
+    assert e1.median().item() < 1e-6
+    gpu_sdf = None
+    if sdf == "siren":
+        from iso_points_amd.sdf_models import siren_sdf_and_grad
+        gpu_sdf = lambda xs: siren_sdf_and_grad(m_gpu, xs.to(dev))[0]
+    counts, left = classify_chain_outliers(O, m_cpu, pts0, r0.points, A["points"], tol=tol, gpu_sdf=gpu_sdf)
+    print("chained outliers (%s, tol %g): %s" % (sdf, tol, {k: v for k, v in counts.items() if k != "detail"}))
+    assert not left, (left, counts)
+    assert counts["outliers"] <= max(2, P // 500), counts
+    # ... and the splat stages, the oracle fed with what the cycle fed its own stages
+    pts_f, nrm_f = A["points"][0].cpu(), A["normals"][0].cpu()
+    Vs, Pm = views.cpu(), SO.perspective(30.0)
+    ndc, ell, cut, rad, sca, keep, nums = [], [], [], [], [], [], []
+    for v in range(NV):
+        m = SO.filter_renderable(pts_f, nrm_f, Vs[v])
+        keep.append(m)
+        nums.append(int(m.sum()))
+    assert nums == A["num"].tolist(), (nums, A["num"].tolist())
+    mx = max(nums)
+    padded = torch.zeros(NV, mx, 3)
+    for v in range(NV):
+        padded[v, :nums[v]] = pts_f[keep[v]]
+    h = SO.vrk_h(padded, torch.tensor(nums), 0.2)
+    s = 0
+    for v in range(NV):
+        M44 = Vs[v] @ Pm
+        info = SO.per_point_info(pts_f[keep[v]], nrm_f[keep[v]], h[s:s + nums[v]], M44, S)
+        s += nums[v]
+        ndc.append(SO.transform_to_ndc(pts_f[keep[v]], Vs[v], M44))
+        ell.append(info["ellipse_params"]); cut.append(info["cutoff_threshold"]); rad.append(info["radii"]); sca.append(info["scaler"])
+    for k, ref in (("ndc", torch.cat(ndc)), ("ellipse", torch.cat(ell)), ("radii", torch.cat(rad)), ("scaler", torch.cat(sca)),
+                   ("cutoff", torch.cat(cut))):
+        assert rel_err(A[k], ref) < 1e-5, (k, rel_err(A[k], ref))
+    first = A["first"].cpu()
+    numt = A["num"].cpu()
+    ref_f = SO.splat_forward(A["ndc"].cpu(), A["ellipse"].cpu(), A["cutoff"].cpu(), A["radii"].cpu(), first, numt, 0.05, S, K, bbox_or=True)
+    for k, r in zip(("idx", "zbuf", "qvalue", "occ"), ref_f):
+        assert torch.equal(A[k].cpu(), r), "oracle raster on the cycle's rows: %s differs in %d entries" % (k, int((A[k].cpu() != r).sum()))
+    from iso_points_amd.rasterizer import PointFragments
+    fr_cpu = PointFragments(ref_f[0], ref_f[1], ref_f[2], SO.gather_scaler(A["scaler"].cpu(), ref_f[0]), ref_f[3])
+    img_o = SO.composite(fr_cpu, A["features"].cpu())
+    assert rel_err(A["img"], img_o) < 1e-5
+    g_o, _, _ = SO.splat_backward(A["ndc"].cpu(), A["radii"].cpu(), ref_f[0], first, numt, grad_img[..., 3].cpu().contiguous(),
+                                  cgrad[1].cpu(), radii_s=10.0)
+    assert rel_err(A["grad"], g_o) < 1e-5, rel_err(A["grad"], g_o)

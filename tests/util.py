@@ -69,3 +69,154 @@ def fitted_siren(O, hidden, n_layers, seed=0, fit=0):
             O.fit_siren_to_sphere(m, steps=fit)
         _FIT_CACHE[key] = m
     return copy.deepcopy(_FIT_CACHE[key])
+
+
+# ---- where do the outliers of a CHAINED comparison come from? ---------------------------------------------------------
+def newton_trace(O, model, x0, T, tol):
+    """|sdf| at every evaluation of O.project_points' own Newton path (levelset_sampling.py:290-351: a point stops being
+    evaluated once |sdf| <= tol) -> (T + 1, P) float64, NaN where the point was no longer active."""
+    import torch.nn.functional as F
+    x = x0.reshape(-1, 3).clone()
+    P = x.shape[0]
+    rec = torch.full((T + 1, P), float("nan"), dtype=torch.float64)
+    active = torch.ones(P, dtype=torch.bool)
+    for it in range(T + 1):
+        if not active.any():
+            break
+        sdf, grad = O.compute_sdf_and_grad(x[active], model)
+        sdf = sdf.reshape(-1)
+        rec[it, active] = sdf.abs().double()
+        nc = sdf.abs() > tol
+        a2 = active.clone()
+        a2[active] = nc
+        if it == T:
+            break
+        g, s, p = grad[nc], sdf[nc], x[active][nc]
+        ssg = torch.sum(g ** 2, dim=-1, keepdim=True)
+        move = s.view(-1, 1) * (g / O.eps_denom(ssg, 1.0e-17))
+        move = F.normalize(move, dim=-1, eps=1e-15) * move.norm(dim=-1, keepdim=True).clamp_max(0.1)
+        active = a2
+        x[active] = p - move
+    return rec
+
+
+def classify_chain_outliers(O, model, pts, gpu_stage1, gpu_final, knn_k=8, tol=5e-5, eval_delta=None, out_tol=1e-5,
+                            gpu_sdf=None):
+    """The CHAINED comparison (the GPU resamples ITS OWN projection, the oracle its own) has more points beyond `out_tol`
+    than either stage has on identical inputs: a last-bit difference of stage 1 is amplified wherever a discrete decision
+    sits on the fence.  This attributes every outlier of the final positions to such a decision, from the oracle's side:
+
+      stop_flip_1      the point's own stage-1 Newton iteration has an evaluation with | |sdf| - tol | <= eval_delta (the
+                       two f32 evaluations of the network may fall on different sides: one move more or less)
+      neighbour_flip   its K-neighbour SET differs between the two stage-1 clouds, and the oracle's distances say why: the
+                       last neighbour in and the first one out (or the search radius) are closer than the two clouds'
+                       position differences can move them
+      moved_neighbour  one of its neighbours is itself a stage-1 outlier (a different repulsion)
+      stop_flip_3      its re-projection (T = 3) has an evaluation with |sdf| within eval_delta + the difference of the two
+                       repulsion results of the tolerance
+      chaotic_1 / _3   the ORACLE's own float32 iteration is not reproducible to out_tol at this point: started 2e-7
+                       (relative) away, its stage-1 / stage-3 result moves by more than out_tol (a rough fit has regions
+                       where Newton's map amplifies a last-bit difference a hundredfold: small gradients, clamped moves)
+    eval_delta: how far two float32 evaluations of the network may lie apart -- measured when `gpu_sdf` (points (P,3) on
+    the CPU -> the product's sdf (P,)) is given: 4 x the largest |sdf_product - sdf_oracle| over the start and the end
+    points; 2e-6 otherwise.  A point whose STAGE-1 result already differs must be explained at stage 1.
+    Returns (counts dict, indices left unexplained).  pts (1,P,3) CPU; gpu_stage1 / gpu_final: (1,P,3) positions."""
+    import torch.nn.functional as F
+    P = pts.shape[1]
+    num = torch.tensor([P])
+    g1 = gpu_stage1.detach().cpu().float().reshape(1, P, 3)
+    gf = gpu_final.detach().cpu().float().reshape(1, P, 3)
+    ref0 = O.project_points(model, pts, num, proj_max_iters=10, proj_tolerance=tol)
+    ref = O.resample(model, ref0.points, ref0.normals, num, sample_iters=1, knn_k=knn_k, proj_tolerance=tol)
+    scale = ref.points.abs().max().double()
+    e1 = ((g1.double() - ref0.points.double()).abs().amax(-1) / scale)[0]
+    ef = ((gf.double() - ref.points.double()).abs().amax(-1) / scale)[0]
+    bad = (ef > out_tol).nonzero().reshape(-1).tolist()
+    counts = {"outliers": len(bad), "stage1_outliers": int((e1 > out_tol).sum()), "stop_flip_1": 0, "chaotic_1": 0,
+              "neighbour_flip": 0, "moved_neighbour": 0, "stop_flip_3": 0, "chaotic_3": 0, "unexplained": 0}
+    if not bad:
+        return counts, []
+    if eval_delta is None:
+        eval_delta = 2e-6
+        if gpu_sdf is not None:
+            worst = 0.0
+            for xs in (pts[0], ref.points[0]):
+                so, _ = O.compute_sdf_and_grad(xs, model)
+                worst = max(worst, (gpu_sdf(xs).detach().cpu().reshape(-1).double() - so.reshape(-1).double()).abs().max().item())
+            eval_delta = max(4.0 * worst, 5e-7)
+    counts["eval_delta"] = eval_delta
+    tr1 = newton_trace(O, model, pts, 10, tol)
+    near1 = ((tr1 - tol).abs() <= eval_delta).any(dim=0)
+    # the two stage-1 clouds' neighbour sets, by the oracle's own search
+    r_o = O.search_radius(ref0.points, num, knn_k)
+    r_g = O.search_radius(g1, num, knn_k)
+    d_o, i_o, _, _ = O.frnn_grid_points(ref0.points, ref0.points, num, num, K=knn_k + 3, r=r_o)
+    _, i_g, _, _ = O.frnn_grid_points(g1, g1, num, num, K=knn_k + 1, r=r_g)
+    d_o, i_o, i_g = d_o[0], i_o[0], i_g[0]
+    dpos = (g1.double() - ref0.points.double()).norm(dim=-1)[0]                    # how far each point sits from its twin
+    r2 = float(r_o.reshape(-1)[0]) ** 2
+    # the oracle's repulsion from either stage-1 cloud (same neighbour rule): what stage 3 starts from
+    nrm_o = F.normalize(ref0.normals, dim=-1)
+    flat = ref0.points.view(-1, 3)
+    inv_sigma = num / (flat.max(dim=0).values - flat.min(0).values).norm().item()
+    moved_o = O.repulsion_step(ref0.points, nrm_o, i_o[None, :, 1:knn_k + 1], inv_sigma)
+    moved_g = O.repulsion_step(g1, nrm_o, i_g[None, :, 1:], inv_sigma)
+    dmoved = (moved_g.double() - moved_o.double()).norm(dim=-1)[0]
+    tr3 = newton_trace(O, model, moved_o, 3, tol)
+    # sensitivity of the oracle's own iteration: the same float32 code from a start 2e-7 (relative) away
+    gsign = torch.Generator().manual_seed(12345)
+    def nudged(x):
+        sgn = torch.randint(0, 2, x.shape, generator=gsign).float() * 2.0 - 1.0
+        return x + x.abs() * 2e-7 * sgn
+    chaotic1 = torch.zeros(P, dtype=torch.bool)
+    chaotic3 = torch.zeros(P, dtype=torch.bool)
+    for _ in range(4):                      # (a nudge has a direction: four of them; half of out_tol counts)
+        p1 = O.project_points(model, nudged(pts), num, proj_max_iters=10, proj_tolerance=tol)
+        chaotic1 |= ((p1.points.double() - ref0.points.double()).abs().amax(-1) / scale)[0] > 0.5 * out_tol
+        p3 = O.project_points(model, nudged(moved_o), num, proj_max_iters=3, proj_tolerance=tol)
+        chaotic3 |= ((p3.points.double() - ref.points.double()).abs().amax(-1) / scale)[0] > 0.5 * out_tol
+    left = []
+    for i in bad:
+        set_o = set(i_o[i, :knn_k + 1].tolist()) - {-1}
+        set_g = set(i_g[i].tolist()) - {-1}
+        members = (set_o | set_g) - {i}
+        if e1[i] > out_tol or chaotic1[i]:
+            if e1[i] > out_tol and near1[i]:
+                counts["stop_flip_1"] += 1
+            elif chaotic1[i]:
+                counts["chaotic_1"] += 1
+            else:                                    # its own stage 1 differs and nothing at stage 1 says why
+                counts["unexplained"] += 1
+                left.append(i)
+            continue
+        if set_o != set_g:
+            # the fence: last one in / first one out of the oracle's list (or the radius), against how far the points moved
+            dk, dk1 = float(d_o[i, knn_k]), float(d_o[i, knn_k + 1])
+            dk = r2 if dk < 0 else dk
+            dk1 = r2 if dk1 < 0 else dk1
+            reach = max(float(dpos[j]) for j in (set_o ^ set_g) | {i})
+            slack = 4.0 * (dk1 ** 0.5) * (float(dpos[i]) + reach) + 1e-6 * dk1
+            if abs(dk1 - dk) <= slack or abs(r2 - dk) <= slack or abs(r2 - dk1) <= slack:
+                counts["neighbour_flip"] += 1
+                continue
+        # (a neighbour that is itself a stage-1 outlier; or -- the repulsion sums eight neighbours -- several that moved
+        # by a good fraction of out_tol, when the oracle's own repulsion from the two clouds confirms the difference)
+        if any(e1[j] > out_tol for j in members) or \
+                (float(dmoved[i]) / float(scale) > 0.25 * out_tol and any(e1[j] > 0.1 * out_tol for j in members | {i})):
+            counts["moved_neighbour"] += 1
+            continue
+        if bool(((tr3[:, i] - tol).abs() <= eval_delta + 2.0 * float(dmoved[i])).any()):
+            counts["stop_flip_3"] += 1
+            continue
+        if chaotic3[i]:
+            counts["chaotic_3"] += 1
+            continue
+        counts["unexplained"] += 1
+        left.append(i)
+    for i in ((e1 > out_tol).nonzero().reshape(-1).tolist()):
+        if i not in bad and not (near1[i] or chaotic1[i]):
+            counts["unexplained"] += 1
+            left.append(i)
+    counts["detail"] = [(i, float(ef[i]), float(e1[i]), float(dmoved[i] / scale), max(float(e1[j]) for j in (set(i_o[i, :knn_k + 1].tolist()) | set(i_g[i].tolist())) - {-1}))
+                        for i in left[:8]]
+    return counts, left
