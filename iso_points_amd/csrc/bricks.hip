@@ -917,6 +917,23 @@ __device__ __forceinline__ bool pair_lt(float d1, int i1, float d2, int i2) {
   return d1 < d2 || (d1 == d2 && i1 < i2);
 }
 
+// Which brick of the list a workgroup takes.  Workgroup i of a launch runs on XCD i % 8 (tools/probes/simd_map.hip prints
+// it), and each XCD has its own L2: dealt out in list order, the eight neighbours of a brick -- whose records it stages,
+// and whose queries write into the same cache lines of the row-ordered outputs -- sit in eight different L2s.  With
+// BK_XCD_CHUNKS = 8 the list (x-major brick order: consecutive entries are neighbours along z, then y) is cut into eight
+// contiguous chunks and XCD k walks chunk k.
+#ifndef BK_XCD_CHUNKS
+#define BK_XCD_CHUNKS 8
+#endif
+__device__ __forceinline__ int bk_xcd_span(int n_list) {
+  return BK_XCD_CHUNKS <= 1 ? n_list : BK_XCD_CHUNKS * ((n_list + BK_XCD_CHUNKS - 1) / BK_XCD_CHUNKS);
+}
+__device__ __forceinline__ int bk_xcd_item(int lj, int n_list) {
+  if (BK_XCD_CHUNKS <= 1) return lj;
+  const int chunk = (n_list + BK_XCD_CHUNKS - 1) / BK_XCD_CHUNKS;
+  return (lj % BK_XCD_CHUNKS) * chunk + lj / BK_XCD_CHUNKS;
+}
+
 // ---- fused resample step -------------------------------------------------------------------------
 // K = knn_k + 1 (self included), M = list length (>= K + 1).
 template <int M>
@@ -930,7 +947,9 @@ __global__ __launch_bounds__(BK_THREADS, 4) void k_brick_resample(
   __shared__ int s_unc[BK_THREADS], s_nunc;
   const BrickHdr h = *hp;
   const int n_list = counters[0];
-  for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+  for (int lj = blockIdx.x; lj < bk_xcd_span(n_list); lj += gridDim.x) {
+    const int li = bk_xcd_item(lj, n_list);
+    if (li >= n_list) continue;
     const int b = list[li];
     BrickGeo g;
     if (threadIdx.x == 0) s_nunc = 0;                  // (stage_brick starts with a barrier)
@@ -1392,7 +1411,9 @@ __global__ __launch_bounds__(BK_THREADS, NV <= 4 ? BK_H_WGS : 4) void k_brick_h(
   // 0.5 d2 <= 5e-5 (the lower clamp of h) <=> d2 <= kT: seven such points settle h without their order
   const float kT = 2.0f * 5e-5f;
   const float t2 = fminf(kT, h.r2 > 0.f ? __uint_as_float(__float_as_uint(h.r2) - 1u) : 0.f);   // and d2 < r2
-  for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+  for (int lj = blockIdx.x; lj < bk_xcd_span(n_list); lj += gridDim.x) {
+    const int li = bk_xcd_item(lj, n_list);
+    if (li >= n_list) continue;
     const int b = list[li];
     BrickGeo g;
     constexpr int VS = NV <= 4 ? 8 : 1;                 // staged view masks: one byte per view when they fit a word
@@ -1780,7 +1801,7 @@ extern "C" int iso_bricks_workspace_check(const void* workspace, int64_t n_max, 
   ISO_REQUIRE(((uintptr_t)workspace & 255) == 0, ISO_ERR_INVALID, "iso_bricks_workspace_check: workspace must be 256-B aligned");
   const BrickWs w = bricks_carve(const_cast<void*>(workspace), n_max);
   // the counter block up to the pending box + the chunk totals of the one-launch scan (both at fixed offsets)
-  static int32_t host[kBoxAt + kScan1MaxWords];
+  int32_t host[kBoxAt + kScan1MaxWords];                  // per call (a static one raced between host threads: ADVICE r5)
   ISO_REQUIRE(hipMemcpyAsync(host, w.counters, 4 * kBoxAt, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
                   hipMemcpyAsync(host + kBoxAt, w.scan1, 4 * kScan1MaxWords, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
                   hipStreamSynchronize((hipStream_t)stream) == hipSuccess,

@@ -166,6 +166,7 @@ class UniformProjection(LevelSetProjection):
         self.sample_iters = sample_iters
         self.resampling_clip = resampling_clip  # stored, unused -- as in the reference (:108)
         self._packed_cache = None
+        self._pack_scope, self._pack_depth = 0, 0      # see _packing(): one weight image per operator call
         self._packed_for = None
         self.reuse_packed = False      # keep the packed weight image of the last call (the caller clears
                                        # _packed_cache whenever the weights may have changed)
@@ -215,6 +216,22 @@ class UniformProjection(LevelSetProjection):
             return torch.cat(evals, 0).view(shp[:-1]), torch.cat(grads, 0).view(shp)
 
     # -- projection --------------------------------------------------------------------
+    def _packing(self):
+        """with self._packing(): the projections issued inside share one packed weight image (nested uses join the outer
+        scope)."""
+        owner = self
+
+        class _Scope(object):
+            def __enter__(self_):
+                if owner._pack_depth == 0:
+                    owner._pack_scope += 1
+                owner._pack_depth += 1
+
+            def __exit__(self_, *exc):
+                owner._pack_depth -= 1
+                return False
+        return _Scope()
+
     def _project_packed(self, model, pts, proj_max_iters, proj_tolerance, follow=None, **forward_kwargs):
         """pts (n,3) f32 contiguous on the GPU -> points, normals, mask(bool).  follow: bricks.Follow -- side work of
         the launch for the next stages of the cycle (iso_follow); returns False in `follow.done` when this model's route
@@ -247,11 +264,15 @@ class UniformProjection(LevelSetProjection):
         if follow is not None:
             follow.done = False
         if siren_spec(model) is not None and not forward_kwargs:
-            # the packed weight image is re-used while the weights are the ones it was made from (storage + in-place
-            # version of every tensor: sdf_models.weights_key), or on the caller's word (reuse_packed)
+            # the packed weight image is re-used on the caller's word (reuse_packed), or INSIDE one call of an operator
+            # of this class (project_points / resample run several projections on weights that cannot change in between:
+            # _pack_scope); never across calls on the strength of (storage, version) alone -- in-place updates through
+            # `.data` (EMA copies, weight clipping) and raw-pointer writes bump neither
             pc = self._packed_cache
+            in_scope = self._pack_depth > 0 and getattr(pc, "_scope", None) == self._pack_scope
             ps = pc if (isinstance(pc, PackedSiren) and self._packed_for is model
-                        and (self.reuse_packed or pc.current(model, dev))) else PackedSiren(model, dev)
+                        and (self.reuse_packed or (in_scope and pc.current(model, dev)))) else PackedSiren(model, dev)
+            ps._scope = self._pack_scope if self._pack_depth > 0 else None
             self._packed_for = model
             ws = ps.workspace(n)
             _lib.call("iso_project_siren", p(pts), p(out), p(normals), p(mask), n, p(ps.packed),
@@ -423,6 +444,16 @@ class UniformProjection(LevelSetProjection):
         P = points_init.shape[1]
         fused = (points_init.is_cuda and self.knn_k + 1 <= 13 and host_lengths(num_points)[0] == P
                  and points_init.dtype == torch.float32)
+        scope = self._packing()
+        scope.__enter__()                    # (the projections of all sample iterations share one packed weight image)
+        try:
+            return self._resample_iterations(model, points_init, normals_init, num_points, sample_iters, fused,
+                                             **forward_kwargs)
+        finally:
+            scope.__exit__(None, None, None)
+
+    def _resample_iterations(self, model, points_init, normals_init, num_points, sample_iters, fused, **forward_kwargs):
+        points, projection_result, idx, inv_sigma, P = points_init, None, None, None, points_init.shape[1]
         for sample_iter in range(sample_iters):
             if sample_iter == 0 and fused:
                 # tree + repulsion in one kernel on the brick grid (csrc/bricks.hip); the neighbour lists are
@@ -473,12 +504,12 @@ class UniformProjection(LevelSetProjection):
             kept = _filter_projection_result(res)
             return kept, with_host_lengths(torch.tensor(n_true, dtype=torch.long, device=res.mask.device), n_true)
 
-        with torch.no_grad():
+        with torch.no_grad(), self._packing():
             res = self._project_points(model, cloud, lengths, proj_max_iters=proj_max_iters or self.proj_max_iters,
                                        **forward_kwargs)
             optimistic = None
             if (not skip_resampling and res.mask.is_cuda and res.mask.shape[0] == 1 and not _os.environ.get("ISO_OPAPI_SYNC")
-                    and host_lengths(lengths) == [int(res.mask.shape[1])]):
+                    and host_lengths(lengths) == [int(res.mask.shape[1])] and getattr(self, "_all_converged_last", False)):
                 # On a fitted network every point converges: the resampling is ISSUED on the whole result before the host
                 # knows the number of converged points (the count's kernel is in the queue, its read comes after the
                 # resampling has been queued, so the GPU does not wait for the host between the two stages).  A count that
@@ -490,6 +521,9 @@ class UniformProjection(LevelSetProjection):
                 both = torch.stack([c1, c2]).tolist()                   # ONE host read for both masks
                 res.mask._iso_true, res.mask._iso_true_version = [int(both[0][0])], res.mask._version
                 optimistic.mask._iso_true, optimistic.mask._iso_true_version = [int(both[1][0])], optimistic.mask._version
+            # (the optimistic order only after a call on this object that saw every point converge: on a partly fitted
+            # network it would resample -- and rebuild the grid on -- unconverged points every call for nothing: ADVICE r5)
+            self._all_converged_last = true_counts(res.mask) == host_lengths(lengths)
             if sum(true_counts(res.mask)) == 0:                       # `not mask.any()` (:396), the count is re-used below
                 return {"levelset_points": res.points, "mask": res.mask}
             if not skip_resampling:
@@ -848,7 +882,8 @@ def find_zero_crossing_between_point_pairs(p0, p1, network, n_secant_steps=8, n_
 def mask_padded_to_list(values, mask):
     """DSS/utils/__init__.py:119-146 for padded inputs: per cloud, the rows where mask is True.  The number of True
     rows per cloud is read from the device once per mask tensor (true_counts); a cloud whose mask is all True is
-    returned as it is (no boolean-index pass: nonzero + gather + a host read of its own, 0.1 ms at 1 M points)."""
+    returned as it is (no boolean-index pass: nonzero + gather + a host read of its own, 0.1 ms at 1 M points) -- a VIEW
+    of `values`, where the reference's boolean index returns a copy: clone it before mutating it in place."""
     n_true = true_counts(mask)
     P = int(mask.shape[1]) if mask.ndim > 1 else 0
     return [values[b] if n_true[b] == P else values[b][mask[b]] for b in range(values.shape[0])]

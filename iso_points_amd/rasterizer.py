@@ -962,6 +962,35 @@ class LazyDict(dict):
     def copy(self):
         return dict(self._all())
 
+    # the rest of the plain-dict contract: these would by-pass __missing__ -- materialise first
+    def pop(self, key, *default):
+        if key in self._makers:
+            self[key]
+        return super().pop(key, *default)
+
+    def popitem(self):
+        return super(LazyDict, self._all()).popitem()
+
+    def setdefault(self, key, default=None):
+        if key in self._makers:
+            return self[key]
+        return super().setdefault(key, default)
+
+    def __delitem__(self, key):
+        if key in self._makers:
+            del self._makers[key]
+            if not super().__contains__(key):
+                return
+        super().__delitem__(key)
+
+    def __eq__(self, other):
+        return dict.__eq__(self._all(), other._all() if isinstance(other, LazyDict) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
 
 class _Composite(autograd.Function):
     """iso_splat_composite with its backward: gradients to the per-point features and scaler, the

@@ -117,13 +117,16 @@ def siren_spec(model):
 
 def weights_key(lins, device):
     """Identity of a network's weights as the packed images see them: storage address and in-place version of every
-    weight / bias.  An optimiser step (in-place) or a re-assigned .data changes it; nothing else does."""
+    weight / bias.  An optimiser step (in-place) or a re-assigned .data changes it -- but an in-place update THROUGH
+    `.data` (p.data.mul_(), p.data.copy_(): EMA, weight clipping, hand-written optimisers) or a raw-pointer write bumps
+    neither, so this key is only a sanity check inside one operator call (UniformProjection._packing); across calls a
+    weight image is re-used on the caller's explicit word only (reuse_packed)."""
     return (str(device),) + tuple((t.data_ptr(), t._version) for lin in lins for t in (lin.weight, lin.bias))
 
 
 class PackedSiren(object):
-    """Device-side MFMA weight image of a SIREN (iso_siren_pack_weights).  `key` = weights_key at packing time: a
-    caller holding an image re-uses it as long as `current(model)` says the weights are the ones it was made from."""
+    """Device-side MFMA weight image of a SIREN (iso_siren_pack_weights).  `key` = weights_key at packing time;
+    `current(model)` is necessary, not sufficient, for the image to be up to date (see weights_key)."""
 
     def current(self, model, device):
         spec = siren_spec(model)

@@ -269,3 +269,28 @@ def test_iso_cycle_end_to_end(dev, sdf, tol):
     g_o, _, _ = SO.splat_backward(A["ndc"].cpu(), A["radii"].cpu(), ref_f[0], first, numt, grad_img[..., 3].cpu().contiguous(),
                                   cgrad[1].cpu(), radii_s=10.0)
     assert rel_err(A["grad"], g_o) < 1e-5, rel_err(A["grad"], g_o)
+
+
+def test_weight_image_follows_data_inplace_updates(dev):
+    """an in-place update through `.data` bumps neither the storage address nor the parameter's
+    version; the projection must still run on the NEW weights (one packed image per operator call, none kept across
+    calls unless the caller sets reuse_packed)."""
+    from iso_points_amd.levelset_sampling import UniformProjection, full_lengths
+    from iso_points_amd.sdf_models import Siren
+    torch.manual_seed(3)
+    m = Siren(hidden_size=128, n_layers=2).to(dev)
+    pts = sphere_cloud(5000, seed=3).to(dev)
+    proj = UniformProjection(knn_k=8)
+    a = proj._project_points(m, pts, full_lengths(pts), proj_max_iters=3).points.clone()
+    keys = [(p.data_ptr(), p._version) for p in m.parameters()]
+    for p in m.parameters():
+        p.data.mul_(1.01)
+    assert keys == [(p.data_ptr(), p._version) for p in m.parameters()]          # the hole the advisor described
+    b = proj._project_points(m, pts, full_lengths(pts), proj_max_iters=3).points.clone()
+    fresh = UniformProjection(knn_k=8)._project_points(m, pts, full_lengths(pts), proj_max_iters=3).points
+    assert torch.equal(b, fresh) and not torch.equal(a, b)
+    # inside ONE operator call the image is shared (project T = 10, then the resample's T = 3): same result as separate calls
+    out = proj.project_points(pts, m, skip_upsampling=True)
+    r0 = fresh_proj = UniformProjection(knn_k=8)
+    x0 = r0._project_points(m, pts, full_lengths(pts), proj_max_iters=10)
+    assert out["levelset_points"].shape[-1] == 3 and torch.isfinite(out["levelset_points"]).all()
