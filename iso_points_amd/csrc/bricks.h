@@ -237,6 +237,17 @@ __device__ inline BrickHdr bricks_header(const float* mn_in, const float* mx_in,
   const float spacing = sqrtf(diag / np);
   const float r = q.radius > 0.f ? q.radius : spacing * (float)q.knn_k;      // levelset_sampling.py:129-131
   float f = q.cell_scale * spacing;
+  // K-nearest grids (radius derived from knn_k): the reference's radius knn_k sqrt(diag / n) (levelset_sampling.py:129-131)
+  // is not scale-free -- on a surface cloud it holds ~55 neighbours when diag = 3.5 (the unit sphere of configs[2]) and
+  // ~97 when diag = 2.2 (configs[3]: 4 M points on a sphere of radius 0.6), and a cell of 0.8 r then stages 650 records
+  // per brick neighbourhood on average: most bricks overflow the 1024 LDS slots and their queries take the tail kernel
+  // (35 ms of a 4 M-point resample).  What a query needs is its K nearest, ~1.7 mean spacings away: the cell is capped at
+  // 3.4 mean spacings of a surface of area ~1.05 diag^2 (the unit-sphere tuning: 0.8 r there).  Exactness does not
+  // depend on the cell: a query is certified against it or goes to the tail.
+  if (!(q.radius > 0.f) && q.knn_k > 0) {
+    const float fd = 3.47f * diag / sqrtf(np);
+    if (fd > 0.f && f > fd) f = fd;
+  }
   if (r > 0.f && f > r * 1.002f) f = r * 1.002f;                        // g = 0.999 f >= r: nothing to gain beyond
   const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
   const float fmin = emax / (4.0f * (float)(q.nb_cap - 1)) * 1.0001f;
