@@ -1,0 +1,92 @@
+"""What exactly is wrong in a failing merge?  The slices of a heavy tile write their raw K-best lists to the raster's
+workspace BEFORE the merge (the merging slice too), so the lists the failing binary produced can be read back on the host
+without touching the kernel: this script runs a variant whose merging slice is fixed (haz_top_ns: the highest slice, haz_bot_ns:
+the lowest), reads every slice's list of every heavy tile from the workspace, merges them on the host by the (z, id)
+rule and compares (a) the host merge with the reference output, (b) the kernel's output with both; for every wrong pixel
+it prints which slice holds the two tied points and at which position of the MERGING slice's own list its tie member sits.
+usage: python repro_lists.py NAME   (after `python repro.py default` has written the reference)"""
+import os, sys, struct, torch
+ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from iso_points_amd import _lib
+name = sys.argv[1]
+_lib.LIB_PATH = os.path.join(ROOT, "libiso_%s.so" % name)
+from iso_points_amd.rasterizer import SurfaceSplatting, PointsRasterizationSettings
+from oracle import splat_oracle as SO
+dev = torch.device("cuda:0")
+N, S, K, P = 4, 512, 8, 1000000
+T = S // 16
+g = torch.Generator().manual_seed(5)
+pts = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+nrm = pts.clone()
+views = torch.stack([SO.look_at_view(5.0, 20.0, 90.0 * i) for i in range(N)]).to(dev)
+projs = views @ SO.perspective(30.0).to(dev)
+ss = SurfaceSplatting(raster_settings=PointsRasterizationSettings(image_size=S, points_per_pixel=K))
+ref = torch.load("/tmp/spill_ref_idx.pt")
+tiles = N * T * T
+rws_b = _lib.load().iso_splat_forward_workspace_bytes(tiles, K)
+per_slot = 32 + 3 * 8 * 256 * 4
+max_slots = min((rws_b - 64 - 32 * tiles) // per_slot, 65536)
+seen = []
+orig_empty = torch.empty
+def spy(*a, **k):
+    t = orig_empty(*a, **k)
+    if k.get("dtype") == torch.uint8 and t.numel() == rws_b:
+        seen.append(t)
+    return t
+torch.empty = spy
+top = "top" in name
+tot = {"wrong": 0, "host_merge_wrong": 0, "lists_unsorted": 0, "tie_member_in_merger": 0, "pos": [0] * 8, "other_lower_id": 0}
+for r in range(8):
+    del seen[:]
+    frags, filt = ss.forward(pts, nrm, cameras=(views, projs))
+    torch.cuda.synchronize()
+    idx = frags.idx.cpu()
+    ws = seen[-1].cpu()
+    counters = ws[:64].view(torch.int32)
+    nheavy = int(counters[1])
+    off_heavy = 64 + 16 * (tiles + max_slots)
+    heavy = ws[off_heavy:off_heavy + 16 * tiles].view(torch.int32).view(-1, 4)[:nheavy]
+    off_scr = off_heavy + 16 * tiles + 16 * max_slots
+    scr = ws[off_scr:off_scr + max_slots * 3 * 8 * 256 * 4].view(torch.float32).view(max_slots, 3, 8, 256)
+    bad = (idx != ref).any(-1)
+    tot["wrong"] += int(bad.sum())
+    tile_of = {}
+    for t_, b0, ns, _ in heavy.tolist():
+        tile_of[t_] = (b0, ns)
+    for n, yo, xo in bad.nonzero().tolist():
+        yi, xi = S - 1 - yo, S - 1 - xo
+        tile = (n * T + yi // 16) * T + xi // 16
+        lane = (yi % 16) * 16 + xi % 16
+        if tile not in tile_of:
+            print("   wrong pixel in a tile that was not cut?", (n, yo, xo)); continue
+        b0, ns = tile_of[tile]
+        lists = []
+        for s_ in range(ns):
+            z = scr[b0 + s_, 0, :, lane]; ids = scr[b0 + s_, 2, :, lane].view(torch.int32)
+            ent = [(float(z[j]), int(ids[j])) for j in range(8) if float(z[j]) < 3e38]
+            if ent != sorted(ent):
+                tot["lists_unsorted"] += 1
+            lists.append(ent)
+        allent = sorted(e for l in lists for e in l)[:K]
+        z0 = allent[0][0]
+        want = [e[1] if not (e[0] - z0 > 0.05) else -1 for e in allent] + [-1] * (K - len(allent))
+        if want != ref[n, yo, xo].tolist():
+            tot["host_merge_wrong"] += 1
+        got = idx[n, yo, xo].tolist()
+        # the tie: first position where got differs
+        j = next(q for q in range(K) if got[q] != want[q])
+        A = want[j]                                   # the id that is missing
+        B = got[j]                                    # what sits there instead
+        sA = next((s_ for s_, l in enumerate(lists) if any(e[1] == A for e in l)), -1)
+        sB = next((s_ for s_, l in enumerate(lists) if any(e[1] == B for e in l)), -1)
+        merger = ns - 1 if top else 0
+        own = lists[merger]
+        in_own = [q for q, e in enumerate(own) if e[1] in (A, B)]
+        tot["tie_member_in_merger"] += 1 if in_own else 0
+        for q in in_own:
+            tot["pos"][q] += 1
+        tot["other_lower_id"] += 1 if (sA != merger and A < B) else 0
+        if r == 0 and tot["wrong"] <= 6:
+            print("   px %s: slices %d, merger %d | missing id %d (slice %d), duplicated id %d (slice %d) | own-list positions of the tie members %s | own list ids %s"
+                  % ((n, yo, xo), ns, merger, A, sA, B, sB, in_own, [e[1] for e in own]))
+print("%s: %s" % (name, tot))

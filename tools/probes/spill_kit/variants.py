@@ -4,6 +4,7 @@ folded merge: every list, the merging slice's own included, is read back from sc
   haz          the form that failed in round 5: the merging slice keeps ITS list in registers (2 spilled VGPRs)
   haz_nospill  the same source at 5 instead of 7 workgroups per CU: 0 spilled VGPRs            -> fails the same way
   haz_top/bot  the merging slice is always the highest / lowest one (bounded spin on the arrival word) -> fail
+  haz_top_ns / haz_bot_ns   the same without the spilled registers: what repro_lists.py takes apart
   p1_wait0     s_waitcnt vmcnt(0) between the loads of a list and its insertions               -> fails
   p2_nop       s_nop 0 in the same place (control for p1)                                      -> fails
   p3_plain     plain loads instead of agent-scope atomic loads of the other slices' lists      -> fails
@@ -45,6 +46,9 @@ fixed = """    if (threadIdx.x == 0) {
     }"""
 open(T + "v_haz_top.hip", "w").write(sub(haz, arrive, fixed.replace("MERGER_SLICE", "(nslices - 1)")))
 open(T + "v_haz_bot.hip", "w").write(sub(haz, arrive, fixed.replace("MERGER_SLICE", "0")))
+# ... and the same two without the spilled registers (repro_lists.py reads the slices' lists back from the workspace)
+open(T + "v_haz_top_ns.hip", "w").write(sub(nospill, arrive, fixed.replace("MERGER_SLICE", "(nslices - 1)")))
+open(T + "v_haz_bot_ns.hip", "w").write(sub(nospill, arrive, fixed.replace("MERGER_SLICE", "0")))
 
 pushes = """#pragma unroll
         for (int j = 0; j < 4; ++j)
