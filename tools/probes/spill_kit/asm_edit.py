@@ -1,0 +1,46 @@
+"""ISA-level edits of k_raster<8, true> in the device assembly of a spill_kit variant (asm_variants.sh).
+usage: asm_edit.py IN.s OUT.s MODE"""
+import re, sys
+src, dst, mode = sys.argv[1], sys.argv[2], sys.argv[3]
+L = open(src).read().split("\n")
+# the function k_raster<8, true>
+a = next(i for i, l in enumerate(L) if l.startswith("_ZN12_GLOBAL__N_18k_rasterILi8ELb1EEE") and l.rstrip().endswith(":") or re.match(r"^_ZN12_GLOBAL__N_18k_rasterILi8ELb1EEE\S*:\s", l))
+b = next(i for i in range(a, len(L)) if L[i].startswith(".Lfunc_end") )
+out = L[:a]
+n = 0
+for l in L[a:b]:
+    s = l.strip()
+    if mode == "noswap" and s.startswith("v_swap_b32"):
+        m = re.match(r"v_swap_b32\s+(v\d+),\s*(v\d+)", s)
+        x, y = m.group(1), m.group(2)
+        out += ["\tv_xor_b32_e32 %s, %s, %s" % (x, x, y), "\tv_xor_b32_e32 %s, %s, %s" % (y, x, y), "\tv_xor_b32_e32 %s, %s, %s" % (x, x, y)]
+        n += 1
+        continue
+    if mode == "nomov64" and s.startswith("v_mov_b64_e32"):
+        m = re.match(r"v_mov_b64_e32\s+v\[(\d+):(\d+)\],\s*v\[(\d+):(\d+)\]", s)
+        if m:
+            d0, d1, s0, s1 = map(int, m.groups())
+            if d0 == s1:      # low destination overlaps high source: high half first
+                out += ["\tv_mov_b32_e32 v%d, v%d" % (d1, s1), "\tv_mov_b32_e32 v%d, v%d" % (d0, s0)]
+            else:
+                out += ["\tv_mov_b32_e32 v%d, v%d" % (d0, s0), "\tv_mov_b32_e32 v%d, v%d" % (d1, s1)]
+            n += 1
+            continue
+    out.append(l)
+    if mode == "nops" and (s.startswith("s_or_b64 exec") or s.startswith("s_and_saveexec_b64") or s.startswith("s_andn2_saveexec_b64") or s.startswith("s_mov_b64 exec")):
+        out.append("\ts_nop 7"); n += 1
+    if mode == "cmpnops" and re.match(r"v_cmp\w+_e64\s+s\[", s):
+        out.append("\ts_nop 7"); n += 1
+    if mode == "waits" and s.startswith("scratch_"):
+        out.insert(len(out) - 1, "\ts_waitcnt vmcnt(0) lgkmcnt(0)")
+        out.append("\ts_waitcnt vmcnt(0)"); n += 1
+    if mode == "vccnops" and (s.startswith("v_cmp") and "vcc" in s.split(",")[0]):
+        out.append("\ts_nop 7"); n += 1
+if mode.startswith("init"):           # every VGPR but v0 (the work-item ids) set at kernel entry: init0 / init7fffffff / ...
+    val = int(mode[4:] or "0", 16)
+    k = next(i for i in range(len(out)) if i > a and out[i].strip().startswith("; %bb.0"))
+    out[k + 1:k + 1] = ["\tv_mov_b32_e32 v%d, 0x%x" % (r, val) for r in range(1, 76)]
+    n = 75
+out += L[b:]
+open(dst, "w").write("\n".join(out))
+print(mode, "edits:", n, "function lines", b - a)

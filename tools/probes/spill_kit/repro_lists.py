@@ -86,6 +86,22 @@ for r in range(8):
         for q in in_own:
             tot["pos"][q] += 1
         tot["other_lower_id"] += 1 if (sA != merger and A < B) else 0
+        # where the missing entry and the duplicated one sit in the lists they come from, and their depths
+        pA = next((q for q, e in enumerate(lists[sA]) if e[1] == A), -1) if sA >= 0 else -1
+        pB = next((q for q, e in enumerate(lists[sB]) if e[1] == B), -1) if sB >= 0 else -1
+        zA = lists[sA][pA][0] if pA >= 0 else float("nan")
+        zB = lists[sB][pB][0] if pB >= 0 else float("nan")
+        tot.setdefault("same_slice", 0); tot.setdefault("adjacent_in_one_list", 0); tot.setdefault("equal_depth", 0)
+        tot.setdefault("A_in_merger", 0); tot.setdefault("B_in_merger", 0); tot.setdefault("pAB", {})
+        tot["same_slice"] += 1 if sA == sB else 0
+        tot["adjacent_in_one_list"] += 1 if (sA == sB and abs(pA - pB) == 1) else 0
+        tot["equal_depth"] += 1 if zA == zB else 0
+        tot["A_in_merger"] += 1 if sA == merger else 0
+        tot["B_in_merger"] += 1 if sB == merger else 0
+        key = "%s%d/%s%d" % ("m" if sA == merger else "o", pA, "m" if sB == merger else "o", pB)
+        tot["pAB"][key] = tot["pAB"].get(key, 0) + 1
+        if r == 0 and tot["wrong"] <= 12:
+            print("      missing %d: slice %d pos %d z %.9g | duplicated %d: slice %d pos %d z %.9g | got %s want %s" % (A, sA, pA, zA, B, sB, pB, zB, got, want))
         if r == 0 and tot["wrong"] <= 6:
             print("   px %s: slices %d, merger %d | missing id %d (slice %d), duplicated id %d (slice %d) | own-list positions of the tie members %s | own list ids %s"
                   % ((n, yo, xo), ns, merger, A, sA, B, sB, in_own, [e[1] for e in own]))
