@@ -26,6 +26,15 @@ for l in L[a:b]:
                 out += ["\tv_mov_b32_e32 v%d, v%d" % (d0, s0), "\tv_mov_b32_e32 v%d, v%d" % (d1, s1)]
             n += 1
             continue
+    if mode == "vccz" and (s.startswith("s_cbranch_vccz") or s.startswith("s_cbranch_vccnz")):
+        out += ["\ts_mov_b64 vcc, vcc", "\ts_nop 1"]; n += 1          # (the SI / CI work-around: re-derive VCCZ right in front of the branch)
+    if mode == "vccz" and (s.startswith("s_cbranch_execz") or s.startswith("s_cbranch_execnz")):
+        out += ["\ts_mov_b64 exec, exec", "\ts_nop 1"]; n += 1
+    if mode == "sccnop" and s.startswith("s_cbranch_scc"):
+        out += ["\ts_nop 1"]; n += 1
+    if mode == "delay" and "global_load_dword" in s and " sc1" in s and not globals().get("_delayed"):
+        out += ["\ts_sleep 127"] * 100           # ~0.4 ms in front of the first load of another slice's list (visibility lag?)
+        globals()["_delayed"] = True; n += 1
     out.append(l)
     if mode == "nops" and (s.startswith("s_or_b64 exec") or s.startswith("s_and_saveexec_b64") or s.startswith("s_andn2_saveexec_b64") or s.startswith("s_mov_b64 exec")):
         out.append("\ts_nop 7"); n += 1
@@ -41,6 +50,11 @@ if mode.startswith("init"):           # every VGPR but v0 (the work-item ids) se
     k = next(i for i in range(len(out)) if i > a and out[i].strip().startswith("; %bb.0"))
     out[k + 1:k + 1] = ["\tv_mov_b32_e32 v%d, 0x%x" % (r, val) for r in range(1, 76)]
     n = 75
+if mode.startswith("sinit"):          # every SGPR but s[0:1] (kernarg pointer) and s2 (workgroup id), and VCC, set at kernel entry
+    val = int(mode[5:] or "0", 16)
+    k = next(i for i in range(len(out)) if i > a and out[i].strip().startswith("; %bb.0"))
+    out[k + 1:k + 1] = ["\ts_mov_b32 s%d, 0x%x" % (r, val) for r in range(3, 100)] + ["\ts_mov_b32 vcc_lo, 0x%x" % val, "\ts_mov_b32 vcc_hi, 0x%x" % val]
+    n = 99
 out += L[b:]
 open(dst, "w").write("\n".join(out))
 print(mode, "edits:", n, "function lines", b - a)

@@ -5,7 +5,8 @@
 #   tools/probes/spill_kit/make.sh && tools/probes/spill_kit/asm_variants.sh      -> tree/libiso_asm_{ctl,noswap,...}.so
 #   modes: ctl (unedited: must fail), noswap (v_swap_b32 -> three v_xor), nomov64 (v_mov_b64 -> two v_mov_b32), nops (s_nop 7
 #   behind every write of EXEC), cmpnops / vccnops (s_nop 7 behind every compare that writes an SGPR pair / VCC), waits
-#   (s_waitcnt vmcnt(0) lgkmcnt(0) around every scratch access), init (all VGPRs set at kernel entry: asm_init.py)
+#   (s_waitcnt vmcnt(0) lgkmcnt(0) around every scratch access), initHEX / sinitHEX (all VGPRs / all SGPRs + VCC set at kernel
+#   entry), vccz (VCCZ / EXECZ re-derived in front of every branch on them), delay (0.4 ms of s_sleep before the first list load)
 set -e
 REPO=$(cd "$(dirname "$0")/../../.." && pwd)
 T=$REPO/tools/probes/spill_repro/tree

@@ -21,10 +21,13 @@ runs = []
 for r in range(8):
     frags, filt = ss.forward(pts, nrm, cameras=(views, projs))
     torch.cuda.synchronize()
-    idx, zb = frags.idx.clone(), frags.zbuf.clone()
+    idx, zb, qv = frags.idx.clone(), frags.zbuf.clone(), frags.qvalue.clone()
     if ref is None:
         ref = idx
         torch.save(idx.cpu(), REF)
+        torch.save(qv.cpu(), REF + ".q")
+    if name != "default" and r == 0:
+        refq = torch.load(REF + ".q").to(dev)
     d = (idx != ref).any(-1)
     runs.append(d)
     n = int(d.sum())
@@ -38,6 +41,12 @@ for r in range(8):
         dup = (a[:, 1:] == a[:, :-1]) & (a[:, 1:] >= 0)
         # is the first differing position the first entry of a tie pair?
         at_tie = torch.gather(torch.cat([tie, torch.zeros_like(tie[:, :1])], 1), 1, first[:, None])[:, 0]
+        qa, qb = qv[d], refq[d]
+        qj = torch.gather(qa, 1, first[:, None])[:, 0]                       # q at the first wrong position
+        qref = torch.gather(qb, 1, first[:, None])[:, 0]
+        qnext = torch.gather(qa, 1, (first + 1).clamp(max=K - 1)[:, None])[:, 0]
+        msg += "; q at the wrong slot: = the reference's (the missing point's) %d, = the next slot's (the duplicate's) %d, neither %d" % (
+            int((qj == qref).sum()), int(((qj == qnext) & (qj != qref)).sum()), int(((qj != qref) & (qj != qnext)).sum()))
         msg += "; with a depth tie %d, first difference AT a tie's first entry %d, duplicate id in the list %d; first-difference positions %s" % (
             int(has_tie.sum()), int(at_tie.sum()), int(dup.any(-1).sum()), torch.bincount(first, minlength=K).tolist())
         if r == 0 or r == 7:
