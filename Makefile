@@ -20,9 +20,18 @@ $(LIB): $(OBJS)
 # (max-ilp 2.88, iterative-ilp 2.93; no effect on idr / idr_x16 / bricks / splat, siren.hip slower).  Results are bit-identical.
 FLAGS_siren_x3 := -mllvm -amdgpu-sched-strategy=max-memory-clause
 
+# The SLP vectoriser of this toolchain (ROCm 7.2, clang 22.0.0git) miscompiles the (z, id, q) swap-chain insertion of a
+# loop-carried K-best list: it pairs the (q, z) / (id, id) registers and gives a swap taken by the TIE rule (equal depth,
+# lower id) the values of the no-swap path -- round 5's "wrong lists on depth ties" build, taken apart in round 6
+# (profiles/HISTORY.md; tools/probes/tie_merge.hip reproduces it in 150 lines and is correct with this flag;
+# tests/test_ties_gpu.py).  Every file with selection lists, i.e. everything but the four MFMA files, is built without it
+# (cfg 3a: 0.957-0.960 ms either way); the MFMA files hold no such list and the SIREN step is 0.7 % faster with it.
+SLP_KEPT   := siren siren_x3 idr idr_x16
+NOSLP      := -fno-slp-vectorize
+
 build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/isopoints.h Makefile
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) $(FLAGS_$*) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(if $(filter $*,$(SLP_KEPT)),,$(NOSLP)) $(FLAGS_$*) -c $< -o $@
 
 oracle:
 	$(MAKE) -C oracle

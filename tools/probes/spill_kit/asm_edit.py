@@ -36,6 +36,15 @@ for l in L[a:b]:
         out += ["\ts_sleep 127"] * 100           # ~0.4 ms in front of the first load of another slice's list (visibility lag?)
         globals()["_delayed"] = True; n += 1
     out.append(l)
+    # blanket modes: behind EVERY instruction of the kernel an s_nop 7 (allnops: no wait-state hazard of any kind can be left),
+    # an s_waitcnt vmcnt(0) lgkmcnt(0) (allwaits: no memory result is consumed early, no two memory operations overlap), or both
+    if mode in ("allnops", "allwaits", "allboth") and s and not s.startswith((".", ";", "s_endpgm", "s_getpc", "s_setpc", "s_swappc")) and not s.endswith(":") \
+            and not re.match(r"^[.\w$]+:", s) and "@rel32" not in s and "s_getpc" not in "".join(out[-3:]):
+        if mode in ("allwaits", "allboth"):
+            out.append("\ts_waitcnt vmcnt(0) lgkmcnt(0)")
+        if mode in ("allnops", "allboth"):
+            out.append("\ts_nop 7")
+        n += 1
     if mode == "nops" and (s.startswith("s_or_b64 exec") or s.startswith("s_and_saveexec_b64") or s.startswith("s_andn2_saveexec_b64") or s.startswith("s_mov_b64 exec")):
         out.append("\ts_nop 7"); n += 1
     if mode == "cmpnops" and re.match(r"v_cmp\w+_e64\s+s\[", s):
