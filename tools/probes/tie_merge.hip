@@ -158,6 +158,10 @@ int main() {
   bad += run<0, false, 2, false>("plain loads, nothing skipped (own list is an extra one)", 64, 4, 8, false);
   bad += run<0, false, 1, true>("plain loads, first four, K at compile time, nothing skipped", 64, 4, 8, false);
   bad += run<0, true, 2, false>("as in the raster kernel, K = 7", 64, 3, 7, true);
+  bad += run<0, true, 1, false>("atomic loads, only the first four entries of a list", 64, 4, 8, true);
+  bad += run<0, true, 2, true>("atomic loads, K = KMAX at compile time", 64, 4, 8, true);
+  bad += run<0, true, 2, false>("atomic loads, nothing skipped (own list is an extra one)", 64, 4, 8, false);
+  bad += run<0, true, 1, true>("atomic loads, first four, K at compile time, nothing skipped", 64, 4, 8, false);
   printf(bad ? "WRONG RESULTS\n" : "all correct\n");
   return 0;
 }
