@@ -4,6 +4,7 @@ No compute calls (there is no GPU in the build container)."""
 import ctypes
 import os
 import re
+import sys
 
 from conftest import ROOT
 
@@ -133,3 +134,24 @@ def test_vgpr_spills_only_where_allowed_and_pinned():
                 "9k_bin_ldsILb", "11k_z_scatter", "13k_brick_count", "15k_brick_scatter", "16k_brick_offsets1"):
         hit = [k for k in ks if pat in k[0]]
         assert hit and all(k[1] == 0 for k in hit), (pat, hit)
+
+
+def test_no_kernel_of_the_library_is_hit_by_the_structurizer_defect():
+    """tools/structurize_scan.py: every source compiled to device IR with the Makefile's flags, taken through the code
+    generator's IR passes in one process, and every multi-predecessor block that consists of zero-cost instructions only (the
+    precondition of the defect: ~100 in the library, most of them extracts of vector loads) looked up again behind
+    `structurizecfg`: none may have been emptied, i.e. hoisted into one of its predecessors -- that is the miscompile that
+    gave round 5's raster build its wrong lists.  The detector's control is the reproducer: at plain -O3 it is hit."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import pytest
+    if not (shutil.which("/opt/rocm/bin/hipcc") and shutil.which("/opt/rocm/lib/llvm/bin/opt")):
+        pytest.skip("no ROCm compiler / opt here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "structurize_scan.py")], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "hoisted out of a multi-predecessor block: 0" in r.stdout, r.stdout[-3000:]
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "structurize_scan.py"), "--probe"], stdout=subprocess.PIPE, text=True)
+    lines = c.stdout.strip().splitlines()
+    assert len(lines) == 2 and lines[1].endswith("block: 0"), c.stdout            # with the library's flag: clean
+    if c.returncode == 0:
+        print("the reproducer is no longer hit at plain -O3: this toolchain does not show the defect")
