@@ -140,7 +140,8 @@ def test_no_kernel_of_the_library_is_hit_by_the_structurizer_defect():
     """tools/structurize_scan.py: every source compiled to device IR with the Makefile's flags, taken through the code
     generator's IR passes in one process, and every multi-predecessor block that consists of zero-cost instructions only (the
     precondition of the defect: ~100 in the library, most of them extracts of vector loads) looked up again behind
-    `structurizecfg`: none may have been emptied, i.e. hoisted into one of its predecessors -- that is the miscompile that
+    `structurizecfg` (with the code generator's predecessor orders, and with every block's predecessors reversed): none may have
+    been emptied, i.e. hoisted into one of its predecessors -- that is the miscompile that
     gave round 5's raster build its wrong lists.  The detector's control is the reproducer: at plain -O3 it is hit."""
     import importlib.util
     import shutil

@@ -8,7 +8,8 @@ code generator's IR passes up to the one in front of `structurizecfg`, and lists
   strict  all instructions of the block are vector inserts / extracts / shuffles / bitcasts   (the shape that was hit)
   broad   ... or any other instruction a target may price at zero (casts, freeze, fneg, address arithmetic)
 and then looks at the same blocks BEHIND `structurizecfg` (same process, so with the predecessor orders the code generator really
-has; blocks are named first with `instnamer` so that they can be found again): a listed block that has become EMPTY was hoisted
+has; blocks are named first with `instnamer` so that they can be found again) and behind `opt -passes=structurizecfg` run alone
+on the IR in front of it with the predecessors of EVERY block reversed: a listed block that has become EMPTY in either was hoisted
 out of a multi-predecessor position -- that is the miscompile itself, not merely its precondition.
 usage: python tools/structurize_scan.py [-v] [file.hip ...]   (default: every file of iso_points_amd/csrc; ~15 s)
        python tools/structurize_scan.py --probe               the detector's own control: tools/probes/tie_merge.hip at plain -O3
@@ -54,6 +55,46 @@ def scan_ir(ir):
     return hits
 
 
+def empty_blocks(ir):
+    out = set()
+    for m in re.finditer(r"^define [^\n]*@([\w.$]+)\([^\n]*\{\n(.*?)^\}", ir, flags=re.M | re.S):
+        fn, body = m.group(1), m.group(2)
+        for b in re.finditer(r"^([\w.$]+):[^\n]*\n(.*?)(?=^[\w.$]+:|\Z)", body, flags=re.M | re.S):
+            lines = [l.strip() for l in b.group(2).splitlines() if l.strip() and not l.strip().startswith(";")]
+            if len(lines) == 1 and lines[0].startswith("br label"):
+                out.add((fn, b.group(1)))
+    return out
+
+
+def reversed_order(ir, tmp, base):
+    """blocks emptied by `opt -passes=structurizecfg` when every multi-predecessor block's use list is reversed"""
+    direct = []
+    for m in re.finditer(r"^define [^\n]*@([\w.$]+)\([^\n]*\{\n(.*?)^\}", ir, flags=re.M | re.S):
+        fn, body = m.group(1), m.group(2)
+        for b in re.finditer(r"^([\w.$]+):\s*; preds = ([^\n]*)\n", body, flags=re.M):
+            n = len([p for p in b.group(2).split(",") if p.strip()])
+            if n >= 2 and not b.group(1)[0].isdigit():
+                direct.append((fn, b.group(1), n))
+    skip = set()
+    for _ in range(40):
+        txt = ir + "\n" + "".join("uselistorder_bb @%s, %%%s, { %s }\n" % (fn, blk, ", ".join(str(i) for i in range(n - 1, -1, -1)))
+                                  for fn, blk, n in direct if (fn, blk) not in skip)
+        f = os.path.join(tmp, base + ".rev.ll")
+        open(f, "w").write(txt)
+        r = subprocess.run([OPT, "-S", "-passes=structurizecfg", f, "-o", f + ".out"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode == 0:
+            return empty_blocks(open(f + ".out").read())
+        m = re.search(r":(\d+):\d+: error", r.stderr)                 # a directive whose count does not fit (duplicate edges): drop it
+        if not m:
+            raise RuntimeError(r.stderr[:500])
+        bad = txt.splitlines()[int(m.group(1)) - 1]
+        mm = re.match(r"uselistorder_bb @([\w.$]+), %([\w.$]+),", bad)
+        if not mm:
+            raise RuntimeError(r.stderr[:500])
+        skip.add((mm.group(1), mm.group(2)))
+    raise RuntimeError("too many directives rejected")
+
+
 def one(src, words, tmp):
     base = os.path.basename(src)[:-4]
     bc = os.path.join(tmp, base + ".bc")
@@ -85,6 +126,9 @@ def one(src, words, tmp):
             lines = [l.strip() for l in b.group(2).splitlines() if l.strip() and not l.strip().startswith(";")]
             if len(lines) == 1 and lines[0].startswith("br label"):
                 emptied.add((fn, b.group(1)))
+    # ... and, because the defect depends on the ORDER of a block's predecessors (which a later edit of the source or another
+    # compiler version may change), the same pass alone on the IR in front of it with the predecessors of every block REVERSED
+    emptied |= reversed_order(ir, tmp, base)
     for fn, v in hits.items():
         hits[fn] = [h + ((fn, h[0]) in emptied,) for h in v]
     return base, "-fno-slp-vectorize" in words, len(re.findall(r"^define ", ir, flags=re.M)), hits
