@@ -24,9 +24,11 @@ FLAGS_siren_x3 := -mllvm -amdgpu-sched-strategy=max-memory-clause
 # loop-carried K-best list: it pairs the (q, z) / (id, id) registers and gives a swap taken by the TIE rule (equal depth,
 # lower id) the values of the no-swap path -- round 5's "wrong lists on depth ties" build, taken apart in round 6
 # (profiles/HISTORY.md; tools/probes/tie_merge.hip reproduces it in 150 lines and is correct with this flag;
-# tests/test_ties_gpu.py).  Every file with selection lists, i.e. everything but the four MFMA files, is built without it
-# (cfg 3a: 0.957-0.960 ms either way); the MFMA files hold no such list and the SIREN step is 0.7 % faster with it.
-SLP_KEPT   := siren siren_x3 idr idr_x16
+# tests/test_ties_gpu.py; tools/structurize_scan.py looks for the defect in the built library).  Every file but siren_x3.hip
+# is built without it: all files with selection lists (cfg 3a: 0.957-0.960 ms either way; k_fps_grid loses 922 spilled
+# registers), and the other MFMA files, which are as fast or faster without (IDR 8x512: 27.0 -> 25.9-26.2 ms per 1 M
+# evaluations; the f32-MFMA SIREN step unchanged); the split-fp16 SIREN step is 0.7 % faster WITH it and holds no list.
+SLP_KEPT   := siren_x3
 NOSLP      := -fno-slp-vectorize
 
 build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/isopoints.h Makefile
