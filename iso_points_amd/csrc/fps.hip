@@ -173,6 +173,196 @@ __global__ __launch_bounds__(FPS_BLOCK) void k_fps_grid(const float* __restrict_
   }
 }
 
+// ---- grid-wide form, several samples per exchange ------------------------------------------------
+// k_fps_grid pays one device-wide exchange (~2.2 us) per sample.  Here a workgroup publishes its T LARGEST keys instead of
+// one, and every workgroup replays the selection on the published lists until the outcome stops being certain:
+//   * the listed points of workgroup j are known exactly -- index, position (read from p), current min-distance -- so every
+//     workgroup can update them for each sample it decides, with the arithmetic their owner uses;
+//   * the unlisted points of j lie below B_j = j's T-th published key for the rest of the round (distances only shrink);
+//   * the largest listed key C is a real point's exact key; it is THE arg-max iff C > B_j for every workgroup whose own best
+//     listed key has fallen below B_j (for the others B_j <= their best listed key <= C).
+// The sequence is the sequential one, sample for sample (same keys, same (distance, lowest index) order); only the number
+// of samples per exchange varies -- and every workgroup computes the same number from the same lists.  Then all threads
+// apply the decided samples to their own points and the next lists are drawn.
+constexpr int kFpsT = 4;            // listed keys per workgroup
+constexpr int kFpsMaxRun = 128;     // samples decided per exchange at most
+constexpr int kFpsLazyGrid = 128;   // workgroups at most (their lists live in wave 0's registers: 2 workgroups x T entries per lane)
+struct FpsCtlLazy { unsigned long long slot[2][kFpsLazyGrid * kFpsT]; };
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_BLOCK) void k_fps_lazy(const float* __restrict__ p, const int64_t* __restrict__ lengths,
+                                                        const int64_t* __restrict__ n_samples,
+                                                        const int64_t* __restrict__ start, int n, int64_t p_stride,
+                                                        FpsCtlLazy* ctl, int64_t* __restrict__ out) {
+  constexpr int T = kFpsT, NWL = kFpsLazyGrid / 64;
+  __shared__ unsigned long long s_key[2][FPS_BLOCK / 64];
+  __shared__ unsigned long long s_ent[kFpsLazyGrid * T];
+  __shared__ float s_ex[kFpsLazyGrid * T], s_ey[kFpsLazyGrid * T], s_ez[kFpsLazyGrid * T];
+  __shared__ float s_sx[kFpsMaxRun], s_sy[kFpsMaxRun], s_sz[kFpsMaxRun];
+  __shared__ int s_m;
+  const int64_t len = lengths ? lengths[n] : p_stride;
+  const int64_t ns = n_samples[n] < len ? n_samples[n] : len;
+  if (len <= 0 || ns <= 0) return;                      // uniform over the grid
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const unsigned nb = gridDim.x;
+  const int64_t stride = (int64_t)nb * FPS_BLOCK;
+  const int64_t first = (int64_t)blockIdx.x * FPS_BLOCK + t;
+  float px[PPT], py[PPT], pz[PPT], mind[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int64_t i = first + k * stride;
+    px[k] = py[k] = pz[k] = 0.f;
+    mind[k] = -1.0f;                                    // beyond the cloud: never listed
+    if (i < len) { px[k] = p[i * 3]; py[k] = p[i * 3 + 1]; pz[k] = p[i * 3 + 2]; mind[k] = FLT_MAX; }
+  }
+  if (t == 0) {
+    const int cur = (int)(start[n] < len ? (start[n] < 0 ? 0 : start[n]) : len - 1);
+    s_sx[0] = p[(int64_t)cur * 3]; s_sy[0] = p[(int64_t)cur * 3 + 1]; s_sz[0] = p[(int64_t)cur * 3 + 2];
+    s_m = 1;
+    if (blockIdx.x == 0) out[0] = cur;
+  }
+  __syncthreads();
+  const unsigned long long tmask = 1ull << 31;
+  int64_t done = 0;
+  for (unsigned r = 0;; ++r) {
+    const int m = s_m;
+    for (int i = 0; i < m; ++i) {
+      const float cx = s_sx[i], cy = s_sy[i], cz = s_sz[i];
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        mind[k] = fminf(mind[k], d);
+      }
+    }
+    done += m;
+    if (done >= ns) break;
+    // the workgroup's T largest keys (a thread's points are in ascending index order: the first strict maximum among those
+    // not listed yet is its (largest distance, lowest index))
+    unsigned excl = 0;
+    unsigned long long top[T];
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+      float bm = -1.0f;
+      int bk = 0;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k)
+        if (!((excl >> k) & 1u) && mind[k] > bm) { bm = mind[k]; bk = k; }
+      const unsigned long long mine = bm < 0.f ? 0ull
+          : (((unsigned long long)__float_as_uint(bm) << 32) | (unsigned)(0xffffffffu - (unsigned)(first + bk * stride)));
+      unsigned long long key = mine;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ok = __shfl_xor(key, o);
+        key = ok > key ? ok : key;
+      }
+      if (lane == 0) s_key[q & 1][t >> 6] = key;
+      __syncthreads();
+      unsigned long long best = 0;
+#pragma unroll
+      for (int w = 0; w < FPS_BLOCK / 64; ++w) { const unsigned long long v = s_key[q & 1][w]; best = v > best ? v : best; }
+      top[q] = best;
+      if (best != 0 && mine == best) excl |= 1u << bk;
+    }
+    const unsigned long long tag = (unsigned long long)(((r >> 1) & 1u) ^ 1u) << 31;
+    unsigned long long* slots = ctl->slot[r & 1];
+    if (t < T) {
+      unsigned long long v = top[0];
+#pragma unroll
+      for (int q = 1; q < T; ++q) v = t == q ? top[q] : v;
+      __hip_atomic_store(&slots[blockIdx.x * T + t], (v & ~tmask) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every thread fetches one published key and that point's position
+    if ((unsigned)t < nb * T) {
+      unsigned long long v = __hip_atomic_load(&slots[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((v & tmask) != tag) {
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(&slots[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((v & ~tmask) == 0ull) {
+        s_ent[t] = 0ull;
+      } else {
+        v |= tmask;                                       // the bit is part of ~index (always 1 there)
+        const int64_t idx = (int64_t)(0xffffffffu - (unsigned)(v & 0xffffffffull));
+        s_ent[t] = v;
+        s_ex[t] = p[idx * 3]; s_ey[t] = p[idx * 3 + 1]; s_ez[t] = p[idx * 3 + 2];
+      }
+    }
+    __syncthreads();
+    if (t < 64) {                                         // wave 0: the selection replayed on the lists
+      unsigned long long ek[NWL][T], eb[NWL];
+      float ex[NWL][T], ey[NWL][T], ez[NWL][T];
+#pragma unroll
+      for (int i = 0; i < NWL; ++i) {
+        const unsigned g = (unsigned)lane + 64u * i;
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+          ek[i][q] = 0ull; ex[i][q] = ey[i][q] = ez[i][q] = 0.f;
+          if (g < nb) { ek[i][q] = s_ent[g * T + q]; ex[i][q] = s_ex[g * T + q]; ey[i][q] = s_ey[g * T + q]; ez[i][q] = s_ez[g * T + q]; }
+        }
+        eb[i] = ek[i][T - 1];
+      }
+      const int64_t left = ns - done;
+      const int lim = left < kFpsMaxRun ? (int)left : kFpsMaxRun;
+      int mm = 0;
+      while (mm < lim) {
+        unsigned long long c = 0ull, blk = 0ull;
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+          unsigned long long bl = ek[i][0];
+#pragma unroll
+          for (int q = 1; q < T; ++q) bl = ek[i][q] > bl ? ek[i][q] : bl;
+          if (bl < eb[i]) blk = eb[i] > blk ? eb[i] : blk;
+          c = bl > c ? bl : c;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long oc = __shfl_xor(c, o), ob = __shfl_xor(blk, o);
+          c = oc > c ? oc : c;
+          blk = ob > blk ? ob : blk;
+        }
+        if (c == 0ull || !(c > blk)) break;
+        float wx = 0.f, wy = 0.f, wz = 0.f;
+        bool have = false;
+#pragma unroll
+        for (int i = 0; i < NWL; ++i)
+#pragma unroll
+          for (int q = 0; q < T; ++q)
+            if (ek[i][q] == c) { wx = ex[i][q]; wy = ey[i][q]; wz = ez[i][q]; have = true; }
+        const int src = __ffsll((unsigned long long)__ballot(have)) - 1;
+        wx = __shfl(wx, src); wy = __shfl(wy, src); wz = __shfl(wz, src);
+        if (lane == 0) {
+          s_sx[mm] = wx; s_sy[mm] = wy; s_sz[mm] = wz;
+          if (blockIdx.x == 0) out[done + mm] = (int64_t)(0xffffffffu - (unsigned)(c & 0xffffffffull));
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i)
+#pragma unroll
+          for (int q = 0; q < T; ++q)
+            if (ek[i][q] != 0ull) {
+              const float dx = ex[i][q] - wx, dy = ey[i][q] - wy, dz = ez[i][q] - wz;
+              const float d = (dx * dx + dy * dy) + dz * dz;
+              const float nd = fminf(__uint_as_float((unsigned)(ek[i][q] >> 32)), d);
+              ek[i][q] = ((unsigned long long)__float_as_uint(nd) << 32) | (ek[i][q] & 0xffffffffull);
+            }
+        ++mm;
+      }
+      if (lane == 0) s_m = mm;
+    }
+    __syncthreads();
+  }
+}
+
+template <int PPT>
+hipError_t launch_fps_lazy(int nb, const float* p, const int64_t* lengths, const int64_t* n_samples,
+                           const int64_t* start, int n, int64_t p_stride, FpsCtlLazy* ctl, int64_t* out, hipStream_t s) {
+  void* args[] = {(void*)&p, (void*)&lengths, (void*)&n_samples, (void*)&start, (void*)&n, (void*)&p_stride,
+                  (void*)&ctl, (void*)&out};
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_fps_lazy<PPT>), dim3(nb), dim3(FPS_BLOCK), args,
+                                    0, s);
+}
+
 template <int PPT>
 hipError_t launch_fps_grid(int nb, const float* p, const int64_t* lengths, const int64_t* n_samples,
                            const int64_t* start, int n, int64_t p_stride, FpsCtl* ctl, int64_t* out, hipStream_t s) {
@@ -183,7 +373,7 @@ hipError_t launch_fps_grid(int nb, const float* p, const int64_t* lengths, const
 }
 
 constexpr int64_t kFpsGridMin = 8192;     // below: one workgroup is faster than grid-wide barriers
-constexpr int kFpsCtlFloats = sizeof(FpsCtl) / 4;   // control block at the end of the workspace
+constexpr int kFpsCtlFloats = (sizeof(FpsCtlLazy) > sizeof(FpsCtl) ? sizeof(FpsCtlLazy) : sizeof(FpsCtl)) / 4;   // control block at the end of the workspace
 
 }  // namespace
 
@@ -209,17 +399,29 @@ extern "C" int iso_farthest_point_sampling(const float* points, const int64_t* l
     // round trips, not the arithmetic; fewer, fatter workgroups are not faster)
     static int ppt_target = 0;                       // ISO_FPS_PPT: development override (points per thread the grid is sized for)
     if (ppt_target == 0) { const char* e = getenv("ISO_FPS_PPT"); ppt_target = e ? atoi(e) : 8; if (ppt_target < 1 || ppt_target > 16) ppt_target = 8; }
+    static int lazy = -1;                           // ISO_FPS_LAZY=0: one sample per exchange (k_fps_grid)
+    if (lazy < 0) { const char* e = getenv("ISO_FPS_LAZY"); lazy = e ? atoi(e) != 0 : 1; }
+    const bool use_lazy = lazy && p_stride <= (int64_t)kFpsLazyGrid * FPS_BLOCK * 16;
+    const int64_t nb_max = use_lazy ? kFpsLazyGrid : 256;
     int64_t nb = (p_stride + FPS_BLOCK * ppt_target - 1) / (FPS_BLOCK * ppt_target);
-    nb = nb < 2 ? 2 : (nb > 256 ? 256 : nb);
+    nb = nb < 2 ? 2 : (nb > nb_max ? nb_max : nb);
     const int64_t ppt = (p_stride + nb * FPS_BLOCK - 1) / (nb * FPS_BLOCK);
     // (8-byte slots: the control block starts at the next 8-byte boundary; kFpsCtlFloats leaves room for it)
     FpsCtl* ctl = reinterpret_cast<FpsCtl*>(((uintptr_t)(work + (int64_t)n_clouds * p_stride) + 7) & ~(uintptr_t)7);
     bool refused = false;
     for (int n = 0; n < n_clouds; ++n) {
-      (void)hipMemsetAsync(ctl, 0, sizeof(FpsCtl), st);
+      (void)hipMemsetAsync(ctl, 0, kFpsCtlFloats * 4, st);
       const float* p = points + (int64_t)n * p_stride * 3;
       int64_t* out = out_idx + (int64_t)n * out_stride;
       hipError_t e;
+      if (use_lazy) {
+        FpsCtlLazy* cl = reinterpret_cast<FpsCtlLazy*>(ctl);
+        if (ppt <= 1) e = launch_fps_lazy<1>((int)nb, p, lengths, n_samples, start, n, p_stride, cl, out, st);
+        else if (ppt <= 2) e = launch_fps_lazy<2>((int)nb, p, lengths, n_samples, start, n, p_stride, cl, out, st);
+        else if (ppt <= 4) e = launch_fps_lazy<4>((int)nb, p, lengths, n_samples, start, n, p_stride, cl, out, st);
+        else if (ppt <= 8) e = launch_fps_lazy<8>((int)nb, p, lengths, n_samples, start, n, p_stride, cl, out, st);
+        else e = launch_fps_lazy<16>((int)nb, p, lengths, n_samples, start, n, p_stride, cl, out, st);
+      } else
       if (ppt <= 1) e = launch_fps_grid<1>((int)nb, p, lengths, n_samples, start, n, p_stride, ctl, out, st);
       else if (ppt <= 2) e = launch_fps_grid<2>((int)nb, p, lengths, n_samples, start, n, p_stride, ctl, out, st);
       else if (ppt <= 4) e = launch_fps_grid<4>((int)nb, p, lengths, n_samples, start, n, p_stride, ctl, out, st);
