@@ -9,7 +9,12 @@
 //     thread keeps its <= 16 points AND their min-distances in registers (nothing is read from
 //     memory inside the loop except the winner's coordinates); the workgroup maxima -- 64-bit keys
 //     (distance bits, ~index) -- meet through one store per workgroup and one polling load per lane of
-//     wave 0 (no atomics, no counter barrier: see the comment at the kernel).
+//     wave 0 (no atomics, no counter barrier: see the comment at the kernel).  One device-wide exchange
+//     (~2.2 us) per sample: 3.5-3.7 us per sample at 500 k points.
+//   * k_fps_lazy (the default for 8 k .. 2 M points): the same layout, but a workgroup publishes its FOUR
+//     largest keys and every workgroup replays the selection on the published lists for as long as its
+//     outcome is certain -- 35 samples per exchange on average at 500 k points: 1.0 us per sample
+//     (5 000 of 500 k: 18.3 -> 5.0 ms), the sequence identical sample for sample.
 #include <float.h>
 #include <stdlib.h>
 #include "iso_common.h"
@@ -173,6 +178,29 @@ __global__ __launch_bounds__(FPS_BLOCK) void k_fps_grid(const float* __restrict_
   }
 }
 
+// wave-wide maximum of a 64-bit key through the DPP network (row shifts inside the 16-lane rows, then the two row
+// broadcasts of gfx9; ~6 dependent VALU operations instead of six LDS-crossbar round trips of __shfl_xor); every lane
+// gets the result
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#define FPS_DPP_STEP(CTRL, ROWS)                                                                        \
+  {                                                                                                     \
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROWS, 0xf, false); \
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROWS, 0xf, false); \
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;                                    \
+    v = o > v ? o : v;                                                                                  \
+  }
+  FPS_DPP_STEP(0x111, 0xf)      // row_shr:1
+  FPS_DPP_STEP(0x112, 0xf)      // row_shr:2
+  FPS_DPP_STEP(0x114, 0xf)      // row_shr:4
+  FPS_DPP_STEP(0x118, 0xf)      // row_shr:8   -> lane 15 of every row holds the row's maximum
+  FPS_DPP_STEP(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+  FPS_DPP_STEP(0x143, 0xc)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef FPS_DPP_STEP
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 // ---- grid-wide form, several samples per exchange ------------------------------------------------
 // k_fps_grid pays one device-wide exchange (~2.2 us) per sample.  Here a workgroup publishes its T LARGEST keys instead of
 // one, and every workgroup replays the selection on the published lists until the outcome stops being certain:
@@ -316,22 +344,25 @@ __global__ __launch_bounds__(FPS_BLOCK) void k_fps_lazy(const float* __restrict_
           if (bl < eb[i]) blk = eb[i] > blk ? eb[i] : blk;
           c = bl > c ? bl : c;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const unsigned long long oc = __shfl_xor(c, o), ob = __shfl_xor(blk, o);
-          c = oc > c ? oc : c;
-          blk = ob > blk ? ob : blk;
-        }
+        c = wave_max_u64(c);
+        blk = wave_max_u64(blk);
         if (c == 0ull || !(c > blk)) break;
+        // the winner's position: the one lane and entry that hold key c (selects, no branches: this loop is one wave's
+        // dependent chain and the whole grid waits for it)
         float wx = 0.f, wy = 0.f, wz = 0.f;
         bool have = false;
 #pragma unroll
         for (int i = 0; i < NWL; ++i)
 #pragma unroll
-          for (int q = 0; q < T; ++q)
-            if (ek[i][q] == c) { wx = ex[i][q]; wy = ey[i][q]; wz = ez[i][q]; have = true; }
-        const int src = __ffsll((unsigned long long)__ballot(have)) - 1;
-        wx = __shfl(wx, src); wy = __shfl(wy, src); wz = __shfl(wz, src);
+          for (int q = 0; q < T; ++q) {
+            const bool hit = ek[i][q] == c;
+            wx = hit ? ex[i][q] : wx; wy = hit ? ey[i][q] : wy; wz = hit ? ez[i][q] : wz;
+            have = have || hit;
+          }
+        const int src = __builtin_ctzll((unsigned long long)__ballot(have));
+        wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), src));
+        wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), src));
+        wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), src));
         if (lane == 0) {
           s_sx[mm] = wx; s_sy[mm] = wy; s_sz[mm] = wz;
           if (blockIdx.x == 0) out[done + mm] = (int64_t)(0xffffffffu - (unsigned)(c & 0xffffffffull));
@@ -339,13 +370,14 @@ __global__ __launch_bounds__(FPS_BLOCK) void k_fps_lazy(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < NWL; ++i)
 #pragma unroll
-          for (int q = 0; q < T; ++q)
-            if (ek[i][q] != 0ull) {
-              const float dx = ex[i][q] - wx, dy = ey[i][q] - wy, dz = ez[i][q] - wz;
-              const float d = (dx * dx + dy * dy) + dz * dz;
-              const float nd = fminf(__uint_as_float((unsigned)(ek[i][q] >> 32)), d);
-              ek[i][q] = ((unsigned long long)__float_as_uint(nd) << 32) | (ek[i][q] & 0xffffffffull);
-            }
+          for (int q = 0; q < T; ++q) {
+            const float dx = ex[i][q] - wx, dy = ey[i][q] - wy, dz = ez[i][q] - wz;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const unsigned od = (unsigned)(ek[i][q] >> 32);
+            const unsigned nd = __float_as_uint(fminf(__uint_as_float(od), d));
+            // an absent entry (key 0) stays 0: its distance word is 0 and min(0, d) = 0 for d >= 0
+            ek[i][q] = ((unsigned long long)nd << 32) | (ek[i][q] & 0xffffffffull);
+          }
         ++mm;
       }
       if (lane == 0) s_m = mm;
@@ -397,10 +429,12 @@ extern "C" int iso_farthest_point_sampling(const float* points, const int64_t* l
     // grid-wide form, cloud after cloud; the smallest grid that keeps <= 8 points per thread
     // (measured: 2.8 us per sample up to 50 k points, 5.0 at 500 k, 7.1 at 1 M -- the barrier's atomic
     // round trips, not the arithmetic; fewer, fatter workgroups are not faster)
-    static int ppt_target = 0;                       // ISO_FPS_PPT: development override (points per thread the grid is sized for)
-    if (ppt_target == 0) { const char* e = getenv("ISO_FPS_PPT"); ppt_target = e ? atoi(e) : 8; if (ppt_target < 1 || ppt_target > 16) ppt_target = 8; }
     static int lazy = -1;                           // ISO_FPS_LAZY=0: one sample per exchange (k_fps_grid)
     if (lazy < 0) { const char* e = getenv("ISO_FPS_LAZY"); lazy = e ? atoi(e) != 0 : 1; }
+    // points per thread the grid is sized for (ISO_FPS_PPT: development override).  k_fps_grid: 8 (fewer, fatter workgroups
+    // shorten the exchange); k_fps_lazy: 4 -- the exchange is shared by many samples, the per-sample cost is the update
+    static int ppt_target = 0;
+    if (ppt_target == 0) { const char* e = getenv("ISO_FPS_PPT"); ppt_target = e ? atoi(e) : (lazy ? 4 : 8); if (ppt_target < 1 || ppt_target > 16) ppt_target = lazy ? 4 : 8; }
     const bool use_lazy = lazy && p_stride <= (int64_t)kFpsLazyGrid * FPS_BLOCK * 16;
     const int64_t nb_max = use_lazy ? kFpsLazyGrid : 256;
     int64_t nb = (p_stride + FPS_BLOCK * ppt_target - 1) / (FPS_BLOCK * ppt_target);

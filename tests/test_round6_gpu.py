@@ -62,9 +62,11 @@ def test_idr_step_repeat_stress_1m(dev, H, NL, skip, P, reps, gemm_mode):
     _assert_repeats(run, reps, "IDR %dx%d projection of %d points" % (NL, H, P))
 
 
-def test_fps_repeat_stress_500k(dev):
-    """k_fps_grid<16> (points held in registers: 922 'spilled' VGPRs = its 640 B / lane of private memory) at
-    configs[4]'s size: 5 000 of 500 k, ten repeats, same indices."""
+def test_fps_repeat_stress_500k(dev, monkeypatch):
+    """k_fps_lazy (several samples per device-wide exchange: every workgroup publishes its four largest keys and all of them
+    replay the selection on the lists while its outcome is certain) at configs[4]'s size: 5 000 of 500 k, ten repeats, same
+    indices; and its three register shapes (4 / 8 / 16 points per thread: 500 k, 1.2 M, 2 M points) against the one-workgroup
+    kernel, which shares nothing with it but the arithmetic of a distance."""
     from iso_points_amd.point_processing import farthest_sampling
     pts = sphere_cloud(500000, seed=12).to(dev)
     num = torch.tensor([500000], device=dev)
@@ -73,6 +75,14 @@ def test_fps_repeat_stress_500k(dev):
         s, n, idx = farthest_sampling(pts, num, 0.01)
         return (idx,)
     _assert_repeats(run, 10, "FPS 5000 of 500 k")
+    for P, ns in ((500000, 700), (1200000, 500), (2000000, 300)):
+        big = sphere_cloud(P, seed=P).to(dev)
+        nb = torch.tensor([P], device=dev)
+        a = farthest_sampling(big, nb, ns / P)[2]
+        monkeypatch.setenv("ISO_FPS_ONE_WORKGROUP", "1")
+        b = farthest_sampling(big, nb, ns / P)[2]
+        monkeypatch.delenv("ISO_FPS_ONE_WORKGROUP")
+        assert torch.equal(a, b) and ns <= a.shape[1] <= ns + 1, P
 
 
 def test_resample_k12_repeat_stress(dev):
