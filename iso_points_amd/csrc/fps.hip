@@ -279,12 +279,7 @@ __global__ __launch_bounds__(FPS_BLOCK) void k_fps_lazy(const float* __restrict_
         if (!((excl >> k) & 1u) && mind[k] > bm) { bm = mind[k]; bk = k; }
       const unsigned long long mine = bm < 0.f ? 0ull
           : (((unsigned long long)__float_as_uint(bm) << 32) | (unsigned)(0xffffffffu - (unsigned)(first + bk * stride)));
-      unsigned long long key = mine;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long ok = __shfl_xor(key, o);
-        key = ok > key ? ok : key;
-      }
+      const unsigned long long key = wave_max_u64(mine);
       if (lane == 0) s_key[q & 1][t >> 6] = key;
       __syncthreads();
       unsigned long long best = 0;
