@@ -13,8 +13,8 @@
 //     (~2.2 us) per sample: 3.5-3.7 us per sample at 500 k points.
 //   * k_fps_lazy (the default for 8 k .. 2 M points): the same layout, but a workgroup publishes its FOUR
 //     largest keys and every workgroup replays the selection on the published lists for as long as its
-//     outcome is certain -- 35 samples per exchange on average at 500 k points: 1.0 us per sample
-//     (5 000 of 500 k: 18.3 -> 5.0 ms), the sequence identical sample for sample.
+//     outcome is certain -- 35 samples per exchange on average at 500 k points: 0.8 us per sample
+//     (5 000 of 500 k: 18.3 -> 4.5 ms), the sequence identical sample for sample.
 #include <float.h>
 #include <stdlib.h>
 #include "iso_common.h"
@@ -201,6 +201,14 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return ((unsigned long long)hi << 32) | lo;
 }
 
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define FPS_DPP_STEP32(CTRL, ROWS) { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false); v = o > v ? o : v; }
+  FPS_DPP_STEP32(0x111, 0xf) FPS_DPP_STEP32(0x112, 0xf) FPS_DPP_STEP32(0x114, 0xf) FPS_DPP_STEP32(0x118, 0xf)
+  FPS_DPP_STEP32(0x142, 0xa) FPS_DPP_STEP32(0x143, 0xc)
+#undef FPS_DPP_STEP32
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // ---- grid-wide form, several samples per exchange ------------------------------------------------
 // k_fps_grid pays one device-wide exchange (~2.2 us) per sample.  Here a workgroup publishes its T LARGEST keys instead of
 // one, and every workgroup replays the selection on the published lists until the outcome stops being certain:
@@ -330,31 +338,41 @@ __global__ __launch_bounds__(FPS_BLOCK) void k_fps_lazy(const float* __restrict_
       const int lim = left < kFpsMaxRun ? (int)left : kFpsMaxRun;
       int mm = 0;
       while (mm < lim) {
-        unsigned long long c = 0ull, blk = 0ull;
+        // per lane: its best listed key with that entry's position, and the bound of its uncertain workgroups
+        unsigned long long mine = 0ull, blk = 0ull;
+        float wx = 0.f, wy = 0.f, wz = 0.f;
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
           unsigned long long bl = ek[i][0];
+          float bx = ex[i][0], by = ey[i][0], bz = ez[i][0];
 #pragma unroll
-          for (int q = 1; q < T; ++q) bl = ek[i][q] > bl ? ek[i][q] : bl;
-          if (bl < eb[i]) blk = eb[i] > blk ? eb[i] : blk;
-          c = bl > c ? bl : c;
-        }
-        c = wave_max_u64(c);
-        blk = wave_max_u64(blk);
-        if (c == 0ull || !(c > blk)) break;
-        // the winner's position: the one lane and entry that hold key c (selects, no branches: this loop is one wave's
-        // dependent chain and the whole grid waits for it)
-        float wx = 0.f, wy = 0.f, wz = 0.f;
-        bool have = false;
-#pragma unroll
-        for (int i = 0; i < NWL; ++i)
-#pragma unroll
-          for (int q = 0; q < T; ++q) {
-            const bool hit = ek[i][q] == c;
-            wx = hit ? ex[i][q] : wx; wy = hit ? ey[i][q] : wy; wz = hit ? ez[i][q] : wz;
-            have = have || hit;
+          for (int q = 1; q < T; ++q) {
+            const bool gt = ek[i][q] > bl;
+            bl = gt ? ek[i][q] : bl; bx = gt ? ex[i][q] : bx; by = gt ? ey[i][q] : by; bz = gt ? ez[i][q] : bz;
           }
-        const int src = __builtin_ctzll((unsigned long long)__ballot(have));
+          if (bl < eb[i]) blk = eb[i] > blk ? eb[i] : blk;
+          const bool gt = bl > mine;
+          mine = gt ? bl : mine; wx = gt ? bx : wx; wy = gt ? by : wy; wz = gt ? bz : wz;
+        }
+        // the wave's maximum C.  Fast path: the largest DISTANCE word sits in one lane only (then that lane's key is C);
+        // equal distances in several lanes take the full 64-bit reduction -- same result either way
+        const unsigned cd = wave_max_u32((unsigned)(mine >> 32));
+        const unsigned long long at = (unsigned long long)__ballot((unsigned)(mine >> 32) == cd);
+        unsigned long long c;
+        int src;
+        if (__popcll(at) == 1) {
+          src = __builtin_ctzll(at);
+          c = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), src) << 32)
+              | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, src);
+        } else {
+          c = wave_max_u64(mine);
+          src = __builtin_ctzll((unsigned long long)__ballot(mine == c));
+        }
+        if (c == 0ull) break;
+        // C must exceed the bounds of the uncertain workgroups: decided on the distance words unless they are equal
+        const unsigned bd = wave_max_u32((unsigned)(blk >> 32));
+        if (bd > cd) break;
+        if (bd == cd && !(c > wave_max_u64(blk))) break;
         wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), src));
         wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), src));
         wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), src));
