@@ -209,6 +209,68 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// ---- one workgroup, points in registers (clouds below 8 k points: the reference's own sizes) --------------------
+// k_fps walks the cloud in memory every sample (3 us per sample at 5 000 points: five dependent L2 round trips per thread,
+// a serial final reduction).  Here a thread keeps its <= 8 points and their min-distances in registers, the workgroup's
+// maximum is one DPP reduction per wave + sixteen LDS words read by everybody, and the winner's position comes from its owner
+// through LDS: two barriers and no memory access per sample.
+template <int PPT>
+__global__ __launch_bounds__(FPS_BLOCK) void k_fps_reg(const float* __restrict__ pts, const int64_t* __restrict__ lengths,
+                                                       const int64_t* __restrict__ n_samples,
+                                                       const int64_t* __restrict__ start, int64_t p_stride,
+                                                       int64_t out_stride, int64_t* __restrict__ out_idx) {
+  __shared__ unsigned long long s_key[2][FPS_BLOCK / 64];
+  __shared__ float s_pos[2][3];
+  const int n = blockIdx.x;
+  const int64_t len = lengths ? lengths[n] : p_stride;
+  const int64_t ns = n_samples[n] < len ? n_samples[n] : len;
+  if (len <= 0 || ns <= 0) return;
+  const float* p = pts + (int64_t)n * p_stride * 3;
+  int64_t* out = out_idx + (int64_t)n * out_stride;
+  const int t = threadIdx.x, lane = t & 63;
+  float px[PPT], py[PPT], pz[PPT], mind[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int64_t i = t + (int64_t)k * FPS_BLOCK;
+    px[k] = py[k] = pz[k] = 0.f;
+    mind[k] = -1.0f;
+    if (i < len) { px[k] = p[i * 3]; py[k] = p[i * 3 + 1]; pz[k] = p[i * 3 + 2]; mind[k] = FLT_MAX; }
+  }
+  const int cur0 = (int)(start[n] < len ? (start[n] < 0 ? 0 : start[n]) : len - 1);
+  float cx = p[(int64_t)cur0 * 3], cy = p[(int64_t)cur0 * 3 + 1], cz = p[(int64_t)cur0 * 3 + 2];
+  if (t == 0) out[0] = cur0;
+  for (int64_t s = 1; s < ns; ++s) {
+    float bm = -1.0f;
+    int bk = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      const float m = fminf(mind[k], d);
+      mind[k] = m;
+      if (m > bm) { bm = m; bk = k; }                     // ascending index per thread: first strict maximum
+    }
+    const unsigned long long mine = bm < 0.f ? 0ull
+        : (((unsigned long long)__float_as_uint(bm) << 32) | (unsigned)(0xffffffffu - (unsigned)(t + bk * FPS_BLOCK)));
+    const unsigned long long wk = wave_max_u64(mine);
+    const int b = (int)(s & 1);
+    if (lane == 0) s_key[b][t >> 6] = wk;
+    __syncthreads();
+    unsigned long long best = 0;
+#pragma unroll
+    for (int w = 0; w < FPS_BLOCK / 64; ++w) { const unsigned long long v = s_key[b][w]; best = v > best ? v : best; }
+    if (mine == best && best != 0ull) {                   // the owner (keys are unique): the winner's position
+      float wx = px[0], wy = py[0], wz = pz[0];
+#pragma unroll
+      for (int k = 1; k < PPT; ++k) { const bool h = bk == k; wx = h ? px[k] : wx; wy = h ? py[k] : wy; wz = h ? pz[k] : wz; }
+      s_pos[b][0] = wx; s_pos[b][1] = wy; s_pos[b][2] = wz;
+      out[s] = (int64_t)(0xffffffffu - (unsigned)(best & 0xffffffffull));
+    }
+    __syncthreads();
+    cx = s_pos[b][0]; cy = s_pos[b][1]; cz = s_pos[b][2];
+  }
+}
+
 // ---- grid-wide form, several samples per exchange ------------------------------------------------
 // k_fps_grid pays one device-wide exchange (~2.2 us) per sample.  Here a workgroup publishes its T LARGEST keys instead of
 // one, and every workgroup replays the selection on the published lists until the outcome stops being certain:
@@ -484,6 +546,16 @@ extern "C" int iso_farthest_point_sampling(const float* points, const int64_t* l
     }
     if (!refused) { ISO_CHECK_LAUNCH("iso_farthest_point_sampling"); return ISO_OK; }
     // the device cannot co-schedule the grid (first cloud refused): the one-workgroup form below
+  }
+  if (p_stride <= (int64_t)FPS_BLOCK * 8 && !getenv("ISO_FPS_ONE_WORKGROUP")) {
+    // the cloud fits one workgroup's registers (ISO_FPS_ONE_WORKGROUP keeps the memory-walking kernel for the tests)
+    const int64_t ppt = (p_stride + FPS_BLOCK - 1) / FPS_BLOCK;
+    if (ppt <= 1) hipLaunchKernelGGL(k_fps_reg<1>, dim3(n_clouds), dim3(FPS_BLOCK), 0, st, points, lengths, n_samples, start, p_stride, out_stride, out_idx);
+    else if (ppt <= 2) hipLaunchKernelGGL(k_fps_reg<2>, dim3(n_clouds), dim3(FPS_BLOCK), 0, st, points, lengths, n_samples, start, p_stride, out_stride, out_idx);
+    else if (ppt <= 4) hipLaunchKernelGGL(k_fps_reg<4>, dim3(n_clouds), dim3(FPS_BLOCK), 0, st, points, lengths, n_samples, start, p_stride, out_stride, out_idx);
+    else hipLaunchKernelGGL(k_fps_reg<8>, dim3(n_clouds), dim3(FPS_BLOCK), 0, st, points, lengths, n_samples, start, p_stride, out_stride, out_idx);
+    ISO_CHECK_LAUNCH("iso_farthest_point_sampling");
+    return ISO_OK;
   }
   hipLaunchKernelGGL(k_fps, dim3(n_clouds), dim3(FPS_BLOCK), 0, st, points, lengths,
                      n_samples, start, p_stride, out_stride, work, out_idx);

@@ -78,6 +78,26 @@ def test_fps(dev):
     assert d < 0.12
 
 
+def test_fps_small_clouds_in_registers(dev, monkeypatch):
+    """clouds below 8 k points take k_fps_reg (points and min-distances in registers, no memory access per sample): the
+    memory-walking kernel's sequence on a ragged batch, a lattice (massive distance ties), duplicates sampled past
+    exhaustion, and a non-zero start."""
+    from iso_points_amd.point_processing import farthest_sampling
+    from iso_points_amd.levelset_sampling import with_host_lengths
+    lat = torch.stack(torch.meshgrid(*([torch.arange(14.0)] * 3), indexing="ij"), -1).view(1, -1, 3) * 0.1
+    dup = sphere_cloud(3000, seed=5); dup[0, 1500:] = dup[0, :1500]
+    rag = torch.cat([sphere_cloud(8000, seed=6), sphere_cloud(8000, seed=7)], dim=0)
+    for pts, lens, ratio in ((lat, [2744], 1.0), (dup, [3000], 0.9), (rag, [8000, 4321], 0.5), (sphere_cloud(700, seed=8), [700], 0.3)):
+        num = with_host_lengths(torch.tensor(lens, device=dev), lens)
+        g = torch.Generator().manual_seed(11)
+        a = farthest_sampling(pts.to(dev), num, ratio, random_start=True, generator=g)
+        monkeypatch.setenv("ISO_FPS_ONE_WORKGROUP", "1")
+        g = torch.Generator().manual_seed(11)
+        b = farthest_sampling(pts.to(dev), num, ratio, random_start=True, generator=g)
+        monkeypatch.delenv("ISO_FPS_ONE_WORKGROUP")
+        assert torch.equal(a[2], b[2]) and torch.equal(a[0], b[0]), lens
+
+
 def test_fps_grid_wide_form(dev, monkeypatch):
     """clouds of >= 8 k points take the cooperative grid-wide kernel: same sample sequence as the
     oracle and as the one-workgroup kernel, ragged batch, duplicated points (ties -> lowest index)."""

@@ -19,9 +19,14 @@ sph = lambda n: torch.nn.functional.normalize(torch.randn(1, n, 3, generator=g),
 lat = torch.stack(torch.meshgrid(*([torch.arange(42.0)] * 3), indexing="ij"), -1).view(1, -1, 3) * 0.05
 clumps = torch.cat([torch.randn(1, 30000, 3, generator=g) * 0.05, torch.randn(1, 30000, 3, generator=g) * 0.05 + 4.0], 1)
 dup = sph(40000); dup[0, 20000:] = dup[0, :20000]
+lat14 = torch.stack(torch.meshgrid(*([torch.arange(14.0)] * 3), indexing="ij"), -1).view(1, -1, 3) * 0.1
+dup3 = sph(3000); dup3[0, 1500:] = dup3[0, :1500]
 cases = {"sphere 70 k / 2000": (sph(70000), 2000), "sphere 500 k / 5000": (sph(500000), 5000), "lattice 42^3 / 3000 (ties)": (lat, 3000),
          "volume 200 k / 4000": (torch.rand(1, 200000, 3, generator=g), 4000), "two clumps 60 k / 1500": (clumps, 1500),
-         "duplicates 40 k / 25000": (dup, 25000), "sphere 1.2 M / 3000": (sph(1200000), 3000), "all of 9 k": (sph(9000), 9000)}
+         "duplicates 40 k / 25000": (dup, 25000), "sphere 1.2 M / 3000": (sph(1200000), 3000), "all of 9 k": (sph(9000), 9000),
+         # below 8 k points: the one-workgroup kernels (register-resident k_fps_reg; ISO_FPS_ONE_WORKGROUP=1: k_fps)
+         "sphere 5 k / 2500": (sph(5000), 2500), "lattice 14^3 / all (ties)": (lat14, 2744), "sphere 777 / 500": (sph(777), 500),
+         "duplicates 3 k / 2500": (dup3, 2500), "sphere 8191 / 4000": (sph(8191), 4000)}
 out = {}
 for k, (p, ns) in cases.items():
     P = p.shape[1]
