@@ -1,10 +1,13 @@
 // Farthest-point sampling (exact, sequential by nature).  Stands in for torch_cluster.fps as the
 // reference's wlop calls it (DSS/utils/point_processing.py:473-499, :51).  Every iteration updates
 // the running min-distance of all points to the sample set and takes the arg-max (ties -> lowest
-// index).  Two kernels, same arithmetic, same result:
-//   * k_fps: one 1024-lane workgroup per cloud, min-distances in a caller workspace (L2 resident
-//     for the reference's cloud sizes, 5k-50k points); an iteration costs ~16 B x len through ONE
-//     CU, so it is the small-cloud form.
+// index).  Four kernels, same arithmetic, same result:
+//   * k_fps: one 1024-lane workgroup per cloud, min-distances in a caller workspace; an iteration costs
+//     ~16 B x len through ONE CU (3 us per sample at 5 000 points).  Kept as the plain statement of the
+//     algorithm the others are tested against (ISO_FPS_ONE_WORKGROUP=1) and for clouds beyond 4 M points.
+//   * k_fps_reg (clouds below 8 k points, the reference's own sizes): one workgroup, points and
+//     min-distances in registers, two barriers and no memory access per sample: 1.3 us per sample at
+//     5 000 points.
 //   * k_fps_grid (clouds of >= 8 k points): a cooperative launch of up to 256 workgroups; every
 //     thread keeps its <= 16 points AND their min-distances in registers (nothing is read from
 //     memory inside the loop except the winner's coordinates); the workgroup maxima -- 64-bit keys
