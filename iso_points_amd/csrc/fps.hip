@@ -5,16 +5,16 @@
 //   * k_fps: one 1024-lane workgroup per cloud, min-distances in a caller workspace; an iteration costs
 //     ~16 B x len through ONE CU (3 us per sample at 5 000 points).  Kept as the plain statement of the
 //     algorithm the others are tested against (ISO_FPS_ONE_WORKGROUP=1) and for clouds beyond 4 M points.
-//   * k_fps_reg (clouds below 8 k points, the reference's own sizes): one workgroup, points and
+//   * k_fps_reg (clouds below 4 k points): one workgroup, points and
 //     min-distances in registers, two barriers and no memory access per sample: 1.3 us per sample at
 //     5 000 points.
-//   * k_fps_grid (clouds of >= 8 k points): a cooperative launch of up to 256 workgroups; every
+//   * k_fps_grid (clouds of >= 4 k points): a cooperative launch of up to 256 workgroups; every
 //     thread keeps its <= 16 points AND their min-distances in registers (nothing is read from
 //     memory inside the loop except the winner's coordinates); the workgroup maxima -- 64-bit keys
 //     (distance bits, ~index) -- meet through one store per workgroup and one polling load per lane of
 //     wave 0 (no atomics, no counter barrier: see the comment at the kernel).  One device-wide exchange
 //     (~2.2 us) per sample: 3.5-3.7 us per sample at 500 k points.
-//   * k_fps_lazy (the default for 8 k .. 2 M points): the same layout, but a workgroup publishes its FOUR
+//   * k_fps_lazy (the default for 4 k .. 2 M points): the same layout, but a workgroup publishes its FOUR
 //     largest keys and every workgroup replays the selection on the published lists for as long as its
 //     outcome is certain -- 35 samples per exchange on average at 500 k points: 0.8 us per sample
 //     (5 000 of 500 k: 18.3 -> 4.5 ms), the sequence identical sample for sample.
@@ -482,7 +482,7 @@ hipError_t launch_fps_grid(int nb, const float* p, const int64_t* lengths, const
                                     0, s);
 }
 
-constexpr int64_t kFpsGridMin = 8192;     // below: one workgroup is faster than grid-wide barriers
+constexpr int64_t kFpsGridMin = 4096;     // below: one workgroup (k_fps_reg) is faster (2 500 points: 1.1 against 1.4 us per sample; 5 000: 1.3 against 1.2)
 constexpr int kFpsCtlFloats = (sizeof(FpsCtlLazy) > sizeof(FpsCtl) ? sizeof(FpsCtlLazy) : sizeof(FpsCtl)) / 4;   // control block at the end of the workspace
 
 }  // namespace
@@ -503,16 +503,19 @@ extern "C" int iso_farthest_point_sampling(const float* points, const int64_t* l
               "iso_farthest_point_sampling: null pointer");
   ISO_REQUIRE(p_stride < (1ll << 31), ISO_ERR_UNSUPPORTED, "iso_farthest_point_sampling: cloud too large");
   hipStream_t st = (hipStream_t)stream;
-  if (p_stride >= kFpsGridMin && p_stride <= (int64_t)256 * FPS_BLOCK * 16 && !getenv("ISO_FPS_ONE_WORKGROUP")) {
+  static int64_t grid_min = 0;                       // ISO_FPS_GRID_MIN: development override of the size the grid-wide forms start at
+  if (grid_min == 0) { const char* e = getenv("ISO_FPS_GRID_MIN"); grid_min = e ? atoll(e) : kFpsGridMin; if (grid_min < 2048) grid_min = 2048; }
+  if (p_stride >= grid_min && p_stride <= (int64_t)256 * FPS_BLOCK * 16 && !getenv("ISO_FPS_ONE_WORKGROUP")) {
     // grid-wide form, cloud after cloud; the smallest grid that keeps <= 8 points per thread
     // (measured: 2.8 us per sample up to 50 k points, 5.0 at 500 k, 7.1 at 1 M -- the barrier's atomic
     // round trips, not the arithmetic; fewer, fatter workgroups are not faster)
     static int lazy = -1;                           // ISO_FPS_LAZY=0: one sample per exchange (k_fps_grid)
     if (lazy < 0) { const char* e = getenv("ISO_FPS_LAZY"); lazy = e ? atoi(e) != 0 : 1; }
     // points per thread the grid is sized for (ISO_FPS_PPT: development override).  k_fps_grid: 8 (fewer, fatter workgroups
-    // shorten the exchange); k_fps_lazy: 4 -- the exchange is shared by many samples, the per-sample cost is the update
+    // shorten the exchange); k_fps_lazy: 1, i.e. as many workgroups as the cloud fills, up to 128 -- the exchange is shared by
+    // many samples, more lists make longer runs (24 k points: 13.9 ms at 4 points per thread, 10.1 at 1)
     static int ppt_target = 0;
-    if (ppt_target == 0) { const char* e = getenv("ISO_FPS_PPT"); ppt_target = e ? atoi(e) : (lazy ? 4 : 8); if (ppt_target < 1 || ppt_target > 16) ppt_target = lazy ? 4 : 8; }
+    if (ppt_target == 0) { const char* e = getenv("ISO_FPS_PPT"); ppt_target = e ? atoi(e) : (lazy ? 1 : 8); if (ppt_target < 1 || ppt_target > 16) ppt_target = lazy ? 1 : 8; }
     const bool use_lazy = lazy && p_stride <= (int64_t)kFpsLazyGrid * FPS_BLOCK * 16;
     const int64_t nb_max = use_lazy ? kFpsLazyGrid : 256;
     int64_t nb = (p_stride + FPS_BLOCK * ppt_target - 1) / (FPS_BLOCK * ppt_target);

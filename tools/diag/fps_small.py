@@ -6,7 +6,7 @@ from tools_common import timeit
 from iso_points_amd.point_processing import farthest_sampling
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(1)
-for P in (5000, 8192, 12000, 24000, 50000, 100000, 200000):
+for P in (2500, 5000, 8192, 12000, 24000, 50000, 100000, 200000):
     p = torch.nn.functional.normalize(torch.randn(1, P, 3, generator=g), dim=-1).to(dev)
     num = torch.tensor([P], device=dev)
     ns = P // 2 if P <= 50000 else 5000
