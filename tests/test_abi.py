@@ -81,7 +81,7 @@ def test_selection_list_files_are_built_without_the_slp_vectoriser():
     deterministic miscompile by the SLP vectoriser of this toolchain: a swap taken by the TIE rule of the (z, id, q)
     insertion gets the values of the no-swap path when the list is carried around a loop.  tools/probes/tie_merge.hip
     reproduces it in 150 lines; -fno-slp-vectorize cures it there and in the failing raster builds.  So the guard is the
-    build flag on every file that holds a selection list -- all but the four MFMA files -- plus tests/test_ties_gpu.py."""
+    build flag on every file that holds a selection list -- every file but siren_x3.hip -- plus tests/test_ties_gpu.py."""
     import subprocess
     out = subprocess.run(["make", "-n", "-B", "-C", ROOT, "iso_points_amd/libisopoints_hip.so"], stdout=subprocess.PIPE, text=True).stdout
     lines = [l for l in out.splitlines() if " -c " in l and ".hip" in l]
